@@ -1,0 +1,249 @@
+/* svo.h - C-ABI of the MI355X-native stereo-VO tracking front end.
+ *
+ * This is the drop-in boundary.  The reference
+ * (zssjh/stereo-semantic-vo) exposes no plugin/FFI seam around its hot path: the
+ * seams are C++ member functions that write into public members of `frame`.
+ * Every entry point below names the reference method it replaces (file:line under
+ * the reference tree).  The one true C-ABI the reference owns - the YOLO dlopen
+ * interface, include/YOLOv3SE.h:61-64,221-230 - is the model for the conventions:
+ * opaque handle, caller-owned buffers, plain pointers and sizes, int return.
+ *
+ * Conventions
+ *   - `svo_ctx` is one tracker context bound to ONE GPU (one HIP stream inside).
+ *     Not thread-safe per context; use one context per host thread / per GPU.
+ *   - All buffers are caller-owned.  Entry points ending in `_dev` take DEVICE
+ *     pointers (HBM-resident, e.g. torch tensors' data_ptr()) and enqueue on the
+ *     context stream without synchronising; all others take HOST pointers and
+ *     return after the result is in the caller's memory.
+ *   - Return 0 (SVO_OK) or a negative svo_status.  Nothing here falls back to a
+ *     CPU path: if no HIP device is usable, svo_create fails with SVO_E_NODEVICE.
+ *   - Images are 8-bit gray, row-major, `stride` bytes per row.
+ *   - Keypoints use the 28-byte layout of cv::KeyPoint (pt.x, pt.y, size, angle,
+ *     response, octave, class_id) so `frame::keypoints_l` can alias the buffer.
+ *   - Descriptors are n x 32 bytes row-major, like `frame::f_descriptor`
+ *     (CV_8U 500x32, reference src/frame.cc:78).
+ */
+#ifndef SVO_H
+#define SVO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVO_ABI_VERSION 1
+
+typedef enum svo_status {
+  SVO_OK = 0,
+  SVO_E_INVALID = -1,   /* bad argument (null pointer, size out of range) */
+  SVO_E_NODEVICE = -2,  /* no usable HIP device / kernels not loadable  */
+  SVO_E_NOMEM = -3,     /* device or host allocation failed              */
+  SVO_E_HIP = -4,       /* a HIP runtime call failed; see svo_last_error */
+  SVO_E_CAPACITY = -5   /* batch / keypoint capacity of the ctx exceeded */
+} svo_status;
+
+typedef struct svo_ctx svo_ctx;
+
+/* cv::KeyPoint-compatible record (reference: vector<cv::KeyPoint> keypoints_l,
+ * include/frame.h:48). */
+typedef struct svo_kp {
+  float x, y;      /* pt, level-0 pixel coordinates                      */
+  float size;      /* 31 * 1.2^octave                                     */
+  float angle;     /* degrees [0,360), intensity-centroid orientation     */
+  float response;  /* Harris response                                     */
+  int32_t octave;  /* pyramid level 0..7                                  */
+  int32_t class_id;/* -1                                                  */
+} svo_kp;
+
+/* Camera intrinsics the reference reads from the yaml (src/Tracking.cc:24-38). */
+typedef struct svo_camera {
+  float fx, fy, cx, cy, bf;
+} svo_camera;
+
+/* Statistics of one pose-only LM run (mirrors what g2o's verbose mode prints,
+ * Thirdparty/g2o/g2o/core/sparse_optimizer.cpp:395-409). */
+typedef struct svo_lm_stats {
+  int32_t n_edges;        /* edges used (return value of PoseOptimization)  */
+  int32_t iterations;     /* outer iterations executed (<= 10)              */
+  int32_t trials_total;   /* inner lambda trials over all iterations        */
+  int32_t terminated;     /* 1 if an LM stop rule fired before 10 iters     */
+  double chi2_initial;    /* robust chi2 before the first iteration         */
+  double chi2_final;      /* robust chi2 at the accepted estimate           */
+  double lambda_final;
+} svo_lm_stats;
+
+/* Result of the PnP-RANSAC initial pose (replaces cv::solvePnPRansac call,
+ * src/pnpmatch.cc:227). */
+typedef struct svo_pnp_stats {
+  int32_t n_points;
+  int32_t n_inliers;
+  int32_t best_hypothesis; /* index 0..99 of the winning minimal sample, -1 if none */
+  int32_t ok;              /* 0 => fewer than 5 points / no consensus: pose = prior  */
+} svo_pnp_stats;
+
+/* Per-frame record produced by the tracker (what Tracking::Track leaves behind:
+ * pose + counters, src/Tracking.cc:180-252). */
+typedef struct svo_track_result {
+  float Tcw[16];           /* row-major 4x4, CV_32F like frame::Tcw        */
+  int32_t frame_id;
+  int32_t n_kp;            /* keypoints extracted on the left image         */
+  int32_t n_stereo;        /* keypoints with depth > 0                      */
+  int32_t n_match_pass1;   /* last-frame map points matched (best < 15)     */
+  int32_t n_match_pass2;   /* local-map points matched (best<30, ratio>2)   */
+  int32_t n_pnp_inliers;
+  int32_t n_lm_edges;
+  int32_t n_new_mappoints;
+  int32_t n_local_map;     /* local-map size after culling                  */
+  int32_t lm_iterations;
+  int32_t reserved[2];
+} svo_track_result;
+
+/* ---- lifecycle ----------------------------------------------------------- */
+
+int svo_abi_version(void);
+const char* svo_strerror(int status);
+/* Text of the last HIP/runtime failure on this ctx ("" if none). */
+const char* svo_last_error(const svo_ctx* ctx);
+
+/* One context per GPU.  W,H: image size; max_kp: keypoint budget per image (the
+ * reference hard-codes N = 500, src/frame.cc:54); max_batch: the largest number of
+ * stereo pairs one batched call may carry (>= 1). */
+int svo_create(svo_ctx** out, int device, int W, int H, int max_kp, int max_batch);
+void svo_destroy(svo_ctx* ctx);
+/* Block until everything enqueued on the ctx stream has finished. */
+int svo_sync(svo_ctx* ctx);
+/* The ctx's hipStream_t as an opaque pointer (for event timing by the caller). */
+void* svo_stream(svo_ctx* ctx);
+
+/* ---- geometry the ctx derived from (W,H) ---------------------------------- */
+
+/* Pyramid level sizes / scale factors / per-level keypoint quotas, 8 levels.
+ * (cv::ORB defaults, src/frame.cc:77: nfeatures 500, scaleFactor 1.2, nlevels 8.) */
+int svo_orb_geometry(const svo_ctx* ctx, int32_t w[8], int32_t h[8], float scale[8],
+                     int32_t quota[8]);
+
+/* ---- a-2: frame::featuredetect (src/frame.cc:75-79) ------------------------ */
+
+/* ORB keypoints + descriptors of ONE image.  kp: capacity max_kp; desc: max_kp*32
+ * bytes; *n receives the count.  Order: octave ascending, then Harris response
+ * descending (ties: raster order). */
+int svo_orb_extract(svo_ctx* ctx, const uint8_t* gray, int stride, svo_kp* kp,
+                    uint8_t* desc, int32_t* n);
+
+/* Stage probes used by the parity tests (same kernels as svo_orb_extract):
+ * copy out pyramid level `level` of the last extracted image (tight rows). */
+int svo_debug_pyramid_level(svo_ctx* ctx, int image_slot, int level, uint8_t* out);
+/* FAST corners (after 3x3 NMS and the 31-px border filter) of `level` of the last
+ * extracted image: xy_score receives n x 3 int32 {x, y, score}, UNORDERED. */
+int svo_debug_fast_corners(svo_ctx* ctx, int image_slot, int level, int32_t* xy_score,
+                           int capacity, int32_t* n);
+
+/* ---- a-3/a-4: stereo association + depth ----------------------------------- */
+/* Replaces frame::MB + frame::computekeypoint_r + frame::disp2Depth
+ * (src/Tracking.cc:226-228, src/frame.cc:82-91,122-164) with the sparse epipolar
+ * matcher the north star asks for.  Extracts ORB on both images, then for each
+ * LEFT keypoint: row-band candidates on the right, Hamming argmin, 11x11 SAD
+ * refinement +-5 px at the keypoint's pyramid level, parabola sub-pixel,
+ * median-based outlier cut.  uR[i] / depth[i] = -1 where no match
+ * (depth = bf / disparity, like disp2Depth). */
+int svo_stereo_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL, const uint8_t* grayR,
+                     int strideR, const svo_camera* cam, svo_kp* kpL, uint8_t* descL,
+                     int32_t* nL, float* uR, float* depth);
+/* Also return the right image's keypoints (parity tests). kpR/descR may be NULL. */
+int svo_stereo_frame_ex(svo_ctx* ctx, const uint8_t* grayL, int strideL, const uint8_t* grayR,
+                        int strideR, const svo_camera* cam, svo_kp* kpL, uint8_t* descL,
+                        int32_t* nL, float* uR, float* depth, svo_kp* kpR, uint8_t* descR,
+                        int32_t* nR);
+
+/* frame::disp2Depth (src/frame.cc:140-164): depth = bf/disp where disp != 0, else
+ * -1, over a dense H x W float map. */
+int svo_disp2depth(svo_ctx* ctx, const float* disp, int count, float bf, float* depth);
+/* frame::UnprojectStereo (src/frame.cc:166-180) for n (u,v,z) triples with pose
+ * Rwc (row-major 3x3) / twc: out n x 3 floats; rows with z <= 0 are left NaN. */
+int svo_unproject(svo_ctx* ctx, const float* uvz, int n, const svo_camera* cam,
+                  const float Rwc[9], const float twc[3], float* xyz);
+
+/* ---- a-7/a-8/a-9: Hamming matching (src/pnpmatch.cc:14-30,61-199) ----------- */
+
+/* pnpmatch::DescriptorDistance for `count` pairs: a,b are count x 32 bytes. */
+int svo_descriptor_distance(svo_ctx* ctx, const uint8_t* a, const uint8_t* b, int count,
+                            int32_t* dist);
+
+/* Independent-row argmin: for each query row i (M x 32) scan train rows j (N x 32)
+ * in index order skipping t_mask[j] != 0, with the reference's update rule
+ * `if (d < best) { second = best; best = d; idx = j; }` (src/pnpmatch.cc:89-94):
+ * best/second start at 256, idx at -1, ties go to the lowest j, and `second` is
+ * the running best just before the last improvement - NOT the true runner-up. */
+int svo_hamming_argmin(svo_ctx* ctx, const uint8_t* q, int M, const uint8_t* t, int N,
+                       const uint8_t* t_mask, int32_t* best_idx, int32_t* best,
+                       int32_t* second);
+
+/* The reference's greedy, order-dependent assignment (src/pnpmatch.cc:61-156 pass 1
+ * with max_dist = 15, ratio = 0; :159-199 pass 2 with max_dist = 30, ratio = 2):
+ * rows are visited in index order; row i is skipped if q_skip[i] != 0; an accepted
+ * row claims train column best_idx (assigned[] is updated in place), so later rows
+ * cannot take it.  Accept rule: best < max_dist && (ratio <= 0 ||
+ * (float)second/(float)best > ratio).  Outputs per row: best_idx (or -1), best,
+ * second, accepted (0/1).  `assigned` is N bytes in/out. */
+int svo_match_greedy(svo_ctx* ctx, const uint8_t* q, const uint8_t* q_skip, int M,
+                     const uint8_t* t, int N, uint8_t* assigned, int max_dist, float ratio,
+                     int32_t* best_idx, int32_t* best, int32_t* second, uint8_t* accepted);
+
+/* a-6: cv BruteForce-Hamming match() as used by find_feature_matches
+ * (src/pnpmatch.cc:253-300): nearest train row per query row (ties: lowest j),
+ * then keep[i] = dist[i] <= max(2*min_dist, 30). */
+int svo_bf_match(svo_ctx* ctx, const uint8_t* q, int M, const uint8_t* t, int N,
+                 int32_t* train_idx, int32_t* dist, uint8_t* keep);
+
+/* ---- a-10: PnP-RANSAC initial pose (src/pnpmatch.cc:212-247) ---------------- */
+/* Xw n x 3, obs n x 2 (doubles); K = {fx,fy,cx,cy}; T_prior_cw / T_cw row-major 4x4.
+ * 100 five-point hypotheses (seeded sampler), 8 px threshold, refit on inliers.
+ * inlier_mask: n bytes (may be NULL). */
+int svo_pnp_ransac(svo_ctx* ctx, const double* Xw, const double* obs, int n, const double K[4],
+                   const double T_prior_cw[16], uint64_t seed, double T_cw[16],
+                   uint8_t* inlier_mask, svo_pnp_stats* stats);
+
+/* ---- a-5: Optimizer::PoseOptimization (src/Optimizer.cc:15-86) -------------- */
+/* Pose-only Levenberg-Marquardt exactly as g2o runs it for this graph: one SE3
+ * vertex, n unary EdgeSE3ProjectXYZOnlyPose edges, information I2, Huber
+ * delta = (double)(float)sqrt(5.991), optimize(10).  float64 throughout.
+ * T_cw is in/out (row-major 4x4). */
+int svo_pose_opt(svo_ctx* ctx, const double* Xw, const double* obs, int n, const double K[4],
+                 double T_cw[16], svo_lm_stats* stats);
+
+/* ---- Tracking::Track (src/Tracking.cc:180-252), device-resident ------------- */
+/* Reset the tracker state held in HBM (lastframe, LocalMapPoints, frame_num). */
+int svo_track_reset(svo_ctx* ctx, const svo_camera* cam);
+/* Track one stereo pair given as HOST gray images; fills *res. Boxes: n_boxes x 4
+ * int32 {left,right,top,bottom} (offline detections, main.cpp:82-95), may be NULL. */
+int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL, const uint8_t* grayR,
+                    int strideR, double timestamp, const int32_t* boxes, int n_boxes,
+                    svo_track_result* res);
+
+/* ---- throughput mode: batched, device-resident ------------------------------ */
+/* B stereo pairs already in HBM: d_grayL/d_grayR are B images of H rows x `stride`
+ * bytes.  Runs extraction on all 2B images and the sparse stereo association for
+ * the B pairs in a handful of launches on the ctx stream; does NOT synchronise.
+ * Outputs (device pointers, capacity B*max_kp each): d_kpL, d_descL (x32), d_nL (B),
+ * d_uR, d_depth.  Any output pointer may be NULL to keep results inside the ctx. */
+int svo_frontend_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR,
+                           int stride, int B, const svo_camera* cam, svo_kp* d_kpL,
+                           uint8_t* d_descL, int32_t* d_nL, float* d_uR, float* d_depth);
+/* Batched front end followed by the ordered tracking tail for the same B pairs
+ * (frames are consecutive frames of ONE sequence, in order).  d_results: B
+ * svo_track_result records in HBM.  Does not synchronise. */
+int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR,
+                        int stride, int B, svo_track_result* d_results);
+
+/* Names + accumulated HIP-event time (ms) and launch count of the kernels the ctx
+ * has timed since svo_profile_reset (only when svo_profile_enable(ctx,1)). */
+int svo_profile_enable(svo_ctx* ctx, int on);
+int svo_profile_reset(svo_ctx* ctx);
+int svo_profile_get(svo_ctx* ctx, int index, char* name, int name_cap, double* total_ms,
+                    int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVO_H */

@@ -1,0 +1,204 @@
+"""ctypes binding of the CPU oracle (oracle/libsvo_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg - never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+
+class LmStats(C.Structure):
+    _fields_ = [("n_edges", C.c_int32), ("iterations", C.c_int32), ("trials_total", C.c_int32),
+                ("terminated", C.c_int32), ("chi2_initial", C.c_double), ("chi2_final", C.c_double),
+                ("lambda_final", C.c_double)]
+
+
+class PnpStats(C.Structure):
+    _fields_ = [("n_points", C.c_int32), ("n_inliers", C.c_int32), ("best_hypothesis", C.c_int32),
+                ("ok", C.c_int32)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libsvo_oracle.so")
+    if force or not os.path.exists(so):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_pyramid_size.restype = C.c_int64
+        _LIB.orc_level_offset.restype = C.c_int64
+        _LIB.orc_harris_at.restype = C.c_int64
+        _LIB.orc_harris_to_float.restype = C.c_float
+        _LIB.orc_harris_to_float.argtypes = [C.c_int64]
+        _LIB.orc_fast_atan2.restype = C.c_float
+        _LIB.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        _LIB.orc_ic_angle.restype = C.c_float
+        _LIB.orc_sincos.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def geometry(W, H, nfeatures=500):
+    w = np.zeros(8, np.int32); h = np.zeros(8, np.int32)
+    s = np.zeros(8, np.float32); q = np.zeros(8, np.int32)
+    lib().orc_geometry(W, H, nfeatures, _p(w), _p(h), _p(s), _p(q))
+    return w, h, s, q
+
+
+def umax():
+    u = np.zeros(16, np.int32)
+    lib().orc_umax(_p(u))
+    return u
+
+
+def build_pyramid(gray):
+    gray = np.ascontiguousarray(gray, np.uint8)
+    H, W = gray.shape
+    pyr = np.zeros(lib().orc_pyramid_size(W, H), np.uint8)
+    lib().orc_build_pyramid(_p(gray), W, H, W, _p(pyr))
+    return pyr
+
+
+def pyramid_levels(pyr, W, H):
+    w, h, _, _ = geometry(W, H)
+    out, off = [], 0
+    for l in range(8):
+        out.append(pyr[off:off + w[l] * h[l]].reshape(h[l], w[l]))
+        off += int(w[l]) * int(h[l])
+    return out
+
+
+def fast_corners(img, border=31):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cap = (w // 2 + 1) * (h // 2 + 1)
+    out = np.zeros((cap, 3), np.int32)
+    n = lib().orc_fast_corners(_p(img), w, h, w, 20, border, _p(out), cap)
+    return out[:n].copy()
+
+
+def orb_extract(gray, nfeatures=500, want_pyramid=False):
+    gray = np.ascontiguousarray(gray, np.uint8)
+    H, W = gray.shape
+    kp = np.zeros(nfeatures, KP_DTYPE)
+    desc = np.zeros((nfeatures, 32), np.uint8)
+    pyr = np.zeros(lib().orc_pyramid_size(W, H), np.uint8) if want_pyramid else None
+    n = lib().orc_orb_extract(_p(gray), W, H, W, nfeatures, _p(kp), _p(desc), _p(pyr))
+    if want_pyramid:
+        return kp[:n].copy(), desc[:n].copy(), pyr
+    return kp[:n].copy(), desc[:n].copy()
+
+
+def stereo_frame(grayL, grayR, bf, fx, nfeatures=500):
+    grayL = np.ascontiguousarray(grayL, np.uint8); grayR = np.ascontiguousarray(grayR, np.uint8)
+    H, W = grayL.shape
+    kpL = np.zeros(nfeatures, KP_DTYPE); dL = np.zeros((nfeatures, 32), np.uint8)
+    kpR = np.zeros(nfeatures, KP_DTYPE); dR = np.zeros((nfeatures, 32), np.uint8)
+    uR = np.zeros(nfeatures, np.float32); depth = np.zeros(nfeatures, np.float32)
+    nL = C.c_int32(0); nR = C.c_int32(0)
+    lib().orc_stereo_frame(_p(grayL), W, _p(grayR), W, W, H, nfeatures, C.c_float(bf), C.c_float(fx),
+                           _p(kpL), _p(dL), C.byref(nL), _p(uR), _p(depth), _p(kpR), _p(dR),
+                           C.byref(nR))
+    nl, nr = nL.value, nR.value
+    return dict(kpL=kpL[:nl].copy(), dL=dL[:nl].copy(), uR=uR[:nl].copy(), depth=depth[:nl].copy(),
+                kpR=kpR[:nr].copy(), dR=dR[:nr].copy())
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32); b = np.ascontiguousarray(b, np.uint8).reshape(-1, 32)
+    return np.array([lib().orc_descriptor_distance(_p(a[i]), _p(b[i])) for i in range(len(a))], np.int32)
+
+
+def hamming_argmin(q, t, t_mask=None):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    M, N = len(q), len(t)
+    bi = np.zeros(M, np.int32); b = np.zeros(M, np.int32); s = np.zeros(M, np.int32)
+    m = None if t_mask is None else np.ascontiguousarray(t_mask, np.uint8)
+    lib().orc_hamming_argmin(_p(q), M, _p(t), N, _p(m), _p(bi), _p(b), _p(s))
+    return bi, b, s
+
+
+def match_greedy(q, t, assigned, max_dist, ratio, q_skip=None):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    M, N = len(q), len(t)
+    assigned = np.ascontiguousarray(assigned, np.uint8).copy()
+    sk = None if q_skip is None else np.ascontiguousarray(q_skip, np.uint8)
+    bi = np.zeros(M, np.int32); b = np.zeros(M, np.int32); s = np.zeros(M, np.int32)
+    acc = np.zeros(M, np.uint8)
+    lib().orc_match_greedy(_p(q), _p(sk), M, _p(t), N, _p(assigned), max_dist, C.c_float(ratio),
+                           _p(bi), _p(b), _p(s), _p(acc))
+    return bi, b, s, acc, assigned
+
+
+def bf_match(q, t):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    M, N = len(q), len(t)
+    ti = np.zeros(M, np.int32); d = np.zeros(M, np.int32); keep = np.zeros(M, np.uint8)
+    lib().orc_bf_match(_p(q), M, _p(t), N, _p(ti), _p(d), _p(keep))
+    return ti, d, keep
+
+
+def huber(e, delta):
+    rho = np.zeros(3)
+    lib().orc_huber(C.c_double(e), C.c_double(delta), _p(rho))
+    return rho
+
+
+def se3_exp_matrix(upd):
+    upd = np.ascontiguousarray(upd, np.float64); T = np.zeros(16)
+    lib().orc_se3_exp_matrix(_p(upd), _p(T))
+    return T.reshape(4, 4)
+
+
+def se3_update(upd, T):
+    upd = np.ascontiguousarray(upd, np.float64); T = np.ascontiguousarray(T, np.float64).reshape(16).copy()
+    lib().orc_se3_update(_p(upd), _p(T))
+    return T.reshape(4, 4)
+
+
+def pose_opt(Xw, obs, K, T, trace_cap=128):
+    Xw = np.ascontiguousarray(Xw, np.float64); obs = np.ascontiguousarray(obs, np.float64)
+    K = np.ascontiguousarray(K, np.float64); T = np.ascontiguousarray(T, np.float64).reshape(16).copy()
+    st = LmStats(); trace = np.zeros((trace_cap, 8))
+    nt = lib().orc_pose_opt(_p(Xw), _p(obs), len(Xw), _p(K), _p(T), C.byref(st), _p(trace), trace_cap)
+    return T.reshape(4, 4), st, trace[:nt].copy()
+
+
+def pnp_ransac(Xw, obs, K, T_prior, seed):
+    Xw = np.ascontiguousarray(Xw, np.float64); obs = np.ascontiguousarray(obs, np.float64)
+    K = np.ascontiguousarray(K, np.float64); Tp = np.ascontiguousarray(T_prior, np.float64).reshape(16)
+    T = np.zeros(16); mask = np.zeros(len(Xw), np.uint8); st = PnpStats()
+    lib().orc_pnp_ransac(_p(Xw), _p(obs), len(Xw), _p(K), _p(Tp), C.c_uint64(seed), _p(T), _p(mask),
+                         C.byref(st))
+    return T.reshape(4, 4), mask, st
+
+
+def disp2depth(disp, bf):
+    disp = np.ascontiguousarray(disp, np.float32); out = np.zeros_like(disp)
+    lib().orc_disp2depth(_p(disp), disp.size, C.c_float(bf), _p(out))
+    return out
+
+
+def unproject(uvz, cam, Rwc, twc):
+    uvz = np.ascontiguousarray(uvz, np.float32).reshape(-1, 3)
+    Rwc = np.ascontiguousarray(Rwc, np.float32).reshape(9); twc = np.ascontiguousarray(twc, np.float32).reshape(3)
+    out = np.zeros_like(uvz)
+    fx, fy, cx, cy = (C.c_float(float(v)) for v in cam[:4])
+    lib().orc_unproject(_p(uvz), len(uvz), fx, fy, cx, cy, _p(Rwc), _p(twc), _p(out))
+    return out

@@ -1,0 +1,104 @@
+/* svo_oracle.h - CPU restatement (plain C) of the stereo-VO tracking hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under stereo-semantic-vo_amd/ may include,
+ * link or call this; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker / the timed CPU baseline.
+ *
+ * PARITY UNPINNED for the OpenCV-delegated stages (ORB, BFMatcher, 8-point F,
+ * solvePnPRansac): the reference holds no tests or golden vectors, OpenCV 3.2 is
+ * neither vendored nor installed, and the reference cannot be built here
+ * (SURVEY.md section 8c).  The own-code stages (DescriptorDistance, the two
+ * matching passes, disp2Depth / UnprojectStereo, the g2o pose-only LM) follow the
+ * reference sources line by line; each function cites the lines it restates.
+ */
+#ifndef SVO_ORACLE_H
+#define SVO_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_NLEVELS 8
+#define ORC_EDGE 31          /* cv::ORB edgeThreshold default */
+#define ORC_FAST_THR 20      /* cv::ORB fastThreshold default */
+#define ORC_HALF_PATCH 15
+#define ORC_CAP1 2048        /* cap on Harris candidates per level */
+
+typedef struct orc_kp {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+} orc_kp;
+
+typedef struct orc_lm_stats {
+  int32_t n_edges, iterations, trials_total, terminated;
+  double chi2_initial, chi2_final, lambda_final;
+} orc_lm_stats;
+
+typedef struct orc_pnp_stats {
+  int32_t n_points, n_inliers, best_hypothesis, ok;
+} orc_pnp_stats;
+
+/* geometry */
+int orc_geometry(int W, int H, int nfeatures, int32_t w[8], int32_t h[8], float scale[8],
+                 int32_t quota[8]);
+void orc_umax(int32_t umax[16]);
+int64_t orc_pyramid_size(int W, int H);
+int64_t orc_level_offset(int W, int H, int level);
+
+/* ORB stages */
+void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst,
+                          int dw, int dh, int dstride);
+void orc_build_pyramid(const uint8_t* gray, int W, int H, int stride, uint8_t* pyr);
+int orc_fast_score_at(const uint8_t* img, int w, int h, int stride, int x, int y);
+int orc_fast_corners(const uint8_t* img, int w, int h, int stride, int thr, int border,
+                     int32_t* xys, int cap);
+int64_t orc_harris_at(const uint8_t* img, int stride, int x, int y);
+float orc_harris_to_float(int64_t R);
+float orc_fast_atan2(float y, float x);
+float orc_ic_angle(const uint8_t* img, int stride, int x, int y);
+void orc_sincos(float angle_rad, float* s, float* c);
+void orc_gaussian_blur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
+void orc_describe(const uint8_t* blurred, int stride, int x, int y, float angle_deg,
+                  uint8_t desc[32]);
+int orc_orb_from_pyramid(const uint8_t* pyr, int W, int H, int nfeatures, orc_kp* kp,
+                         uint8_t* desc);
+int orc_orb_extract(const uint8_t* gray, int W, int H, int stride, int nfeatures, orc_kp* kp,
+                    uint8_t* desc, uint8_t* pyr_out);
+
+/* sparse stereo */
+int orc_stereo_match(const uint8_t* pyrL, const uint8_t* pyrR, int W, int H, const orc_kp* kpL,
+                     const uint8_t* dL, int nL, const orc_kp* kpR, const uint8_t* dR, int nR,
+                     float bf, float fx, float* uR, float* depth);
+int orc_stereo_frame(const uint8_t* grayL, int strideL, const uint8_t* grayR, int strideR, int W,
+                     int H, int nfeatures, float bf, float fx, orc_kp* kpL, uint8_t* dL,
+                     int32_t* nL, float* uR, float* depth, orc_kp* kpR, uint8_t* dR,
+                     int32_t* nR);
+void orc_disp2depth(const float* disp, int count, float bf, float* depth);
+void orc_unproject(const float* uvz, int n, float fx, float fy, float cx, float cy,
+                   const float Rwc[9], const float twc[3], float* xyz);
+
+/* matching */
+int orc_descriptor_distance(const uint8_t* a, const uint8_t* b);
+void orc_hamming_argmin(const uint8_t* q, int M, const uint8_t* t, int N, const uint8_t* t_mask,
+                        int32_t* best_idx, int32_t* best, int32_t* second);
+void orc_match_greedy(const uint8_t* q, const uint8_t* q_skip, int M, const uint8_t* t, int N,
+                      uint8_t* assigned, int max_dist, float ratio, int32_t* best_idx,
+                      int32_t* best, int32_t* second, uint8_t* accepted);
+void orc_bf_match(const uint8_t* q, int M, const uint8_t* t, int N, int32_t* train_idx,
+                  int32_t* dist, uint8_t* keep);
+
+/* pose */
+void orc_huber(double e, double delta, double rho[3]);
+void orc_se3_exp(const double upd[6], double q_xyzw[4], double t[3]);
+void orc_se3_exp_matrix(const double upd[6], double T[16]);
+void orc_se3_update(const double upd[6], double T[16]);
+int orc_pose_opt(const double* Xw, const double* obs, int n, const double K[4], double T[16],
+                 orc_lm_stats* stats, double* trace, int trace_cap);
+int orc_pnp_ransac(const double* Xw, const double* obs, int n, const double K[4],
+                   const double T_prior[16], uint64_t seed, double T[16], uint8_t* inlier_mask,
+                   orc_pnp_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

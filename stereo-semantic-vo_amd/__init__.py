@@ -1,0 +1,296 @@
+"""stereo-semantic-vo_amd - MI355X-native stereo-VO tracking front end (host binding).
+
+Thin ctypes layer over the C-ABI shared library ``libsvo_hip.so`` (include/svo.h).
+There is NO CPU fallback: if the library is missing, or no HIP device is usable,
+construction fails loudly.  The directory name carries a hyphen (it mirrors the
+reference repo's name), so import it through ``svo_loader.load()`` at the repo root
+or ``importlib`` - the module registers itself as ``stereo_semantic_vo_amd``.
+
+Class surface mirrors the reference's hot-path seams:
+  Svo.orb_extract       <- frame::featuredetect            (src/frame.cc:75-79)
+  Svo.stereo_frame      <- frame::MB + computekeypoint_r + disp2Depth
+                                                            (src/Tracking.cc:226-228)
+  Svo.descriptor_distance / hamming_argmin / match_greedy / bf_match
+                        <- pnpmatch::DescriptorDistance, poseEstimationPnP passes,
+                           find_feature_matches             (src/pnpmatch.cc)
+  Svo.pnp_ransac        <- cv::solvePnPRansac call          (src/pnpmatch.cc:227)
+  Svo.pose_opt          <- Optimizer::PoseOptimization      (src/Optimizer.cc:15-86)
+  Svo.track_*           <- Tracking::Track                  (src/Tracking.cc:180-252)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvo_hip.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+TRACK_DTYPE = np.dtype([("Tcw", "<f4", (16,)), ("frame_id", "<i4"), ("n_kp", "<i4"),
+                        ("n_stereo", "<i4"), ("n_match_pass1", "<i4"), ("n_match_pass2", "<i4"),
+                        ("n_pnp_inliers", "<i4"), ("n_lm_edges", "<i4"), ("n_new_mappoints", "<i4"),
+                        ("n_local_map", "<i4"), ("lm_iterations", "<i4"), ("reserved", "<i4", (2,))])
+
+# Every symbol include/svo.h declares (checked by tests/test_abi.py without a GPU).
+ABI_SYMBOLS = [
+    "svo_abi_version", "svo_strerror", "svo_last_error", "svo_create", "svo_destroy", "svo_sync",
+    "svo_stream", "svo_orb_geometry", "svo_orb_extract", "svo_debug_pyramid_level",
+    "svo_debug_fast_corners", "svo_stereo_frame", "svo_stereo_frame_ex", "svo_disp2depth",
+    "svo_unproject", "svo_descriptor_distance", "svo_hamming_argmin", "svo_match_greedy",
+    "svo_bf_match", "svo_pnp_ransac", "svo_pose_opt", "svo_track_reset", "svo_track_frame",
+    "svo_frontend_batch_dev", "svo_track_batch_dev", "svo_profile_enable", "svo_profile_reset",
+    "svo_profile_get",
+]
+
+
+class SvoError(RuntimeError):
+    pass
+
+
+class Camera(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("bf", C.c_float)]
+
+
+class LmStats(C.Structure):
+    _fields_ = [("n_edges", C.c_int32), ("iterations", C.c_int32), ("trials_total", C.c_int32),
+                ("terminated", C.c_int32), ("chi2_initial", C.c_double), ("chi2_final", C.c_double),
+                ("lambda_final", C.c_double)]
+
+
+class PnpStats(C.Structure):
+    _fields_ = [("n_points", C.c_int32), ("n_inliers", C.c_int32), ("best_hypothesis", C.c_int32),
+                ("ok", C.c_int32)]
+
+
+# KITTI intrinsics of the reference's settings files (Stereo/KITTI00-02.yaml:8-11,25 and
+# Stereo/KITTI04-12.yaml:8-11,25) - the only five keys Tracking::Tracking reads.
+KITTI_00_02 = dict(fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, bf=386.1448)
+KITTI_04_12 = dict(fx=707.0912, fy=707.0912, cx=601.8873, cy=183.1104, bf=379.8145)
+
+_lib = None
+
+
+def load_library():
+    """dlopen libsvo_hip.so; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SvoError("HIP extension missing: %s (run `make -C %s` or __graft_entry__.build())"
+                           % (LIB_PATH, _HERE))
+        lib = C.CDLL(LIB_PATH)
+        lib.svo_strerror.restype = C.c_char_p
+        lib.svo_last_error.restype = C.c_char_p
+        lib.svo_last_error.argtypes = [C.c_void_p]
+        lib.svo_stream.restype = C.c_void_p
+        lib.svo_stream.argtypes = [C.c_void_p]
+        lib.svo_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        lib.svo_destroy.argtypes = [C.c_void_p]
+        lib.svo_destroy.restype = None
+        _lib = lib
+    return _lib
+
+
+def _p(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, np.uint8)
+
+
+class Svo:
+    """One tracker context bound to one GPU (wraps svo_ctx)."""
+
+    def __init__(self, W, H, device=0, max_kp=500, max_batch=1):
+        self.lib = load_library()
+        self.W, self.H, self.max_kp, self.max_batch = int(W), int(H), int(max_kp), int(max_batch)
+        h = C.c_void_p()
+        rc = self.lib.svo_create(C.byref(h), int(device), self.W, self.H, self.max_kp, self.max_batch)
+        if rc != 0:
+            raise SvoError("svo_create failed: %s" % self.lib.svo_strerror(rc).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.svo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise SvoError("%s: %s" % (self.lib.svo_strerror(rc).decode(),
+                                       self.lib.svo_last_error(self.h).decode()))
+
+    @staticmethod
+    def camera(fx, fy, cx, cy, bf):
+        return Camera(fx, fy, cx, cy, bf)
+
+    def sync(self):
+        self._chk(self.lib.svo_sync(self.h))
+
+    @property
+    def stream(self):
+        return self.lib.svo_stream(self.h)
+
+    def geometry(self):
+        w = np.zeros(8, np.int32); h = np.zeros(8, np.int32)
+        s = np.zeros(8, np.float32); q = np.zeros(8, np.int32)
+        self._chk(self.lib.svo_orb_geometry(self.h, _p(w), _p(h), _p(s), _p(q)))
+        return w, h, s, q
+
+    # ---- frame::featuredetect ------------------------------------------------------
+    def orb_extract(self, gray):
+        gray = _u8(gray)
+        assert gray.shape == (self.H, self.W)
+        kp = np.zeros(self.max_kp, KP_DTYPE); desc = np.zeros((self.max_kp, 32), np.uint8)
+        n = C.c_int32(0)
+        self._chk(self.lib.svo_orb_extract(self.h, _p(gray), self.W, _p(kp), _p(desc), C.byref(n)))
+        return kp[:n.value].copy(), desc[:n.value].copy()
+
+    def debug_pyramid_level(self, slot, level):
+        w, h, _, _ = self.geometry()
+        out = np.zeros((h[level], w[level]), np.uint8)
+        self._chk(self.lib.svo_debug_pyramid_level(self.h, slot, level, _p(out)))
+        return out
+
+    def debug_fast_corners(self, slot, level):
+        w, h, _, _ = self.geometry()
+        cap = (int(w[level]) // 2 + 1) * (int(h[level]) // 2 + 1)
+        out = np.zeros((cap, 3), np.int32); n = C.c_int32(0)
+        self._chk(self.lib.svo_debug_fast_corners(self.h, slot, level, _p(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    # ---- stereo association + depth -------------------------------------------------
+    def stereo_frame(self, grayL, grayR, cam):
+        grayL = _u8(grayL); grayR = _u8(grayR)
+        assert grayL.shape == (self.H, self.W) and grayR.shape == (self.H, self.W)
+        K = self.max_kp
+        kpL = np.zeros(K, KP_DTYPE); dL = np.zeros((K, 32), np.uint8)
+        kpR = np.zeros(K, KP_DTYPE); dR = np.zeros((K, 32), np.uint8)
+        uR = np.zeros(K, np.float32); depth = np.zeros(K, np.float32)
+        nL = C.c_int32(0); nR = C.c_int32(0)
+        self._chk(self.lib.svo_stereo_frame_ex(self.h, _p(grayL), self.W, _p(grayR), self.W,
+                                               C.byref(cam), _p(kpL), _p(dL), C.byref(nL), _p(uR),
+                                               _p(depth), _p(kpR), _p(dR), C.byref(nR)))
+        nl, nr = nL.value, nR.value
+        return dict(kpL=kpL[:nl].copy(), dL=dL[:nl].copy(), uR=uR[:nl].copy(),
+                    depth=depth[:nl].copy(), kpR=kpR[:nr].copy(), dR=dR[:nr].copy())
+
+    def disp2depth(self, disp, bf):
+        disp = np.ascontiguousarray(disp, np.float32); out = np.zeros_like(disp)
+        self._chk(self.lib.svo_disp2depth(self.h, _p(disp), disp.size, C.c_float(bf), _p(out)))
+        return out
+
+    def unproject(self, uvz, cam, Rwc, twc):
+        uvz = np.ascontiguousarray(uvz, np.float32).reshape(-1, 3)
+        Rwc = np.ascontiguousarray(Rwc, np.float32).reshape(9)
+        twc = np.ascontiguousarray(twc, np.float32).reshape(3)
+        out = np.zeros_like(uvz)
+        self._chk(self.lib.svo_unproject(self.h, _p(uvz), len(uvz), C.byref(cam), _p(Rwc), _p(twc),
+                                         _p(out)))
+        return out
+
+    # ---- pnpmatch ---------------------------------------------------------------------
+    def descriptor_distance(self, a, b):
+        a = _u8(a).reshape(-1, 32); b = _u8(b).reshape(-1, 32)
+        out = np.zeros(len(a), np.int32)
+        self._chk(self.lib.svo_descriptor_distance(self.h, _p(a), _p(b), len(a), _p(out)))
+        return out
+
+    def hamming_argmin(self, q, t, t_mask=None):
+        q = _u8(q).reshape(-1, 32); t = _u8(t).reshape(-1, 32)
+        M, N = len(q), len(t)
+        bi = np.zeros(M, np.int32); b = np.zeros(M, np.int32); s = np.zeros(M, np.int32)
+        m = None if t_mask is None else _u8(t_mask)
+        self._chk(self.lib.svo_hamming_argmin(self.h, _p(q), M, _p(t), N, _p(m), _p(bi), _p(b), _p(s)))
+        return bi, b, s
+
+    def match_greedy(self, q, t, assigned, max_dist, ratio, q_skip=None):
+        q = _u8(q).reshape(-1, 32); t = _u8(t).reshape(-1, 32)
+        M, N = len(q), len(t)
+        assigned = _u8(assigned).copy()
+        sk = None if q_skip is None else _u8(q_skip)
+        bi = np.zeros(M, np.int32); b = np.zeros(M, np.int32); s = np.zeros(M, np.int32)
+        acc = np.zeros(M, np.uint8)
+        self._chk(self.lib.svo_match_greedy(self.h, _p(q), _p(sk), M, _p(t), N, _p(assigned),
+                                            int(max_dist), C.c_float(ratio), _p(bi), _p(b), _p(s),
+                                            _p(acc)))
+        return bi, b, s, acc, assigned
+
+    def bf_match(self, q, t):
+        q = _u8(q).reshape(-1, 32); t = _u8(t).reshape(-1, 32)
+        M, N = len(q), len(t)
+        ti = np.zeros(M, np.int32); d = np.zeros(M, np.int32); keep = np.zeros(M, np.uint8)
+        self._chk(self.lib.svo_bf_match(self.h, _p(q), M, _p(t), N, _p(ti), _p(d), _p(keep)))
+        return ti, d, keep
+
+    def pnp_ransac(self, Xw, obs, K, T_prior, seed):
+        Xw = np.ascontiguousarray(Xw, np.float64).reshape(-1, 3)
+        obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 2)
+        K = np.ascontiguousarray(K, np.float64)
+        Tp = np.ascontiguousarray(T_prior, np.float64).reshape(16)
+        T = np.zeros(16); mask = np.zeros(max(len(Xw), 1), np.uint8); st = PnpStats()
+        self._chk(self.lib.svo_pnp_ransac(self.h, _p(Xw), _p(obs), len(Xw), _p(K), _p(Tp),
+                                          C.c_uint64(seed), _p(T), _p(mask), C.byref(st)))
+        return T.reshape(4, 4), mask[:len(Xw)], st
+
+    # ---- Optimizer::PoseOptimization ------------------------------------------------------
+    def pose_opt(self, Xw, obs, K, T):
+        Xw = np.ascontiguousarray(Xw, np.float64).reshape(-1, 3)
+        obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 2)
+        K = np.ascontiguousarray(K, np.float64)
+        T = np.ascontiguousarray(T, np.float64).reshape(16).copy()
+        st = LmStats()
+        self._chk(self.lib.svo_pose_opt(self.h, _p(Xw), _p(obs), len(Xw), _p(K), _p(T), C.byref(st)))
+        return T.reshape(4, 4), st
+
+    # ---- Tracking::Track -------------------------------------------------------------------
+    def track_reset(self, cam):
+        self._chk(self.lib.svo_track_reset(self.h, C.byref(cam)))
+
+    def track_frame(self, grayL, grayR, timestamp=0.0, boxes=None):
+        grayL = _u8(grayL); grayR = _u8(grayR)
+        res = np.zeros(1, TRACK_DTYPE)
+        bx = None if boxes is None or len(boxes) == 0 else np.ascontiguousarray(boxes, np.int32)
+        nb = 0 if bx is None else len(bx)
+        self._chk(self.lib.svo_track_frame(self.h, _p(grayL), self.W, _p(grayR), self.W,
+                                           C.c_double(timestamp), _p(bx), nb, _p(res)))
+        return res[0]
+
+    # ---- throughput mode (device pointers, e.g. torch tensors' data_ptr()) --------------------
+    def frontend_batch_dev(self, d_grayL, d_grayR, stride, B, cam, d_kpL=None, d_descL=None,
+                           d_nL=None, d_uR=None, d_depth=None):
+        self._chk(self.lib.svo_frontend_batch_dev(self.h, _p(d_grayL), _p(d_grayR), int(stride),
+                                                  int(B), C.byref(cam), _p(d_kpL), _p(d_descL),
+                                                  _p(d_nL), _p(d_uR), _p(d_depth)))
+
+    def track_batch_dev(self, d_grayL, d_grayR, stride, B, d_results):
+        self._chk(self.lib.svo_track_batch_dev(self.h, _p(d_grayL), _p(d_grayR), int(stride), int(B),
+                                               _p(d_results)))
+
+    # ---- profiling ----------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._chk(self.lib.svo_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._chk(self.lib.svo_profile_reset(self.h))
+
+    def profile(self):
+        out, i = {}, 0
+        name = C.create_string_buffer(64); ms = C.c_double(0); n = C.c_int64(0)
+        while self.lib.svo_profile_get(self.h, i, name, 64, C.byref(ms), C.byref(n)) == 0:
+            out[name.value.decode()] = (ms.value, n.value)
+            i += 1
+        return out

@@ -1,0 +1,641 @@
+// svo_api.hip - context, geometry/tables and the C-ABI entry points of include/svo.h.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "svo_internal.h"
+
+// ---- profiling ---------------------------------------------------------------------
+// Event pairs are recorded around a stage on the ctx stream and resolved lazily.
+struct PendingEvt { int entry; hipEvent_t a, b; };
+
+struct SvoProfState {
+  std::vector<PendingEvt> pending;
+  std::vector<hipEvent_t> pool;
+};
+static SvoProfState* prof_state(svo_ctx* ctx) {
+  if (!ctx->prof_impl) ctx->prof_impl = new SvoProfState();
+  return reinterpret_cast<SvoProfState*>(ctx->prof_impl);
+}
+static void prof_resolve(svo_ctx* ctx) {
+  SvoProfState* ps = prof_state(ctx);
+  for (auto& p : ps->pending) {
+    hipEventSynchronize(p.b);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      ctx->prof[p.entry].total_ms += ms;
+      ctx->prof[p.entry].launches += 1;
+    }
+    ps->pool.push_back(p.a);
+    ps->pool.push_back(p.b);
+  }
+  ps->pending.clear();
+}
+static hipEvent_t prof_event(SvoProfState* ps) {
+  if (!ps->pool.empty()) {
+    hipEvent_t e = ps->pool.back();
+    ps->pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+SvoTimer::SvoTimer(svo_ctx* c, const char* n) : ctx(c), name(n) {
+  if (!ctx->profiling) return;
+  SvoProfState* ps = prof_state(ctx);
+  if (ps->pending.size() > 8192) prof_resolve(ctx);
+  int entry = -1;
+  for (size_t i = 0; i < ctx->prof.size(); ++i)
+    if (ctx->prof[i].name == n) entry = (int)i;
+  if (entry < 0) {
+    SvoProfileEntry e;
+    e.name = n;
+    ctx->prof.push_back(e);
+    entry = (int)ctx->prof.size() - 1;
+  }
+  PendingEvt p{entry, prof_event(ps), prof_event(ps)};
+  hipEventRecord(p.a, ctx->stream);
+  ps->pending.push_back(p);
+}
+SvoTimer::~SvoTimer() {
+  if (!ctx->profiling) return;
+  SvoProfState* ps = prof_state(ctx);
+  hipEventRecord(ps->pending.back().b, ctx->stream);
+}
+
+// ---- geometry + tables ---------------------------------------------------------------
+static inline int cv_round_f(float v) { return (int)lrintf(v); }
+
+static void build_geometry(SvoGeom& g, int W, int H, int nfeatures) {
+  memset(&g, 0, sizeof g);
+  g.W = W; g.H = H;
+  for (int l = 0; l < SVO_NLEVELS; ++l) {
+    g.scale[l] = (float)pow((double)1.2f, (double)l);
+    const float inv = 1.0f / g.scale[l];
+    g.w[l] = cv_round_f((float)W * inv);
+    g.h[l] = cv_round_f((float)H * inv);
+  }
+  const float factor = (float)(1.0 / (double)1.2f);
+  float ndesired = (float)nfeatures * (1.0f - factor) /
+                   (1.0f - (float)pow((double)factor, (double)SVO_NLEVELS));
+  int sum = 0;
+  for (int l = 0; l < SVO_NLEVELS - 1; ++l) {
+    g.quota[l] = cv_round_f(ndesired);
+    sum += g.quota[l];
+    ndesired *= factor;
+  }
+  g.quota[SVO_NLEVELS - 1] = std::max(nfeatures - sum, 0);
+  int64_t off = 0, coff = 0;
+  int xt = 0, yt = 0, tb = 0;
+  for (int l = 0; l < SVO_NLEVELS; ++l) {
+    g.pitch[l] = (g.w[l] + 63) / 64 * 64;
+    g.loff[l] = off;
+    if (l > 0) off += (int64_t)g.pitch[l] * g.h[l];
+    off = (off + 255) / 256 * 256;
+    const int iw = std::max(g.w[l] - 2 * SVO_EDGE, 0), ih = std::max(g.h[l] - 2 * SVO_EDGE, 0);
+    g.cap[l] = (iw / 2 + 1) * (ih / 2 + 1);
+    g.coff[l] = coff;
+    coff += g.cap[l];
+    g.tiles_x[l] = iw > 0 && ih > 0 ? (g.w[l] - SVO_EDGE - 28 + FAST_TW - 1) / FAST_TW : 0;
+    g.tiles_y[l] = iw > 0 && ih > 0 ? (ih + FAST_TH - 1) / FAST_TH : 0;
+    g.tile_base[l] = tb;
+    tb += g.tiles_x[l] * g.tiles_y[l];
+    g.xtab_off[l] = xt; g.ytab_off[l] = yt;
+    xt += g.w[l]; yt += g.h[l];
+  }
+  g.tile_base[SVO_NLEVELS] = tb;
+  g.pyr_bytes = off;
+  g.corner_entries = coff;
+}
+
+// cv::resize INTER_LINEAR coefficient tables (fixed point, 11 bits)
+static void build_resize_tables(const SvoGeom& g, std::vector<int32_t>& xofs,
+                                std::vector<int32_t>& xalpha, std::vector<int32_t>& yofs,
+                                std::vector<int32_t>& ybeta) {
+  int xt = 0, yt = 0;
+  for (int l = 0; l < SVO_NLEVELS; ++l) { xt += g.w[l]; yt += g.h[l]; }
+  xofs.assign(xt, 0); xalpha.assign(xt, 0); yofs.assign(yt, 0); ybeta.assign(yt, 0);
+  for (int l = 1; l < SVO_NLEVELS; ++l) {
+    const int sw = g.w[l - 1], sh = g.h[l - 1], dw = g.w[l], dh = g.h[l];
+    const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+    for (int dx = 0; dx < dw; ++dx) {
+      float fx = (float)((dx + 0.5) * scale_x - 0.5);
+      int sx = (int)floorf(fx);
+      fx -= (float)sx;
+      if (sx < 0) { fx = 0; sx = 0; }
+      if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+      const int a0 = (short)cv_round_f((1.f - fx) * 2048.f), a1 = (short)cv_round_f(fx * 2048.f);
+      xofs[g.xtab_off[l] + dx] = sx;
+      xalpha[g.xtab_off[l] + dx] = (a0 & 0xffff) | (a1 << 16);
+    }
+    for (int dy = 0; dy < dh; ++dy) {
+      float fy = (float)((dy + 0.5) * scale_y - 0.5);
+      int sy = (int)floorf(fy);
+      fy -= (float)sy;
+      if (sy < 0) { fy = 0; sy = 0; }
+      if (sy >= sh - 1) { fy = 0; sy = sh - 1; }
+      const int b0 = (short)cv_round_f((1.f - fy) * 2048.f), b1 = (short)cv_round_f(fy * 2048.f);
+      yofs[g.ytab_off[l] + dy] = sy;
+      ybeta[g.ytab_off[l] + dy] = (b0 & 0xffff) | (b1 << 16);
+    }
+  }
+}
+
+// ---- lifecycle -------------------------------------------------------------------------
+extern "C" int svo_abi_version(void) { return SVO_ABI_VERSION; }
+
+extern "C" const char* svo_strerror(int status) {
+  switch (status) {
+    case SVO_OK: return "ok";
+    case SVO_E_INVALID: return "invalid argument";
+    case SVO_E_NODEVICE: return "no usable HIP device";
+    case SVO_E_NOMEM: return "out of memory";
+    case SVO_E_HIP: return "HIP runtime error";
+    case SVO_E_CAPACITY: return "capacity exceeded";
+    default: return "unknown status";
+  }
+}
+extern "C" const char* svo_last_error(const svo_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+template <typename T>
+static int dalloc(svo_ctx* ctx, T** p, size_t count) {
+  void* v = nullptr;
+  hipError_t e = hipMalloc(&v, std::max<size_t>(count * sizeof(T), 256));
+  if (e != hipSuccess) {
+    ctx->last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+    return SVO_E_NOMEM;
+  }
+  *p = reinterpret_cast<T*>(v);
+  return SVO_OK;
+}
+
+extern "C" int svo_create(svo_ctx** out, int device, int W, int H, int max_kp, int max_batch) {
+  if (!out || W < 96 || H < 96 || W > 4095 || H > 4095 || max_kp < 8 || max_kp > 512 ||
+      max_batch < 1)
+    return SVO_E_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+    return SVO_E_NODEVICE;
+  if (hipSetDevice(device) != hipSuccess) return SVO_E_NODEVICE;
+  svo_ctx* ctx = new svo_ctx();
+  ctx->device = device;
+  ctx->max_kp = max_kp;
+  ctx->max_batch = max_batch;
+  ctx->max_images = 2 * max_batch;
+  build_geometry(ctx->g, W, H, max_kp);
+  const SvoGeom& g = ctx->g;
+  for (int l = 0; l < SVO_NLEVELS; ++l)
+    if (g.quota[l] > SVO_QMAX) { delete ctx; return SVO_E_INVALID; }
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return SVO_E_NODEVICE;
+  }
+  std::vector<int32_t> xofs, xalpha, yofs, ybeta;
+  build_resize_tables(g, xofs, xalpha, yofs, ybeta);
+  const size_t I = (size_t)ctx->max_images;
+  ctx->stage_pitch = (W + 63) / 64 * 64;
+  ctx->scratch_bytes = 16u << 20;
+  ctx->pinned_bytes = 8u << 20;
+  int rc = SVO_OK;
+#define TRY(x) if (rc == SVO_OK) rc = (x)
+  TRY(dalloc(ctx, &ctx->d_xofs, xofs.size()));
+  TRY(dalloc(ctx, &ctx->d_xalpha, xalpha.size()));
+  TRY(dalloc(ctx, &ctx->d_yofs, yofs.size()));
+  TRY(dalloc(ctx, &ctx->d_ybeta, ybeta.size()));
+  TRY(dalloc(ctx, &ctx->d_stage, I * (size_t)H * ctx->stage_pitch));
+  TRY(dalloc(ctx, &ctx->d_pyr, I * (size_t)g.pyr_bytes));
+  TRY(dalloc(ctx, &ctx->d_corners, I * (size_t)g.corner_entries));
+  TRY(dalloc(ctx, &ctx->d_counters, I * SVO_NLEVELS));
+  TRY(dalloc(ctx, &ctx->d_hist, I * SVO_NLEVELS * 256));
+  TRY(dalloc(ctx, &ctx->d_sel, I * SVO_NLEVELS * SVO_QMAX));
+  TRY(dalloc(ctx, &ctx->d_selcnt, I * SVO_NLEVELS));
+  TRY(dalloc(ctx, &ctx->d_kp, I * (size_t)max_kp));
+  TRY(dalloc(ctx, &ctx->d_desc, I * (size_t)max_kp * 32));
+  TRY(dalloc(ctx, &ctx->d_nkp, I));
+  TRY(dalloc(ctx, &ctx->d_uR, (size_t)max_batch * max_kp));
+  TRY(dalloc(ctx, &ctx->d_depth, (size_t)max_batch * max_kp));
+  TRY(dalloc(ctx, &ctx->d_sad, (size_t)max_batch * max_kp));
+  TRY(dalloc(ctx, &ctx->d_scratch, ctx->scratch_bytes));
+#undef TRY
+  if (rc == SVO_OK && hipHostMalloc((void**)&ctx->h_pinned, ctx->pinned_bytes) != hipSuccess)
+    rc = SVO_E_NOMEM;
+  if (rc == SVO_OK) {
+    hipMemcpy(ctx->d_xofs, xofs.data(), xofs.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(ctx->d_xalpha, xalpha.data(), xalpha.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(ctx->d_yofs, yofs.data(), yofs.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(ctx->d_ybeta, ybeta.data(), ybeta.size() * 4, hipMemcpyHostToDevice);
+    hipMemset(ctx->d_nkp, 0, I * 4);
+    hipMemset(ctx->d_selcnt, 0, I * SVO_NLEVELS * 4);
+  }
+  if (rc != SVO_OK) {
+    svo_destroy(ctx);
+    return rc;
+  }
+  *out = ctx;
+  return SVO_OK;
+}
+
+extern "C" void svo_destroy(svo_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  void* ptrs[] = {ctx->d_xofs, ctx->d_xalpha, ctx->d_yofs, ctx->d_ybeta, ctx->d_stage, ctx->d_pyr,
+                  ctx->d_corners, ctx->d_counters, ctx->d_hist, ctx->d_sel, ctx->d_selcnt,
+                  ctx->d_kp, ctx->d_desc, ctx->d_nkp, ctx->d_uR, ctx->d_depth, ctx->d_sad,
+                  ctx->d_scratch, ctx->d_track};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+  if (ctx->prof_impl) {
+    SvoProfState* ps = reinterpret_cast<SvoProfState*>(ctx->prof_impl);
+    for (auto& p : ps->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto e : ps->pool) hipEventDestroy(e);
+    delete ps;
+  }
+  if (ctx->stream) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" int svo_sync(svo_ctx* ctx) {
+  if (!ctx) return SVO_E_INVALID;
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVO_OK;
+}
+extern "C" void* svo_stream(svo_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" int svo_orb_geometry(const svo_ctx* ctx, int32_t w[8], int32_t h[8], float scale[8],
+                                int32_t quota[8]) {
+  if (!ctx) return SVO_E_INVALID;
+  for (int l = 0; l < SVO_NLEVELS; ++l) {
+    w[l] = ctx->g.w[l]; h[l] = ctx->g.h[l]; scale[l] = ctx->g.scale[l]; quota[l] = ctx->g.quota[l];
+  }
+  return SVO_OK;
+}
+
+// ---- host-path helpers -------------------------------------------------------------------
+static int upload_image(svo_ctx* ctx, const uint8_t* gray, int stride, int slot) {
+  uint8_t* dst = ctx->d_stage + (size_t)slot * ctx->g.H * ctx->stage_pitch;
+  SVO_HIP(ctx, hipMemcpy2DAsync(dst, ctx->stage_pitch, gray, stride, ctx->g.W, ctx->g.H,
+                                hipMemcpyHostToDevice, ctx->stream));
+  return SVO_OK;
+}
+// scratch bump allocator (first half of d_scratch; second half belongs to the launchers)
+struct Bump {
+  svo_ctx* ctx; size_t off = 0;
+  template <typename T> T* take(size_t count) {
+    off = (off + 255) & ~size_t(255);
+    T* p = reinterpret_cast<T*>(ctx->d_scratch + off);
+    off += count * sizeof(T);
+    return p;
+  }
+  bool ok() const { return off <= ctx->scratch_bytes / 2; }
+};
+
+extern "C" int svo_orb_extract(svo_ctx* ctx, const uint8_t* gray, int stride, svo_kp* kp,
+                               uint8_t* desc, int32_t* n) {
+  if (!ctx || !gray || !kp || !desc || !n || stride < ctx->g.W) return SVO_E_INVALID;
+  hipSetDevice(ctx->device);
+  int rc = upload_image(ctx, gray, stride, 0);
+  if (rc) return rc;
+  rc = svo_launch_orb(ctx, ctx->d_stage, ctx->d_stage, ctx->stage_pitch, 1, 1);
+  if (rc) return rc;
+  int32_t cnt = 0;
+  SVO_HIP(ctx, hipMemcpyAsync(&cnt, ctx->d_nkp, 4, hipMemcpyDeviceToHost, ctx->stream));
+  SVO_HIP(ctx, hipMemcpyAsync(kp, ctx->d_kp, sizeof(svo_kp) * ctx->max_kp, hipMemcpyDeviceToHost,
+                              ctx->stream));
+  SVO_HIP(ctx, hipMemcpyAsync(desc, ctx->d_desc, 32 * (size_t)ctx->max_kp, hipMemcpyDeviceToHost,
+                              ctx->stream));
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *n = cnt;
+  return SVO_OK;
+}
+
+extern "C" int svo_debug_pyramid_level(svo_ctx* ctx, int image_slot, int level, uint8_t* out) {
+  if (!ctx || !out || level < 0 || level >= SVO_NLEVELS || image_slot < 0 ||
+      image_slot >= ctx->max_images)
+    return SVO_E_INVALID;
+  const SvoGeom& g = ctx->g;
+  const uint8_t* src;
+  int pitch;
+  if (level == 0) {
+    src = ctx->d_stage + (size_t)image_slot * g.H * ctx->stage_pitch;
+    pitch = ctx->stage_pitch;
+  } else {
+    src = ctx->d_pyr + (size_t)image_slot * g.pyr_bytes + g.loff[level];
+    pitch = g.pitch[level];
+  }
+  SVO_HIP(ctx, hipMemcpy2DAsync(out, g.w[level], src, pitch, g.w[level], g.h[level],
+                                hipMemcpyDeviceToHost, ctx->stream));
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVO_OK;
+}
+
+extern "C" int svo_debug_fast_corners(svo_ctx* ctx, int image_slot, int level, int32_t* xy_score,
+                                      int capacity, int32_t* n) {
+  if (!ctx || !xy_score || !n || level < 0 || level >= SVO_NLEVELS || image_slot < 0 ||
+      image_slot >= ctx->max_images)
+    return SVO_E_INVALID;
+  const SvoGeom& g = ctx->g;
+  int32_t cnt = 0;
+  SVO_HIP(ctx, hipMemcpy(&cnt, ctx->d_counters + image_slot * SVO_NLEVELS + level, 4,
+                         hipMemcpyDeviceToHost));
+  cnt = std::min(cnt, capacity);
+  std::vector<uint32_t> raw((size_t)std::max(cnt, 1));
+  if (cnt > 0)
+    SVO_HIP(ctx, hipMemcpy(raw.data(),
+                           ctx->d_corners + (size_t)image_slot * g.corner_entries + g.coff[level],
+                           4 * (size_t)cnt, hipMemcpyDeviceToHost));
+  for (int i = 0; i < cnt; ++i) {
+    xy_score[3 * i] = raw[i] & 0xfff;
+    xy_score[3 * i + 1] = (raw[i] >> 12) & 0xfff;
+    xy_score[3 * i + 2] = raw[i] >> 24;
+  }
+  *n = cnt;
+  return SVO_OK;
+}
+
+extern "C" int svo_stereo_frame_ex(svo_ctx* ctx, const uint8_t* grayL, int strideL,
+                                   const uint8_t* grayR, int strideR, const svo_camera* cam,
+                                   svo_kp* kpL, uint8_t* descL, int32_t* nL, float* uR,
+                                   float* depth, svo_kp* kpR, uint8_t* descR, int32_t* nR) {
+  if (!ctx || !grayL || !grayR || !cam || !kpL || !descL || !nL || !uR || !depth ||
+      strideL < ctx->g.W || strideR < ctx->g.W)
+    return SVO_E_INVALID;
+  hipSetDevice(ctx->device);
+  // slots: left -> image 0, right -> image 1 (B = 1)
+  int rc = upload_image(ctx, grayL, strideL, 0);
+  if (rc) return rc;
+  rc = upload_image(ctx, grayR, strideR, 1);
+  if (rc) return rc;
+  const uint8_t* dL = ctx->d_stage;
+  const uint8_t* dR = ctx->d_stage + (size_t)ctx->g.H * ctx->stage_pitch;
+  rc = svo_launch_orb(ctx, dL, dR, ctx->stage_pitch, 1, 2);
+  if (rc) return rc;
+  rc = svo_launch_stereo(ctx, dL, dR, ctx->stage_pitch, 1, cam);
+  if (rc) return rc;
+  int32_t cnt[2] = {0, 0};
+  const size_t K = ctx->max_kp;
+  SVO_HIP(ctx, hipMemcpyAsync(cnt, ctx->d_nkp, 8, hipMemcpyDeviceToHost, ctx->stream));
+  SVO_HIP(ctx, hipMemcpyAsync(kpL, ctx->d_kp, sizeof(svo_kp) * K, hipMemcpyDeviceToHost, ctx->stream));
+  SVO_HIP(ctx, hipMemcpyAsync(descL, ctx->d_desc, 32 * K, hipMemcpyDeviceToHost, ctx->stream));
+  SVO_HIP(ctx, hipMemcpyAsync(uR, ctx->d_uR, 4 * K, hipMemcpyDeviceToHost, ctx->stream));
+  SVO_HIP(ctx, hipMemcpyAsync(depth, ctx->d_depth, 4 * K, hipMemcpyDeviceToHost, ctx->stream));
+  if (kpR) SVO_HIP(ctx, hipMemcpyAsync(kpR, ctx->d_kp + K, sizeof(svo_kp) * K, hipMemcpyDeviceToHost, ctx->stream));
+  if (descR) SVO_HIP(ctx, hipMemcpyAsync(descR, ctx->d_desc + 32 * K, 32 * K, hipMemcpyDeviceToHost, ctx->stream));
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *nL = cnt[0];
+  if (nR) *nR = cnt[1];
+  return SVO_OK;
+}
+
+extern "C" int svo_stereo_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL,
+                                const uint8_t* grayR, int strideR, const svo_camera* cam,
+                                svo_kp* kpL, uint8_t* descL, int32_t* nL, float* uR, float* depth) {
+  return svo_stereo_frame_ex(ctx, grayL, strideL, grayR, strideR, cam, kpL, descL, nL, uR, depth,
+                             nullptr, nullptr, nullptr);
+}
+
+#define H2D(dst, src, bytes) SVO_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream))
+#define D2H(dst, src, bytes) SVO_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream))
+
+extern "C" int svo_disp2depth(svo_ctx* ctx, const float* disp, int count, float bf, float* depth) {
+  if (!ctx || !disp || !depth || count < 0) return SVO_E_INVALID;
+  if (count == 0) return SVO_OK;
+  hipSetDevice(ctx->device);
+  Bump b{ctx};
+  float* d_in = b.take<float>(count);
+  float* d_out = b.take<float>(count);
+  if (!b.ok()) return SVO_E_CAPACITY;
+  H2D(d_in, disp, 4 * (size_t)count);
+  int rc = svo_launch_disp2depth(ctx, d_in, count, bf, d_out);
+  if (rc) return rc;
+  D2H(depth, d_out, 4 * (size_t)count);
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVO_OK;
+}
+
+extern "C" int svo_unproject(svo_ctx* ctx, const float* uvz, int n, const svo_camera* cam,
+                             const float Rwc[9], const float twc[3], float* xyz) {
+  if (!ctx || !uvz || !cam || !Rwc || !twc || !xyz || n < 0) return SVO_E_INVALID;
+  if (n == 0) return SVO_OK;
+  hipSetDevice(ctx->device);
+  Bump b{ctx};
+  float* d_in = b.take<float>(3 * (size_t)n);
+  float* d_out = b.take<float>(3 * (size_t)n);
+  float* d_R = b.take<float>(9);
+  float* d_t = b.take<float>(3);
+  if (!b.ok()) return SVO_E_CAPACITY;
+  H2D(d_in, uvz, 12 * (size_t)n);
+  H2D(d_R, Rwc, 36);
+  H2D(d_t, twc, 12);
+  int rc = svo_launch_unproject(ctx, d_in, n, cam, d_R, d_t, d_out);
+  if (rc) return rc;
+  D2H(xyz, d_out, 12 * (size_t)n);
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVO_OK;
+}
+
+extern "C" int svo_descriptor_distance(svo_ctx* ctx, const uint8_t* a, const uint8_t* b, int count,
+                                       int32_t* dist) {
+  if (!ctx || !a || !b || !dist || count < 0) return SVO_E_INVALID;
+  if (count == 0) return SVO_OK;
+  hipSetDevice(ctx->device);
+  Bump bm{ctx};
+  uint8_t* da = bm.take<uint8_t>(32 * (size_t)count);
+  uint8_t* db = bm.take<uint8_t>(32 * (size_t)count);
+  int32_t* dd = bm.take<int32_t>(count);
+  if (!bm.ok()) return SVO_E_CAPACITY;
+  H2D(da, a, 32 * (size_t)count);
+  H2D(db, b, 32 * (size_t)count);
+  int rc = svo_launch_descriptor_distance(ctx, da, db, count, dd);
+  if (rc) return rc;
+  D2H(dist, dd, 4 * (size_t)count);
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVO_OK;
+}
+
+extern "C" int svo_hamming_argmin(svo_ctx* ctx, const uint8_t* q, int M, const uint8_t* t, int N,
+                                  const uint8_t* t_mask, int32_t* best_idx, int32_t* best,
+                                  int32_t* second) {
+  if (!ctx || M < 0 || N < 0 || (M > 0 && (!q || !best_idx || !best || !second)) || (N > 0 && !t))
+    return SVO_E_INVALID;
+  if (M == 0) return SVO_OK;
+  hipSetDevice(ctx->device);
+  Bump bm{ctx};
+  uint8_t* dq = bm.take<uint8_t>(32 * (size_t)M);
+  uint8_t* dt = bm.take<uint8_t>(32 * (size_t)std::max(N, 1));
+  uint8_t* dm = bm.take<uint8_t>(std::max(N, 1));
+  int32_t* di = bm.take<int32_t>(M);
+  int32_t* db = bm.take<int32_t>(M);
+  int32_t* ds = bm.take<int32_t>(M);
+  if (!bm.ok()) return SVO_E_CAPACITY;
+  H2D(dq, q, 32 * (size_t)M);
+  if (N > 0) H2D(dt, t, 32 * (size_t)N);
+  if (t_mask && N > 0) H2D(dm, t_mask, N);
+  int rc = svo_launch_hamming_argmin(ctx, dq, M, dt, N, t_mask ? dm : nullptr, di, db, ds);
+  if (rc) return rc;
+  D2H(best_idx, di, 4 * (size_t)M);
+  D2H(best, db, 4 * (size_t)M);
+  D2H(second, ds, 4 * (size_t)M);
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVO_OK;
+}
+
+extern "C" int svo_match_greedy(svo_ctx* ctx, const uint8_t* q, const uint8_t* q_skip, int M,
+                                const uint8_t* t, int N, uint8_t* assigned, int max_dist,
+                                float ratio, int32_t* best_idx, int32_t* best, int32_t* second,
+                                uint8_t* accepted) {
+  if (!ctx || M < 0 || N < 0 || (M > 0 && (!q || !best_idx || !best || !second || !accepted)) ||
+      (N > 0 && (!t || !assigned)))
+    return SVO_E_INVALID;
+  if (M == 0) return SVO_OK;
+  hipSetDevice(ctx->device);
+  Bump bm{ctx};
+  uint8_t* dq = bm.take<uint8_t>(32 * (size_t)M);
+  uint8_t* dsk = bm.take<uint8_t>(M);
+  uint8_t* dt = bm.take<uint8_t>(32 * (size_t)std::max(N, 1));
+  uint8_t* das = bm.take<uint8_t>(std::max(N, 1));
+  int32_t* di = bm.take<int32_t>(M);
+  int32_t* db = bm.take<int32_t>(M);
+  int32_t* ds = bm.take<int32_t>(M);
+  uint8_t* dacc = bm.take<uint8_t>(M);
+  if (!bm.ok()) return SVO_E_CAPACITY;
+  H2D(dq, q, 32 * (size_t)M);
+  if (q_skip) H2D(dsk, q_skip, M);
+  if (N > 0) { H2D(dt, t, 32 * (size_t)N); H2D(das, assigned, N); }
+  int rc = svo_launch_match_greedy(ctx, dq, q_skip ? dsk : nullptr, M, dt, N, das, max_dist, ratio,
+                                   di, db, ds, dacc);
+  if (rc) return rc;
+  D2H(best_idx, di, 4 * (size_t)M);
+  D2H(best, db, 4 * (size_t)M);
+  D2H(second, ds, 4 * (size_t)M);
+  D2H(accepted, dacc, M);
+  if (N > 0) D2H(assigned, das, N);
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVO_OK;
+}
+
+extern "C" int svo_bf_match(svo_ctx* ctx, const uint8_t* q, int M, const uint8_t* t, int N,
+                            int32_t* train_idx, int32_t* dist, uint8_t* keep) {
+  if (!ctx || M < 0 || N < 0 || (M > 0 && (!q || !train_idx || !dist || !keep)) || (N > 0 && !t))
+    return SVO_E_INVALID;
+  if (M == 0) return SVO_OK;
+  hipSetDevice(ctx->device);
+  Bump bm{ctx};
+  uint8_t* dq = bm.take<uint8_t>(32 * (size_t)M);
+  uint8_t* dt = bm.take<uint8_t>(32 * (size_t)std::max(N, 1));
+  int32_t* di = bm.take<int32_t>(M);
+  int32_t* dd = bm.take<int32_t>(M);
+  uint8_t* dk = bm.take<uint8_t>(M);
+  if (!bm.ok()) return SVO_E_CAPACITY;
+  H2D(dq, q, 32 * (size_t)M);
+  if (N > 0) H2D(dt, t, 32 * (size_t)N);
+  int rc = svo_launch_bf_match(ctx, dq, M, dt, N, di, dd, dk);
+  if (rc) return rc;
+  D2H(train_idx, di, 4 * (size_t)M);
+  D2H(dist, dd, 4 * (size_t)M);
+  D2H(keep, dk, M);
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVO_OK;
+}
+
+extern "C" int svo_pose_opt(svo_ctx* ctx, const double* Xw, const double* obs, int n,
+                            const double K[4], double T_cw[16], svo_lm_stats* stats) {
+  if (!ctx || n < 0 || (n > 0 && (!Xw || !obs)) || !K || !T_cw) return SVO_E_INVALID;
+  hipSetDevice(ctx->device);
+  Bump bm{ctx};
+  double* dX = bm.take<double>(3 * (size_t)std::max(n, 1));
+  double* dO = bm.take<double>(2 * (size_t)std::max(n, 1));
+  double* dK = bm.take<double>(4);
+  double* dT = bm.take<double>(16);
+  svo_lm_stats* dS = bm.take<svo_lm_stats>(1);
+  if (!bm.ok()) return SVO_E_CAPACITY;
+  if (n > 0) { H2D(dX, Xw, 24 * (size_t)n); H2D(dO, obs, 16 * (size_t)n); }
+  H2D(dK, K, 32);
+  H2D(dT, T_cw, 128);
+  int rc = svo_launch_pose_opt(ctx, dX, dO, n, dK, dT, dS);
+  if (rc) return rc;
+  D2H(T_cw, dT, 128);
+  if (stats) D2H(stats, dS, sizeof(svo_lm_stats));
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVO_OK;
+}
+
+extern "C" int svo_pnp_ransac(svo_ctx* ctx, const double* Xw, const double* obs, int n,
+                              const double K[4], const double T_prior_cw[16], uint64_t seed,
+                              double T_cw[16], uint8_t* inlier_mask, svo_pnp_stats* stats) {
+  if (!ctx || n < 0 || (n > 0 && (!Xw || !obs)) || !K || !T_prior_cw || !T_cw) return SVO_E_INVALID;
+  hipSetDevice(ctx->device);
+  Bump bm{ctx};
+  double* dX = bm.take<double>(3 * (size_t)std::max(n, 1));
+  double* dO = bm.take<double>(2 * (size_t)std::max(n, 1));
+  double* dK = bm.take<double>(4);
+  double* dTp = bm.take<double>(16);
+  double* dT = bm.take<double>(16);
+  uint8_t* dM = bm.take<uint8_t>(std::max(n, 1));
+  svo_pnp_stats* dS = bm.take<svo_pnp_stats>(1);
+  if (!bm.ok()) return SVO_E_CAPACITY;
+  if (n > 0) { H2D(dX, Xw, 24 * (size_t)n); H2D(dO, obs, 16 * (size_t)n); }
+  H2D(dK, K, 32);
+  H2D(dTp, T_prior_cw, 128);
+  int rc = svo_launch_pnp(ctx, dX, dO, n, dK, dTp, seed, dT, dM, dS);
+  if (rc) return rc;
+  D2H(T_cw, dT, 128);
+  if (inlier_mask && n > 0) D2H(inlier_mask, dM, n);
+  if (stats) D2H(stats, dS, sizeof(svo_pnp_stats));
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVO_OK;
+}
+
+// ---- throughput mode ---------------------------------------------------------------------
+extern "C" int svo_frontend_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR,
+                                      int stride, int B, const svo_camera* cam, svo_kp* d_kpL,
+                                      uint8_t* d_descL, int32_t* d_nL, float* d_uR,
+                                      float* d_depth) {
+  if (!ctx || !d_grayL || !d_grayR || !cam || B < 1 || stride < ctx->g.W) return SVO_E_INVALID;
+  if (B > ctx->max_batch) return SVO_E_CAPACITY;
+  hipSetDevice(ctx->device);
+  int rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, B, 2 * B);
+  if (rc) return rc;
+  rc = svo_launch_stereo(ctx, d_grayL, d_grayR, stride, B, cam);
+  if (rc) return rc;
+  const size_t K = ctx->max_kp;
+#define D2D(dst, src, bytes) if (dst) SVO_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream))
+  D2D(d_kpL, ctx->d_kp, sizeof(svo_kp) * K * B);
+  D2D(d_descL, ctx->d_desc, 32 * K * B);
+  D2D(d_nL, ctx->d_nkp, 4 * (size_t)B);
+  D2D(d_uR, ctx->d_uR, 4 * K * B);
+  D2D(d_depth, ctx->d_depth, 4 * K * B);
+#undef D2D
+  return SVO_OK;
+}
+
+// ---- profiling API -------------------------------------------------------------------------
+extern "C" int svo_profile_enable(svo_ctx* ctx, int on) {
+  if (!ctx) return SVO_E_INVALID;
+  if (!on && ctx->profiling) prof_resolve(ctx);
+  ctx->profiling = on != 0;
+  return SVO_OK;
+}
+extern "C" int svo_profile_reset(svo_ctx* ctx) {
+  if (!ctx) return SVO_E_INVALID;
+  if (ctx->prof_impl) prof_resolve(ctx);
+  ctx->prof.clear();
+  return SVO_OK;
+}
+extern "C" int svo_profile_get(svo_ctx* ctx, int index, char* name, int name_cap, double* total_ms,
+                               int64_t* launches) {
+  if (!ctx || index < 0) return SVO_E_INVALID;
+  if (ctx->prof_impl) prof_resolve(ctx);
+  if (index >= (int)ctx->prof.size()) return SVO_E_INVALID;
+  const SvoProfileEntry& e = ctx->prof[index];
+  if (name && name_cap > 0) {
+    strncpy(name, e.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (total_ms) *total_ms = e.total_ms;
+  if (launches) *launches = e.launches;
+  return SVO_OK;
+}

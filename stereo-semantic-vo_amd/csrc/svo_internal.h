@@ -1,0 +1,140 @@
+// svo_internal.h - shared declarations of the HIP implementation behind include/svo.h.
+// gfx950 (MI355X) only.  Everything here is compiled with -ffp-contract=off: the
+// float/double stages must round once per operation to stay bit-identical with the
+// parity oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/svo.h"
+
+#define SVO_NLEVELS 8
+#define SVO_EDGE 31
+#define SVO_FAST_THR 20
+#define SVO_HALF_PATCH 15
+#define SVO_CAP1 2048     // cap on Harris candidates per (image, level)
+#define SVO_QMAX 128      // >= largest per-level quota (109 for 500 features)
+#define SVO_DESC_BYTES 32
+
+// FAST tile: 120 x 14 output pixels per 256-thread workgroup (see svo_orb.hip).
+#define FAST_TW 120
+#define FAST_TH 14
+
+struct SvoGeom {
+  int W, H;
+  int w[SVO_NLEVELS], h[SVO_NLEVELS];
+  int pitch[SVO_NLEVELS];          // bytes per row of the stored level (levels 1..7)
+  int64_t loff[SVO_NLEVELS];       // byte offset of level l inside one image's pyramid slot
+  int64_t pyr_bytes;               // bytes of one image's pyramid slot (levels 1..7)
+  float scale[SVO_NLEVELS];
+  int quota[SVO_NLEVELS];
+  int cap[SVO_NLEVELS];            // raw-corner capacity per level
+  int64_t coff[SVO_NLEVELS];       // entry offset of level l in one image's raw-corner slot
+  int64_t corner_entries;          // entries of one image's raw-corner slot
+  int tiles_x[SVO_NLEVELS], tiles_y[SVO_NLEVELS];
+  int tile_base[SVO_NLEVELS + 1];  // prefix of tiles over levels (FAST kernel grid)
+  // resize tables: offsets (in elements) into the device table arrays
+  int xtab_off[SVO_NLEVELS], ytab_off[SVO_NLEVELS];
+};
+
+// Entry of the level-local selection (output of k_select).
+struct SvoSel {
+  int64_t R;     // exact Harris measure 25(ab-c^2)-(a+b)^2
+  int16_t x, y;  // level coordinates
+  int32_t pad;
+};
+
+struct SvoProfileEntry {
+  std::string name;
+  double total_ms = 0;
+  int64_t launches = 0;
+};
+
+struct svo_ctx {
+  int device = 0;
+  int max_kp = 500, max_batch = 1, max_images = 2;
+  SvoGeom g;
+  hipStream_t stream = nullptr;
+  std::string last_error;
+
+  // device tables
+  SvoGeom* d_geom = nullptr;
+  int32_t* d_xofs = nullptr;  // per level: w[l] entries
+  int32_t* d_xalpha = nullptr;  // packed (a0 | a1<<16)
+  int32_t* d_yofs = nullptr;
+  int32_t* d_ybeta = nullptr;
+
+  // per-batch working set (HBM resident, sized for max_images)
+  uint8_t* d_stage = nullptr;      // host-path image staging: max_images x H x stage_pitch
+  int stage_pitch = 0;
+  uint8_t* d_pyr = nullptr;        // max_images x pyr_bytes
+  uint32_t* d_corners = nullptr;   // max_images x corner_entries, packed x|y<<12|score<<24
+  int32_t* d_counters = nullptr;   // max_images x 8 raw-corner counts, then x 8*256 hist
+  int32_t* d_hist = nullptr;
+  SvoSel* d_sel = nullptr;         // max_images x 8 x SVO_QMAX
+  int32_t* d_selcnt = nullptr;     // max_images x 8
+  svo_kp* d_kp = nullptr;          // max_images x max_kp
+  uint8_t* d_desc = nullptr;       // max_images x max_kp x 32
+  int32_t* d_nkp = nullptr;        // max_images
+  float* d_uR = nullptr;           // max_batch x max_kp
+  float* d_depth = nullptr;
+  int32_t* d_sad = nullptr;        // max_batch x max_kp best SAD (or -1)
+  // generic scratch for the small host-path ops
+  uint8_t* d_scratch = nullptr;
+  size_t scratch_bytes = 0;
+  uint8_t* h_pinned = nullptr;
+  size_t pinned_bytes = 0;
+
+  // tracker state (svo_track.hip)
+  void* d_track = nullptr;
+  svo_camera cam{};
+  int track_frame = 0;
+
+  bool profiling = false;
+  std::vector<SvoProfileEntry> prof;
+  void* prof_impl = nullptr;  // SvoProfState (svo_api.hip)
+};
+
+#define SVO_HIP(ctx, expr)                                                        \
+  do {                                                                            \
+    hipError_t _e = (expr);                                                       \
+    if (_e != hipSuccess) {                                                       \
+      (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);      \
+      return SVO_E_HIP;                                                           \
+    }                                                                             \
+  } while (0)
+
+// ---- stage launchers (each enqueues on ctx->stream, no sync) -------------------
+// Images of a batch: index i < B is left image i, i >= B is right image i-B (nimg = B or 2B).
+int svo_launch_orb(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR, int stride,
+                   int B, int nimg);
+int svo_launch_stereo(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR, int stride,
+                      int B, const svo_camera* cam);
+int svo_launch_descriptor_distance(svo_ctx* ctx, const uint8_t* a, const uint8_t* b, int count,
+                                   int32_t* dist);
+int svo_launch_hamming_argmin(svo_ctx* ctx, const uint8_t* q, int M, const uint8_t* t, int N,
+                              const uint8_t* mask, int32_t* idx, int32_t* best, int32_t* second);
+int svo_launch_match_greedy(svo_ctx* ctx, const uint8_t* q, const uint8_t* q_skip, int M,
+                            const uint8_t* t, int N, uint8_t* assigned, int max_dist, float ratio,
+                            int32_t* idx, int32_t* best, int32_t* second, uint8_t* accepted);
+int svo_launch_bf_match(svo_ctx* ctx, const uint8_t* q, int M, const uint8_t* t, int N,
+                        int32_t* train_idx, int32_t* dist, uint8_t* keep);
+int svo_launch_pose_opt(svo_ctx* ctx, const double* Xw, const double* obs, int n, const double* K,
+                        double* T, svo_lm_stats* stats);
+int svo_launch_pnp(svo_ctx* ctx, const double* Xw, const double* obs, int n, const double* K,
+                   const double* Tprior, uint64_t seed, double* T, uint8_t* mask,
+                   svo_pnp_stats* stats);
+int svo_launch_disp2depth(svo_ctx* ctx, const float* disp, int count, float bf, float* depth);
+int svo_launch_unproject(svo_ctx* ctx, const float* uvz, int n, const svo_camera* cam,
+                         const float* Rwc, const float* twc, float* xyz);
+
+// profiling helper: time `fn` with HIP events on ctx->stream when profiling is on
+struct SvoTimer {
+  svo_ctx* ctx;
+  const char* name;
+  SvoTimer(svo_ctx* c, const char* n);
+  ~SvoTimer();
+};

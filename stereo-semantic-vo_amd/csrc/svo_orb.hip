@@ -1,0 +1,539 @@
+// svo_orb.hip - ORB extraction for gfx950: pyramid, FAST-9/16 + NMS, Harris top-k,
+// intensity-centroid orientation, on-demand 7x7 Gaussian + rBRIEF.
+//
+// Replaces frame::featuredetect (reference src/frame.cc:75-79), i.e. the
+// cv::ORB::create()->detectAndCompute call with default parameters; stage
+// semantics are the ones listed in SURVEY.md section 8 a-notes and DESIGN.md.
+//
+// Data layout in HBM (per image slot): level 0 is read in place from the caller's
+// gray image; levels 1..7 live in one pyramid slot with 64-byte-aligned row
+// pitches; FAST corners are appended as packed 32-bit words x | y<<12 | score<<24
+// into a per-(image, level) segment sized for the NMS density bound (1/4 of the
+// pixels), so no overflow path exists; a 256-bin score histogram per
+// (image, level) gives the retainBest threshold without sorting.
+#include "svo_internal.h"
+#include "../../include/svo_brief_pattern.h"
+
+__constant__ int8_t c_pattern[SVO_BRIEF_NTESTS][4] = SVO_BRIEF_PATTERN_INIT;
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+struct ImgSrc {
+  const uint8_t* L;
+  const uint8_t* R;
+  int stride;
+  int B;
+  const uint8_t* pyr;
+};
+
+__device__ __forceinline__ const uint8_t* level_ptr(const SvoGeom& g, const ImgSrc& s, int img,
+                                                     int l, int* pitch) {
+  if (l == 0) {
+    *pitch = s.stride;
+    return img < s.B ? s.L + (size_t)img * s.stride * g.H
+                     : s.R + (size_t)(img - s.B) * s.stride * g.H;
+  }
+  *pitch = g.pitch[l];
+  return s.pyr + (size_t)img * g.pyr_bytes + g.loff[l];
+}
+
+// ---------------------------------------------------------------------------------
+// Pyramid: level l from level l-1, cv::resize INTER_LINEAR fixed-point semantics
+// (11-bit coefficients; vertical pass ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2)>>2).
+// One thread = 4 output pixels = one dword store; rows are coalesced.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pyr_level(SvoGeom g, ImgSrc s, int l, uint8_t* pyr,
+                                                   const int32_t* __restrict__ xofs,
+                                                   const int32_t* __restrict__ xalpha,
+                                                   const int32_t* __restrict__ yofs,
+                                                   const int32_t* __restrict__ ybeta) {
+  const int img = blockIdx.z;
+  const int dy = blockIdx.y * 4 + threadIdx.y;
+  const int dx4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+  const int dw = g.w[l], dh = g.h[l];
+  if (dy >= dh || dx4 >= dw) return;
+  int sp;
+  const uint8_t* src = level_ptr(g, s, img, l - 1, &sp);
+  const int sw = g.w[l - 1], sh = g.h[l - 1];
+  const int sy0 = yofs[g.ytab_off[l] + dy];
+  const int sy1 = min(sy0 + 1, sh - 1);
+  const int bb = ybeta[g.ytab_off[l] + dy];
+  const int b0 = (int)(int16_t)(bb & 0xffff), b1 = bb >> 16;
+  const uint8_t* r0 = src + (size_t)sy0 * sp;
+  const uint8_t* r1 = src + (size_t)sy1 * sp;
+  uint32_t out = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int dx = dx4 + k;
+    if (dx < dw) {
+      const int sx0 = xofs[g.xtab_off[l] + dx];
+      const int sx1 = min(sx0 + 1, sw - 1);
+      const int aa = xalpha[g.xtab_off[l] + dx];
+      const int a0 = (int)(int16_t)(aa & 0xffff), a1 = aa >> 16;
+      const int S0 = r0[sx0] * a0 + r0[sx1] * a1;
+      const int S1 = r1[sx0] * a0 + r1[sx1] * a1;
+      int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+      v = min(max(v, 0), 255);
+      out |= (uint32_t)v << (8 * k);
+    }
+  }
+  uint8_t* dst = pyr + (size_t)img * g.pyr_bytes + g.loff[l] + (size_t)dy * g.pitch[l];
+  *reinterpret_cast<uint32_t*>(dst + dx4) = out;
+}
+
+// ---------------------------------------------------------------------------------
+// FAST-9/16 (threshold 20) + corner score + strict 3x3 NMS + 31-px border filter.
+// One 256-thread workgroup owns a 120 x 14 output tile.  It stages the 136 x 22
+// pixel window in LDS with coalesced dword row loads, scores the 128 x 16 window
+// (tile + 1 ring for NMS; 8 consecutive pixels per thread from 7 x 16-byte LDS row
+// reads), suppresses non-maxima in LDS and appends survivors to the level list.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int has9(uint32_t m) {  // 9 contiguous set bits in a circular 16-bit mask
+  uint32_t m2 = m | (m << 16);
+  uint32_t x = m2 & (m2 >> 1);
+  x &= x >> 2;
+  x &= x >> 4;
+  x &= m2 >> 8;
+  return (x & 0xffffu) != 0;
+}
+
+__device__ __forceinline__ int fast_score16(const int d[16]) {
+  int a1[16], b1[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    a1[i] = min(d[i], d[(i + 1) & 15]);
+    b1[i] = max(d[i], d[(i + 1) & 15]);
+  }
+  int a2[16], b2[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    a2[i] = min(a1[i], a1[(i + 2) & 15]);
+    b2[i] = max(b1[i], b1[(i + 2) & 15]);
+  }
+  int A = -256, Bm = 256;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int a = min(min(a2[i], a2[(i + 4) & 15]), d[(i + 8) & 15]);
+    int b = max(max(b2[i], b2[(i + 4) & 15]), d[(i + 8) & 15]);
+    A = max(A, a);
+    Bm = min(Bm, b);
+  }
+  return max(A, -Bm) - 1;
+}
+
+#define PXW 34  // dwords per staged pixel row (136 bytes)
+#define SCW 128 // bytes per score row
+
+__global__ __launch_bounds__(256) void k_fast(SvoGeom g, ImgSrc s, uint32_t* corners,
+                                              int32_t* counters, int32_t* hist) {
+  __shared__ uint32_t px[22 * PXW];
+  __shared__ uint32_t sc[16 * (SCW / 4)];
+  __shared__ int lhist[256];
+  __shared__ uint32_t lcorn[512];
+  __shared__ int lcount, lbase;
+
+  const int tid = threadIdx.x;
+  const int img = blockIdx.y;
+  int tile = blockIdx.x;
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < SVO_NLEVELS; ++k)
+    if (tile >= g.tile_base[k]) l = k;
+  tile -= g.tile_base[l];
+  const int ty = tile / g.tiles_x[l], tx = tile - ty * g.tiles_x[l];
+  const int x0 = 28 + tx * FAST_TW, y0 = SVO_EDGE + ty * FAST_TH;
+  const int w = g.w[l], h = g.h[l];
+  int pitch;
+  const uint8_t* img_p = level_ptr(g, s, img, l, &pitch);
+
+  lhist[tid] = 0;
+  if (tid == 0) lcount = 0;
+
+  // stage pixels: rows y0-4 .. y0+17, columns x0-8 .. x0+127
+  const bool aligned = ((pitch & 3) == 0) && ((reinterpret_cast<uintptr_t>(img_p) & 3) == 0);
+  for (int i = tid; i < 22 * PXW; i += 256) {
+    const int r = i / PXW, c = i - r * PXW;
+    const int gy = min(max(y0 - 4 + r, 0), h - 1);
+    const int gx = x0 - 8 + 4 * c;
+    const uint8_t* row = img_p + (size_t)gy * pitch;
+    uint32_t v;
+    if (aligned && gx + 3 < w) {
+      v = *reinterpret_cast<const uint32_t*>(row + gx);
+    } else {
+      v = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v |= (uint32_t)row[min(gx + k, w - 1)] << (8 * k);
+    }
+    px[i] = v;
+  }
+  __syncthreads();
+
+  // score 8 consecutive pixels: score row r <-> y = y0-1+r, columns x0-4+8c+k
+  {
+    const int r = tid >> 4, c = tid & 15;
+    uint32_t rw[7][4];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const uint2 lo = *reinterpret_cast<const uint2*>(&px[(r + j) * PXW + 2 * c]);
+      const uint2 hi = *reinterpret_cast<const uint2*>(&px[(r + j) * PXW + 2 * c + 2]);
+      rw[j][0] = lo.x; rw[j][1] = lo.y; rw[j][2] = hi.x; rw[j][3] = hi.y;
+    }
+#define PIX(j, cc) (int)((rw[(j)][(cc) >> 2] >> (8 * ((cc) & 3))) & 0xffu)
+    uint32_t out[2] = {0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int cc = 4 + k;  // byte column of the centre inside the 16-byte window
+      const int v = PIX(3, cc);
+      int d[16];
+      d[0] = v - PIX(6, cc);      d[1] = v - PIX(6, cc + 1);  d[2] = v - PIX(5, cc + 2);
+      d[3] = v - PIX(4, cc + 3);  d[4] = v - PIX(3, cc + 3);  d[5] = v - PIX(2, cc + 3);
+      d[6] = v - PIX(1, cc + 2);  d[7] = v - PIX(0, cc + 1);  d[8] = v - PIX(0, cc);
+      d[9] = v - PIX(0, cc - 1);  d[10] = v - PIX(1, cc - 2); d[11] = v - PIX(2, cc - 3);
+      d[12] = v - PIX(3, cc - 3); d[13] = v - PIX(4, cc - 3); d[14] = v - PIX(5, cc - 2);
+      d[15] = v - PIX(6, cc - 1);
+      uint32_t dark = 0, bright = 0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        dark |= (uint32_t)(d[i] > SVO_FAST_THR) << i;
+        bright |= (uint32_t)(d[i] < -SVO_FAST_THR) << i;
+      }
+      int score = 0;
+      if (has9(dark) || has9(bright)) score = fast_score16(d);
+      out[k >> 2] |= (uint32_t)score << (8 * (k & 3));
+    }
+#undef PIX
+    *reinterpret_cast<uint2*>(&sc[r * (SCW / 4) + 2 * c]) = make_uint2(out[0], out[1]);
+  }
+  __syncthreads();
+
+  // NMS + border filter over the 120 x 14 tile
+  const uint8_t* scb = reinterpret_cast<const uint8_t*>(sc);
+  for (int i = tid; i < FAST_TW * FAST_TH; i += 256) {
+    const int oy = i / FAST_TW, ox = i - oy * FAST_TW;
+    const int x = x0 + ox, y = y0 + oy;
+    const int sr = oy + 1, scol = ox + 4;
+    const int sv = scb[sr * SCW + scol];
+    if (sv == 0) continue;
+    if (x < SVO_EDGE || x >= w - SVO_EDGE || y >= h - SVO_EDGE) continue;
+    bool keep = true;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx)
+        if ((dx | dy) != 0) keep = keep && (scb[(sr + dy) * SCW + scol + dx] < sv);
+    if (keep) {
+      const int p = atomicAdd(&lcount, 1);
+      lcorn[p] = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)sv << 24);
+      atomicAdd(&lhist[sv], 1);
+    }
+  }
+  __syncthreads();
+  const int cnt = lcount;
+  if (cnt == 0) return;
+  if (tid == 0) lbase = atomicAdd(&counters[img * SVO_NLEVELS + l], cnt);
+  __syncthreads();
+  uint32_t* dst = corners + (size_t)img * g.corner_entries + g.coff[l] + lbase;
+  for (int i = tid; i < cnt; i += 256) dst[i] = lcorn[i];
+  const int hv = lhist[tid];
+  if (hv) atomicAdd(&hist[(img * SVO_NLEVELS + l) * 256 + tid], hv);
+}
+
+// ---------------------------------------------------------------------------------
+// Per (image, level): retainBest(2*quota) by FAST score with ties kept (threshold
+// from the histogram) -> exact Harris measure -> rank by (R desc, raster asc) ->
+// keep `quota`.  One workgroup; candidates live in LDS.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t harris_at(const uint8_t* img, int pitch, int x, int y) {
+  int64_t a = 0, b = 0, c = 0;
+  // 9 x 9 neighbourhood; gradients of the inner 7 x 7
+  int row[3][9];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) row[j + 1][i] = img[(size_t)(y - 4 + j) * pitch + x - 4 + i];
+#pragma unroll 1
+  for (int dy = -3; dy <= 3; ++dy) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      row[0][i] = row[1][i];
+      row[1][i] = row[2][i];
+      row[2][i] = img[(size_t)(y + dy + 1) * pitch + x - 4 + i];
+    }
+    int sa = 0, sb = 0, scv = 0;
+#pragma unroll
+    for (int i = 1; i <= 7; ++i) {
+      const int Ix = (row[1][i + 1] - row[1][i - 1]) * 2 + (row[0][i + 1] - row[0][i - 1]) +
+                     (row[2][i + 1] - row[2][i - 1]);
+      const int Iy = (row[2][i] - row[0][i]) * 2 + (row[2][i - 1] - row[0][i - 1]) +
+                     (row[2][i + 1] - row[0][i + 1]);
+      sa += Ix * Ix; sb += Iy * Iy; scv += Ix * Iy;
+    }
+    a += sa; b += sb; c += scv;
+  }
+  return 25 * (a * b - c * c) - (a + b) * (a + b);
+}
+
+__global__ __launch_bounds__(256) void k_select(SvoGeom g, ImgSrc s, const uint32_t* corners,
+                                                const int32_t* counters, const int32_t* hist,
+                                                SvoSel* sel, int32_t* selcnt) {
+  __shared__ int64_t cR[SVO_CAP1];
+  __shared__ int32_t ckey[SVO_CAP1];
+  __shared__ uint32_t cxy[SVO_CAP1];
+  __shared__ int cum[257];
+  __shared__ int sT, nc;
+  const int tid = threadIdx.x;
+  const int l = blockIdx.x, img = blockIdx.y;
+  const int n = counters[img * SVO_NLEVELS + l];
+  const int quota = g.quota[l];
+  const int w = g.w[l];
+  if (n == 0 || quota == 0) {
+    if (tid == 0) selcnt[img * SVO_NLEVELS + l] = 0;
+    return;
+  }
+  cum[tid] = hist[(img * SVO_NLEVELS + l) * 256 + tid];
+  if (tid == 0) { cum[256] = 0; nc = 0; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int sidx = 255; sidx >= 0; --sidx) cum[sidx] += cum[sidx + 1];  // suffix counts
+    int T = 0;
+    const int target = 2 * quota;
+    if (n > target) {
+      for (int sidx = 255; sidx >= 0; --sidx)
+        if (cum[sidx] >= target) { T = sidx; break; }
+    }
+    while (cum[T] > SVO_CAP1) ++T;
+    sT = T;
+  }
+  __syncthreads();
+  const int T = sT;
+  const uint32_t* src = corners + (size_t)img * g.corner_entries + g.coff[l];
+  for (int i = tid; i < n; i += 256) {
+    const uint32_t e = src[i];
+    if ((int)(e >> 24) >= T) {
+      const int p = atomicAdd(&nc, 1);
+      cxy[p] = e;
+    }
+  }
+  __syncthreads();
+  const int ncand = nc;
+  int pitch;
+  const uint8_t* img_p = level_ptr(g, s, img, l, &pitch);
+  for (int c = tid; c < ncand; c += 256) {
+    const uint32_t e = cxy[c];
+    const int x = e & 0xfff, y = (e >> 12) & 0xfff;
+    cR[c] = harris_at(img_p, pitch, x, y);
+    ckey[c] = y * w + x;
+  }
+  __syncthreads();
+  SvoSel* out = sel + (size_t)(img * SVO_NLEVELS + l) * SVO_QMAX;
+  for (int c = tid; c < ncand; c += 256) {
+    const int64_t R = cR[c];
+    const int key = ckey[c];
+    int rank = 0;
+    for (int j = 0; j < ncand; ++j) {
+      const int64_t Rj = cR[j];
+      rank += (Rj > R) || (Rj == R && ckey[j] < key);
+    }
+    if (rank < quota) {
+      const uint32_t e = cxy[c];
+      SvoSel v;
+      v.R = R; v.x = (int16_t)(e & 0xfff); v.y = (int16_t)((e >> 12) & 0xfff); v.pad = 0;
+      out[rank] = v;
+    }
+  }
+  if (tid == 0) selcnt[img * SVO_NLEVELS + l] = min(ncand, quota);
+}
+
+// ---------------------------------------------------------------------------------
+// Per keypoint (one wave): orientation + descriptor.  The 37 x 37 source window is
+// staged in LDS once; the 7 x 7 Gaussian (fixed-point {18,34,49,55,49,34,18},
+// (sum+2^15)>>16) is evaluated only on the 31 x 31 patch the rotated pattern can
+// reach, so the blurred pyramid is never written to HBM.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+  const float p1 = 57.283627f, p3 = -18.667446f, p5 = 8.9140005f, p7 = -2.5397246f;
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + 2.220446e-16f);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + 2.220446e-16f);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+__device__ __forceinline__ void det_sincos(float angle_rad, float* s, float* c) {
+  const double TWO_OVER_PI = 0.63661977236758134308;
+  const double PIO2_HI = 1.57079632679489655800e+00;
+  const double PIO2_LO = 6.12323399573676603587e-17;
+  const double x = (double)angle_rad;
+  const double kq = floor(x * TWO_OVER_PI + 0.5);
+  const double r = (x - kq * PIO2_HI) - kq * PIO2_LO;
+  const double r2 = r * r;
+  double ps = -1.0 / 1307674368000.0;
+  ps = ps * r2 + 1.0 / 6227020800.0;
+  ps = ps * r2 - 1.0 / 39916800.0;
+  ps = ps * r2 + 1.0 / 362880.0;
+  ps = ps * r2 - 1.0 / 5040.0;
+  ps = ps * r2 + 1.0 / 120.0;
+  ps = ps * r2 - 1.0 / 6.0;
+  const double sr = r + r * (r2 * ps);
+  double pc = 1.0 / 20922789888000.0;
+  pc = pc * r2 - 1.0 / 87178291200.0;
+  pc = pc * r2 + 1.0 / 479001600.0;
+  pc = pc * r2 - 1.0 / 3628800.0;
+  pc = pc * r2 + 1.0 / 40320.0;
+  pc = pc * r2 - 1.0 / 720.0;
+  pc = pc * r2 + 1.0 / 24.0;
+  pc = pc * r2 - 0.5;
+  const double cr = 1.0 + r2 * pc;
+  const int q = (int)((long long)kq & 3);
+  double sv, cv;
+  switch (q) {
+    case 0: sv = sr; cv = cr; break;
+    case 1: sv = cr; cv = -sr; break;
+    case 2: sv = -sr; cv = -cr; break;
+    default: sv = -cr; cv = sr; break;
+  }
+  *s = (float)sv;
+  *c = (float)cv;
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+#define PW 37      // staged window side (31 + 2*3)
+#define PWP 40     // padded row, bytes
+
+__global__ __launch_bounds__(64) void k_describe(SvoGeom g, ImgSrc s, const SvoSel* sel,
+                                                 const int32_t* selcnt, svo_kp* kp, uint8_t* desc,
+                                                 int32_t* nkp, int max_kp) {
+  __shared__ uint8_t patch[PW * PWP];
+  __shared__ uint16_t hb[PW * 32];
+  __shared__ uint8_t bl[31 * 32];
+  const int lane = threadIdx.x;
+  const int slot = blockIdx.x, img = blockIdx.y;
+  // slot -> (level, rank)
+  int l = -1, rank = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < SVO_NLEVELS; ++k) {
+    const int c = selcnt[img * SVO_NLEVELS + k];
+    if (l < 0 && slot < total + c) { l = k; rank = slot - total; }
+    total += c;
+  }
+  total = min(total, max_kp);
+  if (slot == 0 && lane == 0) nkp[img] = total;
+  if (l < 0 || slot >= total) return;
+  const SvoSel sv = sel[(size_t)(img * SVO_NLEVELS + l) * SVO_QMAX + rank];
+  const int x = sv.x, y = sv.y;
+  int pitch;
+  const uint8_t* img_p = level_ptr(g, s, img, l, &pitch);
+  for (int i = lane; i < PW * PW; i += 64) {
+    const int r = i / PW, c = i - r * PW;
+    patch[r * PWP + c] = img_p[(size_t)(y - 18 + r) * pitch + x - 18 + c];
+  }
+  __syncthreads();
+  // intensity centroid over the radius-15 disc
+  int m10 = 0, m01 = 0;
+  for (int i = lane; i < 31 * 31; i += 64) {
+    const int r = i / 31, c = i - r * 31;
+    const int v = r - 15, u = c - 15;
+    if (abs(u) <= c_umax[abs(v)]) {
+      const int I = patch[(r + 3) * PWP + c + 3];
+      m10 += u * I;
+      m01 += v * I;
+    }
+  }
+  m10 = wave_sum(m10);
+  m01 = wave_sum(m01);
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+  // horizontal pass: 37 rows x 31 columns
+  for (int i = lane; i < PW * 31; i += 64) {
+    const int r = i / 31, c = i - r * 31;
+    const uint8_t* p = &patch[r * PWP + c];
+    const int sum = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
+    hb[r * 32 + c] = (uint16_t)sum;
+  }
+  __syncthreads();
+  for (int i = lane; i < 31 * 31; i += 64) {
+    const int r = i / 31, c = i - r * 31;
+    const uint16_t* p = &hb[r * 32 + c];
+    const int sum = 18 * (p[0] + p[6 * 32]) + 34 * (p[32] + p[5 * 32]) + 49 * (p[2 * 32] + p[4 * 32]) +
+                    55 * p[3 * 32];
+    bl[r * 32 + c] = (uint8_t)min((sum + 32768) >> 16, 255);
+  }
+  __syncthreads();
+  float sn, cs;
+  det_sincos(angle * 0.017453292f, &sn, &cs);
+  const size_t oidx = (size_t)img * max_kp + slot;
+  uint64_t* dout = reinterpret_cast<uint64_t*>(desc + oidx * SVO_DESC_BYTES);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = t * 64 + lane;
+    const float px0 = (float)c_pattern[i][0], py0 = (float)c_pattern[i][1];
+    const float px1 = (float)c_pattern[i][2], py1 = (float)c_pattern[i][3];
+    const float rx0 = px0 * cs - py0 * sn, ry0 = px0 * sn + py0 * cs;
+    const float rx1 = px1 * cs - py1 * sn, ry1 = px1 * sn + py1 * cs;
+    const int v0 = bl[(15 + __float2int_rn(ry0)) * 32 + 15 + __float2int_rn(rx0)];
+    const int v1 = bl[(15 + __float2int_rn(ry1)) * 32 + 15 + __float2int_rn(rx1)];
+    const uint64_t m = __ballot(v0 < v1);
+    if (lane == 0) dout[t] = m;
+  }
+  if (lane == 0) {
+    svo_kp k;
+    const float sc = g.scale[l];
+    k.x = (float)x * sc;
+    k.y = (float)y * sc;
+    k.size = 31.0f * sc;
+    k.angle = angle;
+    const double kscale = 1.0 / (4.0 * 7.0 * 255.0);
+    k.response = (float)((double)sv.R * (kscale * kscale * kscale * kscale / 25.0));
+    k.octave = l;
+    k.class_id = -1;
+    kp[oidx] = k;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+int svo_launch_orb(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR, int stride,
+                   int B, int nimg) {
+  const SvoGeom& g = ctx->g;
+  if (nimg > ctx->max_images || B < 1) return SVO_E_CAPACITY;
+  ImgSrc s{d_grayL, d_grayR, stride, B, ctx->d_pyr};
+  hipStream_t st = ctx->stream;
+  SVO_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(int32_t) * (size_t)nimg * SVO_NLEVELS, st));
+  SVO_HIP(ctx, hipMemsetAsync(ctx->d_hist, 0, sizeof(int32_t) * (size_t)nimg * SVO_NLEVELS * 256, st));
+  {
+    SvoTimer t(ctx, "k_pyr_level");
+    for (int l = 1; l < SVO_NLEVELS; ++l) {
+      dim3 grid((g.w[l] / 4 + 64) / 64, (g.h[l] + 3) / 4, nimg);
+      hipLaunchKernelGGL(k_pyr_level, grid, dim3(64, 4, 1), 0, st, g, s, l, ctx->d_pyr, ctx->d_xofs,
+                         ctx->d_xalpha, ctx->d_yofs, ctx->d_ybeta);
+    }
+  }
+  {
+    SvoTimer t(ctx, "k_fast");
+    hipLaunchKernelGGL(k_fast, dim3(g.tile_base[SVO_NLEVELS], nimg), dim3(256), 0, st, g, s,
+                       ctx->d_corners, ctx->d_counters, ctx->d_hist);
+  }
+  {
+    SvoTimer t(ctx, "k_select");
+    hipLaunchKernelGGL(k_select, dim3(SVO_NLEVELS, nimg), dim3(256), 0, st, g, s, ctx->d_corners,
+                       ctx->d_counters, ctx->d_hist, ctx->d_sel, ctx->d_selcnt);
+  }
+  {
+    SvoTimer t(ctx, "k_describe");
+    hipLaunchKernelGGL(k_describe, dim3(ctx->max_kp, nimg), dim3(64), 0, st, g, s, ctx->d_sel,
+                       ctx->d_selcnt, ctx->d_kp, ctx->d_desc, ctx->d_nkp, ctx->max_kp);
+  }
+  SVO_HIP(ctx, hipGetLastError());
+  return SVO_OK;
+}

@@ -1,0 +1,273 @@
+// svo_stereo.hip - sparse epipolar stereo association + depth for gfx950.
+//
+// Stands where frame::MB + frame::computekeypoint_r + frame::disp2Depth stand in
+// the reference (src/Tracking.cc:226-228; src/frame.cc:82-91,122-164): it turns a
+// stereo pair into per-keypoint right-image x and depth.  The algorithm is the
+// sparse matcher BASELINE.json's north_star names ("ComputeStereoMatches"):
+// row-band candidates, Hamming argmin, 11x11 SAD refinement +-5 px at the
+// keypoint's level, parabola sub-pixel, median-based outlier cut.
+// The dense helpers disp2Depth / UnprojectStereo are kept as kernels too.
+#include "svo_internal.h"
+
+#define TH_HIGH 100
+#define TH_ORB ((100 + 50) / 2)
+#define SAD_W 5
+#define SAD_L 5
+#define KP_PER_WG 16
+#define MAXKP_LDS 512
+
+struct StereoSrc {
+  const uint8_t* L;
+  const uint8_t* R;
+  int stride;
+  int B;
+  const uint8_t* pyr;
+};
+
+__device__ __forceinline__ const uint8_t* st_level_ptr(const SvoGeom& g, const StereoSrc& s,
+                                                        int img, int l, int* pitch) {
+  if (l == 0) {
+    *pitch = s.stride;
+    return img < s.B ? s.L + (size_t)img * s.stride * g.H
+                     : s.R + (size_t)(img - s.B) * s.stride * g.H;
+  }
+  *pitch = g.pitch[l];
+  return s.pyr + (size_t)img * g.pyr_bytes + g.loff[l];
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
+  return v;
+}
+
+// One workgroup = 16 left keypoints of one pair (4 waves x 4 keypoints); the right
+// image's keypoint bands and descriptors are staged in LDS once per workgroup.
+__global__ __launch_bounds__(256) void k_stereo_match(SvoGeom g, StereoSrc s, const svo_kp* kp,
+                                                      const uint8_t* desc, const int32_t* nkp,
+                                                      int max_kp, float bf, float fx, float* uR,
+                                                      float* depth, int32_t* sad_out) {
+  __shared__ uint32_t rdesc[MAXKP_LDS * 8];
+  __shared__ int16_t rminr[MAXKP_LDS], rmaxr[MAXKP_LDS];
+  __shared__ int8_t roct[MAXKP_LDS];
+  __shared__ float rx[MAXKP_LDS];
+  __shared__ int sadbuf[4][128];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int pair = blockIdx.y;
+  const int imgL = pair, imgR = s.B + pair;
+  const int nL = nkp[imgL], nR = min(nkp[imgR], MAXKP_LDS);
+  const svo_kp* kpL = kp + (size_t)imgL * max_kp;
+  const svo_kp* kpR = kp + (size_t)imgR * max_kp;
+  const uint32_t* dL = reinterpret_cast<const uint32_t*>(desc + (size_t)imgL * max_kp * 32);
+  const uint32_t* dR = reinterpret_cast<const uint32_t*>(desc + (size_t)imgR * max_kp * 32);
+  for (int i = tid; i < nR * 8; i += 256) rdesc[i] = dR[i];
+  for (int i = tid; i < nR; i += 256) {
+    const svo_kp k = kpR[i];
+    const float r = 2.0f * g.scale[k.octave];
+    rmaxr[i] = (int16_t)(int)ceilf(k.y + r);
+    rminr[i] = (int16_t)(int)floorf(k.y - r);
+    roct[i] = (int8_t)k.octave;
+    rx[i] = k.x;
+  }
+  __syncthreads();
+  const float maxD = fx;
+  for (int q = 0; q < KP_PER_WG / 4; ++q) {
+    const int iL = blockIdx.x * KP_PER_WG + wv * (KP_PER_WG / 4) + q;
+    if (iL >= max_kp) break;
+    const size_t o = (size_t)pair * max_kp + iL;
+    if (iL >= nL) {
+      if (lane == 0) { uR[o] = -1.f; depth[o] = -1.f; sad_out[o] = -1; }
+      continue;
+    }
+    const svo_kp kl = kpL[iL];
+    const int levelL = kl.octave;
+    const float uL = kl.x, vL = kl.y;
+    const int row = (int)vL;
+    const float minU = uL - maxD, maxU = uL;
+    uint32_t ql[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ql[k] = dL[(size_t)iL * 8 + k];
+    uint32_t best = ((uint32_t)TH_HIGH << 16) | 0xffffu;
+    if (maxU >= 0) {
+      for (int iR = lane; iR < nR; iR += 64) {
+        const int oc = roct[iR];
+        const float u = rx[iR];
+        const bool ok = row >= rminr[iR] && row <= rmaxr[iR] && oc >= levelL - 1 &&
+                        oc <= levelL + 1 && u >= minU && u <= maxU;
+        if (ok) {
+          int dist = 0;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) dist += __popc(ql[k] ^ rdesc[iR * 8 + k]);
+          best = min(best, ((uint32_t)dist << 16) | (uint32_t)iR);
+        }
+      }
+    }
+    best = wave_min_u32(best);
+    const int bestDist = (int)(best >> 16), bestIdxR = (int)(best & 0xffffu);
+    float out_u = -1.f, out_d = -1.f;
+    int out_sad = -1;
+    if (bestDist < TH_ORB && bestIdxR != 0xffff) {
+      const float uR0 = rx[bestIdxR];
+      const float sc = g.scale[levelL];
+      const float inv = 1.0f / sc;
+      const int su = (int)roundf(uL * inv), sv = (int)roundf(vL * inv), sr0 = (int)roundf(uR0 * inv);
+      const int lw = g.w[levelL], lh = g.h[levelL];
+      const bool inb = !(sv - SAD_W < 0 || sv + SAD_W >= lh || su - SAD_W < 0 || su + SAD_W >= lw ||
+                         sr0 - SAD_L - SAD_W < 0 || sr0 + SAD_L + SAD_W >= lw);
+      if (inb) {
+        int pl, pr;
+        const uint8_t* IL = st_level_ptr(g, s, imgL, levelL, &pl);
+        const uint8_t* IR = st_level_ptr(g, s, imgR, levelL, &pr);
+        const int cL = IL[(size_t)sv * pl + su];
+        // (inc, dy) pairs: 121 partial row sums
+        for (int p = lane; p < 121; p += 64) {
+          const int inc = p / 11 - SAD_L, dy = p % 11 - SAD_W;
+          const int cR = IR[(size_t)sv * pr + sr0 + inc];
+          const uint8_t* a = IL + (size_t)(sv + dy) * pl + su - SAD_W;
+          const uint8_t* b = IR + (size_t)(sv + dy) * pr + sr0 + inc - SAD_W;
+          int sum = 0;
+#pragma unroll
+          for (int dx = 0; dx < 11; ++dx) sum += abs(((int)a[dx] - cL) - ((int)b[dx] - cR));
+          sadbuf[wv][p] = sum;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        int mysad = 0x7fffffff;
+        if (lane < 11) {
+          mysad = 0;
+#pragma unroll
+          for (int k = 0; k < 11; ++k) mysad += sadbuf[wv][lane * 11 + k];
+        }
+        int dists[11];
+#pragma unroll
+        for (int k = 0; k < 11; ++k) dists[k] = __shfl(mysad, k, 64);
+        int bsad = 0x7fffffff, binc = 0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k)
+          if (dists[k] < bsad) { bsad = dists[k]; binc = k - SAD_L; }
+        if (binc != -SAD_L && binc != SAD_L) {
+          float d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+          for (int k = 1; k < 10; ++k)
+            if (k - SAD_L == binc) { d1 = (float)dists[k - 1]; d2 = (float)dists[k]; d3 = (float)dists[k + 1]; }
+          const float deltaR = (d1 - d3) / (2.0f * (d1 + d3 - 2.0f * d2));
+          if (!(deltaR < -1 || deltaR > 1)) {
+            float bestuR = sc * ((float)sr0 + (float)binc + deltaR);
+            float disparity = uL - bestuR;
+            if (disparity >= 0.f && disparity < maxD) {
+              if (disparity <= 0) { disparity = 0.01f; bestuR = uL - 0.01f; }
+              out_d = bf / disparity;
+              out_u = bestuR;
+              out_sad = bsad;
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (lane == 0) { uR[o] = out_u; depth[o] = out_d; sad_out[o] = out_sad; }
+  }
+}
+
+// Median-based outlier cut over one pair: median = the (nd/2)-th smallest best SAD
+// among accepted keypoints; reject sad >= 1.5f*1.4f*median.
+__global__ __launch_bounds__(256) void k_stereo_median(int max_kp, float* uR, float* depth,
+                                                       const int32_t* sad) {
+  __shared__ int ssad[1024];
+  __shared__ int nd, smed;
+  const int tid = threadIdx.x, pair = blockIdx.x;
+  const size_t base = (size_t)pair * max_kp;
+  if (tid == 0) { nd = 0; smed = -1; }
+  __syncthreads();
+  int cnt = 0;
+  for (int i = tid; i < max_kp; i += 256) {
+    const int v = sad[base + i];
+    ssad[i] = v;
+    cnt += v >= 0;
+  }
+  if (cnt) atomicAdd(&nd, cnt);
+  __syncthreads();
+  const int n = nd;
+  if (n == 0) return;
+  for (int i = tid; i < max_kp; i += 256) {
+    const int v = ssad[i];
+    if (v < 0) continue;
+    int rank = 0;
+    for (int j = 0; j < max_kp; ++j) {
+      const int u = ssad[j];
+      rank += (u >= 0) && (u < v || (u == v && j < i));
+    }
+    if (rank == n / 2) smed = v;
+  }
+  __syncthreads();
+  const float thDist = 2.1f * (float)smed;
+  for (int i = tid; i < max_kp; i += 256) {
+    const int v = ssad[i];
+    if (v >= 0 && !((float)v < thDist)) { uR[base + i] = -1.f; depth[base + i] = -1.f; }
+  }
+}
+
+// frame::disp2Depth (reference src/frame.cc:140-164), dense float map.
+__global__ void k_disp2depth(const float* __restrict__ disp, int count, float bf,
+                             float* __restrict__ depth) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+    const float d = disp[i];
+    depth[i] = d != 0.f ? bf / d : -1.f;
+  }
+}
+
+// frame::UnprojectStereo (reference src/frame.cc:166-180).
+__global__ void k_unproject(const float* __restrict__ uvz, int n, svo_camera cam, const float* Rwc,
+                            const float* twc, float* __restrict__ xyz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float u = uvz[3 * i], v = uvz[3 * i + 1], z = uvz[3 * i + 2];
+  if (z > 0) {
+    const float x = (u - cam.cx) * z * (1 / cam.fx);
+    const float y = (v - cam.cy) * z * (1 / cam.fy);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double acc = (double)Rwc[3 * r] * (double)x + (double)Rwc[3 * r + 1] * (double)y +
+                         (double)Rwc[3 * r + 2] * (double)z;
+      xyz[3 * i + r] = (float)(acc + (double)twc[r]);
+    }
+  } else {
+    xyz[3 * i] = xyz[3 * i + 1] = xyz[3 * i + 2] = __builtin_nanf("");
+  }
+}
+
+int svo_launch_stereo(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR, int stride,
+                      int B, const svo_camera* cam) {
+  if (B > ctx->max_batch || ctx->max_kp > 1024) return SVO_E_CAPACITY;
+  StereoSrc s{d_grayL, d_grayR, stride, B, ctx->d_pyr};
+  {
+    SvoTimer t(ctx, "k_stereo_match");
+    hipLaunchKernelGGL(k_stereo_match, dim3((ctx->max_kp + KP_PER_WG - 1) / KP_PER_WG, B), dim3(256),
+                       0, ctx->stream, ctx->g, s, ctx->d_kp, ctx->d_desc, ctx->d_nkp, ctx->max_kp,
+                       cam->bf, cam->fx, ctx->d_uR, ctx->d_depth, ctx->d_sad);
+  }
+  {
+    SvoTimer t(ctx, "k_stereo_median");
+    hipLaunchKernelGGL(k_stereo_median, dim3(B), dim3(256), 0, ctx->stream, ctx->max_kp, ctx->d_uR,
+                       ctx->d_depth, ctx->d_sad);
+  }
+  SVO_HIP(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
+int svo_launch_disp2depth(svo_ctx* ctx, const float* disp, int count, float bf, float* depth) {
+  const int blocks = min((count + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_disp2depth, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, ctx->stream, disp,
+                     count, bf, depth);
+  SVO_HIP(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
+int svo_launch_unproject(svo_ctx* ctx, const float* uvz, int n, const svo_camera* cam,
+                         const float* Rwc, const float* twc, float* xyz) {
+  if (n <= 0) return SVO_OK;
+  hipLaunchKernelGGL(k_unproject, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, uvz, n, *cam,
+                     Rwc, twc, xyz);
+  SVO_HIP(ctx, hipGetLastError());
+  return SVO_OK;
+}

@@ -1,0 +1,54 @@
+"""CPU suite: the C-ABI library builds, loads and exports every symbol include/svo.h
+declares.  No compute calls (there is no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "svo.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(svo_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_and_binding_agree(pkg):
+    assert declared_symbols() == sorted(pkg.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    assert os.path.exists(pkg.LIB_PATH), "run __graft_entry__.build() first"
+    lib = C.CDLL(pkg.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.svo_abi_version() == 1
+
+
+def test_strerror_and_argument_checks(pkg):
+    lib = pkg.load_library()
+    assert lib.svo_strerror(0) == b"ok"
+    assert lib.svo_strerror(-2) == b"no usable HIP device"
+    h = C.c_void_p()
+    # invalid sizes are rejected before any device is touched
+    assert lib.svo_create(C.byref(h), 0, 10, 10, 500, 1) == -1
+    assert lib.svo_create(None, 0, 1241, 376, 500, 1) == -1
+
+
+def test_missing_library_fails_loudly(pkg, monkeypatch):
+    monkeypatch.setattr(pkg, "_lib", None)
+    monkeypatch.setattr(pkg, "LIB_PATH", os.path.join(ROOT, "does_not_exist.so"))
+    with pytest.raises(pkg.SvoError):
+        pkg.load_library()
+
+
+def test_product_never_touches_the_oracle():
+    """The shipped package must not import, link or call anything under oracle/."""
+    pkg_dir = os.path.join(ROOT, "stereo-semantic-vo_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".cc", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "svo_oracle" not in txt and "oracle/" not in txt and "orc_" not in txt, f

@@ -1,0 +1,236 @@
+"""GPU suite (-m gpu): the HIP path, called through the C-ABI, against the CPU oracle on
+the same inputs.  Integer / index / descriptor outputs must be bit-exact; float64 pose
+outputs within the tolerances written below."""
+import os
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+G = np.load(os.path.join(util.GOLDEN, "vectors.npz"))
+POSE_ATOL_T = 1e-6      # metres  (1e-4 m per frame is far inside the reference's noise)
+POSE_ATOL_R = 1e-8      # rotation-matrix entries
+
+
+@pytest.fixture(scope="module")
+def svo_kitti(pkg):
+    s = pkg.Svo(util.KITTI_W, util.KITTI_H, max_batch=2)
+    yield s
+    s.close()
+
+
+@pytest.fixture(scope="module")
+def svo_small(pkg):
+    s = pkg.Svo(640, 240, max_batch=2)
+    yield s
+    s.close()
+
+
+def same_kp(a, b):
+    for f in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+        assert np.array_equal(a[f].view(np.uint32) if a[f].dtype.kind == "f" else a[f],
+                              b[f].view(np.uint32) if b[f].dtype.kind == "f" else b[f]), f
+
+
+def test_loaded_library_is_the_in_tree_hip_extension(pkg):
+    pkg.load_library()
+    maps = open("/proc/self/maps").read()
+    assert "libsvo_hip.so" in maps
+
+
+# ---- ORB stages ---------------------------------------------------------------------------
+@pytest.mark.parametrize("src", ["urban", "blocky"])
+def test_pyramid_bit_exact(svo_kitti, orc, src):
+    img = util.urban_pair()[0] if src == "urban" else util.blocky_image(11, util.KITTI_W, util.KITTI_H)
+    svo_kitti.orb_extract(img)
+    levels = orc.pyramid_levels(orc.build_pyramid(img), util.KITTI_W, util.KITTI_H)
+    for l in range(8):
+        assert np.array_equal(svo_kitti.debug_pyramid_level(0, l), levels[l]), "level %d" % l
+
+
+@pytest.mark.parametrize("src", ["urban", "blocky"])
+def test_fast_corners_bit_exact(svo_kitti, orc, src):
+    img = util.urban_pair()[0] if src == "urban" else util.blocky_image(12, util.KITTI_W, util.KITTI_H)
+    svo_kitti.orb_extract(img)
+    levels = orc.pyramid_levels(orc.build_pyramid(img), util.KITTI_W, util.KITTI_H)
+    total = 0
+    for l in range(8):
+        ref = orc.fast_corners(levels[l])
+        got = svo_kitti.debug_fast_corners(0, l)
+        # the GPU list is unordered: compare as sets of (y, x, score)
+        ref_s = ref[np.lexsort((ref[:, 0], ref[:, 1]))]
+        got_s = got[np.lexsort((got[:, 0], got[:, 1]))]
+        assert np.array_equal(ref_s, got_s), "level %d: %d vs %d" % (l, len(ref), len(got))
+        total += len(ref)
+    assert total > 2000
+
+
+@pytest.mark.parametrize("src", ["urban", "blocky", "flat", "noise"])
+def test_orb_extract_bit_exact(svo_kitti, orc, src):
+    if src == "urban":
+        img = util.urban_pair()[1]
+    elif src == "blocky":
+        img = util.blocky_image(13, util.KITTI_W, util.KITTI_H)
+    elif src == "flat":                       # no corners at all: n == 0
+        img = np.full((util.KITTI_H, util.KITTI_W), 77, np.uint8)
+    else:                                     # white noise: corner-saturated, exercises caps/ties
+        img = np.random.default_rng(1234).integers(0, 256, (util.KITTI_H, util.KITTI_W), dtype=np.uint8)
+    kp, desc = svo_kitti.orb_extract(img)
+    rkp, rdesc = orc.orb_extract(img)
+    assert len(kp) == len(rkp)
+    same_kp(kp, rkp)
+    assert np.array_equal(desc, rdesc)
+
+
+def test_orb_extract_small_image_bit_exact(svo_small, orc):
+    img = util.blocky_image(21, 640, 240)
+    kp, desc = svo_small.orb_extract(img)
+    rkp, rdesc = orc.orb_extract(img)
+    same_kp(kp, rkp)
+    assert np.array_equal(desc, rdesc)
+    # idempotence: a second call on the same context returns the same bytes
+    kp2, desc2 = svo_small.orb_extract(img)
+    same_kp(kp, kp2)
+    assert np.array_equal(desc, desc2)
+
+
+# ---- stereo -----------------------------------------------------------------------------------
+def test_stereo_real_pair_bit_exact(svo_kitti, orc, pkg):
+    L, R = util.urban_pair()
+    cam = pkg.Camera(**pkg.KITTI_00_02)
+    g = svo_kitti.stereo_frame(L, R, cam)
+    r = orc.stereo_frame(L, R, cam.bf, cam.fx)
+    same_kp(g["kpL"], r["kpL"]); same_kp(g["kpR"], r["kpR"])
+    assert np.array_equal(g["dL"], r["dL"]) and np.array_equal(g["dR"], r["dR"])
+    assert np.array_equal(g["uR"].view(np.uint32), r["uR"].view(np.uint32))
+    assert np.array_equal(g["depth"].view(np.uint32), r["depth"].view(np.uint32))
+    assert (g["depth"] > 0).sum() > 150
+
+
+def test_stereo_constant_disparity(svo_small, orc, pkg):
+    L, R = util.shifted_pair(5, 640, 240, disparity=12)
+    cam = pkg.Camera(**pkg.KITTI_00_02)
+    g = svo_small.stereo_frame(L, R, cam)
+    r = orc.stereo_frame(L, R, cam.bf, cam.fx)
+    assert np.array_equal(g["uR"].view(np.uint32), r["uR"].view(np.uint32))
+    assert np.array_equal(g["depth"].view(np.uint32), r["depth"].view(np.uint32))
+    v = g["depth"] > 0
+    assert v.sum() > 100 and np.abs(np.median(g["kpL"]["x"][v] - g["uR"][v]) - 12) < 0.1
+
+
+def test_disp2depth_and_unproject_golden(svo_small, pkg):
+    assert np.array_equal(svo_small.disp2depth(G["d2d_disp"], float(G["d2d_bf"][0])), G["d2d_depth"])
+    c = G["un_cam"]
+    cam = pkg.Camera(c[0], c[1], c[2], c[3], 386.1448)
+    out = svo_small.unproject(G["un_uvz"], cam, G["un_R"], G["un_t"])
+    assert np.array_equal(np.isnan(out), np.isnan(G["un_xyz"]))
+    ok = ~np.isnan(out)
+    assert np.allclose(out[ok], G["un_xyz"][ok], rtol=2e-7, atol=0)
+
+
+def test_disp2depth_full_kitti_map(svo_kitti, orc):
+    rng = np.random.default_rng(5)
+    disp = rng.integers(-1, 49, (util.KITTI_H, util.KITTI_W)).astype(np.float32)
+    assert np.array_equal(svo_kitti.disp2depth(disp, 386.1448), orc.disp2depth(disp, 386.1448))
+
+
+# ---- Hamming matching ----------------------------------------------------------------------------
+def test_hamming_golden(svo_small):
+    assert np.array_equal(svo_small.descriptor_distance(G["ham_a"], G["ham_b"]), G["ham_d"])
+
+
+def test_argmin_golden_and_oracle(svo_small, orc):
+    bi, b, s = svo_small.hamming_argmin(G["m_q"], G["m_t"], G["m_mask"])
+    assert np.array_equal(np.stack([bi, b, s], 1), G["m_argmin"])
+    q, t = util.planted_descriptors(31, 1500, 500)
+    mask = (np.random.default_rng(3).random(500) < 0.3).astype(np.uint8)
+    for m in (None, mask, np.ones(500, np.uint8)):
+        got = svo_small.hamming_argmin(q, t, m)
+        ref = orc.hamming_argmin(q, t, m)
+        for a, r in zip(got, ref):
+            assert np.array_equal(a, r)
+
+
+@pytest.mark.parametrize("name,md,ratio", [("p1_14", 14, 0.0), ("p1_15", 15, 0.0),
+                                            ("p2_29", 29, 2.0), ("p2_30", 30, 2.0)])
+def test_greedy_golden(svo_small, name, md, ratio):
+    bi, b, s, acc, asg = svo_small.match_greedy(G["m_q"], G["m_t"], G["m_mask"], md, ratio)
+    assert np.array_equal(np.stack([bi, b, s, acc], 1), G["m_greedy_" + name])
+    assert np.array_equal(asg, G["m_assigned_" + name])
+
+
+@pytest.mark.parametrize("M,N,md,ratio", [(500, 500, 15, 0.0), (1500, 500, 30, 2.0), (64, 7, 30, 2.0),
+                                          (3, 500, 15, 0.0), (700, 1000, 30, 2.0)])
+def test_greedy_against_oracle(svo_small, orc, M, N, md, ratio):
+    q, t = util.planted_descriptors(100 + M + N, M, N)
+    rng = np.random.default_rng(M)
+    assigned = (rng.random(N) < 0.1).astype(np.uint8)
+    skip = (rng.random(M) < 0.2).astype(np.uint8)
+    got = svo_small.match_greedy(q, t, assigned, md, ratio, q_skip=skip)
+    ref = orc.match_greedy(q, t, assigned, md, ratio, q_skip=skip)
+    for a, r in zip(got, ref):
+        assert np.array_equal(a, r)
+    assert got[3].sum() > 0
+
+
+def test_greedy_ratio_exactly_two_is_rejected(svo_small):
+    bi, b, s, acc, _ = svo_small.match_greedy(G["r_q"], G["r_t"], np.zeros(8, np.uint8), 30, 2.0)
+    assert (bi[0], b[0], s[0], acc[0]) == (5, 10, 20, 0)
+
+
+def test_bf_match_against_oracle(svo_small, orc):
+    q, t = util.planted_descriptors(77, 500, 500)
+    for a, r in zip(svo_small.bf_match(q, t), orc.bf_match(q, t)):
+        assert np.array_equal(a, r)
+
+
+def test_empty_inputs(svo_small):
+    z = np.zeros((0, 32), np.uint8)
+    assert len(svo_small.descriptor_distance(z, z)) == 0
+    bi, b, s = svo_small.hamming_argmin(z, util.random_descriptors(1, 5))
+    assert len(bi) == 0
+    bi, b, s = svo_small.hamming_argmin(util.random_descriptors(1, 5), z)
+    assert list(bi) == [-1] * 5 and list(b) == [256] * 5 and list(s) == [256] * 5
+
+
+# ---- pose ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["lm", "lm2"])
+def test_pose_opt_golden(svo_small, case):
+    T, st = svo_small.pose_opt(G[case + "_Xw"], G[case + "_obs"], G[case + "_K"], G[case + "_T0"])
+    chi0, chi1, lam, iters = G[case + "_scalars"]
+    assert st.iterations == int(iters) and st.trials_total == len(G[case + "_trace"])
+    assert np.isclose(st.chi2_initial, chi0, rtol=1e-10) and np.isclose(st.chi2_final, chi1, rtol=1e-7)
+    assert np.abs(T[:3, 3] - G[case + "_T"][:3, 3]).max() < POSE_ATOL_T
+    assert np.abs(T[:3, :3] - G[case + "_T"][:3, :3]).max() < POSE_ATOL_R
+
+
+@pytest.mark.parametrize("seed,n", [(7, 500), (8, 37), (9, 5), (10, 1)])
+def test_pose_opt_against_oracle(svo_small, orc, seed, n):
+    Xw, obs, K, T_true = util.pose_problem(seed, n=n)
+    T0 = np.eye(4)
+    T, st = svo_small.pose_opt(Xw, obs, K, T0)
+    Tr, sr, _ = orc.pose_opt(Xw, obs, K, T0)
+    assert (st.iterations, st.trials_total, st.terminated) == (sr.iterations, sr.trials_total, sr.terminated)
+    assert np.abs(T[:3, 3] - Tr[:3, 3]).max() < POSE_ATOL_T
+    assert np.abs(T[:3, :3] - Tr[:3, :3]).max() < POSE_ATOL_R
+
+
+def test_pose_opt_zero_edges_keeps_pose(svo_small):
+    T0 = np.eye(4); T0[:3, 3] = [1, 2, 3]
+    T, st = svo_small.pose_opt(np.zeros((0, 3)), np.zeros((0, 2)), G["lm_K"], T0)
+    assert st.n_edges == 0 and np.allclose(T, T0)
+
+
+@pytest.mark.parametrize("seed,n", [(7, 500), (12, 60), (13, 4)])
+def test_pnp_ransac_against_oracle(svo_small, orc, seed, n):
+    Xw, obs, K, T_true = util.pose_problem(seed, n=n)
+    T0 = np.eye(4)
+    T, mask, st = svo_small.pnp_ransac(Xw, obs, K, T0, 0x5EED0000 + seed)
+    Tr, mr, sr = orc.pnp_ransac(Xw, obs, K, T0, 0x5EED0000 + seed)
+    assert (st.ok, st.best_hypothesis, st.n_inliers) == (sr.ok, sr.best_hypothesis, sr.n_inliers)
+    assert np.array_equal(mask, mr)
+    assert np.abs(T[:3, 3] - Tr[:3, 3]).max() < POSE_ATOL_T
+    assert np.abs(T[:3, :3] - Tr[:3, :3]).max() < POSE_ATOL_R

@@ -42,9 +42,10 @@ def blocky_image(seed, W, H, cells=(4, 9, 23, 61)):
 
 def shifted_pair(seed, W, H, disparity=12):
     """Left/right pair with a constant integer disparity (right = left shifted left)."""
-    big = blocky_image(seed, W + 64, H)
-    L = big[:, 32:32 + W]
-    R = big[:, 32 + disparity:32 + disparity + W]
+    assert 0 <= disparity <= 64
+    big = blocky_image(seed, W + 128, H)
+    L = big[:, 64:64 + W]
+    R = big[:, 64 + disparity:64 + disparity + W]
     return np.ascontiguousarray(L), np.ascontiguousarray(R)
 
 

@@ -221,6 +221,10 @@ int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL, const uint8
                     int strideR, double timestamp, const int32_t* boxes, int n_boxes,
                     svo_track_result* res);
 
+/* Parity probe: map-point pool row matched to each keypoint of the frame just tracked
+ * (CurrentFrame->MapPoints after both passes, -1 = none). cur_mp: max_kp int32. */
+int svo_debug_track_matches(svo_ctx* ctx, int32_t* cur_mp);
+
 /* ---- throughput mode: batched, device-resident ------------------------------ */
 /* B stereo pairs already in HBM: d_grayL/d_grayR are B images of H rows x `stride`
  * bytes.  Runs extraction on all 2B images and the sparse stereo association for

@@ -202,3 +202,34 @@ def unproject(uvz, cam, Rwc, twc):
     fx, fy, cx, cy = (C.c_float(float(v)) for v in cam[:4])
     lib().orc_unproject(_p(uvz), len(uvz), fx, fy, cx, cy, _p(Rwc), _p(twc), _p(out))
     return out
+
+
+TRACK_DTYPE = np.dtype([("Tcw", "<f4", (16,)), ("frame_id", "<i4"), ("n_kp", "<i4"),
+                        ("n_stereo", "<i4"), ("n_match_pass1", "<i4"), ("n_match_pass2", "<i4"),
+                        ("n_pnp_inliers", "<i4"), ("n_lm_edges", "<i4"), ("n_new_mappoints", "<i4"),
+                        ("n_local_map", "<i4"), ("lm_iterations", "<i4"), ("reserved", "<i4", (2,))])
+
+
+class Tracker:
+    """orc_track.c: the reference's Tracking::Track loop on the CPU."""
+
+    def __init__(self, W, H, cam, nfeatures=500):
+        l = lib()
+        l.orc_track_create.restype = C.c_void_p
+        l.orc_track_create.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_float] * 5
+        l.orc_track_destroy.argtypes = [C.c_void_p]
+        l.orc_track_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_void_p]
+        self.W, self.H, self.nf = W, H, nfeatures
+        self.h = l.orc_track_create(W, H, nfeatures, cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["bf"])
+
+    def track(self, grayL, grayR):
+        grayL = np.ascontiguousarray(grayL, np.uint8); grayR = np.ascontiguousarray(grayR, np.uint8)
+        res = np.zeros(1, TRACK_DTYPE); cur = np.zeros(self.nf, np.int32)
+        lib().orc_track_frame(self.h, _p(grayL), self.W, _p(grayR), self.W, _p(res), _p(cur))
+        return res[0], cur
+
+    def close(self):
+        if self.h:
+            lib().orc_track_destroy(self.h)
+            self.h = None

@@ -1,1 +1,235 @@
+/* orc_track.c - CPU restatement of the per-frame tracking loop.
+ *
+ * TEST INFRASTRUCTURE ONLY (see svo_oracle.h).
+ *
+ * Follows Tracking::Track (reference src/Tracking.cc:180-252) and what it calls:
+ *   frame ctor / SetPose            src/frame.cc:36-73
+ *   Tracking::init                  src/Tracking.cc:42-97   (frame 0)
+ *   pnpmatch::poseEstimationPnP     src/pnpmatch.cc:33-251  (passes 1 and 2, PnP)
+ *   Optimizer::PoseOptimization     src/Optimizer.cc:15-86
+ *   frame::createmappoint           src/frame.cc:182-238
+ *   mappoint ctor / AddObservation  src/mappoint.cc:10-23
+ *   local-map culling               src/Tracking.cc:239-250
+ * with the north-star substitutions already made by the other oracle files: ORB
+ * from orc_orb.c, per-keypoint sparse-stereo depth (orc_stereo.c) instead of the
+ * dense depthimg lookup, orc_pnp_ransac instead of cv::solvePnPRansac (prior = last
+ * frame's pose, seed 0x5EED0000 + frame id).  Deterministic orders replace the
+ * reference's run-dependent ones: LocalMapPoints (a std::set<mappoint*> ordered by
+ * heap address, include/Tracking.h:41) is iterated in creation order.
+ * Offline detection boxes (semantic gating, SURVEY f-3) are not modelled yet: the
+ * tracker runs the reference's "empty box list" configuration (BASELINE config 1).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
 #include "svo_oracle.h"
+
+#define TRK_MAXKP 512
+#define TRK_CAP 4096
+
+typedef struct {
+  float pos[3];
+  uint8_t desc[32];
+  uint8_t bad, in_local;
+  int32_t create_id;
+  int32_t obs_frame; /* id of the last frame that observed it (observations.count(cur)) */
+} mp_t;
+
+struct orc_tracker {
+  int W, H, nfeatures;
+  float fx, fy, cx, cy, bf;
+  int frame_num;
+  mp_t* pool;
+  int npool;
+  int lastN;
+  int32_t last_mp[TRK_MAXKP];
+  float lastTcw[16];
+};
+
+orc_tracker* orc_track_create(int W, int H, int nfeatures, float fx, float fy, float cx, float cy,
+                              float bf) {
+  if (nfeatures > TRK_MAXKP) return NULL;
+  orc_tracker* t = (orc_tracker*)calloc(1, sizeof(orc_tracker));
+  t->W = W; t->H = H; t->nfeatures = nfeatures;
+  t->fx = fx; t->fy = fy; t->cx = cx; t->cy = cy; t->bf = bf;
+  t->pool = (mp_t*)calloc(TRK_CAP, sizeof(mp_t));
+  for (int i = 0; i < 16; ++i) t->lastTcw[i] = (i % 5 == 0) ? 1.f : 0.f;
+  return t;
+}
+void orc_track_destroy(orc_tracker* t) {
+  if (!t) return;
+  free(t->pool);
+  free(t);
+}
+
+/* frame::SetPose (src/frame.cc:66-73): Rwc = Rcw^T, twc = -Rwc*tcw (CV_32F; the
+ * product accumulates in double and rounds once [upstream-memory]). */
+static void pose_inverse_f(const float Tcw[16], float Rwc[9], float twc[3]) {
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) Rwc[3 * r + c] = Tcw[4 * c + r];
+  for (int r = 0; r < 3; ++r) {
+    double acc = (double)Rwc[3 * r] * (double)Tcw[3] + (double)Rwc[3 * r + 1] * (double)Tcw[7] +
+                 (double)Rwc[3 * r + 2] * (double)Tcw[11];
+    twc[r] = (float)(-acc);
+  }
+}
+
+/* new mappoint(x3D, frame, i) + AddObservation + create_id (src/frame.cc:226-232) */
+static int new_mappoint(orc_tracker* t, const float xyz[3], const uint8_t* desc, int frame_id) {
+  if (t->npool >= TRK_CAP) return -1;
+  mp_t* m = &t->pool[t->npool];
+  memcpy(m->pos, xyz, sizeof m->pos);
+  memcpy(m->desc, desc, 32);
+  m->bad = 0; m->in_local = 1; m->create_id = frame_id; m->obs_frame = -1;
+  return t->npool++;
+}
+
+int orc_track_frame(orc_tracker* t, const uint8_t* grayL, int strideL, const uint8_t* grayR,
+                    int strideR, orc_track_result* res, int32_t* cur_mp_out) {
+  const int NF = t->nfeatures;
+  orc_kp* kp = (orc_kp*)calloc((size_t)NF, sizeof(orc_kp));
+  uint8_t* desc = (uint8_t*)calloc((size_t)NF, 32);
+  float* uR = (float*)calloc((size_t)NF, sizeof(float));
+  float* depth = (float*)calloc((size_t)NF, sizeof(float));
+  int32_t nkp = 0;
+  orc_stereo_frame(grayL, strideL, grayR, strideR, t->W, t->H, NF, t->bf, t->fx, kp, desc, &nkp, uR,
+                   depth, NULL, NULL, NULL);
+  const int id = t->frame_num;
+  int32_t cur_mp[TRK_MAXKP];
+  for (int i = 0; i < TRK_MAXKP; ++i) cur_mp[i] = -1;
+  float Tcw[16];
+  for (int i = 0; i < 16; ++i) Tcw[i] = (i % 5 == 0) ? 1.f : 0.f; /* frame ctor: SetPose(I) */
+  memset(res, 0, sizeof *res);
+  res->frame_id = id; res->n_kp = nkp;
+  for (int i = 0; i < nkp; ++i) res->n_stereo += depth[i] > 0;
+  const double K[4] = {t->fx, t->fy, t->cx, t->cy};
+
+  if (id == 0) {
+    /* Tracking::init (src/Tracking.cc:42-97): pose I, map points for every keypoint with depth */
+    const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3[3] = {0, 0, 0};
+    for (int i = 0; i < nkp; ++i) {
+      if (depth[i] > 0) {
+        float uvz[3] = {kp[i].x, kp[i].y, depth[i]}, xyz[3];
+        orc_unproject(uvz, 1, t->fx, t->fy, t->cx, t->cy, I3, z3, xyz);
+        cur_mp[i] = new_mappoint(t, xyz, desc + 32 * (size_t)i, id);
+        res->n_new_mappoints++;
+      }
+    }
+  } else {
+    /* pass 1 (src/pnpmatch.cc:61-156): last frame's map points -> current keypoints */
+    uint8_t* assigned = (uint8_t*)calloc(TRK_MAXKP, 1);
+    for (int i = 0; i < t->lastN; ++i) {
+      const int m = t->last_mp[i];
+      if (m < 0 || t->pool[m].bad) continue;
+      int32_t bi, bd, sd;
+      uint8_t acc;
+      orc_match_greedy(t->pool[m].desc, NULL, 1, desc, nkp, assigned, 15, 0.f, &bi, &bd, &sd, &acc);
+      if (acc) {
+        cur_mp[bi] = m;
+        t->pool[m].obs_frame = id;
+        res->n_match_pass1++;
+      }
+    }
+    /* pass 2 (src/pnpmatch.cc:159-199): local map points not yet observed by this frame */
+    for (int m = 0; m < t->npool; ++m) {
+      mp_t* p = &t->pool[m];
+      if (!p->in_local || p->bad || p->obs_frame == id) continue;
+      int32_t bi, bd, sd;
+      uint8_t acc;
+      orc_match_greedy(p->desc, NULL, 1, desc, nkp, assigned, 30, 2.f, &bi, &bd, &sd, &acc);
+      if (acc) {
+        cur_mp[bi] = m;
+        p->obs_frame = id;
+        res->n_match_pass2++;
+      }
+    }
+    free(assigned);
+    /* PnP (src/pnpmatch.cc:212-247): pose = PnP result (Tcl * I), stored CV_32F */
+    double* Xw = (double*)malloc(sizeof(double) * 3 * TRK_MAXKP);
+    double* ob = (double*)malloc(sizeof(double) * 2 * TRK_MAXKP);
+    int n = 0;
+    for (int j = 0; j < nkp; ++j)
+      if (cur_mp[j] >= 0) {
+        const mp_t* p = &t->pool[cur_mp[j]];
+        Xw[3 * n] = p->pos[0]; Xw[3 * n + 1] = p->pos[1]; Xw[3 * n + 2] = p->pos[2];
+        ob[2 * n] = kp[j].x; ob[2 * n + 1] = kp[j].y;
+        ++n;
+      }
+    double Tp[16], Td[16];
+    for (int i = 0; i < 16; ++i) Tp[i] = t->lastTcw[i];
+    orc_pnp_stats ps;
+    orc_pnp_ransac(Xw, ob, n, K, Tp, 0x5EED0000ULL + (uint64_t)id, Td, NULL, &ps);
+    res->n_pnp_inliers = ps.n_inliers;
+    for (int i = 0; i < 16; ++i) Tcw[i] = (float)Td[i];
+    free(Xw); free(ob);
+  }
+  /* Optimizer::PoseOptimization on every frame, frame 0 included (src/Tracking.cc:107-121) */
+  {
+    double* Xw = (double*)malloc(sizeof(double) * 3 * TRK_MAXKP);
+    double* ob = (double*)malloc(sizeof(double) * 2 * TRK_MAXKP);
+    int n = 0;
+    for (int j = 0; j < nkp; ++j)
+      if (cur_mp[j] >= 0) {
+        const mp_t* p = &t->pool[cur_mp[j]];
+        Xw[3 * n] = p->pos[0]; Xw[3 * n + 1] = p->pos[1]; Xw[3 * n + 2] = p->pos[2];
+        ob[2 * n] = kp[j].x; ob[2 * n + 1] = kp[j].y;
+        ++n;
+      }
+    double Td[16];
+    for (int i = 0; i < 16; ++i) Td[i] = Tcw[i];
+    orc_lm_stats ls;
+    memset(&ls, 0, sizeof ls);
+    orc_pose_opt(Xw, ob, n, K, Td, &ls, NULL, 0);
+    res->n_lm_edges = n;
+    res->lm_iterations = ls.iterations;
+    for (int i = 0; i < 16; ++i) Tcw[i] = (float)Td[i];
+    free(Xw); free(ob);
+  }
+  memcpy(res->Tcw, Tcw, sizeof Tcw);
+  if (cur_mp_out) memcpy(cur_mp_out, cur_mp, sizeof(int32_t) * (size_t)NF);
+  /* lastframe = frame(currentframe); lastframe.createmappoint (src/frame.cc:182-238) */
+  {
+    float Rwc[9], twc[3];
+    pose_inverse_f(Tcw, Rwc, twc);
+    for (int i = 0; i < nkp; ++i) {
+      if (cur_mp[i] >= 0) continue;
+      if (depth[i] > 0) {
+        float uvz[3] = {kp[i].x, kp[i].y, depth[i]}, xyz[3];
+        orc_unproject(uvz, 1, t->fx, t->fy, t->cx, t->cy, Rwc, twc, xyz);
+        cur_mp[i] = new_mappoint(t, xyz, desc + 32 * (size_t)i, id);
+        if (id > 0) res->n_new_mappoints++;
+      }
+    }
+  }
+  t->lastN = nkp;
+  memcpy(t->last_mp, cur_mp, sizeof cur_mp);
+  memcpy(t->lastTcw, Tcw, sizeof Tcw);
+  /* cull (src/Tracking.cc:239-250) */
+  if (t->frame_num >= 4)
+    for (int m = 0; m < t->npool; ++m)
+      if (t->pool[m].in_local && t->pool[m].create_id <= t->frame_num - 4) t->pool[m].in_local = 0;
+  /* stable compaction of the pool: keep local-map members and points the last frame references */
+  {
+    uint8_t* live = (uint8_t*)calloc(TRK_CAP, 1);
+    int32_t* remap = (int32_t*)malloc(sizeof(int32_t) * TRK_CAP);
+    for (int m = 0; m < t->npool; ++m) live[m] = t->pool[m].in_local;
+    for (int i = 0; i < t->lastN; ++i)
+      if (t->last_mp[i] >= 0) live[t->last_mp[i]] = 1;
+    int k = 0;
+    for (int m = 0; m < t->npool; ++m) {
+      remap[m] = live[m] ? k : -1;
+      if (live[m]) { if (k != m) t->pool[k] = t->pool[m]; ++k; }
+    }
+    t->npool = k;
+    for (int i = 0; i < t->lastN; ++i)
+      if (t->last_mp[i] >= 0) t->last_mp[i] = remap[t->last_mp[i]];
+    int nl = 0;
+    for (int m = 0; m < t->npool; ++m) nl += t->pool[m].in_local;
+    res->n_local_map = nl;
+    free(live); free(remap);
+  }
+  t->frame_num++;
+  free(kp); free(desc); free(uR); free(depth);
+  return 0;
+}

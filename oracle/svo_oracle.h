@@ -98,6 +98,20 @@ int orc_pnp_ransac(const double* Xw, const double* obs, int n, const double K[4]
                    const double T_prior[16], uint64_t seed, double T[16], uint8_t* inlier_mask,
                    orc_pnp_stats* stats);
 
+/* tracking loop (orc_track.c) */
+typedef struct orc_track_result {
+  float Tcw[16];
+  int32_t frame_id, n_kp, n_stereo, n_match_pass1, n_match_pass2, n_pnp_inliers, n_lm_edges,
+      n_new_mappoints, n_local_map, lm_iterations, reserved[2];
+} orc_track_result;
+typedef struct orc_tracker orc_tracker;
+orc_tracker* orc_track_create(int W, int H, int nfeatures, float fx, float fy, float cx, float cy,
+                              float bf);
+void orc_track_destroy(orc_tracker* t);
+/* cur_mp_out (nullable): nfeatures int32, pool index matched to each keypoint or -1 */
+int orc_track_frame(orc_tracker* t, const uint8_t* grayL, int strideL, const uint8_t* grayR,
+                    int strideR, orc_track_result* res, int32_t* cur_mp_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,7 @@ ABI_SYMBOLS = [
     "svo_debug_fast_corners", "svo_stereo_frame", "svo_stereo_frame_ex", "svo_disp2depth",
     "svo_unproject", "svo_descriptor_distance", "svo_hamming_argmin", "svo_match_greedy",
     "svo_bf_match", "svo_pnp_ransac", "svo_pose_opt", "svo_track_reset", "svo_track_frame",
+    "svo_debug_track_matches",
     "svo_frontend_batch_dev", "svo_track_batch_dev", "svo_profile_enable", "svo_profile_reset",
     "svo_profile_get",
 ]
@@ -268,6 +269,11 @@ class Svo:
         self._chk(self.lib.svo_track_frame(self.h, _p(grayL), self.W, _p(grayR), self.W,
                                            C.c_double(timestamp), _p(bx), nb, _p(res)))
         return res[0]
+
+    def debug_track_matches(self):
+        out = np.zeros(self.max_kp, np.int32)
+        self._chk(self.lib.svo_debug_track_matches(self.h, _p(out)))
+        return out
 
     # ---- throughput mode (device pointers, e.g. torch tensors' data_ptr()) --------------------
     def frontend_batch_dev(self, d_grayL, d_grayR, stride, B, cam, d_kpL=None, d_descL=None,

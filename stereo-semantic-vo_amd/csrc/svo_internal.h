@@ -127,6 +127,11 @@ int svo_launch_pose_opt(svo_ctx* ctx, const double* Xw, const double* obs, int n
 int svo_launch_pnp(svo_ctx* ctx, const double* Xw, const double* obs, int n, const double* K,
                    const double* Tprior, uint64_t seed, double* T, uint8_t* mask,
                    svo_pnp_stats* stats);
+int svo_launch_pose_opt_dev(svo_ctx* ctx, const double* Xw, const double* obs, const int* n_ptr,
+                            const double* K, double* T, svo_lm_stats* stats, int round_in_f32);
+int svo_launch_pnp_dev(svo_ctx* ctx, const double* Xw, const double* obs, const int* n_ptr,
+                       const double* K, const double* Tprior, double* T, svo_pnp_stats* stats,
+                       const int* skip_ptr, const int* frame_ptr);
 int svo_launch_disp2depth(svo_ctx* ctx, const float* disp, int count, float bf, float* depth);
 int svo_launch_unproject(svo_ctx* ctx, const float* uvz, int n, const svo_camera* cam,
                          const float* Rwc, const float* twc, float* xyz);

@@ -254,7 +254,9 @@ struct LmShared {
 __global__ __launch_bounds__(256) void k_pose_opt(const double* __restrict__ Xw,
                                                   const double* __restrict__ obs, int n,
                                                   const double* __restrict__ Kp, double* T,
-                                                  svo_lm_stats* stats) {
+                                                  svo_lm_stats* stats, const int* n_ptr,
+                                                  int round_in_f32) {
+  if (n_ptr) n = *n_ptr;
   __shared__ double red[5 * 28];
   __shared__ LmShared sh;
   __shared__ double K[4];
@@ -263,7 +265,13 @@ __global__ __launch_bounds__(256) void k_pose_opt(const double* __restrict__ Xw,
   const double dsqr = delta * delta;
   if (tid < 4) K[tid] = Kp[tid];
   if (tid == 0) {
-    se3_from_T(T, sh.est);
+    if (round_in_f32) {  // the reference stores the PnP pose as CV_32F before optimising it
+      double Tf[16];
+      for (int j = 0; j < 16; ++j) Tf[j] = (double)(float)T[j];
+      se3_from_T(Tf, sh.est);
+    } else {
+      se3_from_T(T, sh.est);
+    }
     for (int j = 0; j < 6; ++j) sh.x[j] = 0;
     sh.done = 0;
   }
@@ -384,7 +392,14 @@ __global__ __launch_bounds__(256) void k_pnp_ransac(const double* __restrict__ X
                                                     const double* __restrict__ Kp,
                                                     const double* __restrict__ Tprior, uint64_t seed,
                                                     double* T, uint8_t* inlier_mask,
-                                                    svo_pnp_stats* stats) {
+                                                    svo_pnp_stats* stats, const int* n_ptr,
+                                                    const int* skip_ptr, const int* frame_ptr) {
+  if (n_ptr) n = *n_ptr;
+  if (frame_ptr) seed = 0x5EED0000ULL + (uint64_t)*frame_ptr;
+  if (skip_ptr && *skip_ptr) {   // frame 0: no PnP, the pose stays at the prior
+    if (threadIdx.x < 16) T[threadIdx.x] = Tprior[threadIdx.x];
+    return;
+  }
   __shared__ Se3 hyp[PNP_HYP];
   __shared__ int hcnt[PNP_HYP];
   __shared__ uint8_t use[PNP_MAXN];
@@ -517,7 +532,8 @@ __global__ __launch_bounds__(256) void k_pnp_ransac(const double* __restrict__ X
 int svo_launch_pose_opt(svo_ctx* ctx, const double* Xw, const double* obs, int n, const double* K,
                         double* T, svo_lm_stats* stats) {
   SvoTimer tm(ctx, "k_pose_opt");
-  hipLaunchKernelGGL(k_pose_opt, dim3(1), dim3(256), 0, ctx->stream, Xw, obs, n, K, T, stats);
+  hipLaunchKernelGGL(k_pose_opt, dim3(1), dim3(256), 0, ctx->stream, Xw, obs, n, K, T, stats,
+                     (const int*)nullptr, 0);
   SVO_HIP(ctx, hipGetLastError());
   return SVO_OK;
 }
@@ -528,7 +544,24 @@ int svo_launch_pnp(svo_ctx* ctx, const double* Xw, const double* obs, int n, con
   if (n > PNP_MAXN) return SVO_E_CAPACITY;
   SvoTimer tm(ctx, "k_pnp_ransac");
   hipLaunchKernelGGL(k_pnp_ransac, dim3(1), dim3(256), 0, ctx->stream, Xw, obs, n, K, Tprior, seed,
-                     T, mask, stats);
+                     T, mask, stats, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr);
   SVO_HIP(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
+// device-driven variants used by the tracking tail (sizes / seed / skip flag live in HBM)
+int svo_launch_pose_opt_dev(svo_ctx* ctx, const double* Xw, const double* obs, const int* n_ptr,
+                            const double* K, double* T, svo_lm_stats* stats, int round_in_f32) {
+  SvoTimer tm(ctx, "k_pose_opt");
+  hipLaunchKernelGGL(k_pose_opt, dim3(1), dim3(256), 0, ctx->stream, Xw, obs, 0, K, T, stats, n_ptr,
+                     round_in_f32);
+  return SVO_OK;
+}
+int svo_launch_pnp_dev(svo_ctx* ctx, const double* Xw, const double* obs, const int* n_ptr,
+                       const double* K, const double* Tprior, double* T, svo_pnp_stats* stats,
+                       const int* skip_ptr, const int* frame_ptr) {
+  SvoTimer tm(ctx, "k_pnp_ransac");
+  hipLaunchKernelGGL(k_pnp_ransac, dim3(1), dim3(256), 0, ctx->stream, Xw, obs, 0, K, Tprior,
+                     (uint64_t)0, T, (uint8_t*)nullptr, stats, n_ptr, skip_ptr, frame_ptr);
   return SVO_OK;
 }

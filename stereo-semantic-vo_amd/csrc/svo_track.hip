@@ -1,17 +1,493 @@
-// svo_track.hip - Tracking::Track (reference src/Tracking.cc:180-252) on the device.
+// svo_track.hip - Tracking::Track (reference src/Tracking.cc:180-252) with all state in HBM.
+//
+// The ordered tail of a frame - Tracking::init / pnpmatch::poseEstimationPnP passes 1 and 2
+// (src/pnpmatch.cc:61-199), the PnP initial pose (:212-247), Optimizer::PoseOptimization
+// (src/Optimizer.cc:15-86), frame::createmappoint (src/frame.cc:182-238) and the local-map
+// cull (src/Tracking.cc:239-250) - runs as nine small launches per frame with no host
+// round trip: sizes, the frame counter and the map-point pool all live in one TrackState
+// block.  The map-point pool is a structure of arrays kept in creation order (the
+// deterministic stand-in for the reference's std::set<mappoint*> address order); after each
+// frame it is stably compacted into the other half of a ping-pong buffer, so "local map
+// point r" is simply row r and the pass-2 distance matrix needs no gather.
+// Offline detection boxes (semantic gating, SURVEY f-3) are not modelled yet.
+#include <cstddef>
+
 #include "svo_internal.h"
+
+#define TRK_MAXKP 512
+#define TRK_CAP 4096
+
+struct TrackPool {
+  float pos[TRK_CAP * 3];
+  uint32_t desc[TRK_CAP * 8];
+  int32_t create_id[TRK_CAP];
+  int32_t obs_frame[TRK_CAP];
+  uint8_t bad[TRK_CAP];
+  uint8_t in_local[TRK_CAP];
+};
+
+struct TrackState {
+  int32_t frame_num, npool, lastN, cur;      // cur: active half of the pool ping-pong
+  int32_t nkp, m1, m2, n_edges, skip_match;
+  int32_t n_pass1, n_pass2, n_new, n_stereo;
+  float lastTcw[16];
+  int32_t last_mp[TRK_MAXKP];
+  int32_t cur_mp[TRK_MAXKP];
+  int32_t dbg_cur_mp[TRK_MAXKP];
+  uint8_t assigned[TRK_MAXKP];
+  double Xw[TRK_MAXKP * 3], obs[TRK_MAXKP * 2], K[4], Tprior[16], T[16];
+  svo_lm_stats lm;
+  svo_pnp_stats pnp;
+  svo_camera cam;
+  TrackPool pool[2];
+  uint16_t D[(size_t)TRK_CAP * 512];
+};
+
+__device__ __forceinline__ uint32_t tk_wmin(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
+  return v;
+}
+
+// exclusive scan of one int per thread over a 512-thread block; returns the total in *total
+__device__ __forceinline__ int block_excl_scan512(int v, int* sm /*[512]*/, int* total) {
+  const int tid = threadIdx.x;
+  sm[tid] = v;
+  __syncthreads();
+  for (int o = 1; o < 512; o <<= 1) {
+    const int t = tid >= o ? sm[tid - o] : 0;
+    __syncthreads();
+    sm[tid] += t;
+    __syncthreads();
+  }
+  const int incl = sm[tid];
+  *total = sm[511];
+  __syncthreads();
+  return incl - v;
+}
+
+__device__ __forceinline__ void tk_unproject(const svo_camera& cam, float u, float v, float z,
+                                             const float* Rwc, const float* twc, float* xyz) {
+  const float x = (u - cam.cx) * z * (1 / cam.fx);
+  const float y = (v - cam.cy) * z * (1 / cam.fy);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const double acc = (double)Rwc[3 * r] * (double)x + (double)Rwc[3 * r + 1] * (double)y +
+                       (double)Rwc[3 * r + 2] * (double)z;
+    xyz[r] = (float)(acc + (double)twc[r]);
+  }
+}
+
+// ---- 1. frame begin: reset per-frame state; frame 0 runs Tracking::init -------------------
+__global__ __launch_bounds__(512) void k_tk_begin(TrackState* st, const svo_kp* kp,
+                                                  const uint32_t* desc, const int32_t* nkp_p,
+                                                  const float* depth) {
+  __shared__ int sm[512];
+  const int tid = threadIdx.x;
+  const int nkp = min(*nkp_p, TRK_MAXKP);
+  TrackPool& P = st->pool[st->cur];
+  st->cur_mp[tid] = -1;
+  st->assigned[tid] = 0;
+  const bool has_depth = tid < nkp && depth[tid] > 0.f;
+  int total;
+  const int rank = block_excl_scan512(has_depth ? 1 : 0, sm, &total);
+  if (tid == 0) {
+    st->nkp = nkp;
+    st->n_stereo = total;
+    st->n_pass1 = 0; st->n_pass2 = 0; st->n_new = 0;
+    for (int i = 0; i < 4; ++i) st->K[i] = (double)((const float*)&st->cam)[i];
+    for (int i = 0; i < 16; ++i) st->Tprior[i] = (double)st->lastTcw[i];
+  }
+  if (st->frame_num == 0) {
+    // Tracking::init (src/Tracking.cc:42-97): pose I, one map point per keypoint with depth
+    if (has_depth) {
+      const int m = st->npool + rank;
+      const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3[3] = {0, 0, 0};
+      const svo_kp k = kp[tid];
+      tk_unproject(st->cam, k.x, k.y, depth[tid], I3, z3, &P.pos[3 * m]);
+#pragma unroll
+      for (int w = 0; w < 8; ++w) P.desc[8 * m + w] = desc[8 * tid + w];
+      P.bad[m] = 0; P.in_local[m] = 1; P.create_id[m] = 0; P.obs_frame[m] = -1;
+      st->cur_mp[tid] = m;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      st->npool += total;
+      st->n_new = total;
+      st->skip_match = 1; st->m1 = 0; st->m2 = 0;
+      for (int i = 0; i < 16; ++i) st->Tprior[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    }
+  } else if (tid == 0) {
+    st->skip_match = 0;
+    st->m1 = st->lastN;
+    st->m2 = st->npool;
+  }
+}
+
+// ---- 2/4. distance matrix rows of one pass ------------------------------------------------
+// pass 1: row i <-> last frame's keypoint i (map point last_mp[i]); pass 2: row r <-> pool row r.
+__global__ __launch_bounds__(256) void k_tk_dist(TrackState* st, const uint32_t* desc, int pass) {
+  __shared__ uint32_t td[TRK_MAXKP * 8];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int M = pass == 1 ? st->m1 : st->m2;
+  if ((int)blockIdx.x * 4 >= M) return;
+  const int nkp = st->nkp;
+  const TrackPool& P = st->pool[st->cur];
+  for (int i = tid; i < nkp * 8; i += 256) td[i] = desc[i];
+  __syncthreads();
+  const int row = blockIdx.x * 4 + wv;
+  if (row >= M) return;
+  int m = row;
+  if (pass == 1) {
+    m = st->last_mp[row];
+    if (m < 0 || P.bad[m]) return;
+  } else if (!P.in_local[m] || P.bad[m]) {
+    return;
+  }
+  uint32_t qd[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) qd[k] = P.desc[8 * m + k];
+  for (int j = lane; j < 512; j += 64) {
+    int d = 0x7fff;
+    if (j < nkp) {
+      d = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d += __popc(qd[k] ^ td[j * 8 + k]);
+    }
+    st->D[(size_t)row * 512 + j] = (uint16_t)d;
+  }
+}
+
+// ---- 3/5. the order-dependent greedy assignment, one wave -----------------------------------
+// The wave first compacts the rows that take part (ballot + prefix popcount, order kept),
+// then walks them with a 4-deep register prefetch of the distance rows so the serial chain
+// pays ALU time, not one L2 round trip, per row.  Lane L owns columns 8L..8L+7 and keeps
+// their claim bits in a register.
+__global__ __launch_bounds__(64) void k_tk_greedy(TrackState* st, int pass) {
+  __shared__ int16_t rows[TRK_CAP];
+  __shared__ int16_t rowmp[TRK_CAP];
+  const int lane = threadIdx.x;
+  const int M = pass == 1 ? st->m1 : st->m2;
+  if (M <= 0 || st->skip_match) return;
+  TrackPool& P = st->pool[st->cur];
+  const int nkp = st->nkp, id = st->frame_num;
+  const int max_dist = pass == 1 ? 15 : 30;
+  const float ratio = pass == 1 ? 0.f : 2.f;
+  int n = 0;
+  for (int base = 0; base < M; base += 64) {
+    const int i = base + lane;
+    int m = i;
+    bool valid = i < M;
+    if (valid) {
+      if (pass == 1) {
+        m = st->last_mp[i];
+        valid = m >= 0 && !P.bad[m];
+      } else {
+        valid = P.in_local[m] && !P.bad[m] && P.obs_frame[m] != id;
+      }
+    }
+    const uint64_t mask = __ballot(valid);
+    if (valid) {
+      const int pos = n + __popcll(mask & ((1ull << lane) - 1ull));
+      rows[pos] = (int16_t)i;
+      rowmp[pos] = (int16_t)m;
+    }
+    n += __popcll(mask);
+  }
+  __syncthreads();
+  uint32_t claimed = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int j = lane * 8 + k;
+    if (j >= nkp || st->assigned[j]) claimed |= 1u << k;
+  }
+  const uint16_t* Dl = st->D + lane * 8;
+  uint4 buf[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < n) buf[k] = *reinterpret_cast<const uint4*>(Dl + (size_t)rows[k] * 512);
+  int accepted_total = 0;
+  for (int a = 0; a < n; a += 4) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (a + k < n) {
+        const uint4 v = buf[k];
+        if (a + k + 4 < n) buf[k] = *reinterpret_cast<const uint4*>(Dl + (size_t)rows[a + k + 4] * 512);
+        const uint32_t cur[8] = {v.x & 0xffff, v.x >> 16, v.y & 0xffff, v.y >> 16,
+                                 v.z & 0xffff, v.z >> 16, v.w & 0xffff, v.w >> 16};
+        uint32_t lp = (256u << 16) | 0xffffu;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (!((claimed >> c) & 1u)) lp = min(lp, (cur[c] << 16) | (uint32_t)(lane * 8 + c));
+        const uint32_t bp = tk_wmin(lp);
+        const int bj = (int)(bp & 0xffffu), bd = (int)(bp >> 16);
+        bool ok = bj != 0xffff && bd < max_dist;
+        if (ok && ratio > 0.f) {
+          uint32_t ls = 256;
+#pragma unroll
+          for (int c = 0; c < 8; ++c)
+            if (!((claimed >> c) & 1u) && lane * 8 + c < bj) ls = min(ls, cur[c]);
+          const int sec = (int)tk_wmin(ls);
+          ok = (float)sec / (float)bd > ratio;
+        }
+        if (ok) {
+          if ((bj >> 3) == lane) claimed |= 1u << (bj & 7);
+          if (lane == 0) {
+            const int m = rowmp[a + k];
+            st->cur_mp[bj] = m;
+            P.obs_frame[m] = id;
+          }
+          ++accepted_total;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int j = lane * 8 + k;
+    if (j < nkp) st->assigned[j] = (uint8_t)((claimed >> k) & 1u);
+  }
+  if (lane == 0) {
+    if (pass == 1) st->n_pass1 = accepted_total; else st->n_pass2 = accepted_total;
+  }
+}
+
+// ---- 6. gather the 3D-2D correspondences (ordered by keypoint index) -----------------------
+__global__ __launch_bounds__(512) void k_tk_gather(TrackState* st, const svo_kp* kp) {
+  __shared__ int sm[512];
+  const int tid = threadIdx.x;
+  const TrackPool& P = st->pool[st->cur];
+  const int m = tid < st->nkp ? st->cur_mp[tid] : -1;
+  st->dbg_cur_mp[tid] = m;
+  int total;
+  const int pos = block_excl_scan512(m >= 0 ? 1 : 0, sm, &total);
+  if (m >= 0) {
+    st->Xw[3 * pos] = (double)P.pos[3 * m];
+    st->Xw[3 * pos + 1] = (double)P.pos[3 * m + 1];
+    st->Xw[3 * pos + 2] = (double)P.pos[3 * m + 2];
+    const svo_kp k = kp[tid];
+    st->obs[2 * pos] = (double)k.x;
+    st->obs[2 * pos + 1] = (double)k.y;
+  }
+  if (tid == 0) st->n_edges = total;
+}
+
+// ---- 9. frame end: SetPose, result record, createmappoint, cull, compaction ----------------
+__global__ __launch_bounds__(512) void k_tk_end(TrackState* st, const svo_kp* kp,
+                                                const uint32_t* desc, const float* depth,
+                                                svo_track_result* res_out) {
+  __shared__ int sm[512];
+  __shared__ float sT[16], sRwc[9], stwc[3];
+  __shared__ int s_np;
+  const int tid = threadIdx.x;
+  const int nkp = st->nkp, id = st->frame_num;
+  TrackPool& P = st->pool[st->cur];
+  TrackPool& Q = st->pool[st->cur ^ 1];
+  if (tid < 16) sT[tid] = (float)st->T[tid];   // SetPose(pose) stores CV_32F (src/Optimizer.cc:82-83)
+  __syncthreads();
+  if (tid < 9) sRwc[tid] = sT[4 * (tid % 3) + tid / 3];
+  __syncthreads();
+  if (tid < 3) {
+    const double acc = (double)sRwc[3 * tid] * (double)sT[3] + (double)sRwc[3 * tid + 1] * (double)sT[7] +
+                       (double)sRwc[3 * tid + 2] * (double)sT[11];
+    stwc[tid] = (float)(-acc);
+  }
+  __syncthreads();
+  // frame::createmappoint for keypoints without a map point and with depth
+  int m_cur = tid < nkp ? st->cur_mp[tid] : -1;
+  const bool create = tid < nkp && m_cur < 0 && depth[tid] > 0.f;
+  int n_new;
+  const int rank = block_excl_scan512(create ? 1 : 0, sm, &n_new);
+  const int np0 = st->npool;
+  if (create && np0 + rank < TRK_CAP) {
+    const int m = np0 + rank;
+    const svo_kp k = kp[tid];
+    tk_unproject(st->cam, k.x, k.y, depth[tid], sRwc, stwc, &P.pos[3 * m]);
+#pragma unroll
+    for (int w = 0; w < 8; ++w) P.desc[8 * m + w] = desc[8 * tid + w];
+    P.bad[m] = 0; P.in_local[m] = 1; P.create_id[m] = id; P.obs_frame[m] = -1;
+    m_cur = m;
+  }
+  __syncthreads();
+  const int np1 = min(np0 + n_new, TRK_CAP);
+  // cull + liveness: thread t owns pool rows 8t .. 8t+7
+  if (tid < TRK_MAXKP) st->last_mp[tid] = m_cur;   // pre-compaction indices
+  __syncthreads();
+  // mark rows referenced by the (new) last frame: reuse obs_frame sign? use a flag pass in Q.bad
+  for (int r = tid; r < TRK_CAP; r += 512) Q.bad[r] = 0;
+  __syncthreads();
+  if (tid < nkp && m_cur >= 0) Q.bad[m_cur] = 1;   // Q.bad is scratch here: "referenced" flag
+  __syncthreads();
+  int live_cnt = 0;
+  uint32_t live_bits = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int r = tid * 8 + k;
+    if (r < np1) {
+      bool loc = P.in_local[r] != 0;
+      if (id >= 4 && P.create_id[r] <= id - 4) loc = false;   // cull (src/Tracking.cc:239-250)
+      P.in_local[r] = loc ? 1 : 0;
+      if (loc || Q.bad[r]) { live_bits |= 1u << k; ++live_cnt; }
+    }
+  }
+  int total_live;
+  int base = block_excl_scan512(live_cnt, sm, &total_live);
+  __syncthreads();
+  for (int r = tid; r < TRK_CAP; r += 512) Q.bad[r] = 0;
+  __syncthreads();
+  // remap table lives in Q.obs_frame temporarily (rows of P -> rows of Q)
+  int nl = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int r = tid * 8 + k;
+    if ((live_bits >> k) & 1u) {
+      const int q = base++;
+      Q.pos[3 * q] = P.pos[3 * r]; Q.pos[3 * q + 1] = P.pos[3 * r + 1]; Q.pos[3 * q + 2] = P.pos[3 * r + 2];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) Q.desc[8 * q + w] = P.desc[8 * r + w];
+      Q.create_id[q] = P.create_id[r];
+      Q.bad[q] = P.bad[r];
+      Q.in_local[q] = P.in_local[r];
+      nl += P.in_local[r];
+      P.obs_frame[r] = q;            // remap (P is dead after this kernel)
+    } else if (r < np1) {
+      P.obs_frame[r] = -1;
+    }
+  }
+  int nl_total;
+  block_excl_scan512(nl, sm, &nl_total);
+  __syncthreads();
+  if (tid < TRK_MAXKP) {
+    const int m = st->last_mp[tid];
+    st->last_mp[tid] = (tid < nkp && m >= 0) ? P.obs_frame[m] : -1;
+  }
+  for (int q = tid; q < total_live; q += 512) Q.obs_frame[q] = -1;
+  if (tid == 0) {
+    svo_track_result r;
+    for (int i = 0; i < 16; ++i) { r.Tcw[i] = sT[i]; st->lastTcw[i] = sT[i]; }
+    r.frame_id = id; r.n_kp = nkp; r.n_stereo = st->n_stereo;
+    r.n_match_pass1 = st->n_pass1; r.n_match_pass2 = st->n_pass2;
+    r.n_pnp_inliers = st->skip_match ? 0 : st->pnp.n_inliers;
+    r.n_lm_edges = st->n_edges;
+    r.n_new_mappoints = (id == 0 ? st->n_new : 0) + n_new;
+    r.n_local_map = nl_total;
+    r.lm_iterations = st->lm.iterations;
+    r.reserved[0] = 0; r.reserved[1] = 0;
+    *res_out = r;
+    st->lastN = nkp;
+    st->npool = total_live;
+    st->cur ^= 1;
+    st->frame_num = id + 1;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+static int tail_launch(svo_ctx* ctx, int slot, svo_track_result* d_res) {
+  TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
+  hipStream_t s = ctx->stream;
+  const size_t K = ctx->max_kp;
+  const svo_kp* kp = ctx->d_kp + slot * K;
+  const uint32_t* desc = reinterpret_cast<const uint32_t*>(ctx->d_desc + slot * K * 32);
+  const float* depth = ctx->d_depth + slot * K;
+  {
+    SvoTimer t(ctx, "k_tk_begin");
+    hipLaunchKernelGGL(k_tk_begin, dim3(1), dim3(512), 0, s, st, kp, desc, ctx->d_nkp + slot, depth);
+  }
+  {
+    SvoTimer t(ctx, "k_tk_match");
+    hipLaunchKernelGGL(k_tk_dist, dim3(TRK_MAXKP / 4), dim3(256), 0, s, st, desc, 1);
+    hipLaunchKernelGGL(k_tk_greedy, dim3(1), dim3(64), 0, s, st, 1);
+    hipLaunchKernelGGL(k_tk_dist, dim3(TRK_CAP / 4), dim3(256), 0, s, st, desc, 2);
+    hipLaunchKernelGGL(k_tk_greedy, dim3(1), dim3(64), 0, s, st, 2);
+  }
+  {
+    SvoTimer t(ctx, "k_tk_gather");
+    hipLaunchKernelGGL(k_tk_gather, dim3(1), dim3(512), 0, s, st, kp);
+  }
+  svo_launch_pnp_dev(ctx, st->Xw, st->obs, &st->n_edges, st->K, st->Tprior, st->T, &st->pnp,
+                     &st->skip_match, &st->frame_num);
+  svo_launch_pose_opt_dev(ctx, st->Xw, st->obs, &st->n_edges, st->K, st->T, &st->lm, 1);
+  {
+    SvoTimer t(ctx, "k_tk_end");
+    hipLaunchKernelGGL(k_tk_end, dim3(1), dim3(512), 0, s, st, kp, desc, depth, d_res);
+  }
+  SVO_HIP(ctx, hipGetLastError());
+  return SVO_OK;
+}
 
 extern "C" int svo_track_reset(svo_ctx* ctx, const svo_camera* cam) {
   if (!ctx || !cam) return SVO_E_INVALID;
+  if (ctx->max_kp > TRK_MAXKP) return SVO_E_CAPACITY;
+  hipSetDevice(ctx->device);
+  if (!ctx->d_track) {
+    void* p = nullptr;
+    if (hipMalloc(&p, sizeof(TrackState)) != hipSuccess) return SVO_E_NOMEM;
+    ctx->d_track = p;
+  }
+  TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
+  // zero the scalar header + index arrays (everything before the pools), then set identity pose
+  SVO_HIP(ctx, hipMemsetAsync(st, 0, offsetof(TrackState, pool), ctx->stream));
+  float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  SVO_HIP(ctx, hipMemcpyAsync(st->lastTcw, I, sizeof I, hipMemcpyHostToDevice, ctx->stream));
+  SVO_HIP(ctx, hipMemcpyAsync(&st->cam, cam, sizeof *cam, hipMemcpyHostToDevice, ctx->stream));
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->cam = *cam;
   ctx->track_frame = 0;
   return SVO_OK;
 }
-extern "C" int svo_track_frame(svo_ctx*, const uint8_t*, int, const uint8_t*, int, double,
-                               const int32_t*, int, svo_track_result*) {
-  return SVO_E_INVALID;
+
+extern "C" int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL,
+                               const uint8_t* grayR, int strideR, double timestamp,
+                               const int32_t* boxes, int n_boxes, svo_track_result* res) {
+  (void)timestamp;
+  if (!ctx || !grayL || !grayR || !res || strideL < ctx->g.W || strideR < ctx->g.W)
+    return SVO_E_INVALID;
+  if (n_boxes > 0 || boxes) return SVO_E_INVALID;  // semantic gating (SURVEY f-3) not modelled yet
+  if (!ctx->d_track) return SVO_E_INVALID;          // svo_track_reset first
+  hipSetDevice(ctx->device);
+  const SvoGeom& g = ctx->g;
+  uint8_t* dL = ctx->d_stage;
+  uint8_t* dR = ctx->d_stage + (size_t)g.H * ctx->stage_pitch;
+  SVO_HIP(ctx, hipMemcpy2DAsync(dL, ctx->stage_pitch, grayL, strideL, g.W, g.H,
+                                hipMemcpyHostToDevice, ctx->stream));
+  SVO_HIP(ctx, hipMemcpy2DAsync(dR, ctx->stage_pitch, grayR, strideR, g.W, g.H,
+                                hipMemcpyHostToDevice, ctx->stream));
+  int rc = svo_launch_orb(ctx, dL, dR, ctx->stage_pitch, 1, 2);
+  if (rc) return rc;
+  rc = svo_launch_stereo(ctx, dL, dR, ctx->stage_pitch, 1, &ctx->cam);
+  if (rc) return rc;
+  svo_track_result* d_res = reinterpret_cast<svo_track_result*>(ctx->d_scratch);
+  rc = tail_launch(ctx, 0, d_res);
+  if (rc) return rc;
+  SVO_HIP(ctx, hipMemcpyAsync(res, d_res, sizeof *res, hipMemcpyDeviceToHost, ctx->stream));
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->track_frame++;
+  return SVO_OK;
 }
-extern "C" int svo_track_batch_dev(svo_ctx*, const uint8_t*, const uint8_t*, int, int,
-                                   svo_track_result*) {
-  return SVO_E_INVALID;
+
+extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR,
+                                   int stride, int B, svo_track_result* d_results) {
+  if (!ctx || !d_grayL || !d_grayR || !d_results || B < 1 || stride < ctx->g.W) return SVO_E_INVALID;
+  if (B > ctx->max_batch) return SVO_E_CAPACITY;
+  if (!ctx->d_track) return SVO_E_INVALID;
+  hipSetDevice(ctx->device);
+  int rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, B, 2 * B);
+  if (rc) return rc;
+  rc = svo_launch_stereo(ctx, d_grayL, d_grayR, stride, B, &ctx->cam);
+  if (rc) return rc;
+  for (int f = 0; f < B; ++f) {
+    rc = tail_launch(ctx, f, d_results + f);
+    if (rc) return rc;
+  }
+  ctx->track_frame += B;
+  return SVO_OK;
+}
+
+extern "C" int svo_debug_track_matches(svo_ctx* ctx, int32_t* cur_mp) {
+  if (!ctx || !cur_mp || !ctx->d_track) return SVO_E_INVALID;
+  TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
+  SVO_HIP(ctx, hipMemcpyAsync(cur_mp, st->dbg_cur_mp, sizeof(int32_t) * ctx->max_kp,
+                              hipMemcpyDeviceToHost, ctx->stream));
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVO_OK;
 }

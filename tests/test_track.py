@@ -1,0 +1,107 @@
+"""Tracking loop (Tracking::Track, reference src/Tracking.cc:180-252).
+CPU: the oracle tracker on a short synthetic sequence against exact ground truth.
+GPU (-m gpu): the device-resident tracker against the oracle tracker on the same frames -
+match indices bit-exact, poses within the stated tolerance."""
+import importlib
+
+import numpy as np
+import pytest
+
+N_FRAMES = 7
+POSE_TOL_T = 1e-4     # metres per frame   (far inside the reference's noise)
+POSE_TOL_R = 1e-5     # rotation-matrix entries (~radians)
+
+
+@pytest.fixture(scope="module")
+def sequence(pkg):
+    synth = importlib.import_module("stereo_semantic_vo_amd.synth")
+    L, R, T = synth.render_sequence(N_FRAMES)
+    return L.numpy(), R.numpy(), T.numpy()
+
+
+@pytest.fixture(scope="module")
+def oracle_run(orc, pkg, sequence):
+    L, R, T = sequence
+    trk = orc.Tracker(L.shape[2], L.shape[1], pkg.KITTI_00_02)
+    out = [trk.track(L[k], R[k]) for k in range(N_FRAMES)]
+    trk.close()
+    return out
+
+
+def test_synth_geometry(sequence):
+    L, R, T = sequence
+    assert L.shape == (N_FRAMES, 376, 1241) and L.dtype == np.uint8
+    step = np.linalg.norm(np.diff(T[:, :3, 3], axis=0), axis=1)
+    assert np.allclose(step, 1.0, atol=1e-9)
+    assert 20 < L[0].std() < 40 and not np.array_equal(L[0], R[0])
+
+
+def test_oracle_tracker_follows_ground_truth(oracle_run, sequence):
+    _, _, T = sequence
+    errs = []
+    for k, (res, cur) in enumerate(oracle_run):
+        Twc = np.linalg.inv(res["Tcw"].reshape(4, 4).astype(np.float64))
+        errs.append(np.linalg.norm(Twc[:3, 3] - T[k][:3, 3]))
+        assert res["frame_id"] == k and res["n_kp"] > 400 and res["n_stereo"] > 250
+        if k > 0:
+            assert res["n_lm_edges"] == res["n_match_pass1"] + res["n_match_pass2"] >= 20
+            assert res["n_pnp_inliers"] >= 15
+    assert errs[0] < 1e-3
+    assert max(errs) < 0.35          # the reference itself drifts ~0.1 m/frame
+    steps = [np.linalg.norm(np.linalg.inv(oracle_run[k][0]["Tcw"].reshape(4, 4).astype(np.float64))[:3, 3] -
+                            np.linalg.inv(oracle_run[k - 1][0]["Tcw"].reshape(4, 4).astype(np.float64))[:3, 3])
+             for k in range(1, N_FRAMES)]
+    assert all(0.8 < s < 1.2 for s in steps)
+
+
+def test_local_map_window(oracle_run):
+    # points older than 3 frames leave the local map (src/Tracking.cc:239-250)
+    sizes = [r["n_local_map"] for r, _ in oracle_run]
+    assert sizes[3] > sizes[0] and sizes[5] <= sizes[3] + 60
+
+
+@pytest.mark.gpu
+def test_gpu_tracker_matches_oracle(pkg, sequence, oracle_run):
+    L, R, _ = sequence
+    svo = pkg.Svo(L.shape[2], L.shape[1], max_batch=1)
+    svo.track_reset(pkg.Camera(**pkg.KITTI_00_02))
+    for k in range(N_FRAMES):
+        res = svo.track_frame(L[k], R[k])
+        cur = svo.debug_track_matches()
+        ref, ref_cur = oracle_run[k]
+        for f in ("frame_id", "n_kp", "n_stereo", "n_match_pass1", "n_match_pass2", "n_pnp_inliers",
+                  "n_lm_edges", "n_new_mappoints", "n_local_map", "lm_iterations"):
+            assert res[f] == ref[f], (k, f, res[f], ref[f])
+        assert np.array_equal(cur[:ref["n_kp"]], ref_cur[:ref["n_kp"]]), "frame %d match indices" % k
+        T, Tr = res["Tcw"].reshape(4, 4), ref["Tcw"].reshape(4, 4)
+        assert np.abs(T[:3, 3] - Tr[:3, 3]).max() < POSE_TOL_T, k
+        assert np.abs(T[:3, :3] - Tr[:3, :3]).max() < POSE_TOL_R, k
+    svo.close()
+
+
+@pytest.mark.gpu
+def test_gpu_batch_tracker_equals_frame_by_frame(pkg, sequence):
+    """svo_track_batch_dev over HBM-resident frames == svo_track_frame one by one."""
+    import torch
+    L, R, _ = sequence
+    H, W = L.shape[1], L.shape[2]
+    cam = pkg.Camera(**pkg.KITTI_00_02)
+    a = pkg.Svo(W, H, max_batch=1)
+    a.track_reset(cam)
+    single = [a.track_frame(L[k], R[k]) for k in range(N_FRAMES)]
+    a.close()
+    pitch = 1280
+    dev = torch.device("cuda", 0)
+    dL = torch.zeros((N_FRAMES, H, pitch), dtype=torch.uint8, device=dev)
+    dR = torch.zeros_like(dL)
+    dL[:, :, :W] = torch.from_numpy(L).to(dev); dR[:, :, :W] = torch.from_numpy(R).to(dev)
+    res = torch.zeros((N_FRAMES, pkg.TRACK_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    b = pkg.Svo(W, H, max_batch=N_FRAMES)
+    b.track_reset(cam)
+    b.track_batch_dev(dL.data_ptr(), dR.data_ptr(), pitch, N_FRAMES, res.data_ptr())
+    b.sync()
+    out = res.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(-1)
+    b.close()
+    for k in range(N_FRAMES):
+        assert out[k].tobytes() == single[k].tobytes(), k

@@ -81,6 +81,13 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise SvoError("HIP extension missing: %s (run `make -C %s` or __graft_entry__.build())"
                            % (LIB_PATH, _HERE))
+        try:
+            # torch wheels bundle their own libamdhip64; two HIP runtimes in one process cannot
+            # both see the GPU.  Loading torch first makes its runtime the single one (our
+            # library's libamdhip64.so.7 dependency then resolves to it).
+            import torch  # noqa: F401
+        except Exception:
+            pass
         lib = C.CDLL(LIB_PATH)
         lib.svo_strerror.restype = C.c_char_p
         lib.svo_last_error.restype = C.c_char_p

@@ -70,8 +70,11 @@ def test_gpu_tracker_matches_oracle(pkg, sequence, oracle_run):
         cur = svo.debug_track_matches()
         ref, ref_cur = oracle_run[k]
         for f in ("frame_id", "n_kp", "n_stereo", "n_match_pass1", "n_match_pass2", "n_pnp_inliers",
-                  "n_lm_edges", "n_new_mappoints", "n_local_map", "lm_iterations"):
+                  "n_lm_edges", "n_new_mappoints", "n_local_map"):
             assert res[f] == ref[f], (k, f, res[f], ref[f])
+        # at convergence g2o's `rho == 0` stop rule hinges on the last bit of chi2, which depends
+        # on the summation order (sequential on the CPU, tree on the GPU): +-1 iteration allowed
+        assert abs(int(res["lm_iterations"]) - int(ref["lm_iterations"])) <= 1, k
         assert np.array_equal(cur[:ref["n_kp"]], ref_cur[:ref["n_kp"]]), "frame %d match indices" % k
         T, Tr = res["Tcw"].reshape(4, 4), ref["Tcw"].reshape(4, 4)
         assert np.abs(T[:3, 3] - Tr[:3, 3]).max() < POSE_TOL_T, k

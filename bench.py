@@ -2,17 +2,20 @@
 """bench.py - stereo pairs/s through the MI355X-native tracking front end.
 
 One "step" = one pass of the hot path over one batch of B synthetic KITTI-00-shaped
-stereo pairs (1241x376 gray) that are already resident in HBM.  Workloads:
-  frontend : ORB pyramid extraction on both images + sparse epipolar stereo
-             (BASELINE.json configs[1], batched)
-  track    : frontend + the ordered tracking tail (matching, PnP-RANSAC, pose-only LM)
-             over consecutive frames of one synthetic sequence (configs[2])
+stereo pairs (1241x376 gray, synth-kitti renderer) that are already resident in HBM.
+  --workload frontend (default, BASELINE.json configs[1], batched): ORB pyramid
+        extraction on both images + sparse epipolar stereo for B pairs per step.
+  --workload track    (configs[2]): the same front end + the ordered tracking tail
+        (matching passes, PnP-RANSAC, pose-only LM, map-point lifecycle) over B
+        consecutive frames of ONE sequence per step; reports ATE vs ground truth.
+The default run also times a bounded `track` leg and reports it under "track".
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL, used ONLY for the
-barrier and the max-over-ranks clock); pairs are sharded round-robin (pair k -> rank
-k mod N), no data-path collective, weak scaling (B pairs per rank per step).
-Prints ONE JSON line on rank 0.
+barrier and the max-over-ranks clock); stereo pairs are sharded with no data-path
+collective (frontend: pair k -> rank k mod N; track: rank r tracks its own sequence,
+seed + r), weak scaling.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import importlib
 import json
 import os
 import sys
@@ -32,43 +35,56 @@ PITCH = 1280                         # HBM row pitch of the resident images (64-
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 S_PYR = sum(1.44 ** -k for k in range(8))   # 3.0957: pyramid pixels / level-0 pixels
 ALGO_BYTES_PER_PAIR = 14.0e6         # SURVEY.md section 8d / BASELINE.md section 4
-FAST_BYTES_PER_IMAGE = S_PYR * W * H  # the "S [FAST read]" term of that model
+# per-kernel algorithmic bytes per IMAGE (terms of the SURVEY 8d traffic model)
+KERNEL_BYTES_PER_IMAGE = {
+    "k_fast": S_PYR * W * H,                      # "S [FAST read]"
+    "k_pyr_level": (1 + (S_PYR - 1)) * W * H,     # "1 [src read] + (S-1) [pyramid write]"
+    "k_pyr_fast": (1 + (S_PYR - 1) + S_PYR) * W * H,
+}
 
 
-def make_pairs(B, rank, world):
-    """B synthetic stereo pairs for this rank (pair k of the global stream -> rank k mod N)."""
-    import util
-    Ls, Rs = [], []
-    for i in range(B):
-        k = i * world + rank
-        if k % 16 == 0:                      # every 16th pair: the real street scene
-            L, R = util.urban_pair(W, H, x0=40 + (k // 16) % 60, y0=4 + (k // 16) % 10)
-        else:
-            L, R = util.shifted_pair(0x5EED0000 + k, W, H, disparity=4 + k % 40)
-        Ls.append(L); Rs.append(R)
-    return np.stack(Ls), np.stack(Rs)
+def render_frames(synth, n, dev, seed, start=0):
+    """n consecutive synth-kitti frames rendered on `dev`, padded to PITCH; + ground truth."""
+    L, R, T = synth.render_sequence(n, seed=seed, device=dev, start=start)
+    dL = torch.zeros((n, H, PITCH), dtype=torch.uint8, device=dev)
+    dR = torch.zeros_like(dL)
+    dL[:, :, :W] = L
+    dR[:, :, :W] = R
+    return dL, dR, T
 
 
-def to_device(imgs, dev):
-    t = torch.zeros((imgs.shape[0], H, PITCH), dtype=torch.uint8, device=dev)
-    t[:, :, :W] = torch.from_numpy(imgs).to(dev)
-    return t
+def ate_rmse(res, T_gt):
+    """Translation RMSE of the estimated camera centres vs ground truth (no alignment:
+    both start at the identity)."""
+    err = []
+    for k in range(len(res)):
+        Tcw = res[k]["Tcw"].reshape(4, 4).astype(np.float64)
+        Twc = np.linalg.inv(Tcw)
+        err.append(np.linalg.norm(Twc[:3, 3] - T_gt[k][:3, 3]))
+    return float(np.sqrt(np.mean(np.square(err)))), float(err[-1])
 
 
-def cpu_baseline(pairs_L, pairs_R, cam, budget_s=15.0):
+def cpu_baseline(Lh, Rh, cam, workload, budget_s=15.0):
     """The oracle (a single-threaded C port of the same path) timed on this box's host
     cores over a bounded sample of the same workload."""
     from oracle import binding as orc
     orc.build()
     n, t0 = 0, time.perf_counter()
-    while n < len(pairs_L) and (time.perf_counter() - t0) < budget_s:
-        orc.stereo_frame(pairs_L[n], pairs_R[n], cam.bf, cam.fx)
+    trk = orc.Tracker(W, H, dict(fx=cam.fx, fy=cam.fy, cx=cam.cx, cy=cam.cy, bf=cam.bf)) \
+        if workload == "track" else None
+    poses = []
+    while n < len(Lh) and (time.perf_counter() - t0) < budget_s:
+        if trk is not None:
+            poses.append(trk.track(Lh[n], Rh[n])[0])
+        else:
+            orc.stereo_frame(Lh[n], Rh[n], cam.bf, cam.fx)
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "stereo pairs/s", "cores": 1, "kind": "port",
-            "sample": "%d pairs of the benchmark batch (ORB on L and R + sparse stereo), %.1f s, "
-                      "oracle/libsvo_oracle.so single thread; host has %d cores"
-                      % (n, dt, os.cpu_count() or 0)}
+    what = "full tracking loop" if workload == "track" else "ORB on L and R + sparse stereo"
+    out = {"value": n / dt, "unit": "stereo pairs/s", "cores": 1, "kind": "port",
+           "sample": "first %d pairs of the benchmark frames (%s), %.1f s, oracle/libsvo_oracle.so "
+                     "single thread; host has %d cores" % (n, what, dt, os.cpu_count() or 0)}
+    return out, poses
 
 
 def main():
@@ -80,6 +96,7 @@ def main():
     ap.add_argument("--workload", default="frontend", choices=["frontend", "track"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-track-leg", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -97,18 +114,39 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     pkg = svo_loader.load()
+    synth = importlib.import_module("stereo_semantic_vo_amd.synth")
     cam = pkg.Camera(**pkg.KITTI_00_02)
     B = args.batch
     svo = pkg.Svo(W, H, device=local, max_kp=500, max_batch=B)
-    Lh, Rh = make_pairs(B, rank, world)
-    dL, dR = to_device(Lh, dev), to_device(Rh, dev)
-    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_depth = torch.zeros((B, 500), dtype=torch.float32, device=dev)
+    track = args.workload == "track"
+    seed = synth.BASE_SEED + (rank if track else 0)
+    if track:
+        n_frames = B * (args.warmup + args.steps)       # one continuous sequence per rank
+        dL, dR, T_gt = render_frames(synth, n_frames, dev, seed)
+        d_res = torch.zeros((n_frames, pkg.TRACK_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        svo.track_reset(cam)
+    else:
+        # B pairs per rank: global pair k -> rank k mod N (frame index k of one sequence)
+        frames = [synth.render_sequence(1, seed=seed, device=dev, start=i * world + rank) for i in range(B)]
+        dL = torch.zeros((B, H, PITCH), dtype=torch.uint8, device=dev)
+        dR = torch.zeros_like(dL)
+        for i, (L, R, _) in enumerate(frames):
+            dL[i, :, :W] = L[0]
+            dR[i, :, :W] = R[0]
+        d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+        d_depth = torch.zeros((B, 500), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
+    frame_bytes = H * PITCH
+    rec = pkg.TRACK_DTYPE.itemsize
 
-    def step():
-        svo.frontend_batch_dev(dL.data_ptr(), dR.data_ptr(), PITCH, B, cam,
-                               d_nL=d_n.data_ptr(), d_depth=d_depth.data_ptr())
+    def step(s):
+        if track:
+            off = s * B
+            svo.track_batch_dev(dL.data_ptr() + off * frame_bytes, dR.data_ptr() + off * frame_bytes,
+                                PITCH, B, d_res.data_ptr() + off * rec)
+        else:
+            svo.frontend_batch_dev(dL.data_ptr(), dR.data_ptr(), PITCH, B, cam,
+                                   d_nL=d_n.data_ptr(), d_depth=d_depth.data_ptr())
 
     def fence():
         svo.sync()
@@ -116,15 +154,15 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
+    for s in range(args.warmup):
+        step(s)
     fence()
     if not args.no_profile:
         svo.profile_reset()
         svo.profile_enable(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for s in range(args.warmup, args.warmup + args.steps):
+        step(s)
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -136,27 +174,37 @@ def main():
         svo.profile_enable(False)
         prof = svo.profile()
 
-    n_kp = d_n.cpu().numpy()
-    n_depth = int((d_depth > 0).sum().item())
     if rank == 0:
         pairs = world * B * args.steps
+        cfg = {"pairs_per_step_per_gpu": B}
+        if track:
+            res = d_res.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(-1)
+            rmse, last = ate_rmse(res, T_gt.numpy())
+            cfg.update({"workload": "synth-kitti00 sequence 1241x376, full Tracking::Track loop per frame: ORB on L and R, "
+                                    "sparse stereo, matching passes 1+2, PnP-RANSAC, pose-only LM, map-point "
+                                    "lifecycle (BASELINE configs[2]); one sequence per GPU",
+                        "frames_tracked": int(len(res)), "ate_rmse_m_vs_ground_truth": rmse,
+                        "final_position_error_m": last, "path_length_m": float(len(res) - 1),
+                        "mean_lm_edges": float(res["n_lm_edges"][1:].mean())})
+        else:
+            n_kp = d_n.cpu().numpy()
+            cfg.update({"workload": "synth-kitti00 stereo pairs 1241x376: ORB pyramid (8 levels, 500 kp) on L and R "
+                                    "+ sparse epipolar stereo, HBM-resident (BASELINE configs[1], batched)",
+                        "sharding": "pair k -> rank k mod N, no collective",
+                        "mean_keypoints_left": float(n_kp.mean()),
+                        "mean_stereo_depths": int((d_depth > 0).sum().item()) / B})
         out = {
             "metric": "stereo frames/sec on KITTI 00 (tracking front end)",
             "value": pairs / dt, "unit": "stereo pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8",
-            "data": "synthetic",
-            "config": {"workload": "kitti00-shaped stereo pairs 1241x376: ORB pyramid (8 levels, 500 kp) on "
-                                   "L and R + sparse epipolar stereo, HBM-resident (BASELINE configs[1], batched)",
-                       "pairs_per_step_per_gpu": B, "sharding": "pair k -> rank k mod N, no collective",
-                       "mean_keypoints_left": float(n_kp.mean()), "mean_stereo_depths": n_depth / B},
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic", "config": cfg,
         }
         if prof:
             kern = {k: {"avg_ms": v[0] / max(v[1], 1), "launches": v[1]} for k, v in prof.items()}
-            dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
+            cand = {k: v for k, v in prof.items() if k in KERNEL_BYTES_PER_IMAGE}
+            dom = max(cand.items(), key=lambda kv: kv[1][0])[0]
             dom_s = prof[dom][0] / max(prof[dom][1], 1) * 1e-3
-            algo = {"k_fast": FAST_BYTES_PER_IMAGE * 2 * B,
-                    "k_pyr_level": (2 * S_PYR - 1) * W * H * 2 * B}.get(dom, ALGO_BYTES_PER_PAIR * B)
+            algo = KERNEL_BYTES_PER_IMAGE[dom] * 2 * B
             ach = algo / dom_s / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
@@ -164,7 +212,35 @@ def main():
                                "pipeline_frac": ALGO_BYTES_PER_PAIR * (pairs / dt / world) / 1e9 / HBM_PEAK_GBS}
             out["kernels"] = kern
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(Lh, Rh, cam)
+            ns = min(B * (args.warmup + args.steps) if track else B, 64)
+            Lh = dL[:ns, :, :W].cpu().numpy()
+            Rh = dR[:ns, :, :W].cpu().numpy()
+            out["cpu_baseline"], cpu_poses = cpu_baseline(Lh, Rh, cam, args.workload)
+            if track and cpu_poses:
+                k = len(cpu_poses) - 1
+                a = np.linalg.inv(res[k]["Tcw"].reshape(4, 4).astype(np.float64))[:3, 3]
+                b = np.linalg.inv(cpu_poses[k]["Tcw"].reshape(4, 4).astype(np.float64))[:3, 3]
+                out["cpu_baseline"]["gpu_vs_cpu_position_diff_m_at_frame_%d" % k] = float(np.linalg.norm(a - b))
+        if world == 1 and not track and not args.no_track_leg:
+            # bounded full-tracking leg (configs[2]) so the default line also carries it
+            svo.profile_enable(False)
+            nt = 256
+            tL, tR, tT = render_frames(synth, nt, dev, synth.BASE_SEED)
+            tres = torch.zeros((nt, rec), dtype=torch.uint8, device=dev)
+            tb = min(B, 128)
+            svo.track_reset(cam)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for off in range(0, nt, tb):
+                svo.track_batch_dev(tL.data_ptr() + off * frame_bytes, tR.data_ptr() + off * frame_bytes,
+                                    PITCH, min(tb, nt - off), tres.data_ptr() + off * rec)
+            svo.sync()
+            tdt = time.perf_counter() - t1
+            r = tres.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(-1)
+            rmse, last = ate_rmse(r, tT.numpy())
+            out["track"] = {"value": nt / tdt, "unit": "stereo pairs/s", "frames": nt,
+                            "ate_rmse_m_vs_ground_truth": rmse, "final_position_error_m": last,
+                            "note": "one sequence, strict frame order (BASELINE configs[2]); includes the front end"}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

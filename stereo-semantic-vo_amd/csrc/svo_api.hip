@@ -103,7 +103,7 @@ static void build_geometry(SvoGeom& g, int W, int H, int nfeatures) {
     g.tile_base[l] = tb;
     tb += g.tiles_x[l] * g.tiles_y[l];
     g.xtab_off[l] = xt; g.ytab_off[l] = yt;
-    xt += g.w[l]; yt += g.h[l];
+    xt += (g.w[l] + 3) / 4 * 4 + 4; yt += g.h[l];   // x tables padded for 16-byte loads
   }
   g.tile_base[SVO_NLEVELS] = tb;
   g.pyr_bytes = off;
@@ -115,7 +115,7 @@ static void build_resize_tables(const SvoGeom& g, std::vector<int32_t>& xofs,
                                 std::vector<int32_t>& xalpha, std::vector<int32_t>& yofs,
                                 std::vector<int32_t>& ybeta) {
   int xt = 0, yt = 0;
-  for (int l = 0; l < SVO_NLEVELS; ++l) { xt += g.w[l]; yt += g.h[l]; }
+  for (int l = 0; l < SVO_NLEVELS; ++l) { xt += (g.w[l] + 3) / 4 * 4 + 4; yt += g.h[l]; }
   xofs.assign(xt, 0); xalpha.assign(xt, 0); yofs.assign(yt, 0); ybeta.assign(yt, 0);
   for (int l = 1; l < SVO_NLEVELS; ++l) {
     const int sw = g.w[l - 1], sh = g.h[l - 1], dw = g.w[l], dh = g.h[l];
@@ -129,6 +129,11 @@ static void build_resize_tables(const SvoGeom& g, std::vector<int32_t>& xofs,
       const int a0 = (short)cv_round_f((1.f - fx) * 2048.f), a1 = (short)cv_round_f(fx * 2048.f);
       xofs[g.xtab_off[l] + dx] = sx;
       xalpha[g.xtab_off[l] + dx] = (a0 & 0xffff) | (a1 << 16);
+    }
+    // padding entries (read by the last 16-byte table load of a row) repeat the last column
+    for (int dx = dw; dx < (dw + 3) / 4 * 4 + 4; ++dx) {
+      xofs[g.xtab_off[l] + dx] = xofs[g.xtab_off[l] + dw - 1];
+      xalpha[g.xtab_off[l] + dx] = xalpha[g.xtab_off[l] + dw - 1];
     }
     for (int dy = 0; dy < dh; ++dy) {
       float fy = (float)((dy + 0.5) * scale_y - 0.5);

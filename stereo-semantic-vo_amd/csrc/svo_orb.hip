@@ -41,6 +41,8 @@ __device__ __forceinline__ const uint8_t* level_ptr(const SvoGeom& g, const ImgS
 // (11-bit coefficients; vertical pass ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2)>>2).
 // One thread = 4 output pixels = one dword store; rows are coalesced.
 // ---------------------------------------------------------------------------------
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+
 __global__ __launch_bounds__(256) void k_pyr_level(SvoGeom g, ImgSrc s, int l, uint8_t* pyr,
                                                    const int32_t* __restrict__ xofs,
                                                    const int32_t* __restrict__ xalpha,
@@ -60,20 +62,41 @@ __global__ __launch_bounds__(256) void k_pyr_level(SvoGeom g, ImgSrc s, int l, u
   const int b0 = (int)(int16_t)(bb & 0xffff), b1 = bb >> 16;
   const uint8_t* r0 = src + (size_t)sy0 * sp;
   const uint8_t* r1 = src + (size_t)sy1 * sp;
+  // the tables are padded to multiples of 4 entries per level: one 16-byte load each
+  const int4 so = *reinterpret_cast<const int4*>(xofs + g.xtab_off[l] + dx4);
+  const int4 sa = *reinterpret_cast<const int4*>(xalpha + g.xtab_off[l] + dx4);
+  const int sx[4] = {so.x, so.y, so.z, so.w};
+  const int al[4] = {sa.x, sa.y, sa.z, sa.w};
   uint32_t out = 0;
+  const int base = sx[0];
+  if (base + 8 <= sw) {
+    // the 4 outputs read source columns base .. base+5: one unaligned 8-byte load per row
+    const uint64_t w0 = *reinterpret_cast<const u64_unaligned*>(r0 + base);
+    const uint64_t w1 = *reinterpret_cast<const u64_unaligned*>(r1 + base);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int dx = dx4 + k;
-    if (dx < dw) {
-      const int sx0 = xofs[g.xtab_off[l] + dx];
-      const int sx1 = min(sx0 + 1, sw - 1);
-      const int aa = xalpha[g.xtab_off[l] + dx];
-      const int a0 = (int)(int16_t)(aa & 0xffff), a1 = aa >> 16;
-      const int S0 = r0[sx0] * a0 + r0[sx1] * a1;
-      const int S1 = r1[sx0] * a0 + r1[sx1] * a1;
+    for (int k = 0; k < 4; ++k) {
+      const int sh0 = 8 * (sx[k] - base);
+      const int a0 = (int)(int16_t)(al[k] & 0xffff), a1 = al[k] >> 16;
+      const int p00 = (int)((w0 >> sh0) & 0xff), p01 = (int)((w0 >> (sh0 + 8)) & 0xff);
+      const int p10 = (int)((w1 >> sh0) & 0xff), p11 = (int)((w1 >> (sh0 + 8)) & 0xff);
+      const int S0 = p00 * a0 + p01 * a1;
+      const int S1 = p10 * a0 + p11 * a1;
       int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
       v = min(max(v, 0), 255);
       out |= (uint32_t)v << (8 * k);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (dx4 + k < dw) {
+        const int sx0 = sx[k], sx1 = min(sx0 + 1, sw - 1);
+        const int a0 = (int)(int16_t)(al[k] & 0xffff), a1 = al[k] >> 16;
+        const int S0 = r0[sx0] * a0 + r0[sx1] * a1;
+        const int S1 = r1[sx0] * a0 + r1[sx1] * a1;
+        int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+        v = min(max(v, 0), 255);
+        out |= (uint32_t)v << (8 * k);
+      }
     }
   }
   uint8_t* dst = pyr + (size_t)img * g.pyr_bytes + g.loff[l] + (size_t)dy * g.pitch[l];
@@ -87,37 +110,54 @@ __global__ __launch_bounds__(256) void k_pyr_level(SvoGeom g, ImgSrc s, int l, u
 // (tile + 1 ring for NMS; 8 consecutive pixels per thread from 7 x 16-byte LDS row
 // reads), suppresses non-maxima in LDS and appends survivors to the level list.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ int has9(uint32_t m) {  // 9 contiguous set bits in a circular 16-bit mask
-  uint32_t m2 = m | (m << 16);
-  uint32_t x = m2 & (m2 >> 1);
-  x &= x >> 2;
-  x &= x >> 4;
-  x &= m2 >> 8;
-  return (x & 0xffffu) != 0;
+// Corner score of TWO horizontally adjacent pixels at once in packed 16-bit lanes
+// (v_pk_sub/min/max_i16): d[i] = centre - ring[i]; score = max over the 16 arcs of 9 of
+// min(d) (dark ring) and of min(-d) (bright ring), minus 1; 0 unless that exceeds the
+// threshold.  Branch-free - a 64-wide wave never diverges on the rare corner pixels.  The
+// ring pixel pairs are cut out of the staged 16-byte row windows with v_perm_b32.
+typedef short v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s as_v2s(uint32_t x) { return __builtin_bit_cast(v2s, x); }
+__device__ __forceinline__ uint32_t as_u32(v2s x) { return __builtin_bit_cast(uint32_t, x); }
+template <int B>
+__device__ __forceinline__ v2s pix_pair(const uint32_t* row) {  // bytes B, B+1 -> two i16 lanes
+  constexpr int w = B >> 2, k = B & 3;
+  constexpr uint32_t sel = 0x0c000c00u | ((uint32_t)(k + 1) << 16) | (uint32_t)k;
+  return as_v2s(__builtin_amdgcn_perm(row[w + 1 > 3 ? 3 : w + 1], row[w], sel));
 }
-
-__device__ __forceinline__ int fast_score16(const int d[16]) {
-  int a1[16], b1[16];
+#define VMIN(a, b) __builtin_elementwise_min(a, b)
+#define VMAX(a, b) __builtin_elementwise_max(a, b)
+template <int K>
+__device__ __forceinline__ uint32_t fast_pair(const uint32_t (&rw)[7][4]) {
+  constexpr int cc = 4 + K;  // byte column of the first centre inside the 16-byte window
+  const v2s v = pix_pair<cc>(rw[3]);
+  v2s d[16];
+  d[0] = v - pix_pair<cc>(rw[6]);      d[1] = v - pix_pair<cc + 1>(rw[6]);  d[2] = v - pix_pair<cc + 2>(rw[5]);
+  d[3] = v - pix_pair<cc + 3>(rw[4]);  d[4] = v - pix_pair<cc + 3>(rw[3]);  d[5] = v - pix_pair<cc + 3>(rw[2]);
+  d[6] = v - pix_pair<cc + 2>(rw[1]);  d[7] = v - pix_pair<cc + 1>(rw[0]);  d[8] = v - pix_pair<cc>(rw[0]);
+  d[9] = v - pix_pair<cc - 1>(rw[0]);  d[10] = v - pix_pair<cc - 2>(rw[1]); d[11] = v - pix_pair<cc - 3>(rw[2]);
+  d[12] = v - pix_pair<cc - 3>(rw[3]); d[13] = v - pix_pair<cc - 3>(rw[4]); d[14] = v - pix_pair<cc - 2>(rw[5]);
+  d[15] = v - pix_pair<cc - 1>(rw[6]);
+  v2s a1[16], b1[16], a2[16], b2[16], a9[16], b9[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { a1[i] = VMIN(d[i], d[(i + 1) & 15]); b1[i] = VMAX(d[i], d[(i + 1) & 15]); }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { a2[i] = VMIN(a1[i], a1[(i + 2) & 15]); b2[i] = VMAX(b1[i], b1[(i + 2) & 15]); }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    a1[i] = min(d[i], d[(i + 1) & 15]);
-    b1[i] = max(d[i], d[(i + 1) & 15]);
+    a9[i] = VMIN(VMIN(a2[i], a2[(i + 4) & 15]), d[(i + 8) & 15]);
+    b9[i] = VMAX(VMAX(b2[i], b2[(i + 4) & 15]), d[(i + 8) & 15]);
   }
-  int a2[16], b2[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    a2[i] = min(a1[i], a1[(i + 2) & 15]);
-    b2[i] = max(b1[i], b1[(i + 2) & 15]);
-  }
-  int A = -256, Bm = 256;
+  for (int s = 8; s > 0; s >>= 1)   // balanced trees: dependent v_pk ops need a wait state
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    int a = min(min(a2[i], a2[(i + 4) & 15]), d[(i + 8) & 15]);
-    int b = max(max(b2[i], b2[(i + 4) & 15]), d[(i + 8) & 15]);
-    A = max(A, a);
-    Bm = min(Bm, b);
-  }
-  return max(A, -Bm) - 1;
+    for (int i = 0; i < s; ++i) { a9[i] = VMAX(a9[i], a9[i + s]); b9[i] = VMIN(b9[i], b9[i + s]); }
+  const v2s zero = {0, 0}, cT = {SVO_FAST_THR, SVO_FAST_THR}, one = {1, 1},
+            cTm1 = {SVO_FAST_THR - 1, SVO_FAST_THR - 1};
+  const v2s S = VMAX(a9[0], zero - b9[0]);
+  const v2s u = VMAX(S, cT) - cT;             // S - T if S > T else 0
+  const v2s r = u + VMIN(u, one) * cTm1;      // S - 1 if S > T else 0
+  const uint32_t x = as_u32(r);
+  return (x & 0xffu) | ((x >> 8) & 0xff00u);  // two score bytes
 }
 
 #define PXW 34  // dwords per staged pixel row (136 bytes)
@@ -177,30 +217,9 @@ __global__ __launch_bounds__(256) void k_fast(SvoGeom g, ImgSrc s, uint32_t* cor
       const uint2 hi = *reinterpret_cast<const uint2*>(&px[(r + j) * PXW + 2 * c + 2]);
       rw[j][0] = lo.x; rw[j][1] = lo.y; rw[j][2] = hi.x; rw[j][3] = hi.y;
     }
-#define PIX(j, cc) (int)((rw[(j)][(cc) >> 2] >> (8 * ((cc) & 3))) & 0xffu)
-    uint32_t out[2] = {0, 0};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int cc = 4 + k;  // byte column of the centre inside the 16-byte window
-      const int v = PIX(3, cc);
-      int d[16];
-      d[0] = v - PIX(6, cc);      d[1] = v - PIX(6, cc + 1);  d[2] = v - PIX(5, cc + 2);
-      d[3] = v - PIX(4, cc + 3);  d[4] = v - PIX(3, cc + 3);  d[5] = v - PIX(2, cc + 3);
-      d[6] = v - PIX(1, cc + 2);  d[7] = v - PIX(0, cc + 1);  d[8] = v - PIX(0, cc);
-      d[9] = v - PIX(0, cc - 1);  d[10] = v - PIX(1, cc - 2); d[11] = v - PIX(2, cc - 3);
-      d[12] = v - PIX(3, cc - 3); d[13] = v - PIX(4, cc - 3); d[14] = v - PIX(5, cc - 2);
-      d[15] = v - PIX(6, cc - 1);
-      uint32_t dark = 0, bright = 0;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        dark |= (uint32_t)(d[i] > SVO_FAST_THR) << i;
-        bright |= (uint32_t)(d[i] < -SVO_FAST_THR) << i;
-      }
-      int score = 0;
-      if (has9(dark) || has9(bright)) score = fast_score16(d);
-      out[k >> 2] |= (uint32_t)score << (8 * (k & 3));
-    }
-#undef PIX
+    uint32_t out[2];
+    out[0] = fast_pair<0>(rw) | (fast_pair<2>(rw) << 16);
+    out[1] = fast_pair<4>(rw) | (fast_pair<6>(rw) << 16);
     *reinterpret_cast<uint2*>(&sc[r * (SCW / 4) + 2 * c]) = make_uint2(out[0], out[1]);
   }
   __syncthreads();

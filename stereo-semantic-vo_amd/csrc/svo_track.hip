@@ -9,6 +9,9 @@
 // deterministic stand-in for the reference's std::set<mappoint*> address order); after each
 // frame it is stably compacted into the other half of a ping-pong buffer, so "local map
 // point r" is simply row r and the pass-2 distance matrix needs no gather.
+// The reference also stores match_score[i] = second/best for every pass-1 row
+// (src/pnpmatch.cc:99); nothing ever reads it (its only use is commented out at
+// src/Optimizer.cc:54), so the tracker does not materialise it - svo_match_greedy does.
 // Offline detection boxes (semantic gating, SURVEY f-3) are not modelled yet.
 #include <cstddef>
 
@@ -40,6 +43,7 @@ struct TrackState {
   svo_pnp_stats pnp;
   svo_camera cam;
   TrackPool pool[2];
+  uint16_t rowmin[TRK_CAP];    // min over ALL current keypoints of the row's distances
   uint16_t D[(size_t)TRK_CAP * 512];
 };
 
@@ -147,6 +151,7 @@ __global__ __launch_bounds__(256) void k_tk_dist(TrackState* st, const uint32_t*
   uint32_t qd[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) qd[k] = P.desc[8 * m + k];
+  uint32_t mn = 0x7fff;
   for (int j = lane; j < 512; j += 64) {
     int d = 0x7fff;
     if (j < nkp) {
@@ -154,8 +159,11 @@ __global__ __launch_bounds__(256) void k_tk_dist(TrackState* st, const uint32_t*
 #pragma unroll
       for (int k = 0; k < 8; ++k) d += __popc(qd[k] ^ td[j * 8 + k]);
     }
+    mn = min(mn, (uint32_t)d);
     st->D[(size_t)row * 512 + j] = (uint16_t)d;
   }
+  mn = tk_wmin(mn);
+  if (lane == 0) st->rowmin[row] = (uint16_t)mn;
 }
 
 // ---- 3/5. the order-dependent greedy assignment, one wave -----------------------------------
@@ -185,6 +193,10 @@ __global__ __launch_bounds__(64) void k_tk_greedy(TrackState* st, int pass) {
       } else {
         valid = P.in_local[m] && !P.bad[m] && P.obs_frame[m] != id;
       }
+      // a row can only be accepted if its best distance over the unclaimed columns is
+      // < max_dist; the minimum over ALL columns bounds that from below, so rows that
+      // fail it are skipped without changing any result (they never claim a column).
+      valid = valid && st->rowmin[i] < max_dist;
     }
     const uint64_t mask = __ballot(valid);
     if (valid) {
@@ -278,7 +290,6 @@ __global__ __launch_bounds__(512) void k_tk_end(TrackState* st, const svo_kp* kp
                                                 svo_track_result* res_out) {
   __shared__ int sm[512];
   __shared__ float sT[16], sRwc[9], stwc[3];
-  __shared__ int s_np;
   const int tid = threadIdx.x;
   const int nkp = st->nkp, id = st->frame_num;
   TrackPool& P = st->pool[st->cur];

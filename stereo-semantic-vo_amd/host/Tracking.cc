@@ -1,0 +1,132 @@
+#include "Tracking.h"
+
+#include <iomanip>
+#include <sstream>
+#include <stdexcept>
+
+#include "Optimizer.h"
+#include "convert.h"
+#include "pnpmatch.h"
+
+using namespace svo_host;
+
+// cv::FileStorage stand-in: "Camera.fx: 718.856" style keys of Stereo/KITTI*.yaml
+bool read_camera_yaml(const std::string& path, svo_camera& cam, int* width, int* height) {
+  std::ifstream in(path);
+  if (!in) return false;
+  std::string line;
+  int found = 0;
+  while (std::getline(in, line)) {
+    const size_t c = line.find(':');
+    if (c == std::string::npos || line[0] == '#' || line[0] == '%') continue;
+    const std::string key = line.substr(0, c);
+    const double v = atof(line.c_str() + c + 1);
+    if (key == "Camera.fx") { cam.fx = (float)v; ++found; }
+    else if (key == "Camera.fy") { cam.fy = (float)v; ++found; }
+    else if (key == "Camera.cx") { cam.cx = (float)v; ++found; }
+    else if (key == "Camera.cy") { cam.cy = (float)v; ++found; }
+    else if (key == "Camera.bf") { cam.bf = (float)v; ++found; }
+    else if (key == "Camera.width" && width) *width = (int)v;
+    else if (key == "Camera.height" && height) *height = (int)v;
+  }
+  return found == 5;
+}
+
+Tracking::Tracking(const std::string& strSettingPath, int dev) : device(dev) {
+  int w = 1241, h = 376;
+  if (!read_camera_yaml(strSettingPath, K, &w, &h)) throw std::runtime_error("bad settings file " + strSettingPath);
+  bf = K.bf;
+  if (svo_create(&ctx, device, w, h, 500, 1) != SVO_OK) throw std::runtime_error("svo_create failed (no GPU?)");
+  Velocity = eye4();
+}
+Tracking::Tracking(const svo_camera& cam, int w, int h, int dev) : device(dev), K(cam), bf(cam.bf) {
+  if (svo_create(&ctx, device, w, h, 500, 1) != SVO_OK) throw std::runtime_error("svo_create failed (no GPU?)");
+  Velocity = eye4();
+}
+Tracking::~Tracking() { svo_destroy(ctx); }
+
+void Tracking::init() {
+  bool dynamic = false;   // declared outside the loop and never reset, exactly as src/Tracking.cc:44
+  currentframe->SetPose(eye4());
+  Velocity = eye4();
+  const int n = (int)currentframe->keypoints_l.size();
+  for (int i = 0; i < n && i < currentframe->N; ++i) {
+    const float u = currentframe->keypoints_l[i].x, v = currentframe->keypoints_l[i].y;
+    const float z = currentframe->kp_depth[i];
+    for (const auto& b : currentframe->offline_box)
+      if (u > b[0] - 5 && u < b[1] + 5 && v > b[2] - 5 && v < b[3] + 5) { dynamic = true; break; }
+    Vec3f x3D;
+    if (z > 0 && !dynamic && currentframe->UnprojectStereo(u, v, z, x3D)) {
+      mappoint* newmp = new mappoint(x3D, currentframe, i);
+      newmp->AddObservation(currentframe, i);
+      newmp->create_id = (int)currentframe->id;
+      LocalMapPoints.insert(newmp);
+      currentframe->MapPoints[i] = newmp;
+    }
+  }
+}
+
+void Tracking::GetVelocity() {
+  // Velocity = Tcw * LastTwc (computed, never consumed - src/Tracking.cc:99-106)
+  const Mat44f LastTwc = convert::R_t_to_Twc(lastframe.Rcw, lastframe.tcw);
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) {
+      double acc = 0;
+      for (int k = 0; k < 4; ++k) acc += (double)currentframe->Tcw.at(r, k) * (double)LastTwc.at(k, c);
+      Velocity.at(r, c) = (float)acc;
+    }
+}
+
+void Tracking::Tracklastframe() {
+  if (frame_num == 0) init();
+  else pnpmatch::poseEstimationPnP(currentframe, lastframe, LocalMapPoints, Velocity, K);
+  Optimizer::PoseOptimization(currentframe);
+}
+
+void Tracking::SaveTrajectoryAndDraw(std::ofstream& f, std::ofstream& f2) {
+  const Mat33f& R = currentframe->Rwc;
+  const std::vector<float> q = convert::toQuaternion(R);
+  const Vec3f& t = currentframe->twc;
+  if (f2.is_open())
+    f2 << std::setprecision(6) << currentframe->timestamp << std::setprecision(7) << " " << t.at(0) << " "
+       << t.at(1) << " " << t.at(2) << " " << q[0] << " " << q[1] << " " << q[2] << " " << q[3] << std::endl;
+  if (f.is_open())
+    f << std::setprecision(9) << R.at(0, 0) << " " << R.at(0, 1) << " " << R.at(0, 2) << " " << t.at(0) << " "
+      << R.at(1, 0) << " " << R.at(1, 1) << " " << R.at(1, 2) << " " << t.at(1) << " " << R.at(2, 0) << " "
+      << R.at(2, 1) << " " << R.at(2, 2) << " " << t.at(2) << std::endl;
+}
+
+void Tracking::Track(const GrayImage& imLeft, const GrayImage& imRight, double timestamp, std::ofstream& f,
+                     std::ofstream& f2, const std::vector<std::vector<int>>& detection_box) {
+  currentframe = new frame(ctx, imLeft, imRight, timestamp, K, detection_box);
+  currentframe->MB(imLeft, imRight);      // featuredetect + stereo association in one device pass
+  currentframe->computekeypoint_r();
+  currentframe->disp2Depth(bf);
+  currentframe->id = frame_num;
+  Tracklastframe();
+  SaveTrajectoryAndDraw(f, f2);
+  if (frame_num > 0) GetVelocity();
+  frame* prev = currentframe;
+  lastframe = frame(currentframe);
+  lastframe.createmappoint(LocalMapPoints);
+  if (frame_num >= 4) {
+    for (auto it = LocalMapPoints.begin(); it != LocalMapPoints.end();) {
+      if ((*it)->create_id <= frame_num - 4) it = LocalMapPoints.erase(it);
+      else ++it;
+    }
+  }
+  // The reference leaks every frame (`new frame`, never deleted).  Map points key their
+  // observations by the frame's ADDRESS, so the object must stay allocated for addresses to
+  // remain unique; its payload (images, keypoints, descriptors) is released instead.
+  prev->leftimg = GrayImage(); prev->rightimg = GrayImage();
+  std::vector<svo_kp>().swap(prev->keypoints_l);
+  std::vector<uint8_t>().swap(prev->f_descriptor);
+  std::vector<float>().swap(prev->keypoints_r);
+  std::vector<float>().swap(prev->kp_disp);
+  std::vector<float>().swap(prev->kp_depth);
+  std::vector<mappoint*>().swap(prev->MapPoints);
+  std::vector<float>().swap(prev->match_score);
+  std::vector<bool>().swap(prev->inlier);
+  currentframe = nullptr;
+  frame_num++;
+}

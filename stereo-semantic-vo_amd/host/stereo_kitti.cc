@@ -1,0 +1,89 @@
+// stereo_kitti.cc - the reference's driver (main.cpp:100-210) over the MI355X front end.
+// usage: stereo_kitti <vocabulary (ignored, as in the reference)> <settings.yaml> <sequence_dir>
+// Sequence layout as main.cpp:20-57: times.txt, image_2/NNNNNN.png, image_3/NNNNNN.png (gray
+// image_0/image_1 and .pgm are accepted too).  Writes cameratrajectory_kitti.txt / _tum.txt and
+// prints the median / mean tracking time exactly like main.cpp:200-208.  No GUI, no pacing sleep,
+// offline detection boxes: <sequence_dir>/boxes/<ni+1>.txt (optional; 4 ints per line,
+// left right top bottom - main.cpp:82-95).
+#include <algorithm>
+#include <chrono>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+
+#include "Tracking.h"
+#include "png_reader.h"
+
+using namespace svo_host;
+
+static bool exists(const std::string& p) { FILE* f = fopen(p.c_str(), "rb"); if (f) fclose(f); return f != nullptr; }
+
+int main(int argc, char** argv) {
+  if (argc == 4 && std::string(argv[1]) == "--decode") {   // image codec self-test: png/pgm -> pgm
+    GrayImage img;
+    if (!read_image(argv[2], img)) return 1;
+    FILE* o = fopen(argv[3], "wb");
+    if (!o) return 1;
+    fprintf(o, "P5\n%d %d\n255\n", img.cols, img.rows);
+    fwrite(img.data.data(), 1, img.data.size(), o);
+    fclose(o);
+    return 0;
+  }
+  if (argc != 4) {
+    std::cerr << "Usage: ./stereo_kitti path_to_vocabulary path_to_settings path_to_sequence" << std::endl;
+    return 1;
+  }
+  const std::string seq = argv[3];
+  std::vector<double> vTimestamps;
+  {
+    std::ifstream fTimes(seq + "/times.txt");
+    std::string s;
+    while (std::getline(fTimes, s))
+      if (!s.empty()) vTimestamps.push_back(atof(s.c_str()));
+  }
+  const int nImages = (int)vTimestamps.size();
+  if (nImages == 0) { std::cerr << "no times.txt in " << seq << std::endl; return 1; }
+  auto name = [&](const char* dir, int i, const char* ext) {
+    std::stringstream ss;
+    ss << seq << "/" << dir << "/" << std::setfill('0') << std::setw(6) << i << ext;
+    return ss.str();
+  };
+  const char* dl = "image_2"; const char* dr = "image_3"; const char* ext = ".png";
+  if (!exists(name(dl, 0, ext))) { dl = "image_0"; dr = "image_1"; }
+  if (!exists(name(dl, 0, ext))) { ext = ".pgm"; }
+  if (!exists(name(dl, 0, ext))) { dl = "image_2"; dr = "image_3"; }
+  Tracking* mpTracker = new Tracking(argv[2]);
+  std::ofstream f("cameratrajectory_kitti.txt"); f << std::fixed;
+  std::ofstream f2("cameratrajectory_tum.txt"); f2 << std::fixed;
+  std::vector<float> vTimesTrack(nImages);
+  std::cout << std::endl << "-------" << std::endl << "Start processing sequence ..." << std::endl
+            << "Images in the sequence: " << nImages << std::endl << std::endl;
+  for (int ni = 0; ni < nImages; ++ni) {
+    GrayImage imLeft, imRight;
+    if (!read_image(name(dl, ni, ext), imLeft) || !read_image(name(dr, ni, ext), imRight)) {
+      std::cerr << std::endl << "Failed to load image at: " << name(dl, ni, ext) << std::endl;
+      return 1;
+    }
+    std::vector<std::vector<int>> boxes;
+    {
+      std::stringstream bp; bp << seq << "/boxes/" << (ni + 1) << ".txt";
+      std::ifstream bf(bp.str());
+      int l, r, t, b;
+      while (bf >> l >> r >> t >> b) boxes.push_back({l, r, t, b});
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    mpTracker->Track(imLeft, imRight, vTimestamps[ni], f, f2, boxes);
+    const auto t2 = std::chrono::steady_clock::now();
+    vTimesTrack[ni] = (float)std::chrono::duration_cast<std::chrono::duration<double>>(t2 - t1).count();
+  }
+  f.close(); f2.close();
+  std::cout << std::endl << "trajectory saved!" << std::endl;
+  std::sort(vTimesTrack.begin(), vTimesTrack.end());
+  float totaltime = 0;
+  for (int ni = 0; ni < nImages; ++ni) totaltime += vTimesTrack[ni];
+  std::cout << "-------" << std::endl << std::endl;
+  std::cout << "median tracking time: " << vTimesTrack[nImages / 2] << std::endl;
+  std::cout << "mean tracking time: " << totaltime / nImages << std::endl;
+  delete mpTracker;
+  return 0;
+}

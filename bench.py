@@ -99,9 +99,10 @@ def main():
     ap.add_argument("--no-track-leg", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    pkg = svo_loader.load()
+    synth = importlib.import_module("stereo_semantic_vo_amd.synth")
+    shard = importlib.import_module("stereo_semantic_vo_amd.shard")
+    rank, world, local = shard.env_rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     torch.cuda.set_device(local)
@@ -113,13 +114,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    pkg = svo_loader.load()
-    synth = importlib.import_module("stereo_semantic_vo_amd.synth")
     cam = pkg.Camera(**pkg.KITTI_00_02)
     B = args.batch
     svo = pkg.Svo(W, H, device=local, max_kp=500, max_batch=B)
     track = args.workload == "track"
-    seed = synth.BASE_SEED + (rank if track else 0)
+    seed = shard.sequence_seed_for_rank(synth.BASE_SEED, rank) if track else synth.BASE_SEED
     if track:
         n_frames = B * (args.warmup + args.steps)       # one continuous sequence per rank
         dL, dR, T_gt = render_frames(synth, n_frames, dev, seed)
@@ -127,7 +126,7 @@ def main():
         svo.track_reset(cam)
     else:
         # B pairs per rank: global pair k -> rank k mod N (frame index k of one sequence)
-        frames = [synth.render_sequence(1, seed=seed, device=dev, start=i * world + rank) for i in range(B)]
+        frames = [synth.render_sequence(1, seed=seed, device=dev, start=k) for k in shard.pairs_for_rank(rank, world, B)]
         dL = torch.zeros((B, H, PITCH), dtype=torch.uint8, device=dev)
         dR = torch.zeros_like(dL)
         for i, (L, R, _) in enumerate(frames):
@@ -165,10 +164,7 @@ def main():
         step(s)
     fence()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = shard.max_over_ranks(dt, dist, dev)
     prof = {}
     if not args.no_profile:
         svo.profile_enable(False)

@@ -160,6 +160,24 @@ __device__ __forceinline__ uint32_t fast_pair(const uint32_t (&rw)[7][4]) {
   return (x & 0xffu) | ((x >> 8) & 0xff00u);  // two score bytes
 }
 
+// Necessary condition for a 9-arc, from the 4 compass ring pixels only: an arc of 9 covers at
+// least two ADJACENT compass points (0,4,8,12), so two adjacent ones must both be darker (or both
+// brighter) than the centre by more than the threshold.  Returns nonzero if either pixel of the
+// pair can still be a corner.
+template <int K>
+__device__ __forceinline__ uint32_t compass_pair(const uint32_t (&r0)[4], const uint32_t (&r3)[4],
+                                                 const uint32_t (&r6)[4]) {
+  constexpr int cc = 4 + K;
+  const v2s v = pix_pair<cc>(r3);
+  const v2s d0 = v - pix_pair<cc>(r6), d8 = v - pix_pair<cc>(r0);
+  const v2s d4 = v - pix_pair<cc + 3>(r3), d12 = v - pix_pair<cc - 3>(r3);
+  const v2s A = VMAX(VMAX(VMIN(d0, d4), VMIN(d4, d8)), VMAX(VMIN(d8, d12), VMIN(d12, d0)));
+  const v2s B = VMIN(VMIN(VMAX(d0, d4), VMAX(d4, d8)), VMIN(VMAX(d8, d12), VMAX(d12, d0)));
+  const v2s zero = {0, 0}, cT1 = {SVO_FAST_THR + 1, SVO_FAST_THR + 1};
+  const uint32_t x = as_u32(VMAX(A, zero - B) - cT1);   // lane >= 0  <=>  possible corner
+  return ~x & 0x80008000u;
+}
+
 #define PXW 34  // dwords per staged pixel row (136 bytes)
 #define SCW 128 // bytes per score row
 
@@ -169,9 +187,11 @@ __global__ __launch_bounds__(256) void k_fast(SvoGeom g, ImgSrc s, uint32_t* cor
   __shared__ uint32_t sc[16 * (SCW / 4)];
   __shared__ int lhist[256];
   __shared__ uint32_t lcorn[512];
-  __shared__ int lcount, lbase;
+  __shared__ uint16_t queue[2][1024];   // surviving pixel pairs by column parity: id = r*64 + pc
+  __shared__ uint16_t cand[2048];       // pixels with a nonzero score: id = r*128 + col
+  __shared__ int nq[2], ncand, lcount, lbase;
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int img = blockIdx.y;
   int tile = blockIdx.x;
   int l = 0;
@@ -186,7 +206,8 @@ __global__ __launch_bounds__(256) void k_fast(SvoGeom g, ImgSrc s, uint32_t* cor
   const uint8_t* img_p = level_ptr(g, s, img, l, &pitch);
 
   lhist[tid] = 0;
-  if (tid == 0) lcount = 0;
+  sc[tid] = 0; sc[tid + 256] = 0;
+  if (tid == 0) { lcount = 0; nq[0] = 0; nq[1] = 0; ncand = 0; }
 
   // stage pixels: rows y0-4 .. y0+17, columns x0-8 .. x0+127
   const bool aligned = ((pitch & 3) == 0) && ((reinterpret_cast<uintptr_t>(img_p) & 3) == 0);
@@ -207,32 +228,74 @@ __global__ __launch_bounds__(256) void k_fast(SvoGeom g, ImgSrc s, uint32_t* cor
   }
   __syncthreads();
 
-  // score 8 consecutive pixels: score row r <-> y = y0-1+r, columns x0-4+8c+k
+  // phase A: compass pre-test of 4 pixel pairs per thread; score row r <-> y = y0-1+r, pair
+  // column pc = 4c + K/2 <-> x = x0-4+2pc.  Survivors are compacted per wave with a ballot.
   {
     const int r = tid >> 4, c = tid & 15;
-    uint32_t rw[7][4];
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      const uint2 lo = *reinterpret_cast<const uint2*>(&px[(r + j) * PXW + 2 * c]);
-      const uint2 hi = *reinterpret_cast<const uint2*>(&px[(r + j) * PXW + 2 * c + 2]);
-      rw[j][0] = lo.x; rw[j][1] = lo.y; rw[j][2] = hi.x; rw[j][3] = hi.y;
+    uint32_t r0[4], r3[4], r6[4];
+    {
+      const uint2 a = *reinterpret_cast<const uint2*>(&px[(r + 0) * PXW + 2 * c]);
+      const uint2 b = *reinterpret_cast<const uint2*>(&px[(r + 0) * PXW + 2 * c + 2]);
+      r0[0] = a.x; r0[1] = a.y; r0[2] = b.x; r0[3] = b.y;
+      const uint2 e = *reinterpret_cast<const uint2*>(&px[(r + 3) * PXW + 2 * c]);
+      const uint2 f = *reinterpret_cast<const uint2*>(&px[(r + 3) * PXW + 2 * c + 2]);
+      r3[0] = e.x; r3[1] = e.y; r3[2] = f.x; r3[3] = f.y;
+      const uint2 p = *reinterpret_cast<const uint2*>(&px[(r + 6) * PXW + 2 * c]);
+      const uint2 q = *reinterpret_cast<const uint2*>(&px[(r + 6) * PXW + 2 * c + 2]);
+      r6[0] = p.x; r6[1] = p.y; r6[2] = q.x; r6[3] = q.y;
     }
-    uint32_t out[2];
-    out[0] = fast_pair<0>(rw) | (fast_pair<2>(rw) << 16);
-    out[1] = fast_pair<4>(rw) | (fast_pair<6>(rw) << 16);
-    *reinterpret_cast<uint2*>(&sc[r * (SCW / 4) + 2 * c]) = make_uint2(out[0], out[1]);
+    const uint32_t pass[4] = {compass_pair<0>(r0, r3, r6), compass_pair<2>(r0, r3, r6),
+                              compass_pair<4>(r0, r3, r6), compass_pair<6>(r0, r3, r6)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint64_t m = __ballot(pass[k] != 0);
+      if (m) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&nq[k & 1], __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (pass[k]) queue[k & 1][base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(r * 64 + 4 * c + k);
+      }
+    }
   }
   __syncthreads();
 
-  // NMS + border filter over the 120 x 14 tile
+  // phase B: exact score of the surviving pairs only, all lanes busy.  Even pair columns use the
+  // window that starts at the pair's own dword (centre at byte 4), odd ones the same dword with
+  // the centre at byte 6: both variants read window bytes 1..10 = three dwords per row.
+  uint16_t* sc16 = reinterpret_cast<uint16_t*>(sc);
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int n = nq[par];
+    for (int q = tid; q < n; q += 256) {
+      const int id = queue[par][q];
+      const int r = id >> 6, pc = id & 63;
+      uint32_t rw[7][4];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const uint32_t* p = &px[(r + j) * PXW + (pc >> 1)];
+        rw[j][0] = p[0]; rw[j][1] = p[1]; rw[j][2] = p[2]; rw[j][3] = p[2];
+      }
+      const uint32_t sp = par == 0 ? fast_pair<0>(rw) : fast_pair<2>(rw);
+      if (sp) {
+        sc16[r * 64 + pc] = (uint16_t)sp;
+        if (sp & 0xffu) cand[atomicAdd(&ncand, 1)] = (uint16_t)(r * 128 + 2 * pc);
+        if (sp & 0xff00u) cand[atomicAdd(&ncand, 1)] = (uint16_t)(r * 128 + 2 * pc + 1);
+      }
+    }
+  }
+  __syncthreads();
+
+  // phase C: strict 3x3 NMS + border filter, over the corner candidates only
   const uint8_t* scb = reinterpret_cast<const uint8_t*>(sc);
-  for (int i = tid; i < FAST_TW * FAST_TH; i += 256) {
-    const int oy = i / FAST_TW, ox = i - oy * FAST_TW;
+  const int nc = ncand;
+  for (int i = tid; i < nc; i += 256) {
+    const int id = cand[i];
+    const int sr = id >> 7, scol = id & 127;
+    const int oy = sr - 1, ox = scol - 4;
+    if (oy < 0 || oy >= FAST_TH || ox < 0 || ox >= FAST_TW) continue;
     const int x = x0 + ox, y = y0 + oy;
-    const int sr = oy + 1, scol = ox + 4;
-    const int sv = scb[sr * SCW + scol];
-    if (sv == 0) continue;
     if (x < SVO_EDGE || x >= w - SVO_EDGE || y >= h - SVO_EDGE) continue;
+    const int sv = scb[sr * SCW + scol];
     bool keep = true;
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy)

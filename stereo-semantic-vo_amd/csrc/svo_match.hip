@@ -12,14 +12,11 @@
 // column): a parallel kernel first writes the full distance matrix, then ONE wave
 // walks the rows in order with each lane holding the claim bits of its 8 columns.
 #include "svo_internal.h"
+#include "svo_wave.h"
 
 #define MAXT 1024
 
-__device__ __forceinline__ uint32_t wmin_u32(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
-  return v;
-}
+__device__ __forceinline__ uint32_t wmin_u32(uint32_t v) { return wave_min_u32_dpp(v); }
 
 __global__ void k_desc_dist(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
                             int count, int32_t* __restrict__ dist) {

@@ -12,6 +12,7 @@
 // pixels), so no overflow path exists; a 256-bin score histogram per
 // (image, level) gives the retainBest threshold without sorting.
 #include "svo_internal.h"
+#include "svo_wave.h"
 #include "../../include/svo_brief_pattern.h"
 
 __constant__ int8_t c_pattern[SVO_BRIEF_NTESTS][4] = SVO_BRIEF_PATTERN_INIT;
@@ -486,11 +487,7 @@ __device__ __forceinline__ void det_sincos(float angle_rad, float* s, float* c) 
   *c = (float)cv;
 }
 
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ __forceinline__ int wave_sum(int v) { return wave_sum_i32_dpp(v); }
 
 #define PW 37      // staged window side (31 + 2*3)
 #define PWP 40     // padded row, bytes

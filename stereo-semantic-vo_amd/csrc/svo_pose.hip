@@ -13,6 +13,7 @@
 // wave shuffles + one LDS hop; lane 0 runs the scalar LM logic (LDLT, exp map,
 // lambda schedule) so every accept/reject branch is taken in float64 exactly once.
 #include "svo_internal.h"
+#include "svo_wave.h"
 
 struct Se3 { double q[4]; double t[3]; };
 
@@ -177,11 +178,7 @@ __device__ __forceinline__ void edge_jacobian(const double pc[3], const double* 
   J[11] = y * invz_2 * K[1];
 }
 
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ __forceinline__ double wave_sum_d(double v) { return wave_sum_f64_dpp(v); }
 // block reduction of NV doubles per thread (256 threads = 4 waves); result in red[0..NV)
 template <int NV>
 __device__ __forceinline__ void block_reduce(double* acc, double* red /* [4][NV] + [NV] */) {

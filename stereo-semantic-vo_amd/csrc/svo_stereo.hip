@@ -8,6 +8,7 @@
 // keypoint's level, parabola sub-pixel, median-based outlier cut.
 // The dense helpers disp2Depth / UnprojectStereo are kept as kernels too.
 #include "svo_internal.h"
+#include "svo_wave.h"
 
 #define TH_HIGH 100
 #define TH_ORB ((100 + 50) / 2)
@@ -35,11 +36,7 @@ __device__ __forceinline__ const uint8_t* st_level_ptr(const SvoGeom& g, const S
   return s.pyr + (size_t)img * g.pyr_bytes + g.loff[l];
 }
 
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
-  return v;
-}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { return wave_min_u32_dpp(v); }
 
 // One workgroup = 16 left keypoints of one pair (4 waves x 4 keypoints); the right
 // image's keypoint bands and descriptors are staged in LDS once per workgroup.

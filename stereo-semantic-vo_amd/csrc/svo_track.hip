@@ -16,6 +16,7 @@
 #include <cstddef>
 
 #include "svo_internal.h"
+#include "svo_wave.h"
 
 #define TRK_MAXKP 512
 #define TRK_CAP 4096
@@ -33,6 +34,7 @@ struct TrackState {
   int32_t frame_num, npool, lastN, cur;      // cur: active half of the pool ping-pong
   int32_t nkp, m1, m2, n_edges, skip_match;
   int32_t n_pass1, n_pass2, n_new, n_stereo;
+  int32_t n_rows1, n_rows2, n_slow2;         // rows the serial passes visited / re-scanned (diagnostics)
   float lastTcw[16];
   int32_t last_mp[TRK_MAXKP];
   int32_t cur_mp[TRK_MAXKP];
@@ -44,14 +46,13 @@ struct TrackState {
   svo_camera cam;
   TrackPool pool[2];
   uint16_t rowmin[TRK_CAP];    // min over ALL current keypoints of the row's distances
+  uint8_t active[TRK_CAP];     // row takes part in the greedy pass (valid && rowmin < threshold)
+  uint2 pre[TRK_CAP];          // speculative row result under the claims at pass start:
+                               //   x = best<<16 | idx, y = second<<16 | idx_of_second (0xffff: none)
   uint16_t D[(size_t)TRK_CAP * 512];
 };
 
-__device__ __forceinline__ uint32_t tk_wmin(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
-  return v;
-}
+__device__ __forceinline__ uint32_t tk_wmin(uint32_t v) { return wave_min_u32_dpp(v); }
 
 // exclusive scan of one int per thread over a 512-thread block; returns the total in *total
 __device__ __forceinline__ int block_excl_scan512(int v, int* sm /*[512]*/, int* total) {
@@ -130,22 +131,35 @@ __global__ __launch_bounds__(512) void k_tk_begin(TrackState* st, const svo_kp* 
 
 // ---- 2/4. distance matrix rows of one pass ------------------------------------------------
 // pass 1: row i <-> last frame's keypoint i (map point last_mp[i]); pass 2: row r <-> pool row r.
+// Also decides, in parallel, which rows the serial pass must visit: a row can only be accepted
+// if its best distance over the unclaimed columns is < max_dist; the minimum over ALL columns
+// bounds that from below, so rows failing it never claim a column and are dropped.
 __global__ __launch_bounds__(256) void k_tk_dist(TrackState* st, const uint32_t* desc, int pass) {
   __shared__ uint32_t td[TRK_MAXKP * 8];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int M = pass == 1 ? st->m1 : st->m2;
-  if ((int)blockIdx.x * 4 >= M) return;
-  const int nkp = st->nkp;
+  const int M = st->skip_match ? 0 : (pass == 1 ? st->m1 : st->m2);
+  const int row = blockIdx.x * 4 + wv;
+  if ((int)blockIdx.x * 4 >= M) {
+    if (lane == 0 && row < TRK_CAP) st->active[row] = 0;
+    return;
+  }
+  const int nkp = st->nkp, id = st->frame_num;
+  const int max_dist = pass == 1 ? 15 : 30;
   const TrackPool& P = st->pool[st->cur];
   for (int i = tid; i < nkp * 8; i += 256) td[i] = desc[i];
   __syncthreads();
-  const int row = blockIdx.x * 4 + wv;
-  if (row >= M) return;
+  bool valid = row < M;
   int m = row;
-  if (pass == 1) {
-    m = st->last_mp[row];
-    if (m < 0 || P.bad[m]) return;
-  } else if (!P.in_local[m] || P.bad[m]) {
+  if (valid) {
+    if (pass == 1) {
+      m = st->last_mp[row];
+      valid = m >= 0 && !P.bad[m];
+    } else {
+      valid = P.in_local[m] && !P.bad[m] && P.obs_frame[m] != id;
+    }
+  }
+  if (!valid) {
+    if (lane == 0) st->active[row] = 0;
     return;
   }
   uint32_t qd[8];
@@ -163,17 +177,61 @@ __global__ __launch_bounds__(256) void k_tk_dist(TrackState* st, const uint32_t*
     st->D[(size_t)row * 512 + j] = (uint16_t)d;
   }
   mn = tk_wmin(mn);
-  if (lane == 0) st->rowmin[row] = (uint16_t)mn;
+  if (lane == 0) {
+    st->rowmin[row] = (uint16_t)mn;
+    st->active[row] = (int)mn < max_dist ? 1 : 0;
+  }
+  if ((int)mn >= max_dist) return;
+  // Speculative result of this row under the claims at the START of the pass (pass 1: none,
+  // pass 2: what pass 1 claimed).  Keys (dist<<16 | j) order by distance, then by column, so the
+  // wave minimum is the reference's strict-`<` scan result (first minimum) and the minimum over
+  // the columns before it is the "runner-up" (src/pnpmatch.cc:89-94) together with its column.
+  uint32_t kb = 0xffffffffu;
+  uint32_t keys[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int j = lane + 64 * t;
+    uint32_t key = 0xffffffffu;
+    if (j < nkp && !(pass == 2 && st->assigned[j])) {
+      int d = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d += __popc(qd[k] ^ td[j * 8 + k]);
+      key = ((uint32_t)d << 16) | (uint32_t)j;
+    }
+    keys[t] = key;
+    kb = min(kb, key);
+  }
+  kb = tk_wmin(kb);
+  uint32_t ks = 0xffffffffu;
+  const uint32_t bj = kb & 0xffffu;
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+    if ((keys[t] & 0xffffu) < bj) ks = min(ks, keys[t]);
+  ks = tk_wmin(ks);
+  if (lane == 0) {
+    const uint32_t y = ks == 0xffffffffu ? ((256u << 16) | 0xffffu) : ks;
+    st->pre[row] = make_uint2(kb, y);
+  }
 }
 
 // ---- 3/5. the order-dependent greedy assignment, one wave -----------------------------------
-// The wave first compacts the rows that take part (ballot + prefix popcount, order kept),
-// then walks them with a 4-deep register prefetch of the distance rows so the serial chain
-// pays ALU time, not one L2 round trip, per row.  Lane L owns columns 8L..8L+7 and keeps
-// their claim bits in a register.
+// The row flags written by k_tk_dist are loaded in ONE round trip (64 bytes per lane), compacted
+// in order into LDS with a wave prefix sum, and the surviving rows are walked with an 8-deep
+// register prefetch of their distance rows, so the serial chain pays ALU time, not an L2 round
+// trip, per row.  Lane L owns columns 8L..8L+7 and keeps their claim bits in a register.
+__device__ __forceinline__ int tk_wave_incl_scan(int v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(v, o, 64);
+    if ((int)(threadIdx.x & 63) >= o) v += t;
+  }
+  return v;
+}
+
 __global__ __launch_bounds__(64) void k_tk_greedy(TrackState* st, int pass) {
   __shared__ int16_t rows[TRK_CAP];
   __shared__ int16_t rowmp[TRK_CAP];
+  __shared__ uint4 drow[32 * 64];   // distance rows of the current 32-row chunk (32 KB)
   const int lane = threadIdx.x;
   const int M = pass == 1 ? st->m1 : st->m2;
   if (M <= 0 || st->skip_match) return;
@@ -181,50 +239,73 @@ __global__ __launch_bounds__(64) void k_tk_greedy(TrackState* st, int pass) {
   const int nkp = st->nkp, id = st->frame_num;
   const int max_dist = pass == 1 ? 15 : 30;
   const float ratio = pass == 1 ? 0.f : 2.f;
-  int n = 0;
-  for (int base = 0; base < M; base += 64) {
-    const int i = base + lane;
-    int m = i;
-    bool valid = i < M;
-    if (valid) {
-      if (pass == 1) {
-        m = st->last_mp[i];
-        valid = m >= 0 && !P.bad[m];
-      } else {
-        valid = P.in_local[m] && !P.bad[m] && P.obs_frame[m] != id;
-      }
-      // a row can only be accepted if its best distance over the unclaimed columns is
-      // < max_dist; the minimum over ALL columns bounds that from below, so rows that
-      // fail it are skipped without changing any result (they never claim a column).
-      valid = valid && st->rowmin[i] < max_dist;
+  // flags of rows 64*lane .. 64*lane+63
+  uint4 fl[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    fl[k] = make_uint4(0, 0, 0, 0);
+    if (64 * lane + 16 * k < M) fl[k] = *reinterpret_cast<const uint4*>(&st->active[64 * lane + 16 * k]);
+  }
+  const uint32_t fw[16] = {fl[0].x, fl[0].y, fl[0].z, fl[0].w, fl[1].x, fl[1].y, fl[1].z, fl[1].w,
+                           fl[2].x, fl[2].y, fl[2].z, fl[2].w, fl[3].x, fl[3].y, fl[3].z, fl[3].w};
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) cnt += __popc(fw[k] & 0x01010101u);
+  const int incl = tk_wave_incl_scan(cnt);
+  const int n = __shfl(incl, 63, 64);
+  int pos = incl - cnt;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int r = 64 * lane + 4 * k + b;
+      if (((fw[k] >> (8 * b)) & 1u) && r < M) rows[pos++] = (int16_t)r;
     }
-    const uint64_t mask = __ballot(valid);
-    if (valid) {
-      const int pos = n + __popcll(mask & ((1ull << lane) - 1ull));
-      rows[pos] = (int16_t)i;
-      rowmp[pos] = (int16_t)m;
-    }
-    n += __popcll(mask);
   }
   __syncthreads();
-  uint32_t claimed = 0;
+  for (int a = lane; a < n; a += 64) rowmp[a] = (int16_t)(pass == 1 ? st->last_mp[rows[a]] : rows[a]);
+  __syncthreads();
+  uint32_t claimed = 0;       // all claims (initial + this pass), columns 8*lane .. 8*lane+7
+  uint32_t claimed_now = 0;   // claims made during THIS pass only
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int j = lane * 8 + k;
     if (j >= nkp || st->assigned[j]) claimed |= 1u << k;
   }
   const uint16_t* Dl = st->D + lane * 8;
-  uint4 buf[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (k < n) buf[k] = *reinterpret_cast<const uint4*>(Dl + (size_t)rows[k] * 512);
-  int accepted_total = 0;
-  for (int a = 0; a < n; a += 4) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (a + k < n) {
-        const uint4 v = buf[k];
-        if (a + k + 4 < n) buf[k] = *reinterpret_cast<const uint4*>(Dl + (size_t)rows[a + k + 4] * 512);
+  int accepted_total = 0, n_slow = 0;
+  // Fast path: a row's speculative result (st->pre) stays valid unless one of the two columns it
+  // depends on - its best column or the column of its runner-up - was claimed during this pass:
+  // removing any other column cannot change a minimum that is still present.  Only then is the
+  // row re-scanned by the wave under the current claims (slow path).
+  for (int a0 = 0; a0 < n; a0 += 32) {
+    const int mine = a0 + lane;
+    uint2 pv = make_uint2(0xffffffffu, 0xffffffffu);
+    if (lane < 32 && mine < n) pv = st->pre[rows[mine]];
+    const int cntb = min(32, n - a0);
+    // stage the chunk's distance rows in LDS with all loads in flight at once: a stale row then
+    // costs an LDS read, not an L2 round trip, on the serial chain
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < cntb; ++k) drow[k * 64 + lane] = *reinterpret_cast<const uint4*>(Dl + (size_t)rows[a0 + k] * 512);
+    __syncthreads();
+    for (int k = 0; k < cntb; ++k) {
+      const uint32_t kb = __builtin_amdgcn_readlane((int)pv.x, k);
+      const uint32_t ks = __builtin_amdgcn_readlane((int)pv.y, k);
+      int bj = (int)(kb & 0xffffu), bd = (int)(kb >> 16), sec = (int)(ks >> 16);
+      const int js = (int)(ks & 0xffffu);
+      bool stale = false;
+      if (bj != 0xffff) {
+        const uint32_t cb = __builtin_amdgcn_readlane((int)claimed_now, bj >> 3);
+        stale = (cb >> (bj & 7)) & 1u;
+        if (!stale && js != 0xffff) {
+          const uint32_t cs = __builtin_amdgcn_readlane((int)claimed_now, js >> 3);
+          stale = (cs >> (js & 7)) & 1u;
+        }
+      }
+      if (stale) {
+        ++n_slow;
+        const uint4 v = drow[k * 64 + lane];
         const uint32_t cur[8] = {v.x & 0xffff, v.x >> 16, v.y & 0xffff, v.y >> 16,
                                  v.z & 0xffff, v.z >> 16, v.w & 0xffff, v.w >> 16};
         uint32_t lp = (256u << 16) | 0xffffu;
@@ -232,25 +313,23 @@ __global__ __launch_bounds__(64) void k_tk_greedy(TrackState* st, int pass) {
         for (int c = 0; c < 8; ++c)
           if (!((claimed >> c) & 1u)) lp = min(lp, (cur[c] << 16) | (uint32_t)(lane * 8 + c));
         const uint32_t bp = tk_wmin(lp);
-        const int bj = (int)(bp & 0xffffu), bd = (int)(bp >> 16);
-        bool ok = bj != 0xffff && bd < max_dist;
-        if (ok && ratio > 0.f) {
-          uint32_t ls = 256;
+        bj = (int)(bp & 0xffffu); bd = (int)(bp >> 16);
+        uint32_t ls = 256;
 #pragma unroll
-          for (int c = 0; c < 8; ++c)
-            if (!((claimed >> c) & 1u) && lane * 8 + c < bj) ls = min(ls, cur[c]);
-          const int sec = (int)tk_wmin(ls);
-          ok = (float)sec / (float)bd > ratio;
+        for (int c = 0; c < 8; ++c)
+          if (!((claimed >> c) & 1u) && lane * 8 + c < bj) ls = min(ls, cur[c]);
+        sec = (int)tk_wmin(ls);
+      }
+      bool ok = bj != 0xffff && bd < max_dist;
+      if (ok && ratio > 0.f) ok = (float)sec / (float)bd > ratio;
+      if (ok) {
+        if ((bj >> 3) == lane) { claimed |= 1u << (bj & 7); claimed_now |= 1u << (bj & 7); }
+        if (lane == 0) {
+          const int m = rowmp[a0 + k];
+          st->cur_mp[bj] = m;
+          P.obs_frame[m] = id;
         }
-        if (ok) {
-          if ((bj >> 3) == lane) claimed |= 1u << (bj & 7);
-          if (lane == 0) {
-            const int m = rowmp[a + k];
-            st->cur_mp[bj] = m;
-            P.obs_frame[m] = id;
-          }
-          ++accepted_total;
-        }
+        ++accepted_total;
       }
     }
   }
@@ -260,7 +339,8 @@ __global__ __launch_bounds__(64) void k_tk_greedy(TrackState* st, int pass) {
     if (j < nkp) st->assigned[j] = (uint8_t)((claimed >> k) & 1u);
   }
   if (lane == 0) {
-    if (pass == 1) st->n_pass1 = accepted_total; else st->n_pass2 = accepted_total;
+    if (pass == 1) { st->n_pass1 = accepted_total; st->n_rows1 = n; }
+    else { st->n_pass2 = accepted_total; st->n_rows2 = n; st->n_slow2 = n_slow; }
   }
 }
 
@@ -383,7 +463,8 @@ __global__ __launch_bounds__(512) void k_tk_end(TrackState* st, const svo_kp* kp
     r.n_new_mappoints = (id == 0 ? st->n_new : 0) + n_new;
     r.n_local_map = nl_total;
     r.lm_iterations = st->lm.iterations;
-    r.reserved[0] = 0; r.reserved[1] = 0;
+    r.reserved[0] = st->skip_match ? 0 : st->n_rows1;   // diagnostics: rows visited by pass 1; [1]: pass 2 | rescanned<<16
+    r.reserved[1] = st->skip_match ? 0 : (st->n_rows2 | (st->n_slow2 << 16));
     *res_out = r;
     st->lastN = nkp;
     st->npool = total_live;

@@ -43,6 +43,18 @@ KERNEL_BYTES_PER_IMAGE = {
 }
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same
+    command (profiles/pmc_latest.json; FETCH_SIZE and WRITE_SIZE collected in separate passes,
+    KB units, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        d = json.load(open(path))[kernel]
+        return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
+
+
 def render_frames(synth, n, dev, seed, start=0):
     """n consecutive synth-kitti frames rendered on `dev`, padded to PITCH; + ground truth."""
     L, R, T = synth.render_sequence(n, seed=seed, device=dev, start=start)
@@ -206,7 +218,8 @@ def main():
             algo = KERNEL_BYTES_PER_IMAGE[dom] * 2 * B
             ach = algo / dom_s / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "traffic": pmc_traffic(dom) if (B == 128 and not track) else None,
                                "algorithmic_bytes_per_launch": algo,
                                "pipeline_frac": ALGO_BYTES_PER_PAIR * (pairs / dt / world) / 1e9 / HBM_PEAK_GBS}
             out["kernels"] = kern

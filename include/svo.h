@@ -190,11 +190,27 @@ int svo_match_greedy(svo_ctx* ctx, const uint8_t* q, const uint8_t* q_skip, int 
                      const uint8_t* t, int N, uint8_t* assigned, int max_dist, float ratio,
                      int32_t* best_idx, int32_t* best, int32_t* second, uint8_t* accepted);
 
+/* svo_match_greedy with the reference's semantic veto of pass 1 (src/pnpmatch.cc:101-144): a row
+ * that would be accepted, whose matched train point t_xy[best_idx] lies inside a detection box
+ * padded by 10 px and more than 0.1 px off the line F*[q_xy[i],1], is NOT accepted, claims no
+ * column, and is reported in vetoed[i] (the caller marks its map point bad).  q_xy: M x 2 floats
+ * (last-frame point of each row), t_xy: N x 2 floats, boxes: n_boxes x {left,right,top,bottom}. */
+int svo_match_greedy_gated(svo_ctx* ctx, const uint8_t* q, const uint8_t* q_skip, int M,
+                           const uint8_t* t, int N, uint8_t* assigned, int max_dist, float ratio,
+                           const float* q_xy, const float* t_xy, const int32_t* boxes, int n_boxes,
+                           const double F[9], int32_t* best_idx, int32_t* best, int32_t* second,
+                           uint8_t* accepted, uint8_t* vetoed);
+
 /* a-6: cv BruteForce-Hamming match() as used by find_feature_matches
  * (src/pnpmatch.cc:253-300): nearest train row per query row (ties: lowest j),
  * then keep[i] = dist[i] <= max(2*min_dist, 30). */
 int svo_bf_match(svo_ctx* ctx, const uint8_t* q, int M, const uint8_t* t, int N,
                  int32_t* train_idx, int32_t* dist, uint8_t* keep);
+
+/* a-6: cv::findFundamentalMat(cur_pts, last_pts, CV_FM_8POINT) (src/pnpmatch.cc:336): normalised
+ * 8-point algorithm, float64, evaluated on the host (9x9 eigenproblem).  pts1/pts2: n x 2;
+ * F row-major with p2^T F p1 = 0, scaled to F[8] = 1.  n < 8 -> F = 0 (OpenCV returns empty). */
+int svo_fundamental_8point(const double* pts1, const double* pts2, int n, double F[9]);
 
 /* ---- a-10: PnP-RANSAC initial pose (src/pnpmatch.cc:212-247) ---------------- */
 /* Xw n x 3, obs n x 2 (doubles); K = {fx,fy,cx,cy}; T_prior_cw / T_cw row-major 4x4.
@@ -215,8 +231,11 @@ int svo_pose_opt(svo_ctx* ctx, const double* Xw, const double* obs, int n, const
 /* ---- Tracking::Track (src/Tracking.cc:180-252), device-resident ------------- */
 /* Reset the tracker state held in HBM (lastframe, LocalMapPoints, frame_num). */
 int svo_track_reset(svo_ctx* ctx, const svo_camera* cam);
-/* Track one stereo pair given as HOST gray images; fills *res. Boxes: n_boxes x 4
- * int32 {left,right,top,bottom} (offline detections, main.cpp:82-95), may be NULL. */
+/* Track one stereo pair given as HOST gray images; fills *res. Boxes: n_boxes (<= 64) x 4
+ * int32 {left,right,top,bottom} (offline detections, main.cpp:82-95), may be NULL.  With boxes
+ * the frame is gated as in the reference: no map points are created inside a box padded by 5 px,
+ * and a pass-1 match that lands in a box padded by 10 px and lies > 0.1 px off the epipolar line
+ * marks its map point bad (src/pnpmatch.cc:101-144). */
 int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL, const uint8_t* grayR,
                     int strideR, double timestamp, const int32_t* boxes, int n_boxes,
                     svo_track_result* res);
@@ -224,6 +243,8 @@ int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL, const uint8
 /* Parity probe: map-point pool row matched to each keypoint of the frame just tracked
  * (CurrentFrame->MapPoints after both passes, -1 = none). cur_mp: max_kp int32. */
 int svo_debug_track_matches(svo_ctx* ctx, int32_t* cur_mp);
+/* Parity probe: the F matrix and the number of epipolar vetoes of the frame just tracked. */
+int svo_debug_track_gate(svo_ctx* ctx, double F[9], int32_t* n_vetoed);
 
 /* ---- throughput mode: batched, device-resident ------------------------------ */
 /* B stereo pairs already in HBM: d_grayL/d_grayR are B images of H rows x `stride`

@@ -223,13 +223,36 @@ class Tracker:
         self.W, self.H, self.nf = W, H, nfeatures
         self.h = l.orc_track_create(W, H, nfeatures, cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["bf"])
 
-    def track(self, grayL, grayR):
+    def track(self, grayL, grayR, boxes=None):
         grayL = np.ascontiguousarray(grayL, np.uint8); grayR = np.ascontiguousarray(grayR, np.uint8)
         res = np.zeros(1, TRACK_DTYPE); cur = np.zeros(self.nf, np.int32)
-        lib().orc_track_frame(self.h, _p(grayL), self.W, _p(grayR), self.W, _p(res), _p(cur))
+        bx = None if boxes is None or len(boxes) == 0 else np.ascontiguousarray(boxes, np.int32)
+        self.F = np.zeros(9)
+        l = lib()
+        l.orc_track_frame_boxes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.orc_track_frame_boxes(self.h, _p(grayL), self.W, _p(grayR), self.W, _p(bx),
+                                0 if bx is None else len(bx), _p(res), _p(cur), _p(self.F))
+        self.vetoes = l.orc_track_last_vetoes(C.c_void_p(self.h))
         return res[0], cur
 
     def close(self):
         if self.h:
             lib().orc_track_destroy(self.h)
             self.h = None
+
+
+def fundamental_8point(pts1, pts2):
+    pts1 = np.ascontiguousarray(pts1, np.float64).reshape(-1, 2)
+    pts2 = np.ascontiguousarray(pts2, np.float64).reshape(-1, 2)
+    F = np.zeros(9)
+    lib().orc_fundamental_8point(_p(pts1), _p(pts2), len(pts1), _p(F))
+    return F.reshape(3, 3)
+
+
+def epipolar_distance(F, last_xy, cur_xy):
+    l = lib()
+    l.orc_epipolar_distance.restype = C.c_double
+    l.orc_epipolar_distance.argtypes = [C.c_void_p] + [C.c_float] * 4
+    F = np.ascontiguousarray(F, np.float64).reshape(9)
+    return l.orc_epipolar_distance(_p(F), last_xy[0], last_xy[1], cur_xy[0], cur_xy[1])

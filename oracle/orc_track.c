@@ -16,8 +16,11 @@
  * frame's pose, seed 0x5EED0000 + frame id).  Deterministic orders replace the
  * reference's run-dependent ones: LocalMapPoints (a std::set<mappoint*> ordered by
  * heap address, include/Tracking.h:41) is iterated in creation order.
- * Offline detection boxes (semantic gating, SURVEY f-3) are not modelled yet: the
- * tracker runs the reference's "empty box list" configuration (BASELINE config 1).
+ * Offline detection boxes (semantic gating, SURVEY f-3; main.cpp:82-95 format) are honoured
+ * exactly where the reference uses them: the +-5 px creation gate in Tracking::init (with its
+ * never-reset `dynamic` flag, src/Tracking.cc:44,61-66,86) and frame::createmappoint
+ * (src/frame.cc:198-203), and the +-10 px epipolar veto of pass 1 (src/pnpmatch.cc:101-144)
+ * with F from pnpmatch::poseEstimation2D_2D (:302-337).
  */
 #include <math.h>
 #include <stdlib.h>
@@ -45,6 +48,9 @@ struct orc_tracker {
   int lastN;
   int32_t last_mp[TRK_MAXKP];
   float lastTcw[16];
+  float last_xy[TRK_MAXKP][2];        /* LastFrame.keypoints_l[i].pt */
+  uint8_t last_desc[TRK_MAXKP * 32];  /* LastFrame.f_descriptor      */
+  int last_vetoes;                    /* epipolar vetoes in the frame just tracked */
 };
 
 orc_tracker* orc_track_create(int W, int H, int nfeatures, float fx, float fy, float cx, float cy,
@@ -57,6 +63,7 @@ orc_tracker* orc_track_create(int W, int H, int nfeatures, float fx, float fy, f
   for (int i = 0; i < 16; ++i) t->lastTcw[i] = (i % 5 == 0) ? 1.f : 0.f;
   return t;
 }
+int orc_track_last_vetoes(const orc_tracker* t) { return t->last_vetoes; }
 void orc_track_destroy(orc_tracker* t) {
   if (!t) return;
   free(t->pool);
@@ -87,7 +94,15 @@ static int new_mappoint(orc_tracker* t, const float xyz[3], const uint8_t* desc,
 
 int orc_track_frame(orc_tracker* t, const uint8_t* grayL, int strideL, const uint8_t* grayR,
                     int strideR, orc_track_result* res, int32_t* cur_mp_out) {
+  return orc_track_frame_boxes(t, grayL, strideL, grayR, strideR, NULL, 0, res, cur_mp_out, NULL);
+}
+
+int orc_track_frame_boxes(orc_tracker* t, const uint8_t* grayL, int strideL, const uint8_t* grayR,
+                          int strideR, const int32_t* boxes, int n_boxes, orc_track_result* res,
+                          int32_t* cur_mp_out, double F_out[9]) {
   const int NF = t->nfeatures;
+  double F[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  t->last_vetoes = 0;
   orc_kp* kp = (orc_kp*)calloc((size_t)NF, sizeof(orc_kp));
   uint8_t* desc = (uint8_t*)calloc((size_t)NF, 32);
   float* uR = (float*)calloc((size_t)NF, sizeof(float));
@@ -108,8 +123,10 @@ int orc_track_frame(orc_tracker* t, const uint8_t* grayL, int strideL, const uin
   if (id == 0) {
     /* Tracking::init (src/Tracking.cc:42-97): pose I, map points for every keypoint with depth */
     const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3[3] = {0, 0, 0};
+    int dynamic = 0; /* declared outside the loop and never reset (src/Tracking.cc:44) */
     for (int i = 0; i < nkp; ++i) {
-      if (depth[i] > 0) {
+      if (n_boxes > 0 && orc_point_in_boxes(kp[i].x, kp[i].y, boxes, n_boxes, 5)) dynamic = 1;
+      if (depth[i] > 0 && !dynamic) {
         float uvz[3] = {kp[i].x, kp[i].y, depth[i]}, xyz[3];
         orc_unproject(uvz, 1, t->fx, t->fy, t->cx, t->cy, I3, z3, xyz);
         cur_mp[i] = new_mappoint(t, xyz, desc + 32 * (size_t)i, id);
@@ -117,15 +134,42 @@ int orc_track_frame(orc_tracker* t, const uint8_t* grayL, int strideL, const uin
       }
     }
   } else {
+    /* pnpmatch::poseEstimation2D_2D (src/pnpmatch.cc:302-337): F from background matches.
+     * Only its use inside boxes matters, so it is computed when the frame has boxes. */
+    if (n_boxes > 0) {
+      int32_t* ti = (int32_t*)malloc(sizeof(int32_t) * TRK_MAXKP);
+      int32_t* td = (int32_t*)malloc(sizeof(int32_t) * TRK_MAXKP);
+      uint8_t* keep = (uint8_t*)malloc(TRK_MAXKP);
+      double* p1 = (double*)malloc(sizeof(double) * 2 * TRK_MAXKP);
+      double* p2 = (double*)malloc(sizeof(double) * 2 * TRK_MAXKP);
+      orc_bf_match(desc, nkp, t->last_desc, t->lastN, ti, td, keep);
+      int np = 0;
+      for (int i = 0; i < nkp; ++i) {
+        if (!keep[i]) continue;
+        if (orc_point_in_boxes(kp[i].x, kp[i].y, boxes, n_boxes, 10)) continue;
+        p1[2 * np] = kp[i].x; p1[2 * np + 1] = kp[i].y;
+        p2[2 * np] = t->last_xy[ti[i]][0]; p2[2 * np + 1] = t->last_xy[ti[i]][1];
+        ++np;
+      }
+      orc_fundamental_8point(p1, p2, np, F);
+      free(ti); free(td); free(keep); free(p1); free(p2);
+    }
     /* pass 1 (src/pnpmatch.cc:61-156): last frame's map points -> current keypoints */
     uint8_t* assigned = (uint8_t*)calloc(TRK_MAXKP, 1);
     for (int i = 0; i < t->lastN; ++i) {
       const int m = t->last_mp[i];
       if (m < 0 || t->pool[m].bad) continue;
       int32_t bi, bd, sd;
-      uint8_t acc;
-      orc_match_greedy(t->pool[m].desc, NULL, 1, desc, nkp, assigned, 15, 0.f, &bi, &bd, &sd, &acc);
-      if (acc) {
+      orc_hamming_argmin(t->pool[m].desc, 1, desc, nkp, assigned, &bi, &bd, &sd);
+      if (bi >= 0 && bd < 15) {
+        /* epipolar veto for matches that land inside a padded box (:103-144) */
+        if (n_boxes > 0 && orc_point_in_boxes(kp[bi].x, kp[bi].y, boxes, n_boxes, 10) &&
+            orc_epipolar_distance(F, t->last_xy[i][0], t->last_xy[i][1], kp[bi].x, kp[bi].y) > 0.1) {
+          t->pool[m].bad = 1;
+          t->last_vetoes++;
+          continue;
+        }
+        assigned[bi] = 1;
         cur_mp[bi] = m;
         t->pool[m].obs_frame = id;
         res->n_match_pass1++;
@@ -194,15 +238,19 @@ int orc_track_frame(orc_tracker* t, const uint8_t* grayL, int strideL, const uin
     pose_inverse_f(Tcw, Rwc, twc);
     for (int i = 0; i < nkp; ++i) {
       if (cur_mp[i] >= 0) continue;
+      if (n_boxes > 0 && orc_point_in_boxes(kp[i].x, kp[i].y, boxes, n_boxes, 5)) continue;
       if (depth[i] > 0) {
         float uvz[3] = {kp[i].x, kp[i].y, depth[i]}, xyz[3];
         orc_unproject(uvz, 1, t->fx, t->fy, t->cx, t->cy, Rwc, twc, xyz);
         cur_mp[i] = new_mappoint(t, xyz, desc + 32 * (size_t)i, id);
-        if (id > 0) res->n_new_mappoints++;
+        res->n_new_mappoints++;
       }
     }
   }
   t->lastN = nkp;
+  for (int i = 0; i < nkp; ++i) { t->last_xy[i][0] = kp[i].x; t->last_xy[i][1] = kp[i].y; }
+  memcpy(t->last_desc, desc, 32 * (size_t)nkp);
+  if (F_out) memcpy(F_out, F, sizeof F);
   memcpy(t->last_mp, cur_mp, sizeof cur_mp);
   memcpy(t->lastTcw, Tcw, sizeof Tcw);
   /* cull (src/Tracking.cc:239-250) */

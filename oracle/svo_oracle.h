@@ -98,6 +98,11 @@ int orc_pnp_ransac(const double* Xw, const double* obs, int n, const double K[4]
                    const double T_prior[16], uint64_t seed, double T[16], uint8_t* inlier_mask,
                    orc_pnp_stats* stats);
 
+/* fundamental matrix + semantic gating (orc_fmat.c) */
+int orc_fundamental_8point(const double* pts1, const double* pts2, int n, double F[9]);
+int orc_point_in_boxes(float x, float y, const int32_t* boxes, int n_boxes, int pad);
+double orc_epipolar_distance(const double F[9], float last_x, float last_y, float cur_x, float cur_y);
+
 /* tracking loop (orc_track.c) */
 typedef struct orc_track_result {
   float Tcw[16];
@@ -108,9 +113,14 @@ typedef struct orc_tracker orc_tracker;
 orc_tracker* orc_track_create(int W, int H, int nfeatures, float fx, float fy, float cx, float cy,
                               float bf);
 void orc_track_destroy(orc_tracker* t);
+int orc_track_last_vetoes(const orc_tracker* t);
 /* cur_mp_out (nullable): nfeatures int32, pool index matched to each keypoint or -1 */
 int orc_track_frame(orc_tracker* t, const uint8_t* grayL, int strideL, const uint8_t* grayR,
                     int strideR, orc_track_result* res, int32_t* cur_mp_out);
+/* same, with the frame's offline detection boxes: n_boxes x {left,right,top,bottom} (main.cpp:82-95) */
+int orc_track_frame_boxes(orc_tracker* t, const uint8_t* grayL, int strideL, const uint8_t* grayR,
+                          int strideR, const int32_t* boxes, int n_boxes, orc_track_result* res,
+                          int32_t* cur_mp_out, double F_out[9]);
 
 #ifdef __cplusplus
 }

@@ -39,8 +39,9 @@ ABI_SYMBOLS = [
     "svo_stream", "svo_orb_geometry", "svo_orb_extract", "svo_debug_pyramid_level",
     "svo_debug_fast_corners", "svo_stereo_frame", "svo_stereo_frame_ex", "svo_disp2depth",
     "svo_unproject", "svo_descriptor_distance", "svo_hamming_argmin", "svo_match_greedy",
+    "svo_match_greedy_gated",
     "svo_bf_match", "svo_pnp_ransac", "svo_pose_opt", "svo_track_reset", "svo_track_frame",
-    "svo_debug_track_matches",
+    "svo_debug_track_matches", "svo_debug_track_gate", "svo_fundamental_8point",
     "svo_frontend_batch_dev", "svo_track_batch_dev", "svo_profile_enable", "svo_profile_reset",
     "svo_profile_get",
 ]
@@ -276,6 +277,21 @@ class Svo:
         self._chk(self.lib.svo_track_frame(self.h, _p(grayL), self.W, _p(grayR), self.W,
                                            C.c_double(timestamp), _p(bx), nb, _p(res)))
         return res[0]
+
+    def debug_track_gate(self):
+        F = np.zeros(9); n = C.c_int32(0)
+        self._chk(self.lib.svo_debug_track_gate(self.h, _p(F), C.byref(n)))
+        return F.reshape(3, 3), n.value
+
+    @staticmethod
+    def fundamental_8point(pts1, pts2):
+        pts1 = np.ascontiguousarray(pts1, np.float64).reshape(-1, 2)
+        pts2 = np.ascontiguousarray(pts2, np.float64).reshape(-1, 2)
+        F = np.zeros(9)
+        rc = load_library().svo_fundamental_8point(_p(pts1), _p(pts2), len(pts1), _p(F))
+        if rc != 0:
+            raise SvoError("svo_fundamental_8point failed")
+        return F.reshape(3, 3)
 
     def debug_track_matches(self):
         out = np.zeros(self.max_kp, np.int32)

@@ -522,6 +522,56 @@ extern "C" int svo_match_greedy(svo_ctx* ctx, const uint8_t* q, const uint8_t* q
   return SVO_OK;
 }
 
+extern "C" int svo_match_greedy_gated(svo_ctx* ctx, const uint8_t* q, const uint8_t* q_skip, int M,
+                                      const uint8_t* t, int N, uint8_t* assigned, int max_dist,
+                                      float ratio, const float* q_xy, const float* t_xy,
+                                      const int32_t* boxes, int n_boxes, const double F[9],
+                                      int32_t* best_idx, int32_t* best, int32_t* second,
+                                      uint8_t* accepted, uint8_t* vetoed) {
+  if (n_boxes <= 0) {
+    if (vetoed && M > 0) memset(vetoed, 0, (size_t)M);
+    return svo_match_greedy(ctx, q, q_skip, M, t, N, assigned, max_dist, ratio, best_idx, best, second, accepted);
+  }
+  if (!ctx || M < 0 || N < 0 || n_boxes > 64 || !boxes || !F || !q_xy || !t_xy || !vetoed ||
+      (M > 0 && (!q || !best_idx || !best || !second || !accepted)) || (N > 0 && (!t || !assigned)))
+    return SVO_E_INVALID;
+  if (M == 0) return SVO_OK;
+  hipSetDevice(ctx->device);
+  Bump bm{ctx};
+  uint8_t* dq = bm.take<uint8_t>(32 * (size_t)M);
+  uint8_t* dsk = bm.take<uint8_t>(M);
+  uint8_t* dt = bm.take<uint8_t>(32 * (size_t)std::max(N, 1));
+  uint8_t* das = bm.take<uint8_t>(std::max(N, 1));
+  int32_t* di = bm.take<int32_t>(M);
+  int32_t* db = bm.take<int32_t>(M);
+  int32_t* ds = bm.take<int32_t>(M);
+  uint8_t* dacc = bm.take<uint8_t>(M);
+  uint8_t* dvet = bm.take<uint8_t>(M);
+  float* dqxy = bm.take<float>(2 * (size_t)M);
+  float* dtxy = bm.take<float>(2 * (size_t)std::max(N, 1));
+  int32_t* dbox = bm.take<int32_t>(4 * (size_t)n_boxes);
+  double* dF = bm.take<double>(9);
+  if (!bm.ok()) return SVO_E_CAPACITY;
+  H2D(dq, q, 32 * (size_t)M);
+  if (q_skip) H2D(dsk, q_skip, M);
+  if (N > 0) { H2D(dt, t, 32 * (size_t)N); H2D(das, assigned, N); H2D(dtxy, t_xy, 8 * (size_t)N); }
+  H2D(dqxy, q_xy, 8 * (size_t)M);
+  H2D(dbox, boxes, 16 * (size_t)n_boxes);
+  H2D(dF, F, 72);
+  SVO_HIP(ctx, hipMemsetAsync(dvet, 0, M, ctx->stream));
+  int rc = svo_launch_match_greedy(ctx, dq, q_skip ? dsk : nullptr, M, dt, N, das, max_dist, ratio, di, db,
+                                   ds, dacc, dqxy, dtxy, dbox, n_boxes, dF, dvet);
+  if (rc) return rc;
+  D2H(best_idx, di, 4 * (size_t)M);
+  D2H(best, db, 4 * (size_t)M);
+  D2H(second, ds, 4 * (size_t)M);
+  D2H(accepted, dacc, M);
+  D2H(vetoed, dvet, M);
+  if (N > 0) D2H(assigned, das, N);
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVO_OK;
+}
+
 extern "C" int svo_bf_match(svo_ctx* ctx, const uint8_t* q, int M, const uint8_t* t, int N,
                             int32_t* train_idx, int32_t* dist, uint8_t* keep) {
   if (!ctx || M < 0 || N < 0 || (M > 0 && (!q || !train_idx || !dist || !keep)) || (N > 0 && !t))

@@ -119,9 +119,15 @@ int svo_launch_hamming_argmin(svo_ctx* ctx, const uint8_t* q, int M, const uint8
                               const uint8_t* mask, int32_t* idx, int32_t* best, int32_t* second);
 int svo_launch_match_greedy(svo_ctx* ctx, const uint8_t* q, const uint8_t* q_skip, int M,
                             const uint8_t* t, int N, uint8_t* assigned, int max_dist, float ratio,
-                            int32_t* idx, int32_t* best, int32_t* second, uint8_t* accepted);
+                            int32_t* idx, int32_t* best, int32_t* second, uint8_t* accepted,
+                            const float* q_xy = nullptr, const float* t_xy = nullptr,
+                            const int32_t* boxes = nullptr, int n_boxes = 0, const double* F = nullptr,
+                            uint8_t* vetoed = nullptr);
 int svo_launch_bf_match(svo_ctx* ctx, const uint8_t* q, int M, const uint8_t* t, int N,
                         int32_t* train_idx, int32_t* dist, uint8_t* keep);
+int svo_launch_bf_match_dev(svo_ctx* ctx, const uint8_t* q, const int* M_ptr, const uint8_t* t,
+                            const int* N_ptr, int Mmax, int32_t* train_idx, int32_t* dist,
+                            uint8_t* keep, int32_t* gmin);
 int svo_launch_pose_opt(svo_ctx* ctx, const double* Xw, const double* obs, int n, const double* K,
                         double* T, svo_lm_stats* stats);
 int svo_launch_pnp(svo_ctx* ctx, const double* Xw, const double* obs, int n, const double* K,

@@ -13,6 +13,7 @@
 // walks the rows in order with each lane holding the claim bits of its 8 columns.
 #include "svo_internal.h"
 #include "svo_wave.h"
+#include "svo_gate.h"
 
 #define MAXT 1024
 
@@ -105,7 +106,10 @@ __global__ __launch_bounds__(64) void k_greedy_serial(const uint16_t* __restrict
                                                       const uint8_t* __restrict__ q_skip,
                                                       uint8_t* assigned, int max_dist, float ratio,
                                                       int32_t* best_idx, int32_t* best,
-                                                      int32_t* second, uint8_t* accepted) {
+                                                      int32_t* second, uint8_t* accepted,
+                                                      const float* q_xy, const float* t_xy,
+                                                      const int32_t* boxes, int n_boxes,
+                                                      const double* F, uint8_t* vetoed) {
   const int lane = threadIdx.x;
   constexpr int Npad = CPL * 64;
   uint32_t claimed = 0;
@@ -145,11 +149,19 @@ __global__ __launch_bounds__(64) void k_greedy_serial(const uint16_t* __restrict
         const int sec = (int)wmin_u32(ls);
         bool ok = bd < max_dist;
         if (ok && ratio > 0.f) ok = (float)sec / (float)bd > ratio;
+        int veto = 0;
+        if (ok && n_boxes > 0) {   // epipolar veto of pass 1 (reference src/pnpmatch.cc:103-144)
+          const float cx = t_xy[2 * bj], cy = t_xy[2 * bj + 1];
+          if (svo_in_boxes(cx, cy, boxes, n_boxes, 10) &&
+              svo_epipolar_distance(F, q_xy[2 * i], q_xy[2 * i + 1], cx, cy) > 0.1) { veto = 1; ok = false; }
+        }
+        if (vetoed && lane == 0) vetoed[i] = (uint8_t)veto;
         o_idx = bj; o_best = bd; o_sec = sec; o_acc = ok ? 1 : 0;
         if (ok && (bj / CPL) == lane) claimed |= 1u << (bj % CPL);
       }
     }
     if (lane == 0) { best_idx[i] = o_idx; best[i] = o_best; second[i] = o_sec; accepted[i] = (uint8_t)o_acc; }
+    if (vetoed && lane == 0 && o_idx < 0) vetoed[i] = 0;
 #pragma unroll
     for (int k = 0; k < CPL; ++k) cur[k] = nxt[k];
   }
@@ -164,8 +176,11 @@ __global__ __launch_bounds__(64) void k_greedy_serial(const uint16_t* __restrict
 __global__ __launch_bounds__(256) void k_bf_nearest(const uint32_t* __restrict__ q, int M,
                                                     const uint32_t* __restrict__ t, int N,
                                                     int32_t* train_idx, int32_t* dist,
-                                                    int32_t* gmin) {
+                                                    int32_t* gmin, const int* M_ptr,
+                                                    const int* N_ptr) {
   __shared__ uint32_t td[MAXT * 8];
+  if (M_ptr) M = *M_ptr;
+  if (N_ptr) N = min(*N_ptr, MAXT);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (int i = tid; i < N * 8; i += 256) td[i] = t[i];
   __syncthreads();
@@ -190,7 +205,8 @@ __global__ __launch_bounds__(256) void k_bf_nearest(const uint32_t* __restrict__
   }
 }
 __global__ void k_bf_filter(int M, const int32_t* train_idx, const int32_t* dist,
-                            const int32_t* gmin, uint8_t* keep) {
+                            const int32_t* gmin, uint8_t* keep, const int* M_ptr) {
+  if (M_ptr) M = *M_ptr;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M) return;
   const double md = (double)min(*gmin, 10000);
@@ -221,7 +237,9 @@ int svo_launch_hamming_argmin(svo_ctx* ctx, const uint8_t* q, int M, const uint8
 
 int svo_launch_match_greedy(svo_ctx* ctx, const uint8_t* q, const uint8_t* q_skip, int M,
                             const uint8_t* t, int N, uint8_t* assigned, int max_dist, float ratio,
-                            int32_t* idx, int32_t* best, int32_t* second, uint8_t* accepted) {
+                            int32_t* idx, int32_t* best, int32_t* second, uint8_t* accepted,
+                            const float* q_xy, const float* t_xy, const int32_t* boxes, int n_boxes,
+                            const double* F, uint8_t* vetoed) {
   if (N > MAXT) return SVO_E_CAPACITY;
   if (M <= 0) return SVO_OK;
   const int Npad = N <= 512 ? 512 : 1024;
@@ -237,10 +255,12 @@ int svo_launch_match_greedy(svo_ctx* ctx, const uint8_t* q, const uint8_t* q_ski
     SvoTimer tm(ctx, "k_greedy_serial");
     if (Npad == 512)
       hipLaunchKernelGGL(k_greedy_serial<8>, dim3(1), dim3(64), 0, ctx->stream, D, M, N, q_skip,
-                         assigned, max_dist, ratio, idx, best, second, accepted);
+                         assigned, max_dist, ratio, idx, best, second, accepted, q_xy, t_xy, boxes,
+                         n_boxes, F, vetoed);
     else
       hipLaunchKernelGGL(k_greedy_serial<16>, dim3(1), dim3(64), 0, ctx->stream, D, M, N, q_skip,
-                         assigned, max_dist, ratio, idx, best, second, accepted);
+                         assigned, max_dist, ratio, idx, best, second, accepted, q_xy, t_xy, boxes,
+                         n_boxes, F, vetoed);
   }
   SVO_HIP(ctx, hipGetLastError());
   return SVO_OK;
@@ -254,9 +274,24 @@ int svo_launch_bf_match(svo_ctx* ctx, const uint8_t* q, int M, const uint8_t* t,
   const int32_t big = 0x7fffffff;
   SVO_HIP(ctx, hipMemcpyAsync(gmin, &big, sizeof big, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(k_bf_nearest, dim3((M + 3) / 4), dim3(256), 0, ctx->stream, (const uint32_t*)q,
-                     M, (const uint32_t*)t, N, train_idx, dist, gmin);
+                     M, (const uint32_t*)t, N, train_idx, dist, gmin, (const int*)nullptr,
+                     (const int*)nullptr);
   hipLaunchKernelGGL(k_bf_filter, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, M, train_idx,
-                     dist, gmin, keep);
+                     dist, gmin, keep, (const int*)nullptr);
+  SVO_HIP(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
+// device-driven variant for the tracker: row counts live in HBM (M_ptr / N_ptr), grid sized for Mmax
+int svo_launch_bf_match_dev(svo_ctx* ctx, const uint8_t* q, const int* M_ptr, const uint8_t* t,
+                            const int* N_ptr, int Mmax, int32_t* train_idx, int32_t* dist,
+                            uint8_t* keep, int32_t* gmin) {
+  const int32_t big = 0x7fffffff;
+  SVO_HIP(ctx, hipMemcpyAsync(gmin, &big, sizeof big, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_bf_nearest, dim3((Mmax + 3) / 4), dim3(256), 0, ctx->stream, (const uint32_t*)q,
+                     0, (const uint32_t*)t, 0, train_idx, dist, gmin, M_ptr, N_ptr);
+  hipLaunchKernelGGL(k_bf_filter, dim3((Mmax + 255) / 256), dim3(256), 0, ctx->stream, 0, train_idx,
+                     dist, gmin, keep, M_ptr);
   SVO_HIP(ctx, hipGetLastError());
   return SVO_OK;
 }

@@ -12,11 +12,15 @@
 // The reference also stores match_score[i] = second/best for every pass-1 row
 // (src/pnpmatch.cc:99); nothing ever reads it (its only use is commented out at
 // src/Optimizer.cc:54), so the tracker does not materialise it - svo_match_greedy does.
-// Offline detection boxes (semantic gating, SURVEY f-3) are not modelled yet.
+// Offline detection boxes (main.cpp:82-95) gate the path exactly where the reference uses them:
+// the +-5 px creation gates (src/Tracking.cc:61-66 with its never-reset flag, src/frame.cc:198-203)
+// and the +-10 px epipolar veto of pass 1 (src/pnpmatch.cc:101-144) with F from the 8-point
+// algorithm over brute-force matches (src/pnpmatch.cc:302-337; svo_fmat.hip, host side).
 #include <cstddef>
 
 #include "svo_internal.h"
 #include "svo_wave.h"
+#include "svo_gate.h"
 
 #define TRK_MAXKP 512
 #define TRK_CAP 4096
@@ -44,6 +48,14 @@ struct TrackState {
   svo_lm_stats lm;
   svo_pnp_stats pnp;
   svo_camera cam;
+  // semantic gating state
+  int32_t n_boxes, n_vetoed;
+  int32_t boxes[SVO_MAX_BOXES * 4];    // {left, right, top, bottom} of the current frame
+  double F[9];                         // fundamental matrix cur <- last (row-major)
+  float last_xy[TRK_MAXKP * 2];        // LastFrame.keypoints_l[i].pt
+  uint32_t last_desc[TRK_MAXKP * 8];   // LastFrame.f_descriptor
+  int32_t bf_idx[TRK_MAXKP], bf_dist[TRK_MAXKP], bf_min;
+  uint8_t bf_keep[TRK_MAXKP];
   TrackPool pool[2];
   uint16_t rowmin[TRK_CAP];    // min over ALL current keypoints of the row's distances
   uint8_t active[TRK_CAP];     // row takes part in the greedy pass (valid && rowmin < threshold)
@@ -94,18 +106,30 @@ __global__ __launch_bounds__(512) void k_tk_begin(TrackState* st, const svo_kp* 
   st->cur_mp[tid] = -1;
   st->assigned[tid] = 0;
   const bool has_depth = tid < nkp && depth[tid] > 0.f;
+  int n_stereo;
+  block_excl_scan512(has_depth ? 1 : 0, sm, &n_stereo);
+  // Tracking::init's `dynamic` flag is declared outside the keypoint loop and never reset
+  // (src/Tracking.cc:44): once a keypoint falls into a padded box, every later one is skipped.
+  bool create0 = has_depth;
+  if (st->frame_num == 0 && st->n_boxes > 0) {
+    const svo_kp k = kp[min(tid, max(nkp - 1, 0))];
+    const bool inb = tid < nkp && svo_in_boxes(k.x, k.y, st->boxes, st->n_boxes, 5);
+    int tot_in;
+    const int before = block_excl_scan512(inb ? 1 : 0, sm, &tot_in);
+    if (before + (inb ? 1 : 0) > 0) create0 = false;
+  }
   int total;
-  const int rank = block_excl_scan512(has_depth ? 1 : 0, sm, &total);
+  const int rank = block_excl_scan512(create0 ? 1 : 0, sm, &total);
   if (tid == 0) {
     st->nkp = nkp;
-    st->n_stereo = total;
-    st->n_pass1 = 0; st->n_pass2 = 0; st->n_new = 0;
+    st->n_stereo = n_stereo;
+    st->n_pass1 = 0; st->n_pass2 = 0; st->n_new = 0; st->n_vetoed = 0;
     for (int i = 0; i < 4; ++i) st->K[i] = (double)((const float*)&st->cam)[i];
     for (int i = 0; i < 16; ++i) st->Tprior[i] = (double)st->lastTcw[i];
   }
   if (st->frame_num == 0) {
     // Tracking::init (src/Tracking.cc:42-97): pose I, one map point per keypoint with depth
-    if (has_depth) {
+    if (create0) {
       const int m = st->npool + rank;
       const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3[3] = {0, 0, 0};
       const svo_kp k = kp[tid];
@@ -228,7 +252,7 @@ __device__ __forceinline__ int tk_wave_incl_scan(int v) {
   return v;
 }
 
-__global__ __launch_bounds__(64) void k_tk_greedy(TrackState* st, int pass) {
+__global__ __launch_bounds__(64) void k_tk_greedy(TrackState* st, int pass, const svo_kp* kp) {
   __shared__ int16_t rows[TRK_CAP];
   __shared__ int16_t rowmp[TRK_CAP];
   __shared__ uint4 drow[32 * 64];   // distance rows of the current 32-row chunk (32 KB)
@@ -273,7 +297,8 @@ __global__ __launch_bounds__(64) void k_tk_greedy(TrackState* st, int pass) {
     if (j >= nkp || st->assigned[j]) claimed |= 1u << k;
   }
   const uint16_t* Dl = st->D + lane * 8;
-  int accepted_total = 0, n_slow = 0;
+  int accepted_total = 0, n_slow = 0, n_veto = 0;
+  const int n_boxes = st->n_boxes;
   // Fast path: a row's speculative result (st->pre) stays valid unless one of the two columns it
   // depends on - its best column or the column of its runner-up - was claimed during this pass:
   // removing any other column cannot change a minimum that is still present.  Only then is the
@@ -322,6 +347,18 @@ __global__ __launch_bounds__(64) void k_tk_greedy(TrackState* st, int pass) {
       }
       bool ok = bj != 0xffff && bd < max_dist;
       if (ok && ratio > 0.f) ok = (float)sec / (float)bd > ratio;
+      if (ok && pass == 1 && n_boxes > 0) {
+        // epipolar veto (src/pnpmatch.cc:103-144): the match lands in a padded box and is off
+        // the epipolar line -> the map point is marked bad and claims nothing
+        const svo_kp kc = kp[bj];
+        const int i_last = rows[a0 + k];
+        if (svo_in_boxes(kc.x, kc.y, st->boxes, n_boxes, 10) &&
+            svo_epipolar_distance(st->F, st->last_xy[2 * i_last], st->last_xy[2 * i_last + 1], kc.x, kc.y) > 0.1) {
+          if (lane == 0) P.bad[rowmp[a0 + k]] = 1;
+          ++n_veto;
+          ok = false;
+        }
+      }
       if (ok) {
         if ((bj >> 3) == lane) { claimed |= 1u << (bj & 7); claimed_now |= 1u << (bj & 7); }
         if (lane == 0) {
@@ -339,7 +376,7 @@ __global__ __launch_bounds__(64) void k_tk_greedy(TrackState* st, int pass) {
     if (j < nkp) st->assigned[j] = (uint8_t)((claimed >> k) & 1u);
   }
   if (lane == 0) {
-    if (pass == 1) { st->n_pass1 = accepted_total; st->n_rows1 = n; }
+    if (pass == 1) { st->n_pass1 = accepted_total; st->n_rows1 = n; st->n_vetoed = n_veto; }
     else { st->n_pass2 = accepted_total; st->n_rows2 = n; st->n_slow2 = n_slow; }
   }
 }
@@ -386,7 +423,14 @@ __global__ __launch_bounds__(512) void k_tk_end(TrackState* st, const svo_kp* kp
   __syncthreads();
   // frame::createmappoint for keypoints without a map point and with depth
   int m_cur = tid < nkp ? st->cur_mp[tid] : -1;
-  const bool create = tid < nkp && m_cur < 0 && depth[tid] > 0.f;
+  bool create = tid < nkp && m_cur < 0 && depth[tid] > 0.f;
+  if (tid < nkp) {
+    const svo_kp k = kp[tid];
+    if (create && st->n_boxes > 0 && svo_in_boxes(k.x, k.y, st->boxes, st->n_boxes, 5)) create = false;
+    st->last_xy[2 * tid] = k.x; st->last_xy[2 * tid + 1] = k.y;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) st->last_desc[8 * tid + w] = desc[8 * tid + w];
+  }
   int n_new;
   const int rank = block_excl_scan512(create ? 1 : 0, sm, &n_new);
   const int np0 = st->npool;
@@ -488,9 +532,9 @@ static int tail_launch(svo_ctx* ctx, int slot, svo_track_result* d_res) {
   {
     SvoTimer t(ctx, "k_tk_match");
     hipLaunchKernelGGL(k_tk_dist, dim3(TRK_MAXKP / 4), dim3(256), 0, s, st, desc, 1);
-    hipLaunchKernelGGL(k_tk_greedy, dim3(1), dim3(64), 0, s, st, 1);
+    hipLaunchKernelGGL(k_tk_greedy, dim3(1), dim3(64), 0, s, st, 1, kp);
     hipLaunchKernelGGL(k_tk_dist, dim3(TRK_CAP / 4), dim3(256), 0, s, st, desc, 2);
-    hipLaunchKernelGGL(k_tk_greedy, dim3(1), dim3(64), 0, s, st, 2);
+    hipLaunchKernelGGL(k_tk_greedy, dim3(1), dim3(64), 0, s, st, 2, kp);
   }
   {
     SvoTimer t(ctx, "k_tk_gather");
@@ -528,26 +572,70 @@ extern "C" int svo_track_reset(svo_ctx* ctx, const svo_camera* cam) {
   return SVO_OK;
 }
 
+extern "C" int svo_fundamental_8point(const double* pts1, const double* pts2, int n, double F[9]);
+
+// pnpmatch::poseEstimation2D_2D (src/pnpmatch.cc:302-337) for the frame in slot 0: brute-force
+// matches cur -> last on the device, then the (tiny) 8-point solve on the host.
+static int estimate_F(svo_ctx* ctx, const int32_t* boxes, int n_boxes) {
+  TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
+  const int K = ctx->max_kp;
+  int rc = svo_launch_bf_match_dev(ctx, ctx->d_desc, ctx->d_nkp, reinterpret_cast<const uint8_t*>(st->last_desc),
+                                   &st->lastN, K, st->bf_idx, st->bf_dist, st->bf_keep, &st->bf_min);
+  if (rc) return rc;
+  std::vector<int32_t> idx(K);
+  std::vector<uint8_t> keep(K);
+  std::vector<svo_kp> kp(K);
+  std::vector<float> lxy(2 * (size_t)TRK_MAXKP);
+  int32_t nkp = 0;
+  SVO_HIP(ctx, hipMemcpyAsync(idx.data(), st->bf_idx, 4 * (size_t)K, hipMemcpyDeviceToHost, ctx->stream));
+  SVO_HIP(ctx, hipMemcpyAsync(keep.data(), st->bf_keep, (size_t)K, hipMemcpyDeviceToHost, ctx->stream));
+  SVO_HIP(ctx, hipMemcpyAsync(kp.data(), ctx->d_kp, sizeof(svo_kp) * (size_t)K, hipMemcpyDeviceToHost, ctx->stream));
+  SVO_HIP(ctx, hipMemcpyAsync(lxy.data(), st->last_xy, sizeof(float) * lxy.size(), hipMemcpyDeviceToHost, ctx->stream));
+  SVO_HIP(ctx, hipMemcpyAsync(&nkp, ctx->d_nkp, 4, hipMemcpyDeviceToHost, ctx->stream));
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<double> p1, p2;
+  for (int i = 0; i < nkp && i < K; ++i) {
+    if (!keep[i] || idx[i] < 0) continue;
+    if (svo_in_boxes(kp[i].x, kp[i].y, boxes, n_boxes, 10)) continue;   // :318-328
+    p1.push_back(kp[i].x); p1.push_back(kp[i].y);
+    p2.push_back(lxy[2 * idx[i]]); p2.push_back(lxy[2 * idx[i] + 1]);
+  }
+  double F[9];
+  svo_fundamental_8point(p1.data(), p2.data(), (int)p1.size() / 2, F);
+  SVO_HIP(ctx, hipMemcpyAsync(st->F, F, sizeof F, hipMemcpyHostToDevice, ctx->stream));
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));   // F lives on this stack frame
+  return SVO_OK;
+}
+
 extern "C" int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL,
                                const uint8_t* grayR, int strideR, double timestamp,
                                const int32_t* boxes, int n_boxes, svo_track_result* res) {
   (void)timestamp;
-  if (!ctx || !grayL || !grayR || !res || strideL < ctx->g.W || strideR < ctx->g.W)
+  if (!ctx || !grayL || !grayR || !res || strideL < ctx->g.W || strideR < ctx->g.W || n_boxes < 0 ||
+      n_boxes > SVO_MAX_BOXES || (n_boxes > 0 && !boxes))
     return SVO_E_INVALID;
-  if (n_boxes > 0 || boxes) return SVO_E_INVALID;  // semantic gating (SURVEY f-3) not modelled yet
   if (!ctx->d_track) return SVO_E_INVALID;          // svo_track_reset first
   hipSetDevice(ctx->device);
   const SvoGeom& g = ctx->g;
+  TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
   uint8_t* dL = ctx->d_stage;
   uint8_t* dR = ctx->d_stage + (size_t)g.H * ctx->stage_pitch;
   SVO_HIP(ctx, hipMemcpy2DAsync(dL, ctx->stage_pitch, grayL, strideL, g.W, g.H,
                                 hipMemcpyHostToDevice, ctx->stream));
   SVO_HIP(ctx, hipMemcpy2DAsync(dR, ctx->stage_pitch, grayR, strideR, g.W, g.H,
                                 hipMemcpyHostToDevice, ctx->stream));
+  const int32_t nb = n_boxes;
+  SVO_HIP(ctx, hipMemcpyAsync(&st->n_boxes, &nb, 4, hipMemcpyHostToDevice, ctx->stream));
+  if (n_boxes > 0)
+    SVO_HIP(ctx, hipMemcpyAsync(st->boxes, boxes, 16 * (size_t)n_boxes, hipMemcpyHostToDevice, ctx->stream));
   int rc = svo_launch_orb(ctx, dL, dR, ctx->stage_pitch, 1, 2);
   if (rc) return rc;
   rc = svo_launch_stereo(ctx, dL, dR, ctx->stage_pitch, 1, &ctx->cam);
   if (rc) return rc;
+  if (n_boxes > 0 && ctx->track_frame > 0) {
+    rc = estimate_F(ctx, boxes, n_boxes);
+    if (rc) return rc;
+  }
   svo_track_result* d_res = reinterpret_cast<svo_track_result*>(ctx->d_scratch);
   rc = tail_launch(ctx, 0, d_res);
   if (rc) return rc;
@@ -563,6 +651,8 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
   if (B > ctx->max_batch) return SVO_E_CAPACITY;
   if (!ctx->d_track) return SVO_E_INVALID;
   hipSetDevice(ctx->device);
+  // the batched mode carries no detection boxes (the offline box files are a per-frame host input)
+  SVO_HIP(ctx, hipMemsetAsync(&reinterpret_cast<TrackState*>(ctx->d_track)->n_boxes, 0, 4, ctx->stream));
   int rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, B, 2 * B);
   if (rc) return rc;
   rc = svo_launch_stereo(ctx, d_grayL, d_grayR, stride, B, &ctx->cam);
@@ -580,6 +670,15 @@ extern "C" int svo_debug_track_matches(svo_ctx* ctx, int32_t* cur_mp) {
   TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
   SVO_HIP(ctx, hipMemcpyAsync(cur_mp, st->dbg_cur_mp, sizeof(int32_t) * ctx->max_kp,
                               hipMemcpyDeviceToHost, ctx->stream));
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVO_OK;
+}
+
+extern "C" int svo_debug_track_gate(svo_ctx* ctx, double F[9], int32_t* n_vetoed) {
+  if (!ctx || !ctx->d_track) return SVO_E_INVALID;
+  TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
+  if (F) SVO_HIP(ctx, hipMemcpyAsync(F, st->F, 72, hipMemcpyDeviceToHost, ctx->stream));
+  if (n_vetoed) SVO_HIP(ctx, hipMemcpyAsync(n_vetoed, &st->n_vetoed, 4, hipMemcpyDeviceToHost, ctx->stream));
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SVO_OK;
 }

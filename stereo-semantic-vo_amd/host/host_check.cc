@@ -1,6 +1,7 @@
 // host_check.cc - runs the C++ host classes (one C-ABI call per reference seam) and the
 // device-resident tracker (svo_track_frame) on the same PGM sequence and compares their poses
-// frame by frame.  usage: host_check <sequence_dir> <n_frames>   (frames: image_0/NNNNNN.pgm ...)
+// frame by frame.  usage: host_check <sequence_dir> <n_frames>   (frames: image_0/NNNNNN.pgm ...;
+// optional detection boxes in <sequence_dir>/boxes/<k+1>.txt, 4 ints per line: left right top bottom)
 #include <cmath>
 #include <iomanip>
 #include <iostream>
@@ -31,9 +32,18 @@ int main(int argc, char** argv) {
       host = new Tracking(cam, L.cols, L.rows, 0);
       if (svo_create(&dev, 0, L.cols, L.rows, 500, 1) != SVO_OK || svo_track_reset(dev, &cam) != SVO_OK) return 3;
     }
-    host->Track(L, R, 0.1 * k, f, f2, {});
+    std::vector<std::vector<int>> boxes;
+    std::vector<int32_t> flat;
+    {
+      std::stringstream bp; bp << seq << "/boxes/" << (k + 1) << ".txt";
+      std::ifstream bfile(bp.str());
+      int l, r, t, b2;
+      while (bfile >> l >> r >> t >> b2) { boxes.push_back({l, r, t, b2}); flat.insert(flat.end(), {l, r, t, b2}); }
+    }
+    host->Track(L, R, 0.1 * k, f, f2, boxes);
     svo_track_result res;
-    if (svo_track_frame(dev, L.ptr(), L.cols, R.ptr(), R.cols, 0.1 * k, nullptr, 0, &res) != SVO_OK) return 4;
+    if (svo_track_frame(dev, L.ptr(), L.cols, R.ptr(), R.cols, 0.1 * k, flat.empty() ? nullptr : flat.data(),
+                        (int)boxes.size(), &res) != SVO_OK) return 4;
     double d = 0;
     for (int i = 0; i < 16; ++i) d = std::max(d, (double)std::fabs(res.Tcw[i] - host->lastframe.Tcw.m[i]));
     worst = std::max(worst, d);

@@ -74,6 +74,23 @@ def test_host_classes_equal_device_tracker(pkg, tmp_path):
 
 
 @pytest.mark.gpu
+def test_host_classes_equal_device_tracker_with_boxes(pkg, tmp_path):
+    """Same comparison with offline detection boxes (creation gates + epipolar veto)."""
+    import importlib
+    synth = importlib.import_module("stereo_semantic_vo_amd.synth")
+    n = 5
+    L, R, _ = synth.render_sequence(n)
+    (tmp_path / "image_0").mkdir(); (tmp_path / "image_1").mkdir(); (tmp_path / "boxes").mkdir()
+    for k in range(n):
+        write_pgm(str(tmp_path / "image_0" / ("%06d.pgm" % k)), L[k].numpy())
+        write_pgm(str(tmp_path / "image_1" / ("%06d.pgm" % k)), R[k].numpy())
+        txt = "500 760 200 330\n" if k == 0 else "200 1000 195 370\n20 120 30 90\n"
+        (tmp_path / "boxes" / ("%d.txt" % (k + 1))).write_text(txt)
+    p = subprocess.run([os.path.join(HOST, "host_check"), str(tmp_path), str(n)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+
+
+@pytest.mark.gpu
 def test_stereo_kitti_driver_runs(pkg, tmp_path):
     import importlib
     synth = importlib.import_module("stereo_semantic_vo_amd.synth")

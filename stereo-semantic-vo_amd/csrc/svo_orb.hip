@@ -43,6 +43,7 @@ __device__ __forceinline__ const uint8_t* level_ptr(const SvoGeom& g, const ImgS
 // One thread = 4 output pixels = one dword store; rows are coalesced.
 // ---------------------------------------------------------------------------------
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void k_pyr_level(SvoGeom g, ImgSrc s, int l, uint8_t* pyr,
                                                    const int32_t* __restrict__ xofs,
@@ -72,16 +73,20 @@ __global__ __launch_bounds__(256) void k_pyr_level(SvoGeom g, ImgSrc s, int l, u
   const int base = sx[0];
   if (base + 8 <= sw) {
     // the 4 outputs read source columns base .. base+5: one unaligned 8-byte load per row
+    // (three aligned dwords + v_alignbyte measured 15 % slower: the kernel is load-latency bound)
     const uint64_t w0 = *reinterpret_cast<const u64_unaligned*>(r0 + base);
     const uint64_t w1 = *reinterpret_cast<const u64_unaligned*>(r1 + base);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+      // the two horizontal taps are adjacent bytes: one 64-bit shift brings them to bits 0..15,
+      // v_perm spreads them into u16 lanes and v_dot2_u32_u16 applies the packed (a0, a1) pair
       const int sh0 = 8 * (sx[k] - base);
-      const int a0 = (int)(int16_t)(al[k] & 0xffff), a1 = al[k] >> 16;
-      const int p00 = (int)((w0 >> sh0) & 0xff), p01 = (int)((w0 >> (sh0 + 8)) & 0xff);
-      const int p10 = (int)((w1 >> sh0) & 0xff), p11 = (int)((w1 >> (sh0 + 8)) & 0xff);
-      const int S0 = p00 * a0 + p01 * a1;
-      const int S1 = p10 * a0 + p11 * a1;
+      const uint32_t t0 = (uint32_t)(w0 >> sh0), t1 = (uint32_t)(w1 >> sh0);
+      const v2u16 p0 = __builtin_bit_cast(v2u16, __builtin_amdgcn_perm(0u, t0, 0x0c010c00u));
+      const v2u16 p1 = __builtin_bit_cast(v2u16, __builtin_amdgcn_perm(0u, t1, 0x0c010c00u));
+      const v2u16 al2 = __builtin_bit_cast(v2u16, (uint32_t)al[k]);
+      const int S0 = (int)__builtin_amdgcn_udot2(p0, al2, 0u, false);
+      const int S1 = (int)__builtin_amdgcn_udot2(p1, al2, 0u, false);
       int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
       v = min(max(v, 0), 255);
       out |= (uint32_t)v << (8 * k);
@@ -490,14 +495,38 @@ __device__ __forceinline__ void det_sincos(float angle_rad, float* s, float* c) 
 __device__ __forceinline__ int wave_sum(int v) { return wave_sum_i32_dpp(v); }
 
 #define PW 37      // staged window side (31 + 2*3)
-#define PWP 40     // padded row, bytes
+#define PROW 10    // dwords per staged row: byte 0 = column x-19, pixel column x+u at byte u+19
 
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+
+// Per-row byte weights of the intensity-centroid moments over the radius-15 disc (umax table):
+// row v (-15..15), byte c (0..31) <-> u = c-15; w = u (as int8) inside the disc, else 0; one = 1/0.
+struct MomTables { uint32_t w[31][8]; uint32_t one[31][8]; };
+constexpr MomTables make_mom_tables() {
+  MomTables t{};
+  const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+  for (int v = -15; v <= 15; ++v)
+    for (int c = 0; c < 32; ++c) {
+      const int u = c - 15, av = v < 0 ? -v : v, au = u < 0 ? -u : u;
+      const bool inside = c < 31 && au <= umax[av];
+      if (inside) {
+        t.w[v + 15][c / 4] |= (uint32_t)((uint8_t)(int8_t)u) << (8 * (c % 4));
+        t.one[v + 15][c / 4] |= 1u << (8 * (c % 4));
+      }
+    }
+  return t;
+}
+__constant__ MomTables c_mom = make_mom_tables();
+
+// One wave per keypoint.  Everything between the staged window and the descriptor bits runs on
+// the byte/short dot-product instructions: v_dot4 for the moments and the horizontal Gaussian
+// pass (bytes x {18,34,49,55 | 49,34,18,0}), v_dot2_u32_u16 for the vertical pass.
 __global__ __launch_bounds__(64) void k_describe(SvoGeom g, ImgSrc s, const SvoSel* sel,
                                                  const int32_t* selcnt, svo_kp* kp, uint8_t* desc,
                                                  int32_t* nkp, int max_kp) {
-  __shared__ uint8_t patch[PW * PWP];
-  __shared__ uint16_t hb[PW * 32];
-  __shared__ uint8_t bl[31 * 32];
+  __shared__ uint32_t patch[PW * PROW];          // 37 rows x 40 bytes
+  __shared__ uint32_t hbT[31 * 20];              // horizontal pass, TRANSPOSED: [column][row] u16, 40 rows pitch
+  __shared__ uint32_t blT[31 * 8];               // blurred 31 x 31 patch, TRANSPOSED: [column][row] u8, 32 pitch
   const int lane = threadIdx.x;
   const int slot = blockIdx.x, img = blockIdx.y;
   // slot -> (level, rank)
@@ -515,41 +544,72 @@ __global__ __launch_bounds__(64) void k_describe(SvoGeom g, ImgSrc s, const SvoS
   const int x = sv.x, y = sv.y;
   int pitch;
   const uint8_t* img_p = level_ptr(g, s, img, l, &pitch);
-  for (int i = lane; i < PW * PW; i += 64) {
-    const int r = i / PW, c = i - r * PW;
-    patch[r * PWP + c] = img_p[(size_t)(y - 18 + r) * pitch + x - 18 + c];
+  const uint8_t* org = img_p + (size_t)(y - 18) * pitch + (x - 19);
+  for (int i = lane; i < PW * PROW; i += 64) {
+    const int r = i / PROW, d = i - r * PROW;
+    patch[i] = *reinterpret_cast<const u32_unaligned*>(org + (size_t)r * pitch + 4 * d);
   }
+  for (int i = lane; i < 31 * 20; i += 64) hbT[i] = 0;   // rows 37..39 of each column stay zero
   __syncthreads();
-  // intensity centroid over the radius-15 disc
+  // intensity centroid: lane = disc row v+15; m10 = sum u*I (via I-128, the row weights sum to 0),
+  // m01 = v * sum I
   int m10 = 0, m01 = 0;
-  for (int i = lane; i < 31 * 31; i += 64) {
-    const int r = i / 31, c = i - r * 31;
-    const int v = r - 15, u = c - 15;
-    if (abs(u) <= c_umax[abs(v)]) {
-      const int I = patch[(r + 3) * PWP + c + 3];
-      m10 += u * I;
-      m01 += v * I;
+  if (lane < 31) {
+    const uint32_t* row = &patch[(lane + 3) * PROW + 1];   // bytes 4..35 = u -15..16
+    int rs = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const uint32_t px4 = row[k];
+      m10 = __builtin_amdgcn_sdot4((int)(px4 ^ 0x80808080u), (int)c_mom.w[lane][k], m10, false);
+      rs = (int)__builtin_amdgcn_udot4(px4, c_mom.one[lane][k], (uint32_t)rs, false);
     }
+    m01 = (lane - 15) * rs;
   }
   m10 = wave_sum(m10);
   m01 = wave_sum(m01);
   const float angle = fast_atan2_deg((float)m01, (float)m10);
-  // horizontal pass: 37 rows x 31 columns
-  for (int i = lane; i < PW * 31; i += 64) {
-    const int r = i / 31, c = i - r * 31;
-    const uint8_t* p = &patch[r * PWP + c];
-    const int sum = 18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3];
-    hb[r * 32 + c] = (uint16_t)sum;
+  // horizontal pass: item = (row r, group of 4 output columns c0 = 4g); taps = bytes c+1 .. c+7
+  const uint32_t K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24), K1 = 49u | (34u << 8) | (18u << 16);
+  uint16_t* hb16 = reinterpret_cast<uint16_t*>(hbT);
+  for (int i = lane; i < PW * 8; i += 64) {
+    const int r = i >> 3, gq = i & 7;
+    const uint32_t* p = &patch[r * PROW + gq];
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+    uint32_t o[4];
+    o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 1), K1,
+                                  __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 1), K0, 0u, false), false);
+    o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), K1,
+                                  __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 2), K0, 0u, false), false);
+    o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 3), K1,
+                                  __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), K0, 0u, false), false);
+    o[3] = __builtin_amdgcn_udot4(d2, K1, __builtin_amdgcn_udot4(d1, K0, 0u, false), false);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (4 * gq + j < 31) hb16[(4 * gq + j) * 40 + r] = (uint16_t)o[j];
   }
   __syncthreads();
-  for (int i = lane; i < 31 * 31; i += 64) {
-    const int r = i / 31, c = i - r * 31;
-    const uint16_t* p = &hb[r * 32 + c];
-    const int sum = 18 * (p[0] + p[6 * 32]) + 34 * (p[32] + p[5 * 32]) + 49 * (p[2 * 32] + p[4 * 32]) +
-                    55 * p[3 * 32];
-    bl[r * 32 + c] = (uint8_t)min((sum + 32768) >> 16, 255);
+  // vertical pass: item = (column c, group of 4 output rows r0 = 4h); rows r..r+6 of hbT[c]
+  const uint32_t W01 = 18u | (34u << 16), W23 = 49u | (55u << 16), W45 = 49u | (34u << 16), W6 = 18u;
+  for (int i = lane; i < 31 * 8; i += 64) {
+    const int c = i >> 3, hq = i & 7;
+    const uint32_t* p = &hbT[c * 20 + 2 * hq];
+    const uint32_t q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
+    auto dot7 = [&](uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3) {
+      uint32_t acc = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, a0), __builtin_bit_cast(v2u16, W01), 32768u, false);
+      acc = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, a1), __builtin_bit_cast(v2u16, W23), acc, false);
+      acc = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, a2), __builtin_bit_cast(v2u16, W45), acc, false);
+      acc = __builtin_amdgcn_udot2(__builtin_bit_cast(v2u16, a3), __builtin_bit_cast(v2u16, W6), acc, false);
+      return min(acc >> 16, 255u);
+    };
+    const uint32_t s01 = __builtin_amdgcn_alignbyte(q1, q0, 2), s12 = __builtin_amdgcn_alignbyte(q2, q1, 2),
+                   s23 = __builtin_amdgcn_alignbyte(q3, q2, 2), s34 = __builtin_amdgcn_alignbyte(q4, q3, 2),
+                   s45 = __builtin_amdgcn_alignbyte(0u, q4, 2);
+    const uint32_t b0 = dot7(q0, q1, q2, q3), b1 = dot7(s01, s12, s23, s34), b2 = dot7(q1, q2, q3, q4),
+                   b3 = dot7(s12, s23, s34, s45);
+    blT[c * 8 + hq] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
   }
   __syncthreads();
+  const uint8_t* bl = reinterpret_cast<const uint8_t*>(blT);
   float sn, cs;
   det_sincos(angle * 0.017453292f, &sn, &cs);
   const size_t oidx = (size_t)img * max_kp + slot;
@@ -561,8 +621,8 @@ __global__ __launch_bounds__(64) void k_describe(SvoGeom g, ImgSrc s, const SvoS
     const float px1 = (float)c_pattern[i][2], py1 = (float)c_pattern[i][3];
     const float rx0 = px0 * cs - py0 * sn, ry0 = px0 * sn + py0 * cs;
     const float rx1 = px1 * cs - py1 * sn, ry1 = px1 * sn + py1 * cs;
-    const int v0 = bl[(15 + __float2int_rn(ry0)) * 32 + 15 + __float2int_rn(rx0)];
-    const int v1 = bl[(15 + __float2int_rn(ry1)) * 32 + 15 + __float2int_rn(rx1)];
+    const int v0 = bl[(15 + __float2int_rn(rx0)) * 32 + 15 + __float2int_rn(ry0)];
+    const int v1 = bl[(15 + __float2int_rn(rx1)) * 32 + 15 + __float2int_rn(ry1)];
     const uint64_t m = __ballot(v0 < v1);
     if (lane == 0) dout[t] = m;
   }

@@ -331,21 +331,26 @@ __global__ __launch_bounds__(256) void k_fast(SvoGeom g, ImgSrc s, uint32_t* cor
 // keep `quota`.  One workgroup; candidates live in LDS.
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ int64_t harris_at(const uint8_t* img, int pitch, int x, int y) {
+  typedef uint32_t __attribute__((aligned(1))) u32u;
   int64_t a = 0, b = 0, c = 0;
-  // 9 x 9 neighbourhood; gradients of the inner 7 x 7
+  // 9 x 9 neighbourhood (bytes x-4 .. x+4), three unaligned dword loads per row; gradients of the
+  // inner 7 x 7 with a rolling window of three rows
   int row[3][9];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int i = 0; i < 9; ++i) row[j + 1][i] = img[(size_t)(y - 4 + j) * pitch + x - 4 + i];
+  auto load_row = [&](int yy, int* dst) {
+    const uint8_t* p = img + (size_t)yy * pitch + x - 4;
+    const uint32_t w0 = *reinterpret_cast<const u32u*>(p), w1 = *reinterpret_cast<const u32u*>(p + 4),
+                   w2 = *reinterpret_cast<const u32u*>(p + 8);
+    dst[0] = w0 & 0xff; dst[1] = (w0 >> 8) & 0xff; dst[2] = (w0 >> 16) & 0xff; dst[3] = w0 >> 24;
+    dst[4] = w1 & 0xff; dst[5] = (w1 >> 8) & 0xff; dst[6] = (w1 >> 16) & 0xff; dst[7] = w1 >> 24;
+    dst[8] = w2 & 0xff;
+  };
+  load_row(y - 4, row[1]);
+  load_row(y - 3, row[2]);
 #pragma unroll 1
   for (int dy = -3; dy <= 3; ++dy) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      row[0][i] = row[1][i];
-      row[1][i] = row[2][i];
-      row[2][i] = img[(size_t)(y + dy + 1) * pitch + x - 4 + i];
-    }
+    for (int i = 0; i < 9; ++i) { row[0][i] = row[1][i]; row[1][i] = row[2][i]; }
+    load_row(y + dy + 1, row[2]);
     int sa = 0, sb = 0, scv = 0;
 #pragma unroll
     for (int i = 1; i <= 7; ++i) {
@@ -378,18 +383,24 @@ __global__ __launch_bounds__(256) void k_select(SvoGeom g, ImgSrc s, const uint3
     return;
   }
   cum[tid] = hist[(img * SVO_NLEVELS + l) * 256 + tid];
-  if (tid == 0) { cum[256] = 0; nc = 0; }
+  if (tid == 0) { cum[256] = 0; nc = 0; sT = 0; }
   __syncthreads();
-  if (tid == 0) {
-    for (int sidx = 255; sidx >= 0; --sidx) cum[sidx] += cum[sidx + 1];  // suffix counts
-    int T = 0;
+  // suffix counts cum[s] = #corners with score >= s (parallel scan over the 256 bins)
+  for (int o = 1; o < 256; o <<= 1) {
+    const int t = tid + o < 256 ? cum[tid + o] : 0;
+    __syncthreads();
+    cum[tid] += t;
+    __syncthreads();
+  }
+  {
+    // retainBest(2*quota) with ties: the largest s whose suffix count reaches the target;
+    // then the CAP1 rule: the smallest s whose suffix count fits.  cum[] is non-increasing in s,
+    // so each condition holds at exactly one bin.
     const int target = 2 * quota;
-    if (n > target) {
-      for (int sidx = 255; sidx >= 0; --sidx)
-        if (cum[sidx] >= target) { T = sidx; break; }
-    }
-    while (cum[T] > SVO_CAP1) ++T;
-    sT = T;
+    int cand = 0;
+    if (n > target && cum[tid] >= target && cum[tid + 1] < target) cand = tid;
+    if (cum[tid] <= SVO_CAP1 && (tid == 0 || cum[tid - 1] > SVO_CAP1)) cand = max(cand, tid);
+    if (cand) atomicMax(&sT, cand);
   }
   __syncthreads();
   const int T = sT;

@@ -12,6 +12,7 @@
 #include <sstream>
 
 #include "Tracking.h"
+#include "convert.h"
 #include "png_reader.h"
 
 using namespace svo_host;
@@ -27,6 +28,13 @@ int main(int argc, char** argv) {
     fprintf(o, "P5\n%d %d\n255\n", img.cols, img.rows);
     fwrite(img.data.data(), 1, img.data.size(), o);
     fclose(o);
+    return 0;
+  }
+  if (argc == 11 && std::string(argv[1]) == "--quat") {   // convert::toQuaternion self-test
+    Mat33f R;
+    for (int i = 0; i < 9; ++i) R.m[i] = (float)atof(argv[2 + i]);
+    const std::vector<float> q = convert::toQuaternion(R);
+    std::cout << std::fixed << std::setprecision(7) << q[0] << " " << q[1] << " " << q[2] << " " << q[3] << std::endl;
     return 0;
   }
   if (argc != 4) {

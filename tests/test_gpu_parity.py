@@ -234,3 +234,76 @@ def test_pnp_ransac_against_oracle(svo_small, orc, seed, n):
     assert np.array_equal(mask, mr)
     assert np.abs(T[:3, 3] - Tr[:3, 3]).max() < POSE_ATOL_T
     assert np.abs(T[:3, :3] - Tr[:3, :3]).max() < POSE_ATOL_R
+
+
+# ---- batched device path, other sizes, ragged outputs ------------------------------------------------
+def test_frontend_batch_dev_equals_per_pair(pkg, orc):
+    """svo_frontend_batch_dev over HBM-resident, pitched images == the per-pair host API == oracle."""
+    import torch
+    W, H, B, pitch = 640, 240, 3, 704
+    cam = pkg.Camera(**pkg.KITTI_00_02)
+    pairs = [util.shifted_pair(30 + i, W, H, disparity=6 + 9 * i) for i in range(B)]
+    dev = torch.device("cuda", 0)
+    dL = torch.zeros((B, H, pitch), dtype=torch.uint8, device=dev)
+    dR = torch.zeros_like(dL)
+    for i, (L, R) in enumerate(pairs):
+        dL[i, :, :W] = torch.from_numpy(L).to(dev); dR[i, :, :W] = torch.from_numpy(R).to(dev)
+    kp = torch.zeros((B, 500, 28), dtype=torch.uint8, device=dev)
+    desc = torch.zeros((B, 500, 32), dtype=torch.uint8, device=dev)
+    n = torch.zeros(B, dtype=torch.int32, device=dev)
+    uR = torch.zeros((B, 500), dtype=torch.float32, device=dev)
+    depth = torch.zeros((B, 500), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    svo = pkg.Svo(W, H, max_batch=B)
+    svo.frontend_batch_dev(dL.data_ptr(), dR.data_ptr(), pitch, B, cam, kp.data_ptr(), desc.data_ptr(),
+                           n.data_ptr(), uR.data_ptr(), depth.data_ptr())
+    svo.sync()
+    n_h = n.cpu().numpy(); kp_h = kp.cpu().numpy().view(pkg.KP_DTYPE).reshape(B, 500)
+    desc_h = desc.cpu().numpy(); uR_h = uR.cpu().numpy(); depth_h = depth.cpu().numpy()
+    for i, (L, R) in enumerate(pairs):
+        r = orc.stereo_frame(L, R, cam.bf, cam.fx)
+        m = len(r["kpL"])
+        assert n_h[i] == m
+        same_kp(kp_h[i][:m], r["kpL"])
+        assert np.array_equal(desc_h[i][:m], r["dL"])
+        assert np.array_equal(uR_h[i][:m].view(np.uint32), r["uR"].view(np.uint32))
+        assert np.array_equal(depth_h[i][:m].view(np.uint32), r["depth"].view(np.uint32))
+    svo.close()
+
+
+@pytest.mark.parametrize("W,H", [(1344, 391), (333, 207), (96, 96), (2048, 96)])
+def test_orb_other_image_sizes(pkg, orc, W, H):
+    if (W, H) == (1344, 391):
+        img = util.read_pgm(os.path.join(util.GOLDEN, "urban1_left.pgm"))
+    else:
+        img = util.blocky_image(W * 7 + H, W, H)
+    svo = pkg.Svo(W, H)
+    kp, desc = svo.orb_extract(img)
+    rkp, rdesc = orc.orb_extract(img)
+    assert len(kp) == len(rkp)
+    same_kp(kp, rkp)
+    assert np.array_equal(desc, rdesc)
+    svo.close()
+
+
+def test_orb_ragged_fewer_than_500_keypoints(svo_kitti, orc):
+    """Texture in one corner only: far fewer than 500 keypoints, several empty pyramid levels."""
+    img = np.full((util.KITTI_H, util.KITTI_W), 90, np.uint8)
+    img[100:150, 300:370] = util.blocky_image(77, 70, 50)
+    kp, desc = svo_kitti.orb_extract(img)
+    rkp, rdesc = orc.orb_extract(img)
+    assert 0 < len(rkp) < 500 and len(kp) == len(rkp)
+    same_kp(kp, rkp)
+    assert np.array_equal(desc, rdesc)
+
+
+def test_invalid_arguments_are_rejected(pkg, svo_small):
+    import ctypes as C
+    lib = pkg.load_library()
+    h = C.c_void_p()
+    assert lib.svo_create(C.byref(h), 99, 640, 240, 500, 1) == -2          # no such device
+    assert lib.svo_create(C.byref(h), 0, 640, 240, 1000, 1) == -1          # max_kp out of range
+    n = C.c_int32(0)
+    assert lib.svo_orb_extract(svo_small.h, None, 640, None, None, C.byref(n)) == -1
+    with pytest.raises(pkg.SvoError):                                       # capacity: max_batch = 2
+        svo_small.frontend_batch_dev(1, 1, 640, 5, pkg.Camera(**pkg.KITTI_00_02))

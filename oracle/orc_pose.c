@@ -25,8 +25,9 @@
  * orc_pnp_ransac stands in for cv::solvePnPRansac (src/pnpmatch.cc:227;
  * 100 iterations, 8 px, confidence 0.99, EPnP on 5-point minimal sets
  * [upstream-memory]).  OpenCV is absent, so the algorithm is this framework's
- * own: 100 seeded 5-point hypotheses, each solved by 6 Gauss-Newton steps from
- * the prior pose, scored at 8 px, best refit on its inliers.  PARITY UNPINNED.
+ * own: 100 seeded 5-point hypotheses, each solved by up to 6 Gauss-Newton steps from
+ * the prior pose (stopping once max|dx| < 1e-10), scored at 8 px, best refit on its inliers
+ * (up to 10 steps, same stop rule).  PARITY UNPINNED.
  */
 #include <float.h>
 #include <math.h>
@@ -366,9 +367,11 @@ static void gn_refine(se3_t* est, const double* Xw, const double* obs, const int
     }
     if (!ldlt6_solve(H, b, x)) return;
     int fin = 1;
-    for (int j = 0; j < 6; ++j) fin &= isfinite(x[j]) ? 1 : 0;
+    double xmax = 0;
+    for (int j = 0; j < 6; ++j) { fin &= isfinite(x[j]) ? 1 : 0; xmax = fmax(xmax, fabs(x[j])); }
     if (!fin) return;
     se3_oplus(x, est);
+    if (xmax < 1e-10) return; /* converged: further steps would not move the pose */
   }
 }
 static int count_inliers(const se3_t* est, const double* Xw, const double* obs, int n,

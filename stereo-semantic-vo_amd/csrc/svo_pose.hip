@@ -17,6 +17,8 @@
 
 struct Se3 { double q[4]; double t[3]; };
 
+// Eigen Quaternion(Matrix3): the three "largest diagonal" cases are written out so that nothing is
+// indexed dynamically (dynamic indices would push the matrix into scratch memory).
 __device__ __forceinline__ void quat_from_R(const double m[9], double q[4]) {
   double t = m[0] + m[4] + m[8];
   if (t > 0.0) {
@@ -29,16 +31,20 @@ __device__ __forceinline__ void quat_from_R(const double m[9], double q[4]) {
   } else {
     int i = 0;
     if (m[4] > m[0]) i = 1;
-    if (m[8] > m[4 * i]) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    t = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
-    double qq[3];
-    qq[i] = 0.5 * t;
-    t = 0.5 / t;
-    q[3] = (m[3 * k + j] - m[3 * j + k]) * t;
-    qq[j] = (m[3 * j + i] + m[3 * i + j]) * t;
-    qq[k] = (m[3 * k + i] + m[3 * i + k]) * t;
-    q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2];
+    if (m[8] > (i == 1 ? m[4] : m[0])) i = 2;
+    if (i == 0) {            // j = 1, k = 2
+      t = sqrt(m[0] - m[4] - m[8] + 1.0);
+      q[0] = 0.5 * t; t = 0.5 / t;
+      q[3] = (m[7] - m[5]) * t; q[1] = (m[3] + m[1]) * t; q[2] = (m[6] + m[2]) * t;
+    } else if (i == 1) {     // j = 2, k = 0
+      t = sqrt(m[4] - m[8] - m[0] + 1.0);
+      q[1] = 0.5 * t; t = 0.5 / t;
+      q[3] = (m[2] - m[6]) * t; q[2] = (m[7] + m[5]) * t; q[0] = (m[1] + m[3]) * t;
+    } else {                 // j = 0, k = 1
+      t = sqrt(m[8] - m[0] - m[4] + 1.0);
+      q[2] = 0.5 * t; t = 0.5 / t;
+      q[3] = (m[3] - m[1]) * t; q[0] = (m[2] + m[6]) * t; q[1] = (m[5] + m[7]) * t;
+    }
   }
 }
 __device__ __forceinline__ void normalize_rotation(Se3& s) {
@@ -126,33 +132,53 @@ __device__ __forceinline__ void huber(double e, double delta, double dsqr, doubl
   if (e <= dsqr) { rho0 = e; rho1 = 1.; }
   else { const double sq = sqrt(e); rho0 = 2 * sq * delta - dsqr; rho1 = delta / sq; }
 }
-__device__ int ldlt6_solve(const double* Hin, const double* b, double* x) {
-  double L[36], D[6];
-  for (int i = 0; i < 36; ++i) L[i] = 0;
+// 6x6 LDL^T solve, fully unrolled so L, D and y stay in registers (dynamically indexed local arrays
+// would be placed in scratch memory, and this sits on the serial path of every LM / RANSAC step).
+// Returns 0 if a pivot is not positive (Eigen LDLT::isPositive() false).
+__device__ __forceinline__ int ldlt6_solve(const double* Hin, const double* b, double* x) {
+  double L[6][6], D[6], y[6];
+  bool ok = true;
+#pragma unroll
   for (int j = 0; j < 6; ++j) {
     double d = Hin[6 * j + j];
-    for (int k = 0; k < j; ++k) d -= L[6 * j + k] * L[6 * j + k] * D[k];
-    if (!(d > 0.0)) return 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      if (k < j) d -= L[j][k] * L[j][k] * D[k];
+    ok = ok && (d > 0.0);
     D[j] = d;
-    L[6 * j + j] = 1.0;
-    for (int i = j + 1; i < 6; ++i) {
-      double s = Hin[6 * i + j];
-      for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k] * D[k];
-      L[6 * i + j] = s / d;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (i > j) {
+        double sacc = Hin[6 * i + j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          if (k < j) sacc -= L[i][k] * L[j][k] * D[k];
+        L[i][j] = sacc / d;
+      }
     }
   }
-  double y[6];
+  if (!ok) return 0;
+#pragma unroll
   for (int i = 0; i < 6; ++i) {
-    double s = b[i];
-    for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k];
-    y[i] = s;
+    double sacc = b[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      if (k < i) sacc -= L[i][k] * y[k];
+    y[i] = sacc;
   }
+#pragma unroll
   for (int i = 0; i < 6; ++i) y[i] /= D[i];
+  double xs[6];
+#pragma unroll
   for (int i = 5; i >= 0; --i) {
-    double s = y[i];
-    for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k];
-    x[i] = s;
+    double sacc = y[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      if (k > i) sacc -= L[k][i] * xs[k];
+    xs[i] = sacc;
   }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) x[i] = xs[i];
   return 1;
 }
 __device__ __forceinline__ void edge_error(const Se3& est, const double* Xw, const double* obs,
@@ -235,8 +261,11 @@ __device__ __forceinline__ double partial_chi2(const Se3& est, const double* Xw,
 }
 __device__ __forceinline__ void unpack_system(const double* red, double H[36], double b[6]) {
   int k = 0;
+#pragma unroll
   for (int r = 0; r < 6; ++r)
+#pragma unroll
     for (int c = r; c < 6; ++c) { H[6 * r + c] = red[k]; H[6 * c + r] = red[k]; ++k; }
+#pragma unroll
   for (int r = 0; r < 6; ++r) b[r] = red[21 + r];
 }
 
@@ -309,11 +338,15 @@ __global__ __launch_bounds__(256) void k_pose_opt(const double* __restrict__ Xw,
       if (tid == 0) {
         sh.backup = sh.est;
         double Hl[36];
+#pragma unroll
         for (int j = 0; j < 36; ++j) Hl[j] = H[j];
+#pragma unroll
         for (int j = 0; j < 6; ++j) Hl[7 * j] += lambda;
         double xloc[6];
+#pragma unroll
         for (int j = 0; j < 6; ++j) xloc[j] = sh.x[j];
         ok2 = ldlt6_solve(Hl, b, xloc);
+#pragma unroll
         for (int j = 0; j < 6; ++j) sh.x[j] = xloc[j];
         Se3 e2 = sh.est;
         se3_oplus(xloc, e2);
@@ -414,35 +447,50 @@ __global__ __launch_bounds__(256) void k_pnp_ransac(const double* __restrict__ X
   if (tid < PNP_HYP && n >= 5) {
     uint64_t s = seed ^ ((uint64_t)(tid + 1) * 0x9E3779B97F4A7C15ULL);
     lcg_next(s);
-    int idx[5], got = 0, draws = 0;
+    int idx[5] = {-1, -1, -1, -1, -1}, got = 0, draws = 0;
     while (got < 5 && draws < 64) {
       const int c = (int)(lcg_next(s) % (uint32_t)n);
       ++draws;
       bool dup = false;
-      for (int j = 0; j < got; ++j) dup |= idx[j] == c;
-      if (!dup) idx[got++] = c;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) dup |= (j < got) && idx[j] == c;
+      if (!dup) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+          if (j == got) idx[j] = c;
+        ++got;
+      }
     }
     if (got == 5) {
       Se3 est = prior;
-      for (int it = 0; it < 6; ++it) {
+      bool active = true;   // per-hypothesis early stop (max|dx| < 1e-10), same rule as the refit
+      for (int it = 0; it < 6 && active; ++it) {
         double H[36], b[6], x[6];
+#pragma unroll
         for (int j = 0; j < 36; ++j) H[j] = 0;
+#pragma unroll
         for (int j = 0; j < 6; ++j) b[j] = 0;
+#pragma unroll
         for (int k = 0; k < 5; ++k) {
           const int i = idx[k];
           double e[2], pc[3], J[12];
           edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc);
           edge_jacobian(pc, K, J);
+#pragma unroll
           for (int r = 0; r < 6; ++r) {
             b[r] -= J[r] * e[0] + J[6 + r] * e[1];
+#pragma unroll
             for (int c = 0; c < 6; ++c) H[6 * r + c] += J[r] * J[c] + J[6 + r] * J[6 + c];
           }
         }
         if (!ldlt6_solve(H, b, x)) break;
         bool fin = true;
-        for (int j = 0; j < 6; ++j) fin = fin && isfinite(x[j]);
+        double xmax = 0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { fin = fin && isfinite(x[j]); xmax = fmax(xmax, fabs(x[j])); }
         if (!fin) break;
         se3_oplus(x, est);
+        if (xmax < 1e-10) active = false;
       }
       hyp[tid] = est;
       hcnt[tid] = 0;
@@ -489,9 +537,14 @@ __global__ __launch_bounds__(256) void k_pnp_ransac(const double* __restrict__ X
         if (!ldlt6_solve(H, b, x)) stop = 1;
         else {
           bool fin = true;
-          for (int j = 0; j < 6; ++j) fin = fin && isfinite(x[j]);
+          double xmax = 0;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) { fin = fin && isfinite(x[j]); xmax = fmax(xmax, fabs(x[j])); }
           if (!fin) stop = 1;
-          else { Se3 e2 = cur; se3_oplus(x, e2); cur = e2; }
+          else {
+            Se3 e2 = cur; se3_oplus(x, e2); cur = e2;
+            if (xmax < 1e-10) stop = 1;   // converged
+          }
         }
         s_stop = stop;
       }

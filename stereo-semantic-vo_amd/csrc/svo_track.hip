@@ -234,7 +234,11 @@ __global__ __launch_bounds__(256) void k_tk_dist(TrackState* st, const uint32_t*
   ks = tk_wmin(ks);
   if (lane == 0) {
     const uint32_t y = ks == 0xffffffffu ? ((256u << 16) | 0xffffu) : ks;
-    st->pre[row] = make_uint2(kb, y);
+    // bit 31 of x: the row would be accepted with this (speculative) result
+    const int bd = (int)(kb >> 16), sec = (int)(y >> 16);
+    bool ok = (kb & 0xffffu) != 0xffffu && bd < max_dist;
+    if (ok && pass == 2) ok = (float)sec / (float)bd > 2.f;
+    st->pre[row] = make_uint2(kb | (ok ? 0x80000000u : 0u), y);
   }
 }
 
@@ -256,6 +260,7 @@ __global__ __launch_bounds__(64) void k_tk_greedy(TrackState* st, int pass, cons
   __shared__ int16_t rows[TRK_CAP];
   __shared__ int16_t rowmp[TRK_CAP];
   __shared__ uint4 drow[32 * 64];   // distance rows of the current 32-row chunk (32 KB)
+  __shared__ uint8_t claimedB[512]; // columns claimed during THIS pass
   const int lane = threadIdx.x;
   const int M = pass == 1 ? st->m1 : st->m2;
   if (M <= 0 || st->skip_match) return;
@@ -290,7 +295,6 @@ __global__ __launch_bounds__(64) void k_tk_greedy(TrackState* st, int pass, cons
   for (int a = lane; a < n; a += 64) rowmp[a] = (int16_t)(pass == 1 ? st->last_mp[rows[a]] : rows[a]);
   __syncthreads();
   uint32_t claimed = 0;       // all claims (initial + this pass), columns 8*lane .. 8*lane+7
-  uint32_t claimed_now = 0;   // claims made during THIS pass only
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int j = lane * 8 + k;
@@ -299,35 +303,38 @@ __global__ __launch_bounds__(64) void k_tk_greedy(TrackState* st, int pass, cons
   const uint16_t* Dl = st->D + lane * 8;
   int accepted_total = 0, n_slow = 0, n_veto = 0;
   const int n_boxes = st->n_boxes;
-  // Fast path: a row's speculative result (st->pre) stays valid unless one of the two columns it
-  // depends on - its best column or the column of its runner-up - was claimed during this pass:
-  // removing any other column cannot change a minimum that is still present.  Only then is the
-  // row re-scanned by the wave under the current claims (slow path).
+  // A row's speculative result (st->pre) stays valid unless one of the two columns it depends on -
+  // its best column or the column of its runner-up - was claimed during this pass: removing any
+  // other column cannot change a minimum that is still present.  So the only rows that can change
+  // any state are EVENTS: rows that would be accepted, and rows whose result went stale.  Each
+  // 32-row chunk is evaluated by 32 lanes in parallel against the claim bytes in LDS; the wave
+  // then jumps from event to event (ballot + ffs) instead of walking every row.
+  for (int j = lane; j < 512; j += 64) claimedB[j] = 0;
   for (int a0 = 0; a0 < n; a0 += 32) {
-    const int mine = a0 + lane;
-    uint2 pv = make_uint2(0xffffffffu, 0xffffffffu);
-    if (lane < 32 && mine < n) pv = st->pre[rows[mine]];
     const int cntb = min(32, n - a0);
-    // stage the chunk's distance rows in LDS with all loads in flight at once: a stale row then
-    // costs an LDS read, not an L2 round trip, on the serial chain
+    const int mine = a0 + lane;
+    uint2 pv = make_uint2(0x0000ffffu, 0xffffffffu);
+    if (lane < cntb) pv = st->pre[rows[mine]];
     __syncthreads();
 #pragma unroll 8
     for (int k = 0; k < cntb; ++k) drow[k * 64 + lane] = *reinterpret_cast<const uint4*>(Dl + (size_t)rows[a0 + k] * 512);
     __syncthreads();
-    for (int k = 0; k < cntb; ++k) {
+    const int my_bj = (int)(pv.x & 0xffffu), my_js = (int)(pv.y & 0xffffu);
+    const bool my_ok = (pv.x >> 31) != 0;
+    int start = 0;
+    for (;;) {
+      bool my_stale = false;
+      if (lane >= start && lane < cntb && my_bj != 0xffff)
+        my_stale = claimedB[my_bj] != 0 || (my_js != 0xffff && claimedB[my_js] != 0);
+      const bool my_event = lane >= start && lane < cntb && (my_stale || my_ok);
+      const uint64_t em = __ballot(my_event);
+      if (em == 0) break;
+      const int k = __ffsll((long long)em) - 1;              // first event row of the chunk
+      const bool stale = (__ballot(my_stale) >> k) & 1ull;
       const uint32_t kb = __builtin_amdgcn_readlane((int)pv.x, k);
       const uint32_t ks = __builtin_amdgcn_readlane((int)pv.y, k);
-      int bj = (int)(kb & 0xffffu), bd = (int)(kb >> 16), sec = (int)(ks >> 16);
-      const int js = (int)(ks & 0xffffu);
-      bool stale = false;
-      if (bj != 0xffff) {
-        const uint32_t cb = __builtin_amdgcn_readlane((int)claimed_now, bj >> 3);
-        stale = (cb >> (bj & 7)) & 1u;
-        if (!stale && js != 0xffff) {
-          const uint32_t cs = __builtin_amdgcn_readlane((int)claimed_now, js >> 3);
-          stale = (cs >> (js & 7)) & 1u;
-        }
-      }
+      int bj = (int)(kb & 0xffffu), bd = (int)((kb >> 16) & 0x7fffu), sec = (int)(ks >> 16);
+      bool ok = (kb >> 31) != 0;
       if (stale) {
         ++n_slow;
         const uint4 v = drow[k * 64 + lane];
@@ -344,9 +351,9 @@ __global__ __launch_bounds__(64) void k_tk_greedy(TrackState* st, int pass, cons
         for (int c = 0; c < 8; ++c)
           if (!((claimed >> c) & 1u) && lane * 8 + c < bj) ls = min(ls, cur[c]);
         sec = (int)tk_wmin(ls);
+        ok = bj != 0xffff && bd < max_dist;
+        if (ok && ratio > 0.f) ok = (float)sec / (float)bd > ratio;
       }
-      bool ok = bj != 0xffff && bd < max_dist;
-      if (ok && ratio > 0.f) ok = (float)sec / (float)bd > ratio;
       if (ok && pass == 1 && n_boxes > 0) {
         // epipolar veto (src/pnpmatch.cc:103-144): the match lands in a padded box and is off
         // the epipolar line -> the map point is marked bad and claims nothing
@@ -360,14 +367,17 @@ __global__ __launch_bounds__(64) void k_tk_greedy(TrackState* st, int pass, cons
         }
       }
       if (ok) {
-        if ((bj >> 3) == lane) { claimed |= 1u << (bj & 7); claimed_now |= 1u << (bj & 7); }
+        if ((bj >> 3) == lane) claimed |= 1u << (bj & 7);
         if (lane == 0) {
+          claimedB[bj] = 1;
           const int m = rowmp[a0 + k];
           st->cur_mp[bj] = m;
           P.obs_frame[m] = id;
         }
         ++accepted_total;
+        __syncthreads();   // claimedB visible to the re-evaluation below
       }
+      start = k + 1;
     }
   }
 #pragma unroll

@@ -111,6 +111,10 @@ const char* svo_last_error(const svo_ctx* ctx);
  * stereo pairs one batched call may carry (>= 1). */
 int svo_create(svo_ctx** out, int device, int W, int H, int max_kp, int max_batch);
 void svo_destroy(svo_ctx* ctx);
+/* Tuning switches.  "pose_mfma" (default 1): build the 6x6 J^T W J / J^T W e of svo_pose_opt, of the
+ * PnP refit and of the tracker's pose optimisation as a Gram contraction on
+ * v_mfma_f64_16x16x4_f64; 0 selects the VALU + DPP reduction (same results to round-off). */
+int svo_set_option(svo_ctx* ctx, const char* key, int value);
 /* Block until everything enqueued on the ctx stream has finished. */
 int svo_sync(svo_ctx* ctx);
 /* The ctx's hipStream_t as an opaque pointer (for event timing by the caller). */

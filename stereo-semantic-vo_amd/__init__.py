@@ -36,6 +36,7 @@ TRACK_DTYPE = np.dtype([("Tcw", "<f4", (16,)), ("frame_id", "<i4"), ("n_kp", "<i
 # Every symbol include/svo.h declares (checked by tests/test_abi.py without a GPU).
 ABI_SYMBOLS = [
     "svo_abi_version", "svo_strerror", "svo_last_error", "svo_create", "svo_destroy", "svo_sync",
+    "svo_set_option",
     "svo_stream", "svo_orb_geometry", "svo_orb_extract", "svo_debug_pyramid_level",
     "svo_debug_fast_corners", "svo_stereo_frame", "svo_stereo_frame_ex", "svo_disp2depth",
     "svo_unproject", "svo_descriptor_distance", "svo_hamming_argmin", "svo_match_greedy",
@@ -145,6 +146,9 @@ class Svo:
     @staticmethod
     def camera(fx, fy, cx, cy, bf):
         return Camera(fx, fy, cx, cy, bf)
+
+    def set_option(self, key, value):
+        self._chk(self.lib.svo_set_option(self.h, key.encode(), int(value)))
 
     def sync(self):
         self._chk(self.lib.svo_sync(self.h))

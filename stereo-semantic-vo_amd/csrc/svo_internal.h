@@ -93,6 +93,7 @@ struct svo_ctx {
   svo_camera cam{};
   int track_frame = 0;
 
+  int opt_pose_mfma = 1;   // svo_set_option("pose_mfma"): Gram accumulation of k_pose_opt on f64 MFMA
   bool profiling = false;
   std::vector<SvoProfileEntry> prof;
   void* prof_impl = nullptr;  // SvoProfState (svo_api.hip)

@@ -247,6 +247,84 @@ __device__ __forceinline__ void accum_system(const Se3& est, const double* Xw, c
     acc[27] += rho0;
   }
 }
+// ---- MFMA variant of the system build ---------------------------------------------------------
+// The normal equations are a Gram matrix: with A~ = sqrt(w) [J | e]  (2n rows x 7 columns)
+//   A~^T A~ = [ H  -b ; -b^T  sum w e^2 ],   H = J^T W J,  b = -J^T W e
+// - the one dense contraction on the path.  Rows are written to LDS once per LM iteration by all
+// 256 lanes (one edge each); every wave then feeds 4 rows per v_mfma_f64_16x16x4_f64 (A = B = the
+// row block, so each lane loads ONE double per instruction) and the four per-wave 16x16 tiles are
+// summed through LDS.  Only the leading 7x7 of the tile is meaningful.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+#define GRAM_MAXN 512
+#define GRAM_STRIDE 7
+
+template <bool ROBUST>
+__device__ __forceinline__ void build_system_mfma(const Se3& est, const double* Xw, const double* obs,
+                                                  int n, const uint8_t* use, const double* K,
+                                                  double delta, double dsqr, double* arow /*[2*512*7]*/,
+                                                  double* gram /*[4][8][8]*/, double* red) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int rows = (2 * n + 63) & ~63;           // 4 waves x whole groups of four 4-row steps
+  double chi = 0;
+  for (int i = tid; 2 * i < rows; i += 256) {
+    double r0[7] = {0, 0, 0, 0, 0, 0, 0}, r1[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (i < n && !(use && !use[i])) {
+      double e[2], pc[3], J[12];
+      edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc);
+      double rho0 = e[0] * e[0] + e[1] * e[1], rho1 = 1.;
+      if (ROBUST) huber(rho0, delta, dsqr, rho0, rho1);
+      edge_jacobian(pc, K, J);
+      const double sw = sqrt(rho1);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) { r0[c] = sw * J[c]; r1[c] = sw * J[6 + c]; }
+      r0[6] = sw * e[0]; r1[6] = sw * e[1];
+      chi += rho0;
+    }
+#pragma unroll
+    for (int c = 0; c < 7; ++c) { arow[(2 * i) * GRAM_STRIDE + c] = r0[c]; arow[(2 * i + 1) * GRAM_STRIDE + c] = r1[c]; }
+  }
+  __syncthreads();
+  const int c = lane & 15, kk = lane >> 4;
+  const int per_wave = rows >> 2;
+  // four independent accumulators: a dependent chain of f64 MFMAs would serialise on the
+  // instruction's own latency
+  v4f64 acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+  for (int r = wv * per_wave; r < (wv + 1) * per_wave; r += 16) {
+    const double* p = &arow[(r + kk) * GRAM_STRIDE + c];
+    const double v0 = c < 7 ? p[0] : 0.0, v1 = c < 7 ? p[4 * GRAM_STRIDE] : 0.0,
+                 v2 = c < 7 ? p[8 * GRAM_STRIDE] : 0.0, v3 = c < 7 ? p[12 * GRAM_STRIDE] : 0.0;
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, acc1, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(v2, v2, acc2, 0, 0, 0);
+    acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(v3, v3, acc3, 0, 0, 0);
+  }
+  const v4f64 acc = (acc0 + acc1) + (acc2 + acc3);
+  // C/D layout of the f64 16x16x4 form: col = lane & 15, row = (lane >> 4) + 4 * reg
+  if (c < 8) {
+    gram[(wv * 8 + kk) * 8 + c] = acc[0];
+    gram[(wv * 8 + kk + 4) * 8 + c] = acc[1];
+  }
+  chi = wave_sum_d(chi);
+  if (lane == 0) gram[256 + wv] = chi;
+  __syncthreads();
+  if (tid < 28) {
+    double out;
+    if (tid < 21) {
+      int r = 0, k = tid;                        // upper-triangular index -> (r, cc)
+      while (k >= 6 - r) { k -= 6 - r; ++r; }
+      const int cc = r + k;
+      out = gram[(0 * 8 + r) * 8 + cc] + gram[(1 * 8 + r) * 8 + cc] + gram[(2 * 8 + r) * 8 + cc] + gram[(3 * 8 + r) * 8 + cc];
+    } else if (tid < 27) {
+      const int r = tid - 21;
+      out = -(gram[(0 * 8 + r) * 8 + 6] + gram[(1 * 8 + r) * 8 + 6] + gram[(2 * 8 + r) * 8 + 6] + gram[(3 * 8 + r) * 8 + 6]);
+    } else {
+      out = gram[256] + gram[257] + gram[258] + gram[259];
+    }
+    red[tid] = out;
+  }
+  __syncthreads();
+}
+
 __device__ __forceinline__ double partial_chi2(const Se3& est, const double* Xw, const double* obs,
                                                int n, const double* K, double delta, double dsqr) {
   double chi = 0;
@@ -281,8 +359,11 @@ __global__ __launch_bounds__(256) void k_pose_opt(const double* __restrict__ Xw,
                                                   const double* __restrict__ obs, int n,
                                                   const double* __restrict__ Kp, double* T,
                                                   svo_lm_stats* stats, const int* n_ptr,
-                                                  int round_in_f32) {
+                                                  int round_in_f32, int use_mfma) {
   if (n_ptr) n = *n_ptr;
+  __shared__ double arow[(2 * GRAM_MAXN + 64) * GRAM_STRIDE];
+  __shared__ double gram[4 * 64 + 4];
+  if (n > GRAM_MAXN) use_mfma = 0;
   __shared__ double red[5 * 28];
   __shared__ LmShared sh;
   __shared__ double K[4];
@@ -315,8 +396,12 @@ __global__ __launch_bounds__(256) void k_pose_opt(const double* __restrict__ Xw,
   for (int it = 0; it < 10; ++it) {
     double acc[28];
     const Se3 est = sh.est;
-    accum_system<true>(est, Xw, obs, n, nullptr, K, delta, dsqr, acc);
-    block_reduce<28>(acc, red);
+    if (use_mfma) {
+      build_system_mfma<true>(est, Xw, obs, n, nullptr, K, delta, dsqr, arow, gram, red);
+    } else {
+      accum_system<true>(est, Xw, obs, n, nullptr, K, delta, dsqr, acc);
+      block_reduce<28>(acc, red);
+    }
     double H[36], b[6], iniChi = 0, rho = 0;
     int qmax = 0;
     if (tid == 0) {
@@ -416,6 +501,7 @@ __device__ __forceinline__ uint32_t lcg_next(uint64_t& s) {
 
 #define PNP_HYP 100
 #define PNP_MAXN 2048
+#define PNP_GRAM_MAXN 256   // refit uses the MFMA Gram build up to this many points
 
 __global__ __launch_bounds__(256) void k_pnp_ransac(const double* __restrict__ Xw,
                                                     const double* __restrict__ obs, int n,
@@ -423,7 +509,8 @@ __global__ __launch_bounds__(256) void k_pnp_ransac(const double* __restrict__ X
                                                     const double* __restrict__ Tprior, uint64_t seed,
                                                     double* T, uint8_t* inlier_mask,
                                                     svo_pnp_stats* stats, const int* n_ptr,
-                                                    const int* skip_ptr, const int* frame_ptr) {
+                                                    const int* skip_ptr, const int* frame_ptr,
+                                                    int use_mfma) {
   if (n_ptr) n = *n_ptr;
   if (frame_ptr) seed = 0x5EED0000ULL + (uint64_t)*frame_ptr;
   if (skip_ptr && *skip_ptr) {   // frame 0: no PnP, the pose stays at the prior
@@ -432,6 +519,8 @@ __global__ __launch_bounds__(256) void k_pnp_ransac(const double* __restrict__ X
   }
   __shared__ Se3 hyp[PNP_HYP];
   __shared__ int hcnt[PNP_HYP];
+  __shared__ double arow[(2 * PNP_GRAM_MAXN + 64) * GRAM_STRIDE];
+  __shared__ double gram[4 * 64 + 4];
   __shared__ uint8_t use[PNP_MAXN];
   __shared__ double red[5 * 28];
   __shared__ Se3 cur;
@@ -528,8 +617,12 @@ __global__ __launch_bounds__(256) void k_pnp_ransac(const double* __restrict__ X
     for (int it = 0; it < 10; ++it) {
       double acc[28];
       const Se3 est = cur;
-      accum_system<false>(est, Xw, obs, n, use, K, 0, 0, acc);
-      block_reduce<28>(acc, red);
+      if (use_mfma && n <= PNP_GRAM_MAXN) {
+        build_system_mfma<false>(est, Xw, obs, n, use, K, 0, 0, arow, gram, red);
+      } else {
+        accum_system<false>(est, Xw, obs, n, use, K, 0, 0, acc);
+        block_reduce<28>(acc, red);
+      }
       if (tid == 0) {
         double H[36], b[6], x[6];
         unpack_system(red, H, b);
@@ -583,7 +676,7 @@ int svo_launch_pose_opt(svo_ctx* ctx, const double* Xw, const double* obs, int n
                         double* T, svo_lm_stats* stats) {
   SvoTimer tm(ctx, "k_pose_opt");
   hipLaunchKernelGGL(k_pose_opt, dim3(1), dim3(256), 0, ctx->stream, Xw, obs, n, K, T, stats,
-                     (const int*)nullptr, 0);
+                     (const int*)nullptr, 0, ctx->opt_pose_mfma);
   SVO_HIP(ctx, hipGetLastError());
   return SVO_OK;
 }
@@ -594,7 +687,8 @@ int svo_launch_pnp(svo_ctx* ctx, const double* Xw, const double* obs, int n, con
   if (n > PNP_MAXN) return SVO_E_CAPACITY;
   SvoTimer tm(ctx, "k_pnp_ransac");
   hipLaunchKernelGGL(k_pnp_ransac, dim3(1), dim3(256), 0, ctx->stream, Xw, obs, n, K, Tprior, seed,
-                     T, mask, stats, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr);
+                     T, mask, stats, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr,
+                     ctx->opt_pose_mfma);
   SVO_HIP(ctx, hipGetLastError());
   return SVO_OK;
 }
@@ -604,7 +698,7 @@ int svo_launch_pose_opt_dev(svo_ctx* ctx, const double* Xw, const double* obs, c
                             const double* K, double* T, svo_lm_stats* stats, int round_in_f32) {
   SvoTimer tm(ctx, "k_pose_opt");
   hipLaunchKernelGGL(k_pose_opt, dim3(1), dim3(256), 0, ctx->stream, Xw, obs, 0, K, T, stats, n_ptr,
-                     round_in_f32);
+                     round_in_f32, ctx->opt_pose_mfma);
   return SVO_OK;
 }
 int svo_launch_pnp_dev(svo_ctx* ctx, const double* Xw, const double* obs, const int* n_ptr,
@@ -612,6 +706,6 @@ int svo_launch_pnp_dev(svo_ctx* ctx, const double* Xw, const double* obs, const 
                        const int* skip_ptr, const int* frame_ptr) {
   SvoTimer tm(ctx, "k_pnp_ransac");
   hipLaunchKernelGGL(k_pnp_ransac, dim3(1), dim3(256), 0, ctx->stream, Xw, obs, 0, K, Tprior,
-                     (uint64_t)0, T, (uint8_t*)nullptr, stats, n_ptr, skip_ptr, frame_ptr);
+                     (uint64_t)0, T, (uint8_t*)nullptr, stats, n_ptr, skip_ptr, frame_ptr, ctx->opt_pose_mfma);
   return SVO_OK;
 }

@@ -307,3 +307,35 @@ def test_invalid_arguments_are_rejected(pkg, svo_small):
     assert lib.svo_orb_extract(svo_small.h, None, 640, None, None, C.byref(n)) == -1
     with pytest.raises(pkg.SvoError):                                       # capacity: max_batch = 2
         svo_small.frontend_batch_dev(1, 1, 640, 5, pkg.Camera(**pkg.KITTI_00_02))
+
+
+# ---- MFMA variant of the J^T W J accumulation ------------------------------------------------------
+@pytest.mark.parametrize("seed,n", [(7, 500), (8, 37), (9, 5), (10, 1), (11, 512)])
+def test_pose_opt_mfma_gram_matches_oracle(pkg, orc, seed, n):
+    """svo_set_option("pose_mfma", 1): the 7x7 Gram contraction on v_mfma_f64_16x16x4_f64 gives the
+    same LM branch sequence and pose as the oracle (and as the VALU + DPP reduction)."""
+    Xw, obs, K, _ = util.pose_problem(seed, n=n)
+    svo = pkg.Svo(640, 240)
+    T0 = np.eye(4)
+    svo.set_option("pose_mfma", 0)
+    Tv, sv = svo.pose_opt(Xw, obs, K, T0)
+    svo.set_option("pose_mfma", 1)
+    Tm, sm = svo.pose_opt(Xw, obs, K, T0)
+    Tr, sr, _ = orc.pose_opt(Xw, obs, K, T0)
+    svo.close()
+    assert (sm.iterations, sm.trials_total, sm.terminated) == (sr.iterations, sr.trials_total, sr.terminated)
+    assert np.abs(Tm[:3, 3] - Tr[:3, 3]).max() < POSE_ATOL_T and np.abs(Tm[:3, :3] - Tr[:3, :3]).max() < POSE_ATOL_R
+    assert np.abs(Tm - Tv).max() < 1e-9
+    assert np.isclose(sm.chi2_final, sr.chi2_final, rtol=1e-9)
+
+
+@pytest.mark.parametrize("case", ["lm", "lm2"])
+def test_pose_opt_mfma_golden(pkg, case):
+    svo = pkg.Svo(640, 240)
+    svo.set_option("pose_mfma", 1)
+    T, st = svo.pose_opt(G[case + "_Xw"], G[case + "_obs"], G[case + "_K"], G[case + "_T0"])
+    svo.close()
+    chi0, chi1, lam, iters = G[case + "_scalars"]
+    assert st.iterations == int(iters) and st.trials_total == len(G[case + "_trace"])
+    assert np.isclose(st.chi2_initial, chi0, rtol=1e-10) and np.isclose(st.chi2_final, chi1, rtol=1e-7)
+    assert np.abs(T - G[case + "_T"]).max() < POSE_ATOL_T

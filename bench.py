@@ -56,8 +56,18 @@ def pmc_traffic(kernel):
 
 
 def render_frames(synth, n, dev, seed, start=0):
-    """n consecutive synth-kitti frames rendered on `dev`, padded to PITCH; + ground truth."""
-    L, R, T = synth.render_sequence(n, seed=seed, device=dev, start=start)
+    """n consecutive frames resident on `dev`, padded to PITCH; + ground truth.  synth-kitti by
+    default; real KITTI 00 frames when KITTI_ROOT is set (layout of the reference's main.cpp:20-57)."""
+    root = os.environ.get("KITTI_ROOT")
+    if root:
+        kio = importlib.import_module("stereo_semantic_vo_amd.kitti_io")
+        Ln, Rn = kio.load_frames(root, "00", start, n)
+        assert Ln.shape[1:] == (H, W), "KITTI 00 frames are expected to be %dx%d" % (W, H)
+        gt = kio.load_poses(root, "00")
+        T = torch.from_numpy(gt[start:start + n] if gt is not None else np.tile(np.eye(4), (n, 1, 1)))
+        L, R = torch.from_numpy(Ln).to(dev), torch.from_numpy(Rn).to(dev)
+    else:
+        L, R, T = synth.render_sequence(n, seed=seed, device=dev, start=start)
     dL = torch.zeros((n, H, PITCH), dtype=torch.uint8, device=dev)
     dR = torch.zeros_like(dL)
     dL[:, :, :W] = L
@@ -74,6 +84,30 @@ def ate_rmse(res, T_gt):
         Twc = np.linalg.inv(Tcw)
         err.append(np.linalg.norm(Twc[:3, 3] - T_gt[k][:3, 3]))
     return float(np.sqrt(np.mean(np.square(err)))), float(err[-1])
+
+
+def cpu_baseline_all_cores(Lh, Rh, cam, budget_s=8.0):
+    """Same port, frame-parallel over the host cores (the stateless front end shards by stereo pair
+    on the CPU too; ctypes releases the GIL inside the C calls)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import binding as orc
+    cores = min(os.cpu_count() or 1, 64)
+    deadline = time.perf_counter() + budget_s
+    done = [0] * cores
+
+    def worker(t):
+        i = t
+        while time.perf_counter() < deadline:
+            orc.stereo_frame(Lh[i % len(Lh)], Rh[i % len(Lh)], cam.bf, cam.fx)
+            done[t] += 1
+            i += cores
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(worker, range(cores)))
+    dt = time.perf_counter() - t0
+    return {"value": sum(done) / dt, "unit": "stereo pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d pairs in %.1f s, %d threads each running the single-thread port on its own pairs"
+                      % (sum(done), dt, cores)}
 
 
 def cpu_baseline(Lh, Rh, cam, workload, budget_s=15.0):
@@ -138,12 +172,12 @@ def main():
         svo.track_reset(cam)
     else:
         # B pairs per rank: global pair k -> rank k mod N (frame index k of one sequence)
-        frames = [synth.render_sequence(1, seed=seed, device=dev, start=k) for k in shard.pairs_for_rank(rank, world, B)]
         dL = torch.zeros((B, H, PITCH), dtype=torch.uint8, device=dev)
         dR = torch.zeros_like(dL)
-        for i, (L, R, _) in enumerate(frames):
-            dL[i, :, :W] = L[0]
-            dR[i, :, :W] = R[0]
+        for i, k in enumerate(shard.pairs_for_rank(rank, world, B)):
+            fl, fr, _ = render_frames(synth, 1, dev, seed, start=k)
+            dL[i] = fl[0]
+            dR[i] = fr[0]
         d_n = torch.zeros(B, dtype=torch.int32, device=dev)
         d_depth = torch.zeros((B, 500), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
@@ -208,7 +242,8 @@ def main():
             "metric": "stereo frames/sec on KITTI 00 (tracking front end)",
             "value": pairs / dt, "unit": "stereo pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic", "config": cfg,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "kitti00" if os.environ.get("KITTI_ROOT") else "synthetic", "config": cfg,
         }
         if prof:
             kern = {k: {"avg_ms": v[0] / max(v[1], 1), "launches": v[1]} for k, v in prof.items()}
@@ -228,6 +263,8 @@ def main():
             Lh = dL[:ns, :, :W].cpu().numpy()
             Rh = dR[:ns, :, :W].cpu().numpy()
             out["cpu_baseline"], cpu_poses = cpu_baseline(Lh, Rh, cam, args.workload)
+            if not track:
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(Lh, Rh, cam)
             if track and cpu_poses:
                 k = len(cpu_poses) - 1
                 a = np.linalg.inv(res[k]["Tcw"].reshape(4, 4).astype(np.float64))[:3, 3]

@@ -50,72 +50,80 @@ __global__ __launch_bounds__(256) void k_pyr_level(SvoGeom g, ImgSrc s, int l, u
                                                    const int32_t* __restrict__ xalpha,
                                                    const int32_t* __restrict__ yofs,
                                                    const int32_t* __restrict__ ybeta) {
+  // One thread = a 4 (wide) x 4 (tall) block of output pixels: the x coefficients are fetched once
+  // for four rows and all source rows of the block are requested before any is used, so the
+  // table -> source dependency is paid once per 16 pixels.
   const int img = blockIdx.z;
-  const int dy = blockIdx.y * 4 + threadIdx.y;
+  const int dy0 = (blockIdx.y * 4 + threadIdx.y) * 4;
   const int dx4 = (blockIdx.x * 64 + threadIdx.x) * 4;
   const int dw = g.w[l], dh = g.h[l];
-  if (dy >= dh || dx4 >= dw) return;
+  if (dy0 >= dh || dx4 >= dw) return;
   int sp;
   const uint8_t* src = level_ptr(g, s, img, l - 1, &sp);
   const int sw = g.w[l - 1], sh = g.h[l - 1];
-  const int sy0 = yofs[g.ytab_off[l] + dy];
-  const int sy1 = min(sy0 + 1, sh - 1);
-  const int bb = ybeta[g.ytab_off[l] + dy];
-  const int b0 = (int)(int16_t)(bb & 0xffff), b1 = bb >> 16;
-  const uint8_t* r0 = src + (size_t)sy0 * sp;
-  const uint8_t* r1 = src + (size_t)sy1 * sp;
-  // the tables are padded to multiples of 4 entries per level: one 16-byte load each
   const int4 so = *reinterpret_cast<const int4*>(xofs + g.xtab_off[l] + dx4);
   const int4 sa = *reinterpret_cast<const int4*>(xalpha + g.xtab_off[l] + dx4);
+  int syv[4], bbv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int dy = min(dy0 + r, dh - 1);
+    syv[r] = yofs[g.ytab_off[l] + dy];
+    bbv[r] = ybeta[g.ytab_off[l] + dy];
+  }
   const int sx[4] = {so.x, so.y, so.z, so.w};
   const int al[4] = {sa.x, sa.y, sa.z, sa.w};
-  uint32_t out = 0;
   const int base = sx[0];
-  if (base + 8 <= sw) {
-    // the 4 outputs read source columns base .. base+5: one unaligned 8-byte load per row
-    // (three aligned dwords + v_alignbyte measured 15 % slower: the kernel is load-latency bound)
-    const uint64_t w0 = *reinterpret_cast<const u64_unaligned*>(r0 + base);
-    const uint64_t w1 = *reinterpret_cast<const u64_unaligned*>(r1 + base);
+  const bool wide = base + 8 <= sw;
+  uint64_t w0[4], w1[4];
+  if (wide) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      // the two horizontal taps are adjacent bytes: one 64-bit shift brings them to bits 0..15,
-      // v_perm spreads them into u16 lanes and v_dot2_u32_u16 applies the packed (a0, a1) pair
-      const int sh0 = 8 * (sx[k] - base);
-      const uint32_t t0 = (uint32_t)(w0 >> sh0), t1 = (uint32_t)(w1 >> sh0);
-      const v2u16 p0 = __builtin_bit_cast(v2u16, __builtin_amdgcn_perm(0u, t0, 0x0c010c00u));
-      const v2u16 p1 = __builtin_bit_cast(v2u16, __builtin_amdgcn_perm(0u, t1, 0x0c010c00u));
-      const v2u16 al2 = __builtin_bit_cast(v2u16, (uint32_t)al[k]);
-      const int S0 = (int)__builtin_amdgcn_udot2(p0, al2, 0u, false);
-      const int S1 = (int)__builtin_amdgcn_udot2(p1, al2, 0u, false);
-      int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
-      v = min(max(v, 0), 255);
-      out |= (uint32_t)v << (8 * k);
+    for (int r = 0; r < 4; ++r) {
+      w0[r] = *reinterpret_cast<const u64_unaligned*>(src + (size_t)syv[r] * sp + base);
+      w1[r] = *reinterpret_cast<const u64_unaligned*>(src + (size_t)min(syv[r] + 1, sh - 1) * sp + base);
     }
-  } else {
+  }
+  uint8_t* dst = pyr + (size_t)img * g.pyr_bytes + g.loff[l] + (size_t)dy0 * g.pitch[l] + dx4;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (dx4 + k < dw) {
-        const int sx0 = sx[k], sx1 = min(sx0 + 1, sw - 1);
-        const int a0 = (int)(int16_t)(al[k] & 0xffff), a1 = al[k] >> 16;
-        const int S0 = r0[sx0] * a0 + r0[sx1] * a1;
-        const int S1 = r1[sx0] * a0 + r1[sx1] * a1;
+  for (int r = 0; r < 4; ++r) {
+    if (dy0 + r >= dh) break;
+    const int b0 = (int)(int16_t)(bbv[r] & 0xffff), b1 = bbv[r] >> 16;
+    uint32_t out = 0;
+    if (wide) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        // the two horizontal taps are adjacent bytes: one 64-bit shift brings them to bits 0..15,
+        // v_perm spreads them into u16 lanes and v_dot2_u32_u16 applies the packed (a0, a1) pair
+        const int sh0 = 8 * (sx[k] - base);
+        const uint32_t t0 = (uint32_t)(w0[r] >> sh0), t1 = (uint32_t)(w1[r] >> sh0);
+        const v2u16 p0 = __builtin_bit_cast(v2u16, __builtin_amdgcn_perm(0u, t0, 0x0c010c00u));
+        const v2u16 p1 = __builtin_bit_cast(v2u16, __builtin_amdgcn_perm(0u, t1, 0x0c010c00u));
+        const v2u16 al2 = __builtin_bit_cast(v2u16, (uint32_t)al[k]);
+        const int S0 = (int)__builtin_amdgcn_udot2(p0, al2, 0u, false);
+        const int S1 = (int)__builtin_amdgcn_udot2(p1, al2, 0u, false);
         int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
         v = min(max(v, 0), 255);
         out |= (uint32_t)v << (8 * k);
       }
+    } else {
+      const uint8_t* r0 = src + (size_t)syv[r] * sp;
+      const uint8_t* r1 = src + (size_t)min(syv[r] + 1, sh - 1) * sp;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (dx4 + k < dw) {
+          const int sx0 = sx[k], sx1 = min(sx0 + 1, sw - 1);
+          const int a0 = (int)(int16_t)(al[k] & 0xffff), a1 = al[k] >> 16;
+          const int S0 = r0[sx0] * a0 + r0[sx1] * a1;
+          const int S1 = r1[sx0] * a0 + r1[sx1] * a1;
+          int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+          v = min(max(v, 0), 255);
+          out |= (uint32_t)v << (8 * k);
+        }
+      }
     }
+    *reinterpret_cast<uint32_t*>(dst + (size_t)r * g.pitch[l]) = out;
   }
-  uint8_t* dst = pyr + (size_t)img * g.pyr_bytes + g.loff[l] + (size_t)dy * g.pitch[l];
-  *reinterpret_cast<uint32_t*>(dst + dx4) = out;
 }
 
-// ---------------------------------------------------------------------------------
-// FAST-9/16 (threshold 20) + corner score + strict 3x3 NMS + 31-px border filter.
-// One 256-thread workgroup owns a 120 x 14 output tile.  It stages the 136 x 22
-// pixel window in LDS with coalesced dword row loads, scores the 128 x 16 window
-// (tile + 1 ring for NMS; 8 consecutive pixels per thread from 7 x 16-byte LDS row
-// reads), suppresses non-maxima in LDS and appends survivors to the level list.
-// ---------------------------------------------------------------------------------
 // Corner score of TWO horizontally adjacent pixels at once in packed 16-bit lanes
 // (v_pk_sub/min/max_i16): d[i] = centre - ring[i]; score = max over the 16 arcs of 9 of
 // min(d) (dark ring) and of min(-d) (bright ring), minus 1; 0 unless that exceeds the
@@ -664,7 +672,7 @@ int svo_launch_orb(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR,
   {
     SvoTimer t(ctx, "k_pyr_level");
     for (int l = 1; l < SVO_NLEVELS; ++l) {
-      dim3 grid((g.w[l] / 4 + 64) / 64, (g.h[l] + 3) / 4, nimg);
+      dim3 grid((g.w[l] / 4 + 64) / 64, (g.h[l] + 15) / 16, nimg);
       hipLaunchKernelGGL(k_pyr_level, grid, dim3(64, 4, 1), 0, st, g, s, l, ctx->d_pyr, ctx->d_xofs,
                          ctx->d_xalpha, ctx->d_yofs, ctx->d_ybeta);
     }

@@ -206,8 +206,18 @@ __global__ __launch_bounds__(256) void k_fast(SvoGeom g, ImgSrc s, uint32_t* cor
   __shared__ int nq[2], ncand, lcount, lbase;
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int img = blockIdx.y;
-  int tile = blockIdx.x;
+  // XCD-aware tile order: workgroup b is observed to run on XCD b % 8 and each XCD has a private
+  // L2, so the linear block id is remapped (bijectively) to give every XCD one CONTIGUOUS eighth of
+  // the (image, tile) sequence - vertically adjacent tiles then share their halo rows in one L2
+  // instead of each XCD fetching its own copy.  Placement only affects speed, never results.
+  int img, tile;
+  {
+    const uint32_t total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t xcd = lin & 7u, idx = lin >> 3, q = total >> 3, r = total & 7u;
+    const uint32_t mapped = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    img = (int)(mapped / gridDim.x);
+    tile = (int)(mapped - (uint32_t)img * gridDim.x);
+  }
   int l = 0;
 #pragma unroll
   for (int k = 1; k < SVO_NLEVELS; ++k)

@@ -19,9 +19,9 @@
 #define SVO_QMAX 128      // >= largest per-level quota (109 for 500 features)
 #define SVO_DESC_BYTES 32
 
-// FAST tile: 120 x 14 output pixels per 256-thread workgroup (see svo_orb.hip).
+// FAST tile: 120 x 30 output pixels per 256-thread workgroup (see svo_orb.hip).
 #define FAST_TW 120
-#define FAST_TH 14
+#define FAST_TH 30
 
 struct SvoGeom {
   int W, H;

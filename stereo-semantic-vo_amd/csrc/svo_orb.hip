@@ -194,15 +194,17 @@ __device__ __forceinline__ uint32_t compass_pair(const uint32_t (&r0)[4], const 
 
 #define PXW 34  // dwords per staged pixel row (136 bytes)
 #define SCW 128 // bytes per score row
+#define SCR (FAST_TH + 2)   // score rows: the tile + one ring for NMS
+#define PXR (FAST_TH + 8)   // staged pixel rows: score rows + 3 above and below
 
 __global__ __launch_bounds__(256) void k_fast(SvoGeom g, ImgSrc s, uint32_t* corners,
                                               int32_t* counters, int32_t* hist) {
-  __shared__ uint32_t px[22 * PXW];
-  __shared__ uint32_t sc[16 * (SCW / 4)];
+  __shared__ uint32_t px[PXR * PXW];
+  __shared__ uint32_t sc[SCR * (SCW / 4)];
   __shared__ int lhist[256];
-  __shared__ uint32_t lcorn[512];
-  __shared__ uint16_t queue[2][1024];   // surviving pixel pairs by column parity: id = r*64 + pc
-  __shared__ uint16_t cand[2048];       // pixels with a nonzero score: id = r*128 + col
+  __shared__ uint32_t lcorn[FAST_TW * FAST_TH / 4 + 64];   // NMS density bound
+  __shared__ uint16_t queue[2][SCR * 32];   // surviving pixel pairs by column parity: id = r*64 + pc
+  __shared__ uint16_t cand[SCR * 128];      // pixels with a nonzero score: id = r*128 + col
   __shared__ int nq[2], ncand, lcount, lbase;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -230,12 +232,12 @@ __global__ __launch_bounds__(256) void k_fast(SvoGeom g, ImgSrc s, uint32_t* cor
   const uint8_t* img_p = level_ptr(g, s, img, l, &pitch);
 
   lhist[tid] = 0;
-  sc[tid] = 0; sc[tid + 256] = 0;
+  for (int i = tid; i < SCR * (SCW / 4); i += 256) sc[i] = 0;
   if (tid == 0) { lcount = 0; nq[0] = 0; nq[1] = 0; ncand = 0; }
 
-  // stage pixels: rows y0-4 .. y0+17, columns x0-8 .. x0+127
+  // stage pixels: rows y0-4 .. y0+FAST_TH+3, columns x0-8 .. x0+127
   const bool aligned = ((pitch & 3) == 0) && ((reinterpret_cast<uintptr_t>(img_p) & 3) == 0);
-  for (int i = tid; i < 22 * PXW; i += 256) {
+  for (int i = tid; i < PXR * PXW; i += 256) {
     const int r = i / PXW, c = i - r * PXW;
     const int gy = min(max(y0 - 4 + r, 0), h - 1);
     const int gx = x0 - 8 + 4 * c;
@@ -254,8 +256,8 @@ __global__ __launch_bounds__(256) void k_fast(SvoGeom g, ImgSrc s, uint32_t* cor
 
   // phase A: compass pre-test of 4 pixel pairs per thread; score row r <-> y = y0-1+r, pair
   // column pc = 4c + K/2 <-> x = x0-4+2pc.  Survivors are compacted per wave with a ballot.
-  {
-    const int r = tid >> 4, c = tid & 15;
+  for (int r = tid >> 4; r < SCR; r += 16) {
+    const int c = tid & 15;
     uint32_t r0[4], r3[4], r6[4];
     {
       const uint2 a = *reinterpret_cast<const uint2*>(&px[(r + 0) * PXW + 2 * c]);

@@ -22,7 +22,7 @@ extern "C" {
 #define ORC_EDGE 31          /* cv::ORB edgeThreshold default */
 #define ORC_FAST_THR 20      /* cv::ORB fastThreshold default */
 #define ORC_HALF_PATCH 15
-#define ORC_CAP1 2048        /* cap on Harris candidates per level */
+#define ORC_CAP1 1024        /* cap on Harris candidates per level */
 
 typedef struct orc_kp {
   float x, y, size, angle, response;

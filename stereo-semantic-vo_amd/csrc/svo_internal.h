@@ -15,7 +15,7 @@
 #define SVO_EDGE 31
 #define SVO_FAST_THR 20
 #define SVO_HALF_PATCH 15
-#define SVO_CAP1 2048     // cap on Harris candidates per (image, level)
+#define SVO_CAP1 1024     // cap on Harris candidates per (image, level)
 #define SVO_QMAX 128      // >= largest per-level quota (109 for 500 features)
 #define SVO_DESC_BYTES 32
 

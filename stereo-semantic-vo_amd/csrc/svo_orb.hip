@@ -352,36 +352,32 @@ __global__ __launch_bounds__(256) void k_fast(SvoGeom g, ImgSrc s, uint32_t* cor
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ int64_t harris_at(const uint8_t* img, int pitch, int x, int y) {
   typedef uint32_t __attribute__((aligned(1))) u32u;
-  int64_t a = 0, b = 0, c = 0;
-  // 9 x 9 neighbourhood (bytes x-4 .. x+4), three unaligned dword loads per row; gradients of the
-  // inner 7 x 7 with a rolling window of three rows
-  int row[3][9];
-  auto load_row = [&](int yy, int* dst) {
-    const uint8_t* p = img + (size_t)yy * pitch + x - 4;
-    const uint32_t w0 = *reinterpret_cast<const u32u*>(p), w1 = *reinterpret_cast<const u32u*>(p + 4),
-                   w2 = *reinterpret_cast<const u32u*>(p + 8);
-    dst[0] = w0 & 0xff; dst[1] = (w0 >> 8) & 0xff; dst[2] = (w0 >> 16) & 0xff; dst[3] = w0 >> 24;
-    dst[4] = w1 & 0xff; dst[5] = (w1 >> 8) & 0xff; dst[6] = (w1 >> 16) & 0xff; dst[7] = w1 >> 24;
-    dst[8] = w2 & 0xff;
-  };
-  load_row(y - 4, row[1]);
-  load_row(y - 3, row[2]);
-#pragma unroll 1
-  for (int dy = -3; dy <= 3; ++dy) {
+  // 9 x 9 neighbourhood (bytes x-4 .. x+4): all 27 unaligned dword loads are issued up front (one
+  // memory round trip), then the gradients of the inner 7 x 7 are accumulated row by row
+  uint32_t w[9][3];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { row[0][i] = row[1][i]; row[1][i] = row[2][i]; }
-    load_row(y + dy + 1, row[2]);
+  for (int r = 0; r < 9; ++r) {
+    const uint8_t* p = img + (size_t)(y - 4 + r) * pitch + x - 4;
+    w[r][0] = *reinterpret_cast<const u32u*>(p);
+    w[r][1] = *reinterpret_cast<const u32u*>(p + 4);
+    w[r][2] = *reinterpret_cast<const u32u*>(p + 8);
+  }
+#define HB(r, i) (int)((w[r][(i) >> 2] >> (8 * ((i) & 3))) & 0xffu)
+  int64_t a = 0, b = 0, c = 0;
+#pragma unroll
+  for (int r = 1; r <= 7; ++r) {
     int sa = 0, sb = 0, scv = 0;
 #pragma unroll
     for (int i = 1; i <= 7; ++i) {
-      const int Ix = (row[1][i + 1] - row[1][i - 1]) * 2 + (row[0][i + 1] - row[0][i - 1]) +
-                     (row[2][i + 1] - row[2][i - 1]);
-      const int Iy = (row[2][i] - row[0][i]) * 2 + (row[2][i - 1] - row[0][i - 1]) +
-                     (row[2][i + 1] - row[0][i + 1]);
+      const int Ix = (HB(r, i + 1) - HB(r, i - 1)) * 2 + (HB(r - 1, i + 1) - HB(r - 1, i - 1)) +
+                     (HB(r + 1, i + 1) - HB(r + 1, i - 1));
+      const int Iy = (HB(r + 1, i) - HB(r - 1, i)) * 2 + (HB(r + 1, i - 1) - HB(r - 1, i - 1)) +
+                     (HB(r + 1, i + 1) - HB(r - 1, i + 1));
       sa += Ix * Ix; sb += Iy * Iy; scv += Ix * Iy;
     }
     a += sa; b += sb; c += scv;
   }
+#undef HB
   return 25 * (a * b - c * c) - (a + b) * (a + b);
 }
 
@@ -389,15 +385,13 @@ __global__ __launch_bounds__(256) void k_select(SvoGeom g, ImgSrc s, const uint3
                                                 const int32_t* counters, const int32_t* hist,
                                                 SvoSel* sel, int32_t* selcnt) {
   __shared__ int64_t cR[SVO_CAP1];
-  __shared__ int32_t ckey[SVO_CAP1];
-  __shared__ uint32_t cxy[SVO_CAP1];
+  __shared__ uint32_t cxy[SVO_CAP1];   // x | y<<12 | score<<24; the raster key y*w+x is derived from it
   __shared__ int cum[257];
   __shared__ int sT, nc;
   const int tid = threadIdx.x;
   const int l = blockIdx.x, img = blockIdx.y;
   const int n = counters[img * SVO_NLEVELS + l];
   const int quota = g.quota[l];
-  const int w = g.w[l];
   if (n == 0 || quota == 0) {
     if (tid == 0) selcnt[img * SVO_NLEVELS + l] = 0;
     return;
@@ -425,12 +419,16 @@ __global__ __launch_bounds__(256) void k_select(SvoGeom g, ImgSrc s, const uint3
   __syncthreads();
   const int T = sT;
   const uint32_t* src = corners + (size_t)img * g.corner_entries + g.coff[l];
-  for (int i = tid; i < n; i += 256) {
-    const uint32_t e = src[i];
-    if ((int)(e >> 24) >= T) {
-      const int p = atomicAdd(&nc, 1);
-      cxy[p] = e;
-    }
+  for (int i0 = tid; i0 < n; i0 += 1024) {   // four independent loads in flight per lane
+    uint32_t e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) e[k] = i0 + 256 * k < n ? src[i0 + 256 * k] : 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (i0 + 256 * k < n && (int)(e[k] >> 24) >= T) {
+        const int p = atomicAdd(&nc, 1);
+        cxy[p] = e[k];
+      }
   }
   __syncthreads();
   const int ncand = nc;
@@ -440,24 +438,37 @@ __global__ __launch_bounds__(256) void k_select(SvoGeom g, ImgSrc s, const uint3
     const uint32_t e = cxy[c];
     const int x = e & 0xfff, y = (e >> 12) & 0xfff;
     cR[c] = harris_at(img_p, pitch, x, y);
-    ckey[c] = y * w + x;
   }
   __syncthreads();
+  // Order the candidates by (Harris measure descending, raster index ascending) with a bitonic
+  // sort in LDS - O(n log^2 n) instead of the O(n^2) rank count, which dominated when many FAST
+  // scores tie at the retainBest threshold.  Raster order y*w+x == order of (y<<12 | x), x < 4096.
+  int npow = 64;
+  while (npow < ncand) npow <<= 1;
+  for (int c = ncand + tid; c < npow; c += 256) { cR[c] = INT64_MIN; cxy[c] = 0x00ffffffu; }  // padding sorts last
+  __syncthreads();
+  for (int k = 2; k <= npow; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < npow; i += 256) {
+        const int p2 = i ^ j;
+        if (p2 > i) {
+          const int64_t Ra = cR[i], Rb = cR[p2];
+          const uint32_t ea = cxy[i], eb = cxy[p2];
+          const uint32_t ka = ea & 0x00ffffffu, kb = eb & 0x00ffffffu;   // y<<12 | x
+          const bool a_first = (Ra > Rb) || (Ra == Rb && ka < kb);      // a belongs before b
+          const bool up = (i & k) == 0;                                  // this block sorts "best first"
+          if (a_first != up) { cR[i] = Rb; cR[p2] = Ra; cxy[i] = eb; cxy[p2] = ea; }
+        }
+      }
+      __syncthreads();
+    }
+  }
   SvoSel* out = sel + (size_t)(img * SVO_NLEVELS + l) * SVO_QMAX;
-  for (int c = tid; c < ncand; c += 256) {
-    const int64_t R = cR[c];
-    const int key = ckey[c];
-    int rank = 0;
-    for (int j = 0; j < ncand; ++j) {
-      const int64_t Rj = cR[j];
-      rank += (Rj > R) || (Rj == R && ckey[j] < key);
-    }
-    if (rank < quota) {
-      const uint32_t e = cxy[c];
-      SvoSel v;
-      v.R = R; v.x = (int16_t)(e & 0xfff); v.y = (int16_t)((e >> 12) & 0xfff); v.pad = 0;
-      out[rank] = v;
-    }
+  for (int c = tid; c < min(ncand, quota); c += 256) {
+    const uint32_t e = cxy[c];
+    SvoSel v;
+    v.R = cR[c]; v.x = (int16_t)(e & 0xfff); v.y = (int16_t)((e >> 12) & 0xfff); v.pad = 0;
+    out[c] = v;
   }
   if (tid == 0) selcnt[img * SVO_NLEVELS + l] = min(ncand, quota);
 }

@@ -14,7 +14,7 @@
 #define TH_ORB ((100 + 50) / 2)
 #define SAD_W 5
 #define SAD_L 5
-#define KP_PER_WG 16
+#define KP_PER_WG 64
 #define MAXKP_LDS 512
 
 struct StereoSrc {
@@ -49,6 +49,8 @@ __global__ __launch_bounds__(256) void k_stereo_match(SvoGeom g, StereoSrc s, co
   __shared__ int8_t roct[MAXKP_LDS];
   __shared__ float rx[MAXKP_LDS];
   __shared__ int sadbuf[4][128];
+  __shared__ uint64_t winL[4][11][2];   // per wave: 11 rows x 16 bytes of the left SAD window
+  __shared__ uint64_t winR[4][11][3];   // per wave: 11 rows x 24 bytes of the right search band
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int pair = blockIdx.y;
   const int imgL = pair, imgR = s.B + pair;
@@ -115,13 +117,30 @@ __global__ __launch_bounds__(256) void k_stereo_match(SvoGeom g, StereoSrc s, co
         int pl, pr;
         const uint8_t* IL = st_level_ptr(g, s, imgL, levelL, &pl);
         const uint8_t* IR = st_level_ptr(g, s, imgR, levelL, &pr);
-        const int cL = IL[(size_t)sv * pl + su];
+        // stage both windows with a few wide loads (one memory round trip per keypoint): lanes
+        // 0..10 fetch the left rows (11 px at su-5), lanes 16..26 the right rows (21 px at sr0-10)
+        typedef uint64_t __attribute__((aligned(1))) u64u;
+        if (lane < 11) {
+          const uint8_t* p = IL + (size_t)(sv + lane - SAD_W) * pl + su - SAD_W;
+          winL[wv][lane][0] = *reinterpret_cast<const u64u*>(p);
+          winL[wv][lane][1] = *reinterpret_cast<const u64u*>(p + 8);
+        } else if (lane >= 16 && lane < 27) {
+          const uint8_t* p = IR + (size_t)(sv + lane - 16 - SAD_W) * pr + sr0 - SAD_L - SAD_W;
+          winR[wv][lane - 16][0] = *reinterpret_cast<const u64u*>(p);
+          winR[wv][lane - 16][1] = *reinterpret_cast<const u64u*>(p + 8);
+          winR[wv][lane - 16][2] = *reinterpret_cast<const u64u*>(p + 16);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        const uint8_t* wl = reinterpret_cast<const uint8_t*>(&winL[wv][0][0]);   // row pitch 16
+        const uint8_t* wr = reinterpret_cast<const uint8_t*>(&winR[wv][0][0]);   // row pitch 24
+        const int cL = wl[5 * 16 + 5];
         // (inc, dy) pairs: 121 partial row sums
         for (int p = lane; p < 121; p += 64) {
-          const int inc = p / 11 - SAD_L, dy = p % 11 - SAD_W;
-          const int cR = IR[(size_t)sv * pr + sr0 + inc];
-          const uint8_t* a = IL + (size_t)(sv + dy) * pl + su - SAD_W;
-          const uint8_t* b = IR + (size_t)(sv + dy) * pr + sr0 + inc - SAD_W;
+          const int inc = p / 11 - SAD_L, dy = p % 11;
+          const int cR = wr[5 * 24 + 10 + inc];
+          const uint8_t* a = wl + dy * 16;
+          const uint8_t* b = wr + dy * 24 + 5 + inc;
           int sum = 0;
 #pragma unroll
           for (int dx = 0; dx < 11; ++dx) sum += abs(((int)a[dx] - cL) - ((int)b[dx] - cR));
@@ -137,7 +156,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(SvoGeom g, StereoSrc s, co
         }
         int dists[11];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) dists[k] = __shfl(mysad, k, 64);
+        for (int k = 0; k < 11; ++k) dists[k] = __builtin_amdgcn_readlane(mysad, k);   // lanes 0..10 hold the 11 SADs
         int bsad = 0x7fffffff, binc = 0;
 #pragma unroll
         for (int k = 0; k < 11; ++k)

@@ -143,12 +143,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-track-leg", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (single-GPU dry runs)")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (dry run of the N>1 path on one GPU)")
     args = ap.parse_args()
 
     pkg = svo_loader.load()
     synth = importlib.import_module("stereo_semantic_vo_amd.synth")
     shard = importlib.import_module("stereo_semantic_vo_amd.shard")
     rank, world, local = shard.env_rank_world()
+    if args.share_gpu:
+        local = 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
     torch.cuda.set_device(local)
@@ -158,7 +162,7 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     cam = pkg.Camera(**pkg.KITTI_00_02)
     B = args.batch
@@ -210,7 +214,7 @@ def main():
         step(s)
     fence()
     dt = time.perf_counter() - t0
-    dt = shard.max_over_ranks(dt, dist, dev)
+    dt = shard.max_over_ranks(dt, dist, dev if args.dist_backend == "nccl" else "cpu")
     prof = {}
     if not args.no_profile:
         svo.profile_enable(False)

@@ -256,3 +256,28 @@ def epipolar_distance(F, last_xy, cur_xy):
     l.orc_epipolar_distance.argtypes = [C.c_void_p] + [C.c_float] * 4
     F = np.ascontiguousarray(F, np.float64).reshape(9)
     return l.orc_epipolar_distance(_p(F), last_xy[0], last_xy[1], cur_xy[0], cur_xy[1])
+
+
+# --- compiled REFERENCE pieces (oracle/Makefile.ref -> oracle/_ref/) --------------------------------
+def ref_elas_lib():
+    """The reference's real libelas (Thirdparty/libelas), built by oracle/Makefile.ref.
+    Returns None when oracle/_ref/ has not been built (no /root/reference at build time)."""
+    so = os.path.join(_HERE, "_ref", "libref_elas.so")
+    if not os.path.exists(so):
+        return None
+    L = C.CDLL(so)
+    L.ref_elas_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p]
+    return L
+
+
+def ref_elas(grayL, grayR, robotics=True):
+    """Dense left/right disparity maps (float32, -10 = invalid) from the reference's libelas."""
+    L = ref_elas_lib()
+    if L is None:
+        raise RuntimeError("oracle/_ref/libref_elas.so not built (make -C oracle -f Makefile.ref)")
+    gl = np.ascontiguousarray(grayL, np.uint8); gr = np.ascontiguousarray(grayR, np.uint8)
+    H, W = gl.shape
+    D1 = np.zeros((H, W), np.float32); D2 = np.zeros((H, W), np.float32)
+    L.ref_elas_process(_p(gl), _p(gr), W, H, W, int(robotics), _p(D1), _p(D2))
+    return D1, D2

@@ -272,6 +272,58 @@ int svo_profile_reset(svo_ctx* ctx);
 int svo_profile_get(svo_ctx* ctx, int index, char* name, int name_cap, double* total_ms,
                     int64_t* launches);
 
+/* ------------------------------------------------------------------------------------------------
+ * Dense ELAS stereo.  Replaces the vendored libelas,
+ * Thirdparty/libelas/src/elas.h:40-165 + elas.cpp:32-150 (`Elas::process`).  Results are bit-identical
+ * to the compiled reference stage by stage; see DESIGN.md section 8 for the two documented caveats
+ * (duplicate right-image support points, memory libelas reads uninitialised is defined as 0).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Elas::parameters (elas.h:60-83): same fields, same order, bools as int32. */
+typedef struct svo_elas_params {
+  int32_t disp_min, disp_max;
+  float support_threshold;
+  int32_t support_texture, candidate_stepsize, incon_window_size, incon_threshold, incon_min_support;
+  int32_t add_corners, grid_size;
+  float beta, gamma, sigma, sradius;
+  int32_t match_texture, lr_threshold;
+  float speckle_sim_threshold;
+  int32_t speckle_size, ipol_gap_width, filter_median, filter_adaptive_mean, postprocess_only_left;
+  int32_t subsampling;              /* must be 0: half-resolution mode is not implemented */
+} svo_elas_params;
+
+/* Optional taps of every intermediate (any pointer may be NULL) and optional override of the two
+ * triangle lists; used by the parity tests, which run the reference's stages on the same lists. */
+typedef struct svo_elas_taps {
+  uint8_t *desc1, *desc2;              /* W*H*16 each */
+  int32_t* support;                    /* (u,v,d) triples */
+  int32_t n_support, cap_support;
+  int32_t *tri1, *tri2;                /* (c1,c2,c3) triples */
+  float *planes1, *planes2;            /* (t1a,t1b,t1c,t2a,t2b,t2c) per triangle */
+  int32_t n_tri1, n_tri2, cap_tri;
+  int32_t *grid1, *grid2;              /* (disp_max+2)*grid_w*grid_h */
+  float *D1_raw, *D2_raw, *D1_lr, *D2_lr, *D1_seg, *D2_seg, *D1_gap, *D2_gap, *D1_mean, *D2_mean;
+  const int32_t *tri1_in, *tri2_in;
+  int32_t n_tri1_in, n_tri2_in;
+} svo_elas_taps;
+
+/* `Elas::parameters(setting)` (elas.h:87-142): setting 0 = ROBOTICS, 1 = MIDDLEBURY. */
+int svo_elas_default_params(int32_t setting, svo_elas_params* params);
+
+/* `Elas::process(I1, I2, D1, D2, dims)` (elas.h:162, elas.cpp:32-150): dims = {width, height, bytes per
+ * line}; D1/D2 are width*height floats (left / right reference), negative = invalid.  Host buffers in,
+ * host buffers out.  Returns SVO_E_INVALID for subsampling != 0; with fewer than 3 support points it
+ * returns SVO_OK and leaves D1/D2 untouched, as the reference does (elas.cpp:70-75). */
+int svo_elas_process(svo_ctx* ctx, const uint8_t* I1, const uint8_t* I2, float* D1, float* D2,
+                     const int32_t* dims, const svo_elas_params* params);
+int svo_elas_process_ex(svo_ctx* ctx, const uint8_t* I1, const uint8_t* I2, float* D1, float* D2,
+                        const int32_t* dims, const svo_elas_params* params, svo_elas_taps* taps);
+
+/* `Elas::computeDelaunayTriangulation` (elas.cpp:445-503 -> Triangle "zQB"): host-side, needs no GPU.
+ * xy = n (x,y) int32 pairs; writes up to cap (c1,c2,c3) triples, counter-clockwise, in canonical order
+ * (smallest index first, sorted); *n_tri = number of triangles. */
+int svo_elas_delaunay(const int32_t* xy, int32_t n, int32_t* tri, int32_t cap, int32_t* n_tri);
+
 #ifdef __cplusplus
 }
 #endif

@@ -259,25 +259,115 @@ def epipolar_distance(F, last_xy, cur_xy):
 
 
 # --- compiled REFERENCE pieces (oracle/Makefile.ref -> oracle/_ref/) --------------------------------
+class ElasParams(C.Structure):
+    """Elas::parameters (Thirdparty/libelas/src/elas.h:60-83), bools as int32."""
+    _fields_ = [("disp_min", C.c_int32), ("disp_max", C.c_int32), ("support_threshold", C.c_float),
+                ("support_texture", C.c_int32), ("candidate_stepsize", C.c_int32),
+                ("incon_window_size", C.c_int32), ("incon_threshold", C.c_int32),
+                ("incon_min_support", C.c_int32), ("add_corners", C.c_int32), ("grid_size", C.c_int32),
+                ("beta", C.c_float), ("gamma", C.c_float), ("sigma", C.c_float), ("sradius", C.c_float),
+                ("match_texture", C.c_int32), ("lr_threshold", C.c_int32),
+                ("speckle_sim_threshold", C.c_float), ("speckle_size", C.c_int32),
+                ("ipol_gap_width", C.c_int32), ("filter_median", C.c_int32),
+                ("filter_adaptive_mean", C.c_int32), ("postprocess_only_left", C.c_int32),
+                ("subsampling", C.c_int32)]
+
+
+class _ElasTaps(C.Structure):
+    _fields_ = [("desc1", C.c_void_p), ("desc2", C.c_void_p), ("support", C.c_void_p),
+                ("n_support", C.c_int32), ("cap_support", C.c_int32),
+                ("tri1", C.c_void_p), ("tri2", C.c_void_p), ("planes1", C.c_void_p), ("planes2", C.c_void_p),
+                ("n_tri1", C.c_int32), ("n_tri2", C.c_int32), ("cap_tri", C.c_int32),
+                ("grid1", C.c_void_p), ("grid2", C.c_void_p),
+                ("D1_raw", C.c_void_p), ("D2_raw", C.c_void_p), ("D1_lr", C.c_void_p), ("D2_lr", C.c_void_p),
+                ("D1_seg", C.c_void_p), ("D2_seg", C.c_void_p), ("D1_gap", C.c_void_p), ("D2_gap", C.c_void_p),
+                ("D1_mean", C.c_void_p), ("D2_mean", C.c_void_p),
+                ("tri1_in", C.c_void_p), ("tri2_in", C.c_void_p),
+                ("n_tri1_in", C.c_int32), ("n_tri2_in", C.c_int32)]
+
+
+_REF_ELAS = None
+
+
 def ref_elas_lib():
     """The reference's real libelas (Thirdparty/libelas), built by oracle/Makefile.ref.
     Returns None when oracle/_ref/ has not been built (no /root/reference at build time)."""
+    global _REF_ELAS
     so = os.path.join(_HERE, "_ref", "libref_elas.so")
-    if not os.path.exists(so):
-        return None
-    L = C.CDLL(so)
-    L.ref_elas_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                   C.c_void_p, C.c_void_p]
-    return L
+    if _REF_ELAS is None and os.path.exists(so):
+        _REF_ELAS = C.CDLL(so)
+    return _REF_ELAS
 
 
-def ref_elas(grayL, grayR, robotics=True):
-    """Dense left/right disparity maps (float32, -10 = invalid) from the reference's libelas."""
+def ref_elas_params(middlebury=False):
+    p = ElasParams()
+    ref_elas_lib().ref_elas_default_params(int(middlebury), C.byref(p))
+    return p
+
+
+def ref_elas(grayL, grayR, params=None):
+    """Elas::process untouched: dense left/right disparity maps (float32, negative = invalid)."""
     L = ref_elas_lib()
     if L is None:
         raise RuntimeError("oracle/_ref/libref_elas.so not built (make -C oracle -f Makefile.ref)")
+    params = params or ref_elas_params()
     gl = np.ascontiguousarray(grayL, np.uint8); gr = np.ascontiguousarray(grayR, np.uint8)
     H, W = gl.shape
     D1 = np.zeros((H, W), np.float32); D2 = np.zeros((H, W), np.float32)
-    L.ref_elas_process(_p(gl), _p(gr), W, H, W, int(robotics), _p(D1), _p(D2))
+    L.ref_elas_process(_p(gl), _p(gr), W, H, W, C.byref(params), _p(D1), _p(D2))
     return D1, D2
+
+
+def ref_elas_staged(grayL, grayR, params=None, tri1=None, tri2=None, cap_support=60000, cap_tri=120000):
+    """The reference's stages run one by one with every intermediate tapped; tri1/tri2 (n,3 int32)
+    override the triangle lists of the left/right image (see oracle/ref_elas_wrap.cpp)."""
+    L = ref_elas_lib()
+    params = params or ref_elas_params()
+    gl = np.ascontiguousarray(grayL, np.uint8); gr = np.ascontiguousarray(grayR, np.uint8)
+    H, W = gl.shape
+    gw = -(-W // params.grid_size); gh = -(-H // params.grid_size)
+    o = dict(desc1=np.zeros((H, W, 16), np.uint8), desc2=np.zeros((H, W, 16), np.uint8),
+             support=np.zeros((cap_support, 3), np.int32),
+             tri1=np.zeros((cap_tri, 3), np.int32), tri2=np.zeros((cap_tri, 3), np.int32),
+             planes1=np.zeros((cap_tri, 6), np.float32), planes2=np.zeros((cap_tri, 6), np.float32),
+             grid1=np.zeros((gh, gw, params.disp_max + 2), np.int32),
+             grid2=np.zeros((gh, gw, params.disp_max + 2), np.int32))
+    for k in ("raw", "lr", "seg", "gap", "mean"):
+        o["D1_" + k] = np.zeros((H, W), np.float32); o["D2_" + k] = np.zeros((H, W), np.float32)
+    t = _ElasTaps()
+    for k, a in o.items():
+        setattr(t, k, a.ctypes.data)
+    t.cap_support = cap_support; t.cap_tri = cap_tri
+    keep = []
+    for name, tri in (("tri1_in", tri1), ("tri2_in", tri2)):
+        if tri is not None:
+            a = np.ascontiguousarray(tri, np.int32); keep.append(a)
+            setattr(t, name, a.ctypes.data); setattr(t, "n_" + name, len(a))
+    D1 = np.zeros((H, W), np.float32); D2 = np.zeros((H, W), np.float32)
+    rc = L.ref_elas_staged(_p(gl), _p(gr), W, H, W, C.byref(params), C.byref(t), _p(D1), _p(D2))
+    assert t.n_support <= cap_support and t.n_tri1 <= cap_tri and t.n_tri2 <= cap_tri
+    o["support"] = o["support"][:t.n_support].copy()
+    for s in ("1", "2"):
+        n = getattr(t, "n_tri" + s)
+        o["tri" + s] = o["tri" + s][:n].copy(); o["planes" + s] = o["planes" + s][:n].copy()
+    o["D1"] = D1; o["D2"] = D2; o["rc"] = rc
+    return o
+
+
+def ref_elas_delaunay(xy):
+    """Triangle ("zQB") as libelas calls it, on n (x, y) integer points; (m, 3) int32 triangles."""
+    xy = np.ascontiguousarray(xy, np.int32)
+    cap = 4 * len(xy) + 16
+    tri = np.zeros((cap, 3), np.int32)
+    n = ref_elas_lib().ref_elas_delaunay(_p(xy), len(xy), _p(tri), cap)
+    return tri[:n].copy()
+
+
+def canonical_triangles(tri):
+    """Smallest index first (orientation kept), rows sorted - the order svo_elas_delaunay emits."""
+    t = np.asarray(tri, np.int32).reshape(-1, 3)
+    if len(t) == 0:
+        return t
+    k = np.argmin(t, 1)
+    t = np.stack([np.roll(r, -kk) for r, kk in zip(t, k)])
+    return t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))]

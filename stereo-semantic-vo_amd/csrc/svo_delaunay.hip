@@ -1,0 +1,233 @@
+// svo_delaunay.hip - host-side Delaunay triangulation of the ELAS support points.
+//
+// Replaces the call `triangulate("zQB", ...)` of Elas::computeDelaunayTriangulation
+// (Thirdparty/libelas/src/elas.cpp:445-503), i.e. J. R. Shewchuk's Triangle run with its default
+// algorithm: divide and conquer (Guibas & Stolfi 1985, "Primitives for the manipulation of general
+// subdivisions and the computation of Voronoi diagrams") with Dwyer's alternating cuts.  The support
+// points sit on a 5-pixel lattice, so co-circular quadruples are the rule, not the exception, and
+// which diagonal is chosen changes the plane prior of the pixels underneath.  To reproduce the
+// reference's choice this is the same published algorithm with the same decisions:
+//   * vertices sorted by (x, y), duplicates dropped, halves split by alternating x / y medians,
+//     subsets of <= 3 vertices sorted by x (triangle.cpp:5582-5608, 6160-6220);
+//   * strict tests everywhere: lower tangent by ccw > 0, candidate valid iff ccw > 0 (evaluated once
+//     per knitting step), edge deleted iff incircle > 0 and only while a real triangle is exposed,
+//     right candidate taken iff left is finished or incircle(ul, ll, lr, ur) > 0 (triangle.cpp:5700-5940);
+//   * horizontal cuts run the same merge after moving the four hull handles from the x-extreme to the
+//     y-extreme vertices and back (triangle.cpp:5666-5700, 5795-5820).
+// Own data structure (array quad-edge instead of Triangle's ghost-triangle mesh) and exact int64
+// predicates (coordinates are pixel integers < 2^15, so the 4th-degree incircle determinant fits).
+// Output is canonical: every triangle counter-clockwise in (u, v), smallest vertex index first,
+// triangles sorted lexicographically - Triangle's own output order is an artefact of its memory pool.
+// Of several input points with identical coordinates the lowest index is used (Triangle keeps
+// whichever its randomised quicksort happens to place first).
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+#include "svo_internal.h"
+
+namespace {
+
+struct Pt { int32_t x, y, id; };
+
+struct QuadEdge {
+  std::vector<int32_t> nxt;   // Onext of each of the 4 directed edges of a quad
+  std::vector<int32_t> org;   // origin vertex (slot in `p`) of the primal edges, -1 on dual edges
+  std::vector<uint8_t> dead;  // per quad
+  const Pt* p = nullptr;
+
+  static int rot(int e) { return (e & ~3) | ((e + 1) & 3); }
+  static int sym(int e) { return (e & ~3) | ((e + 2) & 3); }
+  static int irot(int e) { return (e & ~3) | ((e + 3) & 3); }
+  int onext(int e) const { return nxt[e]; }
+  int oprev(int e) const { return rot(nxt[rot(e)]); }
+  int lnext(int e) const { return rot(nxt[irot(e)]); }
+  int lprev(int e) const { return sym(nxt[e]); }
+  int rnext(int e) const { return irot(nxt[rot(e)]); }
+  int rprev(int e) const { return nxt[sym(e)]; }
+  int o(int e) const { return org[e]; }
+  int d(int e) const { return org[sym(e)]; }
+
+  int make_edge(int a, int b) {
+    const int q = (int)nxt.size();
+    nxt.push_back(q); nxt.push_back(q + 3); nxt.push_back(q + 2); nxt.push_back(q + 1);
+    org.push_back(a); org.push_back(-1); org.push_back(b); org.push_back(-1);
+    dead.push_back(0);
+    return q;
+  }
+  void splice(int a, int b) {
+    const int alpha = rot(nxt[a]), beta = rot(nxt[b]);
+    std::swap(nxt[a], nxt[b]);
+    std::swap(nxt[alpha], nxt[beta]);
+  }
+  int connect(int a, int b) {
+    const int e = make_edge(d(a), o(b));
+    splice(e, lnext(a));
+    splice(sym(e), b);
+    return e;
+  }
+  void remove(int e) {
+    splice(e, oprev(e));
+    splice(sym(e), oprev(sym(e)));
+    dead[e >> 2] = 1;
+  }
+
+  // > 0 iff a, b, c make a left turn
+  int64_t ccw(int a, int b, int c) const {
+    return (int64_t)(p[b].x - p[a].x) * (p[c].y - p[a].y) - (int64_t)(p[b].y - p[a].y) * (p[c].x - p[a].x);
+  }
+  // > 0 iff d lies strictly inside the circle through a, b, c (a, b, c counter-clockwise)
+  int64_t incircle(int a, int b, int c, int dd) const {
+    const int64_t ax = p[a].x - p[dd].x, ay = p[a].y - p[dd].y;
+    const int64_t bx = p[b].x - p[dd].x, by = p[b].y - p[dd].y;
+    const int64_t cx = p[c].x - p[dd].x, cy = p[c].y - p[dd].y;
+    const int64_t al = ax * ax + ay * ay, bl = bx * bx + by * by, cl = cx * cx + cy * cy;
+    return al * (bx * cy - by * cx) + bl * (cx * ay - cy * ax) + cl * (ax * by - ay * bx);
+  }
+};
+
+struct Hull { int lo, ro; };   // lo: ccw hull edge out of the "leftmost" vertex, ro: cw hull edge out of the "rightmost"
+
+struct Builder {
+  QuadEdge q;
+  std::vector<Pt> pts;
+
+  static bool less_axis(const Pt& a, const Pt& b, int axis) {
+    const int32_t a1 = axis ? a.y : a.x, b1 = axis ? b.y : b.x;
+    if (a1 != b1) return a1 < b1;
+    return axis ? a.x < b.x : a.y < b.y;
+  }
+
+  Hull build(int lo, int n, int axis) {
+    Pt* s = pts.data() + lo;
+    if (n <= 3) std::sort(s, s + n, [](const Pt& a, const Pt& b) { return less_axis(a, b, 0); });
+    if (n == 2) {
+      const int a = q.make_edge(lo, lo + 1);
+      return {a, QuadEdge::sym(a)};
+    }
+    if (n == 3) {
+      const int a = q.make_edge(lo, lo + 1), b = q.make_edge(lo + 1, lo + 2);
+      q.splice(QuadEdge::sym(a), b);
+      const int64_t area = q.ccw(lo, lo + 1, lo + 2);
+      if (area > 0) { q.connect(b, a); return {a, QuadEdge::sym(b)}; }
+      if (area < 0) { const int c = q.connect(b, a); return {QuadEdge::sym(c), c}; }
+      return {a, QuadEdge::sym(b)};
+    }
+    const int nl = n >> 1;
+    std::nth_element(s, s + nl, s + n, [axis](const Pt& a, const Pt& b) { return less_axis(a, b, axis); });
+    const Hull L = build(lo, nl, 1 - axis);
+    const Hull R = build(lo + nl, n - nl, 1 - axis);
+    return merge(L, R, axis);
+  }
+
+  Hull merge(const Hull& L, const Hull& R, int axis) {
+    int ldo = L.lo, ldi = L.ro, rdi = R.lo, rdo = R.ro;
+    const Pt* p = pts.data();
+    if (axis == 1) {   // horizontal cut: handles move to the bottom-/top-most vertices
+      while (p[q.d(ldo)].y < p[q.o(ldo)].y) ldo = q.rprev(ldo);
+      while (p[q.o(q.lprev(ldi))].y > p[q.o(ldi)].y) ldi = q.lprev(ldi);
+      while (p[q.d(rdi)].y < p[q.o(rdi)].y) rdi = q.rprev(rdi);
+      while (p[q.o(q.lprev(rdo))].y > p[q.o(rdo)].y) rdo = q.lprev(rdo);
+    }
+    // lower common tangent
+    bool changed;
+    do {
+      changed = false;
+      if (q.ccw(q.o(ldi), q.d(ldi), q.o(rdi)) > 0) { ldi = q.lnext(ldi); changed = true; }
+      if (q.ccw(q.d(rdi), q.o(rdi), q.o(ldi)) > 0) { rdi = q.rprev(rdi); changed = true; }
+    } while (changed);
+    int basel = q.connect(QuadEdge::sym(rdi), ldi);   // lower-right -> lower-left
+    if (q.o(ldi) == q.o(ldo)) ldo = QuadEdge::sym(basel);
+    if (q.o(rdi) == q.o(rdo)) rdo = basel;
+    for (;;) {
+      const int ll = q.d(basel), lr = q.o(basel);
+      int lcand = q.onext(QuadEdge::sym(basel));
+      int rcand = q.oprev(basel);
+      const bool left_finished = q.ccw(q.d(lcand), ll, lr) <= 0;
+      const bool right_finished = q.ccw(q.d(rcand), ll, lr) <= 0;
+      if (left_finished && right_finished) break;
+      if (!left_finished) {
+        for (;;) {   // delete left edges that fail the circle test while a real triangle is exposed
+          const int ul = q.d(lcand), x = q.d(q.onext(lcand));
+          if (!(q.d(q.lnext(lcand)) == x && q.ccw(ll, ul, x) > 0)) break;
+          if (!(q.incircle(ll, lr, ul, x) > 0)) break;
+          const int t = q.onext(lcand);
+          q.remove(lcand);
+          lcand = t;
+        }
+      }
+      if (!right_finished) {
+        for (;;) {
+          const int ur = q.d(rcand), x = q.d(q.oprev(rcand));
+          if (!(q.d(q.lnext(QuadEdge::sym(rcand))) == x && q.ccw(ur, lr, x) > 0)) break;
+          if (!(q.incircle(ll, lr, ur, x) > 0)) break;
+          const int t = q.oprev(rcand);
+          q.remove(rcand);
+          rcand = t;
+        }
+      }
+      if (left_finished || (!right_finished && q.incircle(q.d(lcand), ll, lr, q.d(rcand)) > 0))
+        basel = q.connect(rcand, QuadEdge::sym(basel));
+      else
+        basel = q.connect(QuadEdge::sym(basel), QuadEdge::sym(lcand));
+    }
+    if (axis == 1) {   // back to the left-/right-most vertices
+      while (p[q.o(q.rnext(ldo))].x < p[q.o(ldo)].x) ldo = q.rnext(ldo);
+      while (p[q.d(rdo)].x > p[q.o(rdo)].x) rdo = q.lnext(rdo);
+    }
+    return {ldo, rdo};
+  }
+};
+
+}  // namespace
+
+// xy: n points as (x, y) int32 pairs.  tri: up to cap (c1, c2, c3) index triples into xy.
+// Returns the number of triangles (which may exceed cap: nothing is written beyond cap), < 0 on error.
+extern "C" int svo_elas_delaunay(const int32_t* xy, int32_t n, int32_t* tri, int32_t cap, int32_t* n_tri) {
+  if (!xy || !n_tri || n < 0 || cap < 0 || (cap > 0 && !tri)) return SVO_E_INVALID;
+  *n_tri = 0;
+  Builder b;
+  b.pts.resize(n);
+  for (int i = 0; i < n; ++i) {
+    if (xy[2 * i] < -32768 || xy[2 * i] > 32767 || xy[2 * i + 1] < -32768 || xy[2 * i + 1] > 32767)
+      return SVO_E_INVALID;
+    b.pts[i] = {xy[2 * i], xy[2 * i + 1], i};
+  }
+  std::sort(b.pts.begin(), b.pts.end(), [](const Pt& a, const Pt& c) {
+    if (a.x != c.x) return a.x < c.x;
+    if (a.y != c.y) return a.y < c.y;
+    return a.id < c.id;
+  });
+  b.pts.erase(std::unique(b.pts.begin(), b.pts.end(),
+                          [](const Pt& a, const Pt& c) { return a.x == c.x && a.y == c.y; }),
+              b.pts.end());
+  const int m = (int)b.pts.size();
+  if (m < 3) return SVO_OK;
+  b.q.nxt.reserve(16 * m); b.q.org.reserve(16 * m); b.q.dead.reserve(4 * m);
+  b.q.p = b.pts.data();
+  b.build(0, m, 0);
+  b.q.p = b.pts.data();
+  struct T { int32_t a, b, c; };
+  std::vector<T> out;
+  out.reserve(2 * m);
+  const QuadEdge& q = b.q;
+  for (int e = 0; e < (int)q.nxt.size(); e += 2) {   // primal directed edges
+    if (q.dead[e >> 2]) continue;
+    const int e2 = q.lnext(e), e3 = q.lnext(e2);
+    if (q.lnext(e3) != e) continue;
+    const int A = q.o(e), B = q.o(e2), C = q.o(e3);
+    if (q.ccw(A, B, C) <= 0) continue;
+    const int32_t ia = b.pts[A].id, ib = b.pts[B].id, ic = b.pts[C].id;
+    if (ia < ib && ia < ic) out.push_back({ia, ib, ic});
+  }
+  std::sort(out.begin(), out.end(), [](const T& x, const T& y) {
+    if (x.a != y.a) return x.a < y.a;
+    if (x.b != y.b) return x.b < y.b;
+    return x.c < y.c;
+  });
+  *n_tri = (int32_t)out.size();
+  for (int i = 0; i < std::min<int>((int)out.size(), cap); ++i) {
+    tri[3 * i] = out[i].a; tri[3 * i + 1] = out[i].b; tri[3 * i + 2] = out[i].c;
+  }
+  return SVO_OK;
+}

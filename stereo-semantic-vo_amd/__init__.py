@@ -45,6 +45,7 @@ ABI_SYMBOLS = [
     "svo_debug_track_matches", "svo_debug_track_gate", "svo_fundamental_8point",
     "svo_frontend_batch_dev", "svo_track_batch_dev", "svo_profile_enable", "svo_profile_reset",
     "svo_profile_get",
+    "svo_elas_default_params", "svo_elas_process", "svo_elas_process_ex", "svo_elas_delaunay",
 ]
 
 
@@ -327,3 +328,92 @@ class Svo:
             out[name.value.decode()] = (ms.value, n.value)
             i += 1
         return out
+
+    # ---- dense ELAS stereo (include/svo.h: svo_elas_*; replaces Thirdparty/libelas Elas::process) ----
+    def elas_process(self, grayL, grayR, params=None, taps=False, tri1=None, tri2=None):
+        """D1, D2 (float32 H x W, negative = invalid).  With taps=True returns a dict of every
+        intermediate instead (keys as in svo_elas_taps, plus "D1"/"D2")."""
+        gl, gr = _u8(grayL), _u8(grayR)
+        H, W = gl.shape
+        params = params or elas_default_params(0)
+        dims = (C.c_int32 * 3)(W, H, W)
+        D1 = np.zeros((H, W), np.float32); D2 = np.zeros((H, W), np.float32)
+        if not taps and tri1 is None and tri2 is None:
+            self._chk(self.lib.svo_elas_process(self.h, _p(gl), _p(gr), _p(D1), _p(D2), dims, C.byref(params)))
+            return D1, D2
+        cap_sp = (W // params.candidate_stepsize + 2) * (H // params.candidate_stepsize + 2) + 8
+        cap_tri = 2 * cap_sp + 16
+        gw = -(-W // params.grid_size); gh = -(-H // params.grid_size)
+        o = dict(desc1=np.zeros((H, W, 16), np.uint8), desc2=np.zeros((H, W, 16), np.uint8),
+                 support=np.zeros((cap_sp, 3), np.int32),
+                 tri1=np.zeros((cap_tri, 3), np.int32), tri2=np.zeros((cap_tri, 3), np.int32),
+                 planes1=np.zeros((cap_tri, 6), np.float32), planes2=np.zeros((cap_tri, 6), np.float32),
+                 grid1=np.zeros((gh, gw, params.disp_max + 2), np.int32),
+                 grid2=np.zeros((gh, gw, params.disp_max + 2), np.int32))
+        for k in ("raw", "lr", "seg", "gap", "mean"):
+            o["D1_" + k] = np.zeros((H, W), np.float32); o["D2_" + k] = np.zeros((H, W), np.float32)
+        t = ElasTaps()
+        for k, a in o.items():
+            setattr(t, k, a.ctypes.data)
+        t.cap_support = cap_sp; t.cap_tri = cap_tri
+        keep = []
+        for name, tri in (("tri1_in", tri1), ("tri2_in", tri2)):
+            if tri is not None:
+                a = np.ascontiguousarray(tri, np.int32); keep.append(a)
+                setattr(t, name, a.ctypes.data); setattr(t, "n_" + name, len(a))
+        self._chk(self.lib.svo_elas_process_ex(self.h, _p(gl), _p(gr), _p(D1), _p(D2), dims, C.byref(params),
+                                               C.byref(t)))
+        o["support"] = o["support"][:t.n_support].copy()
+        for s in ("1", "2"):
+            n = getattr(t, "n_tri" + s)
+            o["tri" + s] = o["tri" + s][:n].copy(); o["planes" + s] = o["planes" + s][:n].copy()
+        o["D1"] = D1; o["D2"] = D2
+        return o
+
+
+class ElasParams(C.Structure):
+    """svo_elas_params == Elas::parameters (Thirdparty/libelas/src/elas.h:60-83), bools as int32."""
+    _fields_ = [("disp_min", C.c_int32), ("disp_max", C.c_int32), ("support_threshold", C.c_float),
+                ("support_texture", C.c_int32), ("candidate_stepsize", C.c_int32),
+                ("incon_window_size", C.c_int32), ("incon_threshold", C.c_int32),
+                ("incon_min_support", C.c_int32), ("add_corners", C.c_int32), ("grid_size", C.c_int32),
+                ("beta", C.c_float), ("gamma", C.c_float), ("sigma", C.c_float), ("sradius", C.c_float),
+                ("match_texture", C.c_int32), ("lr_threshold", C.c_int32),
+                ("speckle_sim_threshold", C.c_float), ("speckle_size", C.c_int32),
+                ("ipol_gap_width", C.c_int32), ("filter_median", C.c_int32),
+                ("filter_adaptive_mean", C.c_int32), ("postprocess_only_left", C.c_int32),
+                ("subsampling", C.c_int32)]
+
+
+class ElasTaps(C.Structure):
+    _fields_ = [("desc1", C.c_void_p), ("desc2", C.c_void_p), ("support", C.c_void_p),
+                ("n_support", C.c_int32), ("cap_support", C.c_int32),
+                ("tri1", C.c_void_p), ("tri2", C.c_void_p), ("planes1", C.c_void_p), ("planes2", C.c_void_p),
+                ("n_tri1", C.c_int32), ("n_tri2", C.c_int32), ("cap_tri", C.c_int32),
+                ("grid1", C.c_void_p), ("grid2", C.c_void_p),
+                ("D1_raw", C.c_void_p), ("D2_raw", C.c_void_p), ("D1_lr", C.c_void_p), ("D2_lr", C.c_void_p),
+                ("D1_seg", C.c_void_p), ("D2_seg", C.c_void_p), ("D1_gap", C.c_void_p), ("D2_gap", C.c_void_p),
+                ("D1_mean", C.c_void_p), ("D2_mean", C.c_void_p),
+                ("tri1_in", C.c_void_p), ("tri2_in", C.c_void_p),
+                ("n_tri1_in", C.c_int32), ("n_tri2_in", C.c_int32)]
+
+
+def elas_default_params(setting=0):
+    """Elas::parameters(setting): 0 = ROBOTICS (the reference's default), 1 = MIDDLEBURY."""
+    p = ElasParams()
+    rc = load_library().svo_elas_default_params(int(setting), C.byref(p))
+    if rc != 0:
+        raise SvoError("svo_elas_default_params failed")
+    return p
+
+
+def elas_delaunay(xy):
+    """Host-side Delaunay triangulation of n (x, y) integer points (needs no GPU)."""
+    xy = np.ascontiguousarray(xy, np.int32).reshape(-1, 2)
+    cap = 4 * len(xy) + 16
+    tri = np.zeros((cap, 3), np.int32)
+    n = C.c_int32(0)
+    rc = load_library().svo_elas_delaunay(_p(xy), len(xy), _p(tri), cap, C.byref(n))
+    if rc != 0:
+        raise SvoError("svo_elas_delaunay failed (%d)" % rc)
+    return tri[:n.value].copy()

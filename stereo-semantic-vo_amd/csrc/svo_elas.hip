@@ -1,0 +1,844 @@
+// svo_elas.hip - dense ELAS stereo for gfx950.
+//
+// Replaces the reference's vendored libelas, `Elas::process` (Thirdparty/libelas/src/elas.cpp:32-150).
+// Stage map (reference file:line -> here):
+//   Descriptor (descriptor.cpp:27-112, filter.cpp:176-262,372-413)   -> k_elas_desc        (GPU)
+//   computeSupportMatches / computeMatchingDisparity (elas.cpp:267-443) -> k_elas_support   (GPU)
+//   removeInconsistent/RedundantSupportPoints, addCorners (elas.cpp:152-265) -> host (in-place, order dependent)
+//   computeDelaunayTriangulation (elas.cpp:445-503)                  -> svo_delaunay.hip   (host)
+//   computeDisparityPlanes (elas.cpp:505-577, matrix.cpp:414-503)    -> host (float64 Gauss-Jordan)
+//   createGrid (elas.cpp:579-658)                                    -> host
+//   computeDisparity / findMatch (elas.cpp:682-907)                  -> k_elas_raster + k_elas_match (GPU)
+//   leftRightConsistencyCheck (elas.cpp:909-979)                     -> k_elas_lr          (GPU)
+//   removeSmallSegments (elas.cpp:981-1099)                          -> k_cc_* union-find  (GPU)
+//   gapInterpolation (elas.cpp:1101-1285)                            -> k_elas_gap         (GPU)
+//   adaptiveMean (elas.cpp:1287-1483)                                -> k_elas_mean_h/_v   (GPU)
+//   median (elas.cpp:1485-1560)                                      -> k_elas_median_h/_v (GPU)
+// All integer stages are bit-exact against the compiled reference; the float stages repeat its
+// operation order (-ffp-contract=off), including libelas' `_mm_set1_ps(0x7FFFFFFF)` "abs mask", which is
+// really the bit pattern of 2^31f (0x4F000000).  Memory the reference reads without having written it
+// (descriptor rows/columns 2 and N-3; D_tmp of adaptiveMean) is defined as 0 here.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "svo_internal.h"
+#include "svo_wave.h"
+
+extern "C" int svo_elas_delaunay(const int32_t* xy, int32_t n, int32_t* tri, int32_t cap, int32_t* n_tri);
+
+namespace {
+
+struct ElasState {
+  int W = 0, H = 0, Wc = 0, Hc = 0, gw = 0, gh = 0, gd = 0;
+  int cap_sp = 0, cap_tri = 0;
+  uint8_t* d_img[2] = {nullptr, nullptr};
+  uint4* d_desc[2] = {nullptr, nullptr};
+  int16_t* d_can = nullptr;
+  int32_t* d_sp = nullptr;
+  int32_t* d_tri[2] = {nullptr, nullptr};
+  float* d_plane[2] = {nullptr, nullptr};
+  int32_t* d_grid[2] = {nullptr, nullptr};
+  int32_t* d_P = nullptr;
+  int32_t* d_owner[2] = {nullptr, nullptr};
+  float* d_D[2] = {nullptr, nullptr};
+  float* d_T[2] = {nullptr, nullptr};
+  int32_t* d_lab = nullptr;
+  int32_t* d_size = nullptr;
+  std::vector<void*> allocs;
+  void release() {
+    for (void* p : allocs) hipFree(p);
+    allocs.clear();
+    W = H = 0;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Descriptor: 3x3 Sobel responses du, dv (8-bit, offset 128, saturated) and the 16-byte descriptor.
+// ------------------------------------------------------------------------------------------------
+#define DT_X 32
+#define DT_Y 8
+__global__ __launch_bounds__(256) void k_elas_desc(const uint8_t* img0, const uint8_t* img1, int W, int H,
+                                                   uint4* desc0, uint4* desc1) {
+  __shared__ uint8_t im[DT_Y + 6][DT_X + 8];
+  __shared__ uint8_t du[DT_Y + 4][DT_X + 4], dv[DT_Y + 4][DT_X + 4];
+  const uint8_t* img = blockIdx.z ? img1 : img0;
+  uint4* desc = blockIdx.z ? desc1 : desc0;
+  const int x0 = blockIdx.x * DT_X, y0 = blockIdx.y * DT_Y, tid = threadIdx.x;
+  for (int i = tid; i < (DT_Y + 6) * (DT_X + 6); i += 256) {
+    const int r = i / (DT_X + 6), c = i - r * (DT_X + 6);
+    const int gy = min(max(y0 - 3 + r, 0), H - 1), gx = min(max(x0 - 3 + c, 0), W - 1);
+    im[r][c] = img[(size_t)gy * W + gx];
+  }
+  __syncthreads();
+  for (int i = tid; i < (DT_Y + 4) * (DT_X + 4); i += 256) {
+    const int r = i / (DT_X + 4), c = i - r * (DT_X + 4);   // pixel (y0-2+r, x0-2+c); im index (r+1, c+1)
+    const int sl = im[r][c] + 2 * im[r + 1][c] + im[r + 2][c];
+    const int sr = im[r][c + 2] + 2 * im[r + 1][c + 2] + im[r + 2][c + 2];
+    const int tl = im[r][c] - im[r + 2][c], tc = im[r][c + 1] - im[r + 2][c + 1], tr = im[r][c + 2] - im[r + 2][c + 2];
+    du[r][c] = (uint8_t)min(max(((sl - sr) >> 2) + 128, 0), 255);
+    dv[r][c] = (uint8_t)min(max(((tl + 2 * tc + tr) >> 2) + 128, 0), 255);
+  }
+  __syncthreads();
+  const int tx = tid & (DT_X - 1), ty = tid / DT_X;
+  const int u = x0 + tx, v = y0 + ty;
+  if (u >= W || v >= H) return;
+  uint4 o = make_uint4(0, 0, 0, 0);
+  if (u >= 3 && u < W - 3 && v >= 3 && v < H - 3) {
+    const int j = tx + 2, i = ty + 2;   // (v, u) in du/dv indices
+    o.x = du[i - 2][j] | (du[i - 1][j - 2] << 8) | (du[i - 1][j] << 16) | ((uint32_t)du[i - 1][j + 2] << 24);
+    o.y = du[i][j - 1] | (du[i][j] << 8) | (du[i][j] << 16) | ((uint32_t)du[i][j + 1] << 24);
+    o.z = du[i + 1][j - 2] | (du[i + 1][j] << 8) | (du[i + 1][j + 2] << 16) | ((uint32_t)du[i + 2][j] << 24);
+    o.w = dv[i - 1][j] | (dv[i][j - 1] << 8) | (dv[i][j + 1] << 16) | ((uint32_t)dv[i + 1][j] << 24);
+  }
+  desc[(size_t)v * W + u] = o;
+}
+
+__device__ __forceinline__ int sad16(const uint4& a, const uint4& b) {
+  uint32_t s = __builtin_amdgcn_sad_u8(a.x, b.x, 0u);
+  s = __builtin_amdgcn_sad_u8(a.y, b.y, s);
+  s = __builtin_amdgcn_sad_u8(a.z, b.z, s);
+  return (int)__builtin_amdgcn_sad_u8(a.w, b.w, s);
+}
+__device__ __forceinline__ int texture16(const uint4& a) {   // sum |byte - 128|
+  return sad16(a, make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Support matches: one wave per lattice candidate, lanes over disparities.
+// ------------------------------------------------------------------------------------------------
+__device__ int elas_support_match(const uint4* __restrict__ I1d, const uint4* __restrict__ I2d, int u, int v,
+                                  bool right, int W, int H, const svo_elas_params& p, int lane) {
+  if (!(u >= 5 && u <= W - 6 && v >= 5 && v <= H - 6)) return -1;
+  if (texture16(I1d[(size_t)v * W + u]) < p.support_texture) return -1;
+  const size_t r0 = (size_t)(v - 2) * W, r1 = (size_t)(v + 2) * W;
+  const uint4 b1 = I1d[r0 + u - 2], b2 = I1d[r0 + u + 2], b3 = I1d[r1 + u - 2], b4 = I1d[r1 + u + 2];
+  const int dmin = max(p.disp_min, 0);
+  const int dmax = right ? min(p.disp_max, W - u - 5) : min(p.disp_max, u - 5);
+  if (dmax - dmin < 10) return -1;
+  uint32_t k1 = 0xffffffffu, m2 = 0x7fffffu;
+  for (int d = dmin + lane; d <= dmax; d += 64) {
+    const int uw = right ? u + d : u - d;
+    const uint32_t sum = (uint32_t)(sad16(b1, I2d[r0 + uw - 2]) + sad16(b2, I2d[r0 + uw + 2]) +
+                                    sad16(b3, I2d[r1 + uw - 2]) + sad16(b4, I2d[r1 + uw + 2]));
+    const uint32_t key = (sum << 9) | (uint32_t)d;
+    if (key < k1) { m2 = k1 >> 9; k1 = key; }
+    else if (sum < m2) m2 = sum;
+  }
+  const uint32_t K1 = wave_min_u32_dpp(k1);
+  const uint32_t second = wave_min_u32_dpp(k1 == K1 ? m2 : (k1 >> 9));
+  const uint32_t min1 = K1 >> 9;
+  if (second >= 32767u) return -1;   // no second candidate
+  return ((float)min1 < p.support_threshold * (float)second) ? (int)(K1 & 511u) : -1;
+}
+
+__global__ __launch_bounds__(256) void k_elas_support(const uint4* desc1, const uint4* desc2, int W, int H,
+                                                      int Wc, int Hc, svo_elas_params p, int16_t* D_can) {
+  const int lane = threadIdx.x & 63;
+  const int cand = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (cand >= (Wc - 1) * (Hc - 1)) return;
+  const int v_can = 1 + cand / (Wc - 1), u_can = 1 + cand % (Wc - 1);
+  const int u = u_can * p.candidate_stepsize, v = v_can * p.candidate_stepsize;
+  int res = -1;
+  const int d = elas_support_match(desc1, desc2, u, v, false, W, H, p, lane);
+  if (d >= 0) {
+    const int d2 = elas_support_match(desc2, desc1, u - d, v, true, W, H, p, lane);
+    if (d2 >= 0 && abs(d - d2) <= p.lr_threshold) res = d;
+  }
+  if (lane == 0) D_can[v_can * Wc + u_can] = (int16_t)res;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense matching.  k_elas_raster repeats the reference's scanline rasterisation (its float edge
+// equations and truncations) and leaves, per pixel, the LAST triangle covering it (what the
+// reference's sequential overwrite leaves); k_elas_match then runs findMatch once per pixel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_elas_raster(const int32_t* sp, const int32_t* tri0, const int32_t* tri1,
+                                                     int n0, int n1, int W, int H, int32_t* own0, int32_t* own1) {
+  const bool right = blockIdx.y != 0;
+  const int32_t* tri = right ? tri1 : tri0;
+  int32_t* owner = right ? own1 : own0;
+  const int n = right ? n1 : n0;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (t >= n) return;
+  float tu[3], tv[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int c = tri[3 * t + k];
+    tu[k] = right ? (float)(sp[3 * c] - sp[3 * c + 2]) : (float)sp[3 * c];
+    tv[k] = (float)sp[3 * c + 1];
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int k = 0; k < j; ++k)
+      if (tu[k] > tu[j]) {
+        const float a = tu[j]; tu[j] = tu[k]; tu[k] = a;
+        const float b = tv[j]; tv[j] = tv[k]; tv[k] = b;
+      }
+  const float A_u = tu[0], A_v = tv[0], B_u = tu[1], B_v = tv[1], C_u = tu[2], C_v = tv[2];
+  float AB_a = 0, AC_a = 0, BC_a = 0;
+  if ((int)A_u != (int)B_u) AB_a = (A_v - B_v) / (A_u - B_u);
+  if ((int)A_u != (int)C_u) AC_a = (A_v - C_v) / (A_u - C_u);
+  if ((int)B_u != (int)C_u) BC_a = (B_v - C_v) / (B_u - C_u);
+  const float AB_b = A_v - AB_a * A_u, AC_b = A_v - AC_a * A_u, BC_b = B_v - BC_a * B_u;
+#pragma unroll
+  for (int part = 0; part < 2; ++part) {
+    const float s_u = part ? B_u : A_u, e_u = part ? C_u : B_u;
+    const float m_a = part ? BC_a : AB_a, m_b = part ? BC_b : AB_b;
+    if ((int)s_u == (int)e_u) continue;
+    for (int u = max((int)s_u, 0) + lane; u < min((int)e_u, W); u += 64) {
+      const int v_1 = (int)(AC_a * (float)u + AC_b);
+      const int v_2 = (int)(m_a * (float)u + m_b);
+      for (int v = max(min(v_1, v_2), 0); v < min(max(v_1, v_2), H); ++v) atomicMax(&owner[v * W + u], t);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_elas_match(const uint4* desc1, const uint4* desc2, const int32_t* own0,
+                                                    const int32_t* own1, const float* pl0, const float* pl1,
+                                                    const int32_t* grid0, const int32_t* grid1, const int32_t* P,
+                                                    int W, int H, int gw, int gd, int plane_radius,
+                                                    svo_elas_params p, float* D0, float* D1) {
+  const bool right = blockIdx.z != 0;
+  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+  if (u >= W) return;
+  const int addr = v * W + u;
+  float* D = right ? D1 : D0;
+  const int t = (right ? own1 : own0)[addr];
+  float out = -10.0f;
+  if (t >= 0 && u >= 2 && u < W - 2) {
+    const uint4* Is = right ? desc2 : desc1;
+    const uint4* Io = right ? desc1 : desc2;
+    const size_t line = (size_t)max(min(v, H - 3), 2) * W;
+    const uint4 self = Is[line + u];
+    if (texture16(self) >= p.match_texture) {
+      const float* pl = (right ? pl1 : pl0) + 6 * t;
+      const float pa = right ? pl[3] : pl[0], pb = right ? pl[4] : pl[1], pc = right ? pl[5] : pl[2];
+      const float pd = right ? pl[0] : pl[3];
+      const bool valid = (double)fabsf(pa) < 0.7 && (double)fabsf(pd) < 0.7;
+      const int disp_num = gd - 1;
+      const int d_plane = (int)(pa * (float)u + pb * (float)v + pc);
+      const int d_plane_min = max(d_plane - plane_radius, 0);
+      const int d_plane_max = min(d_plane + plane_radius, disp_num - 1);
+      const int gx = (int)floorf((float)u / (float)p.grid_size), gy = (int)floorf((float)v / (float)p.grid_size);
+      const int32_t* cell = (right ? grid1 : grid0) + (size_t)(gy * gw + gx) * gd;
+      const int num_grid = cell[0];
+      int min_val = 10000, min_d = -1;
+      for (int i = 0; i < num_grid; ++i) {
+        const int d = cell[1 + i];
+        if (d < d_plane_min || d > d_plane_max) {
+          const int uw = right ? u + d : u - d;
+          if (uw < 2 || uw >= W - 2) continue;
+          const int val = sad16(self, Io[line + uw]);
+          if (val < min_val) { min_val = val; min_d = d; }
+        }
+      }
+      for (int d = d_plane_min; d <= d_plane_max; ++d) {
+        const int uw = right ? u + d : u - d;
+        if (uw < 2 || uw >= W - 2) continue;
+        const int val = sad16(self, Io[line + uw]) + (valid ? P[abs(d - d_plane)] : 0);
+        if (val < min_val) { min_val = val; min_d = d; }
+      }
+      out = min_d >= 0 ? (float)min_d : -1.0f;
+    }
+  }
+  D[addr] = out;
+}
+
+__global__ __launch_bounds__(256) void k_elas_lr(const float* D1, const float* D2, int W, int H, int lr_threshold,
+                                                 float* O1, float* O2) {
+  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+  if (u >= W) return;
+  const int addr = v * W + u;
+  const float d1 = D1[addr], d2 = D2[addr];
+  const float uw1 = (float)u - d1, uw2 = (float)u + d2;
+  float o1 = d1, o2 = d2;
+  if (d1 >= 0 && uw1 >= 0 && uw1 < (float)W) {
+    if (fabsf(D2[v * W + (int)uw1] - d1) > (float)lr_threshold) o1 = -10.0f;
+  } else o1 = -10.0f;
+  if (d2 >= 0 && uw2 >= 0 && uw2 < (float)W) {
+    if (fabsf(D1[v * W + (int)uw2] - d2) > (float)lr_threshold) o2 = -10.0f;
+  } else o2 = -10.0f;
+  O1[addr] = o1; O2[addr] = o2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// removeSmallSegments: the reference's region growing visits exactly the connected components of the
+// graph "4-neighbours, both valid, |d_a - d_b| <= threshold" (invalid pixels are -10 after the L/R
+// check and can never join); components smaller than speckle_size are invalidated.  Union-find.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int cc_load(const int32_t* L, int i) { return __atomic_load_n(&L[i], __ATOMIC_RELAXED); }
+__device__ int cc_find(const int32_t* L, int i) {
+  int p = cc_load(L, i);
+  while (p != i) { i = p; p = cc_load(L, i); }
+  return i;
+}
+__device__ void cc_union(int32_t* L, int a, int b) {
+  bool done;
+  do {
+    a = cc_find(L, a); b = cc_find(L, b);
+    if (a < b) { const int old = atomicMin(&L[b], a); done = old == b; b = old; }
+    else if (b < a) { const int old = atomicMin(&L[a], b); done = old == a; a = old; }
+    else done = true;
+  } while (!done);
+}
+__global__ void k_cc_init(const float* D, int n, int32_t* L, int32_t* size) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  L[i] = i;
+  size[i] = 0;
+}
+__global__ void k_cc_merge(const float* D, int W, int H, float thr, int32_t* L) {
+  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+  if (u >= W) return;
+  const int i = v * W + u;
+  const float d = D[i];
+  if (!(d >= 0)) return;
+  if (u + 1 < W) { const float e = D[i + 1]; if (e >= 0 && fabsf(d - e) <= thr) cc_union(L, i, i + 1); }
+  if (v + 1 < H) { const float e = D[i + W]; if (e >= 0 && fabsf(d - e) <= thr) cc_union(L, i, i + W); }
+}
+__global__ void k_cc_count(const float* D, int n, int32_t* L, int32_t* size) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int r = cc_find(L, i);
+  L[i] = r;
+  atomicAdd(&size[r], 1);
+}
+__global__ void k_cc_apply(float* D, int n, const int32_t* L, const int32_t* size, int speckle) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (size[L[i]] < speckle) D[i] = -10.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gapInterpolation, one pass over lines (rows: estride 1, lstride W; columns: estride W, lstride 1).
+// A maximal run of invalid pixels strictly inside a line with 1 <= length <= gap is filled with the
+// mean of its two valid neighbours (|d1-d2| < 3) or their minimum; with add_corners the leading and
+// trailing runs are filled up to `gap` pixels from the first / last valid pixel.
+// ------------------------------------------------------------------------------------------------
+#define GAP_MAXLEN 4096
+__global__ __launch_bounds__(256) void k_elas_gap(float* D, int n, int estride, int lstride, int gap, int add_corners) {
+  __shared__ float val[GAP_MAXLEN];
+  __shared__ int16_t last[GAP_MAXLEN], nxt[GAP_MAXLEN];
+  __shared__ int cl[256], cn[256];
+  float* line = D + (size_t)blockIdx.x * lstride;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n; i += 256) val[i] = line[(size_t)i * estride];
+  __syncthreads();
+  const int C = (n + 255) / 256, b = tid * C, e = min(n, b + C);
+  int l = -1, x = n;
+  for (int i = b; i < e; ++i) if (val[i] >= 0) l = i;
+  for (int i = e - 1; i >= b; --i) if (val[i] >= 0) x = i;
+  cl[tid] = l; cn[tid] = x;
+  __syncthreads();
+  if (tid == 0) {
+    int carry = -1;
+    for (int t = 0; t < 256; ++t) { const int own = cl[t]; cl[t] = carry; if (own >= 0) carry = own; }
+    carry = n;
+    for (int t = 255; t >= 0; --t) { const int own = cn[t]; cn[t] = carry; if (own < n) carry = own; }
+  }
+  __syncthreads();
+  l = cl[tid];
+  for (int i = b; i < e; ++i) { last[i] = (int16_t)l; if (val[i] >= 0) l = i; }
+  x = cn[tid];
+  for (int i = e - 1; i >= b; --i) { nxt[i] = (int16_t)x; if (val[i] >= 0) x = i; }
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) {
+    if (val[i] >= 0) continue;
+    const int lo = last[i], hi = nxt[i];
+    if (lo >= 0 && hi < n) {
+      if (hi - lo - 1 <= gap) {
+        const float d1 = val[lo], d2 = val[hi];
+        line[(size_t)i * estride] = fabsf(d1 - d2) < 3.0f ? (d1 + d2) / 2 : fminf(d1, d2);
+      }
+    } else if (add_corners) {
+      if (lo < 0 && hi < n) { if (i >= hi - gap) line[(size_t)i * estride] = val[hi]; }
+      else if (hi >= n && lo >= 0) { if (i <= lo + gap) line[(size_t)i * estride] = val[lo]; }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// adaptiveMean: 8-tap "bilateral" mean along rows, then along columns, in the reference's SSE lane
+// order: window pixel q sits in slot q % 8, lane i adds slots i and i+4, lanes are summed 0..3.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float am_weight(float val, float cur) {
+  const float a = __uint_as_float(__float_as_uint(val - cur) & 0x4F000000u);
+  return fmaxf(0.0f, 4.0f - a);
+}
+__device__ __forceinline__ bool am_filter(const float (&slot)[8], float cur, float* out) {
+  float w[8], f[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { w[i] = am_weight(slot[i], cur); f[i] = slot[i] * w[i]; }
+  const float ws = (((w[0] + w[4]) + (w[1] + w[5])) + (w[2] + w[6])) + (w[3] + w[7]);
+  const float fs = (((f[0] + f[4]) + (f[1] + f[5])) + (f[2] + f[6])) + (f[3] + f[7]);
+  if (ws > 0) {
+    const float d = fs / ws;
+    if (d >= 0) { *out = d; return true; }
+  }
+  return false;
+}
+// horizontal: T = filtered copy of D (invalid -> -10, not written -> 0)
+__global__ __launch_bounds__(256) void k_elas_mean_h(const float* D, int W, int H, float* T) {
+  const int x = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+  if (x >= W) return;
+  const float* row = D + (size_t)v * W;
+  float out = row[x] < 0 ? -10.0f : 0.0f;
+  if (v >= 3 && v < H - 3 && x >= 4 && x <= W - 4) {
+    float slot[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int q = x - 4 + k;
+      const float a = row[q];
+      slot[q & 7] = a < 0 ? -10.0f : a;
+    }
+    const float c = row[x];
+    am_filter(slot, c < 0 ? -10.0f : c, &out);
+  }
+  T[(size_t)v * W + x] = out;
+}
+__global__ __launch_bounds__(256) void k_elas_mean_v(const float* T, int W, int H, float* D) {
+  const int u = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (u >= W) return;
+  if (!(u >= 3 && u < W - 3 && y >= 4 && y <= H - 4)) return;
+  float slot[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int q = y - 4 + k;
+    slot[q & 7] = T[(size_t)q * W + u];
+  }
+  float out;
+  if (am_filter(slot, T[(size_t)y * W + u], &out)) D[(size_t)y * W + u] = out;
+}
+
+__device__ __forceinline__ float median7(float (&a)[7]) {
+#pragma unroll
+  for (int i = 1; i < 7; ++i)
+#pragma unroll
+    for (int j = 6; j >= 1; --j)
+      if (j >= i) { const float lo = fminf(a[j - 1], a[j]), hi = fmaxf(a[j - 1], a[j]); a[j - 1] = lo; a[j] = hi; }
+  return a[3];
+}
+// horizontal median into T (zero elsewhere), vertical median of T back into D
+__global__ __launch_bounds__(256) void k_elas_median_h(const float* D, int W, int H, float* T) {
+  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+  if (u >= W) return;
+  float out = 0.0f;
+  if (u >= 3 && u < W - 3 && v >= 3 && v < H - 3) {
+    const float c = D[(size_t)v * W + u];
+    out = c;
+    if (c >= 0) {
+      float a[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) a[k] = D[(size_t)v * W + u - 3 + k];
+      out = median7(a);
+    }
+  }
+  T[(size_t)v * W + u] = out;
+}
+__global__ __launch_bounds__(256) void k_elas_median_v(const float* T, int W, int H, float* D) {
+  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+  if (u >= W) return;
+  if (!(u >= 3 && u < W - 3 && v >= 3 && v < H - 3)) return;
+  if (!(D[(size_t)v * W + u] >= 0)) return;
+  float a[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) a[k] = T[(size_t)(v - 3 + k) * W + u];
+  D[(size_t)v * W + u] = median7(a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host stages
+// ------------------------------------------------------------------------------------------------
+struct SupportPt { int32_t u, v, d; };
+
+void remove_inconsistent(std::vector<int16_t>& D, int Wc, int Hc, const svo_elas_params& p) {
+  for (int u = 0; u < Wc; ++u)
+    for (int v = 0; v < Hc; ++v) {
+      const int d = D[v * Wc + u];
+      if (d < 0) continue;
+      int support = 0;
+      for (int u2 = u - p.incon_window_size; u2 <= u + p.incon_window_size; ++u2)
+        for (int v2 = v - p.incon_window_size; v2 <= v + p.incon_window_size; ++v2)
+          if (u2 >= 0 && v2 >= 0 && u2 < Wc && v2 < Hc) {
+            const int d2 = D[v2 * Wc + u2];
+            if (d2 >= 0 && abs(d - d2) <= p.incon_threshold) ++support;
+          }
+      if (support < p.incon_min_support) D[v * Wc + u] = -1;
+    }
+}
+
+void remove_redundant(std::vector<int16_t>& D, int Wc, int Hc, int max_dist, int thr, bool vertical) {
+  const int du[2] = {vertical ? 0 : -1, vertical ? 0 : 1}, dv[2] = {vertical ? -1 : 0, vertical ? 1 : 0};
+  for (int u = 0; u < Wc; ++u)
+    for (int v = 0; v < Hc; ++v) {
+      const int d = D[v * Wc + u];
+      if (d < 0) continue;
+      bool redundant = true;
+      for (int i = 0; i < 2 && redundant; ++i) {
+        int u2 = u, v2 = v;
+        bool support = false;
+        for (int j = 0; j < max_dist; ++j) {
+          u2 += du[i]; v2 += dv[i];
+          if (u2 < 0 || v2 < 0 || u2 >= Wc || v2 >= Hc) break;
+          const int d2 = D[v2 * Wc + u2];
+          if (d2 >= 0 && abs(d - d2) <= thr) { support = true; break; }
+        }
+        if (!support) redundant = false;
+      }
+      if (redundant) D[v * Wc + u] = -1;
+    }
+}
+
+void add_corner_points(std::vector<SupportPt>& sp, int W, int H) {
+  SupportPt b[6] = {{0, 0, 0}, {0, H - 1, 0}, {W - 1, 0, 0}, {W - 1, H - 1, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (int i = 0; i < 4; ++i) {
+    int best = 10000000;
+    for (const SupportPt& s : sp) {
+      const int du = b[i].u - s.u, dv = b[i].v - s.v, dist = du * du + dv * dv;
+      if (dist < best) { best = dist; b[i].d = s.d; }
+    }
+  }
+  b[4] = {b[2].u + b[2].d, b[2].v, b[2].d};
+  b[5] = {b[3].u + b[3].d, b[3].v, b[3].d};
+  for (int i = 0; i < 6; ++i) sp.push_back(b[i]);
+}
+
+// Gauss-Jordan elimination with full pivoting on a 3x3 system (the textbook routine behind
+// Matrix::solve, matrix.cpp:414-503): pivot = LAST largest |a| among rows/columns not yet used.
+bool solve3(double A[3][3], double b[3], double eps = 1e-20) {
+  int ipiv[3] = {0, 0, 0};
+  for (int i = 0; i < 3; ++i) {
+    double big = 0.0;
+    int irow = 0, icol = 0;
+    for (int j = 0; j < 3; ++j)
+      if (ipiv[j] != 1)
+        for (int k = 0; k < 3; ++k)
+          if (ipiv[k] == 0 && fabs(A[j][k]) >= big) { big = fabs(A[j][k]); irow = j; icol = k; }
+    ++ipiv[icol];
+    if (irow != icol) {
+      for (int l = 0; l < 3; ++l) std::swap(A[irow][l], A[icol][l]);
+      std::swap(b[irow], b[icol]);
+    }
+    if (fabs(A[icol][icol]) < eps) return false;
+    const double pivinv = 1.0 / A[icol][icol];
+    A[icol][icol] = 1.0;
+    for (int l = 0; l < 3; ++l) A[icol][l] *= pivinv;
+    b[icol] *= pivinv;
+    for (int ll = 0; ll < 3; ++ll)
+      if (ll != icol) {
+        const double dum = A[ll][icol];
+        A[ll][icol] = 0.0;
+        for (int l = 0; l < 3; ++l) A[ll][l] -= A[icol][l] * dum;
+        b[ll] -= b[icol] * dum;
+      }
+  }
+  return true;
+}
+
+void disparity_planes(const std::vector<SupportPt>& sp, const std::vector<int32_t>& tri, std::vector<float>& pl) {
+  const int n = (int)tri.size() / 3;
+  pl.assign((size_t)n * 6, 0.0f);
+  for (int i = 0; i < n; ++i) {
+    const SupportPt c[3] = {sp[tri[3 * i]], sp[tri[3 * i + 1]], sp[tri[3 * i + 2]]};
+    for (int side = 0; side < 2; ++side) {
+      double A[3][3], b[3];
+      for (int k = 0; k < 3; ++k) {
+        A[k][0] = side ? c[k].u - c[k].d : c[k].u; A[k][1] = c[k].v; A[k][2] = 1;
+        b[k] = c[k].d;
+      }
+      if (solve3(A, b)) for (int k = 0; k < 3; ++k) pl[6 * i + 3 * side + k] = (float)b[k];
+    }
+  }
+}
+
+void create_grid(const std::vector<SupportPt>& sp, const svo_elas_params& p, int gw, int gh, bool right,
+                 std::vector<int32_t>& grid) {
+  const int nd = p.disp_max + 1;
+  std::vector<int32_t> t1((size_t)nd * gw * gh, 0), t2((size_t)nd * gw * gh, 0);
+  for (const SupportPt& s : sp) {
+    const int d_min = std::max(s.d - 1, 0), d_max = std::min(s.d + 1, p.disp_max);
+    for (int d = d_min; d <= d_max; ++d) {
+      int x;
+      if (!right) x = (int)floor((float)(s.u / p.grid_size));
+      else x = (int)floor((float)(s.u - s.d) / (float)p.grid_size);
+      const int y = (int)floor((float)s.v / (float)p.grid_size);
+      if (x >= 0 && x < gw && y >= 0 && y < gh) t1[(size_t)(y * gw + x) * nd + d] = 1;
+    }
+  }
+  // 3x3 diffusion over the FLAT array, as the reference's nine marching pointers do (rows wrap)
+  const size_t total = (size_t)gw * gh * nd, off_br = (size_t)(2 * gw + 2) * nd;
+  const size_t o[9] = {0, (size_t)nd, (size_t)2 * nd, (size_t)gw * nd, (size_t)(gw + 1) * nd, (size_t)(gw + 2) * nd,
+                       (size_t)2 * gw * nd, (size_t)(2 * gw + 1) * nd, off_br};
+  if (total > off_br)
+    for (size_t i = 0; i + off_br < total; ++i) {
+      int32_t r = 0;
+      for (int k = 0; k < 9; ++k) r |= t1[i + o[k]];
+      t2[i + o[4]] = r;
+    }
+  grid.assign((size_t)(p.disp_max + 2) * gw * gh, 0);
+  for (int x = 0; x < gw; ++x)
+    for (int y = 0; y < gh; ++y) {
+      int32_t* cell = &grid[(size_t)(y * gw + x) * (p.disp_max + 2)];
+      int cur = 1;
+      for (int d = 0; d <= p.disp_max; ++d)
+        if (t2[(size_t)(y * gw + x) * nd + d] > 0) cell[cur++] = d;
+      cell[0] = cur - 1;
+    }
+}
+
+template <typename T>
+int dev_alloc(svo_ctx* ctx, ElasState* st, T** p, size_t count) {
+  void* q = nullptr;
+  SVO_HIP(ctx, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+  st->allocs.push_back(q);
+  *p = reinterpret_cast<T*>(q);
+  return SVO_OK;
+}
+
+int elas_prepare(svo_ctx* ctx, ElasState* st, int W, int H, const svo_elas_params& p) {
+  int step = p.candidate_stepsize;
+  const int Wc = (W + step - 1) / step, Hc = (H + step - 1) / step;
+  const int gw = (int)ceil((float)W / (float)p.grid_size), gh = (int)ceil((float)H / (float)p.grid_size);
+  const int gd = p.disp_max + 2;
+  if (st->W == W && st->H == H && st->Wc == Wc && st->Hc == Hc && st->gw == gw && st->gh == gh && st->gd == gd)
+    return SVO_OK;
+  st->release();
+  const size_t n = (size_t)W * H;
+  st->cap_sp = Wc * Hc + 8;
+  st->cap_tri = 2 * st->cap_sp + 16;
+  int rc;
+  for (int s = 0; s < 2; ++s) {
+    if ((rc = dev_alloc(ctx, st, &st->d_img[s], n))) return rc;
+    if ((rc = dev_alloc(ctx, st, &st->d_desc[s], n))) return rc;
+    if ((rc = dev_alloc(ctx, st, &st->d_tri[s], (size_t)st->cap_tri * 3))) return rc;
+    if ((rc = dev_alloc(ctx, st, &st->d_plane[s], (size_t)st->cap_tri * 6))) return rc;
+    if ((rc = dev_alloc(ctx, st, &st->d_grid[s], (size_t)gw * gh * gd))) return rc;
+    if ((rc = dev_alloc(ctx, st, &st->d_owner[s], n))) return rc;
+    if ((rc = dev_alloc(ctx, st, &st->d_D[s], n))) return rc;
+    if ((rc = dev_alloc(ctx, st, &st->d_T[s], n))) return rc;
+  }
+  if ((rc = dev_alloc(ctx, st, &st->d_can, (size_t)Wc * Hc))) return rc;
+  if ((rc = dev_alloc(ctx, st, &st->d_sp, (size_t)st->cap_sp * 3))) return rc;
+  if ((rc = dev_alloc(ctx, st, &st->d_P, 256))) return rc;
+  if ((rc = dev_alloc(ctx, st, &st->d_lab, n))) return rc;
+  if ((rc = dev_alloc(ctx, st, &st->d_size, n))) return rc;
+  st->W = W; st->H = H; st->Wc = Wc; st->Hc = Hc; st->gw = gw; st->gh = gh; st->gd = gd;
+  return SVO_OK;
+}
+
+int tap(svo_ctx* ctx, float* dst, const float* src, size_t n) {
+  if (!dst) return SVO_OK;
+  SVO_HIP(ctx, hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVO_OK;
+}
+
+}  // namespace
+
+extern "C" void svo_elas_release(svo_ctx* ctx) {
+  if (!ctx || !ctx->elas) return;
+  ElasState* st = reinterpret_cast<ElasState*>(ctx->elas);
+  st->release();
+  delete st;
+  ctx->elas = nullptr;
+}
+
+extern "C" int svo_elas_default_params(int32_t setting, svo_elas_params* q) {
+  if (!q || (setting != 0 && setting != 1)) return SVO_E_INVALID;
+  const bool mb = setting == 1;   // elas.h:87-142
+  q->disp_min = 0; q->disp_max = 255; q->support_threshold = mb ? 0.95f : 0.85f; q->support_texture = 10;
+  q->candidate_stepsize = 5; q->incon_window_size = 5; q->incon_threshold = 5; q->incon_min_support = 5;
+  q->add_corners = mb ? 1 : 0; q->grid_size = 20; q->beta = 0.02f; q->gamma = mb ? 5.0f : 3.0f; q->sigma = 1.0f;
+  q->sradius = mb ? 3.0f : 2.0f; q->match_texture = mb ? 0 : 1; q->lr_threshold = 2;
+  q->speckle_sim_threshold = 1.0f; q->speckle_size = 200; q->ipol_gap_width = mb ? 5000 : 3;
+  q->filter_median = mb ? 1 : 0; q->filter_adaptive_mean = mb ? 0 : 1; q->postprocess_only_left = mb ? 0 : 1;
+  q->subsampling = 0;
+  return SVO_OK;
+}
+
+extern "C" int svo_elas_process_ex(svo_ctx* ctx, const uint8_t* I1, const uint8_t* I2, float* D1, float* D2,
+                                   const int32_t* dims, const svo_elas_params* params, svo_elas_taps* taps) {
+  if (!ctx) return SVO_E_INVALID;
+  if (!I1 || !I2 || !D1 || !D2 || !dims || !params) { ctx->last_error = "svo_elas_process: null argument"; return SVO_E_INVALID; }
+  const svo_elas_params p = *params;
+  const int W = dims[0], H = dims[1], pitch = dims[2];
+  if (p.subsampling || W < 16 || H < 16 || W > GAP_MAXLEN || H > GAP_MAXLEN || pitch < W || p.disp_min < 0 ||
+      p.disp_max < p.disp_min || p.disp_max > 255 || p.candidate_stepsize < 1 || p.grid_size < 1 ||
+      p.incon_window_size < 0) {
+    ctx->last_error = "svo_elas_process: unsupported parameters (subsampling, sizes, disparity range)";
+    return SVO_E_INVALID;
+  }
+  SVO_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->elas) ctx->elas = new ElasState();
+  ElasState* st = reinterpret_cast<ElasState*>(ctx->elas);
+  int rc = elas_prepare(ctx, st, W, H, p);
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  const size_t n = (size_t)W * H;
+  const int Wc = st->Wc, Hc = st->Hc;
+
+  // 1. images -> descriptors -> lattice candidates
+  SVO_HIP(ctx, hipMemcpy2DAsync(st->d_img[0], W, I1, pitch, W, H, hipMemcpyHostToDevice, s));
+  SVO_HIP(ctx, hipMemcpy2DAsync(st->d_img[1], W, I2, pitch, W, H, hipMemcpyHostToDevice, s));
+  {
+    SvoTimer t(ctx, "k_elas_desc");
+    hipLaunchKernelGGL(k_elas_desc, dim3((W + DT_X - 1) / DT_X, (H + DT_Y - 1) / DT_Y, 2), dim3(256), 0, s,
+                       st->d_img[0], st->d_img[1], W, H, st->d_desc[0], st->d_desc[1]);
+  }
+  std::vector<int16_t> can((size_t)Wc * Hc, 0);   // calloc'ed in the reference: row 0 / column 0 stay 0
+  SVO_HIP(ctx, hipMemsetAsync(st->d_can, 0, can.size() * sizeof(int16_t), s));
+  if (Wc > 1 && Hc > 1) {
+    SvoTimer t(ctx, "k_elas_support");
+    const int ncand = (Wc - 1) * (Hc - 1);
+    hipLaunchKernelGGL(k_elas_support, dim3((ncand + 3) / 4), dim3(256), 0, s, st->d_desc[0], st->d_desc[1], W, H,
+                       Wc, Hc, p, st->d_can);
+  }
+  SVO_HIP(ctx, hipMemcpyAsync(can.data(), st->d_can, can.size() * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+  SVO_HIP(ctx, hipStreamSynchronize(s));
+  if (taps) {
+    if (taps->desc1) SVO_HIP(ctx, hipMemcpy(taps->desc1, st->d_desc[0], n * 16, hipMemcpyDeviceToHost));
+    if (taps->desc2) SVO_HIP(ctx, hipMemcpy(taps->desc2, st->d_desc[1], n * 16, hipMemcpyDeviceToHost));
+  }
+
+  // 2. host: support point clean-up, triangulation, planes, grids
+  remove_inconsistent(can, Wc, Hc, p);
+  remove_redundant(can, Wc, Hc, 5, 1, true);
+  remove_redundant(can, Wc, Hc, 5, 1, false);
+  std::vector<SupportPt> sp;
+  for (int u = 1; u < Wc; ++u)
+    for (int v = 1; v < Hc; ++v)
+      if (can[v * Wc + u] >= 0) sp.push_back({u * p.candidate_stepsize, v * p.candidate_stepsize, can[v * Wc + u]});
+  if (p.add_corners) add_corner_points(sp, W, H);
+  if (taps) {
+    taps->n_support = (int32_t)sp.size();
+    if (taps->support)
+      for (int i = 0; i < std::min<int>(taps->n_support, taps->cap_support); ++i) {
+        taps->support[3 * i] = sp[i].u; taps->support[3 * i + 1] = sp[i].v; taps->support[3 * i + 2] = sp[i].d;
+      }
+  }
+  if (sp.size() < 3) return SVO_OK;   // the reference prints an error and returns with D1/D2 untouched
+  std::vector<int32_t> tri[2];
+  std::vector<float> plane[2];
+  std::vector<int32_t> grid[2];
+  for (int side = 0; side < 2; ++side) {
+    const int32_t* tin = taps ? (side ? taps->tri2_in : taps->tri1_in) : nullptr;
+    if (tin) {
+      const int nt = side ? taps->n_tri2_in : taps->n_tri1_in;
+      if (nt > st->cap_tri) { ctx->last_error = "svo_elas_process: too many triangles"; return SVO_E_INVALID; }
+      for (int i = 0; i < 3 * nt; ++i)
+        if (tin[i] < 0 || tin[i] >= (int)sp.size()) { ctx->last_error = "svo_elas_process: bad triangle index"; return SVO_E_INVALID; }
+      tri[side].assign(tin, tin + 3 * (size_t)nt);
+    } else {
+      std::vector<int32_t> xy(2 * sp.size());
+      for (size_t i = 0; i < sp.size(); ++i) { xy[2 * i] = side ? sp[i].u - sp[i].d : sp[i].u; xy[2 * i + 1] = sp[i].v; }
+      tri[side].resize((size_t)st->cap_tri * 3);
+      int32_t nt = 0;
+      rc = svo_elas_delaunay(xy.data(), (int32_t)sp.size(), tri[side].data(), st->cap_tri, &nt);
+      if (rc || nt > st->cap_tri) { ctx->last_error = "svo_elas_process: triangulation failed"; return rc ? rc : SVO_E_INVALID; }
+      tri[side].resize((size_t)nt * 3);
+    }
+    disparity_planes(sp, tri[side], plane[side]);
+    create_grid(sp, p, st->gw, st->gh, side == 1, grid[side]);
+  }
+  if (taps) {
+    taps->n_tri1 = (int32_t)tri[0].size() / 3; taps->n_tri2 = (int32_t)tri[1].size() / 3;
+    for (int side = 0; side < 2; ++side) {
+      const int nt = std::min<int>((int)tri[side].size() / 3, taps->cap_tri);
+      int32_t* ti = side ? taps->tri2 : taps->tri1;
+      float* pl = side ? taps->planes2 : taps->planes1;
+      int32_t* gr = side ? taps->grid2 : taps->grid1;
+      if (ti) memcpy(ti, tri[side].data(), (size_t)nt * 3 * sizeof(int32_t));
+      if (pl) memcpy(pl, plane[side].data(), (size_t)nt * 6 * sizeof(float));
+      if (gr) memcpy(gr, grid[side].data(), grid[side].size() * sizeof(int32_t));
+    }
+  }
+  int32_t P[256];
+  {
+    const int disp_num = p.disp_max + 1;
+    const float two_sigma_squared = 2 * p.sigma * p.sigma;
+    for (int dd = 0; dd < 256; ++dd)
+      P[dd] = dd < disp_num ? (int32_t)((-logf(p.gamma + expf(-dd * dd / two_sigma_squared)) + logf(p.gamma)) / p.beta) : 0;
+  }
+  const int plane_radius = (int)std::max((float)ceil(p.sigma * p.sradius), (float)2.0);
+
+  // 3. upload, rasterise, match
+  std::vector<int32_t> spflat(3 * sp.size());
+  for (size_t i = 0; i < sp.size(); ++i) { spflat[3 * i] = sp[i].u; spflat[3 * i + 1] = sp[i].v; spflat[3 * i + 2] = sp[i].d; }
+  SVO_HIP(ctx, hipMemcpyAsync(st->d_sp, spflat.data(), spflat.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  SVO_HIP(ctx, hipMemcpyAsync(st->d_P, P, sizeof P, hipMemcpyHostToDevice, s));
+  for (int side = 0; side < 2; ++side) {
+    if (!tri[side].empty()) {
+      SVO_HIP(ctx, hipMemcpyAsync(st->d_tri[side], tri[side].data(), tri[side].size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+      SVO_HIP(ctx, hipMemcpyAsync(st->d_plane[side], plane[side].data(), plane[side].size() * sizeof(float), hipMemcpyHostToDevice, s));
+    }
+    SVO_HIP(ctx, hipMemcpyAsync(st->d_grid[side], grid[side].data(), grid[side].size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    SVO_HIP(ctx, hipMemsetAsync(st->d_owner[side], 0xff, n * sizeof(int32_t), s));
+  }
+  const int nt0 = (int)tri[0].size() / 3, nt1 = (int)tri[1].size() / 3;
+  if (std::max(nt0, nt1) > 0) {
+    SvoTimer t(ctx, "k_elas_raster");
+    hipLaunchKernelGGL(k_elas_raster, dim3((std::max(nt0, nt1) + 3) / 4, 2), dim3(256), 0, s, st->d_sp, st->d_tri[0],
+                       st->d_tri[1], nt0, nt1, W, H, st->d_owner[0], st->d_owner[1]);
+  }
+  const dim3 pix((W + 255) / 256, H), pix2((W + 255) / 256, H, 2);
+  {
+    SvoTimer t(ctx, "k_elas_match");
+    hipLaunchKernelGGL(k_elas_match, pix2, dim3(256), 0, s, st->d_desc[0], st->d_desc[1], st->d_owner[0], st->d_owner[1],
+                       st->d_plane[0], st->d_plane[1], st->d_grid[0], st->d_grid[1], st->d_P, W, H, st->gw, st->gd,
+                       plane_radius, p, st->d_D[0], st->d_D[1]);
+  }
+  SVO_HIP(ctx, hipStreamSynchronize(s));   // host vectors above must outlive the async copies
+  if (taps) { if ((rc = tap(ctx, taps->D1_raw, st->d_D[0], n))) return rc; if ((rc = tap(ctx, taps->D2_raw, st->d_D[1], n))) return rc; }
+
+  // 4. post-processing
+  float* D[2] = {st->d_T[0], st->d_T[1]};       // current maps
+  float* T[2] = {st->d_D[0], st->d_D[1]};       // scratch
+  {
+    SvoTimer t(ctx, "k_elas_lr");
+    hipLaunchKernelGGL(k_elas_lr, pix, dim3(256), 0, s, st->d_D[0], st->d_D[1], W, H, p.lr_threshold, D[0], D[1]);
+  }
+  if (taps) { if ((rc = tap(ctx, taps->D1_lr, D[0], n))) return rc; if ((rc = tap(ctx, taps->D2_lr, D[1], n))) return rc; }
+  const int nsides = p.postprocess_only_left ? 1 : 2;
+  const int nb = (int)((n + 255) / 256);
+  for (int side = 0; side < nsides; ++side) {
+    SvoTimer t(ctx, "k_cc_segments");
+    hipLaunchKernelGGL(k_cc_init, dim3(nb), dim3(256), 0, s, D[side], (int)n, st->d_lab, st->d_size);
+    hipLaunchKernelGGL(k_cc_merge, pix, dim3(256), 0, s, D[side], W, H, p.speckle_sim_threshold, st->d_lab);
+    hipLaunchKernelGGL(k_cc_count, dim3(nb), dim3(256), 0, s, D[side], (int)n, st->d_lab, st->d_size);
+    hipLaunchKernelGGL(k_cc_apply, dim3(nb), dim3(256), 0, s, D[side], (int)n, st->d_lab, st->d_size, p.speckle_size);
+  }
+  if (taps) { if ((rc = tap(ctx, taps->D1_seg, D[0], n))) return rc; if ((rc = tap(ctx, taps->D2_seg, D[1], n))) return rc; }
+  for (int side = 0; side < nsides; ++side) {
+    SvoTimer t(ctx, "k_elas_gap");
+    hipLaunchKernelGGL(k_elas_gap, dim3(H), dim3(256), 0, s, D[side], W, 1, W, p.ipol_gap_width, p.add_corners);
+    hipLaunchKernelGGL(k_elas_gap, dim3(W), dim3(256), 0, s, D[side], H, W, 1, p.ipol_gap_width, p.add_corners);
+  }
+  if (taps) { if ((rc = tap(ctx, taps->D1_gap, D[0], n))) return rc; if ((rc = tap(ctx, taps->D2_gap, D[1], n))) return rc; }
+  if (p.filter_adaptive_mean)
+    for (int side = 0; side < nsides; ++side) {
+      SvoTimer t(ctx, "k_elas_mean");
+      hipLaunchKernelGGL(k_elas_mean_h, pix, dim3(256), 0, s, D[side], W, H, T[side]);
+      hipLaunchKernelGGL(k_elas_mean_v, pix, dim3(256), 0, s, T[side], W, H, D[side]);
+    }
+  if (taps) { if ((rc = tap(ctx, taps->D1_mean, D[0], n))) return rc; if ((rc = tap(ctx, taps->D2_mean, D[1], n))) return rc; }
+  if (p.filter_median)
+    for (int side = 0; side < nsides; ++side) {
+      SvoTimer t(ctx, "k_elas_median");
+      hipLaunchKernelGGL(k_elas_median_h, pix, dim3(256), 0, s, D[side], W, H, T[side]);
+      hipLaunchKernelGGL(k_elas_median_v, pix, dim3(256), 0, s, T[side], W, H, D[side]);
+    }
+  SVO_HIP(ctx, hipMemcpyAsync(D1, D[0], n * sizeof(float), hipMemcpyDeviceToHost, s));
+  SVO_HIP(ctx, hipMemcpyAsync(D2, D[1], n * sizeof(float), hipMemcpyDeviceToHost, s));
+  SVO_HIP(ctx, hipStreamSynchronize(s));
+  SVO_HIP(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
+extern "C" int svo_elas_process(svo_ctx* ctx, const uint8_t* I1, const uint8_t* I2, float* D1, float* D2,
+                                const int32_t* dims, const svo_elas_params* params) {
+  return svo_elas_process_ex(ctx, I1, I2, D1, D2, dims, params, nullptr);
+}

@@ -90,6 +90,7 @@ struct svo_ctx {
 
   // tracker state (svo_track.hip)
   void* d_track = nullptr;
+  void* elas = nullptr;     // ElasState (svo_elas.hip), allocated on first svo_elas_process
   svo_camera cam{};
   int track_frame = 0;
 
@@ -142,6 +143,8 @@ int svo_launch_pnp_dev(svo_ctx* ctx, const double* Xw, const double* obs, const 
 int svo_launch_disp2depth(svo_ctx* ctx, const float* disp, int count, float bf, float* depth);
 int svo_launch_unproject(svo_ctx* ctx, const float* uvz, int n, const svo_camera* cam,
                          const float* Rwc, const float* twc, float* xyz);
+
+extern "C" void svo_elas_release(svo_ctx* ctx);
 
 // profiling helper: time `fn` with HIP events on ctx->stream when profiling is on
 struct SvoTimer {

@@ -22,6 +22,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "svo_internal.h"
@@ -47,10 +49,15 @@ struct ElasState {
   float* d_T[2] = {nullptr, nullptr};
   int32_t* d_lab = nullptr;
   int32_t* d_size = nullptr;
+  uint8_t* h_img = nullptr;   // pinned staging: 2 x W*H bytes in, 2 x W*H floats out
+  float* h_D = nullptr;
   std::vector<void*> allocs;
   void release() {
     for (void* p : allocs) hipFree(p);
     allocs.clear();
+    if (h_img) hipHostFree(h_img);
+    if (h_D) hipHostFree(h_D);
+    h_img = nullptr; h_D = nullptr;
     W = H = 0;
   }
 };
@@ -285,32 +292,65 @@ __device__ void cc_union(int32_t* L, int a, int b) {
     else done = true;
   } while (!done);
 }
-__global__ void k_cc_init(const float* D, int n, int32_t* L, int32_t* size) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  L[i] = i;
-  size[i] = 0;
+// Rows first: every pixel is labelled with the first pixel of its horizontal run (a per-row scan in
+// LDS, no atomics), the run head records the run length.  Only run-to-run contacts are then united
+// vertically (the first column of each contact), and sizes are accumulated per run, not per pixel.
+#define CC_MAXLEN 4096
+__global__ __launch_bounds__(256) void k_cc_rows(const float* D, int W, float thr, int32_t* L, int32_t* rlen,
+                                                 int32_t* size) {
+  __shared__ float val[CC_MAXLEN];
+  __shared__ int16_t start[CC_MAXLEN];
+  __shared__ int cs[256];
+  const int v = blockIdx.x, tid = threadIdx.x;
+  const float* row = D + (size_t)v * W;
+  for (int i = tid; i < W; i += 256) val[i] = row[i];
+  __syncthreads();
+  const int C = (W + 255) / 256, b = tid * C, e = min(W, b + C);
+  // brk(i): pixel i starts a run (invalid pixels are runs of their own)
+  auto brk = [&](int i) { return i == 0 || !(val[i] >= 0) || !(val[i - 1] >= 0) || !(fabsf(val[i] - val[i - 1]) <= thr); };
+  int l = -1;
+  for (int i = b; i < e; ++i) if (brk(i)) l = i;
+  cs[tid] = l;
+  __syncthreads();
+  if (tid == 0) {
+    int carry = 0;
+    for (int t = 0; t < 256; ++t) { const int own = cs[t]; cs[t] = carry; if (own >= 0) carry = own; }
+  }
+  __syncthreads();
+  l = cs[tid];
+  for (int i = b; i < e; ++i) { if (brk(i)) l = i; start[i] = (int16_t)l; }
+  __syncthreads();
+  for (int i = tid; i < W; i += 256) {
+    const int st = start[i];
+    L[v * W + i] = v * W + st;
+    size[v * W + i] = 0;
+    rlen[v * W + i] = 0;
+  }
+  __syncthreads();
+  for (int i = tid; i < W; i += 256)
+    if (i == W - 1 || start[i + 1] != start[i]) rlen[v * W + start[i]] = i - start[i] + 1;
 }
 __global__ void k_cc_merge(const float* D, int W, int H, float thr, int32_t* L) {
   const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
-  if (u >= W) return;
+  if (u >= W || v + 1 >= H) return;
   const int i = v * W + u;
-  const float d = D[i];
-  if (!(d >= 0)) return;
-  if (u + 1 < W) { const float e = D[i + 1]; if (e >= 0 && fabsf(d - e) <= thr) cc_union(L, i, i + 1); }
-  if (v + 1 < H) { const float e = D[i + W]; if (e >= 0 && fabsf(d - e) <= thr) cc_union(L, i, i + W); }
+  const float d = D[i], e = D[i + W];
+  if (!(d >= 0 && e >= 0 && fabsf(d - e) <= thr)) return;
+  if (u > 0) {   // both runs continue from u-1 and already touch there: that column makes the union
+    const float d0 = D[i - 1], e0 = D[i - 1 + W];
+    if (d0 >= 0 && e0 >= 0 && fabsf(d - d0) <= thr && fabsf(e - e0) <= thr && fabsf(d0 - e0) <= thr) return;
+  }
+  cc_union(L, i, i + W);
 }
-__global__ void k_cc_count(const float* D, int n, int32_t* L, int32_t* size) {
+__global__ void k_cc_count(int n, const int32_t* L, const int32_t* rlen, int32_t* size) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const int r = cc_find(L, i);
-  L[i] = r;
-  atomicAdd(&size[r], 1);
+  if (rlen[i] > 0) atomicAdd(&size[cc_find(L, i)], rlen[i]);   // run heads only
 }
 __global__ void k_cc_apply(float* D, int n, const int32_t* L, const int32_t* size, int speckle) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  if (size[L[i]] < speckle) D[i] = -10.0f;
+  if (size[cc_find(L, i)] < speckle) D[i] = -10.0f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -460,13 +500,14 @@ void remove_inconsistent(std::vector<int16_t>& D, int Wc, int Hc, const svo_elas
     for (int v = 0; v < Hc; ++v) {
       const int d = D[v * Wc + u];
       if (d < 0) continue;
-      int support = 0;
-      for (int u2 = u - p.incon_window_size; u2 <= u + p.incon_window_size; ++u2)
-        for (int v2 = v - p.incon_window_size; v2 <= v + p.incon_window_size; ++v2)
-          if (u2 >= 0 && v2 >= 0 && u2 < Wc && v2 < Hc) {
-            const int d2 = D[v2 * Wc + u2];
-            if (d2 >= 0 && abs(d - d2) <= p.incon_threshold) ++support;
-          }
+      int support = 0;   // only compared with the threshold, so counting stops there
+      const int u_lo = std::max(u - p.incon_window_size, 0), u_hi = std::min(u + p.incon_window_size, Wc - 1);
+      const int v_lo = std::max(v - p.incon_window_size, 0), v_hi = std::min(v + p.incon_window_size, Hc - 1);
+      for (int v2 = v_lo; v2 <= v_hi && support < p.incon_min_support; ++v2)
+        for (int u2 = u_lo; u2 <= u_hi; ++u2) {
+          const int d2 = D[v2 * Wc + u2];
+          if (d2 >= 0 && abs(d - d2) <= p.incon_threshold) ++support;
+        }
       if (support < p.incon_min_support) D[v * Wc + u] = -1;
     }
 }
@@ -557,38 +598,55 @@ void disparity_planes(const std::vector<SupportPt>& sp, const std::vector<int32_
 
 void create_grid(const std::vector<SupportPt>& sp, const svo_elas_params& p, int gw, int gh, bool right,
                  std::vector<int32_t>& grid) {
-  const int nd = p.disp_max + 1;
-  std::vector<int32_t> t1((size_t)nd * gw * gh, 0), t2((size_t)nd * gw * gh, 0);
+  // per cell a 256-bit set of disparities (disp_max <= 255) instead of the reference's int per (cell, d)
+  struct Bits { uint64_t w[4]; };
+  const int ncell = gw * gh;
+  std::vector<Bits> t1(ncell, Bits{{0, 0, 0, 0}}), t2(ncell, Bits{{0, 0, 0, 0}});
   for (const SupportPt& s : sp) {
     const int d_min = std::max(s.d - 1, 0), d_max = std::min(s.d + 1, p.disp_max);
-    for (int d = d_min; d <= d_max; ++d) {
-      int x;
-      if (!right) x = (int)floor((float)(s.u / p.grid_size));
-      else x = (int)floor((float)(s.u - s.d) / (float)p.grid_size);
-      const int y = (int)floor((float)s.v / (float)p.grid_size);
-      if (x >= 0 && x < gw && y >= 0 && y < gh) t1[(size_t)(y * gw + x) * nd + d] = 1;
-    }
+    int x;
+    if (!right) x = (int)floor((float)(s.u / p.grid_size));
+    else x = (int)floor((float)(s.u - s.d) / (float)p.grid_size);
+    const int y = (int)floor((float)s.v / (float)p.grid_size);
+    if (x >= 0 && x < gw && y >= 0 && y < gh)
+      for (int d = d_min; d <= d_max; ++d) t1[y * gw + x].w[d >> 6] |= 1ull << (d & 63);
   }
-  // 3x3 diffusion over the FLAT array, as the reference's nine marching pointers do (rows wrap)
-  const size_t total = (size_t)gw * gh * nd, off_br = (size_t)(2 * gw + 2) * nd;
-  const size_t o[9] = {0, (size_t)nd, (size_t)2 * nd, (size_t)gw * nd, (size_t)(gw + 1) * nd, (size_t)(gw + 2) * nd,
-                       (size_t)2 * gw * nd, (size_t)(2 * gw + 1) * nd, off_br};
-  if (total > off_br)
-    for (size_t i = 0; i + off_br < total; ++i) {
-      int32_t r = 0;
-      for (int k = 0; k < 9; ++k) r |= t1[i + o[k]];
-      t2[i + o[4]] = r;
+  // 3x3 diffusion as the reference's nine marching pointers do it over the FLAT (cell, d) array: the
+  // offsets are whole cells, so it acts per disparity on the flat CELL index, rows wrapping, for
+  // cells c with c + 2*gw + 2 < gw*gh; the result lands on cell c + gw + 1.
+  const int o[9] = {0, 1, 2, gw, gw + 1, gw + 2, 2 * gw, 2 * gw + 1, 2 * gw + 2};
+  for (int c = 0; c + 2 * gw + 2 < ncell; ++c) {
+    Bits r{{0, 0, 0, 0}};
+    for (int k = 0; k < 9; ++k)
+      for (int q = 0; q < 4; ++q) r.w[q] |= t1[c + o[k]].w[q];
+    t2[c + gw + 1] = r;
+  }
+  const int gd = p.disp_max + 2;
+  grid.assign((size_t)gd * ncell, 0);
+  for (int c = 0; c < ncell; ++c) {
+    int32_t* cell = &grid[(size_t)c * gd];
+    int cur = 1;
+    for (int q = 0; q < 4; ++q) {
+      uint64_t m = t2[c].w[q];
+      while (m) { cell[cur++] = 64 * q + __builtin_ctzll(m); m &= m - 1; }
     }
-  grid.assign((size_t)(p.disp_max + 2) * gw * gh, 0);
-  for (int x = 0; x < gw; ++x)
-    for (int y = 0; y < gh; ++y) {
-      int32_t* cell = &grid[(size_t)(y * gw + x) * (p.disp_max + 2)];
-      int cur = 1;
-      for (int d = 0; d <= p.disp_max; ++d)
-        if (t2[(size_t)(y * gw + x) * nd + d] > 0) cell[cur++] = d;
-      cell[0] = cur - 1;
-    }
+    cell[0] = cur - 1;
+  }
 }
+
+// wall-clock profile entry for the host stages (reported next to the HIP-event kernel entries)
+struct HostTimer {
+  svo_ctx* ctx; const char* name; std::chrono::steady_clock::time_point t0;
+  HostTimer(svo_ctx* c, const char* n) : ctx(c), name(n), t0(std::chrono::steady_clock::now()) {}
+  ~HostTimer() {
+    if (!ctx->profiling) return;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (auto& e : ctx->prof)
+      if (e.name == name) { e.total_ms += ms; e.launches += 1; return; }
+    SvoProfileEntry e; e.name = name; e.total_ms = ms; e.launches = 1;
+    ctx->prof.push_back(e);
+  }
+};
 
 template <typename T>
 int dev_alloc(svo_ctx* ctx, ElasState* st, T** p, size_t count) {
@@ -626,6 +684,8 @@ int elas_prepare(svo_ctx* ctx, ElasState* st, int W, int H, const svo_elas_param
   if ((rc = dev_alloc(ctx, st, &st->d_P, 256))) return rc;
   if ((rc = dev_alloc(ctx, st, &st->d_lab, n))) return rc;
   if ((rc = dev_alloc(ctx, st, &st->d_size, n))) return rc;
+  SVO_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&st->h_img), 2 * n, hipHostMallocDefault));
+  SVO_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&st->h_D), 2 * n * sizeof(float), hipHostMallocDefault));
   st->W = W; st->H = H; st->Wc = Wc; st->Hc = Hc; st->gw = gw; st->gh = gh; st->gd = gd;
   return SVO_OK;
 }
@@ -681,9 +741,17 @@ extern "C" int svo_elas_process_ex(svo_ctx* ctx, const uint8_t* I1, const uint8_
   const size_t n = (size_t)W * H;
   const int Wc = st->Wc, Hc = st->Hc;
 
+  HostTimer total(ctx, "host_elas_total");
   // 1. images -> descriptors -> lattice candidates
-  SVO_HIP(ctx, hipMemcpy2DAsync(st->d_img[0], W, I1, pitch, W, H, hipMemcpyHostToDevice, s));
-  SVO_HIP(ctx, hipMemcpy2DAsync(st->d_img[1], W, I2, pitch, W, H, hipMemcpyHostToDevice, s));
+  {
+    HostTimer ht(ctx, "host_elas_upload");
+    for (int v = 0; v < H; ++v) {   // pageable -> pinned staging (a pageable 2-D copy costs 14 ms per image)
+      memcpy(st->h_img + (size_t)v * W, I1 + (size_t)v * pitch, W);
+      memcpy(st->h_img + n + (size_t)v * W, I2 + (size_t)v * pitch, W);
+    }
+    SVO_HIP(ctx, hipMemcpyAsync(st->d_img[0], st->h_img, n, hipMemcpyHostToDevice, s));
+    SVO_HIP(ctx, hipMemcpyAsync(st->d_img[1], st->h_img + n, n, hipMemcpyHostToDevice, s));
+  }
   {
     SvoTimer t(ctx, "k_elas_desc");
     hipLaunchKernelGGL(k_elas_desc, dim3((W + DT_X - 1) / DT_X, (H + DT_Y - 1) / DT_Y, 2), dim3(256), 0, s,
@@ -697,22 +765,28 @@ extern "C" int svo_elas_process_ex(svo_ctx* ctx, const uint8_t* I1, const uint8_
     hipLaunchKernelGGL(k_elas_support, dim3((ncand + 3) / 4), dim3(256), 0, s, st->d_desc[0], st->d_desc[1], W, H,
                        Wc, Hc, p, st->d_can);
   }
-  SVO_HIP(ctx, hipMemcpyAsync(can.data(), st->d_can, can.size() * sizeof(int16_t), hipMemcpyDeviceToHost, s));
-  SVO_HIP(ctx, hipStreamSynchronize(s));
+  {
+    HostTimer ht(ctx, "host_elas_wait_candidates");
+    SVO_HIP(ctx, hipMemcpyAsync(can.data(), st->d_can, can.size() * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+    SVO_HIP(ctx, hipStreamSynchronize(s));
+  }
   if (taps) {
     if (taps->desc1) SVO_HIP(ctx, hipMemcpy(taps->desc1, st->d_desc[0], n * 16, hipMemcpyDeviceToHost));
     if (taps->desc2) SVO_HIP(ctx, hipMemcpy(taps->desc2, st->d_desc[1], n * 16, hipMemcpyDeviceToHost));
   }
 
   // 2. host: support point clean-up, triangulation, planes, grids
-  remove_inconsistent(can, Wc, Hc, p);
-  remove_redundant(can, Wc, Hc, 5, 1, true);
-  remove_redundant(can, Wc, Hc, 5, 1, false);
   std::vector<SupportPt> sp;
-  for (int u = 1; u < Wc; ++u)
-    for (int v = 1; v < Hc; ++v)
-      if (can[v * Wc + u] >= 0) sp.push_back({u * p.candidate_stepsize, v * p.candidate_stepsize, can[v * Wc + u]});
-  if (p.add_corners) add_corner_points(sp, W, H);
+  {
+    HostTimer ht(ctx, "host_elas_support_filter");
+    remove_inconsistent(can, Wc, Hc, p);
+    remove_redundant(can, Wc, Hc, 5, 1, true);
+    remove_redundant(can, Wc, Hc, 5, 1, false);
+    for (int u = 1; u < Wc; ++u)
+      for (int v = 1; v < Hc; ++v)
+        if (can[v * Wc + u] >= 0) sp.push_back({u * p.candidate_stepsize, v * p.candidate_stepsize, can[v * Wc + u]});
+    if (p.add_corners) add_corner_points(sp, W, H);
+  }
   if (taps) {
     taps->n_support = (int32_t)sp.size();
     if (taps->support)
@@ -724,26 +798,36 @@ extern "C" int svo_elas_process_ex(svo_ctx* ctx, const uint8_t* I1, const uint8_
   std::vector<int32_t> tri[2];
   std::vector<float> plane[2];
   std::vector<int32_t> grid[2];
-  for (int side = 0; side < 2; ++side) {
+  // the two images are independent from here to the upload: the right one runs on a second host thread
+  const char* side_err[2] = {nullptr, nullptr};
+  auto do_side = [&](int side) {
     const int32_t* tin = taps ? (side ? taps->tri2_in : taps->tri1_in) : nullptr;
     if (tin) {
       const int nt = side ? taps->n_tri2_in : taps->n_tri1_in;
-      if (nt > st->cap_tri) { ctx->last_error = "svo_elas_process: too many triangles"; return SVO_E_INVALID; }
+      if (nt > st->cap_tri) { side_err[side] = "svo_elas_process: too many triangles"; return; }
       for (int i = 0; i < 3 * nt; ++i)
-        if (tin[i] < 0 || tin[i] >= (int)sp.size()) { ctx->last_error = "svo_elas_process: bad triangle index"; return SVO_E_INVALID; }
+        if (tin[i] < 0 || tin[i] >= (int)sp.size()) { side_err[side] = "svo_elas_process: bad triangle index"; return; }
       tri[side].assign(tin, tin + 3 * (size_t)nt);
     } else {
       std::vector<int32_t> xy(2 * sp.size());
       for (size_t i = 0; i < sp.size(); ++i) { xy[2 * i] = side ? sp[i].u - sp[i].d : sp[i].u; xy[2 * i + 1] = sp[i].v; }
       tri[side].resize((size_t)st->cap_tri * 3);
       int32_t nt = 0;
-      rc = svo_elas_delaunay(xy.data(), (int32_t)sp.size(), tri[side].data(), st->cap_tri, &nt);
-      if (rc || nt > st->cap_tri) { ctx->last_error = "svo_elas_process: triangulation failed"; return rc ? rc : SVO_E_INVALID; }
+      const int r = svo_elas_delaunay(xy.data(), (int32_t)sp.size(), tri[side].data(), st->cap_tri, &nt);
+      if (r || nt > st->cap_tri) { side_err[side] = "svo_elas_process: triangulation failed"; return; }
       tri[side].resize((size_t)nt * 3);
     }
     disparity_planes(sp, tri[side], plane[side]);
     create_grid(sp, p, st->gw, st->gh, side == 1, grid[side]);
+  };
+  {
+    HostTimer ht(ctx, "host_elas_delaunay_planes_grid");
+    std::thread right_side(do_side, 1);
+    do_side(0);
+    right_side.join();
   }
+  for (int side = 0; side < 2; ++side)
+    if (side_err[side]) { ctx->last_error = side_err[side]; return SVO_E_INVALID; }
   if (taps) {
     taps->n_tri1 = (int32_t)tri[0].size() / 3; taps->n_tri2 = (int32_t)tri[1].size() / 3;
     for (int side = 0; side < 2; ++side) {
@@ -766,6 +850,7 @@ extern "C" int svo_elas_process_ex(svo_ctx* ctx, const uint8_t* I1, const uint8_
   const int plane_radius = (int)std::max((float)ceil(p.sigma * p.sradius), (float)2.0);
 
   // 3. upload, rasterise, match
+  HostTimer* up2 = new HostTimer(ctx, "host_elas_upload2_match_sync");
   std::vector<int32_t> spflat(3 * sp.size());
   for (size_t i = 0; i < sp.size(); ++i) { spflat[3 * i] = sp[i].u; spflat[3 * i + 1] = sp[i].v; spflat[3 * i + 2] = sp[i].d; }
   SVO_HIP(ctx, hipMemcpyAsync(st->d_sp, spflat.data(), spflat.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
@@ -792,6 +877,7 @@ extern "C" int svo_elas_process_ex(svo_ctx* ctx, const uint8_t* I1, const uint8_
                        plane_radius, p, st->d_D[0], st->d_D[1]);
   }
   SVO_HIP(ctx, hipStreamSynchronize(s));   // host vectors above must outlive the async copies
+  delete up2;
   if (taps) { if ((rc = tap(ctx, taps->D1_raw, st->d_D[0], n))) return rc; if ((rc = tap(ctx, taps->D2_raw, st->d_D[1], n))) return rc; }
 
   // 4. post-processing
@@ -806,9 +892,10 @@ extern "C" int svo_elas_process_ex(svo_ctx* ctx, const uint8_t* I1, const uint8_
   const int nb = (int)((n + 255) / 256);
   for (int side = 0; side < nsides; ++side) {
     SvoTimer t(ctx, "k_cc_segments");
-    hipLaunchKernelGGL(k_cc_init, dim3(nb), dim3(256), 0, s, D[side], (int)n, st->d_lab, st->d_size);
+    int32_t* rlen = st->d_owner[0];   // free once k_elas_match has run
+    hipLaunchKernelGGL(k_cc_rows, dim3(H), dim3(256), 0, s, D[side], W, p.speckle_sim_threshold, st->d_lab, rlen, st->d_size);
     hipLaunchKernelGGL(k_cc_merge, pix, dim3(256), 0, s, D[side], W, H, p.speckle_sim_threshold, st->d_lab);
-    hipLaunchKernelGGL(k_cc_count, dim3(nb), dim3(256), 0, s, D[side], (int)n, st->d_lab, st->d_size);
+    hipLaunchKernelGGL(k_cc_count, dim3(nb), dim3(256), 0, s, (int)n, st->d_lab, rlen, st->d_size);
     hipLaunchKernelGGL(k_cc_apply, dim3(nb), dim3(256), 0, s, D[side], (int)n, st->d_lab, st->d_size, p.speckle_size);
   }
   if (taps) { if ((rc = tap(ctx, taps->D1_seg, D[0], n))) return rc; if ((rc = tap(ctx, taps->D2_seg, D[1], n))) return rc; }
@@ -831,9 +918,14 @@ extern "C" int svo_elas_process_ex(svo_ctx* ctx, const uint8_t* I1, const uint8_
       hipLaunchKernelGGL(k_elas_median_h, pix, dim3(256), 0, s, D[side], W, H, T[side]);
       hipLaunchKernelGGL(k_elas_median_v, pix, dim3(256), 0, s, T[side], W, H, D[side]);
     }
-  SVO_HIP(ctx, hipMemcpyAsync(D1, D[0], n * sizeof(float), hipMemcpyDeviceToHost, s));
-  SVO_HIP(ctx, hipMemcpyAsync(D2, D[1], n * sizeof(float), hipMemcpyDeviceToHost, s));
-  SVO_HIP(ctx, hipStreamSynchronize(s));
+  {
+    HostTimer ht(ctx, "host_elas_download");
+    SVO_HIP(ctx, hipMemcpyAsync(st->h_D, D[0], n * sizeof(float), hipMemcpyDeviceToHost, s));
+    SVO_HIP(ctx, hipMemcpyAsync(st->h_D + n, D[1], n * sizeof(float), hipMemcpyDeviceToHost, s));
+    SVO_HIP(ctx, hipStreamSynchronize(s));
+    memcpy(D1, st->h_D, n * sizeof(float));
+    memcpy(D2, st->h_D + n, n * sizeof(float));
+  }
   SVO_HIP(ctx, hipGetLastError());
   return SVO_OK;
 }

@@ -110,6 +110,52 @@ def cpu_baseline_all_cores(Lh, Rh, cam, budget_s=8.0):
                       % (sum(done), dt, cores)}
 
 
+def elas_leg(pkg, W, H, device, L, R, iters=20, threads=4):
+    """Dense ELAS stereo (BASELINE configs[4] without YOLO): svo_elas_process on host
+    buffers, one call at a time (latency) and from `threads` host threads with one context each
+    (throughput; the host stages - support filtering, Delaunay, planes - overlap across pairs).  Beside it
+    the reference's own compiled libelas on one host core when oracle/_ref is present."""
+    import threading
+    ctxs = [pkg.Svo(W, H, device=device) for _ in range(threads)]
+    p = pkg.elas_default_params(0)
+    for c in ctxs:
+        D1, _ = c.elas_process(L, R, p)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        ctxs[0].elas_process(L, R, p)
+    lat = (time.perf_counter() - t0) / iters
+
+    def worker(c):
+        for _ in range(iters):
+            c.elas_process(L, R, p)
+    th = [threading.Thread(target=worker, args=(c,)) for c in ctxs]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    thr = threads * iters / (time.perf_counter() - t0)
+    for c in ctxs:
+        c.close()
+    out = {"value": thr, "unit": "stereo pairs/s", "host_threads": threads, "latency_ms_per_pair": lat * 1e3,
+           "valid_fraction": float((D1 >= 0).mean()), "setting": "ROBOTICS",
+           "note": "dense disparity maps D1+D2 per pair, host buffers in/out (PCIe-inclusive)"}
+    try:
+        from oracle import binding as ob
+        if ob.ref_elas_lib() is not None:
+            pb = ob.ref_elas_params(False)
+            E1, _ = ob.ref_elas(L, R, pb)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                ob.ref_elas(L, R, pb)
+            out["cpu_baseline"] = {"value": 3 / (time.perf_counter() - t0), "unit": "stereo pairs/s", "cores": 1,
+                                   "kind": "reference", "sample": "3 calls of the reference's Elas::process on the same pair"}
+            out["pixels_differing_from_reference"] = int((E1 != D1).sum())
+    except Exception as e:  # noqa: BLE001
+        out["cpu_baseline_error"] = str(e)
+    return out
+
+
 def cpu_baseline(Lh, Rh, cam, workload, budget_s=15.0):
     """The oracle (a single-threaded C port of the same path) timed on this box's host
     cores over a bounded sample of the same workload."""
@@ -143,6 +189,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-track-leg", action="store_true")
+    ap.add_argument("--no-elas-leg", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (single-GPU dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (dry run of the N>1 path on one GPU)")
     args = ap.parse_args()
@@ -294,6 +341,8 @@ def main():
             out["track"] = {"value": nt / tdt, "unit": "stereo pairs/s", "frames": nt,
                             "ate_rmse_m_vs_ground_truth": rmse, "final_position_error_m": last,
                             "note": "one sequence, strict frame order (BASELINE configs[2]); includes the front end"}
+        if world == 1 and not track and not args.no_elas_leg:
+            out["elas"] = elas_leg(pkg, W, H, dev.index or 0, dL[0, :, :W].cpu().numpy(), dR[0, :, :W].cpu().numpy())
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

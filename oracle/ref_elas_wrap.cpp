@@ -14,9 +14,9 @@
 //                     memory pool, the product emits a canonical order, and the stages downstream
 //                     of the triangulation are compared on identical triangle lists.
 //  Uninitialised reads: libelas reads malloc'ed-but-never-written memory (descriptor rows/columns
-//  2 and N-3, elas.cpp:700 with descriptor.cpp:86; D_tmp in adaptiveMean, elas.cpp:1299).  With
-//  M_MMAP_THRESHOLD pinned below those block sizes every such block is a fresh zero page, which
-//  makes the reference deterministic ("uninitialised = 0"); the product defines it the same way.
+//  2 and N-3, elas.cpp:700 with descriptor.cpp:86; D_tmp in adaptiveMean, elas.cpp:1299).  glibc's
+//  M_PERTURB = 0xff makes malloc hand out zero-filled blocks (fresh mmap'ed blocks are zero anyway),
+//  which makes the reference deterministic ("uninitialised = 0"); the product defines it the same way.
 #include <malloc.h>
 #include <math.h>
 #include <stdint.h>
@@ -62,7 +62,7 @@ struct ref_elas_taps {
 
 static void pin_malloc() {
   static bool done = false;
-  if (!done) { mallopt(M_MMAP_THRESHOLD, 64 * 1024); done = true; }
+  if (!done) { mallopt(M_PERTURB, 0xff); done = true; }
 }
 
 static Elas::parameters to_ref(const ref_elas_params* p) {

@@ -9,14 +9,22 @@ KITTI_W, KITTI_H = 1241, 376
 
 
 def read_pgm(path):
-    with open(path, "rb") as f:
-        assert f.readline().strip() == b"P5"
-        line = f.readline()
-        while line.startswith(b"#"):
-            line = f.readline()
-        w, h = map(int, line.split())
-        int(f.readline())
-        return np.frombuffer(f.read(w * h), np.uint8).reshape(h, w).copy()
+    """Binary PGM (P5, maxval 255); header tokens may be split over lines in any way, '#' comments."""
+    data = open(path, "rb").read()
+    tok, pos = [], 0
+    while len(tok) < 4:
+        while data[pos:pos + 1].isspace():
+            pos += 1
+        if data[pos:pos + 1] == b"#":
+            pos = data.index(b"\n", pos) + 1
+            continue
+        end = pos
+        while not data[end:end + 1].isspace():
+            end += 1
+        tok.append(data[pos:end]); pos = end
+    assert tok[0] == b"P5" and int(tok[3]) == 255
+    w, h = int(tok[1]), int(tok[2])
+    return np.frombuffer(data, np.uint8, w * h, pos + 1).reshape(h, w).copy()
 
 
 def urban_pair(W=KITTI_W, H=KITTI_H, x0=50, y0=8):

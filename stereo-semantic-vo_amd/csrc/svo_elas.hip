@@ -67,7 +67,7 @@ struct ElasState {
 // ------------------------------------------------------------------------------------------------
 #define DT_X 32
 #define DT_Y 8
-__global__ __launch_bounds__(256) void k_elas_desc(const uint8_t* img0, const uint8_t* img1, int W, int H,
+__global__ __launch_bounds__(256) void k_elas_desc(const uint8_t* img0, const uint8_t* img1, int pitch, int W, int H,
                                                    uint4* desc0, uint4* desc1) {
   __shared__ uint8_t im[DT_Y + 6][DT_X + 8];
   __shared__ uint8_t du[DT_Y + 4][DT_X + 4], dv[DT_Y + 4][DT_X + 4];
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_elas_desc(const uint8_t* img0, const ui
   for (int i = tid; i < (DT_Y + 6) * (DT_X + 6); i += 256) {
     const int r = i / (DT_X + 6), c = i - r * (DT_X + 6);
     const int gy = min(max(y0 - 3 + r, 0), H - 1), gx = min(max(x0 - 3 + c, 0), W - 1);
-    im[r][c] = img[(size_t)gy * W + gx];
+    im[r][c] = img[(size_t)gy * pitch + gx];
   }
   __syncthreads();
   for (int i = tid; i < (DT_Y + 4) * (DT_X + 4); i += 256) {
@@ -342,10 +342,21 @@ __global__ void k_cc_merge(const float* D, int W, int H, float thr, int32_t* L) 
   }
   cc_union(L, i, i + W);
 }
-__global__ void k_cc_count(int n, const int32_t* L, const int32_t* rlen, int32_t* size) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  if (rlen[i] > 0) atomicAdd(&size[cc_find(L, i)], rlen[i]);   // run heads only
+__global__ __launch_bounds__(256) void k_cc_count(int n, const int32_t* L, const int32_t* rlen, int32_t* size) {
+  const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  int root = -1, len = 0;
+  if (i < n && rlen[i] > 0) { root = cc_find(L, i); len = rlen[i]; }   // run heads only
+  // neighbouring runs mostly share one root (the big surfaces): add them up per wave first, one atomic
+  // per distinct root, instead of tens of thousands of atomics on the same address
+  uint64_t active = __ballot(root >= 0);
+  while (active) {
+    const int leader = __ffsll((unsigned long long)active) - 1;
+    const int lr = __builtin_amdgcn_readlane(root, leader);
+    const bool same = root == lr;
+    const int sum = wave_sum_i32_dpp(same ? len : 0);
+    if (lane == leader) atomicAdd(&size[lr], sum);
+    active &= ~__ballot(same);
+  }
 }
 __global__ void k_cc_apply(float* D, int n, const int32_t* L, const int32_t* size, int speckle) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -720,42 +731,32 @@ extern "C" int svo_elas_default_params(int32_t setting, svo_elas_params* q) {
   return SVO_OK;
 }
 
-extern "C" int svo_elas_process_ex(svo_ctx* ctx, const uint8_t* I1, const uint8_t* I2, float* D1, float* D2,
-                                   const int32_t* dims, const svo_elas_params* params, svo_elas_taps* taps) {
-  if (!ctx) return SVO_E_INVALID;
-  if (!I1 || !I2 || !D1 || !D2 || !dims || !params) { ctx->last_error = "svo_elas_process: null argument"; return SVO_E_INVALID; }
-  const svo_elas_params p = *params;
-  const int W = dims[0], H = dims[1], pitch = dims[2];
+namespace {
+
+int elas_check(svo_ctx* ctx, int W, int H, int pitch, const svo_elas_params& p) {
   if (p.subsampling || W < 16 || H < 16 || W > GAP_MAXLEN || H > GAP_MAXLEN || pitch < W || p.disp_min < 0 ||
       p.disp_max < p.disp_min || p.disp_max > 255 || p.candidate_stepsize < 1 || p.grid_size < 1 ||
       p.incon_window_size < 0) {
     ctx->last_error = "svo_elas_process: unsupported parameters (subsampling, sizes, disparity range)";
     return SVO_E_INVALID;
   }
-  SVO_HIP(ctx, hipSetDevice(ctx->device));
-  if (!ctx->elas) ctx->elas = new ElasState();
-  ElasState* st = reinterpret_cast<ElasState*>(ctx->elas);
-  int rc = elas_prepare(ctx, st, W, H, p);
-  if (rc) return rc;
+  return SVO_OK;
+}
+
+// Everything between the images in HBM (dL, dR, `pitch` bytes per row) and the two final disparity maps
+// in HBM (*outD1, *outD2; valid until the next call).  *produced = 0 when there are fewer than 3
+// support points (the reference then leaves its outputs untouched).
+int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR, int pitch, int W, int H,
+              const svo_elas_params& p, svo_elas_taps* taps, float** outD1, float** outD2, int* produced) {
   hipStream_t s = ctx->stream;
   const size_t n = (size_t)W * H;
   const int Wc = st->Wc, Hc = st->Hc;
-
-  HostTimer total(ctx, "host_elas_total");
-  // 1. images -> descriptors -> lattice candidates
-  {
-    HostTimer ht(ctx, "host_elas_upload");
-    for (int v = 0; v < H; ++v) {   // pageable -> pinned staging (a pageable 2-D copy costs 14 ms per image)
-      memcpy(st->h_img + (size_t)v * W, I1 + (size_t)v * pitch, W);
-      memcpy(st->h_img + n + (size_t)v * W, I2 + (size_t)v * pitch, W);
-    }
-    SVO_HIP(ctx, hipMemcpyAsync(st->d_img[0], st->h_img, n, hipMemcpyHostToDevice, s));
-    SVO_HIP(ctx, hipMemcpyAsync(st->d_img[1], st->h_img + n, n, hipMemcpyHostToDevice, s));
-  }
+  int rc;
+  *produced = 0;
   {
     SvoTimer t(ctx, "k_elas_desc");
     hipLaunchKernelGGL(k_elas_desc, dim3((W + DT_X - 1) / DT_X, (H + DT_Y - 1) / DT_Y, 2), dim3(256), 0, s,
-                       st->d_img[0], st->d_img[1], W, H, st->d_desc[0], st->d_desc[1]);
+                       dL, dR, pitch, W, H, st->d_desc[0], st->d_desc[1]);
   }
   std::vector<int16_t> can((size_t)Wc * Hc, 0);   // calloc'ed in the reference: row 0 / column 0 stay 0
   SVO_HIP(ctx, hipMemsetAsync(st->d_can, 0, can.size() * sizeof(int16_t), s));
@@ -794,7 +795,7 @@ extern "C" int svo_elas_process_ex(svo_ctx* ctx, const uint8_t* I1, const uint8_
         taps->support[3 * i] = sp[i].u; taps->support[3 * i + 1] = sp[i].v; taps->support[3 * i + 2] = sp[i].d;
       }
   }
-  if (sp.size() < 3) return SVO_OK;   // the reference prints an error and returns with D1/D2 untouched
+  if (sp.size() < 3) return SVO_OK;   // *produced stays 0
   std::vector<int32_t> tri[2];
   std::vector<float> plane[2];
   std::vector<int32_t> grid[2];
@@ -918,10 +919,56 @@ extern "C" int svo_elas_process_ex(svo_ctx* ctx, const uint8_t* I1, const uint8_
       hipLaunchKernelGGL(k_elas_median_h, pix, dim3(256), 0, s, D[side], W, H, T[side]);
       hipLaunchKernelGGL(k_elas_median_v, pix, dim3(256), 0, s, T[side], W, H, D[side]);
     }
+  *outD1 = D[0]; *outD2 = D[1];
+  *produced = 1;
+  return SVO_OK;
+}
+
+}  // namespace
+
+// Device-resident entry used by the tracker (svo_track.hip): images already in HBM, maps stay in HBM.
+int svo_elas_run_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int pitch, int W, int H,
+                     const svo_elas_params* params, float** dD1, float** dD2, int* produced) {
+  int rc = elas_check(ctx, W, H, pitch, *params);
+  if (rc) return rc;
+  if (!ctx->elas) ctx->elas = new ElasState();
+  ElasState* st = reinterpret_cast<ElasState*>(ctx->elas);
+  if ((rc = elas_prepare(ctx, st, W, H, *params))) return rc;
+  return elas_core(ctx, st, dL, dR, pitch, W, H, *params, nullptr, dD1, dD2, produced);
+}
+
+extern "C" int svo_elas_process_ex(svo_ctx* ctx, const uint8_t* I1, const uint8_t* I2, float* D1, float* D2,
+                                   const int32_t* dims, const svo_elas_params* params, svo_elas_taps* taps) {
+  if (!ctx) return SVO_E_INVALID;
+  if (!I1 || !I2 || !D1 || !D2 || !dims || !params) { ctx->last_error = "svo_elas_process: null argument"; return SVO_E_INVALID; }
+  const svo_elas_params p = *params;
+  const int W = dims[0], H = dims[1], pitch = dims[2];
+  int rc = elas_check(ctx, W, H, pitch, p);
+  if (rc) return rc;
+  SVO_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->elas) ctx->elas = new ElasState();
+  ElasState* st = reinterpret_cast<ElasState*>(ctx->elas);
+  if ((rc = elas_prepare(ctx, st, W, H, p))) return rc;
+  hipStream_t s = ctx->stream;
+  const size_t n = (size_t)W * H;
+  HostTimer total(ctx, "host_elas_total");
+  {
+    HostTimer ht(ctx, "host_elas_upload");
+    for (int v = 0; v < H; ++v) {   // pageable -> pinned staging (a pageable 2-D copy costs 14 ms per image)
+      memcpy(st->h_img + (size_t)v * W, I1 + (size_t)v * pitch, W);
+      memcpy(st->h_img + n + (size_t)v * W, I2 + (size_t)v * pitch, W);
+    }
+    SVO_HIP(ctx, hipMemcpyAsync(st->d_img[0], st->h_img, n, hipMemcpyHostToDevice, s));
+    SVO_HIP(ctx, hipMemcpyAsync(st->d_img[1], st->h_img + n, n, hipMemcpyHostToDevice, s));
+  }
+  float *dD1 = nullptr, *dD2 = nullptr;
+  int produced = 0;
+  if ((rc = elas_core(ctx, st, st->d_img[0], st->d_img[1], W, W, H, p, taps, &dD1, &dD2, &produced))) return rc;
+  if (!produced) return SVO_OK;   // the reference prints an error and returns with D1/D2 untouched
   {
     HostTimer ht(ctx, "host_elas_download");
-    SVO_HIP(ctx, hipMemcpyAsync(st->h_D, D[0], n * sizeof(float), hipMemcpyDeviceToHost, s));
-    SVO_HIP(ctx, hipMemcpyAsync(st->h_D + n, D[1], n * sizeof(float), hipMemcpyDeviceToHost, s));
+    SVO_HIP(ctx, hipMemcpyAsync(st->h_D, dD1, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    SVO_HIP(ctx, hipMemcpyAsync(st->h_D + n, dD2, n * sizeof(float), hipMemcpyDeviceToHost, s));
     SVO_HIP(ctx, hipStreamSynchronize(s));
     memcpy(D1, st->h_D, n * sizeof(float));
     memcpy(D2, st->h_D + n, n * sizeof(float));

@@ -86,6 +86,7 @@ struct svo_ctx {
   uint8_t* d_scratch = nullptr;
   size_t scratch_bytes = 0;
   uint8_t* h_pinned = nullptr;
+  uint8_t* h_stage = nullptr;      // pinned image staging of the host path: 2 x H x stage_pitch
   size_t pinned_bytes = 0;
 
   // tracker state (svo_track.hip)
@@ -145,6 +146,10 @@ int svo_launch_unproject(svo_ctx* ctx, const float* uvz, int n, const svo_camera
                          const float* Rwc, const float* twc, float* xyz);
 
 extern "C" void svo_elas_release(svo_ctx* ctx);
+int svo_upload_image(svo_ctx* ctx, const uint8_t* gray, int stride, int slot);
+// dense ELAS stereo on images already in HBM; the two maps stay in HBM (valid until the next call)
+int svo_elas_run_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int pitch, int W, int H,
+                     const svo_elas_params* params, float** dD1, float** dD2, int* produced);
 
 // profiling helper: time `fn` with HIP events on ctx->stream when profiling is on
 struct SvoTimer {

@@ -630,15 +630,14 @@ extern "C" int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL,
   TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
   uint8_t* dL = ctx->d_stage;
   uint8_t* dR = ctx->d_stage + (size_t)g.H * ctx->stage_pitch;
-  SVO_HIP(ctx, hipMemcpy2DAsync(dL, ctx->stage_pitch, grayL, strideL, g.W, g.H,
-                                hipMemcpyHostToDevice, ctx->stream));
-  SVO_HIP(ctx, hipMemcpy2DAsync(dR, ctx->stage_pitch, grayR, strideR, g.W, g.H,
-                                hipMemcpyHostToDevice, ctx->stream));
+  int rc = svo_upload_image(ctx, grayL, strideL, 0);
+  if (rc) return rc;
+  if ((rc = svo_upload_image(ctx, grayR, strideR, 1))) return rc;
   const int32_t nb = n_boxes;
   SVO_HIP(ctx, hipMemcpyAsync(&st->n_boxes, &nb, 4, hipMemcpyHostToDevice, ctx->stream));
   if (n_boxes > 0)
     SVO_HIP(ctx, hipMemcpyAsync(st->boxes, boxes, 16 * (size_t)n_boxes, hipMemcpyHostToDevice, ctx->stream));
-  int rc = svo_launch_orb(ctx, dL, dR, ctx->stage_pitch, 1, 2);
+  rc = svo_launch_orb(ctx, dL, dR, ctx->stage_pitch, 1, 2);
   if (rc) return rc;
   rc = svo_launch_stereo(ctx, dL, dR, ctx->stage_pitch, 1, &ctx->cam);
   if (rc) return rc;

@@ -223,15 +223,17 @@ class Tracker:
         self.W, self.H, self.nf = W, H, nfeatures
         self.h = l.orc_track_create(W, H, nfeatures, cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["bf"])
 
-    def track(self, grayL, grayR, boxes=None):
+    def track(self, grayL, grayR, boxes=None, dense=None):
+        """dense: optional H x W float32 disparity map used as the depth source (frame::MB data flow)."""
         grayL = np.ascontiguousarray(grayL, np.uint8); grayR = np.ascontiguousarray(grayR, np.uint8)
         res = np.zeros(1, TRACK_DTYPE); cur = np.zeros(self.nf, np.int32)
         bx = None if boxes is None or len(boxes) == 0 else np.ascontiguousarray(boxes, np.int32)
+        dn = None if dense is None else np.ascontiguousarray(dense, np.float32)
         self.F = np.zeros(9)
         l = lib()
-        l.orc_track_frame_boxes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
-                                            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-        l.orc_track_frame_boxes(self.h, _p(grayL), self.W, _p(grayR), self.W, _p(bx),
+        l.orc_track_frame_dense.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                            C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.orc_track_frame_dense(self.h, _p(grayL), self.W, _p(grayR), self.W, _p(dn), _p(bx),
                                 0 if bx is None else len(bx), _p(res), _p(cur), _p(self.F))
         self.vetoes = l.orc_track_last_vetoes(C.c_void_p(self.h))
         return res[0], cur

@@ -100,6 +100,17 @@ int orc_track_frame(orc_tracker* t, const uint8_t* grayL, int strideL, const uin
 int orc_track_frame_boxes(orc_tracker* t, const uint8_t* grayL, int strideL, const uint8_t* grayR,
                           int strideR, const int32_t* boxes, int n_boxes, orc_track_result* res,
                           int32_t* cur_mp_out, double F_out[9]) {
+  return orc_track_frame_dense(t, grayL, strideL, grayR, strideR, NULL, boxes, n_boxes, res, cur_mp_out, F_out);
+}
+
+/* dense_disp != NULL: the reference's live data flow (src/Tracking.cc:226-228) - a dense W x H float
+ * disparity map (there from MSA, here from libelas) is turned into depth by frame::disp2Depth
+ * (src/frame.cc:140-164: depth = bf / disp wherever disp != 0, else -1) and read at the truncated keypoint
+ * position as `depthimg.at<float>(y, x)` does; keypoints_r = x - disp unless disp == -1 (frame.cc:122-138,
+ * without its carry-over of the previous keypoint's rx).  The right image is then not used at all. */
+int orc_track_frame_dense(orc_tracker* t, const uint8_t* grayL, int strideL, const uint8_t* grayR,
+                          int strideR, const float* dense_disp, const int32_t* boxes, int n_boxes,
+                          orc_track_result* res, int32_t* cur_mp_out, double F_out[9]) {
   const int NF = t->nfeatures;
   double F[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   t->last_vetoes = 0;
@@ -108,8 +119,17 @@ int orc_track_frame_boxes(orc_tracker* t, const uint8_t* grayL, int strideL, con
   float* uR = (float*)calloc((size_t)NF, sizeof(float));
   float* depth = (float*)calloc((size_t)NF, sizeof(float));
   int32_t nkp = 0;
-  orc_stereo_frame(grayL, strideL, grayR, strideR, t->W, t->H, NF, t->bf, t->fx, kp, desc, &nkp, uR,
-                   depth, NULL, NULL, NULL);
+  if (dense_disp) {
+    nkp = orc_orb_extract(grayL, t->W, t->H, strideL, NF, kp, desc, NULL);
+    for (int i = 0; i < nkp; ++i) {
+      const float disp = dense_disp[(size_t)(int)kp[i].y * t->W + (int)kp[i].x];
+      uR[i] = disp != -1.0f ? kp[i].x - disp : -1.0f;
+      depth[i] = disp != 0.0f ? t->bf / disp : -1.0f;
+    }
+  } else {
+    orc_stereo_frame(grayL, strideL, grayR, strideR, t->W, t->H, NF, t->bf, t->fx, kp, desc, &nkp, uR,
+                     depth, NULL, NULL, NULL);
+  }
   const int id = t->frame_num;
   int32_t cur_mp[TRK_MAXKP];
   for (int i = 0; i < TRK_MAXKP; ++i) cur_mp[i] = -1;

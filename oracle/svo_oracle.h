@@ -118,6 +118,9 @@ int orc_track_last_vetoes(const orc_tracker* t);
 int orc_track_frame(orc_tracker* t, const uint8_t* grayL, int strideL, const uint8_t* grayR,
                     int strideR, orc_track_result* res, int32_t* cur_mp_out);
 /* same, with the frame's offline detection boxes: n_boxes x {left,right,top,bottom} (main.cpp:82-95) */
+int orc_track_frame_dense(orc_tracker* t, const uint8_t* grayL, int strideL, const uint8_t* grayR,
+                          int strideR, const float* dense_disp, const int32_t* boxes, int n_boxes,
+                          orc_track_result* res, int32_t* cur_mp_out, double F_out[9]);
 int orc_track_frame_boxes(orc_tracker* t, const uint8_t* grayL, int strideL, const uint8_t* grayR,
                           int strideR, const int32_t* boxes, int n_boxes, orc_track_result* res,
                           int32_t* cur_mp_out, double F_out[9]);

@@ -271,6 +271,11 @@ extern "C" void svo_destroy(svo_ctx* ctx) {
 extern "C" int svo_set_option(svo_ctx* ctx, const char* key, int value) {
   if (!ctx || !key) return SVO_E_INVALID;
   if (!strcmp(key, "pose_mfma")) { ctx->opt_pose_mfma = value != 0; return SVO_OK; }
+  if (!strcmp(key, "depth_source")) {
+    if (value != 0 && value != 1) return SVO_E_INVALID;
+    ctx->opt_depth_source = value;
+    return SVO_OK;
+  }
   return SVO_E_INVALID;
 }
 extern "C" int svo_sync(svo_ctx* ctx) {

@@ -617,6 +617,23 @@ static int estimate_F(svo_ctx* ctx, const int32_t* boxes, int n_boxes) {
   return SVO_OK;
 }
 
+// Depth source 1 (svo_set_option "depth_source"): the reference's live data flow - a dense disparity map
+// (src/Tracking.cc:226 `MB`, here the ELAS map D1) -> frame::disp2Depth (src/frame.cc:140-164: depth =
+// bf / disp wherever disp != 0, else -1) -> `depthimg.at<float>(y, x)` at the truncated keypoint position;
+// keypoints_r = x - disp unless disp == -1 (src/frame.cc:122-138).  D == nullptr: no map, no depth.
+__global__ void k_tk_dense_depth(const svo_kp* kp, const int32_t* nkp, const float* D, int W, float bf,
+                                 float* uR, float* depth, int K) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K) return;
+  float u = -1.0f, z = -1.0f;
+  if (i < *nkp && D) {
+    const float disp = D[(size_t)(int)kp[i].y * W + (int)kp[i].x];
+    if (disp != -1.0f) u = kp[i].x - disp;
+    if (disp != 0.0f) z = bf / disp;
+  }
+  uR[i] = u; depth[i] = z;
+}
+
 extern "C" int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL,
                                const uint8_t* grayR, int strideR, double timestamp,
                                const int32_t* boxes, int n_boxes, svo_track_result* res) {
@@ -637,10 +654,20 @@ extern "C" int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL,
   SVO_HIP(ctx, hipMemcpyAsync(&st->n_boxes, &nb, 4, hipMemcpyHostToDevice, ctx->stream));
   if (n_boxes > 0)
     SVO_HIP(ctx, hipMemcpyAsync(st->boxes, boxes, 16 * (size_t)n_boxes, hipMemcpyHostToDevice, ctx->stream));
-  rc = svo_launch_orb(ctx, dL, dR, ctx->stage_pitch, 1, 2);
-  if (rc) return rc;
-  rc = svo_launch_stereo(ctx, dL, dR, ctx->stage_pitch, 1, &ctx->cam);
-  if (rc) return rc;
+  if (ctx->opt_depth_source == 1) {
+    if ((rc = svo_launch_orb(ctx, dL, dR, ctx->stage_pitch, 1, 1))) return rc;   // left image only
+    svo_elas_params ep;
+    svo_elas_default_params(0, &ep);
+    float *dD1 = nullptr, *dD2 = nullptr;
+    int produced = 0;
+    if ((rc = svo_elas_run_dev(ctx, dL, dR, ctx->stage_pitch, g.W, g.H, &ep, &dD1, &dD2, &produced))) return rc;
+    SvoTimer t(ctx, "k_tk_dense_depth");
+    hipLaunchKernelGGL(k_tk_dense_depth, dim3((ctx->max_kp + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_kp,
+                       ctx->d_nkp, produced ? dD1 : nullptr, g.W, ctx->cam.bf, ctx->d_uR, ctx->d_depth, ctx->max_kp);
+  } else {
+    if ((rc = svo_launch_orb(ctx, dL, dR, ctx->stage_pitch, 1, 2))) return rc;
+    if ((rc = svo_launch_stereo(ctx, dL, dR, ctx->stage_pitch, 1, &ctx->cam))) return rc;
+  }
   if (n_boxes > 0 && ctx->track_frame > 0) {
     rc = estimate_F(ctx, boxes, n_boxes);
     if (rc) return rc;

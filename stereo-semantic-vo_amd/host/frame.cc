@@ -87,6 +87,19 @@ int frame::MB(const GrayImage& left, const GrayImage& right) {
   return valid;
 }
 
+int frame::ElasMatch(const GrayImage& left, const GrayImage& right) {
+  svo_elas_params ep;
+  svo_elas_default_params(0, &ep);   // Elas::parameters(ROBOTICS), the library's default
+  const size_t n = (size_t)left.cols * left.rows;
+  dispimg.assign(n, -10.f);
+  std::vector<float> D2(n, -10.f);
+  const int32_t dims[3] = {left.cols, left.rows, left.cols};
+  if (svo_elas_process(ctx, left.ptr(), right.ptr(), dispimg.data(), D2.data(), dims, &ep) != SVO_OK) return 0;
+  int valid = 0;
+  for (float d : dispimg) valid += d >= 0;
+  return valid;
+}
+
 void frame::computekeypoint_r() { /* keypoints_r already holds the sub-pixel right x from MB() */ }
 void frame::disp2Depth(float) { /* kp_depth = bf / disparity was produced on the device by MB() */ }
 

@@ -5,6 +5,8 @@
 //   computekeypoint_r  -> copies uR                (src/frame.cc:122-138)
 //   disp2Depth         -> depth = bf / disparity   (src/frame.cc:140-164; per keypoint)
 //   UnprojectStereo    -> same float arithmetic    (src/frame.cc:166-180)
+//   ElasMatch          -> svo_elas_process         (src/frame.cc:93-120 dense disparity; the reference's body is
+//                         OpenCV SGBM under that name, the vendored solver it names is libelas: include/frame.h:15)
 #pragma once
 #include <set>
 #include <vector>
@@ -23,6 +25,9 @@ class frame {
   void SetPose(const svo_host::Mat44f& mTcw);
   void featuredetect(const svo_host::GrayImage& img);
   int MB(const svo_host::GrayImage& left, const svo_host::GrayImage& right);
+  // dense left-reference disparity map (float, width x height, negative = invalid) into `dispimg`;
+  // returns the number of valid pixels
+  int ElasMatch(const svo_host::GrayImage& left, const svo_host::GrayImage& right);
   void disp2Depth(float bf);
   bool UnprojectStereo(float u, float v, float z, svo_host::Vec3f& x3D) const;
   void createmappoint(std::set<mappoint*, mappoint_by_creation>& localmap);
@@ -37,6 +42,7 @@ class frame {
   std::vector<svo_kp> keypoints_l;        // cv::KeyPoint layout
   std::vector<float> keypoints_r;         // right-image x per keypoint (-1: none)
   std::vector<float> kp_disp, kp_depth;   // per-keypoint stand-ins for dispimg / depthimg
+  std::vector<float> dispimg;             // dense disparity of ElasMatch (empty until called)
   std::vector<uint8_t> f_descriptor;      // N x 32
   std::vector<mappoint*> MapPoints;
   std::vector<float> match_score;

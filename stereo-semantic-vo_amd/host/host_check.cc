@@ -32,6 +32,12 @@ int main(int argc, char** argv) {
       host = new Tracking(cam, L.cols, L.rows, 0);
       if (svo_create(&dev, 0, L.cols, L.rows, 500, 1) != SVO_OK || svo_track_reset(dev, &cam) != SVO_OK) return 3;
     }
+    if (k == 0) {   // frame::ElasMatch: dense disparity through the same context
+      frame probe;
+      probe.ctx = dev;
+      const int valid = probe.ElasMatch(L, R);
+      std::cout << "elas_valid " << valid << " of " << (size_t)L.cols * L.rows << std::endl;
+    }
     std::vector<std::vector<int>> boxes;
     std::vector<int32_t> flat;
     {

@@ -71,6 +71,8 @@ def test_host_classes_equal_device_tracker(pkg, tmp_path):
     rows = np.loadtxt(str(tmp_path / "host_kitti.txt"))
     assert rows.shape == (n, 12)
     assert abs(rows[-1, 11] - (n - 1)) < 0.5     # ~1 m per frame forward
+    ev = [ln.split() for ln in p.stdout.splitlines() if ln.startswith("elas_valid")]
+    assert ev and int(ev[0][1]) > 0.5 * int(ev[0][3])      # frame::ElasMatch: dense map mostly valid
 
 
 @pytest.mark.gpu

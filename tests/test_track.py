@@ -108,3 +108,55 @@ def test_gpu_batch_tracker_equals_frame_by_frame(pkg, sequence):
     b.close()
     for k in range(N_FRAMES):
         assert out[k].tobytes() == single[k].tobytes(), k
+
+
+# ---- depth source 1: dense ELAS map (BASELINE configs[4] without YOLO; reference data flow src/Tracking.cc:226-228) ----
+def _ref_elas_or_skip():
+    from oracle import binding as ob
+    if ob.ref_elas_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    return ob
+
+
+@pytest.fixture(scope="module")
+def oracle_run_dense(orc, pkg, sequence):
+    """Oracle tracker fed with the disparity maps of the REAL reference libelas (oracle/_ref)."""
+    ob = _ref_elas_or_skip()
+    L, R, T = sequence
+    trk = orc.Tracker(L.shape[2], L.shape[1], pkg.KITTI_00_02)
+    out = [trk.track(L[k], R[k], dense=ob.ref_elas(L[k], R[k])[0]) for k in range(N_FRAMES)]
+    trk.close()
+    return out
+
+
+def test_oracle_tracker_with_dense_reference_depth_follows_ground_truth(oracle_run_dense, sequence):
+    _, _, T = sequence
+    errs = []
+    for k, (res, cur) in enumerate(oracle_run_dense):
+        Twc = np.linalg.inv(res["Tcw"].reshape(4, 4).astype(np.float64))
+        errs.append(np.linalg.norm(Twc[:3, 3] - T[k][:3, 3]))
+        assert res["n_kp"] > 400 and res["n_stereo"] > 250
+    assert errs[0] < 1e-3 and max(errs) < 0.5   # integer-ish ELAS disparities: coarser depth than the sub-pixel sparse matcher
+
+
+@pytest.mark.gpu
+def test_gpu_tracker_with_dense_elas_depth_matches_oracle(pkg, sequence, oracle_run_dense):
+    """svo_set_option("depth_source", 1): ORB (left) + svo_elas on the device + depth lookups, against the
+    oracle tracker that reads the reference libelas' own maps."""
+    L, R, _ = sequence
+    svo = pkg.Svo(L.shape[2], L.shape[1], max_batch=1)
+    svo.set_option("depth_source", 1)
+    svo.track_reset(pkg.Camera(**pkg.KITTI_00_02))
+    for k in range(N_FRAMES):
+        res = svo.track_frame(L[k], R[k])
+        cur = svo.debug_track_matches()
+        ref, ref_cur = oracle_run_dense[k]
+        for f in ("frame_id", "n_kp", "n_stereo", "n_match_pass1", "n_match_pass2", "n_pnp_inliers",
+                  "n_lm_edges", "n_new_mappoints", "n_local_map"):
+            assert res[f] == ref[f], (k, f, res[f], ref[f])
+        assert abs(int(res["lm_iterations"]) - int(ref["lm_iterations"])) <= 1, k
+        assert np.array_equal(cur[:ref["n_kp"]], ref_cur[:ref["n_kp"]]), "frame %d match indices" % k
+        T, Tr = res["Tcw"].reshape(4, 4), ref["Tcw"].reshape(4, 4)
+        assert np.abs(T[:3, 3] - Tr[:3, 3]).max() < POSE_TOL_T, k
+        assert np.abs(T[:3, :3] - Tr[:3, :3]).max() < POSE_TOL_R, k
+    svo.close()

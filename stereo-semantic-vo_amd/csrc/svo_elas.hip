@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -851,7 +852,7 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
   const int plane_radius = (int)std::max((float)ceil(p.sigma * p.sradius), (float)2.0);
 
   // 3. upload, rasterise, match
-  HostTimer* up2 = new HostTimer(ctx, "host_elas_upload2_match_sync");
+  std::unique_ptr<HostTimer> up2(new HostTimer(ctx, "host_elas_upload2_match_sync"));
   std::vector<int32_t> spflat(3 * sp.size());
   for (size_t i = 0; i < sp.size(); ++i) { spflat[3 * i] = sp[i].u; spflat[3 * i + 1] = sp[i].v; spflat[3 * i + 2] = sp[i].d; }
   SVO_HIP(ctx, hipMemcpyAsync(st->d_sp, spflat.data(), spflat.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
@@ -878,7 +879,7 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
                        plane_radius, p, st->d_D[0], st->d_D[1]);
   }
   SVO_HIP(ctx, hipStreamSynchronize(s));   // host vectors above must outlive the async copies
-  delete up2;
+  up2.reset();
   if (taps) { if ((rc = tap(ctx, taps->D1_raw, st->d_D[0], n))) return rc; if ((rc = tap(ctx, taps->D2_raw, st->d_D[1], n))) return rc; }
 
   // 4. post-processing

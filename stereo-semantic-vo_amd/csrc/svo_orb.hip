@@ -83,25 +83,29 @@ __global__ __launch_bounds__(256) void k_pyr_level(SvoGeom g, ImgSrc s, int l, u
     }
   }
   uint8_t* dst = pyr + (size_t)img * g.pyr_bytes + g.loff[l] + (size_t)dy0 * g.pitch[l] + dx4;
+  // the two horizontal taps of output column k are adjacent bytes off, off+1 of the 8-byte window:
+  // one v_perm with a per-column selector spreads them into u16 lanes (shared by all rows), and
+  // v_dot2_u32_u16 applies the packed (a0, a1) pair
+  uint32_t sel[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sel[k] = 0x0c010c00u + (uint32_t)(sx[k] - base) * 0x00010001u;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     if (dy0 + r >= dh) break;
     const int b0 = (int)(int16_t)(bbv[r] & 0xffff), b1 = bbv[r] >> 16;
     uint32_t out = 0;
     if (wide) {
+      const uint32_t lo0 = (uint32_t)w0[r], hi0 = (uint32_t)(w0[r] >> 32);
+      const uint32_t lo1 = (uint32_t)w1[r], hi1 = (uint32_t)(w1[r] >> 32);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        // the two horizontal taps are adjacent bytes: one 64-bit shift brings them to bits 0..15,
-        // v_perm spreads them into u16 lanes and v_dot2_u32_u16 applies the packed (a0, a1) pair
-        const int sh0 = 8 * (sx[k] - base);
-        const uint32_t t0 = (uint32_t)(w0[r] >> sh0), t1 = (uint32_t)(w1[r] >> sh0);
-        const v2u16 p0 = __builtin_bit_cast(v2u16, __builtin_amdgcn_perm(0u, t0, 0x0c010c00u));
-        const v2u16 p1 = __builtin_bit_cast(v2u16, __builtin_amdgcn_perm(0u, t1, 0x0c010c00u));
+        const v2u16 p0 = __builtin_bit_cast(v2u16, __builtin_amdgcn_perm(hi0, lo0, sel[k]));
+        const v2u16 p1 = __builtin_bit_cast(v2u16, __builtin_amdgcn_perm(hi1, lo1, sel[k]));
         const v2u16 al2 = __builtin_bit_cast(v2u16, (uint32_t)al[k]);
         const int S0 = (int)__builtin_amdgcn_udot2(p0, al2, 0u, false);
         const int S1 = (int)__builtin_amdgcn_udot2(p1, al2, 0u, false);
-        int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
-        v = min(max(v, 0), 255);
+        // weights are non-negative and sum to 2048 in both directions: the result cannot leave 0..255
+        const int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
         out |= (uint32_t)v << (8 * k);
       }
     } else {

@@ -55,6 +55,23 @@ def pmc_traffic(kernel):
         return None
 
 
+def pmc_valu(kernel):
+    """Integer-VALU view of the same PMC summary (the front-end kernels are VALU-bound):
+    instructions per wave and the fraction of SIMD issue time spent on VALU instructions
+    (SQ_ACTIVE_INST_VALU counts quad-cycles, 4 per issued wave64 instruction; GRBM_GUI_ACTIVE is summed
+    over the 8 XCDs; 1024 SIMDs)."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        d = json.load(open(path))[kernel]
+        cycles = d["GRBM_GUI_ACTIVE"] / 8.0
+        return {"instr_per_wave": d["SQ_INSTS_VALU"] / d["SQ_WAVES"],
+                "busy_frac": d["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cycles),
+                "lds_bank_conflict_frac": d["SQ_LDS_BANK_CONFLICT"] / max(d["SQ_LDS_IDX_ACTIVE"], 1.0),
+                "source": "profiles/pmc_latest.json"}
+    except Exception:
+        return None
+
+
 def render_frames(synth, n, dev, seed, start=0):
     """n consecutive frames resident on `dev`, padded to PITCH; + ground truth.  synth-kitti by
     default; real KITTI 00 frames when KITTI_ROOT is set (layout of the reference's main.cpp:20-57)."""
@@ -307,6 +324,7 @@ def main():
                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                "traffic": pmc_traffic(dom) if (B == 128 and not track) else None,
                                "algorithmic_bytes_per_launch": algo,
+                               "valu": pmc_valu(dom) if (B == 128 and not track) else None,
                                "pipeline_frac": ALGO_BYTES_PER_PAIR * (pairs / dt / world) / 1e9 / HBM_PEAK_GBS}
             out["kernels"] = kern
         if world == 1 and not args.no_cpu_baseline:

@@ -289,7 +289,7 @@ typedef struct svo_elas_params {
   int32_t match_texture, lr_threshold;
   float speckle_sim_threshold;
   int32_t speckle_size, ipol_gap_width, filter_median, filter_adaptive_mean, postprocess_only_left;
-  int32_t subsampling;              /* must be 0: half-resolution mode is not implemented */
+  int32_t subsampling;              /* 1: every second pixel only; D1/D2 are then (width/2) x (height/2) */
 } svo_elas_params;
 
 /* Optional taps of every intermediate (any pointer may be NULL) and optional override of the two
@@ -312,8 +312,8 @@ int svo_elas_default_params(int32_t setting, svo_elas_params* params);
 
 /* `Elas::process(I1, I2, D1, D2, dims)` (elas.h:162, elas.cpp:32-150): dims = {width, height, bytes per
  * line}; D1/D2 are width*height floats (left / right reference), negative = invalid.  Host buffers in,
- * host buffers out.  Returns SVO_E_INVALID for subsampling != 0; with fewer than 3 support points it
- * returns SVO_OK and leaves D1/D2 untouched, as the reference does (elas.cpp:70-75). */
+ * host buffers out (with subsampling = 1 the maps are (width/2) x (height/2), elas.h:157-160).  With fewer
+ * than 3 support points it returns SVO_OK and leaves D1/D2 untouched, as the reference does (elas.cpp:70-75). */
 int svo_elas_process(svo_ctx* ctx, const uint8_t* I1, const uint8_t* I2, float* D1, float* D2,
                      const int32_t* dims, const svo_elas_params* params);
 int svo_elas_process_ex(svo_ctx* ctx, const uint8_t* I1, const uint8_t* I2, float* D1, float* D2,

@@ -315,7 +315,8 @@ def ref_elas(grayL, grayR, params=None):
     params = params or ref_elas_params()
     gl = np.ascontiguousarray(grayL, np.uint8); gr = np.ascontiguousarray(grayR, np.uint8)
     H, W = gl.shape
-    D1 = np.zeros((H, W), np.float32); D2 = np.zeros((H, W), np.float32)
+    Hd, Wd = (H // 2, W // 2) if params.subsampling else (H, W)
+    D1 = np.zeros((Hd, Wd), np.float32); D2 = np.zeros((Hd, Wd), np.float32)
     L.ref_elas_process(_p(gl), _p(gr), W, H, W, C.byref(params), _p(D1), _p(D2))
     return D1, D2
 
@@ -334,8 +335,9 @@ def ref_elas_staged(grayL, grayR, params=None, tri1=None, tri2=None, cap_support
              planes1=np.zeros((cap_tri, 6), np.float32), planes2=np.zeros((cap_tri, 6), np.float32),
              grid1=np.zeros((gh, gw, params.disp_max + 2), np.int32),
              grid2=np.zeros((gh, gw, params.disp_max + 2), np.int32))
+    Hd, Wd = (H // 2, W // 2) if params.subsampling else (H, W)
     for k in ("raw", "lr", "seg", "gap", "mean"):
-        o["D1_" + k] = np.zeros((H, W), np.float32); o["D2_" + k] = np.zeros((H, W), np.float32)
+        o["D1_" + k] = np.zeros((Hd, Wd), np.float32); o["D2_" + k] = np.zeros((Hd, Wd), np.float32)
     t = _ElasTaps()
     for k, a in o.items():
         setattr(t, k, a.ctypes.data)
@@ -345,7 +347,7 @@ def ref_elas_staged(grayL, grayR, params=None, tri1=None, tri2=None, cap_support
         if tri is not None:
             a = np.ascontiguousarray(tri, np.int32); keep.append(a)
             setattr(t, name, a.ctypes.data); setattr(t, "n_" + name, len(a))
-    D1 = np.zeros((H, W), np.float32); D2 = np.zeros((H, W), np.float32)
+    D1 = np.zeros((Hd, Wd), np.float32); D2 = np.zeros((Hd, Wd), np.float32)
     rc = L.ref_elas_staged(_p(gl), _p(gr), W, H, W, C.byref(params), C.byref(t), _p(D1), _p(D2))
     assert t.n_support <= cap_support and t.n_tri1 <= cap_tri and t.n_tri2 <= cap_tri
     o["support"] = o["support"][:t.n_support].copy()

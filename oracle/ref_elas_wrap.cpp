@@ -113,6 +113,7 @@ int ref_elas_staged(const uint8_t* left, const uint8_t* right, int width, int he
   const Elas::parameters& param = e.param;
   e.width = width; e.height = height; e.bpl = width + 15 - (width - 1) % 16;
   const size_t n = (size_t)width * height;
+  const size_t nd = p->subsampling ? (size_t)(width / 2) * (height / 2) : n;   // disparity map size
   e.I1 = (uint8_t*)_mm_malloc((size_t)e.bpl * height, 16);
   e.I2 = (uint8_t*)_mm_malloc((size_t)e.bpl * height, 16);
   memset(e.I1, 0, (size_t)e.bpl * height); memset(e.I2, 0, (size_t)e.bpl * height);
@@ -165,20 +166,20 @@ int ref_elas_staged(const uint8_t* left, const uint8_t* right, int width, int he
       if (t->grid2) memcpy(t->grid2, g2, gn * sizeof(int32_t));
       e.computeDisparity(sp, tri1, g1, grid_dims, desc1.I_desc, desc2.I_desc, 0, D1);
       e.computeDisparity(sp, tri2, g2, grid_dims, desc1.I_desc, desc2.I_desc, 1, D2);
-      snap(t->D1_raw, D1, n); snap(t->D2_raw, D2, n);
+      snap(t->D1_raw, D1, nd); snap(t->D2_raw, D2, nd);
       e.leftRightConsistencyCheck(D1, D2);
-      snap(t->D1_lr, D1, n); snap(t->D2_lr, D2, n);
+      snap(t->D1_lr, D1, nd); snap(t->D2_lr, D2, nd);
       e.removeSmallSegments(D1);
       if (!param.postprocess_only_left) e.removeSmallSegments(D2);
-      snap(t->D1_seg, D1, n); snap(t->D2_seg, D2, n);
+      snap(t->D1_seg, D1, nd); snap(t->D2_seg, D2, nd);
       e.gapInterpolation(D1);
       if (!param.postprocess_only_left) e.gapInterpolation(D2);
-      snap(t->D1_gap, D1, n); snap(t->D2_gap, D2, n);
+      snap(t->D1_gap, D1, nd); snap(t->D2_gap, D2, nd);
       if (param.filter_adaptive_mean) {
         e.adaptiveMean(D1);
         if (!param.postprocess_only_left) e.adaptiveMean(D2);
       }
-      snap(t->D1_mean, D1, n); snap(t->D2_mean, D2, n);
+      snap(t->D1_mean, D1, nd); snap(t->D2_mean, D2, nd);
       if (param.filter_median) {
         e.median(D1);
         if (!param.postprocess_only_left) e.median(D2);

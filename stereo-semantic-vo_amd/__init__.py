@@ -337,7 +337,8 @@ class Svo:
         H, W = gl.shape
         params = params or elas_default_params(0)
         dims = (C.c_int32 * 3)(W, H, W)
-        D1 = np.zeros((H, W), np.float32); D2 = np.zeros((H, W), np.float32)
+        Hd, Wd = (H // 2, W // 2) if params.subsampling else (H, W)
+        D1 = np.zeros((Hd, Wd), np.float32); D2 = np.zeros((Hd, Wd), np.float32)
         if not taps and tri1 is None and tri2 is None:
             self._chk(self.lib.svo_elas_process(self.h, _p(gl), _p(gr), _p(D1), _p(D2), dims, C.byref(params)))
             return D1, D2
@@ -351,7 +352,7 @@ class Svo:
                  grid1=np.zeros((gh, gw, params.disp_max + 2), np.int32),
                  grid2=np.zeros((gh, gw, params.disp_max + 2), np.int32))
         for k in ("raw", "lr", "seg", "gap", "mean"):
-            o["D1_" + k] = np.zeros((H, W), np.float32); o["D2_" + k] = np.zeros((H, W), np.float32)
+            o["D1_" + k] = np.zeros((Hd, Wd), np.float32); o["D2_" + k] = np.zeros((Hd, Wd), np.float32)
         t = ElasTaps()
         for k, a in o.items():
             setattr(t, k, a.ctypes.data)

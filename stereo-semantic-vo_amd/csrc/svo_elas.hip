@@ -69,7 +69,7 @@ struct ElasState {
 #define DT_X 32
 #define DT_Y 8
 __global__ __launch_bounds__(256) void k_elas_desc(const uint8_t* img0, const uint8_t* img1, int pitch, int W, int H,
-                                                   uint4* desc0, uint4* desc1) {
+                                                   int half, uint4* desc0, uint4* desc1) {
   __shared__ uint8_t im[DT_Y + 6][DT_X + 8];
   __shared__ uint8_t du[DT_Y + 4][DT_X + 4], dv[DT_Y + 4][DT_X + 4];
   const uint8_t* img = blockIdx.z ? img1 : img0;
@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void k_elas_desc(const uint8_t* img0, const ui
   const int u = x0 + tx, v = y0 + ty;
   if (u >= W || v >= H) return;
   uint4 o = make_uint4(0, 0, 0, 0);
-  if (u >= 3 && u < W - 3 && v >= 3 && v < H - 3) {
+  // half resolution (descriptor.cpp:44-72): only the even rows 4, 6, ... are built
+  if (u >= 3 && u < W - 3 && v >= 3 && v < H - 3 && (!half || (v >= 4 && (v & 1) == 0))) {
     const int j = tx + 2, i = ty + 2;   // (v, u) in du/dv indices
     o.x = du[i - 2][j] | (du[i - 1][j - 2] << 8) | (du[i - 1][j] << 16) | ((uint32_t)du[i - 1][j + 2] << 24);
     o.y = du[i][j - 1] | (du[i][j] << 8) | (du[i][j] << 16) | ((uint32_t)du[i][j + 1] << 24);
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void k_elas_support(const uint4* desc1, const 
 // reference's sequential overwrite leaves); k_elas_match then runs findMatch once per pixel.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_elas_raster(const int32_t* sp, const int32_t* tri0, const int32_t* tri1,
-                                                     int n0, int n1, int W, int H, int32_t* own0, int32_t* own1) {
+                                                     int n0, int n1, int W, int H, int sub, int32_t* own0, int32_t* own1) {
   const bool right = blockIdx.y != 0;
   const int32_t* tri = right ? tri1 : tri0;
   int32_t* owner = right ? own1 : own0;
@@ -198,9 +199,13 @@ __global__ __launch_bounds__(256) void k_elas_raster(const int32_t* sp, const in
     const float m_a = part ? BC_a : AB_a, m_b = part ? BC_b : AB_b;
     if ((int)s_u == (int)e_u) continue;
     for (int u = max((int)s_u, 0) + lane; u < min((int)e_u, W); u += 64) {
+      if (sub && (u & 1)) continue;
       const int v_1 = (int)(AC_a * (float)u + AC_b);
       const int v_2 = (int)(m_a * (float)u + m_b);
-      for (int v = max(min(v_1, v_2), 0); v < min(max(v_1, v_2), H); ++v) atomicMax(&owner[v * W + u], t);
+      for (int v = max(min(v_1, v_2), 0); v < min(max(v_1, v_2), H); ++v) {
+        if (!sub) atomicMax(&owner[v * W + u], t);
+        else if (!(v & 1) && (v >> 1) < H / 2 && (u >> 1) < W / 2) atomicMax(&owner[(v >> 1) * (W / 2) + (u >> 1)], t);
+      }
     }
   }
 }
@@ -211,9 +216,11 @@ __global__ __launch_bounds__(256) void k_elas_match(const uint4* desc1, const ui
                                                     int W, int H, int gw, int gd, int plane_radius,
                                                     svo_elas_params p, float* D0, float* D1) {
   const bool right = blockIdx.z != 0;
-  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
-  if (u >= W) return;
-  const int addr = v * W + u;
+  const int sub = p.subsampling, Wd = sub ? W / 2 : W;
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= Wd) return;
+  const int u = sub ? 2 * x : x, v = sub ? 2 * y : y;   // subsampling: every second pixel (elas.cpp:846-871)
+  const int addr = y * Wd + x;
   float* D = right ? D1 : D0;
   const int t = (right ? own1 : own0)[addr];
   float out = -10.0f;
@@ -257,12 +264,12 @@ __global__ __launch_bounds__(256) void k_elas_match(const uint4* desc1, const ui
 }
 
 __global__ __launch_bounds__(256) void k_elas_lr(const float* D1, const float* D2, int W, int H, int lr_threshold,
-                                                 float* O1, float* O2) {
+                                                 int sub, float* O1, float* O2) {
   const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
   if (u >= W) return;
   const int addr = v * W + u;
   const float d1 = D1[addr], d2 = D2[addr];
-  const float uw1 = (float)u - d1, uw2 = (float)u + d2;
+  const float uw1 = sub ? (float)u - d1 / 2 : (float)u - d1, uw2 = sub ? (float)u + d2 / 2 : (float)u + d2;
   float o1 = d1, o2 = d2;
   if (d1 >= 0 && uw1 >= 0 && uw1 < (float)W) {
     if (fabsf(D2[v * W + (int)uw1] - d1) > (float)lr_threshold) o1 = -10.0f;
@@ -433,13 +440,39 @@ __device__ __forceinline__ bool am_filter(const float (&slot)[8], float cur, flo
   }
   return false;
 }
+// subsampled maps use a 4-tap window (elas.cpp:1322-1385): pixel q in slot q % 4, slots summed 0..3,
+// window x-2 .. x+1 around the output pixel x
+__device__ __forceinline__ bool am_filter4(const float (&slot)[4], float cur, float* out) {
+  float w[4], f[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { w[i] = am_weight(slot[i], cur); f[i] = slot[i] * w[i]; }
+  const float ws = ((w[0] + w[1]) + w[2]) + w[3];
+  const float fs = ((f[0] + f[1]) + f[2]) + f[3];
+  if (ws > 0) {
+    const float d = fs / ws;
+    if (d >= 0) { *out = d; return true; }
+  }
+  return false;
+}
 // horizontal: T = filtered copy of D (invalid -> -10, not written -> 0)
-__global__ __launch_bounds__(256) void k_elas_mean_h(const float* D, int W, int H, float* T) {
+__global__ __launch_bounds__(256) void k_elas_mean_h(const float* D, int W, int H, int half, float* T) {
   const int x = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
   if (x >= W) return;
   const float* row = D + (size_t)v * W;
   float out = row[x] < 0 ? -10.0f : 0.0f;
-  if (v >= 3 && v < H - 3 && x >= 4 && x <= W - 4) {
+  if (half) {
+    if (v >= 3 && v < H - 3 && x >= 2 && x <= W - 2) {
+      float slot[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int q = x - 2 + k;
+        const float a = row[q];
+        slot[q & 3] = a < 0 ? -10.0f : a;
+      }
+      const float c = row[x];
+      am_filter4(slot, c < 0 ? -10.0f : c, &out);
+    }
+  } else if (v >= 3 && v < H - 3 && x >= 4 && x <= W - 4) {
     float slot[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -452,9 +485,21 @@ __global__ __launch_bounds__(256) void k_elas_mean_h(const float* D, int W, int 
   }
   T[(size_t)v * W + x] = out;
 }
-__global__ __launch_bounds__(256) void k_elas_mean_v(const float* T, int W, int H, float* D) {
+__global__ __launch_bounds__(256) void k_elas_mean_v(const float* T, int W, int H, int half, float* D) {
   const int u = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
   if (u >= W) return;
+  if (half) {
+    if (!(u >= 3 && u < W - 3 && y >= 2 && y <= H - 2)) return;
+    float slot[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int q = y - 2 + k;
+      slot[q & 3] = T[(size_t)q * W + u];
+    }
+    float out;
+    if (am_filter4(slot, T[(size_t)y * W + u], &out)) D[(size_t)y * W + u] = out;
+    return;
+  }
   if (!(u >= 3 && u < W - 3 && y >= 4 && y <= H - 4)) return;
   float slot[8];
 #pragma unroll
@@ -671,6 +716,7 @@ int dev_alloc(svo_ctx* ctx, ElasState* st, T** p, size_t count) {
 
 int elas_prepare(svo_ctx* ctx, ElasState* st, int W, int H, const svo_elas_params& p) {
   int step = p.candidate_stepsize;
+  if (p.subsampling) step += step % 2;   // elas.cpp:379-381: at half resolution only every second line exists
   const int Wc = (W + step - 1) / step, Hc = (H + step - 1) / step;
   const int gw = (int)ceil((float)W / (float)p.grid_size), gh = (int)ceil((float)H / (float)p.grid_size);
   const int gd = p.disp_max + 2;
@@ -735,10 +781,10 @@ extern "C" int svo_elas_default_params(int32_t setting, svo_elas_params* q) {
 namespace {
 
 int elas_check(svo_ctx* ctx, int W, int H, int pitch, const svo_elas_params& p) {
-  if (p.subsampling || W < 16 || H < 16 || W > GAP_MAXLEN || H > GAP_MAXLEN || pitch < W || p.disp_min < 0 ||
+  if ((p.subsampling != 0 && p.subsampling != 1) || W < 16 || H < 16 || W > GAP_MAXLEN || H > GAP_MAXLEN || pitch < W || p.disp_min < 0 ||
       p.disp_max < p.disp_min || p.disp_max > 255 || p.candidate_stepsize < 1 || p.grid_size < 1 ||
       p.incon_window_size < 0) {
-    ctx->last_error = "svo_elas_process: unsupported parameters (subsampling, sizes, disparity range)";
+    ctx->last_error = "svo_elas_process: unsupported parameters (sizes, disparity range)";
     return SVO_E_INVALID;
   }
   return SVO_OK;
@@ -750,14 +796,19 @@ int elas_check(svo_ctx* ctx, int W, int H, int pitch, const svo_elas_params& p) 
 int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR, int pitch, int W, int H,
               const svo_elas_params& p, svo_elas_taps* taps, float** outD1, float** outD2, int* produced) {
   hipStream_t s = ctx->stream;
-  const size_t n = (size_t)W * H;
+  const int sub = p.subsampling;
+  const int Wd = sub ? W / 2 : W, Hd = sub ? H / 2 : H;   // disparity map size (elas.h:157-160)
+  const size_t n = (size_t)Wd * Hd;
   const int Wc = st->Wc, Hc = st->Hc;
+  const int step = p.candidate_stepsize + (sub ? p.candidate_stepsize % 2 : 0);
+  svo_elas_params pk = p;   // what the kernels see: the lattice step already adjusted
+  pk.candidate_stepsize = step;
   int rc;
   *produced = 0;
   {
     SvoTimer t(ctx, "k_elas_desc");
     hipLaunchKernelGGL(k_elas_desc, dim3((W + DT_X - 1) / DT_X, (H + DT_Y - 1) / DT_Y, 2), dim3(256), 0, s,
-                       dL, dR, pitch, W, H, st->d_desc[0], st->d_desc[1]);
+                       dL, dR, pitch, W, H, p.subsampling, st->d_desc[0], st->d_desc[1]);
   }
   std::vector<int16_t> can((size_t)Wc * Hc, 0);   // calloc'ed in the reference: row 0 / column 0 stay 0
   SVO_HIP(ctx, hipMemsetAsync(st->d_can, 0, can.size() * sizeof(int16_t), s));
@@ -765,7 +816,7 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
     SvoTimer t(ctx, "k_elas_support");
     const int ncand = (Wc - 1) * (Hc - 1);
     hipLaunchKernelGGL(k_elas_support, dim3((ncand + 3) / 4), dim3(256), 0, s, st->d_desc[0], st->d_desc[1], W, H,
-                       Wc, Hc, p, st->d_can);
+                       Wc, Hc, pk, st->d_can);
   }
   {
     HostTimer ht(ctx, "host_elas_wait_candidates");
@@ -773,8 +824,8 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
     SVO_HIP(ctx, hipStreamSynchronize(s));
   }
   if (taps) {
-    if (taps->desc1) SVO_HIP(ctx, hipMemcpy(taps->desc1, st->d_desc[0], n * 16, hipMemcpyDeviceToHost));
-    if (taps->desc2) SVO_HIP(ctx, hipMemcpy(taps->desc2, st->d_desc[1], n * 16, hipMemcpyDeviceToHost));
+    if (taps->desc1) SVO_HIP(ctx, hipMemcpy(taps->desc1, st->d_desc[0], (size_t)W * H * 16, hipMemcpyDeviceToHost));
+    if (taps->desc2) SVO_HIP(ctx, hipMemcpy(taps->desc2, st->d_desc[1], (size_t)W * H * 16, hipMemcpyDeviceToHost));
   }
 
   // 2. host: support point clean-up, triangulation, planes, grids
@@ -786,7 +837,7 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
     remove_redundant(can, Wc, Hc, 5, 1, false);
     for (int u = 1; u < Wc; ++u)
       for (int v = 1; v < Hc; ++v)
-        if (can[v * Wc + u] >= 0) sp.push_back({u * p.candidate_stepsize, v * p.candidate_stepsize, can[v * Wc + u]});
+        if (can[v * Wc + u] >= 0) sp.push_back({u * step, v * step, can[v * Wc + u]});
     if (p.add_corners) add_corner_points(sp, W, H);
   }
   if (taps) {
@@ -869,9 +920,9 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
   if (std::max(nt0, nt1) > 0) {
     SvoTimer t(ctx, "k_elas_raster");
     hipLaunchKernelGGL(k_elas_raster, dim3((std::max(nt0, nt1) + 3) / 4, 2), dim3(256), 0, s, st->d_sp, st->d_tri[0],
-                       st->d_tri[1], nt0, nt1, W, H, st->d_owner[0], st->d_owner[1]);
+                       st->d_tri[1], nt0, nt1, W, H, sub, st->d_owner[0], st->d_owner[1]);
   }
-  const dim3 pix((W + 255) / 256, H), pix2((W + 255) / 256, H, 2);
+  const dim3 pix((Wd + 255) / 256, Hd), pix2((Wd + 255) / 256, Hd, 2);
   {
     SvoTimer t(ctx, "k_elas_match");
     hipLaunchKernelGGL(k_elas_match, pix2, dim3(256), 0, s, st->d_desc[0], st->d_desc[1], st->d_owner[0], st->d_owner[1],
@@ -887,38 +938,41 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
   float* T[2] = {st->d_D[0], st->d_D[1]};       // scratch
   {
     SvoTimer t(ctx, "k_elas_lr");
-    hipLaunchKernelGGL(k_elas_lr, pix, dim3(256), 0, s, st->d_D[0], st->d_D[1], W, H, p.lr_threshold, D[0], D[1]);
+    hipLaunchKernelGGL(k_elas_lr, pix, dim3(256), 0, s, st->d_D[0], st->d_D[1], Wd, Hd, p.lr_threshold, sub, D[0], D[1]);
   }
   if (taps) { if ((rc = tap(ctx, taps->D1_lr, D[0], n))) return rc; if ((rc = tap(ctx, taps->D2_lr, D[1], n))) return rc; }
   const int nsides = p.postprocess_only_left ? 1 : 2;
+  // elas.cpp:986-991, 1107-1111: thresholds of the half-resolution maps
+  const int speckle_size = sub ? (int)(sqrtf((float)p.speckle_size) * 2) : p.speckle_size;
+  const int gap_width = sub ? p.ipol_gap_width / 2 + 1 : p.ipol_gap_width;
   const int nb = (int)((n + 255) / 256);
   for (int side = 0; side < nsides; ++side) {
     SvoTimer t(ctx, "k_cc_segments");
     int32_t* rlen = st->d_owner[0];   // free once k_elas_match has run
-    hipLaunchKernelGGL(k_cc_rows, dim3(H), dim3(256), 0, s, D[side], W, p.speckle_sim_threshold, st->d_lab, rlen, st->d_size);
-    hipLaunchKernelGGL(k_cc_merge, pix, dim3(256), 0, s, D[side], W, H, p.speckle_sim_threshold, st->d_lab);
+    hipLaunchKernelGGL(k_cc_rows, dim3(Hd), dim3(256), 0, s, D[side], Wd, p.speckle_sim_threshold, st->d_lab, rlen, st->d_size);
+    hipLaunchKernelGGL(k_cc_merge, pix, dim3(256), 0, s, D[side], Wd, Hd, p.speckle_sim_threshold, st->d_lab);
     hipLaunchKernelGGL(k_cc_count, dim3(nb), dim3(256), 0, s, (int)n, st->d_lab, rlen, st->d_size);
-    hipLaunchKernelGGL(k_cc_apply, dim3(nb), dim3(256), 0, s, D[side], (int)n, st->d_lab, st->d_size, p.speckle_size);
+    hipLaunchKernelGGL(k_cc_apply, dim3(nb), dim3(256), 0, s, D[side], (int)n, st->d_lab, st->d_size, speckle_size);
   }
   if (taps) { if ((rc = tap(ctx, taps->D1_seg, D[0], n))) return rc; if ((rc = tap(ctx, taps->D2_seg, D[1], n))) return rc; }
   for (int side = 0; side < nsides; ++side) {
     SvoTimer t(ctx, "k_elas_gap");
-    hipLaunchKernelGGL(k_elas_gap, dim3(H), dim3(256), 0, s, D[side], W, 1, W, p.ipol_gap_width, p.add_corners);
-    hipLaunchKernelGGL(k_elas_gap, dim3(W), dim3(256), 0, s, D[side], H, W, 1, p.ipol_gap_width, p.add_corners);
+    hipLaunchKernelGGL(k_elas_gap, dim3(Hd), dim3(256), 0, s, D[side], Wd, 1, Wd, gap_width, p.add_corners);
+    hipLaunchKernelGGL(k_elas_gap, dim3(Wd), dim3(256), 0, s, D[side], Hd, Wd, 1, gap_width, p.add_corners);
   }
   if (taps) { if ((rc = tap(ctx, taps->D1_gap, D[0], n))) return rc; if ((rc = tap(ctx, taps->D2_gap, D[1], n))) return rc; }
   if (p.filter_adaptive_mean)
     for (int side = 0; side < nsides; ++side) {
       SvoTimer t(ctx, "k_elas_mean");
-      hipLaunchKernelGGL(k_elas_mean_h, pix, dim3(256), 0, s, D[side], W, H, T[side]);
-      hipLaunchKernelGGL(k_elas_mean_v, pix, dim3(256), 0, s, T[side], W, H, D[side]);
+      hipLaunchKernelGGL(k_elas_mean_h, pix, dim3(256), 0, s, D[side], Wd, Hd, sub, T[side]);
+      hipLaunchKernelGGL(k_elas_mean_v, pix, dim3(256), 0, s, T[side], Wd, Hd, sub, D[side]);
     }
   if (taps) { if ((rc = tap(ctx, taps->D1_mean, D[0], n))) return rc; if ((rc = tap(ctx, taps->D2_mean, D[1], n))) return rc; }
   if (p.filter_median)
     for (int side = 0; side < nsides; ++side) {
       SvoTimer t(ctx, "k_elas_median");
-      hipLaunchKernelGGL(k_elas_median_h, pix, dim3(256), 0, s, D[side], W, H, T[side]);
-      hipLaunchKernelGGL(k_elas_median_v, pix, dim3(256), 0, s, T[side], W, H, D[side]);
+      hipLaunchKernelGGL(k_elas_median_h, pix, dim3(256), 0, s, D[side], Wd, Hd, T[side]);
+      hipLaunchKernelGGL(k_elas_median_v, pix, dim3(256), 0, s, T[side], Wd, Hd, D[side]);
     }
   *outD1 = D[0]; *outD2 = D[1];
   *produced = 1;
@@ -968,11 +1022,12 @@ extern "C" int svo_elas_process_ex(svo_ctx* ctx, const uint8_t* I1, const uint8_
   if (!produced) return SVO_OK;   // the reference prints an error and returns with D1/D2 untouched
   {
     HostTimer ht(ctx, "host_elas_download");
-    SVO_HIP(ctx, hipMemcpyAsync(st->h_D, dD1, n * sizeof(float), hipMemcpyDeviceToHost, s));
-    SVO_HIP(ctx, hipMemcpyAsync(st->h_D + n, dD2, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    const size_t nd = p.subsampling ? (size_t)(W / 2) * (H / 2) : n;
+    SVO_HIP(ctx, hipMemcpyAsync(st->h_D, dD1, nd * sizeof(float), hipMemcpyDeviceToHost, s));
+    SVO_HIP(ctx, hipMemcpyAsync(st->h_D + nd, dD2, nd * sizeof(float), hipMemcpyDeviceToHost, s));
     SVO_HIP(ctx, hipStreamSynchronize(s));
-    memcpy(D1, st->h_D, n * sizeof(float));
-    memcpy(D2, st->h_D + n, n * sizeof(float));
+    memcpy(D1, st->h_D, nd * sizeof(float));
+    memcpy(D2, st->h_D + nd, nd * sizeof(float));
   }
   SVO_HIP(ctx, hipGetLastError());
   return SVO_OK;

@@ -121,9 +121,29 @@ def test_textureless_pair_leaves_outputs_untouched(ctx):
     assert len(g["support"]) == 0 and (g["D1"] == 0).all() and (g["D2"] == 0).all()
 
 
-def test_rejects_subsampling(ctx):
-    p = svo.elas_default_params(0)
-    p.subsampling = 1
+@pytest.mark.parametrize("middlebury", [False, True])
+@pytest.mark.parametrize("pair", ["urban-small", "urban-odd-size"])
+def test_subsampling_bit_exact(ctx, pair, middlebury):
+    """param.subsampling = 1: every second pixel, maps of (W/2) x (H/2), lattice step 6, 4-tap adaptive
+    mean, halved gap width, speckle size 2*sqrt(speckle_size) (elas.cpp:379-381, 846-871, 986-991)."""
+    L, R = PAIRS[pair]()
+    pa, pb = params(middlebury)
+    pa.subsampling = 1; pb.subsampling = 1
+    g = ctx.elas_process(L, R, pa, taps=True)
+    assert g["D1"].shape == (L.shape[0] // 2, L.shape[1] // 2)
+    r = ob.ref_elas_staged(L, R, pb, tri1=g["tri1"], tri2=g["tri2"])
+    assert len(g["support"]) > 50
+    for k in STAGES:
+        assert g[k].shape == r[k].shape, k
+        assert np.array_equal(g[k], r[k]), (k, int((g[k] != r[k]).sum()))
+    D1, D2 = ctx.elas_process(L, R, pa)
+    assert np.array_equal(D1, g["D1"]) and np.array_equal(D2, g["D2"])
+
+
+def test_rejects_bad_parameters(ctx):
     L, R = PAIRS["urban-small"]()
-    with pytest.raises(svo.SvoError):
-        ctx.elas_process(L, R, p)
+    for field, value in (("subsampling", 2), ("disp_max", 300), ("grid_size", 0)):
+        p = svo.elas_default_params(0)
+        setattr(p, field, value)
+        with pytest.raises(svo.SvoError):
+            ctx.elas_process(L, R, p)

@@ -21,7 +21,7 @@ def read_pgm(path):
 
 
 def test_host_binaries_exist():
-    for b in ("stereo_kitti", "host_check", "libstereo_vo_host.a"):
+    for b in ("stereo_kitti", "host_check", "elas", "libstereo_vo_host.a"):
         assert os.path.exists(os.path.join(HOST, b)), "run __graft_entry__.build()"
 
 

@@ -324,6 +324,17 @@ int svo_elas_process_ex(svo_ctx* ctx, const uint8_t* I1, const uint8_t* I2, floa
  * (smallest index first, sorted); *n_tri = number of triangles. */
 int svo_elas_delaunay(const int32_t* xy, int32_t n, int32_t* tri, int32_t cap, int32_t* n_tri);
 
+/* ------------------------------------------------------------------------------------------------
+ * MSA dense stereo: stages built so far.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* `ctmf(src, dst, width, height, src_step_row, dst_step_row, r, channels, memsize)` (Thirdparty/MB/ctmf.h:7,
+ * ctmf.c:222-433; called at Thirdparty/MB/MSA.cpp:58-59 with r = 1 on 3 channels and MSA.cpp:1006 with r = 2 on
+ * 1 channel): per-channel (2r+1)^2 median of an 8-bit interleaved image, window clamped to the image.
+ * Host buffers in and out; r in 1..3, channels in 1..4; `memsize` (a CPU cache hint) is dropped. */
+int svo_ctmf(svo_ctx* ctx, const uint8_t* src, uint8_t* dst, int width, int height, int src_step_row,
+             int dst_step_row, int r, int channels);
+
 #ifdef __cplusplus
 }
 #endif

@@ -375,3 +375,17 @@ def canonical_triangles(tri):
     k = np.argmin(t, 1)
     t = np.stack([np.roll(r, -kk) for r, kk in zip(t, k)])
     return t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))]
+
+
+def ref_ctmf(img, r):
+    """The reference's ctmf() (Thirdparty/MB/ctmf.c, compiled by oracle/Makefile.ref) on an H x W or
+    H x W x C uint8 image, with the memsize MSA passes (the whole image, MSA.cpp:58)."""
+    so = os.path.join(_HERE, "_ref", "libref_ctmf.so")
+    L = C.CDLL(so)
+    a = np.ascontiguousarray(img, np.uint8)
+    cn = 1 if a.ndim == 2 else a.shape[2]
+    H, W = a.shape[:2]
+    out = np.zeros_like(a)
+    L.ctmf.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_ulong]
+    L.ctmf(_p(a), _p(out), W, H, W * cn, W * cn, int(r), cn, max(W * H * cn, 1 << 16))
+    return out

@@ -46,6 +46,7 @@ ABI_SYMBOLS = [
     "svo_frontend_batch_dev", "svo_track_batch_dev", "svo_profile_enable", "svo_profile_reset",
     "svo_profile_get",
     "svo_elas_default_params", "svo_elas_process", "svo_elas_process_ex", "svo_elas_delaunay",
+    "svo_ctmf",
 ]
 
 
@@ -370,6 +371,15 @@ class Svo:
             o["tri" + s] = o["tri" + s][:n].copy(); o["planes" + s] = o["planes" + s][:n].copy()
         o["D1"] = D1; o["D2"] = D2
         return o
+
+    def ctmf(self, img, r):
+        """Median filter of Thirdparty/MB/ctmf.c on an H x W or H x W x C uint8 image."""
+        a = _u8(img)
+        cn = 1 if a.ndim == 2 else a.shape[2]
+        H, W = a.shape[:2]
+        out = np.zeros_like(a)
+        self._chk(self.lib.svo_ctmf(self.h, _p(a), _p(out), W, H, W * cn, W * cn, int(r), cn))
+        return out
 
 
 class ElasParams(C.Structure):

@@ -2,7 +2,7 @@
 // MI355X path: same command line (`elas demo` | `elas left.pgm right.pgm`), same outputs
 // (<name>_disp.pgm next to each input, both maps scaled so that the largest disparity is 255), with
 // Elas::process replaced by svo_elas_process.  tests/test_elas_tool.py compares its output files byte for
-// byte with those of the reference's own program (built by oracle/Makefile.ref).
+// byte with those of the reference's own program.
 #include <algorithm>
 #include <cstdio>
 #include <cstring>

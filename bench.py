@@ -127,7 +127,7 @@ def cpu_baseline_all_cores(Lh, Rh, cam, budget_s=8.0):
                       % (sum(done), dt, cores)}
 
 
-def elas_leg(pkg, W, H, device, L, R, iters=20, threads=4):
+def elas_leg(pkg, W, H, device, L, R, iters=20, threads=16):
     """Dense ELAS stereo (BASELINE configs[4] without YOLO): svo_elas_process on host
     buffers, one call at a time (latency) and from `threads` host threads with one context each
     (throughput; the host stages - support filtering, Delaunay, planes - overlap across pairs).  Beside it

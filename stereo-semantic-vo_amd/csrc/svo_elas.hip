@@ -783,7 +783,7 @@ namespace {
 int elas_check(svo_ctx* ctx, int W, int H, int pitch, const svo_elas_params& p) {
   if ((p.subsampling != 0 && p.subsampling != 1) || W < 16 || H < 16 || W > GAP_MAXLEN || H > GAP_MAXLEN || pitch < W || p.disp_min < 0 ||
       p.disp_max < p.disp_min || p.disp_max > 255 || p.candidate_stepsize < 1 || p.grid_size < 1 ||
-      p.incon_window_size < 0) {
+      p.incon_window_size < 0 || !(p.sigma * p.sradius <= 250.0f)) {   // plane band must fit the prior table
     ctx->last_error = "svo_elas_process: unsupported parameters (sizes, disparity range)";
     return SVO_E_INVALID;
   }

@@ -207,6 +207,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-track-leg", action="store_true")
     ap.add_argument("--no-elas-leg", action="store_true")
+    ap.add_argument("--sequences", type=int, default=1,
+                    help="track workload: S concurrent sequences per GPU (svo_track_multi_step_dev), one frame of each per step")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (single-GPU dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (dry run of the N>1 path on one GPU)")
     args = ap.parse_args()
@@ -230,10 +232,19 @@ def main():
 
     cam = pkg.Camera(**pkg.KITTI_00_02)
     B = args.batch
-    svo = pkg.Svo(W, H, device=local, max_kp=500, max_batch=B)
     track = args.workload == "track"
+    multi = track and args.sequences > 1
+    if multi:
+        B = args.sequences                               # one frame of each of the S sequences per step
+    svo = pkg.Svo(W, H, device=local, max_kp=500, max_batch=B)
     seed = shard.sequence_seed_for_rank(synth.BASE_SEED, rank) if track else synth.BASE_SEED
-    if track:
+    if multi:
+        # sequence q = the rank's synthetic sequence delayed by q frames: step t hands over frames t .. t+S-1
+        n_frames = B + args.warmup + args.steps
+        dL, dR, T_gt = render_frames(synth, n_frames, dev, seed)
+        d_res = torch.zeros(((args.warmup + args.steps) * B, pkg.TRACK_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        svo.track_multi_reset(B, cam)
+    elif track:
         n_frames = B * (args.warmup + args.steps)       # one continuous sequence per rank
         dL, dR, T_gt = render_frames(synth, n_frames, dev, seed)
         d_res = torch.zeros((n_frames, pkg.TRACK_DTYPE.itemsize), dtype=torch.uint8, device=dev)
@@ -253,7 +264,10 @@ def main():
     rec = pkg.TRACK_DTYPE.itemsize
 
     def step(s):
-        if track:
+        if multi:
+            svo.track_multi_step_dev(dL.data_ptr() + s * frame_bytes, dR.data_ptr() + s * frame_bytes, PITCH, B,
+                                     d_res.data_ptr() + s * B * rec)
+        elif track:
             off = s * B
             svo.track_batch_dev(dL.data_ptr() + off * frame_bytes, dR.data_ptr() + off * frame_bytes,
                                 PITCH, B, d_res.data_ptr() + off * rec)
@@ -289,10 +303,15 @@ def main():
         cfg = {"pairs_per_step_per_gpu": B}
         if track:
             res = d_res.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(-1)
-            rmse, last = ate_rmse(res, T_gt.numpy())
+            if multi:                                    # accuracy figures from sequence 0 (starts at frame 0)
+                res = res.reshape(-1, B)[:, 0]
+                cfg["concurrent_sequences_per_gpu"] = B
+            rmse, last = ate_rmse(res, T_gt.numpy()[:len(res)])
             cfg.update({"workload": "synth-kitti00 sequence 1241x376, full Tracking::Track loop per frame: ORB on L and R, "
                                     "sparse stereo, matching passes 1+2, PnP-RANSAC, pose-only LM, map-point "
-                                    "lifecycle (BASELINE configs[2]); one sequence per GPU",
+                                    "lifecycle (BASELINE configs[2]); " +
+                                    ("%d concurrent staggered sequences per GPU, one frame of each per step" % B if multi
+                                     else "one sequence per GPU"),
                         "frames_tracked": int(len(res)), "ate_rmse_m_vs_ground_truth": rmse,
                         "final_position_error_m": last, "path_length_m": float(len(res) - 1),
                         "mean_lm_edges": float(res["n_lm_edges"][1:].mean()),
@@ -359,6 +378,26 @@ def main():
             out["track"] = {"value": nt / tdt, "unit": "stereo pairs/s", "frames": nt,
                             "ate_rmse_m_vs_ground_truth": rmse, "final_position_error_m": last,
                             "note": "one sequence, strict frame order (BASELINE configs[2]); includes the front end"}
+            # the same loop for S staggered sequences advanced together (one workgroup per sequence in the tail)
+            S = min(B, 64)
+            msteps = min(48, nt - S)
+            mres = torch.zeros((msteps * S, rec), dtype=torch.uint8, device=dev)
+            svo.track_multi_reset(S, cam)
+            for t in range(2):
+                svo.track_multi_step_dev(tL.data_ptr() + t * frame_bytes, tR.data_ptr() + t * frame_bytes, PITCH, S,
+                                         mres.data_ptr() + t * S * rec)
+            svo.track_multi_reset(S, cam)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for t in range(msteps):
+                svo.track_multi_step_dev(tL.data_ptr() + t * frame_bytes, tR.data_ptr() + t * frame_bytes, PITCH, S,
+                                         mres.data_ptr() + t * S * rec)
+            svo.sync()
+            mdt = time.perf_counter() - t1
+            m = mres.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(msteps, S)
+            same = all(m[t, 0].tobytes() == r[t].tobytes() for t in range(msteps))
+            out["track"]["multi_sequence"] = {"value": msteps * S / mdt, "unit": "stereo pairs/s", "sequences": S,
+                                              "steps": msteps, "sequence0_equals_single_chain": bool(same)}
         if world == 1 and not track and not args.no_elas_leg:
             out["elas"] = elas_leg(pkg, W, H, dev.index or 0, dL[0, :, :W].cpu().numpy(), dR[0, :, :W].cpu().numpy())
         print(json.dumps(out))

@@ -265,6 +265,18 @@ int svo_frontend_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* 
 int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR,
                         int stride, int B, svo_track_result* d_results);
 
+/* Many independent sequences on one GPU ("G independent sequences" for pure
+ * throughput; no counterpart in the reference, whose tracker is one static chain per process,
+ * src/Tracking.cc:180-252).  svo_track_multi_reset allocates n_seq (<= max_batch) tracker states;
+ * every svo_track_multi_step_dev advances ALL of them by one frame: stereo pair q (device-resident,
+ * `stride` bytes per row, pairs back to back) is the next frame of sequence q, d_results[q] its record.
+ * The front end runs batched over the n_seq pairs and every kernel of the temporal tail runs one
+ * workgroup per sequence, so the strictly serial chain of one sequence overlaps with the others'.
+ * Results are identical to n_seq separate single-sequence trackers.  No detection boxes in this mode. */
+int svo_track_multi_reset(svo_ctx* ctx, int n_seq, const svo_camera* cam);
+int svo_track_multi_step_dev(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR, int stride,
+                             int n_seq, svo_track_result* d_results);
+
 /* Names + accumulated HIP-event time (ms) and launch count of the kernels the ctx
  * has timed since svo_profile_reset (only when svo_profile_enable(ctx,1)). */
 int svo_profile_enable(svo_ctx* ctx, int on);

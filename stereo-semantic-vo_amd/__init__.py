@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "svo_frontend_batch_dev", "svo_track_batch_dev", "svo_profile_enable", "svo_profile_reset",
     "svo_profile_get",
     "svo_elas_default_params", "svo_elas_process", "svo_elas_process_ex", "svo_elas_delaunay",
-    "svo_ctmf",
+    "svo_ctmf", "svo_track_multi_reset", "svo_track_multi_step_dev",
 ]
 
 
@@ -316,6 +316,13 @@ class Svo:
                                                _p(d_results)))
 
     # ---- profiling ----------------------------------------------------------------------------
+    def track_multi_reset(self, n_seq, cam):
+        self._chk(self.lib.svo_track_multi_reset(self.h, int(n_seq), C.byref(cam)))
+
+    def track_multi_step_dev(self, d_grayL, d_grayR, stride, n_seq, d_results):
+        self._chk(self.lib.svo_track_multi_step_dev(self.h, C.c_void_p(d_grayL), C.c_void_p(d_grayR), int(stride),
+                                                     int(n_seq), C.c_void_p(d_results)))
+
     def profile_enable(self, on=True):
         self._chk(self.lib.svo_profile_enable(self.h, 1 if on else 0))
 

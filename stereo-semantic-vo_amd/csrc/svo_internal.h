@@ -90,7 +90,8 @@ struct svo_ctx {
   size_t pinned_bytes = 0;
 
   // tracker state (svo_track.hip)
-  void* d_track = nullptr;
+  void* d_track = nullptr;      // n_seq TrackState records
+  int n_seq = 0;
   void* elas = nullptr;     // ElasState (svo_elas.hip), allocated on first svo_elas_process
   svo_camera cam{};
   int track_frame = 0;
@@ -137,11 +138,17 @@ int svo_launch_pose_opt(svo_ctx* ctx, const double* Xw, const double* obs, int n
 int svo_launch_pnp(svo_ctx* ctx, const double* Xw, const double* obs, int n, const double* K,
                    const double* Tprior, uint64_t seed, double* T, uint8_t* mask,
                    svo_pnp_stats* stats);
+// nseq > 1: one workgroup per sequence, operands of sequence q at byte offset q * seq_stride
 int svo_launch_pose_opt_dev(svo_ctx* ctx, const double* Xw, const double* obs, const int* n_ptr,
-                            const double* K, double* T, svo_lm_stats* stats, int round_in_f32);
+                            const double* K, double* T, svo_lm_stats* stats, int round_in_f32,
+                            int nseq = 1, size_t seq_stride = 0);
 int svo_launch_pnp_dev(svo_ctx* ctx, const double* Xw, const double* obs, const int* n_ptr,
                        const double* K, const double* Tprior, double* T, svo_pnp_stats* stats,
-                       const int* skip_ptr, const int* frame_ptr);
+                       const int* skip_ptr, const int* frame_ptr, int nseq = 1, size_t seq_stride = 0);
+template <typename T>
+__host__ __device__ inline T* svo_byte_offset(T* p, size_t bytes) {
+  return p ? reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + bytes) : p;
+}
 int svo_launch_disp2depth(svo_ctx* ctx, const float* disp, int count, float bf, float* depth);
 int svo_launch_unproject(svo_ctx* ctx, const float* uvz, int n, const svo_camera* cam,
                          const float* Rwc, const float* twc, float* xyz);

@@ -359,7 +359,12 @@ __global__ __launch_bounds__(256) void k_pose_opt(const double* __restrict__ Xw,
                                                   const double* __restrict__ obs, int n,
                                                   const double* __restrict__ Kp, double* T,
                                                   svo_lm_stats* stats, const int* n_ptr,
-                                                  int round_in_f32, int use_mfma) {
+                                                  int round_in_f32, int use_mfma, size_t seq_stride) {
+  if (blockIdx.y) {   // sequence blockIdx.y of a multi-sequence tracker: all operands live in its TrackState
+    const size_t off = (size_t)blockIdx.y * seq_stride;
+    Xw = svo_byte_offset(Xw, off); obs = svo_byte_offset(obs, off); Kp = svo_byte_offset(Kp, off);
+    T = svo_byte_offset(T, off); stats = svo_byte_offset(stats, off); n_ptr = svo_byte_offset(n_ptr, off);
+  }
   if (n_ptr) n = *n_ptr;
   __shared__ double arow[(2 * GRAM_MAXN + 64) * GRAM_STRIDE];
   __shared__ double gram[4 * 64 + 4];
@@ -510,7 +515,14 @@ __global__ __launch_bounds__(256) void k_pnp_ransac(const double* __restrict__ X
                                                     double* T, uint8_t* inlier_mask,
                                                     svo_pnp_stats* stats, const int* n_ptr,
                                                     const int* skip_ptr, const int* frame_ptr,
-                                                    int use_mfma) {
+                                                    int use_mfma, size_t seq_stride) {
+  if (blockIdx.y) {
+    const size_t off = (size_t)blockIdx.y * seq_stride;
+    Xw = svo_byte_offset(Xw, off); obs = svo_byte_offset(obs, off); Kp = svo_byte_offset(Kp, off);
+    Tprior = svo_byte_offset(Tprior, off); T = svo_byte_offset(T, off); stats = svo_byte_offset(stats, off);
+    n_ptr = svo_byte_offset(n_ptr, off); skip_ptr = svo_byte_offset(skip_ptr, off);
+    frame_ptr = svo_byte_offset(frame_ptr, off);
+  }
   if (n_ptr) n = *n_ptr;
   if (frame_ptr) seed = 0x5EED0000ULL + (uint64_t)*frame_ptr;
   if (skip_ptr && *skip_ptr) {   // frame 0: no PnP, the pose stays at the prior
@@ -676,7 +688,7 @@ int svo_launch_pose_opt(svo_ctx* ctx, const double* Xw, const double* obs, int n
                         double* T, svo_lm_stats* stats) {
   SvoTimer tm(ctx, "k_pose_opt");
   hipLaunchKernelGGL(k_pose_opt, dim3(1), dim3(256), 0, ctx->stream, Xw, obs, n, K, T, stats,
-                     (const int*)nullptr, 0, ctx->opt_pose_mfma);
+                     (const int*)nullptr, 0, ctx->opt_pose_mfma, (size_t)0);
   SVO_HIP(ctx, hipGetLastError());
   return SVO_OK;
 }
@@ -688,24 +700,26 @@ int svo_launch_pnp(svo_ctx* ctx, const double* Xw, const double* obs, int n, con
   SvoTimer tm(ctx, "k_pnp_ransac");
   hipLaunchKernelGGL(k_pnp_ransac, dim3(1), dim3(256), 0, ctx->stream, Xw, obs, n, K, Tprior, seed,
                      T, mask, stats, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr,
-                     ctx->opt_pose_mfma);
+                     ctx->opt_pose_mfma, (size_t)0);
   SVO_HIP(ctx, hipGetLastError());
   return SVO_OK;
 }
 
 // device-driven variants used by the tracking tail (sizes / seed / skip flag live in HBM)
 int svo_launch_pose_opt_dev(svo_ctx* ctx, const double* Xw, const double* obs, const int* n_ptr,
-                            const double* K, double* T, svo_lm_stats* stats, int round_in_f32) {
+                            const double* K, double* T, svo_lm_stats* stats, int round_in_f32, int nseq,
+                            size_t seq_stride) {
   SvoTimer tm(ctx, "k_pose_opt");
-  hipLaunchKernelGGL(k_pose_opt, dim3(1), dim3(256), 0, ctx->stream, Xw, obs, 0, K, T, stats, n_ptr,
-                     round_in_f32, ctx->opt_pose_mfma);
+  hipLaunchKernelGGL(k_pose_opt, dim3(1, (unsigned)nseq), dim3(256), 0, ctx->stream, Xw, obs, 0, K, T, stats, n_ptr,
+                     round_in_f32, ctx->opt_pose_mfma, seq_stride);
   return SVO_OK;
 }
 int svo_launch_pnp_dev(svo_ctx* ctx, const double* Xw, const double* obs, const int* n_ptr,
                        const double* K, const double* Tprior, double* T, svo_pnp_stats* stats,
-                       const int* skip_ptr, const int* frame_ptr) {
+                       const int* skip_ptr, const int* frame_ptr, int nseq, size_t seq_stride) {
   SvoTimer tm(ctx, "k_pnp_ransac");
-  hipLaunchKernelGGL(k_pnp_ransac, dim3(1), dim3(256), 0, ctx->stream, Xw, obs, 0, K, Tprior,
-                     (uint64_t)0, T, (uint8_t*)nullptr, stats, n_ptr, skip_ptr, frame_ptr, ctx->opt_pose_mfma);
+  hipLaunchKernelGGL(k_pnp_ransac, dim3(1, (unsigned)nseq), dim3(256), 0, ctx->stream, Xw, obs, 0, K, Tprior,
+                     (uint64_t)0, T, (uint8_t*)nullptr, stats, n_ptr, skip_ptr, frame_ptr, ctx->opt_pose_mfma,
+                     seq_stride);
   return SVO_OK;
 }

@@ -96,10 +96,18 @@ __device__ __forceinline__ void tk_unproject(const svo_camera& cam, float u, flo
 }
 
 // ---- 1. frame begin: reset per-frame state; frame 0 runs Tracking::init -------------------
+// Every tail kernel serves one sequence per blockIdx.y: TrackState number blockIdx.y and frame slot
+// blockIdx.y of the front-end buffers (`kstride` keypoints per slot).  A single sequence is grid.y = 1.
+#define TK_SEQ_SELECT(kstride)                                   \
+  st += blockIdx.y;                                              \
+  kp += (size_t)blockIdx.y * (kstride);
+
 __global__ __launch_bounds__(512) void k_tk_begin(TrackState* st, const svo_kp* kp,
                                                   const uint32_t* desc, const int32_t* nkp_p,
-                                                  const float* depth) {
+                                                  const float* depth, int kstride) {
   __shared__ int sm[512];
+  TK_SEQ_SELECT(kstride)
+  desc += (size_t)blockIdx.y * kstride * 8; nkp_p += blockIdx.y; depth += (size_t)blockIdx.y * kstride;
   const int tid = threadIdx.x;
   const int nkp = min(*nkp_p, TRK_MAXKP);
   TrackPool& P = st->pool[st->cur];
@@ -158,8 +166,9 @@ __global__ __launch_bounds__(512) void k_tk_begin(TrackState* st, const svo_kp* 
 // Also decides, in parallel, which rows the serial pass must visit: a row can only be accepted
 // if its best distance over the unclaimed columns is < max_dist; the minimum over ALL columns
 // bounds that from below, so rows failing it never claim a column and are dropped.
-__global__ __launch_bounds__(256) void k_tk_dist(TrackState* st, const uint32_t* desc, int pass) {
+__global__ __launch_bounds__(256) void k_tk_dist(TrackState* st, const uint32_t* desc, int pass, int kstride) {
   __shared__ uint32_t td[TRK_MAXKP * 8];
+  st += blockIdx.y; desc += (size_t)blockIdx.y * kstride * 8;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int M = st->skip_match ? 0 : (pass == 1 ? st->m1 : st->m2);
   const int row = blockIdx.x * 4 + wv;
@@ -256,7 +265,8 @@ __device__ __forceinline__ int tk_wave_incl_scan(int v) {
   return v;
 }
 
-__global__ __launch_bounds__(64) void k_tk_greedy(TrackState* st, int pass, const svo_kp* kp) {
+__global__ __launch_bounds__(64) void k_tk_greedy(TrackState* st, int pass, const svo_kp* kp, int kstride) {
+  TK_SEQ_SELECT(kstride)
   __shared__ int16_t rows[TRK_CAP];
   __shared__ int16_t rowmp[TRK_CAP];
   __shared__ uint4 drow[32 * 64];   // distance rows of the current 32-row chunk (32 KB)
@@ -392,7 +402,8 @@ __global__ __launch_bounds__(64) void k_tk_greedy(TrackState* st, int pass, cons
 }
 
 // ---- 6. gather the 3D-2D correspondences (ordered by keypoint index) -----------------------
-__global__ __launch_bounds__(512) void k_tk_gather(TrackState* st, const svo_kp* kp) {
+__global__ __launch_bounds__(512) void k_tk_gather(TrackState* st, const svo_kp* kp, int kstride) {
+  TK_SEQ_SELECT(kstride)
   __shared__ int sm[512];
   const int tid = threadIdx.x;
   const TrackPool& P = st->pool[st->cur];
@@ -414,7 +425,9 @@ __global__ __launch_bounds__(512) void k_tk_gather(TrackState* st, const svo_kp*
 // ---- 9. frame end: SetPose, result record, createmappoint, cull, compaction ----------------
 __global__ __launch_bounds__(512) void k_tk_end(TrackState* st, const svo_kp* kp,
                                                 const uint32_t* desc, const float* depth,
-                                                svo_track_result* res_out) {
+                                                svo_track_result* res_out, int kstride) {
+  TK_SEQ_SELECT(kstride)
+  desc += (size_t)blockIdx.y * kstride * 8; depth += (size_t)blockIdx.y * kstride; res_out += blockIdx.y;
   __shared__ int sm[512];
   __shared__ float sT[16], sRwc[9], stwc[3];
   const int tid = threadIdx.x;
@@ -528,58 +541,75 @@ __global__ __launch_bounds__(512) void k_tk_end(TrackState* st, const svo_kp* kp
 }
 
 // --------------------------------------------------------------------------------------------
-static int tail_launch(svo_ctx* ctx, int slot, svo_track_result* d_res) {
+// One frame of `nseq` sequences at once: sequence q uses TrackState q, frame slot `slot + q` and result
+// record d_res[q].  nseq = 1 is the ordinary single chain.
+static int tail_launch(svo_ctx* ctx, int slot, svo_track_result* d_res, int nseq = 1) {
   TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
   hipStream_t s = ctx->stream;
   const size_t K = ctx->max_kp;
+  const int ks = (int)K;
+  const unsigned ny = (unsigned)nseq;
   const svo_kp* kp = ctx->d_kp + slot * K;
   const uint32_t* desc = reinterpret_cast<const uint32_t*>(ctx->d_desc + slot * K * 32);
   const float* depth = ctx->d_depth + slot * K;
   {
     SvoTimer t(ctx, "k_tk_begin");
-    hipLaunchKernelGGL(k_tk_begin, dim3(1), dim3(512), 0, s, st, kp, desc, ctx->d_nkp + slot, depth);
+    hipLaunchKernelGGL(k_tk_begin, dim3(1, ny), dim3(512), 0, s, st, kp, desc, ctx->d_nkp + slot, depth, ks);
   }
   {
     SvoTimer t(ctx, "k_tk_match");
-    hipLaunchKernelGGL(k_tk_dist, dim3(TRK_MAXKP / 4), dim3(256), 0, s, st, desc, 1);
-    hipLaunchKernelGGL(k_tk_greedy, dim3(1), dim3(64), 0, s, st, 1, kp);
-    hipLaunchKernelGGL(k_tk_dist, dim3(TRK_CAP / 4), dim3(256), 0, s, st, desc, 2);
-    hipLaunchKernelGGL(k_tk_greedy, dim3(1), dim3(64), 0, s, st, 2, kp);
+    hipLaunchKernelGGL(k_tk_dist, dim3(TRK_MAXKP / 4, ny), dim3(256), 0, s, st, desc, 1, ks);
+    hipLaunchKernelGGL(k_tk_greedy, dim3(1, ny), dim3(64), 0, s, st, 1, kp, ks);
+    hipLaunchKernelGGL(k_tk_dist, dim3(TRK_CAP / 4, ny), dim3(256), 0, s, st, desc, 2, ks);
+    hipLaunchKernelGGL(k_tk_greedy, dim3(1, ny), dim3(64), 0, s, st, 2, kp, ks);
   }
   {
     SvoTimer t(ctx, "k_tk_gather");
-    hipLaunchKernelGGL(k_tk_gather, dim3(1), dim3(512), 0, s, st, kp);
+    hipLaunchKernelGGL(k_tk_gather, dim3(1, ny), dim3(512), 0, s, st, kp, ks);
   }
   svo_launch_pnp_dev(ctx, st->Xw, st->obs, &st->n_edges, st->K, st->Tprior, st->T, &st->pnp,
-                     &st->skip_match, &st->frame_num);
-  svo_launch_pose_opt_dev(ctx, st->Xw, st->obs, &st->n_edges, st->K, st->T, &st->lm, 1);
+                     &st->skip_match, &st->frame_num, nseq, sizeof(TrackState));
+  svo_launch_pose_opt_dev(ctx, st->Xw, st->obs, &st->n_edges, st->K, st->T, &st->lm, 1, nseq, sizeof(TrackState));
   {
     SvoTimer t(ctx, "k_tk_end");
-    hipLaunchKernelGGL(k_tk_end, dim3(1), dim3(512), 0, s, st, kp, desc, depth, d_res);
+    hipLaunchKernelGGL(k_tk_end, dim3(1, ny), dim3(512), 0, s, st, kp, desc, depth, d_res, ks);
   }
   SVO_HIP(ctx, hipGetLastError());
   return SVO_OK;
 }
 
-extern "C" int svo_track_reset(svo_ctx* ctx, const svo_camera* cam) {
-  if (!ctx || !cam) return SVO_E_INVALID;
+// (Re)allocate `nseq` tracker states and reset them: pose I, empty map, frame counter 0.
+static int track_reset_n(svo_ctx* ctx, const svo_camera* cam, int nseq) {
+  if (!ctx || !cam || nseq < 1) return SVO_E_INVALID;
   if (ctx->max_kp > TRK_MAXKP) return SVO_E_CAPACITY;
   hipSetDevice(ctx->device);
-  if (!ctx->d_track) {
+  if (!ctx->d_track || ctx->n_seq != nseq) {
+    if (ctx->d_track) { hipStreamSynchronize(ctx->stream); hipFree(ctx->d_track); ctx->d_track = nullptr; }
     void* p = nullptr;
-    if (hipMalloc(&p, sizeof(TrackState)) != hipSuccess) return SVO_E_NOMEM;
+    if (hipMalloc(&p, sizeof(TrackState) * (size_t)nseq) != hipSuccess) return SVO_E_NOMEM;
     ctx->d_track = p;
+    ctx->n_seq = nseq;
   }
-  TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
-  // zero the scalar header + index arrays (everything before the pools), then set identity pose
-  SVO_HIP(ctx, hipMemsetAsync(st, 0, offsetof(TrackState, pool), ctx->stream));
   float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-  SVO_HIP(ctx, hipMemcpyAsync(st->lastTcw, I, sizeof I, hipMemcpyHostToDevice, ctx->stream));
-  SVO_HIP(ctx, hipMemcpyAsync(&st->cam, cam, sizeof *cam, hipMemcpyHostToDevice, ctx->stream));
+  for (int q = 0; q < nseq; ++q) {
+    TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track) + q;
+    // zero the scalar header + index arrays (everything before the pools), then set identity pose
+    SVO_HIP(ctx, hipMemsetAsync(st, 0, offsetof(TrackState, pool), ctx->stream));
+    SVO_HIP(ctx, hipMemcpyAsync(st->lastTcw, I, sizeof I, hipMemcpyHostToDevice, ctx->stream));
+    SVO_HIP(ctx, hipMemcpyAsync(&st->cam, cam, sizeof *cam, hipMemcpyHostToDevice, ctx->stream));
+  }
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->cam = *cam;
   ctx->track_frame = 0;
   return SVO_OK;
+}
+
+extern "C" int svo_track_reset(svo_ctx* ctx, const svo_camera* cam) { return track_reset_n(ctx, cam, 1); }
+
+extern "C" int svo_track_multi_reset(svo_ctx* ctx, int n_seq, const svo_camera* cam) {
+  if (!ctx) return SVO_E_INVALID;
+  if (n_seq < 1 || n_seq > ctx->max_batch) return SVO_E_CAPACITY;
+  return track_reset_n(ctx, cam, n_seq);
 }
 
 extern "C" int svo_fundamental_8point(const double* pts1, const double* pts2, int n, double F[9]);
@@ -641,7 +671,7 @@ extern "C" int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL,
   if (!ctx || !grayL || !grayR || !res || strideL < ctx->g.W || strideR < ctx->g.W || n_boxes < 0 ||
       n_boxes > SVO_MAX_BOXES || (n_boxes > 0 && !boxes))
     return SVO_E_INVALID;
-  if (!ctx->d_track) return SVO_E_INVALID;          // svo_track_reset first
+  if (!ctx->d_track || ctx->n_seq != 1) return SVO_E_INVALID;   // svo_track_reset first
   hipSetDevice(ctx->device);
   const SvoGeom& g = ctx->g;
   TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
@@ -681,11 +711,25 @@ extern "C" int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL,
   return SVO_OK;
 }
 
+// One time step of n_seq independent sequences: pair q is the next frame of sequence q.
+extern "C" int svo_track_multi_step_dev(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR,
+                                        int stride, int n_seq, svo_track_result* d_results) {
+  if (!ctx || !d_grayL || !d_grayR || !d_results || stride < ctx->g.W) return SVO_E_INVALID;
+  if (!ctx->d_track || n_seq != ctx->n_seq) return SVO_E_INVALID;   // svo_track_multi_reset(n_seq) first
+  hipSetDevice(ctx->device);
+  int rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, n_seq, 2 * n_seq);
+  if (rc) return rc;
+  if ((rc = svo_launch_stereo(ctx, d_grayL, d_grayR, stride, n_seq, &ctx->cam))) return rc;
+  if ((rc = tail_launch(ctx, 0, d_results, n_seq))) return rc;
+  ctx->track_frame++;
+  return SVO_OK;
+}
+
 extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR,
                                    int stride, int B, svo_track_result* d_results) {
   if (!ctx || !d_grayL || !d_grayR || !d_results || B < 1 || stride < ctx->g.W) return SVO_E_INVALID;
   if (B > ctx->max_batch) return SVO_E_CAPACITY;
-  if (!ctx->d_track) return SVO_E_INVALID;
+  if (!ctx->d_track || ctx->n_seq != 1) return SVO_E_INVALID;
   hipSetDevice(ctx->device);
   // the batched mode carries no detection boxes (the offline box files are a per-frame host input)
   SVO_HIP(ctx, hipMemsetAsync(&reinterpret_cast<TrackState*>(ctx->d_track)->n_boxes, 0, 4, ctx->stream));

@@ -160,3 +160,44 @@ def test_gpu_tracker_with_dense_elas_depth_matches_oracle(pkg, sequence, oracle_
         assert np.abs(T[:3, 3] - Tr[:3, 3]).max() < POSE_TOL_T, k
         assert np.abs(T[:3, :3] - Tr[:3, :3]).max() < POSE_TOL_R, k
     svo.close()
+
+
+@pytest.mark.gpu
+def test_multi_sequence_tracker_equals_independent_chains(pkg, sequence):
+    """svo_track_multi_step_dev: S staggered sequences advanced together == S single-sequence trackers,
+    record for record (byte-identical svo_track_result)."""
+    import torch
+    L, R, _ = sequence
+    H, W = L.shape[1], L.shape[2]
+    S, STEPS = 3, N_FRAMES - 2            # sequence q sees frames q, q+1, ...
+    cam = pkg.Camera(**pkg.KITTI_00_02)
+    pitch = 1280
+    dev = torch.device("cuda", 0)
+    dL = torch.zeros((N_FRAMES, H, pitch), dtype=torch.uint8, device=dev)
+    dR = torch.zeros_like(dL)
+    dL[:, :, :W] = torch.from_numpy(L).to(dev); dR[:, :, :W] = torch.from_numpy(R).to(dev)
+    rec = pkg.TRACK_DTYPE.itemsize
+    fb = H * pitch
+    singles = []
+    for q in range(S):
+        a = pkg.Svo(W, H, max_batch=STEPS)
+        a.track_reset(cam)
+        res = torch.zeros((STEPS, rec), dtype=torch.uint8, device=dev)
+        a.track_batch_dev(dL.data_ptr() + q * fb, dR.data_ptr() + q * fb, pitch, STEPS, res.data_ptr())
+        a.sync()
+        singles.append(res.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(-1))
+        a.close()
+    m = pkg.Svo(W, H, max_batch=S)
+    m.track_multi_reset(S, cam)
+    out = torch.zeros((STEPS, S, rec), dtype=torch.uint8, device=dev)
+    for t in range(STEPS):                # pairs t .. t+S-1 are the next frames of sequences 0 .. S-1
+        m.track_multi_step_dev(dL.data_ptr() + t * fb, dR.data_ptr() + t * fb, pitch, S, out[t].data_ptr())
+    m.sync()
+    multi = out.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(STEPS, S)
+    for q in range(S):
+        for t in range(STEPS):
+            assert multi[t, q].tobytes() == singles[q][t].tobytes(), (q, t)
+    assert multi[-1, 0]["n_lm_edges"] > 20
+    with pytest.raises(pkg.SvoError):     # single-sequence entry points refuse a multi-sequence state
+        m.track_batch_dev(dL.data_ptr(), dR.data_ptr(), pitch, 1, out.data_ptr())
+    m.close()

@@ -239,16 +239,21 @@ __global__ __launch_bounds__(256) void k_elas_match(const uint4* desc1, const ui
       const int d_plane_min = max(d_plane - plane_radius, 0);
       const int d_plane_max = min(d_plane + plane_radius, disp_num - 1);
       const int gx = (int)floorf((float)u / (float)p.grid_size), gy = (int)floorf((float)v / (float)p.grid_size);
-      const int32_t* cell = (right ? grid1 : grid0) + (size_t)(gy * gw + gx) * gd;
-      const int num_grid = cell[0];
+      // the cell's disparity candidates: a 256-bit set, visited in ascending order like the reference's list
+      const uint32_t* cell = reinterpret_cast<const uint32_t*>(right ? grid1 : grid0) + (size_t)(gy * gw + gx) * 8;
       int min_val = 10000, min_d = -1;
-      for (int i = 0; i < num_grid; ++i) {
-        const int d = cell[1 + i];
-        if (d < d_plane_min || d > d_plane_max) {
-          const int uw = right ? u + d : u - d;
-          if (uw < 2 || uw >= W - 2) continue;
-          const int val = sad16(self, Io[line + uw]);
-          if (val < min_val) { min_val = val; min_d = d; }
+#pragma unroll 1
+      for (int q = 0; q < 8; ++q) {
+        uint32_t m = cell[q];
+        while (m) {
+          const int d = 32 * q + __ffs(m) - 1;
+          m &= m - 1;
+          if (d < d_plane_min || d > d_plane_max) {
+            const int uw = right ? u + d : u - d;
+            if (uw < 2 || uw >= W - 2) continue;
+            const int val = sad16(self, Io[line + uw]);
+            if (val < min_val) { min_val = val; min_d = d; }
+          }
         }
       }
       for (int d = d_plane_min; d <= d_plane_max; ++d) {
@@ -548,6 +553,96 @@ __global__ __launch_bounds__(256) void k_elas_median_v(const float* T, int W, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// Plane fit per triangle (elas.cpp:505-577): d = a*u + b*v + c through the three corners, once in left
+// image coordinates (t1) and once in right image coordinates (t2), solved as Matrix::solve does
+// (matrix.cpp:414-503): Gauss-Jordan with full pivoting in float64, pivot = LAST largest |a| among the
+// rows / columns not used yet, singular below 1e-20 -> plane (0, 0, 0).
+// ------------------------------------------------------------------------------------------------
+__device__ bool solve3(double (&A)[3][3], double (&b)[3]) {
+  int ipiv[3] = {0, 0, 0};
+  for (int i = 0; i < 3; ++i) {
+    double big = 0.0;
+    int irow = 0, icol = 0;
+    for (int j = 0; j < 3; ++j)
+      if (ipiv[j] != 1)
+        for (int k = 0; k < 3; ++k)
+          if (ipiv[k] == 0 && fabs(A[j][k]) >= big) { big = fabs(A[j][k]); irow = j; icol = k; }
+    ++ipiv[icol];
+    if (irow != icol) {
+      for (int l = 0; l < 3; ++l) { const double t = A[irow][l]; A[irow][l] = A[icol][l]; A[icol][l] = t; }
+      const double t = b[irow]; b[irow] = b[icol]; b[icol] = t;
+    }
+    if (fabs(A[icol][icol]) < 1e-20) return false;
+    const double pivinv = 1.0 / A[icol][icol];
+    A[icol][icol] = 1.0;
+    for (int l = 0; l < 3; ++l) A[icol][l] *= pivinv;
+    b[icol] *= pivinv;
+    for (int ll = 0; ll < 3; ++ll)
+      if (ll != icol) {
+        const double dum = A[ll][icol];
+        A[ll][icol] = 0.0;
+        for (int l = 0; l < 3; ++l) A[ll][l] -= A[icol][l] * dum;
+        b[ll] -= b[icol] * dum;
+      }
+  }
+  return true;
+}
+__global__ __launch_bounds__(64) void k_elas_planes(const int32_t* sp, const int32_t* tri0, const int32_t* tri1, int n0,
+                                                    int n1, float* pl0, float* pl1) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  const int32_t* tri = blockIdx.y ? tri1 : tri0;
+  float* pl = blockIdx.y ? pl1 : pl0;
+  if (t >= (blockIdx.y ? n1 : n0)) return;
+  int cu[3], cv[3], cd[3];
+  for (int k = 0; k < 3; ++k) { const int c = tri[3 * t + k]; cu[k] = sp[3 * c]; cv[k] = sp[3 * c + 1]; cd[k] = sp[3 * c + 2]; }
+  for (int side = 0; side < 2; ++side) {
+    double A[3][3], b[3];
+    for (int k = 0; k < 3; ++k) {
+      A[k][0] = side ? cu[k] - cd[k] : cu[k]; A[k][1] = cv[k]; A[k][2] = 1;
+      b[k] = cd[k];
+    }
+    const bool ok = solve3(A, b);
+    for (int k = 0; k < 3; ++k) pl[6 * t + 3 * side + k] = ok ? (float)b[k] : 0.0f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Disparity grid (elas.cpp:579-658) as one 256-bit set per cell (disp_max <= 255).  mark: every support
+// point sets d-1..d+1 in its cell; diffuse: the reference's nine marching pointers run over the FLAT
+// (cell, d) array, whole cells apart, so per disparity they OR the flat CELL indices c + {0,1,2, gw..gw+2,
+// 2gw..2gw+2} into cell c + gw + 1 for every c with c + 2gw + 2 < gw*gh (rows wrap); other cells stay empty.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_elas_grid_mark(const int32_t* sp, int nsp, int grid_size, int disp_max, int gw, int gh,
+                                 uint32_t* t1_left, uint32_t* t1_right) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nsp) return;
+  const int u = sp[3 * i], v = sp[3 * i + 1], d0 = sp[3 * i + 2];
+  const int y = (int)floorf((float)v / (float)grid_size);
+  const int xl = (int)floorf((float)(u / grid_size));
+  const int xr = (int)floorf((float)(u - d0) / (float)grid_size);
+  for (int d = max(d0 - 1, 0); d <= min(d0 + 1, disp_max); ++d) {
+    if (xl >= 0 && xl < gw && y >= 0 && y < gh) atomicOr(&t1_left[(size_t)(y * gw + xl) * 8 + (d >> 5)], 1u << (d & 31));
+    if (xr >= 0 && xr < gw && y >= 0 && y < gh) atomicOr(&t1_right[(size_t)(y * gw + xr) * 8 + (d >> 5)], 1u << (d & 31));
+  }
+}
+__global__ void k_elas_grid_diffuse(const uint32_t* t1_left, const uint32_t* t1_right, int gw, int gh,
+                                    uint32_t* t2_left, uint32_t* t2_right) {
+  const int i = blockIdx.x * 256 + threadIdx.x;   // (cell, word)
+  const int ncell = gw * gh;
+  if (i >= ncell * 8) return;
+  const uint32_t* t1 = blockIdx.y ? t1_right : t1_left;
+  uint32_t* t2 = blockIdx.y ? t2_right : t2_left;
+  const int cell = i >> 3, w = i & 7, c = cell - gw - 1;
+  uint32_t r = 0;
+  if (c >= 0 && c + 2 * gw + 2 < ncell) {
+    const int o[9] = {0, 1, 2, gw, gw + 1, gw + 2, 2 * gw, 2 * gw + 1, 2 * gw + 2};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r |= t1[(size_t)(c + o[k]) * 8 + w];
+  }
+  t2[i] = r;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Host stages
 // ------------------------------------------------------------------------------------------------
 struct SupportPt { int32_t u, v, d; };
@@ -603,92 +698,6 @@ void add_corner_points(std::vector<SupportPt>& sp, int W, int H) {
   b[4] = {b[2].u + b[2].d, b[2].v, b[2].d};
   b[5] = {b[3].u + b[3].d, b[3].v, b[3].d};
   for (int i = 0; i < 6; ++i) sp.push_back(b[i]);
-}
-
-// Gauss-Jordan elimination with full pivoting on a 3x3 system (the textbook routine behind
-// Matrix::solve, matrix.cpp:414-503): pivot = LAST largest |a| among rows/columns not yet used.
-bool solve3(double A[3][3], double b[3], double eps = 1e-20) {
-  int ipiv[3] = {0, 0, 0};
-  for (int i = 0; i < 3; ++i) {
-    double big = 0.0;
-    int irow = 0, icol = 0;
-    for (int j = 0; j < 3; ++j)
-      if (ipiv[j] != 1)
-        for (int k = 0; k < 3; ++k)
-          if (ipiv[k] == 0 && fabs(A[j][k]) >= big) { big = fabs(A[j][k]); irow = j; icol = k; }
-    ++ipiv[icol];
-    if (irow != icol) {
-      for (int l = 0; l < 3; ++l) std::swap(A[irow][l], A[icol][l]);
-      std::swap(b[irow], b[icol]);
-    }
-    if (fabs(A[icol][icol]) < eps) return false;
-    const double pivinv = 1.0 / A[icol][icol];
-    A[icol][icol] = 1.0;
-    for (int l = 0; l < 3; ++l) A[icol][l] *= pivinv;
-    b[icol] *= pivinv;
-    for (int ll = 0; ll < 3; ++ll)
-      if (ll != icol) {
-        const double dum = A[ll][icol];
-        A[ll][icol] = 0.0;
-        for (int l = 0; l < 3; ++l) A[ll][l] -= A[icol][l] * dum;
-        b[ll] -= b[icol] * dum;
-      }
-  }
-  return true;
-}
-
-void disparity_planes(const std::vector<SupportPt>& sp, const std::vector<int32_t>& tri, std::vector<float>& pl) {
-  const int n = (int)tri.size() / 3;
-  pl.assign((size_t)n * 6, 0.0f);
-  for (int i = 0; i < n; ++i) {
-    const SupportPt c[3] = {sp[tri[3 * i]], sp[tri[3 * i + 1]], sp[tri[3 * i + 2]]};
-    for (int side = 0; side < 2; ++side) {
-      double A[3][3], b[3];
-      for (int k = 0; k < 3; ++k) {
-        A[k][0] = side ? c[k].u - c[k].d : c[k].u; A[k][1] = c[k].v; A[k][2] = 1;
-        b[k] = c[k].d;
-      }
-      if (solve3(A, b)) for (int k = 0; k < 3; ++k) pl[6 * i + 3 * side + k] = (float)b[k];
-    }
-  }
-}
-
-void create_grid(const std::vector<SupportPt>& sp, const svo_elas_params& p, int gw, int gh, bool right,
-                 std::vector<int32_t>& grid) {
-  // per cell a 256-bit set of disparities (disp_max <= 255) instead of the reference's int per (cell, d)
-  struct Bits { uint64_t w[4]; };
-  const int ncell = gw * gh;
-  std::vector<Bits> t1(ncell, Bits{{0, 0, 0, 0}}), t2(ncell, Bits{{0, 0, 0, 0}});
-  for (const SupportPt& s : sp) {
-    const int d_min = std::max(s.d - 1, 0), d_max = std::min(s.d + 1, p.disp_max);
-    int x;
-    if (!right) x = (int)floor((float)(s.u / p.grid_size));
-    else x = (int)floor((float)(s.u - s.d) / (float)p.grid_size);
-    const int y = (int)floor((float)s.v / (float)p.grid_size);
-    if (x >= 0 && x < gw && y >= 0 && y < gh)
-      for (int d = d_min; d <= d_max; ++d) t1[y * gw + x].w[d >> 6] |= 1ull << (d & 63);
-  }
-  // 3x3 diffusion as the reference's nine marching pointers do it over the FLAT (cell, d) array: the
-  // offsets are whole cells, so it acts per disparity on the flat CELL index, rows wrapping, for
-  // cells c with c + 2*gw + 2 < gw*gh; the result lands on cell c + gw + 1.
-  const int o[9] = {0, 1, 2, gw, gw + 1, gw + 2, 2 * gw, 2 * gw + 1, 2 * gw + 2};
-  for (int c = 0; c + 2 * gw + 2 < ncell; ++c) {
-    Bits r{{0, 0, 0, 0}};
-    for (int k = 0; k < 9; ++k)
-      for (int q = 0; q < 4; ++q) r.w[q] |= t1[c + o[k]].w[q];
-    t2[c + gw + 1] = r;
-  }
-  const int gd = p.disp_max + 2;
-  grid.assign((size_t)gd * ncell, 0);
-  for (int c = 0; c < ncell; ++c) {
-    int32_t* cell = &grid[(size_t)c * gd];
-    int cur = 1;
-    for (int q = 0; q < 4; ++q) {
-      uint64_t m = t2[c].w[q];
-      while (m) { cell[cur++] = 64 * q + __builtin_ctzll(m); m &= m - 1; }
-    }
-    cell[0] = cur - 1;
-  }
 }
 
 // wall-clock profile entry for the host stages (reported next to the HIP-event kernel entries)
@@ -848,10 +857,27 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
       }
   }
   if (sp.size() < 3) return SVO_OK;   // *produced stays 0
+  // support points -> HBM; the disparity grids only need them, so the GPU builds the grids while the host
+  // triangulates
+  std::vector<int32_t> spflat(3 * sp.size());
+  for (size_t i = 0; i < sp.size(); ++i) { spflat[3 * i] = sp[i].u; spflat[3 * i + 1] = sp[i].v; spflat[3 * i + 2] = sp[i].d; }
+  const int ncell = st->gw * st->gh, nsp = (int)sp.size();
+  uint32_t* t1[2] = {reinterpret_cast<uint32_t*>(st->d_grid[0]), reinterpret_cast<uint32_t*>(st->d_grid[1])};
+  uint32_t* t2[2] = {t1[0] + (size_t)ncell * 8, t1[1] + (size_t)ncell * 8};
+  SVO_HIP(ctx, hipMemcpyAsync(st->d_sp, spflat.data(), spflat.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  for (int side = 0; side < 2; ++side) {
+    SVO_HIP(ctx, hipMemsetAsync(t1[side], 0, (size_t)ncell * 8 * sizeof(uint32_t), s));
+    SVO_HIP(ctx, hipMemsetAsync(st->d_owner[side], 0xff, n * sizeof(int32_t), s));
+  }
+  {
+    SvoTimer t(ctx, "k_elas_grid");
+    hipLaunchKernelGGL(k_elas_grid_mark, dim3((nsp + 255) / 256), dim3(256), 0, s, st->d_sp, nsp, p.grid_size, p.disp_max,
+                       st->gw, st->gh, t1[0], t1[1]);
+    hipLaunchKernelGGL(k_elas_grid_diffuse, dim3((ncell * 8 + 255) / 256, 2), dim3(256), 0, s, t1[0], t1[1], st->gw, st->gh,
+                       t2[0], t2[1]);
+  }
   std::vector<int32_t> tri[2];
-  std::vector<float> plane[2];
-  std::vector<int32_t> grid[2];
-  // the two images are independent from here to the upload: the right one runs on a second host thread
+  // the two triangulations are independent: the right image's runs on a second host thread
   const char* side_err[2] = {nullptr, nullptr};
   auto do_side = [&](int side) {
     const int32_t* tin = taps ? (side ? taps->tri2_in : taps->tri1_in) : nullptr;
@@ -870,29 +896,15 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
       if (r || nt > st->cap_tri) { side_err[side] = "svo_elas_process: triangulation failed"; return; }
       tri[side].resize((size_t)nt * 3);
     }
-    disparity_planes(sp, tri[side], plane[side]);
-    create_grid(sp, p, st->gw, st->gh, side == 1, grid[side]);
   };
   {
-    HostTimer ht(ctx, "host_elas_delaunay_planes_grid");
+    HostTimer ht(ctx, "host_elas_delaunay");
     std::thread right_side(do_side, 1);
     do_side(0);
     right_side.join();
   }
   for (int side = 0; side < 2; ++side)
-    if (side_err[side]) { ctx->last_error = side_err[side]; return SVO_E_INVALID; }
-  if (taps) {
-    taps->n_tri1 = (int32_t)tri[0].size() / 3; taps->n_tri2 = (int32_t)tri[1].size() / 3;
-    for (int side = 0; side < 2; ++side) {
-      const int nt = std::min<int>((int)tri[side].size() / 3, taps->cap_tri);
-      int32_t* ti = side ? taps->tri2 : taps->tri1;
-      float* pl = side ? taps->planes2 : taps->planes1;
-      int32_t* gr = side ? taps->grid2 : taps->grid1;
-      if (ti) memcpy(ti, tri[side].data(), (size_t)nt * 3 * sizeof(int32_t));
-      if (pl) memcpy(pl, plane[side].data(), (size_t)nt * 6 * sizeof(float));
-      if (gr) memcpy(gr, grid[side].data(), grid[side].size() * sizeof(int32_t));
-    }
-  }
+    if (side_err[side]) { hipStreamSynchronize(s); ctx->last_error = side_err[side]; return SVO_E_INVALID; }
   int32_t P[256];
   {
     const int disp_num = p.disp_max + 1;
@@ -902,22 +914,19 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
   }
   const int plane_radius = (int)std::max((float)ceil(p.sigma * p.sradius), (float)2.0);
 
-  // 3. upload, rasterise, match
+  // 3. triangles -> HBM, plane fit, rasterise, match
   std::unique_ptr<HostTimer> up2(new HostTimer(ctx, "host_elas_upload2_match_sync"));
-  std::vector<int32_t> spflat(3 * sp.size());
-  for (size_t i = 0; i < sp.size(); ++i) { spflat[3 * i] = sp[i].u; spflat[3 * i + 1] = sp[i].v; spflat[3 * i + 2] = sp[i].d; }
-  SVO_HIP(ctx, hipMemcpyAsync(st->d_sp, spflat.data(), spflat.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
   SVO_HIP(ctx, hipMemcpyAsync(st->d_P, P, sizeof P, hipMemcpyHostToDevice, s));
-  for (int side = 0; side < 2; ++side) {
-    if (!tri[side].empty()) {
+  for (int side = 0; side < 2; ++side)
+    if (!tri[side].empty())
       SVO_HIP(ctx, hipMemcpyAsync(st->d_tri[side], tri[side].data(), tri[side].size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-      SVO_HIP(ctx, hipMemcpyAsync(st->d_plane[side], plane[side].data(), plane[side].size() * sizeof(float), hipMemcpyHostToDevice, s));
-    }
-    SVO_HIP(ctx, hipMemcpyAsync(st->d_grid[side], grid[side].data(), grid[side].size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    SVO_HIP(ctx, hipMemsetAsync(st->d_owner[side], 0xff, n * sizeof(int32_t), s));
-  }
   const int nt0 = (int)tri[0].size() / 3, nt1 = (int)tri[1].size() / 3;
   if (std::max(nt0, nt1) > 0) {
+    {
+      SvoTimer t(ctx, "k_elas_planes");
+      hipLaunchKernelGGL(k_elas_planes, dim3((std::max(nt0, nt1) + 63) / 64, 2), dim3(64), 0, s, st->d_sp, st->d_tri[0],
+                         st->d_tri[1], nt0, nt1, st->d_plane[0], st->d_plane[1]);
+    }
     SvoTimer t(ctx, "k_elas_raster");
     hipLaunchKernelGGL(k_elas_raster, dim3((std::max(nt0, nt1) + 3) / 4, 2), dim3(256), 0, s, st->d_sp, st->d_tri[0],
                        st->d_tri[1], nt0, nt1, W, H, sub, st->d_owner[0], st->d_owner[1]);
@@ -926,11 +935,35 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
   {
     SvoTimer t(ctx, "k_elas_match");
     hipLaunchKernelGGL(k_elas_match, pix2, dim3(256), 0, s, st->d_desc[0], st->d_desc[1], st->d_owner[0], st->d_owner[1],
-                       st->d_plane[0], st->d_plane[1], st->d_grid[0], st->d_grid[1], st->d_P, W, H, st->gw, st->gd,
-                       plane_radius, p, st->d_D[0], st->d_D[1]);
+                       st->d_plane[0], st->d_plane[1], reinterpret_cast<const int32_t*>(t2[0]),
+                       reinterpret_cast<const int32_t*>(t2[1]), st->d_P, W, H, st->gw, st->gd, plane_radius, p, st->d_D[0],
+                       st->d_D[1]);
   }
   SVO_HIP(ctx, hipStreamSynchronize(s));   // host vectors above must outlive the async copies
   up2.reset();
+  if (taps) {
+    taps->n_tri1 = nt0; taps->n_tri2 = nt1;
+    for (int side = 0; side < 2; ++side) {
+      const int nt = std::min<int>((int)tri[side].size() / 3, taps->cap_tri);
+      int32_t* ti = side ? taps->tri2 : taps->tri1;
+      float* pl = side ? taps->planes2 : taps->planes1;
+      int32_t* gr = side ? taps->grid2 : taps->grid1;
+      if (ti) memcpy(ti, tri[side].data(), (size_t)nt * 3 * sizeof(int32_t));
+      if (pl && nt) SVO_HIP(ctx, hipMemcpy(pl, st->d_plane[side], (size_t)nt * 6 * sizeof(float), hipMemcpyDeviceToHost));
+      if (gr) {   // the reference's list layout: per cell [count, d0, d1, ...]
+        std::vector<uint32_t> bits((size_t)ncell * 8);
+        SVO_HIP(ctx, hipMemcpy(bits.data(), t2[side], bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        memset(gr, 0, (size_t)ncell * st->gd * sizeof(int32_t));
+        for (int c = 0; c < ncell; ++c) {
+          int32_t* cell = gr + (size_t)c * st->gd;
+          int cur = 1;
+          for (int q = 0; q < 8; ++q)
+            for (uint32_t m = bits[(size_t)c * 8 + q]; m; m &= m - 1) cell[cur++] = 32 * q + __builtin_ctz(m);
+          cell[0] = cur - 1;
+        }
+      }
+    }
+  }
   if (taps) { if ((rc = tap(ctx, taps->D1_raw, st->d_D[0], n))) return rc; if ((rc = tap(ctx, taps->D2_raw, st->d_D[1], n))) return rc; }
 
   // 4. post-processing

@@ -14,8 +14,8 @@ import svo_loader
 
 svo = svo_loader.load()
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(ob.ref_elas_lib() is None, reason="oracle/_ref not built")]
+pytestmark = [pytest.mark.gpu]
+needs_ref = pytest.mark.skipif(ob.ref_elas_lib() is None, reason="oracle/_ref not built")
 
 def cones_pair():
     """Middlebury `cones` at 900x750 (data files the reference ships under Thirdparty/libelas/img/):
@@ -62,6 +62,7 @@ def ctx():
     c.close()
 
 
+@needs_ref
 @pytest.mark.parametrize("middlebury", [False, True])
 @pytest.mark.parametrize("pair", sorted(PAIRS))
 def test_every_stage_bit_exact(ctx, pair, middlebury):
@@ -91,6 +92,7 @@ CUSTOM = [
 ]
 
 
+@needs_ref
 @pytest.mark.parametrize("custom", range(len(CUSTOM)))
 def test_non_default_parameters_bit_exact(ctx, custom):
     L, R = PAIRS["urban-small"]()
@@ -121,6 +123,7 @@ def test_textureless_pair_leaves_outputs_untouched(ctx):
     assert len(g["support"]) == 0 and (g["D1"] == 0).all() and (g["D2"] == 0).all()
 
 
+@needs_ref
 @pytest.mark.parametrize("middlebury", [False, True])
 @pytest.mark.parametrize("pair", ["urban-small", "urban-odd-size"])
 def test_subsampling_bit_exact(ctx, pair, middlebury):
@@ -147,3 +150,24 @@ def test_rejects_bad_parameters(ctx):
         setattr(p, field, value)
         with pytest.raises(svo.SvoError):
             ctx.elas_process(L, R, p)
+
+
+# ---- committed golden vectors (tests/golden/elas_vectors.npz, made by tests/golden/make_elas_golden.py from the
+# ---- compiled reference): this test needs no oracle/_ref at run time
+GOLD = np.load(__import__("os").path.join(util.GOLDEN, "elas_vectors.npz"))
+
+
+@pytest.mark.parametrize("name", ["small", "tiny"])
+@pytest.mark.parametrize("middlebury", [0, 1])
+def test_against_committed_reference_vectors(ctx, name, middlebury):
+    k = "%s_%d_" % (name, middlebury)
+    L, R = util.urban_pair(*[int(v) for v in GOLD[k + "crop"]])
+    g = ctx.elas_process(L, R, svo.elas_default_params(middlebury), taps=True)
+    assert np.array_equal(g["support"], GOLD[k + "support"])
+    assert np.array_equal(g["tri1"], GOLD[k + "tri1"]) and np.array_equal(g["tri2"], GOLD[k + "tri2"])
+    assert np.array_equal(g["D1"], GOLD[k + "D1"]) and np.array_equal(g["D2"], GOLD[k + "D2"])
+    # the untouched Elas::process differs from that only where Triangle's triangle ORDER matters
+    for side in ("1", "2"):
+        exp = GOLD[k + "D" + side].ravel().copy()
+        exp[GOLD[k + "process_diff_idx" + side]] = GOLD[k + "process_diff_val" + side]
+        assert (exp != g["D" + side].ravel()).sum() == len(GOLD[k + "process_diff_idx" + side]) <= 2

@@ -40,3 +40,23 @@ def test_ctmf_reference_builds():
     import ctypes, os
     so = os.path.join(os.path.dirname(ob.__file__), "_ref", "libref_ctmf.so")
     assert hasattr(ctypes.CDLL(so), "ctmf")
+
+
+def test_committed_elas_vectors_are_what_the_reference_produces():
+    """tests/golden/elas_vectors.npz (used by the GPU suite when oracle/_ref is absent) == the compiled
+    reference, re-run here."""
+    import os
+    G = np.load(os.path.join(util.GOLDEN, "elas_vectors.npz"))
+    for name in ("small", "tiny"):
+        for mb in (0, 1):
+            k = "%s_%d_" % (name, mb)
+            L, R = util.urban_pair(*[int(v) for v in G[k + "crop"]])
+            p = ob.ref_elas_params(bool(mb))
+            r = ob.ref_elas_staged(L, R, p, tri1=G[k + "tri1"], tri2=G[k + "tri2"])
+            assert np.array_equal(r["support"], G[k + "support"])
+            assert np.array_equal(r["D1"], G[k + "D1"]) and np.array_equal(r["D2"], G[k + "D2"])
+            D1, D2 = ob.ref_elas(L, R, p)
+            for side, D in (("1", D1), ("2", D2)):
+                exp = G[k + "D" + side].ravel().copy()
+                exp[G[k + "process_diff_idx" + side]] = G[k + "process_diff_val" + side]
+                assert np.array_equal(exp, D.ravel())

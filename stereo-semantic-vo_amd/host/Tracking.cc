@@ -99,9 +99,16 @@ void Tracking::SaveTrajectoryAndDraw(std::ofstream& f, std::ofstream& f2) {
 void Tracking::Track(const GrayImage& imLeft, const GrayImage& imRight, double timestamp, std::ofstream& f,
                      std::ofstream& f2, const std::vector<std::vector<int>>& detection_box) {
   currentframe = new frame(ctx, imLeft, imRight, timestamp, K, detection_box);
-  currentframe->MB(imLeft, imRight);      // featuredetect + stereo association in one device pass
-  currentframe->computekeypoint_r();
-  currentframe->disp2Depth(bf);
+  if (depth_source == 1) {                // src/Tracking.cc:225-228 literally: features, dense map, lookups
+    currentframe->featuredetect(imLeft);
+    currentframe->ElasMatch(imLeft, imRight);
+    currentframe->computekeypoint_r();
+    currentframe->disp2Depth(bf);
+  } else {
+    currentframe->MB(imLeft, imRight);    // featuredetect + stereo association in one device pass
+    currentframe->computekeypoint_r();
+    currentframe->disp2Depth(bf);
+  }
   currentframe->id = frame_num;
   Tracklastframe();
   SaveTrajectoryAndDraw(f, f2);

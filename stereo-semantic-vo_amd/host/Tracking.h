@@ -11,6 +11,9 @@ class Tracking {
   // Reads Camera.fx/fy/cx/cy/bf from an ORB-SLAM2-format yaml (the only five keys the reference
   // consumes, src/Tracking.cc:22-40) and creates the GPU context.
   Tracking(const std::string& strSettingPath, int device = 0);
+  // 0: sparse epipolar stereo (default); 1: the reference's live flow, a dense disparity map (libelas here,
+  // MSA there) -> disp2Depth -> per-keypoint lookups (src/Tracking.cc:226-228)
+  int depth_source = 0;
   Tracking(const svo_camera& cam, int width, int height, int device = 0);
   ~Tracking();
   void init();                                                          // src/Tracking.cc:42-97

@@ -100,8 +100,27 @@ int frame::ElasMatch(const GrayImage& left, const GrayImage& right) {
   return valid;
 }
 
-void frame::computekeypoint_r() { /* keypoints_r already holds the sub-pixel right x from MB() */ }
-void frame::disp2Depth(float) { /* kp_depth = bf / disparity was produced on the device by MB() */ }
+// src/frame.cc:122-138.  After MB() keypoints_r already holds the sub-pixel right x; after ElasMatch() it is read
+// off the dense map at the truncated keypoint position, as `dispimg.at<float>(ly, lx)` does.
+void frame::computekeypoint_r() {
+  if (dispimg.empty()) return;
+  const int n = (int)keypoints_l.size(), W = (int)width;
+  keypoints_r.assign(n, -1.f);
+  kp_disp.assign(n, -1.f);
+  for (int i = 0; i < n; ++i) {
+    const float d = dispimg[(size_t)(int)keypoints_l[i].y * W + (int)keypoints_l[i].x];
+    kp_disp[i] = d;
+    if (d != -1.f) keypoints_r[i] = keypoints_l[i].x - d;
+  }
+}
+// src/frame.cc:140-164: depth = bf / disp wherever disp != 0, else -1 (per keypoint here)
+void frame::disp2Depth(float bf_) {
+  if (dispimg.empty()) return;   // MB(): kp_depth was produced on the device
+  const int n = (int)keypoints_l.size();
+  kp_depth.assign(n, -1.f);
+  for (int i = 0; i < n; ++i)
+    if (kp_disp[i] != 0.f) kp_depth[i] = bf_ / kp_disp[i];
+}
 
 // src/frame.cc:166-180
 bool frame::UnprojectStereo(float u, float v, float z, Vec3f& x3D) const {

@@ -13,9 +13,10 @@
 using namespace svo_host;
 
 int main(int argc, char** argv) {
-  if (argc != 3) { std::cerr << "usage: host_check <sequence_dir> <n_frames>" << std::endl; return 2; }
+  if (argc != 3 && argc != 4) { std::cerr << "usage: host_check <sequence_dir> <n_frames> [dense]" << std::endl; return 2; }
   const std::string seq = argv[1];
   const int n = atoi(argv[2]);
+  const int depth_source = argc == 4 ? 1 : 0;   // "dense": ELAS map as the depth source on both sides
   const svo_camera cam{718.856f, 718.856f, 607.1928f, 185.2157f, 386.1448f};
   Tracking* host = nullptr;
   svo_ctx* dev = nullptr;
@@ -30,7 +31,9 @@ int main(int argc, char** argv) {
     if (!read_pgm(a.str(), L) || !read_pgm(b.str(), R)) { std::cerr << "cannot read " << a.str() << std::endl; return 2; }
     if (!host) {
       host = new Tracking(cam, L.cols, L.rows, 0);
+      host->depth_source = depth_source;
       if (svo_create(&dev, 0, L.cols, L.rows, 500, 1) != SVO_OK || svo_track_reset(dev, &cam) != SVO_OK) return 3;
+      if (svo_set_option(dev, "depth_source", depth_source) != SVO_OK) return 3;
     }
     if (k == 0) {   // frame::ElasMatch: dense disparity through the same context
       frame probe;

@@ -73,6 +73,12 @@ def test_host_classes_equal_device_tracker(pkg, tmp_path):
     assert abs(rows[-1, 11] - (n - 1)) < 0.5     # ~1 m per frame forward
     ev = [ln.split() for ln in p.stdout.splitlines() if ln.startswith("elas_valid")]
     assert ev and int(ev[0][1]) > 0.5 * int(ev[0][3])      # frame::ElasMatch: dense map mostly valid
+    # the same comparison with the dense ELAS map as the depth source on both sides (Tracking::depth_source = 1
+    # seam by seam vs svo_set_option("depth_source", 1))
+    p = subprocess.run([os.path.join(HOST, "host_check"), str(tmp_path), str(n), "dense"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    worst = [float(ln.split()[1]) for ln in p.stdout.splitlines() if ln.startswith("worst")]
+    assert worst and worst[0] < 1e-3
 
 
 @pytest.mark.gpu

@@ -331,6 +331,15 @@ int svo_elas_process(svo_ctx* ctx, const uint8_t* I1, const uint8_t* I2, float* 
 int svo_elas_process_ex(svo_ctx* ctx, const uint8_t* I1, const uint8_t* I2, float* D1, float* D2,
                         const int32_t* dims, const svo_elas_params* params, svo_elas_taps* taps);
 
+/* Throughput mode (no counterpart in the reference): B stereo pairs already in HBM (pair b at
+ * d_L/d_R + b * stride * height, `stride` bytes per row), dense maps for all of them into d_D1/d_D2 (HBM,
+ * pair b at + b * map size).  The small kernels of different pairs overlap on several HIP streams and the
+ * two sequential host stages (support point clean-up, triangulation) run on a pool of host threads.  Results
+ * are identical to B calls of svo_elas_process.  produced (host, B entries, may be NULL): 0 where a pair had
+ * fewer than 3 support points and its maps were left untouched.  Synchronises before it returns. */
+int svo_elas_batch_dev(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d_R, int stride, int width, int height,
+                       int B, const svo_elas_params* params, float* d_D1, float* d_D2, int32_t* produced);
+
 /* `Elas::computeDelaunayTriangulation` (elas.cpp:445-503 -> Triangle "zQB"): host-side, needs no GPU.
  * xy = n (x,y) int32 pairs; writes up to cap (c1,c2,c3) triples, counter-clockwise, in canonical order
  * (smallest index first, sorted); *n_tri = number of triangles. */

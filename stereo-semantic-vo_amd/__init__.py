@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "svo_frontend_batch_dev", "svo_track_batch_dev", "svo_profile_enable", "svo_profile_reset",
     "svo_profile_get",
     "svo_elas_default_params", "svo_elas_process", "svo_elas_process_ex", "svo_elas_delaunay",
-    "svo_ctmf", "svo_track_multi_reset", "svo_track_multi_step_dev",
+    "svo_ctmf", "svo_track_multi_reset", "svo_track_multi_step_dev", "svo_elas_batch_dev",
 ]
 
 
@@ -378,6 +378,14 @@ class Svo:
             o["tri" + s] = o["tri" + s][:n].copy(); o["planes" + s] = o["planes" + s][:n].copy()
         o["D1"] = D1; o["D2"] = D2
         return o
+
+    def elas_batch_dev(self, d_L, d_R, stride, W, H, B, d_D1, d_D2, params=None):
+        """B device-resident pairs -> B pairs of device-resident maps; returns the per-pair `produced` flags."""
+        params = params or elas_default_params(0)
+        produced = np.zeros(B, np.int32)
+        self._chk(self.lib.svo_elas_batch_dev(self.h, C.c_void_p(d_L), C.c_void_p(d_R), int(stride), int(W), int(H),
+                                              int(B), C.byref(params), C.c_void_p(d_D1), C.c_void_p(d_D2), _p(produced)))
+        return produced
 
     def ctmf(self, img, r):
         """Median filter of Thirdparty/MB/ctmf.c on an H x W or H x W x C uint8 image."""

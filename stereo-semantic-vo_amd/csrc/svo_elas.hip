@@ -19,9 +19,12 @@
 // really the bit pattern of 2^31f (0x4F000000).  Memory the reference reads without having written it
 // (descriptor rows/columns 2 and N-3; D_tmp of adaptiveMean) is defined as 0 here.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <memory>
 #include <thread>
@@ -50,15 +53,17 @@ struct ElasState {
   float* d_T[2] = {nullptr, nullptr};
   int32_t* d_lab = nullptr;
   int32_t* d_size = nullptr;
-  uint8_t* h_img = nullptr;   // pinned staging: 2 x W*H bytes in, 2 x W*H floats out
+  uint8_t* h_img = nullptr;   // pinned staging of the host API: 2 x W*H bytes in, 2 x W*H floats out
   float* h_D = nullptr;
+  int16_t* h_can = nullptr;   // pinned: lattice candidates back from the GPU
   std::vector<void*> allocs;
   void release() {
     for (void* p : allocs) hipFree(p);
     allocs.clear();
     if (h_img) hipHostFree(h_img);
     if (h_D) hipHostFree(h_D);
-    h_img = nullptr; h_D = nullptr;
+    if (h_can) hipHostFree(h_can);
+    h_img = nullptr; h_D = nullptr; h_can = nullptr;
     W = H = 0;
   }
 };
@@ -296,10 +301,22 @@ __device__ int cc_find(const int32_t* L, int i) {
   while (p != i) { i = p; p = cc_load(L, i); }
   return i;
 }
+// find with path halving: every visited node is re-pointed to its grandparent.  The plain store can race
+// with an atomicMin on the same entry only when that entry is not a root any more, and then either value is
+// an ancestor inside the same (already united or about to be re-united) set - cc_union re-reads and retries.
+__device__ int cc_find_halving(int32_t* L, int i) {
+  int p = cc_load(L, i);
+  while (p != i) {
+    const int gp = cc_load(L, p);
+    if (gp != p) __atomic_store_n(&L[i], gp, __ATOMIC_RELAXED);
+    i = p; p = gp;
+  }
+  return i;
+}
 __device__ void cc_union(int32_t* L, int a, int b) {
   bool done;
   do {
-    a = cc_find(L, a); b = cc_find(L, b);
+    a = cc_find_halving(L, a); b = cc_find_halving(L, b);
     if (a < b) { const int old = atomicMin(&L[b], a); done = old == b; b = old; }
     else if (b < a) { const int old = atomicMin(&L[a], b); done = old == a; a = old; }
     else done = true;
@@ -723,25 +740,33 @@ int dev_alloc(svo_ctx* ctx, ElasState* st, T** p, size_t count) {
   return SVO_OK;
 }
 
-int elas_prepare(svo_ctx* ctx, ElasState* st, int W, int H, const svo_elas_params& p) {
+// host_io: also the staging buffers of the host-buffer API (images in HBM, pinned in/out copies)
+int elas_prepare(svo_ctx* ctx, ElasState* st, int W, int H, const svo_elas_params& p, bool host_io) {
   int step = p.candidate_stepsize;
   if (p.subsampling) step += step % 2;   // elas.cpp:379-381: at half resolution only every second line exists
   const int Wc = (W + step - 1) / step, Hc = (H + step - 1) / step;
   const int gw = (int)ceil((float)W / (float)p.grid_size), gh = (int)ceil((float)H / (float)p.grid_size);
   const int gd = p.disp_max + 2;
-  if (st->W == W && st->H == H && st->Wc == Wc && st->Hc == Hc && st->gw == gw && st->gh == gh && st->gd == gd)
-    return SVO_OK;
-  st->release();
   const size_t n = (size_t)W * H;
+  if (st->W == W && st->H == H && st->Wc == Wc && st->Hc == Hc && st->gw == gw && st->gh == gh && st->gd == gd) {
+    if (host_io && !st->h_img) {
+      int rc;
+      for (int s = 0; s < 2; ++s)
+        if ((rc = dev_alloc(ctx, st, &st->d_img[s], n))) return rc;
+      SVO_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&st->h_img), 2 * n, hipHostMallocDefault));
+      SVO_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&st->h_D), 2 * n * sizeof(float), hipHostMallocDefault));
+    }
+    return SVO_OK;
+  }
+  st->release();
   st->cap_sp = Wc * Hc + 8;
   st->cap_tri = 2 * st->cap_sp + 16;
   int rc;
   for (int s = 0; s < 2; ++s) {
-    if ((rc = dev_alloc(ctx, st, &st->d_img[s], n))) return rc;
     if ((rc = dev_alloc(ctx, st, &st->d_desc[s], n))) return rc;
     if ((rc = dev_alloc(ctx, st, &st->d_tri[s], (size_t)st->cap_tri * 3))) return rc;
     if ((rc = dev_alloc(ctx, st, &st->d_plane[s], (size_t)st->cap_tri * 6))) return rc;
-    if ((rc = dev_alloc(ctx, st, &st->d_grid[s], (size_t)gw * gh * gd))) return rc;
+    if ((rc = dev_alloc(ctx, st, &st->d_grid[s], (size_t)gw * gh * 16))) return rc;   // two 256-bit sets per cell
     if ((rc = dev_alloc(ctx, st, &st->d_owner[s], n))) return rc;
     if ((rc = dev_alloc(ctx, st, &st->d_D[s], n))) return rc;
     if ((rc = dev_alloc(ctx, st, &st->d_T[s], n))) return rc;
@@ -751,28 +776,19 @@ int elas_prepare(svo_ctx* ctx, ElasState* st, int W, int H, const svo_elas_param
   if ((rc = dev_alloc(ctx, st, &st->d_P, 256))) return rc;
   if ((rc = dev_alloc(ctx, st, &st->d_lab, n))) return rc;
   if ((rc = dev_alloc(ctx, st, &st->d_size, n))) return rc;
-  SVO_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&st->h_img), 2 * n, hipHostMallocDefault));
-  SVO_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&st->h_D), 2 * n * sizeof(float), hipHostMallocDefault));
+  SVO_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&st->h_can), (size_t)Wc * Hc * sizeof(int16_t), hipHostMallocDefault));
   st->W = W; st->H = H; st->Wc = Wc; st->Hc = Hc; st->gw = gw; st->gh = gh; st->gd = gd;
-  return SVO_OK;
+  return host_io ? elas_prepare(ctx, st, W, H, p, true) : SVO_OK;   // second pass adds the staging buffers
 }
 
-int tap(svo_ctx* ctx, float* dst, const float* src, size_t n) {
+int tap(svo_ctx* ctx, hipStream_t s, float* dst, const float* src, size_t n) {
   if (!dst) return SVO_OK;
-  SVO_HIP(ctx, hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  SVO_HIP(ctx, hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToHost, s));
+  SVO_HIP(ctx, hipStreamSynchronize(s));
   return SVO_OK;
 }
 
 }  // namespace
-
-extern "C" void svo_elas_release(svo_ctx* ctx) {
-  if (!ctx || !ctx->elas) return;
-  ElasState* st = reinterpret_cast<ElasState*>(ctx->elas);
-  st->release();
-  delete st;
-  ctx->elas = nullptr;
-}
 
 extern "C" int svo_elas_default_params(int32_t setting, svo_elas_params* q) {
   if (!q || (setting != 0 && setting != 1)) return SVO_E_INVALID;
@@ -799,112 +815,113 @@ int elas_check(svo_ctx* ctx, int W, int H, int pitch, const svo_elas_params& p) 
   return SVO_OK;
 }
 
-// Everything between the images in HBM (dL, dR, `pitch` bytes per row) and the two final disparity maps
-// in HBM (*outD1, *outD2; valid until the next call).  *produced = 0 when there are fewer than 3
-// support points (the reference then leaves its outputs untouched).
-int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR, int pitch, int W, int H,
-              const svo_elas_params& p, svo_elas_taps* taps, float** outD1, float** outD2, int* produced) {
-  hipStream_t s = ctx->stream;
-  const int sub = p.subsampling;
-  const int Wd = sub ? W / 2 : W, Hd = sub ? H / 2 : H;   // disparity map size (elas.h:157-160)
-  const size_t n = (size_t)Wd * Hd;
+// What the host stages of one pair produce (kept alive until the pair's uploads have completed).
+struct ElasWork {
+  std::vector<SupportPt> sp;
+  std::vector<int32_t> spflat, tri[2];
+  const char* err = nullptr;
+};
+
+// Phase A: descriptors of both images and the lattice candidates, then the candidates on their way back
+// to pinned host memory.  Enqueues on `s`, does not synchronise.
+int elas_phase_a(svo_ctx* ctx, ElasState* st, hipStream_t s, const uint8_t* dL, const uint8_t* dR, int pitch, int W,
+                 int H, const svo_elas_params& p) {
   const int Wc = st->Wc, Hc = st->Hc;
-  const int step = p.candidate_stepsize + (sub ? p.candidate_stepsize % 2 : 0);
-  svo_elas_params pk = p;   // what the kernels see: the lattice step already adjusted
-  pk.candidate_stepsize = step;
-  int rc;
-  *produced = 0;
+  svo_elas_params pk = p;   // what the kernels see: the lattice step already adjusted (elas.cpp:379-381)
+  pk.candidate_stepsize = p.candidate_stepsize + (p.subsampling ? p.candidate_stepsize % 2 : 0);
   {
     SvoTimer t(ctx, "k_elas_desc");
     hipLaunchKernelGGL(k_elas_desc, dim3((W + DT_X - 1) / DT_X, (H + DT_Y - 1) / DT_Y, 2), dim3(256), 0, s,
                        dL, dR, pitch, W, H, p.subsampling, st->d_desc[0], st->d_desc[1]);
   }
-  std::vector<int16_t> can((size_t)Wc * Hc, 0);   // calloc'ed in the reference: row 0 / column 0 stay 0
-  SVO_HIP(ctx, hipMemsetAsync(st->d_can, 0, can.size() * sizeof(int16_t), s));
+  // calloc'ed in the reference: row 0 / column 0 of the lattice stay 0
+  SVO_HIP(ctx, hipMemsetAsync(st->d_can, 0, (size_t)Wc * Hc * sizeof(int16_t), s));
   if (Wc > 1 && Hc > 1) {
     SvoTimer t(ctx, "k_elas_support");
     const int ncand = (Wc - 1) * (Hc - 1);
     hipLaunchKernelGGL(k_elas_support, dim3((ncand + 3) / 4), dim3(256), 0, s, st->d_desc[0], st->d_desc[1], W, H,
                        Wc, Hc, pk, st->d_can);
   }
-  {
-    HostTimer ht(ctx, "host_elas_wait_candidates");
-    SVO_HIP(ctx, hipMemcpyAsync(can.data(), st->d_can, can.size() * sizeof(int16_t), hipMemcpyDeviceToHost, s));
-    SVO_HIP(ctx, hipStreamSynchronize(s));
-  }
-  if (taps) {
-    if (taps->desc1) SVO_HIP(ctx, hipMemcpy(taps->desc1, st->d_desc[0], (size_t)W * H * 16, hipMemcpyDeviceToHost));
-    if (taps->desc2) SVO_HIP(ctx, hipMemcpy(taps->desc2, st->d_desc[1], (size_t)W * H * 16, hipMemcpyDeviceToHost));
-  }
+  SVO_HIP(ctx, hipMemcpyAsync(st->h_can, st->d_can, (size_t)Wc * Hc * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+  return SVO_OK;
+}
 
-  // 2. host: support point clean-up, triangulation, planes, grids
-  std::vector<SupportPt> sp;
-  {
-    HostTimer ht(ctx, "host_elas_support_filter");
-    remove_inconsistent(can, Wc, Hc, p);
-    remove_redundant(can, Wc, Hc, 5, 1, true);
-    remove_redundant(can, Wc, Hc, 5, 1, false);
-    for (int u = 1; u < Wc; ++u)
-      for (int v = 1; v < Hc; ++v)
-        if (can[v * Wc + u] >= 0) sp.push_back({u * step, v * step, can[v * Wc + u]});
-    if (p.add_corners) add_corner_points(sp, W, H);
-  }
-  if (taps) {
-    taps->n_support = (int32_t)sp.size();
-    if (taps->support)
-      for (int i = 0; i < std::min<int>(taps->n_support, taps->cap_support); ++i) {
-        taps->support[3 * i] = sp[i].u; taps->support[3 * i + 1] = sp[i].v; taps->support[3 * i + 2] = sp[i].d;
-      }
-  }
-  if (sp.size() < 3) return SVO_OK;   // *produced stays 0
-  // support points -> HBM; the disparity grids only need them, so the GPU builds the grids while the host
-  // triangulates
-  std::vector<int32_t> spflat(3 * sp.size());
-  for (size_t i = 0; i < sp.size(); ++i) { spflat[3 * i] = sp[i].u; spflat[3 * i + 1] = sp[i].v; spflat[3 * i + 2] = sp[i].d; }
-  const int ncell = st->gw * st->gh, nsp = (int)sp.size();
-  uint32_t* t1[2] = {reinterpret_cast<uint32_t*>(st->d_grid[0]), reinterpret_cast<uint32_t*>(st->d_grid[1])};
-  uint32_t* t2[2] = {t1[0] + (size_t)ncell * 8, t1[1] + (size_t)ncell * 8};
-  SVO_HIP(ctx, hipMemcpyAsync(st->d_sp, spflat.data(), spflat.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-  for (int side = 0; side < 2; ++side) {
-    SVO_HIP(ctx, hipMemsetAsync(t1[side], 0, (size_t)ncell * 8 * sizeof(uint32_t), s));
-    SVO_HIP(ctx, hipMemsetAsync(st->d_owner[side], 0xff, n * sizeof(int32_t), s));
-  }
-  {
-    SvoTimer t(ctx, "k_elas_grid");
-    hipLaunchKernelGGL(k_elas_grid_mark, dim3((nsp + 255) / 256), dim3(256), 0, s, st->d_sp, nsp, p.grid_size, p.disp_max,
-                       st->gw, st->gh, t1[0], t1[1]);
-    hipLaunchKernelGGL(k_elas_grid_diffuse, dim3((ncell * 8 + 255) / 256, 2), dim3(256), 0, s, t1[0], t1[1], st->gw, st->gh,
-                       t2[0], t2[1]);
-  }
-  std::vector<int32_t> tri[2];
-  // the two triangulations are independent: the right image's runs on a second host thread
-  const char* side_err[2] = {nullptr, nullptr};
+// Host stage 1: the order-dependent clean-up of the lattice candidates -> support point list.
+void elas_filter(const ElasState* st, int W, int H, const svo_elas_params& p, ElasWork& w) {
+  const int Wc = st->Wc, Hc = st->Hc;
+  const int step = p.candidate_stepsize + (p.subsampling ? p.candidate_stepsize % 2 : 0);
+  std::vector<int16_t> can(st->h_can, st->h_can + (size_t)Wc * Hc);
+  remove_inconsistent(can, Wc, Hc, p);
+  remove_redundant(can, Wc, Hc, 5, 1, true);
+  remove_redundant(can, Wc, Hc, 5, 1, false);
+  for (int u = 1; u < Wc; ++u)
+    for (int v = 1; v < Hc; ++v)
+      if (can[v * Wc + u] >= 0) w.sp.push_back({u * step, v * step, can[v * Wc + u]});
+  if (p.add_corners) add_corner_points(w.sp, W, H);
+  w.spflat.resize(3 * w.sp.size());
+  for (size_t i = 0; i < w.sp.size(); ++i) { w.spflat[3 * i] = w.sp[i].u; w.spflat[3 * i + 1] = w.sp[i].v; w.spflat[3 * i + 2] = w.sp[i].d; }
+}
+
+// Host stage 2: the two Delaunay triangulations (or the lists a test injects).
+void elas_triangulate(const ElasState* st, const svo_elas_taps* taps, ElasWork& w, bool two_threads) {
   auto do_side = [&](int side) {
     const int32_t* tin = taps ? (side ? taps->tri2_in : taps->tri1_in) : nullptr;
     if (tin) {
       const int nt = side ? taps->n_tri2_in : taps->n_tri1_in;
-      if (nt > st->cap_tri) { side_err[side] = "svo_elas_process: too many triangles"; return; }
+      if (nt > st->cap_tri) { w.err = "svo_elas_process: too many triangles"; return; }
       for (int i = 0; i < 3 * nt; ++i)
-        if (tin[i] < 0 || tin[i] >= (int)sp.size()) { side_err[side] = "svo_elas_process: bad triangle index"; return; }
-      tri[side].assign(tin, tin + 3 * (size_t)nt);
-    } else {
-      std::vector<int32_t> xy(2 * sp.size());
-      for (size_t i = 0; i < sp.size(); ++i) { xy[2 * i] = side ? sp[i].u - sp[i].d : sp[i].u; xy[2 * i + 1] = sp[i].v; }
-      tri[side].resize((size_t)st->cap_tri * 3);
-      int32_t nt = 0;
-      const int r = svo_elas_delaunay(xy.data(), (int32_t)sp.size(), tri[side].data(), st->cap_tri, &nt);
-      if (r || nt > st->cap_tri) { side_err[side] = "svo_elas_process: triangulation failed"; return; }
-      tri[side].resize((size_t)nt * 3);
+        if (tin[i] < 0 || tin[i] >= (int)w.sp.size()) { w.err = "svo_elas_process: bad triangle index"; return; }
+      w.tri[side].assign(tin, tin + 3 * (size_t)nt);
+      return;
     }
+    std::vector<int32_t> xy(2 * w.sp.size());
+    for (size_t i = 0; i < w.sp.size(); ++i) { xy[2 * i] = side ? w.sp[i].u - w.sp[i].d : w.sp[i].u; xy[2 * i + 1] = w.sp[i].v; }
+    w.tri[side].resize((size_t)st->cap_tri * 3);
+    int32_t nt = 0;
+    const int r = svo_elas_delaunay(xy.data(), (int32_t)w.sp.size(), w.tri[side].data(), st->cap_tri, &nt);
+    if (r || nt > st->cap_tri) { w.err = "svo_elas_process: triangulation failed"; w.tri[side].clear(); return; }
+    w.tri[side].resize((size_t)nt * 3);
   };
-  {
-    HostTimer ht(ctx, "host_elas_delaunay");
+  if (two_threads) {   // the two images are independent: the right one runs on a second host thread
     std::thread right_side(do_side, 1);
     do_side(0);
     right_side.join();
+  } else {
+    do_side(0);
+    do_side(1);
   }
-  for (int side = 0; side < 2; ++side)
-    if (side_err[side]) { hipStreamSynchronize(s); ctx->last_error = side_err[side]; return SVO_E_INVALID; }
+}
+
+// Phase B, first part: support points -> HBM and the disparity grids, which need nothing else - so in the
+// one-pair path the GPU builds them while the host triangulates.
+int elas_phase_b_grids(svo_ctx* ctx, ElasState* st, hipStream_t s, size_t nd, const svo_elas_params& p, const ElasWork& w) {
+  const int ncell = st->gw * st->gh, nsp = (int)w.sp.size();
+  uint32_t* t1[2] = {reinterpret_cast<uint32_t*>(st->d_grid[0]), reinterpret_cast<uint32_t*>(st->d_grid[1])};
+  SVO_HIP(ctx, hipMemcpyAsync(st->d_sp, w.spflat.data(), w.spflat.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  for (int side = 0; side < 2; ++side) {
+    SVO_HIP(ctx, hipMemsetAsync(t1[side], 0, (size_t)ncell * 8 * sizeof(uint32_t), s));
+    SVO_HIP(ctx, hipMemsetAsync(st->d_owner[side], 0xff, nd * sizeof(int32_t), s));
+  }
+  SvoTimer t(ctx, "k_elas_grid");
+  hipLaunchKernelGGL(k_elas_grid_mark, dim3((nsp + 255) / 256), dim3(256), 0, s, st->d_sp, nsp, p.grid_size, p.disp_max,
+                     st->gw, st->gh, t1[0], t1[1]);
+  hipLaunchKernelGGL(k_elas_grid_diffuse, dim3((ncell * 8 + 255) / 256, 2), dim3(256), 0, s, t1[0], t1[1], st->gw, st->gh,
+                     t1[0] + (size_t)ncell * 8, t1[1] + (size_t)ncell * 8);
+  return SVO_OK;
+}
+
+// Phase B, second part: triangles -> HBM, plane fits, dense matching and all post-processing.  The final
+// maps are built in place in D1 / D2 (device memory, Wd*Hd floats each).  With taps it synchronises after
+// every stage, otherwise it only enqueues on `s`.
+int elas_phase_b(svo_ctx* ctx, ElasState* st, hipStream_t s, int W, int H, const svo_elas_params& p, const ElasWork& w,
+                 svo_elas_taps* taps, float* D1, float* D2) {
+  const int sub = p.subsampling;
+  const int Wd = sub ? W / 2 : W, Hd = sub ? H / 2 : H;   // disparity map size (elas.h:157-160)
+  const size_t n = (size_t)Wd * Hd;
+  const int ncell = st->gw * st->gh;
+  uint32_t* t2[2] = {reinterpret_cast<uint32_t*>(st->d_grid[0]) + (size_t)ncell * 8,
+                     reinterpret_cast<uint32_t*>(st->d_grid[1]) + (size_t)ncell * 8};
+  int rc;
   int32_t P[256];
   {
     const int disp_num = p.disp_max + 1;
@@ -913,14 +930,11 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
       P[dd] = dd < disp_num ? (int32_t)((-logf(p.gamma + expf(-dd * dd / two_sigma_squared)) + logf(p.gamma)) / p.beta) : 0;
   }
   const int plane_radius = (int)std::max((float)ceil(p.sigma * p.sradius), (float)2.0);
-
-  // 3. triangles -> HBM, plane fit, rasterise, match
-  std::unique_ptr<HostTimer> up2(new HostTimer(ctx, "host_elas_upload2_match_sync"));
-  SVO_HIP(ctx, hipMemcpyAsync(st->d_P, P, sizeof P, hipMemcpyHostToDevice, s));
+  SVO_HIP(ctx, hipMemcpyAsync(st->d_P, P, sizeof P, hipMemcpyHostToDevice, s));   // pageable: staged before it returns
   for (int side = 0; side < 2; ++side)
-    if (!tri[side].empty())
-      SVO_HIP(ctx, hipMemcpyAsync(st->d_tri[side], tri[side].data(), tri[side].size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-  const int nt0 = (int)tri[0].size() / 3, nt1 = (int)tri[1].size() / 3;
+    if (!w.tri[side].empty())
+      SVO_HIP(ctx, hipMemcpyAsync(st->d_tri[side], w.tri[side].data(), w.tri[side].size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  const int nt0 = (int)w.tri[0].size() / 3, nt1 = (int)w.tri[1].size() / 3;
   if (std::max(nt0, nt1) > 0) {
     {
       SvoTimer t(ctx, "k_elas_planes");
@@ -939,16 +953,15 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
                        reinterpret_cast<const int32_t*>(t2[1]), st->d_P, W, H, st->gw, st->gd, plane_radius, p, st->d_D[0],
                        st->d_D[1]);
   }
-  SVO_HIP(ctx, hipStreamSynchronize(s));   // host vectors above must outlive the async copies
-  up2.reset();
   if (taps) {
+    SVO_HIP(ctx, hipStreamSynchronize(s));
     taps->n_tri1 = nt0; taps->n_tri2 = nt1;
     for (int side = 0; side < 2; ++side) {
-      const int nt = std::min<int>((int)tri[side].size() / 3, taps->cap_tri);
+      const int nt = std::min<int>((int)w.tri[side].size() / 3, taps->cap_tri);
       int32_t* ti = side ? taps->tri2 : taps->tri1;
       float* pl = side ? taps->planes2 : taps->planes1;
       int32_t* gr = side ? taps->grid2 : taps->grid1;
-      if (ti) memcpy(ti, tri[side].data(), (size_t)nt * 3 * sizeof(int32_t));
+      if (ti) memcpy(ti, w.tri[side].data(), (size_t)nt * 3 * sizeof(int32_t));
       if (pl && nt) SVO_HIP(ctx, hipMemcpy(pl, st->d_plane[side], (size_t)nt * 6 * sizeof(float), hipMemcpyDeviceToHost));
       if (gr) {   // the reference's list layout: per cell [count, d0, d1, ...]
         std::vector<uint32_t> bits((size_t)ncell * 8);
@@ -963,17 +976,18 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
         }
       }
     }
+    if ((rc = tap(ctx, s, taps->D1_raw, st->d_D[0], n))) return rc;
+    if ((rc = tap(ctx, s, taps->D2_raw, st->d_D[1], n))) return rc;
   }
-  if (taps) { if ((rc = tap(ctx, taps->D1_raw, st->d_D[0], n))) return rc; if ((rc = tap(ctx, taps->D2_raw, st->d_D[1], n))) return rc; }
 
-  // 4. post-processing
-  float* D[2] = {st->d_T[0], st->d_T[1]};       // current maps
-  float* T[2] = {st->d_D[0], st->d_D[1]};       // scratch
+  // post-processing, in place in D[side]; the raw maps become scratch
+  float* D[2] = {D1, D2};
+  float* T[2] = {st->d_D[0], st->d_D[1]};
   {
     SvoTimer t(ctx, "k_elas_lr");
     hipLaunchKernelGGL(k_elas_lr, pix, dim3(256), 0, s, st->d_D[0], st->d_D[1], Wd, Hd, p.lr_threshold, sub, D[0], D[1]);
   }
-  if (taps) { if ((rc = tap(ctx, taps->D1_lr, D[0], n))) return rc; if ((rc = tap(ctx, taps->D2_lr, D[1], n))) return rc; }
+  if (taps) { if ((rc = tap(ctx, s, taps->D1_lr, D[0], n))) return rc; if ((rc = tap(ctx, s, taps->D2_lr, D[1], n))) return rc; }
   const int nsides = p.postprocess_only_left ? 1 : 2;
   // elas.cpp:986-991, 1107-1111: thresholds of the half-resolution maps
   const int speckle_size = sub ? (int)(sqrtf((float)p.speckle_size) * 2) : p.speckle_size;
@@ -987,32 +1001,103 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
     hipLaunchKernelGGL(k_cc_count, dim3(nb), dim3(256), 0, s, (int)n, st->d_lab, rlen, st->d_size);
     hipLaunchKernelGGL(k_cc_apply, dim3(nb), dim3(256), 0, s, D[side], (int)n, st->d_lab, st->d_size, speckle_size);
   }
-  if (taps) { if ((rc = tap(ctx, taps->D1_seg, D[0], n))) return rc; if ((rc = tap(ctx, taps->D2_seg, D[1], n))) return rc; }
+  if (taps) { if ((rc = tap(ctx, s, taps->D1_seg, D[0], n))) return rc; if ((rc = tap(ctx, s, taps->D2_seg, D[1], n))) return rc; }
   for (int side = 0; side < nsides; ++side) {
     SvoTimer t(ctx, "k_elas_gap");
     hipLaunchKernelGGL(k_elas_gap, dim3(Hd), dim3(256), 0, s, D[side], Wd, 1, Wd, gap_width, p.add_corners);
     hipLaunchKernelGGL(k_elas_gap, dim3(Wd), dim3(256), 0, s, D[side], Hd, Wd, 1, gap_width, p.add_corners);
   }
-  if (taps) { if ((rc = tap(ctx, taps->D1_gap, D[0], n))) return rc; if ((rc = tap(ctx, taps->D2_gap, D[1], n))) return rc; }
+  if (taps) { if ((rc = tap(ctx, s, taps->D1_gap, D[0], n))) return rc; if ((rc = tap(ctx, s, taps->D2_gap, D[1], n))) return rc; }
   if (p.filter_adaptive_mean)
     for (int side = 0; side < nsides; ++side) {
       SvoTimer t(ctx, "k_elas_mean");
       hipLaunchKernelGGL(k_elas_mean_h, pix, dim3(256), 0, s, D[side], Wd, Hd, sub, T[side]);
       hipLaunchKernelGGL(k_elas_mean_v, pix, dim3(256), 0, s, T[side], Wd, Hd, sub, D[side]);
     }
-  if (taps) { if ((rc = tap(ctx, taps->D1_mean, D[0], n))) return rc; if ((rc = tap(ctx, taps->D2_mean, D[1], n))) return rc; }
+  if (taps) { if ((rc = tap(ctx, s, taps->D1_mean, D[0], n))) return rc; if ((rc = tap(ctx, s, taps->D2_mean, D[1], n))) return rc; }
   if (p.filter_median)
     for (int side = 0; side < nsides; ++side) {
       SvoTimer t(ctx, "k_elas_median");
       hipLaunchKernelGGL(k_elas_median_h, pix, dim3(256), 0, s, D[side], Wd, Hd, T[side]);
       hipLaunchKernelGGL(k_elas_median_v, pix, dim3(256), 0, s, T[side], Wd, Hd, D[side]);
     }
-  *outD1 = D[0]; *outD2 = D[1];
+  return SVO_OK;
+}
+
+// One pair, latency first: everything between the images in HBM (dL, dR, `pitch` bytes per row) and the two
+// final disparity maps in HBM (st->d_T[0], st->d_T[1]; valid until the next call).  *produced = 0 when there
+// are fewer than 3 support points (the reference then leaves its outputs untouched).
+int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR, int pitch, int W, int H,
+              const svo_elas_params& p, svo_elas_taps* taps, float** outD1, float** outD2, int* produced) {
+  hipStream_t s = ctx->stream;
+  const size_t nd = p.subsampling ? (size_t)(W / 2) * (H / 2) : (size_t)W * H;
+  int rc;
+  *produced = 0;
+  if ((rc = elas_phase_a(ctx, st, s, dL, dR, pitch, W, H, p))) return rc;
+  {
+    HostTimer ht(ctx, "host_elas_wait_candidates");
+    SVO_HIP(ctx, hipStreamSynchronize(s));
+  }
+  if (taps) {
+    if (taps->desc1) SVO_HIP(ctx, hipMemcpy(taps->desc1, st->d_desc[0], (size_t)W * H * 16, hipMemcpyDeviceToHost));
+    if (taps->desc2) SVO_HIP(ctx, hipMemcpy(taps->desc2, st->d_desc[1], (size_t)W * H * 16, hipMemcpyDeviceToHost));
+  }
+  ElasWork w;
+  {
+    HostTimer ht(ctx, "host_elas_support_filter");
+    elas_filter(st, W, H, p, w);
+  }
+  if (taps) {
+    taps->n_support = (int32_t)w.sp.size();
+    if (taps->support)
+      memcpy(taps->support, w.spflat.data(), sizeof(int32_t) * 3 * std::min<size_t>(w.sp.size(), (size_t)std::max(taps->cap_support, 0)));
+  }
+  if (w.sp.size() < 3) return SVO_OK;   // *produced stays 0
+  if ((rc = elas_phase_b_grids(ctx, st, s, nd, p, w))) return rc;
+  {
+    HostTimer ht(ctx, "host_elas_delaunay");
+    elas_triangulate(st, taps, w, true);
+  }
+  if (w.err) { hipStreamSynchronize(s); ctx->last_error = w.err; return SVO_E_INVALID; }
+  {
+    HostTimer ht(ctx, "host_elas_upload2_match_sync");
+    rc = elas_phase_b(ctx, st, s, W, H, p, w, taps, st->d_T[0], st->d_T[1]);
+    hipStreamSynchronize(s);   // `w` must outlive its uploads; the callers read the maps next anyway
+  }
+  if (rc) return rc;
+  *outD1 = st->d_T[0]; *outD2 = st->d_T[1];
   *produced = 1;
   return SVO_OK;
 }
 
+// ---- many pairs at once -----------------------------------------------------------------------------
+// One ElasState ("slot") per pair of the batch and a few HIP streams: the small kernels of different pairs
+// overlap on the GPU, the two sequential host stages of different pairs run on a pool of host threads.
+struct ElasBatch {
+  std::vector<ElasState*> slots;
+  std::vector<hipStream_t> streams;
+  ~ElasBatch() {
+    for (ElasState* st : slots) { st->release(); delete st; }
+    for (hipStream_t s : streams) hipStreamDestroy(s);
+  }
+};
+#define ELAS_BATCH_STREAMS 8
+
 }  // namespace
+
+extern "C" void svo_elas_release(svo_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->elas) {
+    ElasState* st = reinterpret_cast<ElasState*>(ctx->elas);
+    st->release();
+    delete st;
+    ctx->elas = nullptr;
+  }
+  if (ctx->elas_batch) {
+    delete reinterpret_cast<ElasBatch*>(ctx->elas_batch);
+    ctx->elas_batch = nullptr;
+  }
+}
 
 // Device-resident entry used by the tracker (svo_track.hip): images already in HBM, maps stay in HBM.
 int svo_elas_run_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int pitch, int W, int H,
@@ -1021,8 +1106,84 @@ int svo_elas_run_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int pit
   if (rc) return rc;
   if (!ctx->elas) ctx->elas = new ElasState();
   ElasState* st = reinterpret_cast<ElasState*>(ctx->elas);
-  if ((rc = elas_prepare(ctx, st, W, H, *params))) return rc;
+  if ((rc = elas_prepare(ctx, st, W, H, *params, false))) return rc;
   return elas_core(ctx, st, dL, dR, pitch, W, H, *params, nullptr, dD1, dD2, produced);
+}
+
+extern "C" int svo_elas_batch_dev(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d_R, int stride, int W, int H,
+                                  int B, const svo_elas_params* params, float* d_D1, float* d_D2, int32_t* produced) {
+  if (!ctx) return SVO_E_INVALID;
+  if (!d_L || !d_R || !d_D1 || !d_D2 || !params || B < 1) { ctx->last_error = "svo_elas_batch_dev: invalid argument"; return SVO_E_INVALID; }
+  const svo_elas_params p = *params;
+  int rc = elas_check(ctx, W, H, stride, p);
+  if (rc) return rc;
+  SVO_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->elas_batch) ctx->elas_batch = new ElasBatch();
+  ElasBatch* eb = reinterpret_cast<ElasBatch*>(ctx->elas_batch);
+  while ((int)eb->streams.size() < std::min(B, ELAS_BATCH_STREAMS)) {
+    hipStream_t s = nullptr;
+    SVO_HIP(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    eb->streams.push_back(s);
+  }
+  while ((int)eb->slots.size() < B) eb->slots.push_back(new ElasState());
+  for (int b = 0; b < B; ++b)
+    if ((rc = elas_prepare(ctx, eb->slots[b], W, H, p, false))) return rc;
+  const size_t nd = p.subsampling ? (size_t)(W / 2) * (H / 2) : (size_t)W * H;
+  const size_t img = (size_t)stride * H;
+  const int ns = (int)eb->streams.size();
+  const bool prof = ctx->profiling;
+  ctx->profiling = false;   // the HIP-event timers assume the context's own stream
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));   // inputs produced on the context's stream are complete
+  // phase A for every pair
+  const bool dbg = getenv("SVO_ELAS_BATCH_DEBUG") != nullptr;
+  auto tnow = []() { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count(); };
+  const auto t0 = tnow();
+  for (int b = 0; b < B && rc == SVO_OK; ++b)
+    rc = elas_phase_a(ctx, eb->slots[b], eb->streams[b % ns], d_L + b * img, d_R + b * img, stride, W, H, p);
+  const auto t1 = tnow();
+  for (hipStream_t s : eb->streams) hipStreamSynchronize(s);
+  const auto t2 = tnow();
+  // a pool of host threads, one pair at a time each: the two host stages, then that pair's phase B enqueued
+  // straight away on its stream (maps built in place in the caller's buffers) - host work, launches and GPU
+  // work of different pairs overlap
+  std::vector<ElasWork> work(B);
+  std::vector<int> prc(B, SVO_OK);
+  if (rc == SVO_OK) {
+    const int nthreads = std::max(1, std::min<int>(B, std::min(32u, std::max(1u, std::thread::hardware_concurrency() / 2))));
+    std::atomic<int> next(0);
+    auto worker = [&]() {
+      hipSetDevice(ctx->device);   // the current device is per-thread state
+      for (int b = next.fetch_add(1); b < B; b = next.fetch_add(1)) {
+        ElasWork& w = work[b];
+        elas_filter(eb->slots[b], W, H, p, w);
+        const bool ok = w.sp.size() >= 3;
+        if (ok) elas_triangulate(eb->slots[b], nullptr, w, false);
+        if (produced) produced[b] = ok && !w.err ? 1 : 0;
+        if (!ok || w.err) continue;   // fewer than 3 support points: outputs untouched, as the reference leaves them
+        hipStream_t s = eb->streams[b % ns];
+        int r = elas_phase_b_grids(ctx, eb->slots[b], s, nd, p, w);
+        if (r == SVO_OK) r = elas_phase_b(ctx, eb->slots[b], s, W, H, p, w, nullptr, d_D1 + b * nd, d_D2 + b * nd);
+        prc[b] = r;
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
+    worker();
+    for (std::thread& t : pool) t.join();
+    for (int b = 0; b < B && rc == SVO_OK; ++b) {
+      if (work[b].err) { ctx->last_error = work[b].err; rc = SVO_E_INVALID; }
+      else if (prc[b]) rc = prc[b];
+    }
+  }
+  const auto t3 = tnow();
+  for (hipStream_t s : eb->streams) hipStreamSynchronize(s);   // `work` is read by the uploads until here
+  if (dbg) fprintf(stderr, "elas batch B=%d: enqueue A %.2f ms, wait A %.2f, host+enqueue B %.2f, wait B %.2f\n", B,
+                   ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, tnow()));
+  ctx->profiling = prof;
+  if (rc == SVO_OK) SVO_HIP(ctx, hipGetLastError());
+  return rc;
 }
 
 extern "C" int svo_elas_process_ex(svo_ctx* ctx, const uint8_t* I1, const uint8_t* I2, float* D1, float* D2,
@@ -1036,7 +1197,7 @@ extern "C" int svo_elas_process_ex(svo_ctx* ctx, const uint8_t* I1, const uint8_
   SVO_HIP(ctx, hipSetDevice(ctx->device));
   if (!ctx->elas) ctx->elas = new ElasState();
   ElasState* st = reinterpret_cast<ElasState*>(ctx->elas);
-  if ((rc = elas_prepare(ctx, st, W, H, p))) return rc;
+  if ((rc = elas_prepare(ctx, st, W, H, p, true))) return rc;
   hipStream_t s = ctx->stream;
   const size_t n = (size_t)W * H;
   HostTimer total(ctx, "host_elas_total");

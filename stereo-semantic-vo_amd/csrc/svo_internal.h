@@ -93,6 +93,7 @@ struct svo_ctx {
   void* d_track = nullptr;      // n_seq TrackState records
   int n_seq = 0;
   void* elas = nullptr;     // ElasState (svo_elas.hip), allocated on first svo_elas_process
+  void* elas_batch = nullptr;   // ElasBatch: per-pair states + streams of svo_elas_batch_dev
   svo_camera cam{};
   int track_frame = 0;
 

@@ -171,3 +171,35 @@ def test_against_committed_reference_vectors(ctx, name, middlebury):
         exp = GOLD[k + "D" + side].ravel().copy()
         exp[GOLD[k + "process_diff_idx" + side]] = GOLD[k + "process_diff_val" + side]
         assert (exp != g["D" + side].ravel()).sum() == len(GOLD[k + "process_diff_idx" + side]) <= 2
+
+
+@pytest.mark.parametrize("middlebury", [0, 1])
+def test_batch_equals_one_pair_at_a_time(ctx, middlebury):
+    """svo_elas_batch_dev (pairs and maps resident in HBM, streams + host thread pool) == svo_elas_process per
+    pair, bit for bit; a textureless pair in the batch is reported as not produced and left untouched."""
+    import torch
+    W, H = 640, 240
+    crops = [(300, 60), (100, 20), (500, 100), (640, 140), (0, 0), (333, 77), (10, 150), (700, 30), (250, 110)]
+    pairs = [util.urban_pair(W, H, x, y) for x, y in crops]
+    flat = np.full((H, W), 77, np.uint8)
+    pairs.insert(4, (flat, flat))
+    B = len(pairs)
+    p = svo.elas_default_params(middlebury)
+    dev = torch.device("cuda", 0)
+    stride = 704
+    dL = torch.zeros((B, H, stride), dtype=torch.uint8, device=dev); dR = torch.zeros_like(dL)
+    for b, (L, R) in enumerate(pairs):
+        dL[b, :, :W] = torch.from_numpy(L).to(dev); dR[b, :, :W] = torch.from_numpy(R).to(dev)
+    D1 = torch.full((B, H, W), 123.0, dtype=torch.float32, device=dev); D2 = torch.full_like(D1, 123.0)
+    torch.cuda.synchronize()
+    for rep in range(2):     # second call reuses the per-pair states
+        produced = ctx.elas_batch_dev(dL.data_ptr(), dR.data_ptr(), stride, W, H, B, D1.data_ptr(), D2.data_ptr(), p)
+    h1, h2 = D1.cpu().numpy(), D2.cpu().numpy()
+    # with add_corners (MIDDLEBURY) the six corner points alone are a triangulation: the reference goes on
+    assert produced.tolist() == [1, 1, 1, 1, 1 if middlebury else 0, 1, 1, 1, 1, 1]
+    for b, (L, R) in enumerate(pairs):
+        if not produced[b]:
+            assert (h1[b] == 123.0).all() and (h2[b] == 123.0).all()
+            continue
+        e1, e2 = ctx.elas_process(L, R, p)
+        assert np.array_equal(h1[b], e1) and np.array_equal(h2[b], e2), b

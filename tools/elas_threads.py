@@ -4,7 +4,7 @@ import svo_loader, util
 svo = svo_loader.load()
 L, R = util.urban_pair()
 p = svo.elas_default_params(0)
-for T in (1, 2, 4, 8, 16):
+for T in (int(a) for a in (sys.argv[1:] or ["1", "2", "4", "8", "16"])):
     ctxs=[svo.Svo(util.KITTI_W, util.KITTI_H) for _ in range(T)]
     for c in ctxs: c.elas_process(L,R,p)
     iters=30

@@ -56,6 +56,7 @@ struct ElasState {
   uint8_t* h_img = nullptr;   // pinned staging of the host API: 2 x W*H bytes in, 2 x W*H floats out
   float* h_D = nullptr;
   int16_t* h_can = nullptr;   // pinned: lattice candidates back from the GPU
+  struct ElasTab* d_tab = nullptr;   // 1-entry table of the one-pair path
   std::vector<void*> allocs;
   void release() {
     for (void* p : allocs) hipFree(p);
@@ -73,12 +74,12 @@ struct ElasState {
 // ------------------------------------------------------------------------------------------------
 #define DT_X 32
 #define DT_Y 8
-__global__ __launch_bounds__(256) void k_elas_desc(const uint8_t* img0, const uint8_t* img1, int pitch, int W, int H,
-                                                   int half, uint4* desc0, uint4* desc1) {
+__device__ __forceinline__ void d_elas_desc(int side, const uint8_t* img0, const uint8_t* img1, int pitch, int W, int H,
+                                            int half, uint4* desc0, uint4* desc1) {
   __shared__ uint8_t im[DT_Y + 6][DT_X + 8];
   __shared__ uint8_t du[DT_Y + 4][DT_X + 4], dv[DT_Y + 4][DT_X + 4];
-  const uint8_t* img = blockIdx.z ? img1 : img0;
-  uint4* desc = blockIdx.z ? desc1 : desc0;
+  const uint8_t* img = side ? img1 : img0;
+  uint4* desc = side ? desc1 : desc0;
   const int x0 = blockIdx.x * DT_X, y0 = blockIdx.y * DT_Y, tid = threadIdx.x;
   for (int i = tid; i < (DT_Y + 6) * (DT_X + 6); i += 256) {
     const int r = i / (DT_X + 6), c = i - r * (DT_X + 6);
@@ -148,7 +149,7 @@ __device__ int elas_support_match(const uint4* __restrict__ I1d, const uint4* __
   return ((float)min1 < p.support_threshold * (float)second) ? (int)(K1 & 511u) : -1;
 }
 
-__global__ __launch_bounds__(256) void k_elas_support(const uint4* desc1, const uint4* desc2, int W, int H,
+__device__ __forceinline__ void d_elas_support(const uint4* desc1, const uint4* desc2, int W, int H,
                                                       int Wc, int Hc, svo_elas_params p, int16_t* D_can) {
   const int lane = threadIdx.x & 63;
   const int cand = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) void k_elas_support(const uint4* desc1, const 
 // equations and truncations) and leaves, per pixel, the LAST triangle covering it (what the
 // reference's sequential overwrite leaves); k_elas_match then runs findMatch once per pixel.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_elas_raster(const int32_t* sp, const int32_t* tri0, const int32_t* tri1,
+__device__ __forceinline__ void d_elas_raster(const int32_t* sp, const int32_t* tri0, const int32_t* tri1,
                                                      int n0, int n1, int W, int H, int sub, int32_t* own0, int32_t* own1) {
   const bool right = blockIdx.y != 0;
   const int32_t* tri = right ? tri1 : tri0;
@@ -215,12 +216,11 @@ __global__ __launch_bounds__(256) void k_elas_raster(const int32_t* sp, const in
   }
 }
 
-__global__ __launch_bounds__(256) void k_elas_match(const uint4* desc1, const uint4* desc2, const int32_t* own0,
+__device__ __forceinline__ void d_elas_match(bool right, const uint4* desc1, const uint4* desc2, const int32_t* own0,
                                                     const int32_t* own1, const float* pl0, const float* pl1,
                                                     const int32_t* grid0, const int32_t* grid1, const int32_t* P,
                                                     int W, int H, int gw, int gd, int plane_radius,
                                                     svo_elas_params p, float* D0, float* D1) {
-  const bool right = blockIdx.z != 0;
   const int sub = p.subsampling, Wd = sub ? W / 2 : W;
   const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
   if (x >= Wd) return;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void k_elas_match(const uint4* desc1, const ui
   D[addr] = out;
 }
 
-__global__ __launch_bounds__(256) void k_elas_lr(const float* D1, const float* D2, int W, int H, int lr_threshold,
+__device__ __forceinline__ void d_elas_lr(const float* D1, const float* D2, int W, int H, int lr_threshold,
                                                  int sub, float* O1, float* O2) {
   const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
   if (u >= W) return;
@@ -326,7 +326,7 @@ __device__ void cc_union(int32_t* L, int a, int b) {
 // LDS, no atomics), the run head records the run length.  Only run-to-run contacts are then united
 // vertically (the first column of each contact), and sizes are accumulated per run, not per pixel.
 #define CC_MAXLEN 4096
-__global__ __launch_bounds__(256) void k_cc_rows(const float* D, int W, float thr, int32_t* L, int32_t* rlen,
+__device__ __forceinline__ void d_cc_rows(const float* D, int W, float thr, int32_t* L, int32_t* rlen,
                                                  int32_t* size) {
   __shared__ float val[CC_MAXLEN];
   __shared__ int16_t start[CC_MAXLEN];
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void k_cc_rows(const float* D, int W, float th
   for (int i = tid; i < W; i += 256)
     if (i == W - 1 || start[i + 1] != start[i]) rlen[v * W + start[i]] = i - start[i] + 1;
 }
-__global__ void k_cc_merge(const float* D, int W, int H, float thr, int32_t* L) {
+__device__ __forceinline__ void d_cc_merge(const float* D, int W, int H, float thr, int32_t* L) {
   const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
   if (u >= W || v + 1 >= H) return;
   const int i = v * W + u;
@@ -372,7 +372,7 @@ __global__ void k_cc_merge(const float* D, int W, int H, float thr, int32_t* L) 
   }
   cc_union(L, i, i + W);
 }
-__global__ __launch_bounds__(256) void k_cc_count(int n, const int32_t* L, const int32_t* rlen, int32_t* size) {
+__device__ __forceinline__ void d_cc_count(int n, const int32_t* L, const int32_t* rlen, int32_t* size) {
   const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
   int root = -1, len = 0;
   if (i < n && rlen[i] > 0) { root = cc_find(L, i); len = rlen[i]; }   // run heads only
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void k_cc_count(int n, const int32_t* L, const
     active &= ~__ballot(same);
   }
 }
-__global__ void k_cc_apply(float* D, int n, const int32_t* L, const int32_t* size, int speckle) {
+__device__ __forceinline__ void d_cc_apply(float* D, int n, const int32_t* L, const int32_t* size, int speckle) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   if (size[cc_find(L, i)] < speckle) D[i] = -10.0f;
@@ -401,7 +401,7 @@ __global__ void k_cc_apply(float* D, int n, const int32_t* L, const int32_t* siz
 // trailing runs are filled up to `gap` pixels from the first / last valid pixel.
 // ------------------------------------------------------------------------------------------------
 #define GAP_MAXLEN 4096
-__global__ __launch_bounds__(256) void k_elas_gap(float* D, int n, int estride, int lstride, int gap, int add_corners) {
+__device__ __forceinline__ void d_elas_gap(float* D, int n, int estride, int lstride, int gap, int add_corners) {
   __shared__ float val[GAP_MAXLEN];
   __shared__ int16_t last[GAP_MAXLEN], nxt[GAP_MAXLEN];
   __shared__ int cl[256], cn[256];
@@ -477,7 +477,7 @@ __device__ __forceinline__ bool am_filter4(const float (&slot)[4], float cur, fl
   return false;
 }
 // horizontal: T = filtered copy of D (invalid -> -10, not written -> 0)
-__global__ __launch_bounds__(256) void k_elas_mean_h(const float* D, int W, int H, int half, float* T) {
+__device__ __forceinline__ void d_elas_mean_h(const float* D, int W, int H, int half, float* T) {
   const int x = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
   if (x >= W) return;
   const float* row = D + (size_t)v * W;
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void k_elas_mean_h(const float* D, int W, int 
   }
   T[(size_t)v * W + x] = out;
 }
-__global__ __launch_bounds__(256) void k_elas_mean_v(const float* T, int W, int H, int half, float* D) {
+__device__ __forceinline__ void d_elas_mean_v(const float* T, int W, int H, int half, float* D) {
   const int u = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
   if (u >= W) return;
   if (half) {
@@ -542,7 +542,7 @@ __device__ __forceinline__ float median7(float (&a)[7]) {
   return a[3];
 }
 // horizontal median into T (zero elsewhere), vertical median of T back into D
-__global__ __launch_bounds__(256) void k_elas_median_h(const float* D, int W, int H, float* T) {
+__device__ __forceinline__ void d_elas_median_h(const float* D, int W, int H, float* T) {
   const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
   if (u >= W) return;
   float out = 0.0f;
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void k_elas_median_h(const float* D, int W, in
   }
   T[(size_t)v * W + u] = out;
 }
-__global__ __launch_bounds__(256) void k_elas_median_v(const float* T, int W, int H, float* D) {
+__device__ __forceinline__ void d_elas_median_v(const float* T, int W, int H, float* D) {
   const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
   if (u >= W) return;
   if (!(u >= 3 && u < W - 3 && v >= 3 && v < H - 3)) return;
@@ -604,7 +604,7 @@ __device__ bool solve3(double (&A)[3][3], double (&b)[3]) {
   }
   return true;
 }
-__global__ __launch_bounds__(64) void k_elas_planes(const int32_t* sp, const int32_t* tri0, const int32_t* tri1, int n0,
+__device__ __forceinline__ void d_elas_planes(const int32_t* sp, const int32_t* tri0, const int32_t* tri1, int n0,
                                                     int n1, float* pl0, float* pl1) {
   const int t = blockIdx.x * 64 + threadIdx.x;
   const int32_t* tri = blockIdx.y ? tri1 : tri0;
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(64) void k_elas_planes(const int32_t* sp, const int
 // (cell, d) array, whole cells apart, so per disparity they OR the flat CELL indices c + {0,1,2, gw..gw+2,
 // 2gw..2gw+2} into cell c + gw + 1 for every c with c + 2gw + 2 < gw*gh (rows wrap); other cells stay empty.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_elas_grid_mark(const int32_t* sp, int nsp, int grid_size, int disp_max, int gw, int gh,
+__device__ __forceinline__ void d_elas_grid_mark(const int32_t* sp, int nsp, int grid_size, int disp_max, int gw, int gh,
                                  uint32_t* t1_left, uint32_t* t1_right) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= nsp) return;
@@ -642,7 +642,7 @@ __global__ void k_elas_grid_mark(const int32_t* sp, int nsp, int grid_size, int 
     if (xr >= 0 && xr < gw && y >= 0 && y < gh) atomicOr(&t1_right[(size_t)(y * gw + xr) * 8 + (d >> 5)], 1u << (d & 31));
   }
 }
-__global__ void k_elas_grid_diffuse(const uint32_t* t1_left, const uint32_t* t1_right, int gw, int gh,
+__device__ __forceinline__ void d_elas_grid_diffuse(const uint32_t* t1_left, const uint32_t* t1_right, int gw, int gh,
                                     uint32_t* t2_left, uint32_t* t2_right) {
   const int i = blockIdx.x * 256 + threadIdx.x;   // (cell, word)
   const int ncell = gw * gh;
@@ -657,6 +657,116 @@ __global__ void k_elas_grid_diffuse(const uint32_t* t1_left, const uint32_t* t1_
     for (int k = 0; k < 9; ++k) r |= t1[(size_t)(c + o[k]) * 8 + w];
   }
   t2[i] = r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Launch side: every kernel serves a whole batch.  `tab` holds, per pair, the pointers of its buffers and
+// the sizes of its lists; the pair index rides on the highest grid dimension the stage leaves free.  A
+// pair with fewer than 3 support points (`produced` = 0) is skipped by everything after the lattice stage.
+// ------------------------------------------------------------------------------------------------
+struct ElasTab {
+  const uint8_t *imgL, *imgR;
+  uint4 *desc0, *desc1;
+  int16_t* can;
+  int32_t *sp, *tri0, *tri1;
+  float *plane0, *plane1;
+  uint32_t *bits0, *bits1;      // per side: set t1 (support point cells) then set t2 (after diffusion)
+  int32_t *owner0, *owner1;
+  float *raw0, *raw1, *out0, *out1;
+  int32_t *lab, *size;
+  int32_t nsp, nt0, nt1, produced;
+};
+
+__global__ __launch_bounds__(256) void k_elas_desc(const ElasTab* tab, int pitch, int W, int H, int half) {
+  const ElasTab& E = tab[blockIdx.z >> 1];
+  d_elas_desc(blockIdx.z & 1, E.imgL, E.imgR, pitch, W, H, half, E.desc0, E.desc1);
+}
+__global__ __launch_bounds__(256) void k_elas_support(const ElasTab* tab, int W, int H, int Wc, int Hc, svo_elas_params p) {
+  const ElasTab& E = tab[blockIdx.y];
+  d_elas_support(E.desc0, E.desc1, W, H, Wc, Hc, p, E.can);
+}
+__global__ void k_elas_grid_mark(const ElasTab* tab, int grid_size, int disp_max, int gw, int gh) {
+  const ElasTab& E = tab[blockIdx.y];
+  if (!E.produced) return;
+  d_elas_grid_mark(E.sp, E.nsp, grid_size, disp_max, gw, gh, E.bits0, E.bits1);
+}
+__global__ void k_elas_grid_diffuse(const ElasTab* tab, int gw, int gh) {
+  const ElasTab& E = tab[blockIdx.z];
+  if (!E.produced) return;
+  const size_t half_set = (size_t)gw * gh * 8;
+  d_elas_grid_diffuse(E.bits0, E.bits1, gw, gh, E.bits0 + half_set, E.bits1 + half_set);
+}
+__global__ __launch_bounds__(64) void k_elas_planes(const ElasTab* tab) {
+  const ElasTab& E = tab[blockIdx.z];
+  if (!E.produced) return;
+  d_elas_planes(E.sp, E.tri0, E.tri1, E.nt0, E.nt1, E.plane0, E.plane1);
+}
+__global__ __launch_bounds__(256) void k_elas_raster(const ElasTab* tab, int W, int H, int sub) {
+  const ElasTab& E = tab[blockIdx.z];
+  if (!E.produced) return;
+  d_elas_raster(E.sp, E.tri0, E.tri1, E.nt0, E.nt1, W, H, sub, E.owner0, E.owner1);
+}
+__global__ __launch_bounds__(256) void k_elas_match(const ElasTab* tab, const int32_t* P, int W, int H, int gw, int gh,
+                                                    int gd, int plane_radius, svo_elas_params p) {
+  const ElasTab& E = tab[blockIdx.z >> 1];
+  if (!E.produced) return;
+  const size_t half_set = (size_t)gw * gh * 8;
+  d_elas_match((blockIdx.z & 1) != 0, E.desc0, E.desc1, E.owner0, E.owner1, E.plane0, E.plane1,
+               reinterpret_cast<const int32_t*>(E.bits0 + half_set), reinterpret_cast<const int32_t*>(E.bits1 + half_set), P,
+               W, H, gw, gd, plane_radius, p, E.raw0, E.raw1);
+}
+__global__ __launch_bounds__(256) void k_elas_lr(const ElasTab* tab, int W, int H, int lr_threshold, int sub) {
+  const ElasTab& E = tab[blockIdx.z];
+  if (!E.produced) return;
+  d_elas_lr(E.raw0, E.raw1, W, H, lr_threshold, sub, E.out0, E.out1);
+}
+// segment removal works on one side at a time; the run lengths borrow owner0 (free once matching is done)
+__global__ __launch_bounds__(256) void k_cc_rows(const ElasTab* tab, int side, int W, float thr) {
+  const ElasTab& E = tab[blockIdx.y];
+  if (!E.produced) return;
+  d_cc_rows(side ? E.out1 : E.out0, W, thr, E.lab, E.owner0, E.size);
+}
+__global__ void k_cc_merge(const ElasTab* tab, int side, int W, int H, float thr) {
+  const ElasTab& E = tab[blockIdx.z];
+  if (!E.produced) return;
+  d_cc_merge(side ? E.out1 : E.out0, W, H, thr, E.lab);
+}
+__global__ __launch_bounds__(256) void k_cc_count(const ElasTab* tab, int n) {
+  const ElasTab& E = tab[blockIdx.y];
+  if (!E.produced) return;
+  d_cc_count(n, E.lab, E.owner0, E.size);
+}
+__global__ void k_cc_apply(const ElasTab* tab, int side, int n, int speckle) {
+  const ElasTab& E = tab[blockIdx.y];
+  if (!E.produced) return;
+  d_cc_apply(side ? E.out1 : E.out0, n, E.lab, E.size, speckle);
+}
+__global__ __launch_bounds__(256) void k_elas_gap(const ElasTab* tab, int side, int n, int estride, int lstride, int gap,
+                                                  int add_corners) {
+  const ElasTab& E = tab[blockIdx.y];
+  if (!E.produced) return;
+  d_elas_gap(side ? E.out1 : E.out0, n, estride, lstride, gap, add_corners);
+}
+// filters: maps in out*, scratch in raw*
+__global__ __launch_bounds__(256) void k_elas_mean_h(const ElasTab* tab, int side, int W, int H, int half) {
+  const ElasTab& E = tab[blockIdx.z];
+  if (!E.produced) return;
+  d_elas_mean_h(side ? E.out1 : E.out0, W, H, half, side ? E.raw1 : E.raw0);
+}
+__global__ __launch_bounds__(256) void k_elas_mean_v(const ElasTab* tab, int side, int W, int H, int half) {
+  const ElasTab& E = tab[blockIdx.z];
+  if (!E.produced) return;
+  d_elas_mean_v(side ? E.raw1 : E.raw0, W, H, half, side ? E.out1 : E.out0);
+}
+__global__ __launch_bounds__(256) void k_elas_median_h(const ElasTab* tab, int side, int W, int H) {
+  const ElasTab& E = tab[blockIdx.z];
+  if (!E.produced) return;
+  d_elas_median_h(side ? E.out1 : E.out0, W, H, side ? E.raw1 : E.raw0);
+}
+__global__ __launch_bounds__(256) void k_elas_median_v(const ElasTab* tab, int side, int W, int H) {
+  const ElasTab& E = tab[blockIdx.z];
+  if (!E.produced) return;
+  d_elas_median_v(side ? E.raw1 : E.raw0, W, H, side ? E.out1 : E.out0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -776,6 +886,12 @@ int elas_prepare(svo_ctx* ctx, ElasState* st, int W, int H, const svo_elas_param
   if ((rc = dev_alloc(ctx, st, &st->d_P, 256))) return rc;
   if ((rc = dev_alloc(ctx, st, &st->d_lab, n))) return rc;
   if ((rc = dev_alloc(ctx, st, &st->d_size, n))) return rc;
+  {
+    void* q = nullptr;
+    SVO_HIP(ctx, hipMalloc(&q, 1024));   // >= sizeof(ElasTab)
+    st->allocs.push_back(q);
+    st->d_tab = reinterpret_cast<struct ElasTab*>(q);
+  }
   SVO_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&st->h_can), (size_t)Wc * Hc * sizeof(int16_t), hipHostMallocDefault));
   st->W = W; st->H = H; st->Wc = Wc; st->Hc = Hc; st->gw = gw; st->gh = gh; st->gd = gd;
   return host_io ? elas_prepare(ctx, st, W, H, p, true) : SVO_OK;   // second pass adds the staging buffers
@@ -822,35 +938,45 @@ struct ElasWork {
   const char* err = nullptr;
 };
 
-// Phase A: descriptors of both images and the lattice candidates, then the candidates on their way back
-// to pinned host memory.  Enqueues on `s`, does not synchronise.
-int elas_phase_a(svo_ctx* ctx, ElasState* st, hipStream_t s, const uint8_t* dL, const uint8_t* dR, int pitch, int W,
-                 int H, const svo_elas_params& p) {
-  const int Wc = st->Wc, Hc = st->Hc;
+// the table entry of a pair whose buffers live in `st`
+ElasTab tab_entry(const ElasState* st, const uint8_t* imgL, const uint8_t* imgR, int16_t* can, float* out0, float* out1) {
+  ElasTab e;
+  memset(&e, 0, sizeof e);
+  e.imgL = imgL; e.imgR = imgR;
+  e.desc0 = st->d_desc[0]; e.desc1 = st->d_desc[1];
+  e.can = can;
+  e.sp = st->d_sp; e.tri0 = st->d_tri[0]; e.tri1 = st->d_tri[1];
+  e.plane0 = st->d_plane[0]; e.plane1 = st->d_plane[1];
+  e.bits0 = reinterpret_cast<uint32_t*>(st->d_grid[0]); e.bits1 = reinterpret_cast<uint32_t*>(st->d_grid[1]);
+  e.owner0 = st->d_owner[0]; e.owner1 = st->d_owner[1];
+  e.raw0 = st->d_D[0]; e.raw1 = st->d_D[1]; e.out0 = out0; e.out1 = out1;
+  e.lab = st->d_lab; e.size = st->d_size;
+  e.produced = 1;
+  return e;
+}
+
+// Phase A for B pairs: descriptors of both images and the lattice candidates.  Enqueues on `s`.
+int elas_phase_a(svo_ctx* ctx, hipStream_t s, const ElasTab* d_tab, int B, int pitch, int W, int H, int Wc, int Hc,
+                 const svo_elas_params& p) {
   svo_elas_params pk = p;   // what the kernels see: the lattice step already adjusted (elas.cpp:379-381)
   pk.candidate_stepsize = p.candidate_stepsize + (p.subsampling ? p.candidate_stepsize % 2 : 0);
   {
     SvoTimer t(ctx, "k_elas_desc");
-    hipLaunchKernelGGL(k_elas_desc, dim3((W + DT_X - 1) / DT_X, (H + DT_Y - 1) / DT_Y, 2), dim3(256), 0, s,
-                       dL, dR, pitch, W, H, p.subsampling, st->d_desc[0], st->d_desc[1]);
+    hipLaunchKernelGGL(k_elas_desc, dim3((W + DT_X - 1) / DT_X, (H + DT_Y - 1) / DT_Y, 2 * B), dim3(256), 0, s, d_tab,
+                       pitch, W, H, p.subsampling);
   }
-  // calloc'ed in the reference: row 0 / column 0 of the lattice stay 0
-  SVO_HIP(ctx, hipMemsetAsync(st->d_can, 0, (size_t)Wc * Hc * sizeof(int16_t), s));
   if (Wc > 1 && Hc > 1) {
     SvoTimer t(ctx, "k_elas_support");
     const int ncand = (Wc - 1) * (Hc - 1);
-    hipLaunchKernelGGL(k_elas_support, dim3((ncand + 3) / 4), dim3(256), 0, s, st->d_desc[0], st->d_desc[1], W, H,
-                       Wc, Hc, pk, st->d_can);
+    hipLaunchKernelGGL(k_elas_support, dim3((ncand + 3) / 4, B), dim3(256), 0, s, d_tab, W, H, Wc, Hc, pk);
   }
-  SVO_HIP(ctx, hipMemcpyAsync(st->h_can, st->d_can, (size_t)Wc * Hc * sizeof(int16_t), hipMemcpyDeviceToHost, s));
   return SVO_OK;
 }
 
 // Host stage 1: the order-dependent clean-up of the lattice candidates -> support point list.
-void elas_filter(const ElasState* st, int W, int H, const svo_elas_params& p, ElasWork& w) {
-  const int Wc = st->Wc, Hc = st->Hc;
+void elas_filter(const int16_t* h_can, int Wc, int Hc, int W, int H, const svo_elas_params& p, ElasWork& w) {
   const int step = p.candidate_stepsize + (p.subsampling ? p.candidate_stepsize % 2 : 0);
-  std::vector<int16_t> can(st->h_can, st->h_can + (size_t)Wc * Hc);
+  std::vector<int16_t> can(h_can, h_can + (size_t)Wc * Hc);
   remove_inconsistent(can, Wc, Hc, p);
   remove_redundant(can, Wc, Hc, 5, 1, true);
   remove_redundant(can, Wc, Hc, 5, 1, false);
@@ -863,12 +989,12 @@ void elas_filter(const ElasState* st, int W, int H, const svo_elas_params& p, El
 }
 
 // Host stage 2: the two Delaunay triangulations (or the lists a test injects).
-void elas_triangulate(const ElasState* st, const svo_elas_taps* taps, ElasWork& w, bool two_threads) {
+void elas_triangulate(int cap_tri, const svo_elas_taps* taps, ElasWork& w, bool two_threads) {
   auto do_side = [&](int side) {
     const int32_t* tin = taps ? (side ? taps->tri2_in : taps->tri1_in) : nullptr;
     if (tin) {
       const int nt = side ? taps->n_tri2_in : taps->n_tri1_in;
-      if (nt > st->cap_tri) { w.err = "svo_elas_process: too many triangles"; return; }
+      if (nt > cap_tri) { w.err = "svo_elas_process: too many triangles"; return; }
       for (int i = 0; i < 3 * nt; ++i)
         if (tin[i] < 0 || tin[i] >= (int)w.sp.size()) { w.err = "svo_elas_process: bad triangle index"; return; }
       w.tri[side].assign(tin, tin + 3 * (size_t)nt);
@@ -876,10 +1002,10 @@ void elas_triangulate(const ElasState* st, const svo_elas_taps* taps, ElasWork& 
     }
     std::vector<int32_t> xy(2 * w.sp.size());
     for (size_t i = 0; i < w.sp.size(); ++i) { xy[2 * i] = side ? w.sp[i].u - w.sp[i].d : w.sp[i].u; xy[2 * i + 1] = w.sp[i].v; }
-    w.tri[side].resize((size_t)st->cap_tri * 3);
+    w.tri[side].resize((size_t)cap_tri * 3);
     int32_t nt = 0;
-    const int r = svo_elas_delaunay(xy.data(), (int32_t)w.sp.size(), w.tri[side].data(), st->cap_tri, &nt);
-    if (r || nt > st->cap_tri) { w.err = "svo_elas_process: triangulation failed"; w.tri[side].clear(); return; }
+    const int r = svo_elas_delaunay(xy.data(), (int32_t)w.sp.size(), w.tri[side].data(), cap_tri, &nt);
+    if (r || nt > cap_tri) { w.err = "svo_elas_process: triangulation failed"; w.tri[side].clear(); return; }
     w.tri[side].resize((size_t)nt * 3);
   };
   if (two_threads) {   // the two images are independent: the right one runs on a second host thread
@@ -892,83 +1018,61 @@ void elas_triangulate(const ElasState* st, const svo_elas_taps* taps, ElasWork& 
   }
 }
 
-// Phase B, first part: support points -> HBM and the disparity grids, which need nothing else - so in the
-// one-pair path the GPU builds them while the host triangulates.
-int elas_phase_b_grids(svo_ctx* ctx, ElasState* st, hipStream_t s, size_t nd, const svo_elas_params& p, const ElasWork& w) {
-  const int ncell = st->gw * st->gh, nsp = (int)w.sp.size();
-  uint32_t* t1[2] = {reinterpret_cast<uint32_t*>(st->d_grid[0]), reinterpret_cast<uint32_t*>(st->d_grid[1])};
-  SVO_HIP(ctx, hipMemcpyAsync(st->d_sp, w.spflat.data(), w.spflat.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-  for (int side = 0; side < 2; ++side) {
-    SVO_HIP(ctx, hipMemsetAsync(t1[side], 0, (size_t)ncell * 8 * sizeof(uint32_t), s));
-    SVO_HIP(ctx, hipMemsetAsync(st->d_owner[side], 0xff, nd * sizeof(int32_t), s));
-  }
+// Phase B, first part (needs the support points only): clear the per-pair grids / owner maps and build the
+// disparity grids.  In the one-pair path this runs while the host triangulates.
+int elas_phase_b_grids(svo_ctx* ctx, hipStream_t s, const ElasTab* d_tab, int B, int max_nsp, int gw, int gh,
+                       const svo_elas_params& p) {
   SvoTimer t(ctx, "k_elas_grid");
-  hipLaunchKernelGGL(k_elas_grid_mark, dim3((nsp + 255) / 256), dim3(256), 0, s, st->d_sp, nsp, p.grid_size, p.disp_max,
-                     st->gw, st->gh, t1[0], t1[1]);
-  hipLaunchKernelGGL(k_elas_grid_diffuse, dim3((ncell * 8 + 255) / 256, 2), dim3(256), 0, s, t1[0], t1[1], st->gw, st->gh,
-                     t1[0] + (size_t)ncell * 8, t1[1] + (size_t)ncell * 8);
+  hipLaunchKernelGGL(k_elas_grid_mark, dim3((std::max(max_nsp, 1) + 255) / 256, B), dim3(256), 0, s, d_tab, p.grid_size,
+                     p.disp_max, gw, gh);
+  hipLaunchKernelGGL(k_elas_grid_diffuse, dim3((gw * gh * 8 + 255) / 256, 2, B), dim3(256), 0, s, d_tab, gw, gh);
   return SVO_OK;
 }
 
-// Phase B, second part: triangles -> HBM, plane fits, dense matching and all post-processing.  The final
-// maps are built in place in D1 / D2 (device memory, Wd*Hd floats each).  With taps it synchronises after
-// every stage, otherwise it only enqueues on `s`.
-int elas_phase_b(svo_ctx* ctx, ElasState* st, hipStream_t s, int W, int H, const svo_elas_params& p, const ElasWork& w,
-                 svo_elas_taps* taps, float* D1, float* D2) {
+// Phase B, second part: plane fits, dense matching and all post-processing for B pairs; the final maps are
+// built in place in each pair's out0 / out1.  `tap_st` (B = 1 only): tap every intermediate of that pair,
+// synchronising after every stage; otherwise it only enqueues on `s`.
+int elas_phase_b(svo_ctx* ctx, hipStream_t s, const ElasTab* d_tab, int B, int max_nt, int W, int H, int gw, int gh, int gd,
+                 const int32_t* d_P, const svo_elas_params& p, const ElasState* tap_st, const ElasTab* tap_e,
+                 const ElasWork* tap_w, svo_elas_taps* taps) {
   const int sub = p.subsampling;
   const int Wd = sub ? W / 2 : W, Hd = sub ? H / 2 : H;   // disparity map size (elas.h:157-160)
   const size_t n = (size_t)Wd * Hd;
-  const int ncell = st->gw * st->gh;
-  uint32_t* t2[2] = {reinterpret_cast<uint32_t*>(st->d_grid[0]) + (size_t)ncell * 8,
-                     reinterpret_cast<uint32_t*>(st->d_grid[1]) + (size_t)ncell * 8};
-  int rc;
-  int32_t P[256];
-  {
-    const int disp_num = p.disp_max + 1;
-    const float two_sigma_squared = 2 * p.sigma * p.sigma;
-    for (int dd = 0; dd < 256; ++dd)
-      P[dd] = dd < disp_num ? (int32_t)((-logf(p.gamma + expf(-dd * dd / two_sigma_squared)) + logf(p.gamma)) / p.beta) : 0;
-  }
+  const int ncell = gw * gh;
   const int plane_radius = (int)std::max((float)ceil(p.sigma * p.sradius), (float)2.0);
-  SVO_HIP(ctx, hipMemcpyAsync(st->d_P, P, sizeof P, hipMemcpyHostToDevice, s));   // pageable: staged before it returns
-  for (int side = 0; side < 2; ++side)
-    if (!w.tri[side].empty())
-      SVO_HIP(ctx, hipMemcpyAsync(st->d_tri[side], w.tri[side].data(), w.tri[side].size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-  const int nt0 = (int)w.tri[0].size() / 3, nt1 = (int)w.tri[1].size() / 3;
-  if (std::max(nt0, nt1) > 0) {
+  const unsigned ub = (unsigned)B;
+  int rc;
+  if (max_nt > 0) {
     {
       SvoTimer t(ctx, "k_elas_planes");
-      hipLaunchKernelGGL(k_elas_planes, dim3((std::max(nt0, nt1) + 63) / 64, 2), dim3(64), 0, s, st->d_sp, st->d_tri[0],
-                         st->d_tri[1], nt0, nt1, st->d_plane[0], st->d_plane[1]);
+      hipLaunchKernelGGL(k_elas_planes, dim3((max_nt + 63) / 64, 2, ub), dim3(64), 0, s, d_tab);
     }
     SvoTimer t(ctx, "k_elas_raster");
-    hipLaunchKernelGGL(k_elas_raster, dim3((std::max(nt0, nt1) + 3) / 4, 2), dim3(256), 0, s, st->d_sp, st->d_tri[0],
-                       st->d_tri[1], nt0, nt1, W, H, sub, st->d_owner[0], st->d_owner[1]);
+    hipLaunchKernelGGL(k_elas_raster, dim3((max_nt + 3) / 4, 2, ub), dim3(256), 0, s, d_tab, W, H, sub);
   }
-  const dim3 pix((Wd + 255) / 256, Hd), pix2((Wd + 255) / 256, Hd, 2);
+  const dim3 pix((Wd + 255) / 256, Hd, ub), pix2((Wd + 255) / 256, Hd, 2 * ub);
   {
     SvoTimer t(ctx, "k_elas_match");
-    hipLaunchKernelGGL(k_elas_match, pix2, dim3(256), 0, s, st->d_desc[0], st->d_desc[1], st->d_owner[0], st->d_owner[1],
-                       st->d_plane[0], st->d_plane[1], reinterpret_cast<const int32_t*>(t2[0]),
-                       reinterpret_cast<const int32_t*>(t2[1]), st->d_P, W, H, st->gw, st->gd, plane_radius, p, st->d_D[0],
-                       st->d_D[1]);
+    hipLaunchKernelGGL(k_elas_match, pix2, dim3(256), 0, s, d_tab, d_P, W, H, gw, gh, gd, plane_radius, p);
   }
   if (taps) {
     SVO_HIP(ctx, hipStreamSynchronize(s));
-    taps->n_tri1 = nt0; taps->n_tri2 = nt1;
+    const int nt[2] = {(int)tap_w->tri[0].size() / 3, (int)tap_w->tri[1].size() / 3};
+    taps->n_tri1 = nt[0]; taps->n_tri2 = nt[1];
     for (int side = 0; side < 2; ++side) {
-      const int nt = std::min<int>((int)w.tri[side].size() / 3, taps->cap_tri);
+      const int k = std::min<int>(nt[side], taps->cap_tri);
       int32_t* ti = side ? taps->tri2 : taps->tri1;
       float* pl = side ? taps->planes2 : taps->planes1;
       int32_t* gr = side ? taps->grid2 : taps->grid1;
-      if (ti) memcpy(ti, w.tri[side].data(), (size_t)nt * 3 * sizeof(int32_t));
-      if (pl && nt) SVO_HIP(ctx, hipMemcpy(pl, st->d_plane[side], (size_t)nt * 6 * sizeof(float), hipMemcpyDeviceToHost));
+      if (ti) memcpy(ti, tap_w->tri[side].data(), (size_t)k * 3 * sizeof(int32_t));
+      if (pl && k) SVO_HIP(ctx, hipMemcpy(pl, tap_st->d_plane[side], (size_t)k * 6 * sizeof(float), hipMemcpyDeviceToHost));
       if (gr) {   // the reference's list layout: per cell [count, d0, d1, ...]
         std::vector<uint32_t> bits((size_t)ncell * 8);
-        SVO_HIP(ctx, hipMemcpy(bits.data(), t2[side], bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        memset(gr, 0, (size_t)ncell * st->gd * sizeof(int32_t));
+        SVO_HIP(ctx, hipMemcpy(bits.data(), reinterpret_cast<const uint32_t*>(tap_st->d_grid[side]) + (size_t)ncell * 8,
+                               bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        memset(gr, 0, (size_t)ncell * gd * sizeof(int32_t));
         for (int c = 0; c < ncell; ++c) {
-          int32_t* cell = gr + (size_t)c * st->gd;
+          int32_t* cell = gr + (size_t)c * gd;
           int cur = 1;
           for (int q = 0; q < 8; ++q)
             for (uint32_t m = bits[(size_t)c * 8 + q]; m; m &= m - 1) cell[cur++] = 32 * q + __builtin_ctz(m);
@@ -976,18 +1080,14 @@ int elas_phase_b(svo_ctx* ctx, ElasState* st, hipStream_t s, int W, int H, const
         }
       }
     }
-    if ((rc = tap(ctx, s, taps->D1_raw, st->d_D[0], n))) return rc;
-    if ((rc = tap(ctx, s, taps->D2_raw, st->d_D[1], n))) return rc;
+    if ((rc = tap(ctx, s, taps->D1_raw, tap_e->raw0, n))) return rc;
+    if ((rc = tap(ctx, s, taps->D2_raw, tap_e->raw1, n))) return rc;
   }
-
-  // post-processing, in place in D[side]; the raw maps become scratch
-  float* D[2] = {D1, D2};
-  float* T[2] = {st->d_D[0], st->d_D[1]};
   {
     SvoTimer t(ctx, "k_elas_lr");
-    hipLaunchKernelGGL(k_elas_lr, pix, dim3(256), 0, s, st->d_D[0], st->d_D[1], Wd, Hd, p.lr_threshold, sub, D[0], D[1]);
+    hipLaunchKernelGGL(k_elas_lr, pix, dim3(256), 0, s, d_tab, Wd, Hd, p.lr_threshold, sub);
   }
-  if (taps) { if ((rc = tap(ctx, s, taps->D1_lr, D[0], n))) return rc; if ((rc = tap(ctx, s, taps->D2_lr, D[1], n))) return rc; }
+  if (taps) { if ((rc = tap(ctx, s, taps->D1_lr, tap_e->out0, n))) return rc; if ((rc = tap(ctx, s, taps->D2_lr, tap_e->out1, n))) return rc; }
   const int nsides = p.postprocess_only_left ? 1 : 2;
   // elas.cpp:986-991, 1107-1111: thresholds of the half-resolution maps
   const int speckle_size = sub ? (int)(sqrtf((float)p.speckle_size) * 2) : p.speckle_size;
@@ -995,33 +1095,39 @@ int elas_phase_b(svo_ctx* ctx, ElasState* st, hipStream_t s, int W, int H, const
   const int nb = (int)((n + 255) / 256);
   for (int side = 0; side < nsides; ++side) {
     SvoTimer t(ctx, "k_cc_segments");
-    int32_t* rlen = st->d_owner[0];   // free once k_elas_match has run
-    hipLaunchKernelGGL(k_cc_rows, dim3(Hd), dim3(256), 0, s, D[side], Wd, p.speckle_sim_threshold, st->d_lab, rlen, st->d_size);
-    hipLaunchKernelGGL(k_cc_merge, pix, dim3(256), 0, s, D[side], Wd, Hd, p.speckle_sim_threshold, st->d_lab);
-    hipLaunchKernelGGL(k_cc_count, dim3(nb), dim3(256), 0, s, (int)n, st->d_lab, rlen, st->d_size);
-    hipLaunchKernelGGL(k_cc_apply, dim3(nb), dim3(256), 0, s, D[side], (int)n, st->d_lab, st->d_size, speckle_size);
+    hipLaunchKernelGGL(k_cc_rows, dim3(Hd, ub), dim3(256), 0, s, d_tab, side, Wd, p.speckle_sim_threshold);
+    hipLaunchKernelGGL(k_cc_merge, pix, dim3(256), 0, s, d_tab, side, Wd, Hd, p.speckle_sim_threshold);
+    hipLaunchKernelGGL(k_cc_count, dim3(nb, ub), dim3(256), 0, s, d_tab, (int)n);
+    hipLaunchKernelGGL(k_cc_apply, dim3(nb, ub), dim3(256), 0, s, d_tab, side, (int)n, speckle_size);
   }
-  if (taps) { if ((rc = tap(ctx, s, taps->D1_seg, D[0], n))) return rc; if ((rc = tap(ctx, s, taps->D2_seg, D[1], n))) return rc; }
+  if (taps) { if ((rc = tap(ctx, s, taps->D1_seg, tap_e->out0, n))) return rc; if ((rc = tap(ctx, s, taps->D2_seg, tap_e->out1, n))) return rc; }
   for (int side = 0; side < nsides; ++side) {
     SvoTimer t(ctx, "k_elas_gap");
-    hipLaunchKernelGGL(k_elas_gap, dim3(Hd), dim3(256), 0, s, D[side], Wd, 1, Wd, gap_width, p.add_corners);
-    hipLaunchKernelGGL(k_elas_gap, dim3(Wd), dim3(256), 0, s, D[side], Hd, Wd, 1, gap_width, p.add_corners);
+    hipLaunchKernelGGL(k_elas_gap, dim3(Hd, ub), dim3(256), 0, s, d_tab, side, Wd, 1, Wd, gap_width, p.add_corners);
+    hipLaunchKernelGGL(k_elas_gap, dim3(Wd, ub), dim3(256), 0, s, d_tab, side, Hd, Wd, 1, gap_width, p.add_corners);
   }
-  if (taps) { if ((rc = tap(ctx, s, taps->D1_gap, D[0], n))) return rc; if ((rc = tap(ctx, s, taps->D2_gap, D[1], n))) return rc; }
+  if (taps) { if ((rc = tap(ctx, s, taps->D1_gap, tap_e->out0, n))) return rc; if ((rc = tap(ctx, s, taps->D2_gap, tap_e->out1, n))) return rc; }
   if (p.filter_adaptive_mean)
     for (int side = 0; side < nsides; ++side) {
       SvoTimer t(ctx, "k_elas_mean");
-      hipLaunchKernelGGL(k_elas_mean_h, pix, dim3(256), 0, s, D[side], Wd, Hd, sub, T[side]);
-      hipLaunchKernelGGL(k_elas_mean_v, pix, dim3(256), 0, s, T[side], Wd, Hd, sub, D[side]);
+      hipLaunchKernelGGL(k_elas_mean_h, pix, dim3(256), 0, s, d_tab, side, Wd, Hd, sub);
+      hipLaunchKernelGGL(k_elas_mean_v, pix, dim3(256), 0, s, d_tab, side, Wd, Hd, sub);
     }
-  if (taps) { if ((rc = tap(ctx, s, taps->D1_mean, D[0], n))) return rc; if ((rc = tap(ctx, s, taps->D2_mean, D[1], n))) return rc; }
+  if (taps) { if ((rc = tap(ctx, s, taps->D1_mean, tap_e->out0, n))) return rc; if ((rc = tap(ctx, s, taps->D2_mean, tap_e->out1, n))) return rc; }
   if (p.filter_median)
     for (int side = 0; side < nsides; ++side) {
       SvoTimer t(ctx, "k_elas_median");
-      hipLaunchKernelGGL(k_elas_median_h, pix, dim3(256), 0, s, D[side], Wd, Hd, T[side]);
-      hipLaunchKernelGGL(k_elas_median_v, pix, dim3(256), 0, s, T[side], Wd, Hd, D[side]);
+      hipLaunchKernelGGL(k_elas_median_h, pix, dim3(256), 0, s, d_tab, side, Wd, Hd);
+      hipLaunchKernelGGL(k_elas_median_v, pix, dim3(256), 0, s, d_tab, side, Wd, Hd);
     }
   return SVO_OK;
+}
+
+void fill_prior(const svo_elas_params& p, int32_t (&P)[256]) {   // elas.cpp:795-799
+  const int disp_num = p.disp_max + 1;
+  const float two_sigma_squared = 2 * p.sigma * p.sigma;
+  for (int dd = 0; dd < 256; ++dd)
+    P[dd] = dd < disp_num ? (int32_t)((-logf(p.gamma + expf(-dd * dd / two_sigma_squared)) + logf(p.gamma)) / p.beta) : 0;
 }
 
 // One pair, latency first: everything between the images in HBM (dL, dR, `pitch` bytes per row) and the two
@@ -1031,11 +1137,17 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
               const svo_elas_params& p, svo_elas_taps* taps, float** outD1, float** outD2, int* produced) {
   hipStream_t s = ctx->stream;
   const size_t nd = p.subsampling ? (size_t)(W / 2) * (H / 2) : (size_t)W * H;
+  const int ncell = st->gw * st->gh;
   int rc;
   *produced = 0;
-  if ((rc = elas_phase_a(ctx, st, s, dL, dR, pitch, W, H, p))) return rc;
+  ElasTab e = tab_entry(st, dL, dR, st->d_can, st->d_T[0], st->d_T[1]);
+  SVO_HIP(ctx, hipMemcpyAsync(st->d_tab, &e, sizeof e, hipMemcpyHostToDevice, s));
+  // calloc'ed in the reference: row 0 / column 0 of the lattice stay 0
+  SVO_HIP(ctx, hipMemsetAsync(st->d_can, 0, (size_t)st->Wc * st->Hc * sizeof(int16_t), s));
+  if ((rc = elas_phase_a(ctx, s, st->d_tab, 1, pitch, W, H, st->Wc, st->Hc, p))) return rc;
   {
     HostTimer ht(ctx, "host_elas_wait_candidates");
+    SVO_HIP(ctx, hipMemcpyAsync(st->h_can, st->d_can, (size_t)st->Wc * st->Hc * sizeof(int16_t), hipMemcpyDeviceToHost, s));
     SVO_HIP(ctx, hipStreamSynchronize(s));
   }
   if (taps) {
@@ -1045,7 +1157,7 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
   ElasWork w;
   {
     HostTimer ht(ctx, "host_elas_support_filter");
-    elas_filter(st, W, H, p, w);
+    elas_filter(st->h_can, st->Wc, st->Hc, W, H, p, w);
   }
   if (taps) {
     taps->n_support = (int32_t)w.sp.size();
@@ -1053,16 +1165,32 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
       memcpy(taps->support, w.spflat.data(), sizeof(int32_t) * 3 * std::min<size_t>(w.sp.size(), (size_t)std::max(taps->cap_support, 0)));
   }
   if (w.sp.size() < 3) return SVO_OK;   // *produced stays 0
-  if ((rc = elas_phase_b_grids(ctx, st, s, nd, p, w))) return rc;
+  // support points -> HBM; the disparity grids need nothing else, so the GPU builds them while the host triangulates
+  e.nsp = (int32_t)w.sp.size();
+  SVO_HIP(ctx, hipMemcpyAsync(st->d_tab, &e, sizeof e, hipMemcpyHostToDevice, s));
+  SVO_HIP(ctx, hipMemcpyAsync(st->d_sp, w.spflat.data(), w.spflat.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  for (int side = 0; side < 2; ++side) {
+    SVO_HIP(ctx, hipMemsetAsync(st->d_grid[side], 0, (size_t)ncell * 8 * sizeof(uint32_t), s));
+    SVO_HIP(ctx, hipMemsetAsync(st->d_owner[side], 0xff, nd * sizeof(int32_t), s));
+  }
+  if ((rc = elas_phase_b_grids(ctx, s, st->d_tab, 1, e.nsp, st->gw, st->gh, p))) return rc;
   {
     HostTimer ht(ctx, "host_elas_delaunay");
-    elas_triangulate(st, taps, w, true);
+    elas_triangulate(st->cap_tri, taps, w, true);
   }
   if (w.err) { hipStreamSynchronize(s); ctx->last_error = w.err; return SVO_E_INVALID; }
   {
     HostTimer ht(ctx, "host_elas_upload2_match_sync");
-    rc = elas_phase_b(ctx, st, s, W, H, p, w, taps, st->d_T[0], st->d_T[1]);
-    hipStreamSynchronize(s);   // `w` must outlive its uploads; the callers read the maps next anyway
+    int32_t P[256];
+    fill_prior(p, P);
+    e.nt0 = (int32_t)w.tri[0].size() / 3; e.nt1 = (int32_t)w.tri[1].size() / 3;
+    SVO_HIP(ctx, hipMemcpyAsync(st->d_tab, &e, sizeof e, hipMemcpyHostToDevice, s));
+    SVO_HIP(ctx, hipMemcpyAsync(st->d_P, P, sizeof P, hipMemcpyHostToDevice, s));
+    for (int side = 0; side < 2; ++side)
+      if (!w.tri[side].empty())
+        SVO_HIP(ctx, hipMemcpyAsync(st->d_tri[side], w.tri[side].data(), w.tri[side].size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    rc = elas_phase_b(ctx, s, st->d_tab, 1, std::max(e.nt0, e.nt1), W, H, st->gw, st->gh, st->gd, st->d_P, p, st, &e, &w, taps);
+    hipStreamSynchronize(s);   // `w`, `e`, `P` must outlive their uploads; the callers read the maps next anyway
   }
   if (rc) return rc;
   *outD1 = st->d_T[0]; *outD2 = st->d_T[1];
@@ -1071,14 +1199,31 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
 }
 
 // ---- many pairs at once -----------------------------------------------------------------------------
-// One ElasState ("slot") per pair of the batch and a few HIP streams: the small kernels of different pairs
-// overlap on the GPU, the two sequential host stages of different pairs run on a pool of host threads.
+// One ElasState ("slot") per pair; every stage is ONE launch for the whole batch (pair index in the grid);
+// the two sequential host stages of the pairs run on a pool of host threads, which also upload their pair's
+// support points and triangles on a few copy streams.
 struct ElasBatch {
   std::vector<ElasState*> slots;
   std::vector<hipStream_t> streams;
+  int cap = 0, can_elems = 0;
+  ElasTab* d_tab = nullptr;
+  ElasTab* h_tab = nullptr;      // pinned
+  int16_t* d_can = nullptr;      // [cap][Wc*Hc]
+  int16_t* h_can = nullptr;      // pinned
+  int32_t* d_P = nullptr;
+  void release_tables() {
+    if (d_tab) hipFree(d_tab);
+    if (h_tab) hipHostFree(h_tab);
+    if (d_can) hipFree(d_can);
+    if (h_can) hipHostFree(h_can);
+    d_tab = nullptr; h_tab = nullptr; d_can = nullptr; h_can = nullptr;
+    cap = 0; can_elems = 0;
+  }
   ~ElasBatch() {
     for (ElasState* st : slots) { st->release(); delete st; }
     for (hipStream_t s : streams) hipStreamDestroy(s);
+    release_tables();
+    if (d_P) hipFree(d_P);
   }
 };
 #define ELAS_BATCH_STREAMS 8
@@ -1128,60 +1273,98 @@ extern "C" int svo_elas_batch_dev(svo_ctx* ctx, const uint8_t* d_L, const uint8_
   while ((int)eb->slots.size() < B) eb->slots.push_back(new ElasState());
   for (int b = 0; b < B; ++b)
     if ((rc = elas_prepare(ctx, eb->slots[b], W, H, p, false))) return rc;
+  const ElasState* s0 = eb->slots[0];
+  const int Wc = s0->Wc, Hc = s0->Hc, gw = s0->gw, gh = s0->gh, ncell = gw * gh, wh = Wc * Hc;
+  if (eb->cap < B || eb->can_elems != wh) {
+    SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    eb->release_tables();
+    SVO_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&eb->d_tab), sizeof(ElasTab) * (size_t)B));
+    SVO_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&eb->h_tab), sizeof(ElasTab) * (size_t)B, hipHostMallocDefault));
+    SVO_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&eb->d_can), sizeof(int16_t) * (size_t)B * wh));
+    SVO_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&eb->h_can), sizeof(int16_t) * (size_t)B * wh, hipHostMallocDefault));
+    eb->cap = B; eb->can_elems = wh;
+  }
+  if (!eb->d_P) SVO_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&eb->d_P), 256 * sizeof(int32_t)));
   const size_t nd = p.subsampling ? (size_t)(W / 2) * (H / 2) : (size_t)W * H;
   const size_t img = (size_t)stride * H;
   const int ns = (int)eb->streams.size();
-  const bool prof = ctx->profiling;
-  ctx->profiling = false;   // the HIP-event timers assume the context's own stream
-  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));   // inputs produced on the context's stream are complete
-  // phase A for every pair
+  hipStream_t s = ctx->stream;
   const bool dbg = getenv("SVO_ELAS_BATCH_DEBUG") != nullptr;
   auto tnow = []() { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double, std::milli>(b - a).count(); };
   const auto t0 = tnow();
-  for (int b = 0; b < B && rc == SVO_OK; ++b)
-    rc = elas_phase_a(ctx, eb->slots[b], eb->streams[b % ns], d_L + b * img, d_R + b * img, stride, W, H, p);
+
+  // phase A: one launch per stage for all pairs, candidates back in one copy
+  for (int b = 0; b < B; ++b)
+    eb->h_tab[b] = tab_entry(eb->slots[b], d_L + b * img, d_R + b * img, eb->d_can + (size_t)b * wh, d_D1 + b * nd, d_D2 + b * nd);
+  SVO_HIP(ctx, hipMemcpyAsync(eb->d_tab, eb->h_tab, sizeof(ElasTab) * (size_t)B, hipMemcpyHostToDevice, s));
+  SVO_HIP(ctx, hipMemsetAsync(eb->d_can, 0, sizeof(int16_t) * (size_t)B * wh, s));   // lattice row 0 / column 0 stay 0
+  if ((rc = elas_phase_a(ctx, s, eb->d_tab, B, stride, W, H, Wc, Hc, p))) return rc;
+  SVO_HIP(ctx, hipMemcpyAsync(eb->h_can, eb->d_can, sizeof(int16_t) * (size_t)B * wh, hipMemcpyDeviceToHost, s));
+  for (int b = 0; b < B; ++b)
+    for (int side = 0; side < 2; ++side) {   // cleared while the host stages run
+      SVO_HIP(ctx, hipMemsetAsync(eb->slots[b]->d_grid[side], 0, (size_t)ncell * 8 * sizeof(uint32_t), eb->streams[b % ns]));
+      SVO_HIP(ctx, hipMemsetAsync(eb->slots[b]->d_owner[side], 0xff, nd * sizeof(int32_t), eb->streams[b % ns]));
+    }
+  SVO_HIP(ctx, hipStreamSynchronize(s));
   const auto t1 = tnow();
-  for (hipStream_t s : eb->streams) hipStreamSynchronize(s);
-  const auto t2 = tnow();
-  // a pool of host threads, one pair at a time each: the two host stages, then that pair's phase B enqueued
-  // straight away on its stream (maps built in place in the caller's buffers) - host work, launches and GPU
-  // work of different pairs overlap
+
+  // host stages on a pool of threads, one pair at a time each; each worker uploads its pair's lists itself
   std::vector<ElasWork> work(B);
   std::vector<int> prc(B, SVO_OK);
-  if (rc == SVO_OK) {
+  {
     const int nthreads = std::max(1, std::min<int>(B, std::min(32u, std::max(1u, std::thread::hardware_concurrency() / 2))));
     std::atomic<int> next(0);
     auto worker = [&]() {
       hipSetDevice(ctx->device);   // the current device is per-thread state
       for (int b = next.fetch_add(1); b < B; b = next.fetch_add(1)) {
         ElasWork& w = work[b];
-        elas_filter(eb->slots[b], W, H, p, w);
+        ElasState* st = eb->slots[b];
+        elas_filter(eb->h_can + (size_t)b * wh, Wc, Hc, W, H, p, w);
         const bool ok = w.sp.size() >= 3;
-        if (ok) elas_triangulate(eb->slots[b], nullptr, w, false);
-        if (produced) produced[b] = ok && !w.err ? 1 : 0;
-        if (!ok || w.err) continue;   // fewer than 3 support points: outputs untouched, as the reference leaves them
-        hipStream_t s = eb->streams[b % ns];
-        int r = elas_phase_b_grids(ctx, eb->slots[b], s, nd, p, w);
-        if (r == SVO_OK) r = elas_phase_b(ctx, eb->slots[b], s, W, H, p, w, nullptr, d_D1 + b * nd, d_D2 + b * nd);
-        prc[b] = r;
+        if (ok) elas_triangulate(st->cap_tri, nullptr, w, false);
+        if (!ok || w.err) continue;
+        hipStream_t cs = eb->streams[b % ns];
+        hipError_t e = hipMemcpyAsync(st->d_sp, w.spflat.data(), w.spflat.size() * sizeof(int32_t), hipMemcpyHostToDevice, cs);
+        for (int side = 0; side < 2 && e == hipSuccess; ++side)
+          if (!w.tri[side].empty())
+            e = hipMemcpyAsync(st->d_tri[side], w.tri[side].data(), w.tri[side].size() * sizeof(int32_t), hipMemcpyHostToDevice, cs);
+        if (e != hipSuccess) prc[b] = SVO_E_HIP;
       }
     };
     std::vector<std::thread> pool;
     for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
     worker();
     for (std::thread& t : pool) t.join();
-    for (int b = 0; b < B && rc == SVO_OK; ++b) {
-      if (work[b].err) { ctx->last_error = work[b].err; rc = SVO_E_INVALID; }
-      else if (prc[b]) rc = prc[b];
-    }
   }
-  const auto t3 = tnow();
-  for (hipStream_t s : eb->streams) hipStreamSynchronize(s);   // `work` is read by the uploads until here
-  if (dbg) fprintf(stderr, "elas batch B=%d: enqueue A %.2f ms, wait A %.2f, host+enqueue B %.2f, wait B %.2f\n", B,
-                   ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, tnow()));
-  ctx->profiling = prof;
+  int max_nsp = 0, max_nt = 0;
+  for (int b = 0; b < B && rc == SVO_OK; ++b) {
+    const ElasWork& w = work[b];
+    if (w.err) { ctx->last_error = w.err; rc = SVO_E_INVALID; break; }
+    if (prc[b]) { ctx->last_error = "svo_elas_batch_dev: upload failed"; rc = prc[b]; break; }
+    ElasTab& e = eb->h_tab[b];
+    e.produced = w.sp.size() >= 3;   // fewer than 3 support points: outputs untouched, as the reference leaves them
+    e.nsp = (int32_t)w.sp.size(); e.nt0 = (int32_t)w.tri[0].size() / 3; e.nt1 = (int32_t)w.tri[1].size() / 3;
+    if (produced) produced[b] = e.produced;
+    if (e.produced) { max_nsp = std::max(max_nsp, e.nsp); max_nt = std::max(max_nt, std::max(e.nt0, e.nt1)); }
+  }
+  for (hipStream_t cs : eb->streams) hipStreamSynchronize(cs);   // lists uploaded, grids cleared
+  const auto t2 = tnow();
+
+  // phase B: again one launch per stage for the whole batch, maps built in place in the caller's buffers
+  if (rc == SVO_OK && max_nsp > 0) {
+    int32_t P[256];
+    fill_prior(p, P);
+    hipMemcpyAsync(eb->d_P, P, sizeof P, hipMemcpyHostToDevice, s);
+    hipMemcpyAsync(eb->d_tab, eb->h_tab, sizeof(ElasTab) * (size_t)B, hipMemcpyHostToDevice, s);
+    rc = elas_phase_b_grids(ctx, s, eb->d_tab, B, max_nsp, gw, gh, p);
+    if (rc == SVO_OK)
+      rc = elas_phase_b(ctx, s, eb->d_tab, B, max_nt, W, H, gw, gh, s0->gd, eb->d_P, p, nullptr, nullptr, nullptr, nullptr);
+  }
+  hipStreamSynchronize(s);
+  if (dbg) fprintf(stderr, "elas batch B=%d: phase A %.2f ms, host stages %.2f, phase B %.2f\n", B, ms(t0, t1), ms(t1, t2),
+                   ms(t2, tnow()));
   if (rc == SVO_OK) SVO_HIP(ctx, hipGetLastError());
   return rc;
 }

@@ -203,3 +203,18 @@ def test_batch_equals_one_pair_at_a_time(ctx, middlebury):
             continue
         e1, e2 = ctx.elas_process(L, R, p)
         assert np.array_equal(h1[b], e1) and np.array_equal(h2[b], e2), b
+
+
+def test_batch_argument_checks(ctx):
+    import torch
+    dev = torch.device("cuda", 0)
+    z = torch.zeros((2, 64, 128), dtype=torch.uint8, device=dev)
+    D = torch.zeros((2, 64, 128), dtype=torch.float32, device=dev)
+    with pytest.raises(svo.SvoError):      # B < 1
+        ctx.elas_batch_dev(z.data_ptr(), z.data_ptr(), 128, 128, 64, 0, D.data_ptr(), D.data_ptr())
+    with pytest.raises(svo.SvoError):      # stride < width
+        ctx.elas_batch_dev(z.data_ptr(), z.data_ptr(), 64, 128, 64, 2, D.data_ptr(), D.data_ptr())
+    with pytest.raises(svo.SvoError):      # null output
+        ctx.elas_batch_dev(z.data_ptr(), z.data_ptr(), 128, 128, 64, 2, 0, D.data_ptr())
+    produced = ctx.elas_batch_dev(z.data_ptr(), z.data_ptr(), 128, 128, 64, 2, D.data_ptr(), D.data_ptr())
+    assert produced.tolist() == [0, 0]     # black images: no support points, nothing written

@@ -200,4 +200,8 @@ def test_multi_sequence_tracker_equals_independent_chains(pkg, sequence):
     assert multi[-1, 0]["n_lm_edges"] > 20
     with pytest.raises(pkg.SvoError):     # single-sequence entry points refuse a multi-sequence state
         m.track_batch_dev(dL.data_ptr(), dR.data_ptr(), pitch, 1, out.data_ptr())
+    with pytest.raises(pkg.SvoError):     # a step must advance exactly the sequences that were reset
+        m.track_multi_step_dev(dL.data_ptr(), dR.data_ptr(), pitch, S - 1, out.data_ptr())
+    with pytest.raises(pkg.SvoError):     # more sequences than the context was created for
+        m.track_multi_reset(S + 1, cam)
     m.close()

@@ -26,6 +26,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <memory>
 #include <thread>
 #include <vector>
@@ -677,6 +679,14 @@ struct ElasTab {
   int32_t nsp, nt0, nt1, produced;
 };
 
+// before phase B: owner maps to "no triangle", support-point cell sets to empty
+__global__ void k_elas_clear(const ElasTab* tab, int nd, int nbits) {
+  const ElasTab& E = tab[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (!E.produced || i >= nd) return;
+  E.owner0[i] = -1; E.owner1[i] = -1;
+  if (i < nbits) { E.bits0[i] = 0; E.bits1[i] = 0; }
+}
 __global__ __launch_bounds__(256) void k_elas_desc(const ElasTab* tab, int pitch, int W, int H, int half) {
   const ElasTab& E = tab[blockIdx.z >> 1];
   d_elas_desc(blockIdx.z & 1, E.imgL, E.imgR, pitch, W, H, half, E.desc0, E.desc1);
@@ -1199,18 +1209,30 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
 }
 
 // ---- many pairs at once -----------------------------------------------------------------------------
-// One ElasState ("slot") per pair; every stage is ONE launch for the whole batch (pair index in the grid);
-// the two sequential host stages of the pairs run on a pool of host threads, which also upload their pair's
-// support points and triangles on a few copy streams.
+// One ElasState ("slot") per pair; every stage is ONE launch for a chunk of pairs (pair index in the grid);
+// the two sequential host stages of the pairs run on a pool of host threads; the lists they produce go up
+// packed, one copy per chunk.
 struct ElasBatch {
   std::vector<ElasState*> slots;
-  std::vector<hipStream_t> streams;
   int cap = 0, can_elems = 0;
   ElasTab* d_tab = nullptr;
   ElasTab* h_tab = nullptr;      // pinned
   int16_t* d_can = nullptr;      // [cap][Wc*Hc]
   int16_t* h_can = nullptr;      // pinned
   int32_t* d_P = nullptr;
+  int32_t* d_lists = nullptr;    // per call: support points and triangle lists of all pairs, packed
+  int32_t* h_lists = nullptr;    // pinned
+  size_t lists_cap = 0;          // ints
+  int grow_lists(svo_ctx* ctx, size_t need) {
+    if (need <= lists_cap) return SVO_OK;
+    if (d_lists) hipFree(d_lists);
+    if (h_lists) hipHostFree(h_lists);
+    d_lists = nullptr; h_lists = nullptr; lists_cap = 0;
+    SVO_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&d_lists), need * sizeof(int32_t)));
+    SVO_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&h_lists), need * sizeof(int32_t), hipHostMallocDefault));
+    lists_cap = need;
+    return SVO_OK;
+  }
   void release_tables() {
     if (d_tab) hipFree(d_tab);
     if (h_tab) hipHostFree(h_tab);
@@ -1221,12 +1243,13 @@ struct ElasBatch {
   }
   ~ElasBatch() {
     for (ElasState* st : slots) { st->release(); delete st; }
-    for (hipStream_t s : streams) hipStreamDestroy(s);
     release_tables();
     if (d_P) hipFree(d_P);
+    if (d_lists) hipFree(d_lists);
+    if (h_lists) hipHostFree(h_lists);
   }
 };
-#define ELAS_BATCH_STREAMS 8
+#define ELAS_BATCH_CHUNK 32
 
 }  // namespace
 
@@ -1265,16 +1288,11 @@ extern "C" int svo_elas_batch_dev(svo_ctx* ctx, const uint8_t* d_L, const uint8_
   SVO_HIP(ctx, hipSetDevice(ctx->device));
   if (!ctx->elas_batch) ctx->elas_batch = new ElasBatch();
   ElasBatch* eb = reinterpret_cast<ElasBatch*>(ctx->elas_batch);
-  while ((int)eb->streams.size() < std::min(B, ELAS_BATCH_STREAMS)) {
-    hipStream_t s = nullptr;
-    SVO_HIP(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    eb->streams.push_back(s);
-  }
   while ((int)eb->slots.size() < B) eb->slots.push_back(new ElasState());
   for (int b = 0; b < B; ++b)
     if ((rc = elas_prepare(ctx, eb->slots[b], W, H, p, false))) return rc;
   const ElasState* s0 = eb->slots[0];
-  const int Wc = s0->Wc, Hc = s0->Hc, gw = s0->gw, gh = s0->gh, ncell = gw * gh, wh = Wc * Hc;
+  const int Wc = s0->Wc, Hc = s0->Hc, gw = s0->gw, gh = s0->gh, wh = Wc * Hc;
   if (eb->cap < B || eb->can_elems != wh) {
     SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     eb->release_tables();
@@ -1287,84 +1305,156 @@ extern "C" int svo_elas_batch_dev(svo_ctx* ctx, const uint8_t* d_L, const uint8_
   if (!eb->d_P) SVO_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&eb->d_P), 256 * sizeof(int32_t)));
   const size_t nd = p.subsampling ? (size_t)(W / 2) * (H / 2) : (size_t)W * H;
   const size_t img = (size_t)stride * H;
-  const int ns = (int)eb->streams.size();
   hipStream_t s = ctx->stream;
+
+  // The batch is cut into chunks that move through  A (GPU) -> host stages -> B (GPU)  as a pipeline: while the
+  // host threads work on chunk c, the GPU runs phase A of chunk c+1 and phase B of chunk c-1.
+  const char* chunk_env = getenv("SVO_ELAS_CHUNK");   // tuning knob, default ELAS_BATCH_CHUNK
+  const int C = std::min(B, chunk_env && atoi(chunk_env) > 0 ? atoi(chunk_env) : ELAS_BATCH_CHUNK), NC = (B + C - 1) / C;
+  std::vector<hipEvent_t> evA(NC, nullptr);
+  for (int c = 0; c < NC; ++c) SVO_HIP(ctx, hipEventCreateWithFlags(&evA[c], hipEventDisableTiming));
+  int32_t P[256];
+  fill_prior(p, P);
+  for (int b = 0; b < B; ++b)
+    eb->h_tab[b] = tab_entry(eb->slots[b], d_L + b * img, d_R + b * img, eb->d_can + (size_t)b * wh, d_D1 + b * nd, d_D2 + b * nd);
+  SVO_HIP(ctx, hipMemcpyAsync(eb->d_tab, eb->h_tab, sizeof(ElasTab) * (size_t)B, hipMemcpyHostToDevice, s));
+  SVO_HIP(ctx, hipMemcpyAsync(eb->d_P, P, sizeof P, hipMemcpyHostToDevice, s));
+  SVO_HIP(ctx, hipMemsetAsync(eb->d_can, 0, sizeof(int16_t) * (size_t)B * wh, s));   // lattice row 0 / column 0 stay 0
+
+  auto enqueue_a = [&](int c) -> int {   // descriptors + lattice candidates of the chunk, candidates on their way back
+    const int b0 = c * C, nb = std::min(C, B - b0);
+    int r = elas_phase_a(ctx, s, eb->d_tab + b0, nb, stride, W, H, Wc, Hc, p);
+    if (r) return r;
+    SVO_HIP(ctx, hipMemcpyAsync(eb->h_can + (size_t)b0 * wh, eb->d_can + (size_t)b0 * wh, sizeof(int16_t) * (size_t)nb * wh,
+                                hipMemcpyDeviceToHost, s));
+    SVO_HIP(ctx, hipEventRecord(evA[c], s));
+    return SVO_OK;
+  };
+
+  // persistent pool: the two host stages of one pair per task
+  std::vector<ElasWork> work(B);
+  std::vector<int> prc(B, SVO_OK);
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  int task_begin = 0, task_end = 0, next_task = 0, running = 0;
+  bool quit = false;
+  auto do_pair = [&](int b) {
+    ElasWork& w = work[b];
+    ElasState* st = eb->slots[b];
+    elas_filter(eb->h_can + (size_t)b * wh, Wc, Hc, W, H, p, w);
+    const bool ok = w.sp.size() >= 3;
+    if (ok) elas_triangulate(st->cap_tri, nullptr, w, false);
+  };
+  auto worker = [&]() {
+    hipSetDevice(ctx->device);   // the current device is per-thread state
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv_go.wait(lk, [&] { return quit || next_task < task_end; });
+      if (quit) return;
+      const int b = next_task++;
+      ++running;
+      lk.unlock();
+      do_pair(b);
+      lk.lock();
+      if (--running == 0 && next_task >= task_end) cv_done.notify_all();
+    }
+  };
+  const int nthreads = std::max(1, std::min<int>(C, std::min(32u, std::max(1u, std::thread::hardware_concurrency() / 2))));
+  std::vector<std::thread> pool;
+  for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker);
+  auto host_stage = [&](int c) {
+    const int b0 = c * C, nb = std::min(C, B - b0);
+    std::unique_lock<std::mutex> lk(mu);
+    task_begin = b0; next_task = b0; task_end = b0 + nb;
+    cv_go.notify_all();
+    cv_done.wait(lk, [&] { return next_task >= task_end && running == 0; });
+  };
+  double t_sync_copy = 0;
+  size_t lists_used = 0;
+  if ((rc = eb->grow_lists(ctx, (size_t)B * 49152))) return rc;   // ~2x the typical 90 KB of lists per pair
+  auto enqueue_b = [&](int c) -> int {   // counts into the table, then the whole phase B of the chunk
+    const int b0 = c * C, nb = std::min(C, B - b0);
+    int max_nsp = 0, max_nt = 0;
+    for (int b = b0; b < b0 + nb; ++b) {
+      const ElasWork& w = work[b];
+      if (w.err) { ctx->last_error = w.err; return SVO_E_INVALID; }
+      if (prc[b]) { ctx->last_error = "svo_elas_batch_dev: upload failed"; return prc[b]; }
+      ElasTab& e = eb->h_tab[b];
+      e.produced = w.sp.size() >= 3;   // fewer than 3 support points: outputs untouched, as the reference leaves them
+      e.nsp = (int32_t)w.sp.size(); e.nt0 = (int32_t)w.tri[0].size() / 3; e.nt1 = (int32_t)w.tri[1].size() / 3;
+      if (produced) produced[b] = e.produced;
+      if (e.produced) { max_nsp = std::max(max_nsp, e.nsp); max_nt = std::max(max_nt, std::max(e.nt0, e.nt1)); }
+    }
+    if (max_nsp == 0) return SVO_OK;
+    // the chunk's lists, packed, in ONE copy (a copy per list costs ~25 us each under load)
+    const auto tq0 = std::chrono::steady_clock::now();
+    size_t need = 0;
+    for (int b = b0; b < b0 + nb; ++b)
+      if (eb->h_tab[b].produced) need += work[b].spflat.size() + work[b].tri[0].size() + work[b].tri[1].size();
+    if (lists_used + need > eb->lists_cap) {   // earlier chunks may still read the arena: drain, then grow
+      hipStreamSynchronize(s);
+      int r = eb->grow_lists(ctx, std::max(need * (size_t)(NC - c + 1), (size_t)1 << 20));
+      if (r) return r;
+      lists_used = 0;
+    }
+    const size_t chunk_off = lists_used;
+    for (int b = b0; b < b0 + nb; ++b) {
+      ElasTab& e = eb->h_tab[b];
+      if (!e.produced) continue;
+      const ElasWork& w = work[b];
+      const std::vector<int32_t>* src[3] = {&w.spflat, &w.tri[0], &w.tri[1]};
+      int32_t** dst[3] = {&e.sp, &e.tri0, &e.tri1};
+      for (int k = 0; k < 3; ++k) {
+        memcpy(eb->h_lists + lists_used, src[k]->data(), src[k]->size() * sizeof(int32_t));
+        *dst[k] = eb->d_lists + lists_used;
+        lists_used += src[k]->size();
+      }
+    }
+    SVO_HIP(ctx, hipMemcpyAsync(eb->d_lists + chunk_off, eb->h_lists + chunk_off, (lists_used - chunk_off) * sizeof(int32_t),
+                                hipMemcpyHostToDevice, s));
+    t_sync_copy += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count();
+    SVO_HIP(ctx, hipMemcpyAsync(eb->d_tab + b0, eb->h_tab + b0, sizeof(ElasTab) * (size_t)nb, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_elas_clear, dim3((unsigned)((nd + 255) / 256), (unsigned)nb), dim3(256), 0, s, eb->d_tab + b0, (int)nd,
+                       gw * gh * 8);
+    int r = elas_phase_b_grids(ctx, s, eb->d_tab + b0, nb, max_nsp, gw, gh, p);
+    if (r == SVO_OK)
+      r = elas_phase_b(ctx, s, eb->d_tab + b0, nb, max_nt, W, H, gw, gh, s0->gd, eb->d_P, p, nullptr, nullptr, nullptr, nullptr);
+    return r;
+  };
+
+  const bool prof = ctx->profiling;
+  ctx->profiling = false;   // per-chunk launches interleave: the per-kernel event timers would mix chunks
   const bool dbg = getenv("SVO_ELAS_BATCH_DEBUG") != nullptr;
   auto tnow = []() { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
     return std::chrono::duration<double, std::milli>(b - a).count(); };
-  const auto t0 = tnow();
-
-  // phase A: one launch per stage for all pairs, candidates back in one copy
-  for (int b = 0; b < B; ++b)
-    eb->h_tab[b] = tab_entry(eb->slots[b], d_L + b * img, d_R + b * img, eb->d_can + (size_t)b * wh, d_D1 + b * nd, d_D2 + b * nd);
-  SVO_HIP(ctx, hipMemcpyAsync(eb->d_tab, eb->h_tab, sizeof(ElasTab) * (size_t)B, hipMemcpyHostToDevice, s));
-  SVO_HIP(ctx, hipMemsetAsync(eb->d_can, 0, sizeof(int16_t) * (size_t)B * wh, s));   // lattice row 0 / column 0 stay 0
-  if ((rc = elas_phase_a(ctx, s, eb->d_tab, B, stride, W, H, Wc, Hc, p))) return rc;
-  SVO_HIP(ctx, hipMemcpyAsync(eb->h_can, eb->d_can, sizeof(int16_t) * (size_t)B * wh, hipMemcpyDeviceToHost, s));
-  for (int b = 0; b < B; ++b)
-    for (int side = 0; side < 2; ++side) {   // cleared while the host stages run
-      SVO_HIP(ctx, hipMemsetAsync(eb->slots[b]->d_grid[side], 0, (size_t)ncell * 8 * sizeof(uint32_t), eb->streams[b % ns]));
-      SVO_HIP(ctx, hipMemsetAsync(eb->slots[b]->d_owner[side], 0xff, nd * sizeof(int32_t), eb->streams[b % ns]));
-    }
-  SVO_HIP(ctx, hipStreamSynchronize(s));
-  const auto t1 = tnow();
-
-  // host stages on a pool of threads, one pair at a time each; each worker uploads its pair's lists itself
-  std::vector<ElasWork> work(B);
-  std::vector<int> prc(B, SVO_OK);
+  double t_wait = 0, t_host = 0, t_enq = 0;
+  const auto t_start = tnow();
+  rc = enqueue_a(0);
+  for (int c = 0; c < NC && rc == SVO_OK; ++c) {
+    auto t0 = tnow();
+    if (c + 1 < NC) rc = enqueue_a(c + 1);
+    if (rc) break;
+    auto t1 = tnow();
+    hipEventSynchronize(evA[c]);
+    auto t2 = tnow();
+    host_stage(c);
+    auto t3 = tnow();
+    rc = enqueue_b(c);
+    t_enq += ms(t0, t1) + ms(t3, tnow()); t_wait += ms(t1, t2); t_host += ms(t2, t3);
+  }
+  const auto t_loop = tnow();
   {
-    const int nthreads = std::max(1, std::min<int>(B, std::min(32u, std::max(1u, std::thread::hardware_concurrency() / 2))));
-    std::atomic<int> next(0);
-    auto worker = [&]() {
-      hipSetDevice(ctx->device);   // the current device is per-thread state
-      for (int b = next.fetch_add(1); b < B; b = next.fetch_add(1)) {
-        ElasWork& w = work[b];
-        ElasState* st = eb->slots[b];
-        elas_filter(eb->h_can + (size_t)b * wh, Wc, Hc, W, H, p, w);
-        const bool ok = w.sp.size() >= 3;
-        if (ok) elas_triangulate(st->cap_tri, nullptr, w, false);
-        if (!ok || w.err) continue;
-        hipStream_t cs = eb->streams[b % ns];
-        hipError_t e = hipMemcpyAsync(st->d_sp, w.spflat.data(), w.spflat.size() * sizeof(int32_t), hipMemcpyHostToDevice, cs);
-        for (int side = 0; side < 2 && e == hipSuccess; ++side)
-          if (!w.tri[side].empty())
-            e = hipMemcpyAsync(st->d_tri[side], w.tri[side].data(), w.tri[side].size() * sizeof(int32_t), hipMemcpyHostToDevice, cs);
-        if (e != hipSuccess) prc[b] = SVO_E_HIP;
-      }
-    };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nthreads; ++t) pool.emplace_back(worker);
-    worker();
-    for (std::thread& t : pool) t.join();
+    std::unique_lock<std::mutex> lk(mu);
+    quit = true;
+    cv_go.notify_all();
   }
-  int max_nsp = 0, max_nt = 0;
-  for (int b = 0; b < B && rc == SVO_OK; ++b) {
-    const ElasWork& w = work[b];
-    if (w.err) { ctx->last_error = w.err; rc = SVO_E_INVALID; break; }
-    if (prc[b]) { ctx->last_error = "svo_elas_batch_dev: upload failed"; rc = prc[b]; break; }
-    ElasTab& e = eb->h_tab[b];
-    e.produced = w.sp.size() >= 3;   // fewer than 3 support points: outputs untouched, as the reference leaves them
-    e.nsp = (int32_t)w.sp.size(); e.nt0 = (int32_t)w.tri[0].size() / 3; e.nt1 = (int32_t)w.tri[1].size() / 3;
-    if (produced) produced[b] = e.produced;
-    if (e.produced) { max_nsp = std::max(max_nsp, e.nsp); max_nt = std::max(max_nt, std::max(e.nt0, e.nt1)); }
-  }
-  for (hipStream_t cs : eb->streams) hipStreamSynchronize(cs);   // lists uploaded, grids cleared
-  const auto t2 = tnow();
-
-  // phase B: again one launch per stage for the whole batch, maps built in place in the caller's buffers
-  if (rc == SVO_OK && max_nsp > 0) {
-    int32_t P[256];
-    fill_prior(p, P);
-    hipMemcpyAsync(eb->d_P, P, sizeof P, hipMemcpyHostToDevice, s);
-    hipMemcpyAsync(eb->d_tab, eb->h_tab, sizeof(ElasTab) * (size_t)B, hipMemcpyHostToDevice, s);
-    rc = elas_phase_b_grids(ctx, s, eb->d_tab, B, max_nsp, gw, gh, p);
-    if (rc == SVO_OK)
-      rc = elas_phase_b(ctx, s, eb->d_tab, B, max_nt, W, H, gw, gh, s0->gd, eb->d_P, p, nullptr, nullptr, nullptr, nullptr);
-  }
-  hipStreamSynchronize(s);
-  if (dbg) fprintf(stderr, "elas batch B=%d: phase A %.2f ms, host stages %.2f, phase B %.2f\n", B, ms(t0, t1), ms(t1, t2),
-                   ms(t2, tnow()));
+  for (std::thread& t : pool) t.join();
+  hipStreamSynchronize(s);   // the pinned table and list arena are read by copies until here
+  if (dbg) fprintf(stderr, "elas batch B=%d chunk=%d: enqueue %.2f ms (of it packing the lists %.2f), wait for A %.2f, host stages %.2f, tail wait %.2f, total %.2f\n",
+                   B, C, t_enq, t_sync_copy, t_wait, t_host, ms(t_loop, tnow()), ms(t_start, tnow()));
+  for (hipEvent_t e : evA) hipEventDestroy(e);
+  ctx->profiling = prof;
   if (rc == SVO_OK) SVO_HIP(ctx, hipGetLastError());
   return rc;
 }

@@ -206,11 +206,17 @@ __device__ __forceinline__ void d_elas_raster(const int32_t* sp, const int32_t* 
     const float s_u = part ? B_u : A_u, e_u = part ? C_u : B_u;
     const float m_a = part ? BC_a : AB_a, m_b = part ? BC_b : AB_b;
     if ((int)s_u == (int)e_u) continue;
-    for (int u = max((int)s_u, 0) + lane; u < min((int)e_u, W); u += 64) {
+    // the lattice triangles are ~10-25 columns wide: the 64 lanes form lx x ly, lx = the power of two that
+    // covers the columns of this part, the other lanes share each column's rows
+    const int u_lo = max((int)s_u, 0), u_hi = min((int)e_u, W);
+    int lx = 4;
+    while (lx < 64 && lx < u_hi - u_lo) lx <<= 1;
+    const int ly = 64 / lx, my_x = lane & (lx - 1), my_y = lane / lx;
+    for (int u = u_lo + my_x; u < u_hi; u += lx) {
       if (sub && (u & 1)) continue;
       const int v_1 = (int)(AC_a * (float)u + AC_b);
       const int v_2 = (int)(m_a * (float)u + m_b);
-      for (int v = max(min(v_1, v_2), 0); v < min(max(v_1, v_2), H); ++v) {
+      for (int v = max(min(v_1, v_2), 0) + my_y; v < min(max(v_1, v_2), H); v += ly) {
         if (!sub) atomicMax(&owner[v * W + u], t);
         else if (!(v & 1) && (v >> 1) < H / 2 && (u >> 1) < W / 2) atomicMax(&owner[(v >> 1) * (W / 2) + (u >> 1)], t);
       }

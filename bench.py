@@ -206,6 +206,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-track-leg", action="store_true")
     ap.add_argument("--no-elas-leg", action="store_true")
+    ap.add_argument("--depth-source", type=int, default=0, choices=[0, 1],
+                    help="track workload: 0 sparse epipolar stereo (north star), 1 dense ELAS map (BASELINE configs[4] without YOLO)")
     ap.add_argument("--sequences", type=int, default=1,
                     help="track workload: S concurrent sequences per GPU (svo_track_multi_step_dev), one frame of each per step")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (single-GPU dry runs)")
@@ -244,6 +246,8 @@ def main():
         d_res = torch.zeros(((args.warmup + args.steps) * B, pkg.TRACK_DTYPE.itemsize), dtype=torch.uint8, device=dev)
         svo.track_multi_reset(B, cam)
     elif track:
+        if args.depth_source:
+            svo.set_option("depth_source", args.depth_source)
         n_frames = B * (args.warmup + args.steps)       # one continuous sequence per rank
         dL, dR, T_gt = render_frames(synth, n_frames, dev, seed)
         d_res = torch.zeros((n_frames, pkg.TRACK_DTYPE.itemsize), dtype=torch.uint8, device=dev)
@@ -306,7 +310,9 @@ def main():
                 res = res.reshape(-1, B)[:, 0]
                 cfg["concurrent_sequences_per_gpu"] = B
             rmse, last = ate_rmse(res, T_gt.numpy()[:len(res)])
-            cfg.update({"workload": "synth-kitti00 sequence 1241x376, full Tracking::Track loop per frame: ORB on L and R, "
+            cfg.update({"depth_source": "dense ELAS map (svo_elas_batch_dev) -> disp2Depth -> per-keypoint lookups" if args.depth_source
+                        else "sparse epipolar stereo",
+                        "workload": "synth-kitti00 sequence 1241x376, full Tracking::Track loop per frame: ORB on L and R, "
                                     "sparse stereo, matching passes 1+2, PnP-RANSAC, pose-only LM, map-point "
                                     "lifecycle (BASELINE configs[2]); " +
                                     ("%d concurrent staggered sequences per GPU, one frame of each per step" % B if multi

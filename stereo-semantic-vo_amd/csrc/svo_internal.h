@@ -93,7 +93,9 @@ struct svo_ctx {
   void* d_track = nullptr;      // n_seq TrackState records
   int n_seq = 0;
   void* elas = nullptr;     // ElasState (svo_elas.hip), allocated on first svo_elas_process
-  void* elas_batch = nullptr;   // ElasBatch: per-pair states + streams of svo_elas_batch_dev
+  void* elas_batch = nullptr;   // ElasBatch: per-pair states of svo_elas_batch_dev
+  float* d_dense = nullptr;     // dense maps of svo_track_batch_dev with depth_source 1: 2 x dense_cap x W*H
+  int dense_cap = 0;
   svo_camera cam{};
   int track_frame = 0;
 

@@ -651,10 +651,15 @@ static int estimate_F(svo_ctx* ctx, const int32_t* boxes, int n_boxes) {
 // (src/Tracking.cc:226 `MB`, here the ELAS map D1) -> frame::disp2Depth (src/frame.cc:140-164: depth =
 // bf / disp wherever disp != 0, else -1) -> `depthimg.at<float>(y, x)` at the truncated keypoint position;
 // keypoints_r = x - disp unless disp == -1 (src/frame.cc:122-138).  D == nullptr: no map, no depth.
+// blockIdx.y = frame slot of a batch: map `map_stride` floats further on (0 floats: one frame), `produced` (may
+// be null) says whether that frame has a map at all.
 __global__ void k_tk_dense_depth(const svo_kp* kp, const int32_t* nkp, const float* D, int W, float bf,
-                                 float* uR, float* depth, int K) {
+                                 float* uR, float* depth, int K, size_t map_stride, const int32_t* produced) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= K) return;
+  kp += (size_t)blockIdx.y * K; nkp += blockIdx.y; uR += (size_t)blockIdx.y * K; depth += (size_t)blockIdx.y * K;
+  if (D) D += (size_t)blockIdx.y * map_stride;
+  if (produced && !produced[blockIdx.y]) D = nullptr;
   float u = -1.0f, z = -1.0f;
   if (i < *nkp && D) {
     const float disp = D[(size_t)(int)kp[i].y * W + (int)kp[i].x];
@@ -693,7 +698,8 @@ extern "C" int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL,
     if ((rc = svo_elas_run_dev(ctx, dL, dR, ctx->stage_pitch, g.W, g.H, &ep, &dD1, &dD2, &produced))) return rc;
     SvoTimer t(ctx, "k_tk_dense_depth");
     hipLaunchKernelGGL(k_tk_dense_depth, dim3((ctx->max_kp + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_kp,
-                       ctx->d_nkp, produced ? dD1 : nullptr, g.W, ctx->cam.bf, ctx->d_uR, ctx->d_depth, ctx->max_kp);
+                       ctx->d_nkp, produced ? dD1 : nullptr, g.W, ctx->cam.bf, ctx->d_uR, ctx->d_depth, ctx->max_kp, (size_t)0,
+                       (const int32_t*)nullptr);
   } else {
     if ((rc = svo_launch_orb(ctx, dL, dR, ctx->stage_pitch, 1, 2))) return rc;
     if ((rc = svo_launch_stereo(ctx, dL, dR, ctx->stage_pitch, 1, &ctx->cam))) return rc;
@@ -733,10 +739,33 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
   hipSetDevice(ctx->device);
   // the batched mode carries no detection boxes (the offline box files are a per-frame host input)
   SVO_HIP(ctx, hipMemsetAsync(&reinterpret_cast<TrackState*>(ctx->d_track)->n_boxes, 0, 4, ctx->stream));
-  int rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, B, 2 * B);
-  if (rc) return rc;
-  rc = svo_launch_stereo(ctx, d_grayL, d_grayR, stride, B, &ctx->cam);
-  if (rc) return rc;
+  int rc;
+  if (ctx->opt_depth_source == 1) {
+    // dense ELAS maps for the B frames (svo_elas_batch_dev), then the reference's per-keypoint lookups
+    const size_t n = (size_t)ctx->g.W * ctx->g.H;
+    if (ctx->dense_cap < B) {
+      SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->d_dense) hipFree(ctx->d_dense);
+      ctx->d_dense = nullptr; ctx->dense_cap = 0;
+      SVO_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_dense), (2 * n * sizeof(float) + sizeof(int32_t)) * (size_t)B));
+      ctx->dense_cap = B;
+    }
+    float* dD1 = ctx->d_dense;
+    float* dD2 = dD1 + n * (size_t)B;
+    int32_t* d_prod = reinterpret_cast<int32_t*>(dD2 + n * (size_t)B);
+    if ((rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, B, B))) return rc;   // left images only
+    svo_elas_params ep;
+    svo_elas_default_params(0, &ep);
+    std::vector<int32_t> prod(B, 0);
+    if ((rc = svo_elas_batch_dev(ctx, d_grayL, d_grayR, stride, ctx->g.W, ctx->g.H, B, &ep, dD1, dD2, prod.data()))) return rc;
+    SVO_HIP(ctx, hipMemcpyAsync(d_prod, prod.data(), sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_tk_dense_depth, dim3((ctx->max_kp + 255) / 256, B), dim3(256), 0, ctx->stream, ctx->d_kp, ctx->d_nkp,
+                       dD1, ctx->g.W, ctx->cam.bf, ctx->d_uR, ctx->d_depth, ctx->max_kp, n, d_prod);
+    SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `prod` is on this stack frame
+  } else {
+    if ((rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, B, 2 * B))) return rc;
+    if ((rc = svo_launch_stereo(ctx, d_grayL, d_grayR, stride, B, &ctx->cam))) return rc;
+  }
   for (int f = 0; f < B; ++f) {
     rc = tail_launch(ctx, f, d_results + f);
     if (rc) return rc;

@@ -205,3 +205,35 @@ def test_multi_sequence_tracker_equals_independent_chains(pkg, sequence):
     with pytest.raises(pkg.SvoError):     # more sequences than the context was created for
         m.track_multi_reset(S + 1, cam)
     m.close()
+
+
+@pytest.mark.gpu
+def test_gpu_batch_tracker_with_dense_depth_equals_frame_by_frame(pkg, sequence):
+    """depth_source = 1 in the batched, device-resident mode (svo_elas_batch_dev under svo_track_batch_dev) ==
+    svo_track_frame one by one with the same option."""
+    import torch
+    L, R, _ = sequence
+    H, W = L.shape[1], L.shape[2]
+    cam = pkg.Camera(**pkg.KITTI_00_02)
+    a = pkg.Svo(W, H, max_batch=1)
+    a.set_option("depth_source", 1)
+    a.track_reset(cam)
+    single = [a.track_frame(L[k], R[k]) for k in range(N_FRAMES)]
+    a.close()
+    pitch = 1280
+    dev = torch.device("cuda", 0)
+    dL = torch.zeros((N_FRAMES, H, pitch), dtype=torch.uint8, device=dev)
+    dR = torch.zeros_like(dL)
+    dL[:, :, :W] = torch.from_numpy(L).to(dev); dR[:, :, :W] = torch.from_numpy(R).to(dev)
+    res = torch.zeros((N_FRAMES, pkg.TRACK_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    b = pkg.Svo(W, H, max_batch=N_FRAMES)
+    b.set_option("depth_source", 1)
+    b.track_reset(cam)
+    b.track_batch_dev(dL.data_ptr(), dR.data_ptr(), pitch, N_FRAMES, res.data_ptr())
+    b.sync()
+    out = res.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(-1)
+    b.close()
+    assert out[-1]["n_stereo"] > 250 and out[-1]["n_lm_edges"] > 20
+    for k in range(N_FRAMES):
+        assert out[k].tobytes() == single[k].tobytes(), k

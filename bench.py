@@ -143,6 +143,25 @@ def elas_leg(pkg, W, H, device, d_L, d_R, pitch, B, iters=4):
     for _ in range(iters):
         produced = ctx.elas_batch_dev(d_L.data_ptr(), d_R.data_ptr(), pitch, W, H, B, D1.data_ptr(), D2.data_ptr(), p)
     thr = B * iters / (time.perf_counter() - t0)
+    # per-kernel time per pair (HIP events around every launch on the context's stream) and the HBM roofline of
+    # the dominant kernel among those with a defined compulsory traffic (bytes per pair, P = W*H pixels):
+    #   k_elas_desc   2P image bytes in, 2*16P descriptor bytes out
+    #   k_elas_match  2*16P descriptors + 2*4P owner ids in, 2*4P raw maps out
+    #   k_elas_raster 2*4P owner ids written
+    #   k_cc_segments 4P map + 3*4P label / run-length / size arrays written and read once
+    #   k_elas_gap    2 passes over a 4P map, read + write
+    ctx.profile_enable(True); ctx.profile_reset()
+    ctx.elas_batch_dev(d_L.data_ptr(), d_R.data_ptr(), pitch, W, H, B, D1.data_ptr(), D2.data_ptr(), p)
+    ctx.profile_enable(False)
+    P = W * H
+    algo = {"k_elas_desc": 34 * P, "k_elas_match": 48 * P, "k_elas_raster": 8 * P, "k_cc_segments": 28 * P,
+            "k_elas_gap": 16 * P}
+    kern = {k: v[0] * 1e3 / B for k, v in ctx.profile().items() if k.startswith("k_")}
+    dom = max((k for k in kern if k in algo), key=lambda k: kern[k])
+    ach = algo[dom] / (kern[dom] * 1e-6) / 1e9
+    roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": None, "algorithmic_bytes_per_pair": algo[dom],
+            "note": "latency / atomic bound, not bandwidth bound: see DESIGN.md section 8"}
     L = d_L[0, :, :W].cpu().numpy(); R = d_R[0, :, :W].cpu().numpy()
     for _ in range(3):
         E1, _ = ctx.elas_process(L, R, p)
@@ -153,6 +172,7 @@ def elas_leg(pkg, W, H, device, d_L, d_R, pitch, B, iters=4):
     G1 = D1[0].cpu().numpy()
     ctx.close()
     out = {"value": thr, "unit": "stereo pairs/s", "pairs_per_call": B, "pairs_with_maps": int(produced.sum()),
+           "kernel_us_per_pair": {k: round(v, 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])}, "roofline": roof,
            "latency_ms_per_pair_host_buffers": lat * 1e3, "valid_fraction": float((G1 >= 0).mean()),
            "batch_equals_single_call": bool(np.array_equal(G1, E1)), "setting": "ROBOTICS",
            "note": "dense disparity maps D1+D2 per pair; throughput with pairs and maps resident in HBM, latency host to host"}

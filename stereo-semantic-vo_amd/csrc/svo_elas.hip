@@ -1428,8 +1428,6 @@ extern "C" int svo_elas_batch_dev(svo_ctx* ctx, const uint8_t* d_L, const uint8_
     return r;
   };
 
-  const bool prof = ctx->profiling;
-  ctx->profiling = false;   // per-chunk launches interleave: the per-kernel event timers would mix chunks
   const bool dbg = getenv("SVO_ELAS_BATCH_DEBUG") != nullptr;
   auto tnow = []() { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
@@ -1460,7 +1458,6 @@ extern "C" int svo_elas_batch_dev(svo_ctx* ctx, const uint8_t* d_L, const uint8_
   if (dbg) fprintf(stderr, "elas batch B=%d chunk=%d: enqueue %.2f ms (of it packing the lists %.2f), wait for A %.2f, host stages %.2f, tail wait %.2f, total %.2f\n",
                    B, C, t_enq, t_sync_copy, t_wait, t_host, ms(t_loop, tnow()), ms(t_start, tnow()));
   for (hipEvent_t e : evA) hipEventDestroy(e);
-  ctx->profiling = prof;
   if (rc == SVO_OK) SVO_HIP(ctx, hipGetLastError());
   return rc;
 }

@@ -339,3 +339,62 @@ def test_pose_opt_mfma_golden(pkg, case):
     assert st.iterations == int(iters) and st.trials_total == len(G[case + "_trace"])
     assert np.isclose(st.chi2_initial, chi0, rtol=1e-10) and np.isclose(st.chi2_final, chi1, rtol=1e-7)
     assert np.abs(T - G[case + "_T"]).max() < POSE_ATOL_T
+
+
+def test_full_size_batch_properties(pkg):
+    """BASELINE-sized batch (128 pairs of 1241x376, what bench.py times), through size-independent properties:
+    the batch is deterministic (two runs byte-identical), permuting the pairs permutes the outputs, every pair
+    equals the same pair processed alone, and depth = bf / (x - uR) wherever a depth exists."""
+    import importlib
+    import torch
+    synth = importlib.import_module("stereo_semantic_vo_amd.synth")
+    W, H, B, pitch = util.KITTI_W, util.KITTI_H, 128, 1280
+    cam = pkg.Camera(**pkg.KITTI_00_02)
+    dev = torch.device("cuda", 0)
+    L, R, _ = synth.render_sequence(8)
+    dL = torch.zeros((B, H, pitch), dtype=torch.uint8, device=dev); dR = torch.zeros_like(dL)
+    for i in range(B):      # 8 rendered frames, repeated with a cyclic column shift so that all 128 pairs differ
+        s = 3 * (i // 8)
+        dL[i, :, :W] = torch.roll(L[i % 8].to(dev), s, 1); dR[i, :, :W] = torch.roll(R[i % 8].to(dev), s, 1)
+
+    def run(svo, l, r, b):
+        kp = torch.zeros((b, 500, 28), dtype=torch.uint8, device=dev)
+        desc = torch.zeros((b, 500, 32), dtype=torch.uint8, device=dev)
+        n = torch.zeros(b, dtype=torch.int32, device=dev)
+        uR = torch.zeros((b, 500), dtype=torch.float32, device=dev)
+        depth = torch.zeros((b, 500), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        svo.frontend_batch_dev(l.data_ptr(), r.data_ptr(), pitch, b, cam, kp.data_ptr(), desc.data_ptr(), n.data_ptr(),
+                               uR.data_ptr(), depth.data_ptr())
+        svo.sync()
+        return [t.cpu().numpy() for t in (n, kp, desc, uR, depth)]
+
+    svo = pkg.Svo(W, H, max_batch=B)
+    a = run(svo, dL, dR, B)
+    b = run(svo, dL, dR, B)
+    for x, y in zip(a, b):
+        assert x.tobytes() == y.tobytes()                       # deterministic
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(5))
+    c = run(svo, dL[perm.to(dev)].contiguous(), dR[perm.to(dev)].contiguous(), B)
+    n = a[0]
+    assert n.min() > 300
+    for j, i in enumerate(perm.tolist()):                       # permutation equivariance
+        m = int(n[i])
+        assert c[0][j] == m
+        for q in range(1, 5):
+            assert a[q][i][:m].tobytes() == c[q][j][:m].tobytes(), (i, q)
+    one = pkg.Svo(W, H, max_batch=1)
+    for i in (0, 37, 127):                                      # each pair alone == inside the batch
+        s = run(one, dL[i:i + 1].contiguous(), dR[i:i + 1].contiguous(), 1)
+        m = int(n[i])
+        assert s[0][0] == m
+        for q in range(1, 5):
+            assert a[q][i][:m].tobytes() == s[q][0][:m].tobytes(), (i, q)
+    one.close()
+    kp = a[1].view(pkg.KP_DTYPE).reshape(B, 500)
+    for i in range(B):                                          # depth is bf / disparity, float32, wherever it exists
+        m = int(n[i]); d = a[4][i][:m]; has = d > 0
+        assert has.sum() > 150
+        disp = kp[i]["x"][:m][has] - a[3][i][:m][has]
+        assert np.array_equal(d[has], (np.float32(cam.bf) / disp).astype(np.float32))
+    svo.close()

@@ -351,7 +351,7 @@ def test_full_size_batch_properties(pkg):
     W, H, B, pitch = util.KITTI_W, util.KITTI_H, 128, 1280
     cam = pkg.Camera(**pkg.KITTI_00_02)
     dev = torch.device("cuda", 0)
-    L, R, _ = synth.render_sequence(8)
+    L, R, _ = synth.render_sequence(8, device=dev)
     dL = torch.zeros((B, H, pitch), dtype=torch.uint8, device=dev); dR = torch.zeros_like(dL)
     for i in range(B):      # 8 rendered frames, repeated with a cyclic column shift so that all 128 pairs differ
         s = 3 * (i // 8)

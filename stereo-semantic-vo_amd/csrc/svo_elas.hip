@@ -450,6 +450,54 @@ __device__ __forceinline__ void d_elas_gap(float* D, int n, int estride, int lst
   }
 }
 
+// The column pass of gapInterpolation on a tile of C adjacent columns (C a power of two, chosen so that the
+// tile fits the LDS): rows of the tile are read and written as C consecutive floats - the line-per-block
+// kernel above reads a column with a stride of one image row per element.  256 threads = C columns x
+// (256 / C) row chunks; same fill rule.
+__device__ __forceinline__ void d_elas_gap_cols(float* D, int W, int H, int C, int gap, int add_corners) {
+  extern __shared__ unsigned char gap_smem[];
+  float* val = reinterpret_cast<float*>(gap_smem);                    // [H][C]
+  int16_t* nxt = reinterpret_cast<int16_t*>(val + (size_t)H * C);     // [H][C]
+  __shared__ int cl[256], cn[256];
+  const int tid = threadIdx.x, c = tid & (C - 1), t = tid / C, T = 256 / C;
+  const int x0 = blockIdx.x * C, x = x0 + c;
+  const bool col_ok = x < W;
+  for (int v = t; v < H; v += T) val[v * C + c] = col_ok ? D[(size_t)v * W + x] : -10.0f;
+  __syncthreads();
+  const int R = (H + T - 1) / T, b = t * R, e = min(H, b + R);
+  int l = -1, nx = H;
+  for (int v = b; v < e; ++v) if (val[v * C + c] >= 0) l = v;
+  for (int v = e - 1; v >= b; --v) if (val[v * C + c] >= 0) nx = v;
+  cl[t * C + c] = l; cn[t * C + c] = nx;
+  __syncthreads();
+  if (t == 0) {   // one thread per column turns the chunk summaries into carries
+    int carry = -1;
+    for (int k = 0; k < T; ++k) { const int own = cl[k * C + c]; cl[k * C + c] = carry; if (own >= 0) carry = own; }
+    carry = H;
+    for (int k = T - 1; k >= 0; --k) { const int own = cn[k * C + c]; cn[k * C + c] = carry; if (own < H) carry = own; }
+  }
+  __syncthreads();
+  nx = cn[t * C + c];
+  for (int v = e - 1; v >= b; --v) { nxt[v * C + c] = (int16_t)nx; if (val[v * C + c] >= 0) nx = v; }
+  l = cl[t * C + c];
+  for (int v = b; v < e; ++v) {
+    const float cur = val[v * C + c];
+    if (cur >= 0) { l = v; continue; }
+    if (!col_ok) continue;
+    const int lo = l, hi = nxt[v * C + c];
+    float* dst = D + (size_t)v * W + x;
+    if (lo >= 0 && hi < H) {
+      if (hi - lo - 1 <= gap) {
+        const float d1 = val[lo * C + c], d2 = val[hi * C + c];
+        *dst = fabsf(d1 - d2) < 3.0f ? (d1 + d2) / 2 : fminf(d1, d2);
+      }
+    } else if (add_corners) {
+      if (lo < 0 && hi < H) { if (v >= hi - gap) *dst = val[hi * C + c]; }
+      else if (hi >= H && lo >= 0) { if (v <= lo + gap) *dst = val[lo * C + c]; }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // adaptiveMean: 8-tap "bilateral" mean along rows, then along columns, in the reference's SSE lane
 // order: window pixel q sits in slot q % 8, lane i adds slots i and i+4, lanes are summed 0..3.
@@ -762,6 +810,12 @@ __global__ __launch_bounds__(256) void k_elas_gap(const ElasTab* tab, int side, 
   const ElasTab& E = tab[blockIdx.y];
   if (!E.produced) return;
   d_elas_gap(side ? E.out1 : E.out0, n, estride, lstride, gap, add_corners);
+}
+__global__ __launch_bounds__(256) void k_elas_gap_cols(const ElasTab* tab, int side, int W, int H, int C, int gap,
+                                                       int add_corners) {
+  const ElasTab& E = tab[blockIdx.y];
+  if (!E.produced) return;
+  d_elas_gap_cols(side ? E.out1 : E.out0, W, H, C, gap, add_corners);
 }
 // filters: maps in out*, scratch in raw*
 __global__ __launch_bounds__(256) void k_elas_mean_h(const ElasTab* tab, int side, int W, int H, int half) {
@@ -1120,7 +1174,10 @@ int elas_phase_b(svo_ctx* ctx, hipStream_t s, const ElasTab* d_tab, int B, int m
   for (int side = 0; side < nsides; ++side) {
     SvoTimer t(ctx, "k_elas_gap");
     hipLaunchKernelGGL(k_elas_gap, dim3(Hd, ub), dim3(256), 0, s, d_tab, side, Wd, 1, Wd, gap_width, p.add_corners);
-    hipLaunchKernelGGL(k_elas_gap, dim3(Wd, ub), dim3(256), 0, s, d_tab, side, Hd, Wd, 1, gap_width, p.add_corners);
+    int C = 32;   // columns per tile: val (4 B) + next-valid (2 B) per pixel within 60 KB of dynamic LDS
+    while (C > 1 && (size_t)Hd * C * 6 > 60 * 1024) C >>= 1;
+    hipLaunchKernelGGL(k_elas_gap_cols, dim3((Wd + C - 1) / C, ub), dim3(256), (size_t)Hd * C * 6, s, d_tab, side, Wd, Hd, C,
+                       gap_width, p.add_corners);
   }
   if (taps) { if ((rc = tap(ctx, s, taps->D1_gap, tap_e->out0, n))) return rc; if ((rc = tap(ctx, s, taps->D2_gap, tap_e->out1, n))) return rc; }
   if (p.filter_adaptive_mean)

@@ -231,16 +231,24 @@ __device__ __forceinline__ void d_elas_match(bool right, const uint4* desc1, con
                                                     svo_elas_params p, float* D0, float* D1) {
   const int sub = p.subsampling, Wd = sub ? W / 2 : W;
   const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-  if (x >= Wd) return;
   const int u = sub ? 2 * x : x, v = sub ? 2 * y : y;   // subsampling: every second pixel (elas.cpp:846-871)
+  const uint4* Is = right ? desc2 : desc1;
+  const uint4* Io = right ? desc1 : desc2;
+  const size_t line = (size_t)max(min(v, H - 3), 2) * W;
+  // the descriptors of the other image this block can reach (its columns -255 .. +0 for the left map,
+  // +0 .. +255 for the right one) are staged in LDS once: every pixel then reads its 20-60 candidates there
+  __shared__ uint4 win[768];
+  const int u_first = sub ? 2 * (int)(blockIdx.x * 256) : (int)(blockIdx.x * 256);
+  const int u_last = min(sub ? u_first + 510 : u_first + 255, W - 1);
+  const int w0 = max(right ? u_first : u_first - 255, 0), w1 = min(right ? u_last + 255 : u_last, W - 1);
+  for (int i = threadIdx.x; i <= w1 - w0; i += 256) win[i] = Io[line + w0 + i];
+  __syncthreads();
+  if (x >= Wd) return;
   const int addr = y * Wd + x;
   float* D = right ? D1 : D0;
   const int t = (right ? own1 : own0)[addr];
   float out = -10.0f;
   if (t >= 0 && u >= 2 && u < W - 2) {
-    const uint4* Is = right ? desc2 : desc1;
-    const uint4* Io = right ? desc1 : desc2;
-    const size_t line = (size_t)max(min(v, H - 3), 2) * W;
     const uint4 self = Is[line + u];
     if (texture16(self) >= p.match_texture) {
       const float* pl = (right ? pl1 : pl0) + 6 * t;
@@ -264,7 +272,7 @@ __device__ __forceinline__ void d_elas_match(bool right, const uint4* desc1, con
           if (d < d_plane_min || d > d_plane_max) {
             const int uw = right ? u + d : u - d;
             if (uw < 2 || uw >= W - 2) continue;
-            const int val = sad16(self, Io[line + uw]);
+            const int val = sad16(self, win[uw - w0]);
             if (val < min_val) { min_val = val; min_d = d; }
           }
         }
@@ -272,7 +280,7 @@ __device__ __forceinline__ void d_elas_match(bool right, const uint4* desc1, con
       for (int d = d_plane_min; d <= d_plane_max; ++d) {
         const int uw = right ? u + d : u - d;
         if (uw < 2 || uw >= W - 2) continue;
-        const int val = sad16(self, Io[line + uw]) + (valid ? P[abs(d - d_plane)] : 0);
+        const int val = sad16(self, win[uw - w0]) + (valid ? P[abs(d - d_plane)] : 0);
         if (val < min_val) { min_val = val; min_d = d; }
       }
       out = min_d >= 0 ? (float)min_d : -1.0f;

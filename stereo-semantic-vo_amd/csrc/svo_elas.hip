@@ -410,6 +410,97 @@ __device__ __forceinline__ void d_cc_apply(float* D, int n, const int32_t* L, co
   if (size[cc_find(L, i)] < speckle) D[i] = -10.0f;
 }
 
+// Strips: the same labelling, but the rows are cut into strips of CCS_ROWS rows and one workgroup unites
+// everything INSIDE its strip in LDS (run starts per row, vertical contacts between the strip's rows, LDS
+// atomics); only the contacts across strip borders are left for the device-wide union-find - an eighth of
+// the global atomics on the hot roots, which is what the per-pixel version spends its time on.  What the
+// strip kernel leaves behind has the shape the later kernels expect: every pixel points at the root pixel
+// of its strip component, that root carries the component's pixel count in `rlen` (others 0).
+#define CCS_ROWS 8
+__device__ __forceinline__ int lds_find(const int32_t* lab, int i) {
+  int p = lab[i];
+  while (p != i) { i = p; p = lab[i]; }
+  return i;
+}
+__device__ __forceinline__ void lds_union(int32_t* lab, int a, int b) {
+  bool done;
+  do {
+    a = lds_find(lab, a); b = lds_find(lab, b);
+    if (a < b) { const int old = atomicMin(&lab[b], a); done = old == b; b = old; }
+    else if (b < a) { const int old = atomicMin(&lab[a], b); done = old == a; a = old; }
+    else done = true;
+  } while (!done);
+}
+__device__ __forceinline__ void d_cc_strip(const float* D, int W, int H, float thr, int32_t* L, int32_t* rlen, int32_t* size) {
+  extern __shared__ unsigned char ccs_smem[];
+  float* val = reinterpret_cast<float*>(ccs_smem);                           // [rows][W], later the counters
+  int32_t* lab = reinterpret_cast<int32_t*>(ccs_smem) + (size_t)CCS_ROWS * W;   // [rows][W]
+  __shared__ int carry[CCS_ROWS][32];
+  const int tid = threadIdx.x, v0 = blockIdx.x * CCS_ROWS, rows = min(CCS_ROWS, H - v0), n = rows * W;
+  for (int i = tid; i < n; i += 256) val[i] = D[(size_t)v0 * W + i];
+  __syncthreads();
+  // run starts: 32 threads per row, each a chunk; a run start is a break = first pixel, an invalid pixel, or
+  // a jump of more than thr against the left neighbour
+  const int r = tid >> 5, k = tid & 31, chunk = (W + 31) / 32, cb = k * chunk, ce = min(W, cb + chunk);
+  auto brk = [&](int row, int x) {
+    const float c = val[row * W + x];
+    if (x == 0 || !(c >= 0)) return true;
+    const float l = val[row * W + x - 1];
+    return !(l >= 0) || !(fabsf(c - l) <= thr);
+  };
+  int last = -1;
+  if (r < rows) for (int x = cb; x < ce; ++x) if (brk(r, x)) last = x;
+  carry[r][k] = last;
+  __syncthreads();
+  if (k == 0 && r < rows) {
+    int c = 0;
+    for (int q = 0; q < 32; ++q) { const int own = carry[r][q]; carry[r][q] = c; if (own >= 0) c = own; }
+  }
+  __syncthreads();
+  if (r < rows) {
+    int st = carry[r][k];
+    for (int x = cb; x < ce; ++x) { if (brk(r, x)) st = x; lab[r * W + x] = r * W + st; }
+  }
+  __syncthreads();
+  // vertical contacts inside the strip (first column of each run-to-run contact)
+  for (int i = tid; i < n - W; i += 256) {
+    const int x = i % W;
+    const float d = val[i], e = val[i + W];
+    if (!(d >= 0 && e >= 0 && fabsf(d - e) <= thr)) continue;
+    if (x > 0) {
+      const float d0 = val[i - 1], e0 = val[i - 1 + W];
+      if (d0 >= 0 && e0 >= 0 && fabsf(d - d0) <= thr && fabsf(e - e0) <= thr && fabsf(d0 - e0) <= thr) continue;
+    }
+    lds_union(lab, lab[i] == i ? i : lab[i], lab[i + W] == i + W ? i + W : lab[i + W]);
+  }
+  __syncthreads();
+  int32_t* cnt = reinterpret_cast<int32_t*>(val);   // the disparities are not needed any more
+  for (int i = tid; i < n; i += 256) cnt[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) atomicAdd(&cnt[lds_find(lab, i)], 1);
+  __syncthreads();
+  const int g0 = v0 * W;
+  for (int i = tid; i < n; i += 256) {
+    const int root = lds_find(lab, i);
+    L[g0 + i] = g0 + root;
+    size[g0 + i] = 0;
+    rlen[g0 + i] = root == i ? cnt[i] : 0;
+  }
+}
+// the contacts the strips could not see: between the last row of a strip and the first row of the next
+__device__ __forceinline__ void d_cc_merge_borders(const float* D, int W, int H, float thr, int32_t* L) {
+  const int u = blockIdx.x * 256 + threadIdx.x, v = (blockIdx.y + 1) * CCS_ROWS - 1;
+  if (u >= W || v + 1 >= H) return;
+  const int i = v * W + u;
+  const float d = D[i], e = D[i + W];
+  if (!(d >= 0 && e >= 0 && fabsf(d - e) <= thr)) return;
+  if (u > 0) {
+    const float d0 = D[i - 1], e0 = D[i - 1 + W];
+    if (d0 >= 0 && e0 >= 0 && fabsf(d - d0) <= thr && fabsf(e - e0) <= thr && fabsf(d0 - e0) <= thr) return;
+  }
+  cc_union(L, i, i + W);
+}
+
 // ------------------------------------------------------------------------------------------------
 // gapInterpolation, one pass over lines (rows: estride 1, lstride W; columns: estride W, lstride 1).
 // A maximal run of invalid pixels strictly inside a line with 1 <= length <= gap is filled with the
@@ -808,6 +899,16 @@ __global__ __launch_bounds__(256) void k_cc_count(const ElasTab* tab, int n) {
   if (!E.produced) return;
   d_cc_count(n, E.lab, E.owner0, E.size);
 }
+__global__ __launch_bounds__(256) void k_cc_strip(const ElasTab* tab, int side, int W, int H, float thr) {
+  const ElasTab& E = tab[blockIdx.y];
+  if (!E.produced) return;
+  d_cc_strip(side ? E.out1 : E.out0, W, H, thr, E.lab, E.owner0, E.size);
+}
+__global__ void k_cc_merge_borders(const ElasTab* tab, int side, int W, int H, float thr) {
+  const ElasTab& E = tab[blockIdx.z];
+  if (!E.produced) return;
+  d_cc_merge_borders(side ? E.out1 : E.out0, W, H, thr, E.lab);
+}
 __global__ void k_cc_apply(const ElasTab* tab, int side, int n, int speckle) {
   const ElasTab& E = tab[blockIdx.y];
   if (!E.produced) return;
@@ -1171,8 +1272,28 @@ int elas_phase_b(svo_ctx* ctx, hipStream_t s, const ElasTab* d_tab, int B, int m
   const int speckle_size = sub ? (int)(sqrtf((float)p.speckle_size) * 2) : p.speckle_size;
   const int gap_width = sub ? p.ipol_gap_width / 2 + 1 : p.ipol_gap_width;
   const int nb = (int)((n + 255) / 256);
+  // strips in LDS when two strip-sized arrays fit (more than the default 64 KB of dynamic LDS needs an opt-in)
+  const size_t strip_lds = (size_t)2 * CCS_ROWS * Wd * sizeof(int32_t);
+  static bool strip_ok = false, strip_tried = false;
+  if (!strip_tried) {
+    strip_tried = true;
+    strip_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_cc_strip), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   150 * 1024) == hipSuccess;
+    (void)hipGetLastError();
+  }
+  const char* cc_env = getenv("SVO_ELAS_CC_STRIPS");
+  const bool use_strips = strip_ok && strip_lds <= 150 * 1024 && Hd > CCS_ROWS && (!cc_env || atoi(cc_env) != 0);
   for (int side = 0; side < nsides; ++side) {
     SvoTimer t(ctx, "k_cc_segments");
+    if (use_strips) {
+      const int nstrips = (Hd + CCS_ROWS - 1) / CCS_ROWS;
+      hipLaunchKernelGGL(k_cc_strip, dim3(nstrips, ub), dim3(256), strip_lds, s, d_tab, side, Wd, Hd, p.speckle_sim_threshold);
+      hipLaunchKernelGGL(k_cc_merge_borders, dim3((Wd + 255) / 256, nstrips - 1, ub), dim3(256), 0, s, d_tab, side, Wd, Hd,
+                         p.speckle_sim_threshold);
+      hipLaunchKernelGGL(k_cc_count, dim3(nb, ub), dim3(256), 0, s, d_tab, (int)n);
+      hipLaunchKernelGGL(k_cc_apply, dim3(nb, ub), dim3(256), 0, s, d_tab, side, (int)n, speckle_size);
+      continue;
+    }
     hipLaunchKernelGGL(k_cc_rows, dim3(Hd, ub), dim3(256), 0, s, d_tab, side, Wd, p.speckle_sim_threshold);
     hipLaunchKernelGGL(k_cc_merge, pix, dim3(256), 0, s, d_tab, side, Wd, Hd, p.speckle_sim_threshold);
     hipLaunchKernelGGL(k_cc_count, dim3(nb, ub), dim3(256), 0, s, d_tab, (int)n);

@@ -424,7 +424,7 @@ def main():
             out["track"]["multi_sequence"] = {"value": msteps * S / mdt, "unit": "stereo pairs/s", "sequences": S,
                                               "steps": msteps, "sequence0_equals_single_chain": bool(same)}
         if world == 1 and not track and not args.no_elas_leg:
-            out["elas"] = elas_leg(pkg, W, H, dev.index or 0, dL, dR, PITCH, min(B, 64))
+            out["elas"] = elas_leg(pkg, W, H, dev.index or 0, dL, dR, PITCH, min(B, 128))
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

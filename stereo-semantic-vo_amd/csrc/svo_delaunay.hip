@@ -207,18 +207,38 @@ extern "C" int svo_elas_delaunay(const int32_t* xy, int32_t n, int32_t* tri, int
   b.q.p = b.pts.data();
   b.build(0, m, 0);
   b.q.p = b.pts.data();
+  // canonical order = lexicographic (a, b, c); with fewer than 2^21 points the triple packs into one 64-bit
+  // key, and sorting plain integers is several times cheaper than sorting structs with a comparator
+  const bool packed = n < (1 << 21);
   struct T { int32_t a, b, c; };
   std::vector<T> out;
-  out.reserve(2 * m);
+  std::vector<uint64_t> keys;
+  if (packed) keys.reserve(2 * m); else out.reserve(2 * m);
   const QuadEdge& q = b.q;
   for (int e = 0; e < (int)q.nxt.size(); e += 2) {   // primal directed edges
     if (q.dead[e >> 2]) continue;
-    const int e2 = q.lnext(e), e3 = q.lnext(e2);
+    const int A = q.o(e);
+    const int32_t ia = b.pts[A].id;
+    const int e2 = q.lnext(e);
+    const int B = q.o(e2);
+    const int32_t ib = b.pts[B].id;
+    if (ia >= ib) continue;                          // emitted from its smallest corner only
+    const int e3 = q.lnext(e2);
     if (q.lnext(e3) != e) continue;
-    const int A = q.o(e), B = q.o(e2), C = q.o(e3);
-    if (q.ccw(A, B, C) <= 0) continue;
-    const int32_t ia = b.pts[A].id, ib = b.pts[B].id, ic = b.pts[C].id;
-    if (ia < ib && ia < ic) out.push_back({ia, ib, ic});
+    const int C = q.o(e3);
+    const int32_t ic = b.pts[C].id;
+    if (ia >= ic || q.ccw(A, B, C) <= 0) continue;
+    if (packed) keys.push_back(((uint64_t)ia << 42) | ((uint64_t)ib << 21) | (uint64_t)ic);
+    else out.push_back({ia, ib, ic});
+  }
+  if (packed) {
+    std::sort(keys.begin(), keys.end());
+    *n_tri = (int32_t)keys.size();
+    for (int i = 0; i < std::min<int>((int)keys.size(), cap); ++i) {
+      tri[3 * i] = (int32_t)(keys[i] >> 42); tri[3 * i + 1] = (int32_t)((keys[i] >> 21) & 0x1fffff);
+      tri[3 * i + 2] = (int32_t)(keys[i] & 0x1fffff);
+    }
+    return SVO_OK;
   }
   std::sort(out.begin(), out.end(), [](const T& x, const T& y) {
     if (x.a != y.a) return x.a < y.a;

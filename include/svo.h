@@ -356,6 +356,15 @@ int svo_elas_delaunay(const int32_t* xy, int32_t n, int32_t* tri, int32_t cap, i
 int svo_ctmf(svo_ctx* ctx, const uint8_t* src, uint8_t* dst, int width, int height, int src_step_row,
              int dst_step_row, int r, int channels);
 
+/* `MSA::init(l, r)` (Thirdparty/MB/MSA.cpp:22-63 with gradient :65-76, getCost :78-108, ctmf, gradient_after_ctmf
+ * :110-139): from two 8UC3 BGR images (width x height, `step` bytes per row) the two matching-cost volumes
+ * (height*width*disp floats each, disparity fastest; disp = MSA's `Disp` = d + 1, 49 in src/frame.cc:86), the
+ * median-filtered colour images and the row / column gray gradients of those (float64, height*width each).
+ * Host buffers in and out.  The later stages of MSA::solve are not built. */
+int svo_msa_init(svo_ctx* ctx, const uint8_t* bgrL, const uint8_t* bgrR, int width, int height, int step, int disp,
+                 float* costL, float* costR, uint8_t* m_img3L, uint8_t* m_img3R, double* r_graL, double* c_graL,
+                 double* r_graR, double* c_graR);
+
 #ifdef __cplusplus
 }
 #endif

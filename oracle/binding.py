@@ -389,3 +389,16 @@ def ref_ctmf(img, r):
     L.ctmf.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_ulong]
     L.ctmf(_p(a), _p(out), W, H, W * cn, W * cn, int(r), cn, max(W * H * cn, 1 << 16))
     return out
+
+
+def msa_init(bgrL, bgrR, disp=49):
+    """orc_msa_init: MSA::init on two H x W x 3 uint8 images -> dict of cost volumes, median images, gradients."""
+    a = np.ascontiguousarray(bgrL, np.uint8); b = np.ascontiguousarray(bgrR, np.uint8)
+    H, W = a.shape[:2]
+    o = dict(costL=np.zeros((H, W, disp), np.float32), costR=np.zeros((H, W, disp), np.float32),
+             m3L=np.zeros_like(a), m3R=np.zeros_like(a),
+             r_graL=np.zeros((H, W)), c_graL=np.zeros((H, W)), r_graR=np.zeros((H, W)), c_graR=np.zeros((H, W)))
+    rc = lib().orc_msa_init(_p(a), _p(b), H, W, int(disp), _p(o["costL"]), _p(o["costR"]), _p(o["m3L"]), _p(o["m3R"]),
+                            _p(o["r_graL"]), _p(o["c_graL"]), _p(o["r_graR"]), _p(o["c_graR"]))
+    assert rc == 0
+    return o

@@ -128,4 +128,8 @@ int orc_track_frame_boxes(orc_tracker* t, const uint8_t* grayL, int strideL, con
 #ifdef __cplusplus
 }
 #endif
+/* first stage of MSA dense stereo (orc_msa.c): MSA::init, Thirdparty/MB/MSA.cpp:22-139 */
+int orc_msa_init(const uint8_t* bgrL, const uint8_t* bgrR, int n, int m, int disp, float* costL, float* costR,
+                 uint8_t* m3L, uint8_t* m3R, double* r_graL, double* c_graL, double* r_graR, double* c_graR);
+
 #endif

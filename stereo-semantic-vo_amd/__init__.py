@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "svo_frontend_batch_dev", "svo_track_batch_dev", "svo_profile_enable", "svo_profile_reset",
     "svo_profile_get",
     "svo_elas_default_params", "svo_elas_process", "svo_elas_process_ex", "svo_elas_delaunay",
-    "svo_ctmf", "svo_track_multi_reset", "svo_track_multi_step_dev", "svo_elas_batch_dev",
+    "svo_ctmf", "svo_track_multi_reset", "svo_track_multi_step_dev", "svo_elas_batch_dev", "svo_msa_init",
 ]
 
 
@@ -386,6 +386,18 @@ class Svo:
         self._chk(self.lib.svo_elas_batch_dev(self.h, C.c_void_p(d_L), C.c_void_p(d_R), int(stride), int(W), int(H),
                                               int(B), C.byref(params), C.c_void_p(d_D1), C.c_void_p(d_D2), _p(produced)))
         return produced
+
+    def msa_init(self, bgrL, bgrR, disp=49):
+        """MSA::init on two H x W x 3 uint8 images: cost volumes, median images, gradients (dict)."""
+        a, b = _u8(bgrL), _u8(bgrR)
+        H, W = a.shape[:2]
+        o = dict(costL=np.zeros((H, W, disp), np.float32), costR=np.zeros((H, W, disp), np.float32),
+                 m3L=np.zeros_like(a), m3R=np.zeros_like(a),
+                 r_graL=np.zeros((H, W)), c_graL=np.zeros((H, W)), r_graR=np.zeros((H, W)), c_graR=np.zeros((H, W)))
+        self._chk(self.lib.svo_msa_init(self.h, _p(a), _p(b), W, H, 3 * W, int(disp), _p(o["costL"]), _p(o["costR"]),
+                                        _p(o["m3L"]), _p(o["m3R"]), _p(o["r_graL"]), _p(o["c_graL"]), _p(o["r_graR"]),
+                                        _p(o["c_graR"])))
+        return o
 
     def ctmf(self, img, r):
         """Median filter of Thirdparty/MB/ctmf.c on an H x W or H x W x C uint8 image."""

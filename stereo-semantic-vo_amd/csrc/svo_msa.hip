@@ -11,6 +11,11 @@
 //             GPU: one thread per (pixel, channel); the median is found by bisection on the 8-bit value
 //             range (8 counting passes over the window held in registers) - O(r^2) per pixel, which for the
 //             radii MSA uses (1, 2) is 9 / 25 elements.
+//  svo_msa_init : `MSA::init` (MSA.cpp:22-63) - gray conversion (:42-47), `gradient` (:65-76), `getCost` (:78-108:
+//             the two cost volumes, cost = 0.11 * min(mean |dBGR|, 7) + 0.89 * min(|dgrad|, 2) in float64, stored
+//             as float), `ctmf` r = 1 on both colour images and `gradient_after_ctmf` (:110-139).  All per-pixel
+//             work; the right-reference volume is the left one re-indexed (costR[j][d] = costL[j + d'][d'],
+//             d' = min(d, m - 1 - j): the reference's "copy the previous disparity" chain in closed form).
 // The rest of MSA (gradient graph, Tarjan arborescence, tree DP; MSA.cpp:152-990) is not built.
 #include "svo_internal.h"
 
@@ -44,7 +49,112 @@ __global__ __launch_bounds__(256) void k_ctmf(const uint8_t* src, uint8_t* dst, 
   dst[(size_t)y * dst_step + xc] = (uint8_t)lo;
 }
 
+__device__ __forceinline__ uint8_t msa_gray(const uint8_t* bgr) {   // MSA.cpp:44-45
+  return (uint8_t)(int)(0.299 * bgr[2] + 0.587 * bgr[1] + 0.114 * bgr[0] + 0.5);
+}
+__global__ void k_msa_gray(const uint8_t* bgr, int n, uint8_t* gray) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) gray[i] = msa_gray(bgr + 3 * (size_t)i);
+}
+// central difference along x (`along_rows`) or y, one-sided at the borders, plus `offset` (MSA.cpp:65-76, 118-138)
+__global__ void k_msa_gradient(const uint8_t* img, int n, int m, int along_rows, double offset, double* gra) {
+  const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+  if (j >= m) return;
+  const int t = i * m + j;
+  const int len = along_rows ? m : n, pos = along_rows ? j : i, st = along_rows ? 1 : m;
+  double g;
+  if (pos == 0) g = (double)img[t + st] - (double)img[t];
+  else if (pos == len - 1) g = (double)img[t] - (double)img[t - st];
+  else g = ((double)img[t + st] - (double)img[t - st]) * 0.5;
+  gra[t] = g + offset;
+}
+__global__ void k_msa_cost(const uint8_t* bgrL, const uint8_t* bgrR, const double* graL, const double* graR, int n, int m,
+                           int disp, float* costL) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;   // (pixel, d), d fastest
+  if (idx >= n * m * disp) return;
+  const int t = idx / disp, d = idx - t * disp, i = t / m, j = t - i * m;
+  const int o = (j - d >= 0) ? t - d : i * m;
+  const double dif_gra = fmin(fabs(graL[t] - graR[o]), 2.0);
+  double dif_col = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) dif_col += abs((int)bgrL[3 * (size_t)t + k] - (int)bgrR[3 * (size_t)o + k]);
+  dif_col = fmin(dif_col / 3, 7.0);
+  costL[idx] = (float)(0.11 * dif_col + (1 - 0.11) * dif_gra);
+}
+__global__ void k_msa_cost_right(const float* costL, int n, int m, int disp, float* costR) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * m * disp) return;
+  const int t = idx / disp, d = idx - t * disp, j = t % m;
+  const int dd = min(d, m - 1 - j);
+  costR[idx] = costL[(size_t)(t + dd) * disp + dd];
+}
+
 }  // namespace
+
+// n rows x m columns (the reference's naming), BGR interleaved, `step` bytes per row.
+extern "C" int svo_msa_init(svo_ctx* ctx, const uint8_t* bgrL, const uint8_t* bgrR, int width, int height, int step, int disp,
+                            float* costL, float* costR, uint8_t* m_img3L, uint8_t* m_img3R, double* r_graL, double* c_graL,
+                            double* r_graR, double* c_graR) {
+  if (!ctx) return SVO_E_INVALID;
+  const int n = height, m = width;
+  if (!bgrL || !bgrR || !costL || !costR || !m_img3L || !m_img3R || !r_graL || !c_graL || !r_graR || !c_graR || n < 2 ||
+      m < 2 || disp < 1 || disp > 256 || step < 3 * m || (size_t)n * m * disp > (size_t)1 << 30) {
+    ctx->last_error = "svo_msa_init: invalid argument";
+    return SVO_E_INVALID;
+  }
+  SVO_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t N = (size_t)n * m, V = N * disp;
+  // one arena: 2 colour images, 2 median images, 2 gray, 2 gray-of-median, 6 gradient maps, 2 cost volumes
+  const size_t bytes = 4 * 3 * N + 4 * N + 6 * N * sizeof(double) + 2 * V * sizeof(float) + 64;
+  uint8_t* base = nullptr;
+  SVO_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&base), bytes));
+  double* g = reinterpret_cast<double*>(base);                 // graL graR r_graL c_graL r_graR c_graR
+  float* cL = reinterpret_cast<float*>(g + 6 * N);
+  float* cR = cL + V;
+  uint8_t* img3[2] = {reinterpret_cast<uint8_t*>(cR + V), reinterpret_cast<uint8_t*>(cR + V) + 3 * N};
+  uint8_t* med3[2] = {img3[1] + 3 * N, img3[1] + 6 * N};
+  uint8_t* gray[2] = {med3[1] + 3 * N, med3[1] + 4 * N};
+  uint8_t* mgray[2] = {gray[1] + N, gray[1] + 2 * N};
+  hipStream_t s = ctx->stream;
+  int rc = SVO_OK;
+  auto chk = [&](hipError_t e) { if (e != hipSuccess && rc == SVO_OK) { rc = SVO_E_HIP; ctx->last_error = hipGetErrorString(e); } };
+  chk(hipMemcpy2DAsync(img3[0], 3 * (size_t)m, bgrL, step, 3 * (size_t)m, n, hipMemcpyHostToDevice, s));
+  chk(hipMemcpy2DAsync(img3[1], 3 * (size_t)m, bgrR, step, 3 * (size_t)m, n, hipMemcpyHostToDevice, s));
+  if (rc == SVO_OK) {
+    const dim3 px((m + 255) / 256, n);
+    const unsigned nbN = (unsigned)((N + 255) / 256), nbV = (unsigned)((V + 255) / 256);
+    for (int side = 0; side < 2; ++side) {
+      SvoTimer t(ctx, "k_msa_gray_gradient");
+      hipLaunchKernelGGL(k_msa_gray, dim3(nbN), dim3(256), 0, s, img3[side], (int)N, gray[side]);
+      hipLaunchKernelGGL(k_msa_gradient, px, dim3(256), 0, s, gray[side], n, m, 1, 127.5, g + side * N);
+    }
+    {
+      SvoTimer t(ctx, "k_msa_cost");
+      hipLaunchKernelGGL(k_msa_cost, dim3(nbV), dim3(256), 0, s, img3[0], img3[1], g, g + N, n, m, disp, cL);
+      hipLaunchKernelGGL(k_msa_cost_right, dim3(nbV), dim3(256), 0, s, cL, n, m, disp, cR);
+    }
+    for (int side = 0; side < 2; ++side) {
+      {
+        SvoTimer t(ctx, "k_ctmf");
+        hipLaunchKernelGGL(k_ctmf<1>, dim3((3 * m + 255) / 256, n), dim3(256), 0, s, img3[side], med3[side], m, n, 3 * m, 3 * m, 3);
+      }
+      SvoTimer t(ctx, "k_msa_gray_gradient");
+      hipLaunchKernelGGL(k_msa_gray, dim3(nbN), dim3(256), 0, s, med3[side], (int)N, mgray[side]);
+      hipLaunchKernelGGL(k_msa_gradient, px, dim3(256), 0, s, mgray[side], n, m, 1, 0.0, g + (2 + 2 * side) * N);
+      hipLaunchKernelGGL(k_msa_gradient, px, dim3(256), 0, s, mgray[side], n, m, 0, 0.0, g + (3 + 2 * side) * N);
+    }
+    chk(hipMemcpyAsync(costL, cL, V * sizeof(float), hipMemcpyDeviceToHost, s));
+    chk(hipMemcpyAsync(costR, cR, V * sizeof(float), hipMemcpyDeviceToHost, s));
+    chk(hipMemcpyAsync(m_img3L, med3[0], 3 * N, hipMemcpyDeviceToHost, s));
+    chk(hipMemcpyAsync(m_img3R, med3[1], 3 * N, hipMemcpyDeviceToHost, s));
+    double* outs[4] = {r_graL, c_graL, r_graR, c_graR};
+    for (int k = 0; k < 4; ++k) chk(hipMemcpyAsync(outs[k], g + (2 + k) * N, N * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  chk(hipStreamSynchronize(s));
+  chk(hipGetLastError());
+  hipFree(base);
+  return rc;
+}
 
 extern "C" int svo_ctmf(svo_ctx* ctx, const uint8_t* src, uint8_t* dst, int width, int height, int src_step,
                         int dst_step, int r, int channels) {

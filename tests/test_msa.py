@@ -48,3 +48,54 @@ def test_gpu_ctmf_equals_reference(pkg):
     with pytest.raises(pkg.SvoError):
         s.ctmf(L, 4)
     s.close()
+
+
+# ---- MSA::init (gray, gradients, cost volumes, median images, gradients of those) ------------------------
+def colour_pair(W=200, H=120):
+    """A BGR stereo pair made of three differently shifted copies of the real urban1 crops."""
+    L, R = util.urban_pair(W, H, 400, 100)
+    mk = lambda g: np.ascontiguousarray(np.stack([g, np.roll(g, 1, 1), np.roll(g, 1, 0)], 2))
+    return mk(L), mk(R)
+
+
+def test_oracle_msa_init_against_numpy_twin():
+    """oracle/orc_msa.c (the C restatement of MSA.cpp:22-139) against an independent float64 numpy twin of the same
+    formulas, and its median images against the reference's compiled ctmf when that is present."""
+    bl, br = colour_pair()
+    o = ob.msa_init(bl, br, 49)
+    gray = lambda b: (0.299 * b[..., 2] + 0.587 * b[..., 1] + 0.114 * b[..., 0] + 0.5).astype(np.int64).astype(np.uint8)
+
+    def grad(img, axis, off):
+        f = np.moveaxis(img.astype(np.float64), axis, 1)
+        g = np.empty_like(f)
+        g[:, 1:-1] = (f[:, 2:] - f[:, :-2]) * 0.5 + off
+        g[:, 0] = f[:, 1] - f[:, 0] + off
+        g[:, -1] = f[:, -1] - f[:, -2] + off
+        return np.moveaxis(g, 1, axis)
+
+    gL, gR = grad(gray(bl), 1, 127.5), grad(gray(br), 1, 127.5)
+    W = bl.shape[1]
+    for d in (0, 1, 7, 30, 48):
+        idx = np.where(np.arange(W) - d >= 0, np.arange(W) - d, 0)
+        dg = np.minimum(np.abs(gL - gR[:, idx]), 2.0)
+        dc = np.minimum(np.abs(bl.astype(np.int64) - br[:, idx].astype(np.int64)).sum(2) / 3.0, 7.0)
+        assert np.array_equal((0.11 * dc + (1 - 0.11) * dg).astype(np.float32), o["costL"][:, :, d])
+        dd = np.minimum(d, W - 1 - np.arange(W))
+        assert np.array_equal(o["costR"][:, :, d], o["costL"][:, np.arange(W) + dd, dd])
+    assert np.array_equal(o["m3L"], median_clamped(bl, 1)) and np.array_equal(o["m3R"], median_clamped(br, 1))
+    if os.path.exists(REF):
+        assert np.array_equal(o["m3L"], ob.ref_ctmf(bl, 1))
+    assert np.array_equal(o["r_graL"], grad(gray(o["m3L"]), 1, 0.0)) and np.array_equal(o["c_graR"], grad(gray(o["m3R"]), 0, 0.0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,disp", [(200, 120, 49), (97, 64, 17), (640, 240, 49)])
+def test_gpu_msa_init_equals_oracle(pkg, W, H, disp):
+    """svo_msa_init through the C-ABI == the oracle, bit for bit (float32 costs, float64 gradients, bytes)."""
+    bl, br = colour_pair(W, H)
+    s = pkg.Svo(640, 240)
+    g = s.msa_init(bl, br, disp)
+    r = ob.msa_init(bl, br, disp)
+    for k in ("costL", "costR", "m3L", "m3R", "r_graL", "c_graL", "r_graR", "c_graR"):
+        assert g[k].tobytes() == r[k].tobytes(), k
+    s.close()

@@ -402,3 +402,37 @@ def msa_init(bgrL, bgrR, disp=49):
                             _p(o["r_graL"]), _p(o["c_graL"]), _p(o["r_graR"]), _p(o["c_graR"]))
     assert rc == 0
     return o
+
+
+def msa_exp_table(o):
+    E = np.zeros(256)
+    lib().orc_msa_exp_table.argtypes = [C.c_double, C.c_void_p]
+    lib().orc_msa_exp_table(float(o), _p(E))
+    return E
+
+
+def msa_tree_dp(cost, seq, child_ptr, child, child_c, root, Exp):
+    cost = np.ascontiguousarray(cost, np.float32)
+    N, D = cost.shape
+    up = np.zeros_like(cost); A = np.zeros_like(cost)
+    lib().orc_msa_tree_dp(_p(cost), N, D, _p(np.ascontiguousarray(seq, np.int32)),
+                          _p(np.ascontiguousarray(child_ptr, np.int32)), _p(np.ascontiguousarray(child, np.int32)),
+                          _p(np.ascontiguousarray(child_c, np.uint8)), int(root), _p(np.ascontiguousarray(Exp, np.float64)),
+                          _p(up), _p(A))
+    return A
+
+
+def msa_wta(costA, n, m):
+    costA = np.ascontiguousarray(costA, np.float32)
+    D = costA.shape[-1]
+    out = np.zeros((n, m), np.uint8)
+    lib().orc_msa_wta(_p(costA), n, m, D, _p(out))
+    return out
+
+
+def msa_lrcheck(d1, d2, D):
+    d1 = np.ascontiguousarray(d1, np.uint8); d2 = np.ascontiguousarray(d2, np.uint8)
+    n, m = d1.shape
+    cost = np.zeros((n, m, D), np.float32); mask = np.zeros((n, m), np.uint8)
+    lib().orc_msa_lrcheck(_p(d1), _p(d2), n, m, D, _p(cost), _p(mask))
+    return cost, mask

@@ -119,3 +119,89 @@ int orc_msa_init(const uint8_t* bgrL, const uint8_t* bgrR, int n, int m, int dis
   free(imgL); free(imgR); free(graL); free(graR);
   return 0;
 }
+
+/* ---- the stages of MSA::solve that consume the tree (MSA.cpp:929-1105) ------------------------------------
+ * The tree arrives as the reference holds it when TreeDp runs: BFS order `seq` (:898-926), parent `fa`, and for
+ * every node its CHILDREN in the order the adjacency chain `lk/branch` yields them (the chain minus the parent),
+ * here as CSR (child_ptr, child, child_c = the edge's colour weight 0..255).  The float accumulation order over
+ * the children is that order, so it is part of the input. */
+
+/* MSA::setExp (:1126-1130) */
+void orc_msa_exp_table(double o, double Exp[256]) {
+  for (int i = 0; i <= 255; ++i) Exp[i] = exp(-i * 1.0 / o / 255);
+}
+
+/* MSA::TreeDp (:929-990): cost -> costA (both N*D floats); costUp is scratch of the same size */
+int orc_msa_tree_dp(const float* cost, int N, int D, const int32_t* seq, const int32_t* child_ptr,
+                    const int32_t* child, const uint8_t* child_c, int root, const double Exp[256], float* costUp,
+                    float* costA) {
+  for (size_t i = 0; i < (size_t)N * D; ++i) costUp[i] = cost[i];
+  for (int k = N - 1; k >= 0; --k) {
+    const int u = seq[k];
+    for (int e = child_ptr[u]; e < child_ptr[u + 1]; ++e) {
+      const int v = child[e];
+      const double w = Exp[child_c[e]];
+      for (int d = 0; d < D; ++d) costUp[(size_t)u * D + d] += w * costUp[(size_t)v * D + d];
+    }
+  }
+  for (int d = 0; d < D; ++d) costA[(size_t)root * D + d] = costUp[(size_t)root * D + d];
+  for (int k = 0; k < N; ++k) {
+    const int u = seq[k];
+    for (int e = child_ptr[u]; e < child_ptr[u + 1]; ++e) {
+      const int v = child[e];
+      const double w = Exp[child_c[e]];
+      for (int d = 0; d < D; ++d)
+        costA[(size_t)v * D + d] = w * costA[(size_t)u * D + d] + (1 - w * w) * costUp[(size_t)v * D + d];
+    }
+  }
+  return 0;
+}
+
+static void median_r2(const uint8_t* src, uint8_t* dst, int n, int m) { /* ctmf r = 2, 1 channel, clamped window */
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < m; ++j) {
+      uint8_t v[25];
+      int k = 0;
+      for (int di = -2; di <= 2; ++di)
+        for (int dj = -2; dj <= 2; ++dj) {
+          int ii = i + di, jj = j + dj;
+          ii = ii < 0 ? 0 : (ii > n - 1 ? n - 1 : ii);
+          jj = jj < 0 ? 0 : (jj > m - 1 ? m - 1 : jj);
+          v[k++] = src[ii * m + jj];
+        }
+      for (int a = 1; a < 25; ++a) {
+        const uint8_t x = v[a];
+        int b = a - 1;
+        while (b >= 0 && v[b] > x) { v[b + 1] = v[b]; --b; }
+        v[b + 1] = x;
+      }
+      dst[i * m + j] = v[12];
+    }
+}
+
+/* MSA::WTA (:992-1006): first minimum over the disparities, then the 5x5 median */
+int orc_msa_wta(const float* costA, int n, int m, int D, uint8_t* disparity) {
+  uint8_t* tmp = (uint8_t*)malloc((size_t)n * m);
+  for (int i = 0; i < n * m; ++i) {
+    int k = 0;
+    for (int j = 1; j < D; ++j)
+      if (costA[(size_t)i * D + j] < costA[(size_t)i * D + k]) k = j;
+    tmp[i] = (uint8_t)k;
+  }
+  median_r2(tmp, disparity, n, m);
+  free(tmp);
+  return 0;
+}
+
+/* MSA::LRcheck (:1027-1105): stable pixels (d > 0 and the right map agrees exactly at j - d) get the cost
+ * |d - d1|, every other pixel a zero cost row; mask = the stable pixels */
+int orc_msa_lrcheck(const uint8_t* d1, const uint8_t* d2, int n, int m, int D, float* cost, uint8_t* mask) {
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < m; ++j) {
+      const int t = i * m + j, d = d1[t];
+      mask[t] = (j - d >= 0 && d > 0 && abs(d - (int)d2[t - d]) == 0) ? 1 : 0;
+    }
+  for (int t = 0; t < n * m; ++t)
+    for (int d = 0; d < D; ++d) cost[(size_t)t * D + d] = mask[t] ? (float)abs(d - (int)d1[t]) : 0.0f;
+  return 0;
+}

@@ -132,4 +132,12 @@ int orc_track_frame_boxes(orc_tracker* t, const uint8_t* grayL, int strideL, con
 int orc_msa_init(const uint8_t* bgrL, const uint8_t* bgrR, int n, int m, int disp, float* costL, float* costR,
                  uint8_t* m3L, uint8_t* m3R, double* r_graL, double* c_graL, double* r_graR, double* c_graR);
 
+/* tree stages of MSA::solve (orc_msa.c): setExp :1126-1130, TreeDp :929-990, WTA :992-1006, LRcheck :1027-1105 */
+void orc_msa_exp_table(double o, double Exp[256]);
+int orc_msa_tree_dp(const float* cost, int N, int D, const int32_t* seq, const int32_t* child_ptr,
+                    const int32_t* child, const uint8_t* child_c, int root, const double Exp[256], float* costUp,
+                    float* costA);
+int orc_msa_wta(const float* costA, int n, int m, int D, uint8_t* disparity);
+int orc_msa_lrcheck(const uint8_t* d1, const uint8_t* d2, int n, int m, int D, float* cost, uint8_t* mask);
+
 #endif

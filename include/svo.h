@@ -365,6 +365,20 @@ int svo_msa_init(svo_ctx* ctx, const uint8_t* bgrL, const uint8_t* bgrR, int wid
                  float* costL, float* costR, uint8_t* m_img3L, uint8_t* m_img3R, double* r_graL, double* c_graL,
                  double* r_graR, double* c_graR);
 
+/* `MSA::TreeDp(cost)` (MSA.cpp:929-990) with `setExp(o)` (:1126-1130): two-pass aggregation of a cost volume (N nodes x
+ * D disparities, float) over a spanning tree.  The tree is given as the reference holds it at that point: `seq` = its
+ * BFS order from `root` (:898-926) and, per node, the children in the order its adjacency chain yields them (CSR:
+ * child_ptr[N+1], child[N-1], child_c[N-1] = the edge's colour weight 0..255) - the order fixes the float rounding.
+ * costA: N*D floats.  Host buffers in and out. */
+int svo_msa_tree_dp(svo_ctx* ctx, const float* cost, int N, int D, const int32_t* seq, const int32_t* child_ptr,
+                    const int32_t* child, const uint8_t* child_c, int root, double o, float* costA);
+/* `MSA::WTA(disparity)` (MSA.cpp:992-1006): first minimum over the D disparities per pixel, then the 5x5 ctmf. */
+int svo_msa_wta(svo_ctx* ctx, const float* costA, int width, int height, int D, uint8_t* disparity);
+/* `MSA::LRcheck(d1, d2, cost)` (MSA.cpp:1027-1105): mask = pixels with d1 > 0 whose right-map disparity at x - d1 is
+ * the same; their cost row becomes |d - d1|, every other row 0. */
+int svo_msa_lrcheck(svo_ctx* ctx, const uint8_t* d1, const uint8_t* d2, int width, int height, int D, float* cost,
+                    uint8_t* mask);
+
 #ifdef __cplusplus
 }
 #endif

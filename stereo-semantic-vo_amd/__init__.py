@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "svo_frontend_batch_dev", "svo_track_batch_dev", "svo_profile_enable", "svo_profile_reset",
     "svo_profile_get",
     "svo_elas_default_params", "svo_elas_process", "svo_elas_process_ex", "svo_elas_delaunay",
-    "svo_ctmf", "svo_track_multi_reset", "svo_track_multi_step_dev", "svo_elas_batch_dev", "svo_msa_init",
+    "svo_ctmf", "svo_track_multi_reset", "svo_track_multi_step_dev", "svo_elas_batch_dev", "svo_msa_init", "svo_msa_tree_dp", "svo_msa_wta", "svo_msa_lrcheck",
 ]
 
 
@@ -398,6 +398,31 @@ class Svo:
                                         _p(o["m3L"]), _p(o["m3R"]), _p(o["r_graL"]), _p(o["c_graL"]), _p(o["r_graR"]),
                                         _p(o["c_graR"])))
         return o
+
+    def msa_tree_dp(self, cost, seq, child_ptr, child, child_c, root, o=0.1):
+        cost = np.ascontiguousarray(cost, np.float32)
+        N, D = cost.shape
+        A = np.zeros_like(cost)
+        self.lib.svo_msa_tree_dp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_int, C.c_double, C.c_void_p]
+        self._chk(self.lib.svo_msa_tree_dp(self.h, _p(cost), N, D, _p(np.ascontiguousarray(seq, np.int32)),
+                                           _p(np.ascontiguousarray(child_ptr, np.int32)),
+                                           _p(np.ascontiguousarray(child, np.int32)),
+                                           _p(np.ascontiguousarray(child_c, np.uint8)), int(root), float(o), _p(A)))
+        return A
+
+    def msa_wta(self, costA, H, W):
+        costA = np.ascontiguousarray(costA, np.float32)
+        out = np.zeros((H, W), np.uint8)
+        self._chk(self.lib.svo_msa_wta(self.h, _p(costA), W, H, costA.shape[-1], _p(out)))
+        return out
+
+    def msa_lrcheck(self, d1, d2, D):
+        d1, d2 = _u8(d1), _u8(d2)
+        H, W = d1.shape
+        cost = np.zeros((H, W, D), np.float32); mask = np.zeros((H, W), np.uint8)
+        self._chk(self.lib.svo_msa_lrcheck(self.h, _p(d1), _p(d2), W, H, int(D), _p(cost), _p(mask)))
+        return cost, mask
 
     def ctmf(self, img, r):
         """Median filter of Thirdparty/MB/ctmf.c on an H x W or H x W x C uint8 image."""

@@ -16,7 +16,18 @@
 //             as float), `ctmf` r = 1 on both colour images and `gradient_after_ctmf` (:110-139).  All per-pixel
 //             work; the right-reference volume is the left one re-indexed (costR[j][d] = costL[j + d'][d'],
 //             d' = min(d, m - 1 - j): the reference's "copy the previous disparity" chain in closed form).
-// The rest of MSA (gradient graph, Tarjan arborescence, tree DP; MSA.cpp:152-990) is not built.
+//  svo_msa_tree_dp : `MSA::TreeDp` (MSA.cpp:929-990) - the two-pass cost aggregation over the spanning tree, level by
+//             level (a node after all its children on the way up, after its parent on the way down), one thread
+//             per (node, disparity); the children are added in the order the reference's adjacency chain yields
+//             them, each `+=` rounded to float as there.
+//  svo_msa_wta / svo_msa_lrcheck : `MSA::WTA` (:992-1006, first minimum + 5x5 ctmf) and `MSA::LRcheck` (:1027-1105).
+// Not built: the host-side graph stages that produce the tree (build, Tarjan arborescence, region Kruskal, BFS
+// orders; MSA.cpp:152-926) and therefore MSA::solve as a whole.
+#include <math.h>
+
+#include <algorithm>
+#include <vector>
+
 #include "svo_internal.h"
 
 namespace {
@@ -89,7 +100,172 @@ __global__ void k_msa_cost_right(const float* costL, int n, int m, int disp, flo
   costR[idx] = costL[(size_t)(t + dd) * disp + dd];
 }
 
+// leaves -> root: nodes of one level, all their children are final
+__global__ void k_msa_dp_up(const int32_t* nodes, int cnt, int D, const int32_t* child_ptr, const int32_t* child,
+                            const uint8_t* child_c, const double* Exp, float* up) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= cnt * D) return;
+  const int u = nodes[idx / D], d = idx % D;
+  float acc = up[(size_t)u * D + d];
+  for (int e = child_ptr[u]; e < child_ptr[u + 1]; ++e)
+    acc = (float)((double)acc + Exp[child_c[e]] * (double)up[(size_t)child[e] * D + d]);
+  up[(size_t)u * D + d] = acc;
+}
+// root -> leaves: nodes of one level, their parent is final
+__global__ void k_msa_dp_down(const int32_t* nodes, int cnt, int D, const int32_t* parent, const uint8_t* parent_c,
+                              const double* Exp, const float* up, float* A) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= cnt * D) return;
+  const int v = nodes[idx / D], d = idx % D, u = parent[v];
+  if (u < 0) { A[(size_t)v * D + d] = up[(size_t)v * D + d]; return; }
+  const double w = Exp[parent_c[v]];
+  A[(size_t)v * D + d] = (float)(w * (double)A[(size_t)u * D + d] + (1 - w * w) * (double)up[(size_t)v * D + d]);
+}
+__global__ void k_msa_argmin(const float* costA, int N, int D, uint8_t* disp) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  int k = 0;
+  float best = costA[(size_t)i * D];
+  for (int j = 1; j < D; ++j) { const float c = costA[(size_t)i * D + j]; if (c < best) { best = c; k = j; } }
+  disp[i] = (uint8_t)k;
+}
+__global__ void k_msa_lrcheck(const uint8_t* d1, const uint8_t* d2, int n, int m, int D, float* cost, uint8_t* mask) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * m * D) return;
+  const int t = idx / D, d = idx - t * D, j = t % m, dd = d1[t];
+  const bool stable = j - dd >= 0 && dd > 0 && d2[t - dd] == dd;
+  if (d == 0) mask[t] = stable ? 1 : 0;
+  cost[idx] = stable ? (float)abs(d - dd) : 0.0f;
+}
+
+struct DevBuf {   // scoped device allocations of the host-buffer entry points
+  std::vector<void*> p;
+  ~DevBuf() { for (void* q : p) hipFree(q); }
+  template <typename T> T* get(size_t count) {
+    void* q = nullptr;
+    if (hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return nullptr;
+    p.push_back(q);
+    return reinterpret_cast<T*>(q);
+  }
+};
+
 }  // namespace
+
+extern "C" int svo_msa_tree_dp(svo_ctx* ctx, const float* cost, int N, int D, const int32_t* seq, const int32_t* child_ptr,
+                               const int32_t* child, const uint8_t* child_c, int root, double o, float* costA) {
+  if (!ctx) return SVO_E_INVALID;
+  if (!cost || !seq || !child_ptr || !child || !child_c || !costA || N < 1 || D < 1 || D > 256 || root < 0 || root >= N ||
+      !(o > 0) || seq[0] != root || child_ptr[0] != 0 || child_ptr[N] != N - 1) {
+    ctx->last_error = "svo_msa_tree_dp: invalid argument (need a spanning tree in BFS order from `root`)";
+    return SVO_E_INVALID;
+  }
+  // parents, edge weights towards the parent, depths (seq is a BFS order: parents come before children)
+  std::vector<int32_t> parent(N, -2), depth(N, 0), level_ptr, nodes(N);
+  std::vector<uint8_t> parent_c(N, 0);
+  parent[root] = -1;
+  int max_depth = 0;
+  for (int k = 0; k < N; ++k) {
+    const int u = seq[k];
+    if (u < 0 || u >= N || parent[u] == -2) { ctx->last_error = "svo_msa_tree_dp: seq is not a BFS order of the tree"; return SVO_E_INVALID; }
+    for (int e = child_ptr[u]; e < child_ptr[u + 1]; ++e) {
+      const int v = child[e];
+      if (v < 0 || v >= N || parent[v] != -2) { ctx->last_error = "svo_msa_tree_dp: not a tree"; return SVO_E_INVALID; }
+      parent[v] = u; parent_c[v] = child_c[e]; depth[v] = depth[u] + 1;
+      max_depth = std::max(max_depth, depth[v]);
+    }
+  }
+  level_ptr.assign(max_depth + 2, 0);
+  for (int v = 0; v < N; ++v) ++level_ptr[depth[v] + 1];
+  for (int l = 0; l <= max_depth; ++l) level_ptr[l + 1] += level_ptr[l];
+  {
+    std::vector<int32_t> fill(level_ptr.begin(), level_ptr.end() - 1);
+    for (int k = 0; k < N; ++k) nodes[fill[depth[seq[k]]]++] = seq[k];
+  }
+  double Exp[256];
+  for (int i = 0; i <= 255; ++i) Exp[i] = exp(-i * 1.0 / o / 255);   // MSA::setExp, MSA.cpp:1126-1130
+  SVO_HIP(ctx, hipSetDevice(ctx->device));
+  DevBuf buf;
+  const size_t V = (size_t)N * D;
+  float* d_up = buf.get<float>(V); float* d_A = buf.get<float>(V);
+  int32_t* d_nodes = buf.get<int32_t>(N); int32_t* d_cptr = buf.get<int32_t>(N + 1); int32_t* d_child = buf.get<int32_t>(N);
+  int32_t* d_parent = buf.get<int32_t>(N);
+  uint8_t* d_cc = buf.get<uint8_t>(N); uint8_t* d_pc = buf.get<uint8_t>(N);
+  double* d_Exp = buf.get<double>(256);
+  if (!d_up || !d_A || !d_nodes || !d_cptr || !d_child || !d_parent || !d_cc || !d_pc || !d_Exp) { ctx->last_error = "svo_msa_tree_dp: hipMalloc"; return SVO_E_NOMEM; }
+  hipStream_t s = ctx->stream;
+  SVO_HIP(ctx, hipMemcpyAsync(d_up, cost, V * sizeof(float), hipMemcpyHostToDevice, s));
+  SVO_HIP(ctx, hipMemcpyAsync(d_nodes, nodes.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  SVO_HIP(ctx, hipMemcpyAsync(d_cptr, child_ptr, (N + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  if (N > 1) {
+    SVO_HIP(ctx, hipMemcpyAsync(d_child, child, (N - 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    SVO_HIP(ctx, hipMemcpyAsync(d_cc, child_c, (N - 1), hipMemcpyHostToDevice, s));
+  }
+  SVO_HIP(ctx, hipMemcpyAsync(d_parent, parent.data(), N * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  SVO_HIP(ctx, hipMemcpyAsync(d_pc, parent_c.data(), N, hipMemcpyHostToDevice, s));
+  SVO_HIP(ctx, hipMemcpyAsync(d_Exp, Exp, sizeof Exp, hipMemcpyHostToDevice, s));
+  {
+    SvoTimer t(ctx, "k_msa_tree_dp");
+    for (int l = max_depth; l >= 0; --l) {
+      const int cnt = level_ptr[l + 1] - level_ptr[l];
+      hipLaunchKernelGGL(k_msa_dp_up, dim3((unsigned)(((size_t)cnt * D + 255) / 256)), dim3(256), 0, s, d_nodes + level_ptr[l], cnt, D,
+                         d_cptr, d_child, d_cc, d_Exp, d_up);
+    }
+    for (int l = 0; l <= max_depth; ++l) {
+      const int cnt = level_ptr[l + 1] - level_ptr[l];
+      hipLaunchKernelGGL(k_msa_dp_down, dim3((unsigned)(((size_t)cnt * D + 255) / 256)), dim3(256), 0, s, d_nodes + level_ptr[l], cnt, D,
+                         d_parent, d_pc, d_Exp, d_up, d_A);
+    }
+  }
+  SVO_HIP(ctx, hipMemcpyAsync(costA, d_A, V * sizeof(float), hipMemcpyDeviceToHost, s));
+  SVO_HIP(ctx, hipStreamSynchronize(s));
+  SVO_HIP(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
+extern "C" int svo_msa_wta(svo_ctx* ctx, const float* costA, int width, int height, int D, uint8_t* disparity) {
+  if (!ctx) return SVO_E_INVALID;
+  if (!costA || !disparity || width < 5 || height < 5 || D < 1 || D > 256) { ctx->last_error = "svo_msa_wta: invalid argument"; return SVO_E_INVALID; }
+  SVO_HIP(ctx, hipSetDevice(ctx->device));
+  DevBuf buf;
+  const size_t N = (size_t)width * height;
+  float* d_A = buf.get<float>(N * D); uint8_t* d_raw = buf.get<uint8_t>(N); uint8_t* d_med = buf.get<uint8_t>(N);
+  if (!d_A || !d_raw || !d_med) { ctx->last_error = "svo_msa_wta: hipMalloc"; return SVO_E_NOMEM; }
+  hipStream_t s = ctx->stream;
+  SVO_HIP(ctx, hipMemcpyAsync(d_A, costA, N * D * sizeof(float), hipMemcpyHostToDevice, s));
+  {
+    SvoTimer t(ctx, "k_msa_wta");
+    hipLaunchKernelGGL(k_msa_argmin, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, d_A, (int)N, D, d_raw);
+    hipLaunchKernelGGL(k_ctmf<2>, dim3((width + 255) / 256, height), dim3(256), 0, s, d_raw, d_med, width, height, width, width, 1);
+  }
+  SVO_HIP(ctx, hipMemcpyAsync(disparity, d_med, N, hipMemcpyDeviceToHost, s));
+  SVO_HIP(ctx, hipStreamSynchronize(s));
+  SVO_HIP(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
+extern "C" int svo_msa_lrcheck(svo_ctx* ctx, const uint8_t* d1, const uint8_t* d2, int width, int height, int D, float* cost,
+                               uint8_t* mask) {
+  if (!ctx) return SVO_E_INVALID;
+  if (!d1 || !d2 || !cost || !mask || width < 1 || height < 1 || D < 1 || D > 256) { ctx->last_error = "svo_msa_lrcheck: invalid argument"; return SVO_E_INVALID; }
+  SVO_HIP(ctx, hipSetDevice(ctx->device));
+  DevBuf buf;
+  const size_t N = (size_t)width * height;
+  uint8_t* a = buf.get<uint8_t>(N); uint8_t* b = buf.get<uint8_t>(N); uint8_t* mk = buf.get<uint8_t>(N);
+  float* c = buf.get<float>(N * D);
+  if (!a || !b || !mk || !c) { ctx->last_error = "svo_msa_lrcheck: hipMalloc"; return SVO_E_NOMEM; }
+  hipStream_t s = ctx->stream;
+  SVO_HIP(ctx, hipMemcpyAsync(a, d1, N, hipMemcpyHostToDevice, s));
+  SVO_HIP(ctx, hipMemcpyAsync(b, d2, N, hipMemcpyHostToDevice, s));
+  {
+    SvoTimer t(ctx, "k_msa_lrcheck");
+    hipLaunchKernelGGL(k_msa_lrcheck, dim3((unsigned)((N * D + 255) / 256)), dim3(256), 0, s, a, b, height, width, D, c, mk);
+  }
+  SVO_HIP(ctx, hipMemcpyAsync(cost, c, N * D * sizeof(float), hipMemcpyDeviceToHost, s));
+  SVO_HIP(ctx, hipMemcpyAsync(mask, mk, N, hipMemcpyDeviceToHost, s));
+  SVO_HIP(ctx, hipStreamSynchronize(s));
+  SVO_HIP(ctx, hipGetLastError());
+  return SVO_OK;
+}
 
 // n rows x m columns (the reference's naming), BGR interleaved, `step` bytes per row.
 extern "C" int svo_msa_init(svo_ctx* ctx, const uint8_t* bgrL, const uint8_t* bgrR, int width, int height, int step, int disp,

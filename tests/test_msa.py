@@ -99,3 +99,74 @@ def test_gpu_msa_init_equals_oracle(pkg, W, H, disp):
     for k in ("costL", "costR", "m3L", "m3R", "r_graL", "c_graL", "r_graR", "c_graR"):
         assert g[k].tobytes() == r[k].tobytes(), k
     s.close()
+
+
+# ---- the stages that consume the tree: TreeDp, WTA, LRcheck ----------------------------------------------
+def random_tree(rng, N, chain=0.0):
+    """A random spanning tree as MSA holds it: BFS order from the root and per-node children in a fixed (here
+    random) order, with edge weights 0..255.  `chain` > 0 makes long paths (deep trees)."""
+    parent = np.full(N, -1, np.int64)
+    for v in range(1, N):
+        parent[v] = v - 1 if rng.random() < chain else rng.integers(0, v)
+    kids = [[] for _ in range(N)]
+    for v in rng.permutation(np.arange(1, N)):
+        kids[parent[v]].append(int(v))
+    child_ptr = np.zeros(N + 1, np.int32); child = []; 
+    for u in range(N):
+        child_ptr[u + 1] = child_ptr[u] + len(kids[u]); child += kids[u]
+    child = np.array(child, np.int32) if child else np.zeros(0, np.int32)
+    child_c = rng.integers(0, 256, len(child)).astype(np.uint8)
+    seq, q = [], [0]
+    while q:
+        nq = []
+        for u in q:
+            seq.append(u); nq += kids[u]
+        q = nq
+    # BFS by queue (the reference's getSeq) visits level by level with the children in chain order: same thing
+    return np.array(seq, np.int32), child_ptr, child, child_c
+
+
+def test_oracle_tree_dp_on_a_path_is_the_closed_form():
+    """On a 3-node path the two passes have a hand-checkable closed form (float32 storage, float64 products)."""
+    E = ob.msa_exp_table(0.1)
+    cost = np.array([[1.0], [2.0], [4.0]], np.float32)
+    seq = np.array([0, 1, 2], np.int32); cp = np.array([0, 1, 2, 2], np.int32); ch = np.array([1, 2], np.int32)
+    cc = np.array([10, 20], np.uint8)
+    A = ob.msa_tree_dp(cost, seq, cp, ch, cc, 0, E)
+    w1, w2 = E[10], E[20]
+    up2 = np.float32(4.0); up1 = np.float32(2.0 + w2 * float(up2)); up0 = np.float32(1.0 + w1 * float(up1))
+    a0 = up0; a1 = np.float32(w1 * float(a0) + (1 - w1 * w1) * float(up1)); a2 = np.float32(w2 * float(a1) + (1 - w2 * w2) * float(up2))
+    assert A[:, 0].tolist() == [a0, a1, a2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,D,chain", [(1, 5, 0.0), (2, 49, 0.0), (5000, 49, 0.0), (20000, 17, 0.9), (3000, 256, 0.5)])
+def test_gpu_tree_dp_equals_oracle(pkg, N, D, chain):
+    rng = np.random.default_rng(N + D)
+    seq, cp, ch, cc = random_tree(rng, N, chain)
+    cost = rng.random((N, D), np.float32) * 3
+    s = pkg.Svo(640, 240)
+    for o in (0.1, 0.05):
+        g = s.msa_tree_dp(cost, seq, cp, ch, cc, 0, o)
+        r = ob.msa_tree_dp(cost, seq, cp, ch, cc, 0, ob.msa_exp_table(o))
+        assert g.tobytes() == r.tobytes()
+    s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_wta_and_lrcheck_equal_oracle(pkg):
+    rng = np.random.default_rng(9)
+    H, W, D = 60, 97, 49
+    costA = rng.random((H, W, D), np.float32)
+    costA[rng.random((H, W)) < 0.3, 7] = 0.0; costA[rng.random((H, W)) < 0.3, 3] = 0.0      # ties: the first minimum wins
+    s = pkg.Svo(640, 240)
+    assert np.array_equal(s.msa_wta(costA, H, W), ob.msa_wta(costA, H, W))
+    d1 = rng.integers(0, D, (H, W)).astype(np.uint8)
+    d2 = np.where(rng.random((H, W)) < 0.5, np.roll(d1, -3, 1), rng.integers(0, D, (H, W))).astype(np.uint8)
+    d1[:, 10:40] = 3; d2[:, 7:37] = 3
+    gc, gm = s.msa_lrcheck(d1, d2, D)
+    rc, rm = ob.msa_lrcheck(d1, d2, D)
+    assert gm.sum() > 100 and np.array_equal(gm, rm) and gc.tobytes() == rc.tobytes()
+    with pytest.raises(pkg.SvoError):
+        s.msa_tree_dp(costA.reshape(-1, D)[:4], [1, 0, 2, 3], [0, 3, 3, 3, 3], [1, 2, 3], [0, 0, 0], 0)   # seq[0] != root
+    s.close()

@@ -436,3 +436,25 @@ def msa_lrcheck(d1, d2, D):
     cost = np.zeros((n, m, D), np.float32); mask = np.zeros((n, m), np.uint8)
     lib().orc_msa_lrcheck(_p(d1), _p(d2), n, m, D, _p(cost), _p(mask))
     return cost, mask
+
+
+def msa_tree(m_img3, r_gra, c_gra):
+    """orc_msa_tree: (root, seq, child_ptr, child, child_c) of the spanning tree MSA aggregates over for one image."""
+    a = np.ascontiguousarray(m_img3, np.uint8)
+    n, m = a.shape[:2]
+    N = n * m
+    seq = np.zeros(N, np.int32); cp = np.zeros(N + 1, np.int32); ch = np.zeros(N, np.int32); cc = np.zeros(N, np.uint8)
+    root = lib().orc_msa_tree(_p(a), _p(np.ascontiguousarray(r_gra, np.float64)), _p(np.ascontiguousarray(c_gra, np.float64)),
+                              n, m, _p(seq), _p(cp), _p(ch), _p(cc))
+    assert root >= 0, root
+    return root, seq, cp, ch[:N - 1].copy(), cc[:N - 1].copy()
+
+
+def msa_solve(bgrL, bgrR, d=48, scale=1):
+    """orc_msa_solve: MSA::solve(l, r, d, scale) -> H x W uint8 disparity image."""
+    a = np.ascontiguousarray(bgrL, np.uint8); b = np.ascontiguousarray(bgrR, np.uint8)
+    n, m = a.shape[:2]
+    out = np.zeros((n, m), np.uint8)
+    rc = lib().orc_msa_solve(_p(a), _p(b), n, m, int(d), int(scale), _p(out))
+    assert rc == 0, rc
+    return out

@@ -140,4 +140,9 @@ int orc_msa_tree_dp(const float* cost, int N, int D, const int32_t* seq, const i
 int orc_msa_wta(const float* costA, int n, int m, int D, uint8_t* disparity);
 int orc_msa_lrcheck(const uint8_t* d1, const uint8_t* d2, int n, int m, int D, float* cost, uint8_t* mask);
 
+/* graph stages + MSA::solve (orc_msa_graph.cpp, C++): MSA.cpp:152-373, 661-808, 854-926, 1132-1169 */
+int orc_msa_tree(const uint8_t* m_img3, const double* r_gra, const double* c_gra, int n, int m, int32_t* seq,
+                 int32_t* child_ptr, int32_t* child, uint8_t* child_c);
+int orc_msa_solve(const uint8_t* bgrL, const uint8_t* bgrR, int n, int m, int d, int scale, uint8_t* out);
+
 #endif

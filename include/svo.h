@@ -365,6 +365,12 @@ int svo_msa_init(svo_ctx* ctx, const uint8_t* bgrL, const uint8_t* bgrR, int wid
                  float* costL, float* costR, uint8_t* m_img3L, uint8_t* m_img3R, double* r_graL, double* c_graL,
                  double* r_graR, double* c_graR);
 
+/* The spanning tree MSA aggregates over, for one image: `build` -> `Tarjan` -> `getSeq0` -> `Kruskal1` -> `getSeq`
+ * (MSA.cpp:152-373, 661-808, 898-926).  Host-side, needs no GPU.  m_img3 / r_gra / c_gra: outputs of svo_msa_init for that
+ * image.  Outputs in the form svo_msa_tree_dp takes: seq[width*height], child_ptr[+1], child / child_c[-1], *root. */
+int svo_msa_tree(const uint8_t* m_img3, const double* r_gra, const double* c_gra, int width, int height, int32_t* seq,
+                 int32_t* child_ptr, int32_t* child, uint8_t* child_c, int32_t* root);
+
 /* `MSA::TreeDp(cost)` (MSA.cpp:929-990) with `setExp(o)` (:1126-1130): two-pass aggregation of a cost volume (N nodes x
  * D disparities, float) over a spanning tree.  The tree is given as the reference holds it at that point: `seq` = its
  * BFS order from `root` (:898-926) and, per node, the children in the order its adjacency chain yields them (CSR:

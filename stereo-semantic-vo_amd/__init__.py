@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "svo_frontend_batch_dev", "svo_track_batch_dev", "svo_profile_enable", "svo_profile_reset",
     "svo_profile_get",
     "svo_elas_default_params", "svo_elas_process", "svo_elas_process_ex", "svo_elas_delaunay",
-    "svo_ctmf", "svo_track_multi_reset", "svo_track_multi_step_dev", "svo_elas_batch_dev", "svo_msa_init", "svo_msa_tree_dp", "svo_msa_wta", "svo_msa_lrcheck",
+    "svo_ctmf", "svo_track_multi_reset", "svo_track_multi_step_dev", "svo_elas_batch_dev", "svo_msa_init", "svo_msa_tree", "svo_msa_tree_dp", "svo_msa_wta", "svo_msa_lrcheck",
 ]
 
 
@@ -468,6 +468,21 @@ def elas_default_params(setting=0):
     if rc != 0:
         raise SvoError("svo_elas_default_params failed")
     return p
+
+
+def msa_tree(m_img3, r_gra, c_gra):
+    """Host-side MSA aggregation tree of one image (needs no GPU): (root, seq, child_ptr, child, child_c)."""
+    a = _u8(m_img3)
+    H, W = a.shape[:2]
+    N = H * W
+    seq = np.zeros(N, np.int32); cp = np.zeros(N + 1, np.int32); ch = np.zeros(N, np.int32); cc = np.zeros(N, np.uint8)
+    root = C.c_int32(-1)
+    rc = load_library().svo_msa_tree(_p(a), _p(np.ascontiguousarray(r_gra, np.float64)),
+                                     _p(np.ascontiguousarray(c_gra, np.float64)), W, H, _p(seq), _p(cp), _p(ch), _p(cc),
+                                     C.byref(root))
+    if rc != 0:
+        raise SvoError("svo_msa_tree failed (%d)" % rc)
+    return root.value, seq, cp, ch[:N - 1].copy(), cc[:N - 1].copy()
 
 
 def elas_delaunay(xy):

@@ -385,6 +385,13 @@ int svo_msa_wta(svo_ctx* ctx, const float* costA, int width, int height, int D, 
 int svo_msa_lrcheck(svo_ctx* ctx, const uint8_t* d1, const uint8_t* d2, int width, int height, int D, float* cost,
                     uint8_t* mask);
 
+/* `MSA::solve(l, r, d, scale, Save)` (Thirdparty/MB/MSA.cpp:1132-1169), what `frame::MB` calls with d = 48, scale = 1
+ * (src/frame.cc:82-91): dense left-reference disparity of two 8UC3 BGR images, one byte per pixel = disparity * scale.
+ * The per-pixel and per-node stages run on the GPU with the cost volumes resident in HBM, the two aggregation trees are
+ * built on two host threads.  No imshow / imwrite("test.png") (the reference does both on every call). */
+int svo_msa_solve(svo_ctx* ctx, const uint8_t* bgrL, const uint8_t* bgrR, int width, int height, int step, int d, int scale,
+                  uint8_t* disparity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "svo_frontend_batch_dev", "svo_track_batch_dev", "svo_profile_enable", "svo_profile_reset",
     "svo_profile_get",
     "svo_elas_default_params", "svo_elas_process", "svo_elas_process_ex", "svo_elas_delaunay",
-    "svo_ctmf", "svo_track_multi_reset", "svo_track_multi_step_dev", "svo_elas_batch_dev", "svo_msa_init", "svo_msa_tree", "svo_msa_tree_dp", "svo_msa_wta", "svo_msa_lrcheck",
+    "svo_ctmf", "svo_track_multi_reset", "svo_track_multi_step_dev", "svo_elas_batch_dev", "svo_msa_init", "svo_msa_tree", "svo_msa_tree_dp", "svo_msa_wta", "svo_msa_lrcheck", "svo_msa_solve",
 ]
 
 
@@ -423,6 +423,14 @@ class Svo:
         cost = np.zeros((H, W, D), np.float32); mask = np.zeros((H, W), np.uint8)
         self._chk(self.lib.svo_msa_lrcheck(self.h, _p(d1), _p(d2), W, H, int(D), _p(cost), _p(mask)))
         return cost, mask
+
+    def msa_solve(self, bgrL, bgrR, d=48, scale=1):
+        """MSA::solve: H x W uint8 disparity image (left reference)."""
+        a, b = _u8(bgrL), _u8(bgrR)
+        H, W = a.shape[:2]
+        out = np.zeros((H, W), np.uint8)
+        self._chk(self.lib.svo_msa_solve(self.h, _p(a), _p(b), W, H, 3 * W, int(d), int(scale), _p(out)))
+        return out
 
     def ctmf(self, img, r):
         """Median filter of Thirdparty/MB/ctmf.c on an H x W or H x W x C uint8 image."""

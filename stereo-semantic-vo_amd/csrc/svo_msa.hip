@@ -26,6 +26,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "svo_internal.h"
@@ -361,4 +362,174 @@ extern "C" int svo_ctmf(svo_ctx* ctx, const uint8_t* src, uint8_t* dst, int widt
   hipFree(d_src); hipFree(d_dst);
   if (rc) ctx->last_error = "svo_ctmf: HIP error";
   return rc;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// MSA::solve (MSA.cpp:1132-1169) end to end: everything per pixel / per node on the GPU and resident there
+// (the four cost volumes never leave HBM), the two aggregation trees on two host threads in between.
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void k_msa_scale(const uint8_t* d, int n, int scale, uint8_t* out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (uint8_t)(d[i] * scale);
+}
+
+struct HostTree {                       // what svo_msa_tree returns, plus what the level-by-level sweep needs
+  std::vector<int32_t> seq, child_ptr, child, parent, nodes, level_ptr;
+  std::vector<uint8_t> child_c, parent_c;
+  int32_t root = -1;
+  int rc = SVO_OK;
+  void levels(int N) {
+    parent.assign(N, -1); parent_c.assign(N, 0);
+    std::vector<int32_t> depth(N, 0);
+    int max_depth = 0;
+    for (int k = 0; k < N; ++k) {
+      const int u = seq[k];
+      for (int e = child_ptr[u]; e < child_ptr[u + 1]; ++e) {
+        const int v = child[e];
+        parent[v] = u; parent_c[v] = child_c[e]; depth[v] = depth[u] + 1;
+        max_depth = std::max(max_depth, depth[v]);
+      }
+    }
+    level_ptr.assign(max_depth + 2, 0);
+    for (int v = 0; v < N; ++v) ++level_ptr[depth[v] + 1];
+    for (int l = 0; l <= max_depth; ++l) level_ptr[l + 1] += level_ptr[l];
+    std::vector<int32_t> fill(level_ptr.begin(), level_ptr.end() - 1);
+    nodes.resize(N);
+    for (int k = 0; k < N; ++k) nodes[fill[depth[seq[k]]]++] = seq[k];
+  }
+};
+
+struct DevTree { int32_t *nodes, *child_ptr, *child, *parent; uint8_t *child_c, *parent_c; };
+
+}  // namespace
+
+extern "C" int svo_msa_tree(const uint8_t* m_img3, const double* r_gra, const double* c_gra, int width, int height, int32_t* seq,
+                            int32_t* child_ptr, int32_t* child, uint8_t* child_c, int32_t* root);
+
+extern "C" int svo_msa_solve(svo_ctx* ctx, const uint8_t* bgrL, const uint8_t* bgrR, int width, int height, int step, int d,
+                             int scale, uint8_t* disparity) {
+  if (!ctx) return SVO_E_INVALID;
+  const int n = height, m = width, D = d + 1;
+  if (!bgrL || !bgrR || !disparity || n < 5 || m < 5 || d < 0 || D > 256 || step < 3 * m || scale < 1 ||
+      (size_t)n * m * D > (size_t)1 << 30 || (int64_t)n * m > (1 << 24)) {
+    ctx->last_error = "svo_msa_solve: invalid argument";
+    return SVO_E_INVALID;
+  }
+  SVO_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t N = (size_t)n * m, V = N * D;
+  DevBuf buf;
+  double* g = buf.get<double>(6 * N);                 // graL graR r_graL c_graL r_graR c_graR
+  float* cost[2] = {buf.get<float>(V), buf.get<float>(V)};   // costL, costR
+  float* d_up = buf.get<float>(V); float* d_A = buf.get<float>(V);
+  uint8_t* img3[2] = {buf.get<uint8_t>(3 * N), buf.get<uint8_t>(3 * N)};
+  uint8_t* med3[2] = {buf.get<uint8_t>(3 * N), buf.get<uint8_t>(3 * N)};
+  uint8_t* gray = buf.get<uint8_t>(N);
+  uint8_t* d_disp[2] = {buf.get<uint8_t>(N), buf.get<uint8_t>(N)};   // d0 (left), d1 (right)
+  uint8_t* d_raw = buf.get<uint8_t>(N); uint8_t* d_mask = buf.get<uint8_t>(N); uint8_t* d_out = buf.get<uint8_t>(N);
+  double* d_Exp = buf.get<double>(256);
+  DevTree dt[2];
+  for (int s2 = 0; s2 < 2; ++s2) {
+    dt[s2].nodes = buf.get<int32_t>(N); dt[s2].child_ptr = buf.get<int32_t>(N + 1); dt[s2].child = buf.get<int32_t>(N);
+    dt[s2].parent = buf.get<int32_t>(N); dt[s2].child_c = buf.get<uint8_t>(N); dt[s2].parent_c = buf.get<uint8_t>(N);
+  }
+  if (!g || !cost[0] || !cost[1] || !d_up || !d_A || !img3[0] || !img3[1] || !med3[0] || !med3[1] || !gray || !d_disp[0] ||
+      !d_disp[1] || !d_raw || !d_mask || !d_out || !d_Exp || !dt[1].parent_c) {
+    ctx->last_error = "svo_msa_solve: hipMalloc";
+    return SVO_E_NOMEM;
+  }
+  hipStream_t s = ctx->stream;
+  const dim3 px((m + 255) / 256, n);
+  const unsigned nbN = (unsigned)((N + 255) / 256), nbV = (unsigned)((V + 255) / 256);
+
+  // 1. MSA::init on the device
+  SVO_HIP(ctx, hipMemcpy2DAsync(img3[0], 3 * (size_t)m, bgrL, step, 3 * (size_t)m, n, hipMemcpyHostToDevice, s));
+  SVO_HIP(ctx, hipMemcpy2DAsync(img3[1], 3 * (size_t)m, bgrR, step, 3 * (size_t)m, n, hipMemcpyHostToDevice, s));
+  {
+    SvoTimer t(ctx, "k_msa_init");
+    for (int side = 0; side < 2; ++side) {
+      hipLaunchKernelGGL(k_msa_gray, dim3(nbN), dim3(256), 0, s, img3[side], (int)N, gray);
+      hipLaunchKernelGGL(k_msa_gradient, px, dim3(256), 0, s, gray, n, m, 1, 127.5, g + side * N);
+    }
+    hipLaunchKernelGGL(k_msa_cost, dim3(nbV), dim3(256), 0, s, img3[0], img3[1], g, g + N, n, m, D, cost[0]);
+    hipLaunchKernelGGL(k_msa_cost_right, dim3(nbV), dim3(256), 0, s, cost[0], n, m, D, cost[1]);
+    for (int side = 0; side < 2; ++side) {
+      hipLaunchKernelGGL(k_ctmf<1>, dim3((3 * m + 255) / 256, n), dim3(256), 0, s, img3[side], med3[side], m, n, 3 * m, 3 * m, 3);
+      hipLaunchKernelGGL(k_msa_gray, dim3(nbN), dim3(256), 0, s, med3[side], (int)N, gray);
+      hipLaunchKernelGGL(k_msa_gradient, px, dim3(256), 0, s, gray, n, m, 1, 0.0, g + (2 + 2 * side) * N);
+      hipLaunchKernelGGL(k_msa_gradient, px, dim3(256), 0, s, gray, n, m, 0, 0.0, g + (3 + 2 * side) * N);
+    }
+  }
+  std::vector<uint8_t> h_med[2] = {std::vector<uint8_t>(3 * N), std::vector<uint8_t>(3 * N)};
+  std::vector<double> h_gra(4 * N);
+  for (int side = 0; side < 2; ++side) SVO_HIP(ctx, hipMemcpyAsync(h_med[side].data(), med3[side], 3 * N, hipMemcpyDeviceToHost, s));
+  SVO_HIP(ctx, hipMemcpyAsync(h_gra.data(), g + 2 * N, 4 * N * sizeof(double), hipMemcpyDeviceToHost, s));
+  SVO_HIP(ctx, hipStreamSynchronize(s));
+
+  // 2. the two aggregation trees, one host thread each (the reference builds them one after the other)
+  HostTree tree[2];
+  auto grow = [&](int side) {
+    HostTree& t = tree[side];
+    t.seq.resize(N); t.child_ptr.resize(N + 1); t.child.resize(N); t.child_c.resize(N);
+    t.rc = svo_msa_tree(h_med[side].data(), h_gra.data() + 2 * side * N, h_gra.data() + (2 * side + 1) * N, m, n, t.seq.data(),
+                        t.child_ptr.data(), t.child.data(), t.child_c.data(), &t.root);
+    if (t.rc == SVO_OK) t.levels((int)N);
+  };
+  {
+    std::thread right(grow, 1);
+    grow(0);
+    right.join();
+  }
+  for (int side = 0; side < 2; ++side)
+    if (tree[side].rc) { ctx->last_error = "svo_msa_solve: tree construction failed"; return tree[side].rc; }
+  for (int side = 0; side < 2; ++side) {
+    const HostTree& t = tree[side];
+    SVO_HIP(ctx, hipMemcpyAsync(dt[side].nodes, t.nodes.data(), N * 4, hipMemcpyHostToDevice, s));
+    SVO_HIP(ctx, hipMemcpyAsync(dt[side].child_ptr, t.child_ptr.data(), (N + 1) * 4, hipMemcpyHostToDevice, s));
+    SVO_HIP(ctx, hipMemcpyAsync(dt[side].child, t.child.data(), (N - 1) * 4, hipMemcpyHostToDevice, s));
+    SVO_HIP(ctx, hipMemcpyAsync(dt[side].parent, t.parent.data(), N * 4, hipMemcpyHostToDevice, s));
+    SVO_HIP(ctx, hipMemcpyAsync(dt[side].child_c, t.child_c.data(), N - 1, hipMemcpyHostToDevice, s));
+    SVO_HIP(ctx, hipMemcpyAsync(dt[side].parent_c, t.parent_c.data(), N, hipMemcpyHostToDevice, s));
+  }
+
+  // 3. TreeDp + WTA per image, L/R check, TreeDp + WTA again with the sharper weights
+  double Exp[2][256];
+  for (int i = 0; i <= 255; ++i) { Exp[0][i] = exp(-i * 1.0 / 0.1 / 255); Exp[1][i] = exp(-i * 1.0 / (0.1 / 2) / 255); }
+  auto aggregate = [&](int side, const float* c, const double* E, uint8_t* out_disp) -> int {
+    const HostTree& t = tree[side];
+    const int levels = (int)t.level_ptr.size() - 1;
+    SVO_HIP(ctx, hipMemcpyAsync(d_Exp, E, 256 * sizeof(double), hipMemcpyHostToDevice, s));
+    SVO_HIP(ctx, hipMemcpyAsync(d_up, c, V * sizeof(float), hipMemcpyDeviceToDevice, s));
+    {
+      SvoTimer tm(ctx, "k_msa_tree_dp");
+      for (int l = levels - 1; l >= 0; --l) {
+        const int cnt = t.level_ptr[l + 1] - t.level_ptr[l];
+        hipLaunchKernelGGL(k_msa_dp_up, dim3((unsigned)(((size_t)cnt * D + 255) / 256)), dim3(256), 0, s, dt[side].nodes + t.level_ptr[l],
+                           cnt, D, dt[side].child_ptr, dt[side].child, dt[side].child_c, d_Exp, d_up);
+      }
+      for (int l = 0; l < levels; ++l) {
+        const int cnt = t.level_ptr[l + 1] - t.level_ptr[l];
+        hipLaunchKernelGGL(k_msa_dp_down, dim3((unsigned)(((size_t)cnt * D + 255) / 256)), dim3(256), 0, s, dt[side].nodes + t.level_ptr[l],
+                           cnt, D, dt[side].parent, dt[side].parent_c, d_Exp, d_up, d_A);
+      }
+    }
+    SvoTimer tm(ctx, "k_msa_wta");
+    hipLaunchKernelGGL(k_msa_argmin, dim3(nbN), dim3(256), 0, s, d_A, (int)N, D, d_raw);
+    hipLaunchKernelGGL(k_ctmf<2>, dim3((m + 255) / 256, n), dim3(256), 0, s, d_raw, out_disp, m, n, m, m, 1);
+    return SVO_OK;
+  };
+  int rc;
+  if ((rc = aggregate(1, cost[1], Exp[0], d_disp[1]))) return rc;   // right image as base image
+  if ((rc = aggregate(0, cost[0], Exp[0], d_disp[0]))) return rc;   // left image as base image
+  {
+    SvoTimer tm(ctx, "k_msa_lrcheck");
+    hipLaunchKernelGGL(k_msa_lrcheck, dim3(nbV), dim3(256), 0, s, d_disp[0], d_disp[1], n, m, D, cost[0], d_mask);
+  }
+  if ((rc = aggregate(0, cost[0], Exp[1], d_disp[0]))) return rc;   // refine
+  hipLaunchKernelGGL(k_msa_scale, dim3(nbN), dim3(256), 0, s, d_disp[0], (int)N, scale, d_out);
+  SVO_HIP(ctx, hipMemcpyAsync(disparity, d_out, N, hipMemcpyDeviceToHost, s));
+  SVO_HIP(ctx, hipStreamSynchronize(s));   // Exp[][] and the trees are read by copies until here
+  SVO_HIP(ctx, hipGetLastError());
+  return SVO_OK;
 }

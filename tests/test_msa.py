@@ -170,3 +170,68 @@ def test_gpu_wta_and_lrcheck_equal_oracle(pkg):
     with pytest.raises(pkg.SvoError):
         s.msa_tree_dp(costA.reshape(-1, D)[:4], [1, 0, 2, 3], [0, 3, 3, 3, 3], [1, 2, 3], [0, 0, 0], 0)   # seq[0] != root
     s.close()
+
+
+# ---- the aggregation tree (build, minimum arborescence, region merging, BFS order) and MSA::solve -----------
+def shifted_colour_pair(W, H, shift):
+    """Left = right shifted by `shift` columns: the disparity MSA has to recover is `shift` wherever the match exists."""
+    L, _ = colour_pair(W + shift, H)
+    return np.ascontiguousarray(L[:, :W]), np.ascontiguousarray(L[:, shift:shift + W])
+
+
+def tree_inputs(bgr):
+    o = ob.msa_init(bgr, bgr, 2)
+    return o["m3L"], o["r_graL"], o["c_graL"]
+
+
+@pytest.mark.parametrize("W,H", [(5, 5), (64, 48), (200, 120)])
+def test_product_tree_equals_literal_restatement(pkg, W, H):
+    """svo_msa_tree (host code of the product, array heaps and union-find written for speed) against orc_msa_tree,
+    the pointer-for-pointer restatement of MSA.cpp:141-927: same root, same BFS order, same child lists and weights."""
+    bgr, _ = colour_pair(W, H)
+    m3, rg, cg = tree_inputs(bgr)
+    a = pkg.msa_tree(m3, rg, cg)
+    b = ob.msa_tree(m3, rg, cg)
+    assert a[0] == b[0]
+    for x, y in zip(a[1:], b[1:]):
+        assert np.array_equal(x, y)
+    root, seq, cp, ch, cc = a
+    N = W * H
+    assert seq[0] == root and sorted(seq.tolist()) == list(range(N)) and cp[-1] == N - 1        # a spanning tree
+    assert sorted(ch.tolist()) == [v for v in range(N) if v != root]
+
+
+def test_product_tree_on_a_flat_image(pkg):
+    """All weights equal: every tie-break of the heaps and of the unstable sort is on the path."""
+    m3 = np.full((40, 56, 3), 90, np.uint8)
+    z = np.zeros((40, 56))
+    a = pkg.msa_tree(m3, z, z); b = ob.msa_tree(m3, z, z)
+    assert a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:]))
+
+
+def test_oracle_solve_recovers_a_known_shift():
+    """Parity unpinned (the reference's MSA needs OpenCV to build): the restatement is at least checked for what the
+    algorithm must do, recover a constant shift away from the left border."""
+    L, R = shifted_colour_pair(120, 64, 7)
+    d = ob.msa_solve(L, R, 16, 1)
+    assert (d[:, 24:] == 7).mean() > 0.97
+    assert np.array_equal(ob.msa_solve(L, R, 16, 3), (d * 3).astype(np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,d,shift", [(120, 64, 16, 7), (200, 120, 48, 11), (321, 97, 31, 0)])
+def test_gpu_solve_equals_oracle(pkg, W, H, d, shift):
+    """svo_msa_solve (GPU stages + host trees, volumes resident in HBM) is bit-identical to orc_msa_solve."""
+    L, R = shifted_colour_pair(W, H, shift) if shift else colour_pair(W, H)
+    s = pkg.Svo(640, 240)
+    g = s.msa_solve(L, R, d, 1)
+    r = ob.msa_solve(L, R, d, 1)
+    assert np.array_equal(g, r), int((g != r).sum())
+    if shift:
+        assert (g[:, 3 * shift:] == shift).mean() > 0.95
+    assert np.array_equal(s.msa_solve(L, R, d, 2), (r * 2).astype(np.uint8))
+    with pytest.raises(pkg.SvoError):
+        s.msa_solve(L[:4], R[:4], d, 1)
+    with pytest.raises(pkg.SvoError):
+        s.msa_solve(L, R, 256, 1)
+    s.close()

@@ -113,7 +113,11 @@ int svo_create(svo_ctx** out, int device, int W, int H, int max_kp, int max_batc
 void svo_destroy(svo_ctx* ctx);
 /* Tuning switches.  "pose_mfma" (default 1): build the 6x6 J^T W J / J^T W e of svo_pose_opt, of the
  * PnP refit and of the tracker's pose optimisation as a Gram contraction on
- * v_mfma_f64_16x16x4_f64; 0 selects the VALU + DPP reduction (same results to round-off). */
+ * v_mfma_f64_16x16x4_f64; 0 selects the VALU + DPP reduction (same results to round-off).
+ * "depth_source" (default 0): where svo_track_frame / svo_track_batch_dev take keypoint depth from - 0 the sparse
+ * epipolar matcher (north star), 1 a dense ELAS map (svo_elas_*), 2 a dense MSA map (svo_msa_solve with d = 48: the
+ * reference's live configuration, src/Tracking.cc:225-228 + src/frame.cc:82-91), both read per keypoint as
+ * frame::computekeypoint_r / disp2Depth do. */
 int svo_set_option(svo_ctx* ctx, const char* key, int value);
 /* Block until everything enqueued on the ctx stream has finished. */
 int svo_sync(svo_ctx* ctx);

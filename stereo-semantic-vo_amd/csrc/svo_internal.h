@@ -159,6 +159,7 @@ int svo_launch_unproject(svo_ctx* ctx, const float* uvz, int n, const svo_camera
 extern "C" void svo_elas_release(svo_ctx* ctx);
 int svo_upload_image(svo_ctx* ctx, const uint8_t* gray, int stride, int slot);
 // dense ELAS stereo on images already in HBM; the two maps stay in HBM (valid until the next call)
+int svo_msa_run_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int pitch, int W, int H, int d, float* d_disp);
 int svo_elas_run_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int pitch, int W, int H,
                      const svo_elas_params* params, float** dD1, float** dD2, int* produced);
 

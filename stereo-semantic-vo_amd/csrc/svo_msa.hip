@@ -408,34 +408,25 @@ struct DevTree { int32_t *nodes, *child_ptr, *child, *parent; uint8_t *child_c, 
 extern "C" int svo_msa_tree(const uint8_t* m_img3, const double* r_gra, const double* c_gra, int width, int height, int32_t* seq,
                             int32_t* child_ptr, int32_t* child, uint8_t* child_c, int32_t* root);
 
-extern "C" int svo_msa_solve(svo_ctx* ctx, const uint8_t* bgrL, const uint8_t* bgrR, int width, int height, int step, int d,
-                             int scale, uint8_t* disparity) {
-  if (!ctx) return SVO_E_INVALID;
-  const int n = height, m = width, D = d + 1;
-  if (!bgrL || !bgrR || !disparity || n < 5 || m < 5 || d < 0 || D > 256 || step < 3 * m || scale < 1 ||
-      (size_t)n * m * D > (size_t)1 << 30 || (int64_t)n * m > (1 << 24)) {
-    ctx->last_error = "svo_msa_solve: invalid argument";
-    return SVO_E_INVALID;
-  }
-  SVO_HIP(ctx, hipSetDevice(ctx->device));
+// img3[side]: packed BGR images on the device (3 * m bytes per row); d_out: n * m bytes on the device.
+static int msa_solve_device(svo_ctx* ctx, DevBuf& buf, uint8_t* const img3[2], int n, int m, int d, int scale, uint8_t* d_out) {
+  const int D = d + 1;
   const size_t N = (size_t)n * m, V = N * D;
-  DevBuf buf;
   double* g = buf.get<double>(6 * N);                 // graL graR r_graL c_graL r_graR c_graR
   float* cost[2] = {buf.get<float>(V), buf.get<float>(V)};   // costL, costR
   float* d_up = buf.get<float>(V); float* d_A = buf.get<float>(V);
-  uint8_t* img3[2] = {buf.get<uint8_t>(3 * N), buf.get<uint8_t>(3 * N)};
   uint8_t* med3[2] = {buf.get<uint8_t>(3 * N), buf.get<uint8_t>(3 * N)};
   uint8_t* gray = buf.get<uint8_t>(N);
   uint8_t* d_disp[2] = {buf.get<uint8_t>(N), buf.get<uint8_t>(N)};   // d0 (left), d1 (right)
-  uint8_t* d_raw = buf.get<uint8_t>(N); uint8_t* d_mask = buf.get<uint8_t>(N); uint8_t* d_out = buf.get<uint8_t>(N);
+  uint8_t* d_raw = buf.get<uint8_t>(N); uint8_t* d_mask = buf.get<uint8_t>(N);
   double* d_Exp = buf.get<double>(256);
   DevTree dt[2];
   for (int s2 = 0; s2 < 2; ++s2) {
     dt[s2].nodes = buf.get<int32_t>(N); dt[s2].child_ptr = buf.get<int32_t>(N + 1); dt[s2].child = buf.get<int32_t>(N);
     dt[s2].parent = buf.get<int32_t>(N); dt[s2].child_c = buf.get<uint8_t>(N); dt[s2].parent_c = buf.get<uint8_t>(N);
   }
-  if (!g || !cost[0] || !cost[1] || !d_up || !d_A || !img3[0] || !img3[1] || !med3[0] || !med3[1] || !gray || !d_disp[0] ||
-      !d_disp[1] || !d_raw || !d_mask || !d_out || !d_Exp || !dt[1].parent_c) {
+  if (!g || !cost[0] || !cost[1] || !d_up || !d_A || !med3[0] || !med3[1] || !gray || !d_disp[0] || !d_disp[1] || !d_raw ||
+      !d_mask || !d_Exp || !dt[1].parent_c) {
     ctx->last_error = "svo_msa_solve: hipMalloc";
     return SVO_E_NOMEM;
   }
@@ -444,8 +435,6 @@ extern "C" int svo_msa_solve(svo_ctx* ctx, const uint8_t* bgrL, const uint8_t* b
   const unsigned nbN = (unsigned)((N + 255) / 256), nbV = (unsigned)((V + 255) / 256);
 
   // 1. MSA::init on the device
-  SVO_HIP(ctx, hipMemcpy2DAsync(img3[0], 3 * (size_t)m, bgrL, step, 3 * (size_t)m, n, hipMemcpyHostToDevice, s));
-  SVO_HIP(ctx, hipMemcpy2DAsync(img3[1], 3 * (size_t)m, bgrR, step, 3 * (size_t)m, n, hipMemcpyHostToDevice, s));
   {
     SvoTimer t(ctx, "k_msa_init");
     for (int side = 0; side < 2; ++side) {
@@ -528,8 +517,64 @@ extern "C" int svo_msa_solve(svo_ctx* ctx, const uint8_t* bgrL, const uint8_t* b
   }
   if ((rc = aggregate(0, cost[0], Exp[1], d_disp[0]))) return rc;   // refine
   hipLaunchKernelGGL(k_msa_scale, dim3(nbN), dim3(256), 0, s, d_disp[0], (int)N, scale, d_out);
-  SVO_HIP(ctx, hipMemcpyAsync(disparity, d_out, N, hipMemcpyDeviceToHost, s));
   SVO_HIP(ctx, hipStreamSynchronize(s));   // Exp[][] and the trees are read by copies until here
   SVO_HIP(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
+extern "C" int svo_msa_solve(svo_ctx* ctx, const uint8_t* bgrL, const uint8_t* bgrR, int width, int height, int step, int d,
+                             int scale, uint8_t* disparity) {
+  if (!ctx) return SVO_E_INVALID;
+  const int n = height, m = width, D = d + 1;
+  if (!bgrL || !bgrR || !disparity || n < 5 || m < 5 || d < 0 || D > 256 || step < 3 * m || scale < 1 ||
+      (size_t)n * m * D > (size_t)1 << 30 || (int64_t)n * m > (1 << 24)) {
+    ctx->last_error = "svo_msa_solve: invalid argument";
+    return SVO_E_INVALID;
+  }
+  SVO_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t N = (size_t)n * m;
+  DevBuf buf;
+  uint8_t* img3[2] = {buf.get<uint8_t>(3 * N), buf.get<uint8_t>(3 * N)};
+  uint8_t* d_out = buf.get<uint8_t>(N);
+  if (!img3[0] || !img3[1] || !d_out) { ctx->last_error = "svo_msa_solve: hipMalloc"; return SVO_E_NOMEM; }
+  hipStream_t s = ctx->stream;
+  SVO_HIP(ctx, hipMemcpy2DAsync(img3[0], 3 * (size_t)m, bgrL, step, 3 * (size_t)m, n, hipMemcpyHostToDevice, s));
+  SVO_HIP(ctx, hipMemcpy2DAsync(img3[1], 3 * (size_t)m, bgrR, step, 3 * (size_t)m, n, hipMemcpyHostToDevice, s));
+  const int rc = msa_solve_device(ctx, buf, img3, n, m, d, scale, d_out);
+  if (rc) return rc;
+  SVO_HIP(ctx, hipMemcpy(disparity, d_out, N, hipMemcpyDeviceToHost));
+  return SVO_OK;
+}
+
+namespace {
+__global__ void k_msa_gray_to_bgr(const uint8_t* gray, int stride, int m, int n, uint8_t* bgr) {
+  const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+  if (j >= m) return;
+  const uint8_t v = gray[(size_t)i * stride + j];
+  uint8_t* o = bgr + ((size_t)i * m + j) * 3;
+  o[0] = v; o[1] = v; o[2] = v;
+}
+__global__ void k_msa_to_float(const uint8_t* d, int n, float* out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (float)d[i];
+}
+}  // namespace
+
+// frame::MB (src/frame.cc:82-91) for the tracker's dense-depth mode: gray images already on the device (a grayscale
+// file read as colour has B = G = R), disparity as CV_32F like `disp_img.convertTo(disp_32f, CV_32F, 1)`.
+int svo_msa_run_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int pitch, int W, int H, int d, float* d_disp) {
+  if (H < 5 || W < 5 || d < 0 || d > 255) return SVO_E_INVALID;
+  const size_t N = (size_t)W * H;
+  DevBuf buf;
+  uint8_t* img3[2] = {buf.get<uint8_t>(3 * N), buf.get<uint8_t>(3 * N)};
+  uint8_t* d_out = buf.get<uint8_t>(N);
+  if (!img3[0] || !img3[1] || !d_out) { ctx->last_error = "svo_msa_run_dev: hipMalloc"; return SVO_E_NOMEM; }
+  const dim3 px((W + 255) / 256, H);
+  hipLaunchKernelGGL(k_msa_gray_to_bgr, px, dim3(256), 0, ctx->stream, dL, pitch, W, H, img3[0]);
+  hipLaunchKernelGGL(k_msa_gray_to_bgr, px, dim3(256), 0, ctx->stream, dR, pitch, W, H, img3[1]);
+  const int rc = msa_solve_device(ctx, buf, img3, H, W, d, 1, d_out);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_msa_to_float, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_out, (int)N, d_disp);
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `buf` is released on return
   return SVO_OK;
 }

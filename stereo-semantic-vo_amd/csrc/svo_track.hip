@@ -669,6 +669,18 @@ __global__ void k_tk_dense_depth(const svo_kp* kp, const int32_t* nkp, const flo
   uR[i] = u; depth[i] = z;
 }
 
+// room for B frames' dense maps (two float maps and one flag per frame)
+static int dense_reserve(svo_ctx* ctx, int B) {
+  if (ctx->dense_cap >= B) return SVO_OK;
+  const size_t n = (size_t)ctx->g.W * ctx->g.H;
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->d_dense) hipFree(ctx->d_dense);
+  ctx->d_dense = nullptr; ctx->dense_cap = 0;
+  SVO_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_dense), (2 * n * sizeof(float) + sizeof(int32_t)) * (size_t)B));
+  ctx->dense_cap = B;
+  return SVO_OK;
+}
+
 extern "C" int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL,
                                const uint8_t* grayR, int strideR, double timestamp,
                                const int32_t* boxes, int n_boxes, svo_track_result* res) {
@@ -699,6 +711,15 @@ extern "C" int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL,
     SvoTimer t(ctx, "k_tk_dense_depth");
     hipLaunchKernelGGL(k_tk_dense_depth, dim3((ctx->max_kp + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_kp,
                        ctx->d_nkp, produced ? dD1 : nullptr, g.W, ctx->cam.bf, ctx->d_uR, ctx->d_depth, ctx->max_kp, (size_t)0,
+                       (const int32_t*)nullptr);
+  } else if (ctx->opt_depth_source == 2) {
+    // the reference's live configuration: frame::MB = MSA::solve(left, right, 48, 1) (src/Tracking.cc:225-228)
+    if ((rc = svo_launch_orb(ctx, dL, dR, ctx->stage_pitch, 1, 1))) return rc;
+    if ((rc = dense_reserve(ctx, 1))) return rc;
+    if ((rc = svo_msa_run_dev(ctx, dL, dR, ctx->stage_pitch, g.W, g.H, 48, ctx->d_dense))) return rc;
+    SvoTimer t(ctx, "k_tk_dense_depth");
+    hipLaunchKernelGGL(k_tk_dense_depth, dim3((ctx->max_kp + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_kp,
+                       ctx->d_nkp, ctx->d_dense, g.W, ctx->cam.bf, ctx->d_uR, ctx->d_depth, ctx->max_kp, (size_t)0,
                        (const int32_t*)nullptr);
   } else {
     if ((rc = svo_launch_orb(ctx, dL, dR, ctx->stage_pitch, 1, 2))) return rc;
@@ -743,13 +764,7 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
   if (ctx->opt_depth_source == 1) {
     // dense ELAS maps for the B frames (svo_elas_batch_dev), then the reference's per-keypoint lookups
     const size_t n = (size_t)ctx->g.W * ctx->g.H;
-    if (ctx->dense_cap < B) {
-      SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      if (ctx->d_dense) hipFree(ctx->d_dense);
-      ctx->d_dense = nullptr; ctx->dense_cap = 0;
-      SVO_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_dense), (2 * n * sizeof(float) + sizeof(int32_t)) * (size_t)B));
-      ctx->dense_cap = B;
-    }
+    if ((rc = dense_reserve(ctx, B))) return rc;
     float* dD1 = ctx->d_dense;
     float* dD2 = dD1 + n * (size_t)B;
     int32_t* d_prod = reinterpret_cast<int32_t*>(dD2 + n * (size_t)B);
@@ -762,6 +777,17 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
     hipLaunchKernelGGL(k_tk_dense_depth, dim3((ctx->max_kp + 255) / 256, B), dim3(256), 0, ctx->stream, ctx->d_kp, ctx->d_nkp,
                        dD1, ctx->g.W, ctx->cam.bf, ctx->d_uR, ctx->d_depth, ctx->max_kp, n, d_prod);
     SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `prod` is on this stack frame
+  } else if (ctx->opt_depth_source == 2) {
+    // MSA maps frame by frame (each solve already fills the GPU and has its host stage between the kernels)
+    const size_t n = (size_t)ctx->g.W * ctx->g.H;
+    if ((rc = dense_reserve(ctx, B))) return rc;
+    if ((rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, B, B))) return rc;   // left images only
+    for (int b = 0; b < B; ++b)
+      if ((rc = svo_msa_run_dev(ctx, d_grayL + (size_t)b * ctx->g.H * stride, d_grayR + (size_t)b * ctx->g.H * stride, stride,
+                                ctx->g.W, ctx->g.H, 48, ctx->d_dense + n * (size_t)b)))
+        return rc;
+    hipLaunchKernelGGL(k_tk_dense_depth, dim3((ctx->max_kp + 255) / 256, B), dim3(256), 0, ctx->stream, ctx->d_kp, ctx->d_nkp,
+                       ctx->d_dense, ctx->g.W, ctx->cam.bf, ctx->d_uR, ctx->d_depth, ctx->max_kp, n, (const int32_t*)nullptr);
   } else {
     if ((rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, B, 2 * B))) return rc;
     if ((rc = svo_launch_stereo(ctx, d_grayL, d_grayR, stride, B, &ctx->cam))) return rc;

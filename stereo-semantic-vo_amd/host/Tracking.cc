@@ -104,6 +104,11 @@ void Tracking::Track(const GrayImage& imLeft, const GrayImage& imRight, double t
     currentframe->ElasMatch(imLeft, imRight);
     currentframe->computekeypoint_r();
     currentframe->disp2Depth(bf);
+  } else if (depth_source == 2) {         // the same four calls with the reference's own MB body (MSA)
+    currentframe->featuredetect(imLeft);
+    currentframe->MBdense(imLeft, imRight);
+    currentframe->computekeypoint_r();
+    currentframe->disp2Depth(bf);
   } else {
     currentframe->MB(imLeft, imRight);    // featuredetect + stereo association in one device pass
     currentframe->computekeypoint_r();

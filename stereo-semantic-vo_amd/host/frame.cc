@@ -100,6 +100,22 @@ int frame::ElasMatch(const GrayImage& left, const GrayImage& right) {
   return valid;
 }
 
+int frame::MBdense(const GrayImage& left, const GrayImage& right) {
+  const size_t n = (size_t)left.cols * left.rows;
+  std::vector<uint8_t> l3(3 * n), r3(3 * n), disp(n, 0);
+  for (int i = 0; i < left.rows; ++i)
+    for (int j = 0; j < left.cols; ++j) {
+      const size_t t = (size_t)i * left.cols + j;
+      l3[3 * t] = l3[3 * t + 1] = l3[3 * t + 2] = left.ptr()[(size_t)i * left.cols + j];
+      r3[3 * t] = r3[3 * t + 1] = r3[3 * t + 2] = right.ptr()[(size_t)i * right.cols + j];
+    }
+  dispimg.assign(n, -1.f);
+  if (svo_msa_solve(ctx, l3.data(), r3.data(), left.cols, left.rows, 3 * left.cols, 48, 1, disp.data()) != SVO_OK) return 0;
+  int valid = 0;
+  for (size_t t = 0; t < n; ++t) { dispimg[t] = (float)disp[t]; valid += disp[t] != 0; }
+  return valid;
+}
+
 // src/frame.cc:122-138.  After MB() keypoints_r already holds the sub-pixel right x; after ElasMatch() it is read
 // off the dense map at the truncated keypoint position, as `dispimg.at<float>(ly, lx)` does.
 void frame::computekeypoint_r() {

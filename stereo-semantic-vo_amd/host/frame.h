@@ -5,6 +5,7 @@
 //   computekeypoint_r  -> copies uR                (src/frame.cc:122-138)
 //   disp2Depth         -> depth = bf / disparity   (src/frame.cc:140-164; per keypoint)
 //   UnprojectStereo    -> same float arithmetic    (src/frame.cc:166-180)
+//   MBdense            -> svo_msa_solve            (src/frame.cc:82-91 as the reference has it: MSA::solve(l, r, 48, 1))
 //   ElasMatch          -> svo_elas_process         (src/frame.cc:93-120 dense disparity; the reference's body is
 //                         OpenCV SGBM under that name, the vendored solver it names is libelas: include/frame.h:15)
 #pragma once
@@ -28,6 +29,8 @@ class frame {
   // dense left-reference disparity map (float, width x height, negative = invalid) into `dispimg`;
   // returns the number of valid pixels
   int ElasMatch(const svo_host::GrayImage& left, const svo_host::GrayImage& right);
+  // the reference's own MB body: MSA dense disparity (0 = none) of the two images as B = G = R colour images
+  int MBdense(const svo_host::GrayImage& left, const svo_host::GrayImage& right);
   void disp2Depth(float bf);
   bool UnprojectStereo(float u, float v, float z, svo_host::Vec3f& x3D) const;
   void createmappoint(std::set<mappoint*, mappoint_by_creation>& localmap);

@@ -13,10 +13,11 @@
 using namespace svo_host;
 
 int main(int argc, char** argv) {
-  if (argc != 3 && argc != 4) { std::cerr << "usage: host_check <sequence_dir> <n_frames> [dense]" << std::endl; return 2; }
+  if (argc != 3 && argc != 4) { std::cerr << "usage: host_check <sequence_dir> <n_frames> [dense|msa]" << std::endl; return 2; }
   const std::string seq = argv[1];
   const int n = atoi(argv[2]);
-  const int depth_source = argc == 4 ? 1 : 0;   // "dense": ELAS map as the depth source on both sides
+  // "dense": ELAS map as the depth source on both sides; "msa": MSA map (the reference's live configuration)
+  const int depth_source = argc == 4 ? (std::string(argv[3]) == "msa" ? 2 : 1) : 0;
   const svo_camera cam{718.856f, 718.856f, 607.1928f, 185.2157f, 386.1448f};
   Tracking* host = nullptr;
   svo_ctx* dev = nullptr;

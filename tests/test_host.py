@@ -79,6 +79,12 @@ def test_host_classes_equal_device_tracker(pkg, tmp_path):
     assert p.returncode == 0, p.stdout + p.stderr
     worst = [float(ln.split()[1]) for ln in p.stdout.splitlines() if ln.startswith("worst")]
     assert worst and worst[0] < 1e-3
+    # and with the MSA map, the reference's live configuration (Tracking::depth_source = 2: featuredetect, MBdense,
+    # computekeypoint_r, disp2Depth vs svo_set_option("depth_source", 2))
+    p = subprocess.run([os.path.join(HOST, "host_check"), str(tmp_path), "3", "msa"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    worst = [float(ln.split()[1]) for ln in p.stdout.splitlines() if ln.startswith("worst")]
+    assert worst and worst[0] < 1e-3
 
 
 @pytest.mark.gpu

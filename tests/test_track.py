@@ -162,6 +162,59 @@ def test_gpu_tracker_with_dense_elas_depth_matches_oracle(pkg, sequence, oracle_
     svo.close()
 
 
+# ---- depth source 2: dense MSA map, the reference's live configuration (src/Tracking.cc:225-228, frame::MB) ----
+MSA_FRAMES = 3
+
+
+def _as_bgr(g):
+    return np.ascontiguousarray(np.repeat(np.asarray(g)[:, :, None], 3, 2))
+
+
+@pytest.mark.gpu
+def test_gpu_tracker_with_dense_msa_depth_matches_oracle(orc, pkg, sequence):
+    """svo_set_option("depth_source", 2): ORB (left) + MSA::solve(l, r, 48, 1) on the device + depth lookups, against
+    the oracle tracker reading the maps of the CPU restatement of MSA (frame by frame, single and batched call)."""
+    import torch
+    from oracle import binding as ob
+    L, R, _ = sequence
+    H, W = L.shape[1], L.shape[2]
+    trk = orc.Tracker(W, H, pkg.KITTI_00_02)
+    svo = pkg.Svo(W, H, max_batch=MSA_FRAMES)
+    svo.set_option("depth_source", 2)
+    svo.track_reset(pkg.Camera(**pkg.KITTI_00_02))
+    single = []
+    for k in range(MSA_FRAMES):
+        dmap = ob.msa_solve(_as_bgr(L[k]), _as_bgr(R[k]), 48, 1).astype(np.float32)
+        ref, ref_cur = trk.track(L[k], R[k], dense=dmap)
+        res = svo.track_frame(L[k], R[k])
+        cur = svo.debug_track_matches()
+        for f in ("frame_id", "n_kp", "n_stereo", "n_match_pass1", "n_match_pass2", "n_pnp_inliers",
+                  "n_lm_edges", "n_new_mappoints", "n_local_map"):
+            assert res[f] == ref[f], (k, f, res[f], ref[f])
+        assert np.array_equal(cur[:ref["n_kp"]], ref_cur[:ref["n_kp"]]), "frame %d match indices" % k
+        T, Tr = res["Tcw"].reshape(4, 4), ref["Tcw"].reshape(4, 4)
+        assert np.abs(T[:3, 3] - Tr[:3, 3]).max() < POSE_TOL_T, k
+        assert np.abs(T[:3, :3] - Tr[:3, :3]).max() < POSE_TOL_R, k
+        assert res["n_stereo"] > 100
+        single.append(res.copy())
+    trk.close()
+    # the batched entry point walks the same frames
+    pitch = 1280
+    dev = torch.device("cuda", 0)
+    dL = torch.zeros((MSA_FRAMES, H, pitch), dtype=torch.uint8, device=dev)
+    dR = torch.zeros_like(dL)
+    dL[:, :, :W] = torch.as_tensor(np.asarray(L[:MSA_FRAMES])).to(dev); dR[:, :, :W] = torch.as_tensor(np.asarray(R[:MSA_FRAMES])).to(dev)
+    out = torch.zeros(MSA_FRAMES * pkg.TRACK_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    svo.track_reset(pkg.Camera(**pkg.KITTI_00_02))
+    svo.track_batch_dev(dL.data_ptr(), dR.data_ptr(), pitch, MSA_FRAMES, out.data_ptr())
+    svo.sync()
+    rec = out.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(-1)
+    for k in range(MSA_FRAMES):
+        assert rec[k].tobytes() == single[k].tobytes(), k
+    svo.close()
+
+
 @pytest.mark.gpu
 def test_multi_sequence_tracker_equals_independent_chains(pkg, sequence):
     """svo_track_multi_step_dev: S staggered sequences advanced together == S single-sequence trackers,

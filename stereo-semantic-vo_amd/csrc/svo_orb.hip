@@ -245,21 +245,34 @@ __global__ __launch_bounds__(256) void k_fast(SvoGeom g, ImgSrc s, uint32_t* cor
   if (tid == 0) { lcount = 0; nq[0] = 0; nq[1] = 0; ncand = 0; }
 
   // stage pixels: rows y0-4 .. y0+FAST_TH+3, columns x0-8 .. x0+127
-  const bool aligned = ((pitch & 3) == 0) && ((reinterpret_cast<uintptr_t>(img_p) & 3) == 0);
-  for (int i = tid; i < PXR * PXW; i += 256) {
-    const int r = i / PXW, c = i - r * PXW;
-    const int gy = min(max(y0 - 4 + r, 0), h - 1);
-    const int gx = x0 - 8 + 4 * c;
-    const uint8_t* row = img_p + (size_t)gy * pitch;
-    uint32_t v;
-    if (aligned && gx + 3 < w) {
-      v = *reinterpret_cast<const uint32_t*>(row + gx);
-    } else {
-      v = 0;
+  {
+    // Every thread issues all of its (unconditional, possibly unaligned) dword loads before the first LDS store: one
+    // memory round trip per tile instead of six.  Columns are clamped to the last full dword of the row; the few
+    // dwords that hang over the right image border are rebuilt from it afterwards (replicated last pixel).
+    typedef uint32_t __attribute__((aligned(1))) u32u;
+    constexpr int NSLOT = (PXR * PXW + 255) / 256;
+    uint32_t v[NSLOT];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v |= (uint32_t)row[min(gx + k, w - 1)] << (8 * k);
+    for (int k = 0; k < NSLOT; ++k) {
+      const int i = min(tid + 256 * k, PXR * PXW - 1);
+      const int r = i / PXW, c = i - r * PXW;
+      const int gy = min(max(y0 - 4 + r, 0), h - 1);
+      const int gx = min(x0 - 8 + 4 * c, w - 4);
+      v[k] = *reinterpret_cast<const u32u*>(img_p + (size_t)gy * pitch + gx);
     }
-    px[i] = v;
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+      const int i = tid + 256 * k;
+      const int c = i % PXW;
+      const int over = x0 - 8 + 4 * c - (w - 4);   // > 0: this dword starts `over` bytes right of the loaded one
+      uint32_t o = v[k];
+      if (over > 0) {
+        o = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) o |= ((v[k] >> (8 * min(over + b, 3))) & 0xffu) << (8 * b);
+      }
+      if (i < PXR * PXW) px[i] = o;
+    }
   }
   __syncthreads();
 

@@ -15,7 +15,7 @@
 #include "svo_wave.h"
 #include "../../include/svo_brief_pattern.h"
 
-__constant__ int8_t c_pattern[SVO_BRIEF_NTESTS][4] = SVO_BRIEF_PATTERN_INIT;
+__constant__ __attribute__((aligned(16))) int8_t c_pattern[SVO_BRIEF_NTESTS][4] = SVO_BRIEF_PATTERN_INIT;
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
 struct ImgSrc {
@@ -607,13 +607,30 @@ __global__ __launch_bounds__(64) void k_describe(SvoGeom g, ImgSrc s, const SvoS
   if (slot == 0 && lane == 0) nkp[img] = total;
   if (l < 0 || slot >= total) return;
   const SvoSel sv = sel[(size_t)(img * SVO_NLEVELS + l) * SVO_QMAX + rank];
+  // the four test pairs of this lane, requested now so that they arrive under the patch loads
+  char4 pat[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) pat[t] = *reinterpret_cast<const char4*>(c_pattern[t * 64 + lane]);
+  uint32_t mw[8], mo[8];   // moment weights of this lane's disc row (same reason)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { mw[k] = c_mom.w[min(lane, 30)][k]; mo[k] = c_mom.one[min(lane, 30)][k]; }
   const int x = sv.x, y = sv.y;
   int pitch;
   const uint8_t* img_p = level_ptr(g, s, img, l, &pitch);
   const uint8_t* org = img_p + (size_t)(y - 18) * pitch + (x - 19);
-  for (int i = lane; i < PW * PROW; i += 64) {
-    const int r = i / PROW, d = i - r * PROW;
-    patch[i] = *reinterpret_cast<const u32_unaligned*>(org + (size_t)r * pitch + 4 * d);
+  {
+    // all six loads of a lane in flight together (one memory round trip, not six)
+    constexpr int NSLOT = (PW * PROW + 63) / 64;
+    uint32_t v[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+      const int i = min(lane + 64 * k, PW * PROW - 1);
+      const int r = i / PROW, d = i - r * PROW;
+      v[k] = *reinterpret_cast<const u32_unaligned*>(org + (size_t)r * pitch + 4 * d);
+    }
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k)
+      if (lane + 64 * k < PW * PROW) patch[lane + 64 * k] = v[k];
   }
   for (int i = lane; i < 31 * 20; i += 64) hbT[i] = 0;   // rows 37..39 of each column stay zero
   __syncthreads();
@@ -626,8 +643,8 @@ __global__ __launch_bounds__(64) void k_describe(SvoGeom g, ImgSrc s, const SvoS
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const uint32_t px4 = row[k];
-      m10 = __builtin_amdgcn_sdot4((int)(px4 ^ 0x80808080u), (int)c_mom.w[lane][k], m10, false);
-      rs = (int)__builtin_amdgcn_udot4(px4, c_mom.one[lane][k], (uint32_t)rs, false);
+      m10 = __builtin_amdgcn_sdot4((int)(px4 ^ 0x80808080u), (int)mw[k], m10, false);
+      rs = (int)__builtin_amdgcn_udot4(px4, mo[k], (uint32_t)rs, false);
     }
     m01 = (lane - 15) * rs;
   }
@@ -682,9 +699,8 @@ __global__ __launch_bounds__(64) void k_describe(SvoGeom g, ImgSrc s, const SvoS
   uint64_t* dout = reinterpret_cast<uint64_t*>(desc + oidx * SVO_DESC_BYTES);
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const int i = t * 64 + lane;
-    const float px0 = (float)c_pattern[i][0], py0 = (float)c_pattern[i][1];
-    const float px1 = (float)c_pattern[i][2], py1 = (float)c_pattern[i][3];
+    const float px0 = (float)pat[t].x, py0 = (float)pat[t].y;
+    const float px1 = (float)pat[t].z, py1 = (float)pat[t].w;
     const float rx0 = px0 * cs - py0 * sn, ry0 = px0 * sn + py0 * cs;
     const float rx1 = px1 * cs - py1 * sn, ry1 = px1 * sn + py1 * cs;
     const int v0 = bl[(15 + __float2int_rn(rx0)) * 32 + 15 + __float2int_rn(ry0)];

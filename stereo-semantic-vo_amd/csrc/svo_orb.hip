@@ -209,12 +209,12 @@ __global__ __launch_bounds__(256) void k_fast(SvoGeom g, ImgSrc s, uint32_t* cor
   __shared__ int lhist[256];
   // 18.5 KB of LDS per workgroup: 8 workgroups (8 waves per SIMD) fit one CU, which is what hides the staging loads
   // of one tile behind the arithmetic of the others (6 per CU: +12 % on the kernel, 4: +45 %)
-  __shared__ uint32_t qbuf[SCR * 32];       // phases A-B: the two queues; phase C on: lcorn (the queues are dead)
-  uint16_t (*queue)[SCR * 32] = reinterpret_cast<uint16_t (*)[SCR * 32]>(qbuf);   // surviving pixel pairs by column parity: id = r*64 + pc
+  __shared__ uint32_t qbuf[SCR * 32];       // phases A-B: the queue; phase C on: lcorn (the queue is dead)
+  uint16_t* queue = reinterpret_cast<uint16_t*>(qbuf);   // surviving pixel pairs: id = r*64 + pc
   uint32_t* lcorn = qbuf;                   // FAST_TW * FAST_TH / 4 entries at most (NMS density bound)
   static_assert(FAST_TW * FAST_TH / 4 + 64 <= SCR * 32, "lcorn must fit the queue buffer");
   __shared__ uint16_t cand[FAST_CAND_CAP];  // pixels with a nonzero score: id = r*128 + col (overflow: phase C scans sc)
-  __shared__ int nq[2], ncand, lcount, lbase;
+  __shared__ int nq, ncand, lcount, lbase;
 
   const int tid = threadIdx.x, lane = tid & 63;
   // XCD-aware tile order: workgroup b is observed to run on XCD b % 8 and each XCD has a private
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_fast(SvoGeom g, ImgSrc s, uint32_t* cor
 
   lhist[tid] = 0;
   for (int i = tid; i < SCR * (SCW / 4); i += 256) sc[i] = 0;
-  if (tid == 0) { lcount = 0; nq[0] = 0; nq[1] = 0; ncand = 0; }
+  if (tid == 0) { lcount = 0; nq = 0; ncand = 0; }
 
   // stage pixels: rows y0-4 .. y0+FAST_TH+3, columns x0-8 .. x0+127
   {
@@ -299,31 +299,35 @@ __global__ __launch_bounds__(256) void k_fast(SvoGeom g, ImgSrc s, uint32_t* cor
       const uint64_t m = __ballot(pass[k] != 0);
       if (m) {
         int base = 0;
-        if (lane == 0) base = atomicAdd(&nq[k & 1], __popcll(m));
+        if (lane == 0) base = atomicAdd(&nq, __popcll(m));
         base = __shfl(base, 0, 64);
-        if (pass[k]) queue[k & 1][base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(r * 64 + 4 * c + k);
+        if (pass[k]) queue[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(r * 64 + 4 * c + k);
       }
     }
   }
   __syncthreads();
 
-  // phase B: exact score of the surviving pairs only, all lanes busy.  Even pair columns use the
-  // window that starts at the pair's own dword (centre at byte 4), odd ones the same dword with
-  // the centre at byte 6: both variants read window bytes 1..10 = three dwords per row.
+  // phase B: exact score of the surviving pairs only.  A pair starts at byte 4 (even pair column) or byte 6 (odd) of
+  // the window beginning at its own dword; odd ones are shifted down by two bytes (v_alignbit, shift 0 or 16) so that
+  // ONE loop serves both - with ~95 survivors of each parity per tile two separate loops ran at 37 % lane occupancy.
   uint16_t* sc16 = reinterpret_cast<uint16_t*>(sc);
-#pragma unroll
-  for (int par = 0; par < 2; ++par) {
-    const int n = nq[par];
+  {
+    const int n = nq;
     for (int q = tid; q < n; q += 256) {
-      const int id = queue[par][q];
+      const int id = queue[q];
       const int r = id >> 6, pc = id & 63;
+      const uint32_t sh = (uint32_t)(pc & 1) * 16u;
       uint32_t rw[7][4];
 #pragma unroll
       for (int j = 0; j < 7; ++j) {
         const uint32_t* p = &px[(r + j) * PXW + (pc >> 1)];
-        rw[j][0] = p[0]; rw[j][1] = p[1]; rw[j][2] = p[2]; rw[j][3] = p[2];
+        const uint32_t a = p[0], b = p[1], c = p[2];
+        rw[j][0] = __builtin_amdgcn_alignbit(b, a, sh);
+        rw[j][1] = __builtin_amdgcn_alignbit(c, b, sh);
+        rw[j][2] = c >> sh;
+        rw[j][3] = rw[j][2];
       }
-      const uint32_t sp = par == 0 ? fast_pair<0>(rw) : fast_pair<2>(rw);
+      const uint32_t sp = fast_pair<0>(rw);
       if (sp) {
         sc16[r * 64 + pc] = (uint16_t)sp;
         if (sp & 0xffu) { const int k = atomicAdd(&ncand, 1); if (k < FAST_CAND_CAP) cand[k] = (uint16_t)(r * 128 + 2 * pc); }

@@ -292,8 +292,26 @@ __global__ __launch_bounds__(256) void k_fast(SvoGeom g, ImgSrc s, uint32_t* cor
       const uint2 q = *reinterpret_cast<const uint2*>(&px[(r + 6) * PXW + 2 * c + 2]);
       r6[0] = p.x; r6[1] = p.y; r6[2] = q.x; r6[3] = q.y;
     }
-    const uint32_t pass[4] = {compass_pair<0>(r0, r3, r6), compass_pair<2>(r0, r3, r6),
-                              compass_pair<4>(r0, r3, r6), compass_pair<6>(r0, r3, r6)};
+    // Compass pre-test on 4 pixels per 32-bit operation: pixels quantised to 6 bits (x >> 2); c - n >= 21 implies
+    // cq - nq >= 5, which is bit 7 of (cq + 123 - nq) computed byte-wise (60 <= . <= 186: no borrow between bytes),
+    // and the "brighter" test is bit 7 of 246 - that.  A 9-arc needs two adjacent compass points both darker or both
+    // brighter: (N|S)&(E|W).  Slightly looser than the exact compass test; phase B scores exactly either way.
+    uint32_t pass[4];
+    {
+      auto q6 = [](uint32_t x) { return (x >> 2) & 0x3f3f3f3fu; };
+      const uint32_t qL = q6(r3[0]), qC1 = q6(r3[1]), qC2 = q6(r3[2]), qR = q6(r3[3]);
+      const uint32_t qN1 = q6(r0[1]), qN2 = q6(r0[2]), qS1 = q6(r6[1]), qS2 = q6(r6[2]);
+      const uint32_t qE1 = __builtin_amdgcn_alignbyte(qC2, qC1, 3), qE2 = __builtin_amdgcn_alignbyte(qR, qC2, 3);
+      const uint32_t qW1 = __builtin_amdgcn_alignbyte(qC1, qL, 1), qW2 = __builtin_amdgcn_alignbyte(qC2, qC1, 1);
+      auto flags = [](uint32_t qc, uint32_t qn, uint32_t qs, uint32_t qe, uint32_t qw) {
+        const uint32_t cg = qc + 0x7b7b7b7bu;
+        const uint32_t dn = cg - qn, ds = cg - qs, de = cg - qe, dw = cg - qw;
+        const uint32_t bn = 0xf6f6f6f6u - dn, bs = 0xf6f6f6f6u - ds, be = 0xf6f6f6f6u - de, bw = 0xf6f6f6f6u - dw;
+        return (((dn | ds) & (de | dw)) | ((bn | bs) & (be | bw))) & 0x80808080u;
+      };
+      const uint32_t m1 = flags(qC1, qN1, qS1, qE1, qW1), m2 = flags(qC2, qN2, qS2, qE2, qW2);
+      pass[0] = m1 & 0x00008080u; pass[1] = m1 & 0x80800000u; pass[2] = m2 & 0x00008080u; pass[3] = m2 & 0x80800000u;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const uint64_t m = __ballot(pass[k] != 0);

@@ -214,6 +214,7 @@ extern "C" int svo_create(svo_ctx** out, int device, int W, int H, int max_kp, i
   TRY(dalloc(ctx, &ctx->d_corners, I * (size_t)g.corner_entries));
   TRY(dalloc(ctx, &ctx->d_counters, I * SVO_NLEVELS));
   TRY(dalloc(ctx, &ctx->d_hist, I * SVO_NLEVELS * 256));
+  if (rc == SVO_OK && hipMemset(ctx->d_hist, 0, sizeof(int32_t) * I * SVO_NLEVELS * 256) != hipSuccess) rc = SVO_E_HIP;   // k_select keeps it zero
   TRY(dalloc(ctx, &ctx->d_sel, I * SVO_NLEVELS * SVO_QMAX));
   TRY(dalloc(ctx, &ctx->d_selcnt, I * SVO_NLEVELS));
   TRY(dalloc(ctx, &ctx->d_kp, I * (size_t)max_kp));

@@ -428,7 +428,7 @@ __device__ __forceinline__ int64_t harris_at(const uint8_t* img, int pitch, int 
 }
 
 __global__ __launch_bounds__(256) void k_select(SvoGeom g, ImgSrc s, const uint32_t* corners,
-                                                const int32_t* counters, const int32_t* hist,
+                                                const int32_t* counters, int32_t* hist,
                                                 SvoSel* sel, int32_t* selcnt) {
   __shared__ int64_t cR[SVO_CAP1];
   __shared__ uint32_t cxy[SVO_CAP1];   // x | y<<12 | score<<24; the raster key y*w+x is derived from it
@@ -438,11 +438,16 @@ __global__ __launch_bounds__(256) void k_select(SvoGeom g, ImgSrc s, const uint3
   const int l = blockIdx.x, img = blockIdx.y;
   const int n = counters[img * SVO_NLEVELS + l];
   const int quota = g.quota[l];
+  // the histogram is consumed here and handed back zeroed: k_fast of the next call accumulates into it without a
+  // 2 MB memset in between (svo_create zeroes it once)
+  int32_t* hbin = &hist[(img * SVO_NLEVELS + l) * 256 + tid];
+  const int hv = n ? *hbin : 0;
+  if (hv) *hbin = 0;
   if (n == 0 || quota == 0) {
     if (tid == 0) selcnt[img * SVO_NLEVELS + l] = 0;
     return;
   }
-  cum[tid] = hist[(img * SVO_NLEVELS + l) * 256 + tid];
+  cum[tid] = hv;
   if (tid == 0) { cum[256] = 0; nc = 0; sT = 0; }
   __syncthreads();
   // suffix counts cum[s] = #corners with score >= s (parallel scan over the 256 bins)
@@ -753,7 +758,6 @@ int svo_launch_orb(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR,
   ImgSrc s{d_grayL, d_grayR, stride, B, ctx->d_pyr};
   hipStream_t st = ctx->stream;
   SVO_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(int32_t) * (size_t)nimg * SVO_NLEVELS, st));
-  SVO_HIP(ctx, hipMemsetAsync(ctx->d_hist, 0, sizeof(int32_t) * (size_t)nimg * SVO_NLEVELS * 256, st));
   {
     SvoTimer t(ctx, "k_pyr_level");
     for (int l = 1; l < SVO_NLEVELS; ++l) {

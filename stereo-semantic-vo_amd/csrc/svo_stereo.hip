@@ -38,8 +38,11 @@ __device__ __forceinline__ const uint8_t* st_level_ptr(const SvoGeom& g, const S
 
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { return wave_min_u32_dpp(v); }
 
-// One workgroup = 16 left keypoints of one pair (4 waves x 4 keypoints); the right
-// image's keypoint bands and descriptors are staged in LDS once per workgroup.
+// One workgroup = KP_PER_WG left keypoints of one pair (4 waves x KP_PER_WG/4 keypoints); the right image's keypoint
+// bands and descriptors are staged in LDS once per workgroup.  A wave takes its keypoints in groups of ST_G: the
+// group's keypoints and descriptors are requested together, then the Hamming search runs for all of them, then the
+// SAD windows of all of them are requested together - two memory round trips per group instead of two per keypoint.
+#define ST_G 4
 __global__ __launch_bounds__(256) void k_stereo_match(SvoGeom g, StereoSrc s, const svo_kp* kp,
                                                       const uint8_t* desc, const int32_t* nkp,
                                                       int max_kp, float bf, float fx, float* uR,
@@ -49,8 +52,8 @@ __global__ __launch_bounds__(256) void k_stereo_match(SvoGeom g, StereoSrc s, co
   __shared__ int8_t roct[MAXKP_LDS];
   __shared__ float rx[MAXKP_LDS];
   __shared__ int sadbuf[4][128];
-  __shared__ uint64_t winL[4][11][2];   // per wave: 11 rows x 16 bytes of the left SAD window
-  __shared__ uint64_t winR[4][11][3];   // per wave: 11 rows x 24 bytes of the right search band
+  __shared__ uint64_t winL[4][ST_G][11][2];   // per wave and keypoint: 11 rows x 16 bytes of the left SAD window
+  __shared__ uint64_t winR[4][ST_G][11][3];   // per wave and keypoint: 11 rows x 24 bytes of the right search band
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int pair = blockIdx.y;
   const int imgL = pair, imgR = s.B + pair;
@@ -70,70 +73,98 @@ __global__ __launch_bounds__(256) void k_stereo_match(SvoGeom g, StereoSrc s, co
   }
   __syncthreads();
   const float maxD = fx;
-  for (int q = 0; q < KP_PER_WG / 4; ++q) {
-    const int iL = blockIdx.x * KP_PER_WG + wv * (KP_PER_WG / 4) + q;
-    if (iL >= max_kp) break;
-    const size_t o = (size_t)pair * max_kp + iL;
-    if (iL >= nL) {
-      if (lane == 0) { uR[o] = -1.f; depth[o] = -1.f; sad_out[o] = -1; }
-      continue;
+  typedef uint64_t __attribute__((aligned(1))) u64u;
+  for (int q0 = 0; q0 < KP_PER_WG / 4; q0 += ST_G) {
+    const int iL0 = blockIdx.x * KP_PER_WG + wv * (KP_PER_WG / 4) + q0;
+    if (iL0 >= max_kp) break;
+    // (1) the group's keypoints and descriptors (indices clamped: every load is unconditional)
+    svo_kp kl[ST_G];
+    uint32_t ql[ST_G][8];
+#pragma unroll
+    for (int j = 0; j < ST_G; ++j) {
+      const int ic = min(iL0 + j, max_kp - 1);
+      kl[j] = kpL[ic];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ql[j][k] = dL[(size_t)ic * 8 + k];
     }
-    const svo_kp kl = kpL[iL];
-    const int levelL = kl.octave;
-    const float uL = kl.x, vL = kl.y;
-    const int row = (int)vL;
-    const float minU = uL - maxD, maxU = uL;
-    uint32_t ql[8];
+    // (2) Hamming search in the row band
+    uint32_t best[ST_G];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) ql[k] = dL[(size_t)iL * 8 + k];
-    uint32_t best = ((uint32_t)TH_HIGH << 16) | 0xffffu;
-    if (maxU >= 0) {
-      for (int iR = lane; iR < nR; iR += 64) {
-        const int oc = roct[iR];
-        const float u = rx[iR];
-        const bool ok = row >= rminr[iR] && row <= rmaxr[iR] && oc >= levelL - 1 &&
-                        oc <= levelL + 1 && u >= minU && u <= maxU;
-        if (ok) {
-          int dist = 0;
+    for (int j = 0; j < ST_G; ++j) {
+      const int levelL = kl[j].octave;
+      const float uL = kl[j].x;
+      const int row = (int)kl[j].y;
+      const float minU = uL - maxD, maxU = uL;
+      uint32_t b = ((uint32_t)TH_HIGH << 16) | 0xffffu;
+      if (iL0 + j < nL && maxU >= 0) {
+        for (int iR = lane; iR < nR; iR += 64) {
+          const int oc = roct[iR];
+          const float u = rx[iR];
+          const bool ok = row >= rminr[iR] && row <= rmaxr[iR] && oc >= levelL - 1 &&
+                          oc <= levelL + 1 && u >= minU && u <= maxU;
+          if (ok) {
+            int dist = 0;
 #pragma unroll
-          for (int k = 0; k < 8; ++k) dist += __popc(ql[k] ^ rdesc[iR * 8 + k]);
-          best = min(best, ((uint32_t)dist << 16) | (uint32_t)iR);
+            for (int k = 0; k < 8; ++k) dist += __popc(ql[j][k] ^ rdesc[iR * 8 + k]);
+            b = min(b, ((uint32_t)dist << 16) | (uint32_t)iR);
+          }
         }
       }
+      best[j] = wave_min_u32(b);
     }
-    best = wave_min_u32(best);
-    const int bestDist = (int)(best >> 16), bestIdxR = (int)(best & 0xffffu);
-    float out_u = -1.f, out_d = -1.f;
-    int out_sad = -1;
-    if (bestDist < TH_ORB && bestIdxR != 0xffff) {
-      const float uR0 = rx[bestIdxR];
-      const float sc = g.scale[levelL];
-      const float inv = 1.0f / sc;
-      const int su = (int)roundf(uL * inv), sv = (int)roundf(vL * inv), sr0 = (int)roundf(uR0 * inv);
+    // (3) SAD windows of the whole group: lanes 0..10 fetch the left rows (11 px at su-5), lanes 16..26 the right
+    // rows (21 px at sr0-10); coordinates are clamped into the level so that the loads need no condition
+    bool refine[ST_G];
+    int sr0s[ST_G];
+    uint64_t wreg[ST_G][3];
+#pragma unroll
+    for (int j = 0; j < ST_G; ++j) {
+      const int bestDist = (int)(best[j] >> 16), bestIdxR = (int)(best[j] & 0xffffu);
+      const int levelL = min(max(kl[j].octave, 0), SVO_NLEVELS - 1);
+      const float inv = 1.0f / g.scale[levelL];
+      const float uR0 = rx[min(bestIdxR, MAXKP_LDS - 1)];
+      const int su = (int)roundf(kl[j].x * inv), sv = (int)roundf(kl[j].y * inv), sr0 = (int)roundf(uR0 * inv);
       const int lw = g.w[levelL], lh = g.h[levelL];
       const bool inb = !(sv - SAD_W < 0 || sv + SAD_W >= lh || su - SAD_W < 0 || su + SAD_W >= lw ||
                          sr0 - SAD_L - SAD_W < 0 || sr0 + SAD_L + SAD_W >= lw);
-      if (inb) {
-        int pl, pr;
-        const uint8_t* IL = st_level_ptr(g, s, imgL, levelL, &pl);
-        const uint8_t* IR = st_level_ptr(g, s, imgR, levelL, &pr);
-        // stage both windows with a few wide loads (one memory round trip per keypoint): lanes
-        // 0..10 fetch the left rows (11 px at su-5), lanes 16..26 the right rows (21 px at sr0-10)
-        typedef uint64_t __attribute__((aligned(1))) u64u;
-        if (lane < 11) {
-          const uint8_t* p = IL + (size_t)(sv + lane - SAD_W) * pl + su - SAD_W;
-          winL[wv][lane][0] = *reinterpret_cast<const u64u*>(p);
-          winL[wv][lane][1] = *reinterpret_cast<const u64u*>(p + 8);
-        } else if (lane >= 16 && lane < 27) {
-          const uint8_t* p = IR + (size_t)(sv + lane - 16 - SAD_W) * pr + sr0 - SAD_L - SAD_W;
-          winR[wv][lane - 16][0] = *reinterpret_cast<const u64u*>(p);
-          winR[wv][lane - 16][1] = *reinterpret_cast<const u64u*>(p + 8);
-          winR[wv][lane - 16][2] = *reinterpret_cast<const u64u*>(p + 16);
-        }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        const uint8_t* wl = reinterpret_cast<const uint8_t*>(&winL[wv][0][0]);   // row pitch 16
-        const uint8_t* wr = reinterpret_cast<const uint8_t*>(&winR[wv][0][0]);   // row pitch 24
+      refine[j] = iL0 + j < nL && bestDist < TH_ORB && bestIdxR != 0xffff && inb;
+      sr0s[j] = sr0;
+      const int svc = refine[j] ? sv : SAD_W, suc = refine[j] ? su : SAD_W, src = refine[j] ? sr0 : SAD_L + SAD_W;
+      int pl, pr;
+      const uint8_t* IL = st_level_ptr(g, s, imgL, levelL, &pl);
+      const uint8_t* IR = st_level_ptr(g, s, imgR, levelL, &pr);
+      const int rowi = lane < 16 ? min(lane, 10) : min(lane - 16, 10);
+      const uint8_t* p = lane < 16 ? IL + (size_t)(svc + rowi - SAD_W) * pl + suc - SAD_W
+                                   : IR + (size_t)(svc + rowi - SAD_W) * pr + src - SAD_L - SAD_W;
+      wreg[j][0] = *reinterpret_cast<const u64u*>(p);
+      wreg[j][1] = *reinterpret_cast<const u64u*>(p + 8);
+      wreg[j][2] = *reinterpret_cast<const u64u*>(p + (lane < 16 ? 8 : 16));
+    }
+#pragma unroll
+    for (int j = 0; j < ST_G; ++j) {
+      if (lane < 11) {
+        winL[wv][j][lane][0] = wreg[j][0]; winL[wv][j][lane][1] = wreg[j][1];
+      } else if (lane >= 16 && lane < 27) {
+        winR[wv][j][lane - 16][0] = wreg[j][0]; winR[wv][j][lane - 16][1] = wreg[j][1]; winR[wv][j][lane - 16][2] = wreg[j][2];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    // (4) SAD refinement, parabola, outputs
+#pragma unroll
+    for (int j = 0; j < ST_G; ++j) {
+      const int iL = iL0 + j;
+      if (iL >= max_kp) break;
+      const size_t o = (size_t)pair * max_kp + iL;
+      float out_u = -1.f, out_d = -1.f;
+      int out_sad = -1;
+      if (refine[j]) {
+        const int levelL = kl[j].octave;
+        const float uL = kl[j].x;
+        const float sc = g.scale[levelL];
+        const int sr0 = sr0s[j];
+        const uint8_t* wl = reinterpret_cast<const uint8_t*>(&winL[wv][j][0][0]);   // row pitch 16
+        const uint8_t* wr = reinterpret_cast<const uint8_t*>(&winR[wv][j][0][0]);   // row pitch 24
         const int cL = wl[5 * 16 + 5];
         // (inc, dy) pairs: 121 partial row sums
         for (int p = lane; p < 121; p += 64) {
@@ -180,8 +211,10 @@ __global__ __launch_bounds__(256) void k_stereo_match(SvoGeom g, StereoSrc s, co
         }
         __builtin_amdgcn_wave_barrier();
       }
+      if (lane == 0) { uR[o] = out_u; depth[o] = out_d; sad_out[o] = out_sad; }
     }
-    if (lane == 0) { uR[o] = out_u; depth[o] = out_d; sad_out[o] = out_sad; }
+    __builtin_amdgcn_wave_barrier();   // the windows are rewritten by the next group
+    __threadfence_block();
   }
 }
 

@@ -114,6 +114,8 @@ void svo_destroy(svo_ctx* ctx);
 /* Tuning switches.  "pose_mfma" (default 1): build the 6x6 J^T W J / J^T W e of svo_pose_opt, of the
  * PnP refit and of the tracker's pose optimisation as a Gram contraction on
  * v_mfma_f64_16x16x4_f64; 0 selects the VALU + DPP reduction (same results to round-off).
+ * "fast_cand_cap" (default 2048, the maximum): length of the per-tile list of scored pixels in the FAST kernel; tiles
+ * with more fall back to scanning the score tile - same results, the switch exists so that tests can force that path.
  * "depth_source" (default 0): where svo_track_frame / svo_track_batch_dev take keypoint depth from - 0 the sparse
  * epipolar matcher (north star), 1 a dense ELAS map (svo_elas_*), 2 a dense MSA map (svo_msa_solve with d = 48: the
  * reference's live configuration, src/Tracking.cc:225-228 + src/frame.cc:82-91), both read per keypoint as

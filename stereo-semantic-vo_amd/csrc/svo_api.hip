@@ -273,6 +273,11 @@ extern "C" void svo_destroy(svo_ctx* ctx) {
 extern "C" int svo_set_option(svo_ctx* ctx, const char* key, int value) {
   if (!ctx || !key) return SVO_E_INVALID;
   if (!strcmp(key, "pose_mfma")) { ctx->opt_pose_mfma = value != 0; return SVO_OK; }
+  if (!strcmp(key, "fast_cand_cap")) {
+    if (value < 0 || value > 2048) return SVO_E_INVALID;
+    ctx->opt_fast_cand_cap = value;
+    return SVO_OK;
+  }
   if (!strcmp(key, "depth_source")) {
     if (value < 0 || value > 2) return SVO_E_INVALID;   // 0 sparse matcher, 1 ELAS map, 2 MSA map
     ctx->opt_depth_source = value;

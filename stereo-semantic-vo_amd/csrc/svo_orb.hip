@@ -203,7 +203,7 @@ __device__ __forceinline__ uint32_t compass_pair(const uint32_t (&r0)[4], const 
 #define PXR (FAST_TH + 8)   // staged pixel rows: score rows + 3 above and below
 
 __global__ __launch_bounds__(256) void k_fast(SvoGeom g, ImgSrc s, uint32_t* corners,
-                                              int32_t* counters, int32_t* hist) {
+                                              int32_t* counters, int32_t* hist, int cand_cap) {
   __shared__ uint32_t px[PXR * PXW];
   __shared__ uint32_t sc[SCR * (SCW / 4)];
   __shared__ int lhist[256];
@@ -247,31 +247,27 @@ __global__ __launch_bounds__(256) void k_fast(SvoGeom g, ImgSrc s, uint32_t* cor
   // stage pixels: rows y0-4 .. y0+FAST_TH+3, columns x0-8 .. x0+127
   {
     // Every thread issues all of its (unconditional, possibly unaligned) dword loads before the first LDS store: one
-    // memory round trip per tile instead of six.  Columns are clamped to the last full dword of the row; the few
-    // dwords that hang over the right image border are rebuilt from it afterwards (replicated last pixel).
+    // memory round trip per tile instead of six.  A thread keeps one dword column (7 row groups x 34 columns = 238
+    // threads) and walks down the rows, so everything that depends on the column is computed once: the column
+    // clamped to the last full dword of the row and the v_perm selector that rebuilds a dword hanging over the right
+    // image border from it (replicated last pixel; identity elsewhere).
     typedef uint32_t __attribute__((aligned(1))) u32u;
-    constexpr int NSLOT = (PXR * PXW + 255) / 256;
+    constexpr int NROWG = 256 / PXW, NSLOT = (PXR + NROWG - 1) / NROWG;
+    const int rg = tid / PXW, c = tid - rg * PXW;   // row group, dword column
+    const int over = x0 - 8 + 4 * c - (w - 4);   // > 0: this dword starts `over` bytes right of the loaded one
+    uint32_t fix = 0x03020100u;
+    if (over > 0) fix = (uint32_t)min(over, 3) | ((uint32_t)min(over + 1, 3) << 8) | ((uint32_t)min(over + 2, 3) << 16) | (3u << 24);
+    const uint8_t* col = img_p + min(x0 - 8 + 4 * c, w - 4);
     uint32_t v[NSLOT];
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k) {
-      const int i = min(tid + 256 * k, PXR * PXW - 1);
-      const int r = i / PXW, c = i - r * PXW;
-      const int gy = min(max(y0 - 4 + r, 0), h - 1);
-      const int gx = min(x0 - 8 + 4 * c, w - 4);
-      v[k] = *reinterpret_cast<const u32u*>(img_p + (size_t)gy * pitch + gx);
+      const int gy = min(max(y0 - 4 + rg + NROWG * k, 0), h - 1);
+      v[k] = *reinterpret_cast<const u32u*>(col + (size_t)gy * pitch);
     }
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k) {
-      const int i = tid + 256 * k;
-      const int c = i % PXW;
-      const int over = x0 - 8 + 4 * c - (w - 4);   // > 0: this dword starts `over` bytes right of the loaded one
-      uint32_t o = v[k];
-      if (over > 0) {
-        o = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) o |= ((v[k] >> (8 * min(over + b, 3))) & 0xffu) << (8 * b);
-      }
-      if (i < PXR * PXW) px[i] = o;
+      const int r = rg + NROWG * k;
+      if (rg < NROWG && r < PXR) px[r * PXW + c] = __builtin_amdgcn_perm(v[k], v[k], fix);
     }
   }
   __syncthreads();
@@ -312,14 +308,21 @@ __global__ __launch_bounds__(256) void k_fast(SvoGeom g, ImgSrc s, uint32_t* cor
       const uint32_t m1 = flags(qC1, qN1, qS1, qE1, qW1), m2 = flags(qC2, qN2, qS2, qE2, qW2);
       pass[0] = m1 & 0x00008080u; pass[1] = m1 & 0x80800000u; pass[2] = m2 & 0x00008080u; pass[3] = m2 & 0x80800000u;
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint64_t m = __ballot(pass[k] != 0);
-      if (m) {
+    {
+      // one LDS atomic per wave and row pair: the four ballots are counted on the scalar unit
+      const uint64_t m0 = __ballot(pass[0] != 0), m1b = __ballot(pass[1] != 0), m2b = __ballot(pass[2] != 0),
+                     m3b = __ballot(pass[3] != 0);
+      const int n0 = __popcll(m0), n1 = __popcll(m1b), n2 = __popcll(m2b), n3 = __popcll(m3b);
+      if (n0 + n1 + n2 + n3) {
         int base = 0;
-        if (lane == 0) base = atomicAdd(&nq, __popcll(m));
-        base = __shfl(base, 0, 64);
-        if (pass[k]) queue[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(r * 64 + 4 * c + k);
+        if (lane == 0) base = atomicAdd(&nq, n0 + n1 + n2 + n3);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const uint64_t below = (1ull << lane) - 1ull;
+        const int id = r * 64 + 4 * c;
+        if (pass[0]) queue[base + __popcll(m0 & below)] = (uint16_t)id;
+        if (pass[1]) queue[base + n0 + __popcll(m1b & below)] = (uint16_t)(id + 1);
+        if (pass[2]) queue[base + n0 + n1 + __popcll(m2b & below)] = (uint16_t)(id + 2);
+        if (pass[3]) queue[base + n0 + n1 + n2 + __popcll(m3b & below)] = (uint16_t)(id + 3);
       }
     }
   }
@@ -348,8 +351,8 @@ __global__ __launch_bounds__(256) void k_fast(SvoGeom g, ImgSrc s, uint32_t* cor
       const uint32_t sp = fast_pair<0>(rw);
       if (sp) {
         sc16[r * 64 + pc] = (uint16_t)sp;
-        if (sp & 0xffu) { const int k = atomicAdd(&ncand, 1); if (k < FAST_CAND_CAP) cand[k] = (uint16_t)(r * 128 + 2 * pc); }
-        if (sp & 0xff00u) { const int k = atomicAdd(&ncand, 1); if (k < FAST_CAND_CAP) cand[k] = (uint16_t)(r * 128 + 2 * pc + 1); }
+        if (sp & 0xffu) { const int k = atomicAdd(&ncand, 1); if (k < cand_cap) cand[k] = (uint16_t)(r * 128 + 2 * pc); }
+        if (sp & 0xff00u) { const int k = atomicAdd(&ncand, 1); if (k < cand_cap) cand[k] = (uint16_t)(r * 128 + 2 * pc + 1); }
       }
     }
   }
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(256) void k_fast(SvoGeom g, ImgSrc s, uint32_t* cor
 
   // phase C: strict 3x3 NMS + border filter, over the corner candidates only
   const uint8_t* scb = reinterpret_cast<const uint8_t*>(sc);
-  const bool listed = ncand <= FAST_CAND_CAP;   // otherwise (dense texture) every score byte is visited
+  const bool listed = ncand <= cand_cap;   // otherwise (dense texture) every score byte is visited
   const int nc = listed ? ncand : SCR * 128;
   for (int i = tid; i < nc; i += 256) {
     const int id = listed ? cand[i] : i;
@@ -769,7 +772,7 @@ int svo_launch_orb(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR,
   {
     SvoTimer t(ctx, "k_fast");
     hipLaunchKernelGGL(k_fast, dim3(g.tile_base[SVO_NLEVELS], nimg), dim3(256), 0, st, g, s,
-                       ctx->d_corners, ctx->d_counters, ctx->d_hist);
+                       ctx->d_corners, ctx->d_counters, ctx->d_hist, ctx->opt_fast_cand_cap);
   }
   {
     SvoTimer t(ctx, "k_select");

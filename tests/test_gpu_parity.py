@@ -85,6 +85,24 @@ def test_orb_extract_bit_exact(svo_kitti, orc, src):
     assert np.array_equal(desc, rdesc)
 
 
+def test_orb_extract_candidate_list_overflow_path(pkg, orc):
+    """k_fast keeps the scored pixels of a tile in a capped LDS list and scans the whole score tile when a tile has
+    more: with the cap forced to 0 and to 7 every / almost every tile takes that path - same keypoints."""
+    img = util.urban_pair()[0]
+    rkp, rdesc = orc.orb_extract(img)
+    for cap in (0, 7, 2048):
+        s = pkg.Svo(util.KITTI_W, util.KITTI_H)
+        s.set_option("fast_cand_cap", cap)
+        kp, desc = s.orb_extract(img)
+        s.close()
+        same_kp(kp, rkp)
+        assert np.array_equal(desc, rdesc), cap
+    s = pkg.Svo(util.KITTI_W, util.KITTI_H)
+    with pytest.raises(pkg.SvoError):
+        s.set_option("fast_cand_cap", 4096)
+    s.close()
+
+
 def test_orb_extract_small_image_bit_exact(svo_small, orc):
     img = util.blocky_image(21, 640, 240)
     kp, desc = svo_small.orb_extract(img)

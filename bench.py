@@ -192,6 +192,37 @@ def elas_leg(pkg, W, H, device, d_L, d_R, pitch, B, iters=4):
     return out
 
 
+def msa_leg(pkg, W, H, device, d_L, d_R):
+    """MSA dense stereo (SURVEY 8 row f-1, the reference's live frame::MB): svo_msa_solve on one synthetic pair, host
+    buffers in and out (the two aggregation trees are built on host threads, so this row has no HBM-resident mode),
+    beside the CPU restatement of the same algorithm on one host core."""
+    ctx = pkg.Svo(W, H, device=device)
+    g2c = lambda g: np.ascontiguousarray(np.repeat(g[:, :, None], 3, 2))
+    L = g2c(d_L[0, :, :W].cpu().numpy()); R = g2c(d_R[0, :, :W].cpu().numpy())
+    ctx.msa_solve(L, R, 48, 1)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        G = ctx.msa_solve(L, R, 48, 1)
+    dt = (time.perf_counter() - t0) / 3
+    ctx.profile_enable(True); ctx.profile_reset(); ctx.msa_solve(L, R, 48, 1); ctx.profile_enable(False)
+    kern = {k: round(v[0], 3) for k, v in ctx.profile().items() if k.startswith("k_msa")}
+    ctx.close()
+    out = {"value": 1.0 / dt, "unit": "stereo pairs/s", "ms_per_pair_host_buffers": dt * 1e3, "max_disparity": 48,
+           "gpu_ms_per_pair": kern, "nonzero_fraction": float((G > 0).mean()),
+           "note": "d = 48, scale = 1 as frame::MB calls it; gray pair as B = G = R colour images"}
+    try:
+        from oracle import binding as ob
+        ob.build()
+        t0 = time.perf_counter()
+        F = ob.msa_solve(L, R, 48, 1)
+        out["cpu_baseline"] = {"value": 1.0 / (time.perf_counter() - t0), "unit": "stereo pairs/s", "cores": 1, "kind": "port",
+                               "sample": "one call of oracle/orc_msa_solve (restatement of MSA::solve) on the same pair"}
+        out["pixels_differing_from_port"] = int((F != G).sum())
+    except Exception as e:  # noqa: BLE001
+        out["cpu_baseline_error"] = str(e)
+    return out
+
+
 def cpu_baseline(Lh, Rh, cam, workload, budget_s=15.0):
     """The oracle (a single-threaded C port of the same path) timed on this box's host
     cores over a bounded sample of the same workload."""
@@ -425,6 +456,7 @@ def main():
                                               "steps": msteps, "sequence0_equals_single_chain": bool(same)}
         if world == 1 and not track and not args.no_elas_leg:
             out["elas"] = elas_leg(pkg, W, H, dev.index or 0, dL, dR, PITCH, min(B, 128))
+            out["msa"] = msa_leg(pkg, W, H, dev.index or 0, dL, dR)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -1006,20 +1006,6 @@ void add_corner_points(std::vector<SupportPt>& sp, int W, int H) {
   for (int i = 0; i < 6; ++i) sp.push_back(b[i]);
 }
 
-// wall-clock profile entry for the host stages (reported next to the HIP-event kernel entries)
-struct HostTimer {
-  svo_ctx* ctx; const char* name; std::chrono::steady_clock::time_point t0;
-  HostTimer(svo_ctx* c, const char* n) : ctx(c), name(n), t0(std::chrono::steady_clock::now()) {}
-  ~HostTimer() {
-    if (!ctx->profiling) return;
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    for (auto& e : ctx->prof)
-      if (e.name == name) { e.total_ms += ms; e.launches += 1; return; }
-    SvoProfileEntry e; e.name = name; e.total_ms = ms; e.launches = 1;
-    ctx->prof.push_back(e);
-  }
-};
-
 template <typename T>
 int dev_alloc(svo_ctx* ctx, ElasState* st, T** p, size_t count) {
   void* q = nullptr;

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -160,6 +161,20 @@ int svo_launch_unproject(svo_ctx* ctx, const float* uvz, int n, const svo_camera
 extern "C" void svo_elas_release(svo_ctx* ctx);
 int svo_upload_image(svo_ctx* ctx, const uint8_t* gray, int stride, int slot);
 // dense ELAS stereo on images already in HBM; the two maps stay in HBM (valid until the next call)
+// wall-clock profile entry for the host stages (reported next to the HIP-event kernel entries)
+struct HostTimer {
+  svo_ctx* ctx; const char* name; std::chrono::steady_clock::time_point t0;
+  HostTimer(svo_ctx* c, const char* n) : ctx(c), name(n), t0(std::chrono::steady_clock::now()) {}
+  ~HostTimer() {
+    if (!ctx->profiling) return;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (auto& e : ctx->prof)
+      if (e.name == name) { e.total_ms += ms; e.launches += 1; return; }
+    SvoProfileEntry e; e.name = name; e.total_ms = ms; e.launches = 1;
+    ctx->prof.push_back(e);
+  }
+};
+
 int svo_msa_run_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int pitch, int W, int H, int d, float* d_disp);
 int svo_elas_run_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int pitch, int W, int H,
                      const svo_elas_params* params, float** dD1, float** dD2, int* produced);

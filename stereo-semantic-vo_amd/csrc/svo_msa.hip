@@ -26,6 +26,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <string.h>
 #include <thread>
 #include <vector>
 
@@ -410,6 +411,18 @@ extern "C" int svo_msa_tree(const uint8_t* m_img3, const double* r_gra, const do
 
 // img3[side]: packed BGR images on the device (3 * m bytes per row); d_out: n * m bytes on the device.
 static int msa_solve_device(svo_ctx* ctx, DevBuf& buf, uint8_t* const img3[2], int n, int m, int d, int scale, uint8_t* d_out) {
+  auto t_last = std::chrono::steady_clock::now();
+  auto mark = [&](const char* name) {   // wall-clock profile entries of the host-visible stages
+    const auto now = std::chrono::steady_clock::now();
+    if (ctx->profiling) {
+      const double ms = std::chrono::duration<double, std::milli>(now - t_last).count();
+      bool found = false;
+      for (auto& e : ctx->prof)
+        if (e.name == name) { e.total_ms += ms; e.launches += 1; found = true; break; }
+      if (!found) { SvoProfileEntry e; e.name = name; e.total_ms = ms; e.launches = 1; ctx->prof.push_back(e); }
+    }
+    t_last = now;
+  };
   const int D = d + 1;
   const size_t N = (size_t)n * m, V = N * D;
   double* g = buf.get<double>(6 * N);                 // graL graR r_graL c_graL r_graR c_graR
@@ -430,6 +443,7 @@ static int msa_solve_device(svo_ctx* ctx, DevBuf& buf, uint8_t* const img3[2], i
     ctx->last_error = "svo_msa_solve: hipMalloc";
     return SVO_E_NOMEM;
   }
+  mark("host_msa_alloc");
   hipStream_t s = ctx->stream;
   const dim3 px((m + 255) / 256, n);
   const unsigned nbN = (unsigned)((N + 255) / 256), nbV = (unsigned)((V + 255) / 256);
@@ -455,6 +469,7 @@ static int msa_solve_device(svo_ctx* ctx, DevBuf& buf, uint8_t* const img3[2], i
   for (int side = 0; side < 2; ++side) SVO_HIP(ctx, hipMemcpyAsync(h_med[side].data(), med3[side], 3 * N, hipMemcpyDeviceToHost, s));
   SVO_HIP(ctx, hipMemcpyAsync(h_gra.data(), g + 2 * N, 4 * N * sizeof(double), hipMemcpyDeviceToHost, s));
   SVO_HIP(ctx, hipStreamSynchronize(s));
+  mark("host_msa_init_and_download");
 
   // 2. the two aggregation trees, one host thread each (the reference builds them one after the other)
   HostTree tree[2];
@@ -470,6 +485,7 @@ static int msa_solve_device(svo_ctx* ctx, DevBuf& buf, uint8_t* const img3[2], i
     grow(0);
     right.join();
   }
+  mark("host_msa_trees");
   for (int side = 0; side < 2; ++side)
     if (tree[side].rc) { ctx->last_error = "svo_msa_solve: tree construction failed"; return tree[side].rc; }
   for (int side = 0; side < 2; ++side) {
@@ -517,7 +533,9 @@ static int msa_solve_device(svo_ctx* ctx, DevBuf& buf, uint8_t* const img3[2], i
   }
   if ((rc = aggregate(0, cost[0], Exp[1], d_disp[0]))) return rc;   // refine
   hipLaunchKernelGGL(k_msa_scale, dim3(nbN), dim3(256), 0, s, d_disp[0], (int)N, scale, d_out);
-  SVO_HIP(ctx, hipStreamSynchronize(s));   // Exp[][] and the trees are read by copies until here
+  mark("host_msa_enqueue_aggregation");
+  SVO_HIP(ctx, hipStreamSynchronize(s));
+  mark("host_msa_wait_aggregation");   // Exp[][] and the trees are read by copies until here
   SVO_HIP(ctx, hipGetLastError());
   return SVO_OK;
 }
@@ -538,8 +556,18 @@ extern "C" int svo_msa_solve(svo_ctx* ctx, const uint8_t* bgrL, const uint8_t* b
   uint8_t* d_out = buf.get<uint8_t>(N);
   if (!img3[0] || !img3[1] || !d_out) { ctx->last_error = "svo_msa_solve: hipMalloc"; return SVO_E_NOMEM; }
   hipStream_t s = ctx->stream;
-  SVO_HIP(ctx, hipMemcpy2DAsync(img3[0], 3 * (size_t)m, bgrL, step, 3 * (size_t)m, n, hipMemcpyHostToDevice, s));
-  SVO_HIP(ctx, hipMemcpy2DAsync(img3[1], 3 * (size_t)m, bgrR, step, 3 * (size_t)m, n, hipMemcpyHostToDevice, s));
+  if (ctx->h_pinned && 6 * N <= ctx->pinned_bytes) {
+    // rows gathered into the pinned buffer, one linear copy per image (a 2-D copy from pageable memory costs ~10 ms)
+    const uint8_t* src[2] = {bgrL, bgrR};
+    for (int side = 0; side < 2; ++side) {
+      uint8_t* h = reinterpret_cast<uint8_t*>(ctx->h_pinned) + 3 * N * side;
+      for (int y = 0; y < n; ++y) memcpy(h + (size_t)y * 3 * m, src[side] + (size_t)y * step, 3 * (size_t)m);
+      SVO_HIP(ctx, hipMemcpyAsync(img3[side], h, 3 * N, hipMemcpyHostToDevice, s));
+    }
+  } else {
+    SVO_HIP(ctx, hipMemcpy2DAsync(img3[0], 3 * (size_t)m, bgrL, step, 3 * (size_t)m, n, hipMemcpyHostToDevice, s));
+    SVO_HIP(ctx, hipMemcpy2DAsync(img3[1], 3 * (size_t)m, bgrR, step, 3 * (size_t)m, n, hipMemcpyHostToDevice, s));
+  }
   const int rc = msa_solve_device(ctx, buf, img3, n, m, d, scale, d_out);
   if (rc) return rc;
   SVO_HIP(ctx, hipMemcpy(disparity, d_out, N, hipMemcpyDeviceToHost));

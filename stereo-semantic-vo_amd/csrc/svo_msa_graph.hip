@@ -16,6 +16,9 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -23,36 +26,42 @@
 
 namespace {
 
-struct DirEdge { int32_t from, to, w; };
-
-// Leftist heaps over edge indices, all in one node pool; node 0 is "empty".  Rank of an empty child counts as 0,
-// like a leaf's (the reference's convention, :1232-1234) - it decides which child ends up left, hence later merges.
+// The directed graph is implicit: pixel p owns five arc slots e = 5p + k for the arcs INTO p - k = 0 from the
+// super-root (weight 1e9), 1 from its left neighbour, 2 right, 3 up, 4 down (present or not) - which is also the
+// order in which the reference inserts them into p's heap (its horizontal loop visits the pair (p-1, p) before
+// (p, p+1), its vertical loop (p-m, p) before (p, p+m); MSA.cpp:152-192).  Heap node e + 1 carries arc e.
+//
+// Leftist heaps over the arcs, all in one node pool; node 0 is "empty".  Rank of an empty child counts as 0, like a
+// leaf's (the reference's convention, :1232-1234) - it decides which child ends up left, hence later merges.
 class EdgeHeaps {
  public:
-  explicit EdgeHeaps(size_t cap) : node_(cap + 1) { node_[0] = Node{0, 0, 0, 0, 0}; used_ = 0; }
-  int make(int edge, int key) { node_[++used_] = Node{0, 0, 0, edge, key}; return used_; }
+  struct Node { int left, right, rank, key; };
+  void reset(size_t arcs) { node_.resize(arcs + 1); node_[0] = Node{0, 0, 0, 0}; }   // nodes are init()-ed before use
+  void init(int h, int key) { node_[h] = Node{0, 0, 0, key}; }
   int key(int h) const { return node_[h].key; }
-  int edge(int h) const { return node_[h].edge; }
-  int meld(int a, int b) {
+  static int arc(int h) { return h - 1; }
+  // `spine` is scratch of the caller (the per-pixel construction runs on several threads)
+  int meld(int a, int b, std::vector<int>& spine) {
     if (!a || !b) return a + b;
-    spine_.clear();
+    spine.clear();
     // walk down the right spines, always continuing below the smaller key (ties: the first heap stays on top)
     for (;;) {
       if (!a || !b) { a += b; break; }
       if (node_[a].key > node_[b].key) std::swap(a, b);
-      spine_.push_back(a);
+      spine.push_back(a);
       a = node_[a].right;
     }
     int sub = a;
-    for (size_t i = spine_.size(); i-- > 0;) {
-      Node& t = node_[spine_[i]];
+    for (size_t i = spine.size(); i-- > 0;) {
+      Node& t = node_[spine[i]];
       t.right = sub;
       if (node_[t.left].rank < node_[t.right].rank) std::swap(t.left, t.right);
       t.rank = t.right ? node_[t.right].rank + 1 : 0;
-      sub = spine_[i];
+      sub = spine[i];
     }
     return sub;
   }
+  int meld(int a, int b) { return meld(a, b, spine_); }
   int drop_min(int h) { return meld(node_[h].left, node_[h].right); }
   void subtract(int h, int delta) {   // from every key of heap h
     if (!h) return;
@@ -66,15 +75,13 @@ class EdgeHeaps {
   }
 
  private:
-  struct Node { int left, right, rank, edge, key; };
   std::vector<Node> node_;
   std::vector<int> spine_, walk_;
-  int used_;
 };
 
 struct Sets {   // union-find with full path compression; unite(a, b) makes a's root the root
   std::vector<int> up;
-  explicit Sets(int n) : up(n + 1) { for (int i = 0; i <= n; ++i) up[i] = i; }
+  void reset(int n) { up.resize(n + 1); for (int i = 0; i <= n; ++i) up[i] = i; }
   int find(int x) {
     int r = x;
     while (up[r] != r) r = up[r];
@@ -89,7 +96,7 @@ struct Sets {   // union-find with full path compression; unite(a, b) makes a's 
 // :1299-1313) - the caller reads the top as up[find(x)].
 struct Contraction {
   std::vector<int> up, grp;
-  explicit Contraction(int n) : up(n + 1), grp(n + 1) { for (int i = 0; i <= n; ++i) { up[i] = i; grp[i] = i; } }
+  void reset(int n) { up.resize(n + 1); grp.resize(n + 1); for (int i = 0; i <= n; ++i) { up[i] = i; grp[i] = i; } }
   int find(int x) {
     path_.clear();
     const int x0 = x;
@@ -108,42 +115,54 @@ struct Link { int32_t to, w, next; };   // adjacency chains, newest first, as Tr
 
 class TreeBuilder {
  public:
-  TreeBuilder(int rows, int cols) : n_(rows), m_(cols), N_(rows * cols) {}
+  // one builder serves many images: every array below keeps its capacity between runs (fresh 100 MB allocations cost
+  // ~10 % of a run in page faults)
+  void reshape(int rows, int cols) { n_ = rows; m_ = cols; N_ = rows * cols; }
 
   // returns the root pixel, or < 0
-  int run(const uint8_t* img3, const double* gx, const double* gy, std::vector<int32_t>& seq, std::vector<int32_t>& child_ptr,
-          std::vector<int32_t>& child, std::vector<uint8_t>& child_w) {
+  int run(const uint8_t* img3, const double* gx, const double* gy, int32_t* seq, int32_t* child_ptr, int32_t* child,
+          uint8_t* child_w) {
     img3_ = img3;
     arborescence(gx, gy);
     if (roots_.empty()) return -1;
     label_regions();
     merge_regions();
     // breadth-first order from the first root; parent[] doubles as the visited mark
-    std::vector<int32_t> parent(N_, -1);
-    seq.clear(); seq.reserve(N_);
-    seq.push_back(roots_[0]);
-    for (size_t t = 0; t < seq.size(); ++t) {
+    std::vector<int32_t>& parent = parent_;
+    parent.assign(N_, -1);
+    int n_seq = 0;
+    seq[n_seq++] = roots_[0];
+    for (int t = 0; t < n_seq; ++t) {
       const int u = seq[t];
       for (int i = head_[u]; i >= 0; i = link_[i].next) {
         const int v = link_[i].to;
         if (v == parent[u]) continue;
-        seq.push_back(v);
+        if (n_seq == N_) return -2;   // not a tree
+        seq[n_seq++] = v;
         parent[v] = u;
       }
     }
-    if ((int)seq.size() != N_) return -2;
-    child_ptr.assign(N_ + 1, 0); child.clear(); child_w.clear();
-    child.reserve(N_); child_w.reserve(N_);
+    if (n_seq != N_) return -2;
+    int n_child = 0;
+    child_ptr[0] = 0;
     for (int u = 0; u < N_; ++u) {
       for (int i = head_[u]; i >= 0; i = link_[i].next)
-        if (link_[i].to != parent[u]) { child.push_back(link_[i].to); child_w.push_back((uint8_t)link_[i].w); }
-      child_ptr[u + 1] = (int32_t)child.size();
+        if (link_[i].to != parent[u]) { child[n_child] = link_[i].to; child_w[n_child] = (uint8_t)link_[i].w; ++n_child; }
+      child_ptr[u + 1] = n_child;
     }
     return roots_[0];
   }
 
  private:
-  int n_, m_, N_;
+  int n_ = 0, m_ = 0, N_ = 0;
+  EdgeHeaps heaps_;
+  Sets strong_, weak_, merged_;
+  Contraction con_;
+  std::vector<int> incoming_, chosen_from_, chosen_key_, chosen_edge_, entry_, todo_, size_, sum_;
+  std::vector<uint8_t> arc_w_, done_;
+  std::vector<int32_t> parent_;
+  struct Cand { int a, b, w; double key; };
+  std::vector<Cand> cand_;
   const uint8_t* img3_ = nullptr;
   std::vector<int32_t> head_;
   std::vector<Link> link_;
@@ -161,31 +180,58 @@ class TreeBuilder {
 
   void arborescence(const double* gx, const double* gy) {
     const int SR = N_;   // the super-root
-    std::vector<DirEdge> edge;
-    edge.reserve((size_t)N_ * 5);
-    EdgeHeaps heaps((size_t)N_ * 5 + 8);
-    std::vector<int> incoming(N_ + 1, 0);
-    auto arc = [&](int from, int to, int w) {
-      edge.push_back({from, to, w});
-      incoming[to] = heaps.meld(incoming[to], heaps.make((int)edge.size() - 1, w));
+    const int SR_W = 1000000000;
+    EdgeHeaps& heaps = heaps_;
+    heaps.reset((size_t)N_ * 5);
+    std::vector<int>& incoming = incoming_;
+    incoming.assign(N_ + 1, 0);
+    std::vector<uint8_t>& arc_w = arc_w_;   // weights of the neighbour arcs (slot 0 is SR_W)
+    arc_w.resize((size_t)N_ * 5);
+    auto arc_from = [&](int e) {
+      const int p = e / 5, k = e - 5 * p;
+      return k == 0 ? SR : k == 1 ? p - 1 : k == 2 ? p + 1 : k == 3 ? p - m_ : p + m_;
     };
-    for (int p = 0; p < N_; ++p) arc(SR, p, 1000000000);
-    auto neighbours = [&](int a, int b, const double* g) {
-      const int w = colour_gap(a, b);
-      const int steeper = (int)(fabs(g[a]) - fabs(g[b]));   // the reference truncates the difference to int
-      if (steeper == 0) { arc(b, a, w); arc(a, b, w); }
-      else if (steeper < 0) arc(a, b, w);                  // a is flatter: a -> b
-      else arc(b, a, w);
-    };
-    for (int i = 0; i < n_; ++i) for (int j = 0; j + 1 < m_; ++j) neighbours(i * m_ + j, i * m_ + j + 1, gx);
-    for (int j = 0; j < m_; ++j) for (int i = 0; i + 1 < n_; ++i) neighbours(i * m_ + j, (i + 1) * m_ + j, gy);
+    auto arc_weight = [&](int e) { return e % 5 == 0 ? SR_W : (int)arc_w[e]; };
+    {
+      // every pixel's heap of incoming arcs depends on that pixel alone: built in row bands on a few threads
+      auto band = [&](int row0, int row1) {
+        std::vector<int> spine;
+        for (int i = row0; i < row1; ++i)
+          for (int j = 0; j < m_; ++j) {
+            const int p = i * m_ + j;
+            int h = 5 * p + 1;
+            heaps.init(h, SR_W);
+            auto add = [&](int slot, int q) {
+              const int e = 5 * p + slot, w = colour_gap(p, q);
+              arc_w[e] = (uint8_t)w;
+              heaps.init(e + 1, w);
+              h = heaps.meld(h, e + 1, spine);
+            };
+            // an arc runs from the flatter pixel to the steeper one, both ways when the gradient magnitudes differ
+            // by less than 1 (the reference truncates the difference to int); a = left / upper pixel of the pair
+            if (j > 0 && (int)(fabs(gx[p - 1]) - fabs(gx[p])) <= 0) add(1, p - 1);
+            if (j + 1 < m_ && (int)(fabs(gx[p]) - fabs(gx[p + 1])) >= 0) add(2, p + 1);
+            if (i > 0 && (int)(fabs(gy[p - m_]) - fabs(gy[p])) <= 0) add(3, p - m_);
+            if (i + 1 < n_ && (int)(fabs(gy[p]) - fabs(gy[p + m_])) >= 0) add(4, p + m_);
+            incoming[p] = h;
+          }
+      };
+      const int nthr = std::max(1, std::min(4, n_ / 64));
+      std::vector<std::thread> pool;
+      for (int t = 1; t < nthr; ++t) pool.emplace_back(band, n_ * t / nthr, n_ * (t + 1) / nthr);
+      band(0, n_ / nthr);
+      for (auto& th : pool) th.join();
+    }
 
     // contraction phase
-    std::vector<int> chosen_from(2 * N_ + 2, -1), chosen_key(2 * N_ + 2, 0), chosen_edge(N_ + 1, -1), entry(2 * N_ + 2, -1);
-    std::vector<int> todo(N_ + 1);
+    std::vector<int>&chosen_from = chosen_from_, &chosen_key = chosen_key_, &chosen_edge = chosen_edge_, &entry = entry_, &todo = todo_;
+    chosen_from.assign(2 * N_ + 2, -1); chosen_key.assign(2 * N_ + 2, 0); chosen_edge.assign(N_ + 1, -1); entry.assign(2 * N_ + 2, -1);
+    todo.resize(N_ + 1);
     for (int i = 0; i <= N_; ++i) todo[i] = i;
-    Sets strong(N_), weak(N_);
-    Contraction con(2 * N_);
+    Sets &strong = strong_, &weak = weak_;
+    strong.reset(N_); weak.reset(N_);
+    Contraction& con = con_;
+    con.reset(2 * N_);
     int n_super = N_ + 1;
     while (!todo.empty()) {
       const int v = todo.back(); todo.pop_back();
@@ -193,14 +239,14 @@ class TreeBuilder {
       int u = -1, w = 0, pick = -1;
       bool found = false;
       while (incoming[v]) {
-        w = heaps.key(incoming[v]); pick = heaps.edge(incoming[v]);
+        w = heaps.key(incoming[v]); pick = EdgeHeaps::arc(incoming[v]);
         incoming[v] = heaps.drop_min(incoming[v]);
-        u = strong.find(edge[pick].from);
+        u = strong.find(arc_from(pick));
         if (u != v) { found = true; break; }
       }
       if (!found) continue;   // the super-root
       chosen_from[v] = u; chosen_key[v] = w; chosen_edge[v] = pick;
-      const int cv = con.find(edge[pick].to), top_v = con.up[cv];
+      const int cv = con.find(pick / 5), top_v = con.up[cv];
       entry[top_v] = pick;
       if (weak.find(u) != weak.find(v)) { weak.unite(v, u); continue; }
       // u already reaches v: the chosen edges close a cycle -> contract it into a new super-node
@@ -209,7 +255,7 @@ class TreeBuilder {
       auto settle = [&](int x) { if (chosen_key[x] > 0) { heaps.subtract(incoming[x], chosen_key[x]); chosen_key[x] = 0; } };
       settle(v);
       for (int ek = chosen_edge[u], k = strong.find(chosen_from[u]); k != v; ek = chosen_edge[k], k = strong.find(chosen_from[k])) {
-        const int ck = con.find(edge[ek].from), top_k = con.up[ck];
+        const int ck = con.find(arc_from(ek)), top_k = con.up[ck];
         con.up[top_k] = con.up[top_v];
         con.grp[top_k] = con.grp[top_v];
         strong.unite(v, k);
@@ -217,7 +263,7 @@ class TreeBuilder {
         incoming[v] = heaps.meld(incoming[v], incoming[k]);
       }
       settle(u);
-      const int cu = con.find(edge[pick].from), top_u = con.up[cu];
+      const int cu = con.find(arc_from(pick)), top_u = con.up[cu];
       con.up[top_u] = con.up[top_v];
       con.grp[top_u] = con.grp[top_v];
       strong.unite(v, u);
@@ -226,19 +272,20 @@ class TreeBuilder {
     }
     // expansion phase: newest super-nodes first, each keeps the entering edge that was chosen for it
     for (int i = 0; i < n_super; ++i) { con.find(i); chosen_from[i] = -1; }
-    std::vector<uint8_t> done(n_super, 0);
+    std::vector<uint8_t>& done = done_;
+    done.assign(n_super, 0);
     for (int i = n_super - 1; i >= 0; --i) {
       if (i == SR || done[i]) continue;
       done[i] = 1;
       const int k = entry[i];
       if (k < 0) continue;
-      int u = edge[k].to;
+      int u = k / 5;
       while (u != i) {
         done[u] = 1;
         u = con.grp[u];
         if (u == con.grp[u]) break;
       }
-      if (u == i) { chosen_from[edge[k].to] = edge[k].from; chosen_key[edge[k].to] = edge[k].w; }
+      if (u == i) { chosen_from[k / 5] = arc_from(k); chosen_key[k / 5] = arc_weight(k); }
     }
     head_.assign(N_ + 1, -1);
     link_.clear(); link_.reserve((size_t)N_ * 2 + 4);
@@ -253,7 +300,8 @@ class TreeBuilder {
   // region id and largest edge per tree of the forest, breadth-first from all roots (the reference's getSeq0)
   void label_regions() {
     region_.assign(N_, 0); region_max_.assign(roots_.size(), 0);
-    std::vector<int32_t> parent(N_, 0);
+    std::vector<int32_t>& parent = parent_;
+    parent.assign(N_, 0);
     order_.clear(); order_.reserve(N_);
     for (size_t i = 0; i < roots_.size(); ++i) { order_.push_back(roots_[i]); parent[roots_[i]] = -1; region_[roots_[i]] = (int)i; }
     for (size_t t = 0; t < order_.size(); ++t) {
@@ -270,14 +318,15 @@ class TreeBuilder {
 
   void merge_regions() {
     // pixel count and colour sums per region, kept at the region's root pixel
-    std::vector<int> size(N_, 0), sum((size_t)N_ * 3, 0);
+    std::vector<int>&size = size_, &sum = sum_;
+    size.assign(N_, 0); sum.assign((size_t)N_ * 3, 0);
     for (int u : order_) {
       const int rt = roots_[region_[u]];
       ++size[rt];
       for (int k = 0; k < 3; ++k) sum[rt * 3 + k] += img3_[u * 3 + k];
     }
-    struct Cand { int a, b, w; double key; };
-    std::vector<Cand> cand;
+    std::vector<Cand>& cand = cand_;
+    cand.clear();
     auto candidates = [&](int u, int v) {
       const int fu = region_[u], fv = region_[v];
       if (fu == fv) return;
@@ -294,7 +343,8 @@ class TreeBuilder {
     for (int j = 0; j < m_; ++j) for (int i = 0; i + 1 < n_; ++i) candidates(i * m_ + j, i * m_ + j + 1);
     std::sort(cand.begin(), cand.end(), [](const Cand& x, const Cand& y) { return x.key < y.key; });
 
-    Sets merged((int)roots_.size());
+    Sets& merged = merged_;
+    merged.reset((int)roots_.size());
     const size_t full = (size_t)(N_ - 1) * 2;
     for (size_t i = 0; i < cand.size() && link_.size() < full; ++i) {
       const int u = cand[i].a, v = cand[i].b, c = cand[i].w;
@@ -328,15 +378,22 @@ extern "C" int svo_msa_tree(const uint8_t* m_img3, const double* r_gra, const do
   if (!m_img3 || !r_gra || !c_gra || !seq || !child_ptr || !child || !child_w || !root || width < 2 || height < 2 ||
       (int64_t)width * height > (1 << 24))
     return SVO_E_INVALID;
-  TreeBuilder tb(height, width);
-  std::vector<int32_t> s, p, c;
-  std::vector<uint8_t> w;
-  const int rt = tb.run(m_img3, r_gra, c_gra, s, p, c, w);
+  // builders are kept (at most four) for their allocations; concurrent callers each get their own
+  static std::mutex pool_mutex;
+  static std::vector<std::unique_ptr<TreeBuilder>> pool;
+  std::unique_ptr<TreeBuilder> tb;
+  {
+    std::lock_guard<std::mutex> lock(pool_mutex);
+    if (!pool.empty()) { tb = std::move(pool.back()); pool.pop_back(); }
+  }
+  if (!tb) tb.reset(new TreeBuilder());
+  tb->reshape(height, width);
+  const int rt = tb->run(m_img3, r_gra, c_gra, seq, child_ptr, child, child_w);
+  {
+    std::lock_guard<std::mutex> lock(pool_mutex);
+    if (pool.size() < 4) pool.push_back(std::move(tb));
+  }
   if (rt < 0) return SVO_E_INVALID;
-  std::copy(s.begin(), s.end(), seq);
-  std::copy(p.begin(), p.end(), child_ptr);
-  std::copy(c.begin(), c.end(), child);
-  std::copy(w.begin(), w.end(), child_w);
   *root = rt;
   return SVO_OK;
 }

@@ -257,7 +257,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-track-leg", action="store_true")
     ap.add_argument("--no-elas-leg", action="store_true")
-    ap.add_argument("--depth-source", type=int, default=0, choices=[0, 1],
+    ap.add_argument("--depth-source", type=int, default=0, choices=[0, 1, 2],
                     help="track workload: 0 sparse epipolar stereo (north star), 1 dense ELAS map (BASELINE configs[4] without YOLO)")
     ap.add_argument("--sequences", type=int, default=1,
                     help="track workload: S concurrent sequences per GPU (svo_track_multi_step_dev), one frame of each per step")

@@ -251,6 +251,7 @@ extern "C" void svo_destroy(svo_ctx* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   svo_elas_release(ctx);
+  svo_msa_release(ctx);
   if (ctx->d_dense) hipFree(ctx->d_dense);
   void* ptrs[] = {ctx->d_xofs, ctx->d_xalpha, ctx->d_yofs, ctx->d_ybeta, ctx->d_stage, ctx->d_pyr,
                   ctx->d_corners, ctx->d_counters, ctx->d_hist, ctx->d_sel, ctx->d_selcnt,

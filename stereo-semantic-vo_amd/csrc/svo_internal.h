@@ -95,6 +95,7 @@ struct svo_ctx {
   int n_seq = 0;
   void* elas = nullptr;     // ElasState (svo_elas.hip), allocated on first svo_elas_process
   void* elas_batch = nullptr;   // ElasBatch: per-pair states of svo_elas_batch_dev
+  void* msa_arenas = nullptr;   // MsaArenas: device buffers of svo_msa_solve and of the tracker's MSA mode
   float* d_dense = nullptr;     // dense maps of svo_track_batch_dev with depth_source 1: 2 x dense_cap x W*H
   int dense_cap = 0;
   svo_camera cam{};
@@ -159,6 +160,7 @@ int svo_launch_unproject(svo_ctx* ctx, const float* uvz, int n, const svo_camera
                          const float* Rwc, const float* twc, float* xyz);
 
 extern "C" void svo_elas_release(svo_ctx* ctx);
+void svo_msa_release(svo_ctx* ctx);
 int svo_upload_image(svo_ctx* ctx, const uint8_t* gray, int stride, int slot);
 // dense ELAS stereo on images already in HBM; the two maps stay in HBM (valid until the next call)
 // wall-clock profile entry for the host stages (reported next to the HIP-event kernel entries)
@@ -176,6 +178,8 @@ struct HostTimer {
 };
 
 int svo_msa_run_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int pitch, int W, int H, int d, float* d_disp);
+int svo_msa_run_many_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int pitch, size_t frame_stride, int W, int H, int d,
+                         int B, float* d_disp);
 int svo_elas_run_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int pitch, int W, int H,
                      const svo_elas_params* params, float** dD1, float** dD2, int* produced);
 

@@ -27,6 +27,8 @@
 
 #include <algorithm>
 #include <string.h>
+#include <atomic>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -140,16 +142,37 @@ __global__ void k_msa_lrcheck(const uint8_t* d1, const uint8_t* d2, int n, int m
   cost[idx] = stable ? (float)abs(d - dd) : 0.0f;
 }
 
-struct DevBuf {   // scoped device allocations of the host-buffer entry points
-  std::vector<void*> p;
-  ~DevBuf() { for (void* q : p) hipFree(q); }
+struct DevBuf {   // device allocations of one solve; reset() hands the same buffers out again in the same order
+  struct Slot { void* p; size_t bytes; };
+  std::vector<Slot> slots;
+  size_t cursor = 0;
+  ~DevBuf() { for (Slot& q : slots) hipFree(q.p); }
+  void reset() { cursor = 0; }
   template <typename T> T* get(size_t count) {
-    void* q = nullptr;
-    if (hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return nullptr;
-    p.push_back(q);
-    return reinterpret_cast<T*>(q);
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    if (cursor == slots.size()) slots.push_back(Slot{nullptr, 0});
+    Slot& q = slots[cursor++];
+    if (q.bytes < bytes) {
+      if (q.p) hipFree(q.p);
+      q.p = nullptr; q.bytes = 0;
+      if (hipMalloc(&q.p, bytes) != hipSuccess) { q.p = nullptr; return nullptr; }
+      q.bytes = bytes;
+    }
+    return reinterpret_cast<T*>(q.p);
   }
 };
+
+// the buffers of svo_msa_solve / the tracker's MSA mode live as long as the ctx (index 0: the ctx stream; 1..: the
+// streams of svo_msa_run_many_dev) - a solve allocates ~0.5 GB at KITTI size and hipFree synchronises the device
+struct MsaArenas { std::vector<DevBuf*> a; std::mutex m; };
+DevBuf& msa_arena(svo_ctx* ctx, int idx) {
+  if (!ctx->msa_arenas) ctx->msa_arenas = new MsaArenas();
+  MsaArenas* A = static_cast<MsaArenas*>(ctx->msa_arenas);
+  std::lock_guard<std::mutex> lock(A->m);
+  while ((int)A->a.size() <= idx) A->a.push_back(new DevBuf());
+  A->a[idx]->reset();
+  return *A->a[idx];
+}
 
 }  // namespace
 
@@ -410,7 +433,8 @@ extern "C" int svo_msa_tree(const uint8_t* m_img3, const double* r_gra, const do
                             int32_t* child_ptr, int32_t* child, uint8_t* child_c, int32_t* root);
 
 // img3[side]: packed BGR images on the device (3 * m bytes per row); d_out: n * m bytes on the device.
-static int msa_solve_device(svo_ctx* ctx, DevBuf& buf, uint8_t* const img3[2], int n, int m, int d, int scale, uint8_t* d_out) {
+static int msa_solve_device(svo_ctx* ctx, hipStream_t s, DevBuf& buf, uint8_t* const img3[2], int n, int m, int d, int scale,
+                            uint8_t* d_out) {
   auto t_last = std::chrono::steady_clock::now();
   auto mark = [&](const char* name) {   // wall-clock profile entries of the host-visible stages
     const auto now = std::chrono::steady_clock::now();
@@ -444,7 +468,6 @@ static int msa_solve_device(svo_ctx* ctx, DevBuf& buf, uint8_t* const img3[2], i
     return SVO_E_NOMEM;
   }
   mark("host_msa_alloc");
-  hipStream_t s = ctx->stream;
   const dim3 px((m + 255) / 256, n);
   const unsigned nbN = (unsigned)((N + 255) / 256), nbV = (unsigned)((V + 255) / 256);
 
@@ -551,7 +574,7 @@ extern "C" int svo_msa_solve(svo_ctx* ctx, const uint8_t* bgrL, const uint8_t* b
   }
   SVO_HIP(ctx, hipSetDevice(ctx->device));
   const size_t N = (size_t)n * m;
-  DevBuf buf;
+  DevBuf& buf = msa_arena(ctx, 0);
   uint8_t* img3[2] = {buf.get<uint8_t>(3 * N), buf.get<uint8_t>(3 * N)};
   uint8_t* d_out = buf.get<uint8_t>(N);
   if (!img3[0] || !img3[1] || !d_out) { ctx->last_error = "svo_msa_solve: hipMalloc"; return SVO_E_NOMEM; }
@@ -568,7 +591,7 @@ extern "C" int svo_msa_solve(svo_ctx* ctx, const uint8_t* bgrL, const uint8_t* b
     SVO_HIP(ctx, hipMemcpy2DAsync(img3[0], 3 * (size_t)m, bgrL, step, 3 * (size_t)m, n, hipMemcpyHostToDevice, s));
     SVO_HIP(ctx, hipMemcpy2DAsync(img3[1], 3 * (size_t)m, bgrR, step, 3 * (size_t)m, n, hipMemcpyHostToDevice, s));
   }
-  const int rc = msa_solve_device(ctx, buf, img3, n, m, d, scale, d_out);
+  const int rc = msa_solve_device(ctx, s, buf, img3, n, m, d, scale, d_out);
   if (rc) return rc;
   SVO_HIP(ctx, hipMemcpy(disparity, d_out, N, hipMemcpyDeviceToHost));
   return SVO_OK;
@@ -590,19 +613,71 @@ __global__ void k_msa_to_float(const uint8_t* d, int n, float* out) {
 
 // frame::MB (src/frame.cc:82-91) for the tracker's dense-depth mode: gray images already on the device (a grayscale
 // file read as colour has B = G = R), disparity as CV_32F like `disp_img.convertTo(disp_32f, CV_32F, 1)`.
-int svo_msa_run_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int pitch, int W, int H, int d, float* d_disp) {
+static int msa_run_on_stream(svo_ctx* ctx, hipStream_t st, int arena, const uint8_t* dL, const uint8_t* dR, int pitch, int W,
+                             int H, int d, float* d_disp) {
   if (H < 5 || W < 5 || d < 0 || d > 255) return SVO_E_INVALID;
   const size_t N = (size_t)W * H;
-  DevBuf buf;
+  DevBuf& buf = msa_arena(ctx, arena);
   uint8_t* img3[2] = {buf.get<uint8_t>(3 * N), buf.get<uint8_t>(3 * N)};
   uint8_t* d_out = buf.get<uint8_t>(N);
   if (!img3[0] || !img3[1] || !d_out) { ctx->last_error = "svo_msa_run_dev: hipMalloc"; return SVO_E_NOMEM; }
   const dim3 px((W + 255) / 256, H);
-  hipLaunchKernelGGL(k_msa_gray_to_bgr, px, dim3(256), 0, ctx->stream, dL, pitch, W, H, img3[0]);
-  hipLaunchKernelGGL(k_msa_gray_to_bgr, px, dim3(256), 0, ctx->stream, dR, pitch, W, H, img3[1]);
-  const int rc = msa_solve_device(ctx, buf, img3, H, W, d, 1, d_out);
+  hipLaunchKernelGGL(k_msa_gray_to_bgr, px, dim3(256), 0, st, dL, pitch, W, H, img3[0]);
+  hipLaunchKernelGGL(k_msa_gray_to_bgr, px, dim3(256), 0, st, dR, pitch, W, H, img3[1]);
+  const int rc = msa_solve_device(ctx, st, buf, img3, H, W, d, 1, d_out);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_msa_to_float, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_out, (int)N, d_disp);
-  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `buf` is released on return
+  hipLaunchKernelGGL(k_msa_to_float, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_out, (int)N, d_disp);
+  SVO_HIP(ctx, hipStreamSynchronize(st));   // the arena is handed out again by the next solve
   return SVO_OK;
+}
+
+int svo_msa_run_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int pitch, int W, int H, int d, float* d_disp) {
+  return msa_run_on_stream(ctx, ctx->stream, 0, dL, dR, pitch, W, H, d, d_disp);
+}
+
+// B frames (frame b at dL + b * frame_stride bytes, map b at d_disp + b * W * H floats).  The frames are independent
+// and most of a solve is the two host tree builds, so up to eight frames are in flight at once, each on its own
+// stream and host thread (which starts a second thread for its right tree); the ctx stream is idle meanwhile.
+int svo_msa_run_many_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int pitch, size_t frame_stride, int W, int H, int d,
+                         int B, float* d_disp) {
+  const size_t N = (size_t)W * H;
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));   // whatever produced the frames
+  const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
+  const char* env = getenv("SVO_MSA_INFLIGHT");
+  const int cap = env ? atoi(env) : 8;
+  const int T = ctx->profiling ? 1 : std::max(1, std::min(std::min(B, cap), (int)(hw / 2)));
+  if (T == 1) {
+    for (int b = 0; b < B; ++b) {
+      const int rc = svo_msa_run_dev(ctx, dL + b * frame_stride, dR + b * frame_stride, pitch, W, H, d, d_disp + b * N);
+      if (rc) return rc;
+    }
+    return SVO_OK;
+  }
+  std::vector<hipStream_t> streams(T, nullptr);
+  for (int t = 0; t < T; ++t) SVO_HIP(ctx, hipStreamCreateWithFlags(&streams[t], hipStreamNonBlocking));
+  std::vector<int> rcs(T, SVO_OK);
+  std::atomic<int> next(0);
+  auto worker = [&](int t) {
+    if (hipSetDevice(ctx->device) != hipSuccess) { rcs[t] = SVO_E_HIP; return; }
+    for (int b = next.fetch_add(1); b < B; b = next.fetch_add(1)) {
+      const int rc = msa_run_on_stream(ctx, streams[t], 1 + t, dL + b * frame_stride, dR + b * frame_stride, pitch, W, H, d, d_disp + b * N);
+      if (rc) { rcs[t] = rc; return; }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < T; ++t) pool.emplace_back(worker, t);
+  worker(0);
+  for (auto& th : pool) th.join();
+  for (int t = 0; t < T; ++t) hipStreamDestroy(streams[t]);
+  for (int t = 0; t < T; ++t)
+    if (rcs[t]) return rcs[t];
+  return SVO_OK;
+}
+
+void svo_msa_release(svo_ctx* ctx) {
+  if (!ctx || !ctx->msa_arenas) return;
+  MsaArenas* A = static_cast<MsaArenas*>(ctx->msa_arenas);
+  for (DevBuf* b : A->a) delete b;
+  delete A;
+  ctx->msa_arenas = nullptr;
 }

@@ -778,14 +778,13 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
                        dD1, ctx->g.W, ctx->cam.bf, ctx->d_uR, ctx->d_depth, ctx->max_kp, n, d_prod);
     SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `prod` is on this stack frame
   } else if (ctx->opt_depth_source == 2) {
-    // MSA maps frame by frame (each solve already fills the GPU and has its host stage between the kernels)
+    // MSA maps, up to eight frames in flight (most of a solve is the host tree builds)
     const size_t n = (size_t)ctx->g.W * ctx->g.H;
     if ((rc = dense_reserve(ctx, B))) return rc;
     if ((rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, B, B))) return rc;   // left images only
-    for (int b = 0; b < B; ++b)
-      if ((rc = svo_msa_run_dev(ctx, d_grayL + (size_t)b * ctx->g.H * stride, d_grayR + (size_t)b * ctx->g.H * stride, stride,
-                                ctx->g.W, ctx->g.H, 48, ctx->d_dense + n * (size_t)b)))
-        return rc;
+    if ((rc = svo_msa_run_many_dev(ctx, d_grayL, d_grayR, stride, (size_t)ctx->g.H * stride, ctx->g.W, ctx->g.H, 48, B,
+                                   ctx->d_dense)))
+      return rc;
     hipLaunchKernelGGL(k_tk_dense_depth, dim3((ctx->max_kp + 255) / 256, B), dim3(256), 0, ctx->stream, ctx->d_kp, ctx->d_nkp,
                        ctx->d_dense, ctx->g.W, ctx->cam.bf, ctx->d_uR, ctx->d_depth, ctx->max_kp, n, (const int32_t*)nullptr);
   } else {

@@ -64,9 +64,10 @@ __global__ __launch_bounds__(256) void k_pyr_level(SvoGeom g, ImgSrc s, int l, u
   const int4 so = *reinterpret_cast<const int4*>(xofs + g.xtab_off[l] + dx4);
   const int4 sa = *reinterpret_cast<const int4*>(xalpha + g.xtab_off[l] + dx4);
   int syv[4], bbv[4];
+  const int dy0u = __builtin_amdgcn_readfirstlane(dy0);   // a wave is one row of the (64, 4) block: scalar table loads
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int dy = min(dy0 + r, dh - 1);
+    const int dy = min(dy0u + r, dh - 1);
     syv[r] = yofs[g.ytab_off[l] + dy];
     bbv[r] = ybeta[g.ytab_off[l] + dy];
   }
@@ -93,6 +94,9 @@ __global__ __launch_bounds__(256) void k_pyr_level(SvoGeom g, ImgSrc s, int l, u
   for (int r = 0; r < 4; ++r) {
     if (dy0 + r >= dh) break;
     const int b0 = (int)(int16_t)(bbv[r] & 0xffff), b1 = bbv[r] >> 16;
+    // (b * (S >> 4)) >> 16 as the high half of a 24 x 24-bit product: (b << 12) * (S & ~15) >> 32 (0 <= b <= 2048, S < 2^19)
+    const uint32_t B0 = (uint32_t)b0 << 12, B1 = (uint32_t)b1 << 12;
+    auto vterm = [](uint32_t Bs, uint32_t S) { return (uint32_t)(((uint64_t)(Bs & 0xffffffu) * ((S & ~15u) & 0xffffffu)) >> 32); };
     uint32_t out = 0;
     if (wide) {
       const uint32_t lo0 = (uint32_t)w0[r], hi0 = (uint32_t)(w0[r] >> 32);
@@ -102,10 +106,10 @@ __global__ __launch_bounds__(256) void k_pyr_level(SvoGeom g, ImgSrc s, int l, u
         const v2u16 p0 = __builtin_bit_cast(v2u16, __builtin_amdgcn_perm(hi0, lo0, sel[k]));
         const v2u16 p1 = __builtin_bit_cast(v2u16, __builtin_amdgcn_perm(hi1, lo1, sel[k]));
         const v2u16 al2 = __builtin_bit_cast(v2u16, (uint32_t)al[k]);
-        const int S0 = (int)__builtin_amdgcn_udot2(p0, al2, 0u, false);
-        const int S1 = (int)__builtin_amdgcn_udot2(p1, al2, 0u, false);
+        const uint32_t S0 = __builtin_amdgcn_udot2(p0, al2, 0u, false);
+        const uint32_t S1 = __builtin_amdgcn_udot2(p1, al2, 0u, false);
         // weights are non-negative and sum to 2048 in both directions: the result cannot leave 0..255
-        const int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+        const uint32_t v = (vterm(B0, S0) + vterm(B1, S1) + 2) >> 2;
         out |= (uint32_t)v << (8 * k);
       }
     } else {

@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(SvoGeom g, StereoSrc s, co
 __global__ __launch_bounds__(256) void k_stereo_median(int max_kp, float* uR, float* depth,
                                                        const int32_t* sad) {
   __shared__ int ssad[1024];
+  __shared__ __attribute__((aligned(16))) int skey[1024];
   __shared__ int nd, smed;
   const int tid = threadIdx.x, pair = blockIdx.x;
   const size_t base = (size_t)pair * max_kp;
@@ -238,13 +239,25 @@ __global__ __launch_bounds__(256) void k_stereo_median(int max_kp, float* uR, fl
   __syncthreads();
   const int n = nd;
   if (n == 0) return;
+  // rank of each accepted SAD among the accepted ones (ties by index).  Rejected entries (-1) are mapped to INT_MAX so
+  // that one unsigned-free comparison serves; the array is read four entries per LDS instruction, several in flight.
+  for (int i = tid; i < 1024; i += 256) {
+    const int v = i < max_kp ? ssad[i] : -1;
+    skey[i] = v < 0 ? 0x7fffffff : v;
+  }
+  __syncthreads();
+  const int4* skey4 = reinterpret_cast<const int4*>(skey);
+  const int n4 = (max_kp + 3) / 4;
   for (int i = tid; i < max_kp; i += 256) {
     const int v = ssad[i];
     if (v < 0) continue;
     int rank = 0;
-    for (int j = 0; j < max_kp; ++j) {
-      const int u = ssad[j];
-      rank += (u >= 0) && (u < v || (u == v && j < i));
+#pragma unroll 4
+    for (int j4 = 0; j4 < n4; ++j4) {
+      const int4 u = skey4[j4];
+      const int j = 4 * j4;
+      rank += (u.x < v || (u.x == v && j < i)) + (u.y < v || (u.y == v && j + 1 < i)) + (u.z < v || (u.z == v && j + 2 < i)) +
+              (u.w < v || (u.w == v && j + 3 < i));
     }
     if (rank == n / 2) smed = v;
   }

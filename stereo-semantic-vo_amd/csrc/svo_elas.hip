@@ -75,6 +75,20 @@ struct ElasState {
 // Descriptor: 3x3 Sobel responses du, dv (8-bit, offset 128, saturated) and the 16-byte descriptor.
 // ------------------------------------------------------------------------------------------------
 #define DT_X 32
+// global -> LDS staging with a thread's loads in flight together: written as a plain loop the compiler waits for every
+// load before the LDS store (one memory round trip per iteration); DEPTH loads are issued back to back instead
+template <int DEPTH, typename T>
+__device__ __forceinline__ void stage_lds(T* dst, const T* src, int n, size_t stride, int tid) {
+  for (int i0 = tid; i0 < n; i0 += 256 * DEPTH) {
+    T v[DEPTH];
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) v[k] = src[(size_t)min(i0 + 256 * k, n - 1) * stride];
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k)
+      if (i0 + 256 * k < n) dst[i0 + 256 * k] = v[k];
+  }
+}
+
 #define DT_Y 8
 __device__ __forceinline__ void d_elas_desc(int side, const uint8_t* img0, const uint8_t* img1, int pitch, int W, int H,
                                             int half, uint4* desc0, uint4* desc1) {
@@ -83,10 +97,21 @@ __device__ __forceinline__ void d_elas_desc(int side, const uint8_t* img0, const
   const uint8_t* img = side ? img1 : img0;
   uint4* desc = side ? desc1 : desc0;
   const int x0 = blockIdx.x * DT_X, y0 = blockIdx.y * DT_Y, tid = threadIdx.x;
-  for (int i = tid; i < (DT_Y + 6) * (DT_X + 6); i += 256) {
-    const int r = i / (DT_X + 6), c = i - r * (DT_X + 6);
-    const int gy = min(max(y0 - 3 + r, 0), H - 1), gx = min(max(x0 - 3 + c, 0), W - 1);
-    im[r][c] = img[(size_t)gy * pitch + gx];
+  {
+    constexpr int NPX = (DT_Y + 6) * (DT_X + 6), NSLOT = (NPX + 255) / 256;
+    uint8_t pv[NSLOT];
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+      const int i = min(tid + 256 * k, NPX - 1);
+      const int r = i / (DT_X + 6), c = i - r * (DT_X + 6);
+      const int gy = min(max(y0 - 3 + r, 0), H - 1), gx = min(max(x0 - 3 + c, 0), W - 1);
+      pv[k] = img[(size_t)gy * pitch + gx];
+    }
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+      const int i = tid + 256 * k;
+      if (i < NPX) im[i / (DT_X + 6)][i % (DT_X + 6)] = pv[k];
+    }
   }
   __syncthreads();
   for (int i = tid; i < (DT_Y + 4) * (DT_X + 4); i += 256) {
@@ -241,7 +266,15 @@ __device__ __forceinline__ void d_elas_match(bool right, const uint4* desc1, con
   const int u_first = sub ? 2 * (int)(blockIdx.x * 256) : (int)(blockIdx.x * 256);
   const int u_last = min(sub ? u_first + 510 : u_first + 255, W - 1);
   const int w0 = max(right ? u_first : u_first - 255, 0), w1 = min(right ? u_last + 255 : u_last, W - 1);
-  for (int i = threadIdx.x; i <= w1 - w0; i += 256) win[i] = Io[line + w0 + i];
+  {
+    // all three loads of a thread in flight together (a load inside the loop was waited for at once)
+    uint4 wv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) wv[k] = Io[line + w0 + min((int)threadIdx.x + 256 * k, w1 - w0)];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if ((int)threadIdx.x + 256 * k <= w1 - w0) win[threadIdx.x + 256 * k] = wv[k];
+  }
   __syncthreads();
   if (x >= Wd) return;
   const int addr = y * Wd + x;
@@ -349,7 +382,7 @@ __device__ __forceinline__ void d_cc_rows(const float* D, int W, float thr, int3
   __shared__ int cs[256];
   const int v = blockIdx.x, tid = threadIdx.x;
   const float* row = D + (size_t)v * W;
-  for (int i = tid; i < W; i += 256) val[i] = row[i];
+  stage_lds<8>(val, row, W, 1, tid);
   __syncthreads();
   const int C = (W + 255) / 256, b = tid * C, e = min(W, b + C);
   // brk(i): pixel i starts a run (invalid pixels are runs of their own)
@@ -432,12 +465,19 @@ __device__ __forceinline__ void lds_union(int32_t* lab, int a, int b) {
   } while (!done);
 }
 __device__ __forceinline__ void d_cc_strip(const float* D, int W, int H, float thr, int32_t* L, int32_t* rlen, int32_t* size) {
-  extern __shared__ unsigned char ccs_smem[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char ccs_smem[];
   float* val = reinterpret_cast<float*>(ccs_smem);                           // [rows][W], later the counters
   int32_t* lab = reinterpret_cast<int32_t*>(ccs_smem) + (size_t)CCS_ROWS * W;   // [rows][W]
   __shared__ int carry[CCS_ROWS][32];
   const int tid = threadIdx.x, v0 = blockIdx.x * CCS_ROWS, rows = min(CCS_ROWS, H - v0), n = rows * W;
-  for (int i = tid; i < n; i += 256) val[i] = D[(size_t)v0 * W + i];
+  // a strip is 8 * W floats: its byte offset is a multiple of 16, so it moves as float4 (then the tail)
+  if ((reinterpret_cast<uintptr_t>(D) & 15) == 0) {
+    const int n4 = n / 4;
+    stage_lds<5>(reinterpret_cast<float4*>(val), reinterpret_cast<const float4*>(D + (size_t)v0 * W), n4, 1, tid);
+    if (tid < n - 4 * n4) val[4 * n4 + tid] = D[(size_t)v0 * W + 4 * n4 + tid];
+  } else {
+    stage_lds<8>(val, D + (size_t)v0 * W, n, 1, tid);
+  }
   __syncthreads();
   // run starts: 32 threads per row, each a chunk; a run start is a break = first pixel, an invalid pixel, or
   // a jump of more than thr against the left neighbour
@@ -514,7 +554,7 @@ __device__ __forceinline__ void d_elas_gap(float* D, int n, int estride, int lst
   __shared__ int cl[256], cn[256];
   float* line = D + (size_t)blockIdx.x * lstride;
   const int tid = threadIdx.x;
-  for (int i = tid; i < n; i += 256) val[i] = line[(size_t)i * estride];
+  stage_lds<8>(val, const_cast<const float*>(line), n, (size_t)estride, tid);
   __syncthreads();
   const int C = (n + 255) / 256, b = tid * C, e = min(n, b + C);
   int l = -1, x = n;

@@ -9,7 +9,7 @@ set -u
 TAG=${1:-r01}; shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out; mkdir -p $OUT
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-track-leg $*"
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-profile --no-track-leg $*"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_*
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py $ARGS > /tmp/prof_stats.log 2>&1

@@ -207,7 +207,24 @@ def msa_leg(pkg, W, H, device, d_L, d_R):
     ctx.profile_enable(True); ctx.profile_reset(); ctx.msa_solve(L, R, 48, 1); ctx.profile_enable(False)
     kern = {k: round(v[0], 3) for k, v in ctx.profile().items() if k.startswith("k_msa")}
     ctx.close()
+    # the reference's live configuration end to end: ORB + MSA depth + tracking, 16 frames per call (the frames' trees are
+    # built side by side and their level sweeps share launches)
+    import torch
+    nb = min(16, d_L.shape[0])
+    cam = pkg.Camera(**pkg.KITTI_00_02)
+    trk = pkg.Svo(W, H, max_batch=nb, device=device)
+    trk.set_option("depth_source", 2)
+    res = torch.zeros((nb, pkg.TRACK_DTYPE.itemsize), dtype=torch.uint8, device=d_L.device)
+    torch.cuda.synchronize()
+    fps = 0.0
+    for _ in range(2):
+        trk.track_reset(cam)
+        t0 = time.perf_counter()
+        trk.track_batch_dev(d_L.data_ptr(), d_R.data_ptr(), d_L.stride(1), nb, res.data_ptr()); trk.sync()
+        fps = nb / (time.perf_counter() - t0)
+    trk.close()
     out = {"value": 1.0 / dt, "unit": "stereo pairs/s", "ms_per_pair_host_buffers": dt * 1e3, "max_disparity": 48,
+           "tracker_frames_per_s_msa_depth_16_per_call": fps,
            "gpu_ms_per_pair": kern, "nonzero_fraction": float((G > 0).mean()),
            "note": "d = 48, scale = 1 as frame::MB calls it; gray pair as B = G = R colour images"}
     try:

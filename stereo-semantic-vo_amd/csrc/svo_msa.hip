@@ -26,6 +26,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <stdio.h>
 #include <string.h>
 #include <atomic>
 #include <mutex>
@@ -125,6 +126,40 @@ __global__ void k_msa_dp_down(const int32_t* nodes, int cnt, int D, const int32_
   const double w = Exp[parent_c[v]];
   A[(size_t)v * D + d] = (float)(w * (double)A[(size_t)u * D + d] + (1 - w * w) * (double)up[(size_t)v * D + d]);
 }
+// The same two sweeps for several frames at once (blockIdx.y = frame): the level sweep of one frame is a chain of
+// ~2000 tiny dependent launches, so a batch shares them - level l of every frame in one launch.
+struct MsaTreeTab {   // one tree on the device
+  const int32_t *nodes, *level_ptr, *child_ptr, *child, *parent;
+  const uint8_t *child_c, *parent_c;
+  int32_t levels;
+};
+__global__ void k_msa_dp_up_many(const MsaTreeTab* tabs, int l, int D, const double* Exp, float* up_slab, size_t V) {
+  const MsaTreeTab t = tabs[blockIdx.y];
+  if (l >= t.levels) return;
+  const int beg = t.level_ptr[l], cnt = t.level_ptr[l + 1] - beg;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= cnt * D) return;
+  float* up = up_slab + (size_t)blockIdx.y * V;
+  const int u = t.nodes[beg + idx / D], d = idx % D;
+  float acc = up[(size_t)u * D + d];
+  for (int e = t.child_ptr[u]; e < t.child_ptr[u + 1]; ++e)
+    acc = (float)((double)acc + Exp[t.child_c[e]] * (double)up[(size_t)t.child[e] * D + d]);
+  up[(size_t)u * D + d] = acc;
+}
+__global__ void k_msa_dp_down_many(const MsaTreeTab* tabs, int l, int D, const double* Exp, const float* up_slab, float* A_slab,
+                                   size_t V) {
+  const MsaTreeTab t = tabs[blockIdx.y];
+  if (l >= t.levels) return;
+  const int beg = t.level_ptr[l], cnt = t.level_ptr[l + 1] - beg;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= cnt * D) return;
+  const float* up = up_slab + (size_t)blockIdx.y * V;
+  float* A = A_slab + (size_t)blockIdx.y * V;
+  const int v = t.nodes[beg + idx / D], d = idx % D, u = t.parent[v];
+  if (u < 0) { A[(size_t)v * D + d] = up[(size_t)v * D + d]; return; }
+  const double w = Exp[t.parent_c[v]];
+  A[(size_t)v * D + d] = (float)(w * (double)A[(size_t)u * D + d] + (1 - w * w) * (double)up[(size_t)v * D + d]);
+}
 __global__ void k_msa_argmin(const float* costA, int N, int D, uint8_t* disp) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
@@ -164,7 +199,8 @@ struct DevBuf {   // device allocations of one solve; reset() hands the same buf
 
 // the buffers of svo_msa_solve / the tracker's MSA mode live as long as the ctx (index 0: the ctx stream; 1..: the
 // streams of svo_msa_run_many_dev) - a solve allocates ~0.5 GB at KITTI size and hipFree synchronises the device
-struct MsaArenas { std::vector<DevBuf*> a; std::mutex m; };
+struct MsaHostStore;   // host-side buffers of the batched solve (kept for the same reason: page faults)
+struct MsaArenas { std::vector<DevBuf*> a; std::mutex m; MsaHostStore* host = nullptr; };
 DevBuf& msa_arena(svo_ctx* ctx, int idx) {
   if (!ctx->msa_arenas) ctx->msa_arenas = new MsaArenas();
   MsaArenas* A = static_cast<MsaArenas*>(ctx->msa_arenas);
@@ -400,13 +436,14 @@ __global__ void k_msa_scale(const uint8_t* d, int n, int scale, uint8_t* out) {
 }
 
 struct HostTree {                       // what svo_msa_tree returns, plus what the level-by-level sweep needs
-  std::vector<int32_t> seq, child_ptr, child, parent, nodes, level_ptr;
+  std::vector<int32_t> seq, child_ptr, child, parent, nodes, level_ptr, depth_, fill_;
   std::vector<uint8_t> child_c, parent_c;
   int32_t root = -1;
   int rc = SVO_OK;
   void levels(int N) {
     parent.assign(N, -1); parent_c.assign(N, 0);
-    std::vector<int32_t> depth(N, 0);
+    std::vector<int32_t>& depth = depth_;
+    depth.assign(N, 0);
     int max_depth = 0;
     for (int k = 0; k < N; ++k) {
       const int u = seq[k];
@@ -419,13 +456,18 @@ struct HostTree {                       // what svo_msa_tree returns, plus what 
     level_ptr.assign(max_depth + 2, 0);
     for (int v = 0; v < N; ++v) ++level_ptr[depth[v] + 1];
     for (int l = 0; l <= max_depth; ++l) level_ptr[l + 1] += level_ptr[l];
-    std::vector<int32_t> fill(level_ptr.begin(), level_ptr.end() - 1);
+    fill_.assign(level_ptr.begin(), level_ptr.end() - 1);
     nodes.resize(N);
-    for (int k = 0; k < N; ++k) nodes[fill[depth[seq[k]]]++] = seq[k];
+    for (int k = 0; k < N; ++k) nodes[fill_[depth[seq[k]]]++] = seq[k];
   }
 };
 
 struct DevTree { int32_t *nodes, *child_ptr, *child, *parent; uint8_t *child_c, *parent_c; };
+struct MsaHostStore {
+  std::vector<HostTree> tree;
+  std::vector<std::vector<uint8_t>> med;
+  std::vector<std::vector<double>> gra;
+};
 
 }  // namespace
 
@@ -635,42 +677,177 @@ int svo_msa_run_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int pitc
   return msa_run_on_stream(ctx, ctx->stream, 0, dL, dR, pitch, W, H, d, d_disp);
 }
 
-// B frames (frame b at dL + b * frame_stride bytes, map b at d_disp + b * W * H floats).  The frames are independent
-// and most of a solve is the two host tree builds, so up to eight frames are in flight at once, each on its own
-// stream and host thread (which starts a second thread for its right tree); the ctx stream is idle meanwhile.
+// MSA::solve for C frames together (gray frames on the device, float maps out): init per frame, all 2C trees on host
+// threads, then every stage of the aggregation once for the whole chunk - the level sweeps as one launch per level for
+// all frames, the per-pixel stages over the C maps stacked into one tall image.
+static int msa_many_device(svo_ctx* ctx, hipStream_t s, const uint8_t* dL, const uint8_t* dR, int pitch, size_t frame_stride,
+                           int m, int n, int d, int C, float* d_disp_out) {
+  const bool dbg = getenv("SVO_MSA_DEBUG") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    const auto now = std::chrono::steady_clock::now();
+    if (dbg) fprintf(stderr, "[msa x%d] %-28s %8.2f ms\n", C, what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
+  const int D = d + 1;
+  const size_t N = (size_t)n * m, V = N * D;
+  DevBuf& buf = msa_arena(ctx, 1);
+  uint8_t* img3[2] = {buf.get<uint8_t>(3 * N), buf.get<uint8_t>(3 * N)};
+  uint8_t* med3[2] = {buf.get<uint8_t>(3 * N), buf.get<uint8_t>(3 * N)};
+  uint8_t* gray = buf.get<uint8_t>(N);
+  double* g = buf.get<double>(6 * N);
+  float* cost[2] = {buf.get<float>(V * C), buf.get<float>(V * C)};   // [side][frame][pixel][disparity]
+  float* d_up = buf.get<float>(V * C); float* d_A = buf.get<float>(V * C);
+  uint8_t* d_disp[2] = {buf.get<uint8_t>(N * C), buf.get<uint8_t>(N * C)};
+  uint8_t* d_raw = buf.get<uint8_t>(N * C); uint8_t* d_mask = buf.get<uint8_t>(N * C);
+  double* d_Exp = buf.get<double>(512);
+  int32_t* d_int = buf.get<int32_t>((size_t)2 * C * (5 * N + 4));     // nodes, level_ptr, child_ptr, child, parent per tree
+  uint8_t* d_byte = buf.get<uint8_t>((size_t)2 * C * 2 * N);          // child_c, parent_c per tree
+  MsaTreeTab* d_tabs = buf.get<MsaTreeTab>((size_t)2 * C);
+  if (!img3[0] || !img3[1] || !med3[0] || !med3[1] || !gray || !g || !cost[0] || !cost[1] || !d_up || !d_A || !d_disp[0] ||
+      !d_disp[1] || !d_raw || !d_mask || !d_Exp || !d_int || !d_byte || !d_tabs) {
+    ctx->last_error = "svo_msa (batched): hipMalloc";
+    return SVO_E_NOMEM;
+  }
+  mark("device buffers");
+  const dim3 px((m + 255) / 256, n);
+  const unsigned nbN = (unsigned)((N + 255) / 256), nbV = (unsigned)((V + 255) / 256);
+  // 1. MSA::init per frame; the median images and their gradients go to the host for the tree builders
+  MsaArenas* arenas = static_cast<MsaArenas*>(ctx->msa_arenas);
+  if (!arenas->host) arenas->host = new MsaHostStore();
+  MsaHostStore& hs = *arenas->host;
+  if ((int)hs.tree.size() < 2 * C) { hs.tree.resize(2 * C); hs.med.resize(2 * C); }
+  if ((int)hs.gra.size() < C) hs.gra.resize(C);
+  for (int k = 0; k < 2 * C; ++k) hs.med[k].resize(3 * N);
+  for (int b = 0; b < C; ++b) hs.gra[b].resize(4 * N);
+  std::vector<std::vector<uint8_t>>& h_med = hs.med;
+  std::vector<std::vector<double>>& h_gra = hs.gra;
+  mark("host buffers");
+  for (int b = 0; b < C; ++b) {
+    hipLaunchKernelGGL(k_msa_gray_to_bgr, px, dim3(256), 0, s, dL + b * frame_stride, pitch, m, n, img3[0]);
+    hipLaunchKernelGGL(k_msa_gray_to_bgr, px, dim3(256), 0, s, dR + b * frame_stride, pitch, m, n, img3[1]);
+    for (int side = 0; side < 2; ++side) {
+      hipLaunchKernelGGL(k_msa_gray, dim3(nbN), dim3(256), 0, s, img3[side], (int)N, gray);
+      hipLaunchKernelGGL(k_msa_gradient, px, dim3(256), 0, s, gray, n, m, 1, 127.5, g + side * N);
+    }
+    hipLaunchKernelGGL(k_msa_cost, dim3(nbV), dim3(256), 0, s, img3[0], img3[1], g, g + N, n, m, D, cost[0] + (size_t)b * V);
+    hipLaunchKernelGGL(k_msa_cost_right, dim3(nbV), dim3(256), 0, s, cost[0] + (size_t)b * V, n, m, D, cost[1] + (size_t)b * V);
+    for (int side = 0; side < 2; ++side) {
+      hipLaunchKernelGGL(k_ctmf<1>, dim3((3 * m + 255) / 256, n), dim3(256), 0, s, img3[side], med3[side], m, n, 3 * m, 3 * m, 3);
+      hipLaunchKernelGGL(k_msa_gray, dim3(nbN), dim3(256), 0, s, med3[side], (int)N, gray);
+      hipLaunchKernelGGL(k_msa_gradient, px, dim3(256), 0, s, gray, n, m, 1, 0.0, g + (2 + 2 * side) * N);
+      hipLaunchKernelGGL(k_msa_gradient, px, dim3(256), 0, s, gray, n, m, 0, 0.0, g + (3 + 2 * side) * N);
+      SVO_HIP(ctx, hipMemcpyAsync(h_med[2 * b + side].data(), med3[side], 3 * N, hipMemcpyDeviceToHost, s));
+    }
+    SVO_HIP(ctx, hipMemcpyAsync(h_gra[b].data(), g + 2 * N, 4 * N * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  SVO_HIP(ctx, hipStreamSynchronize(s));
+  mark("init + download");
+  // 2. the 2C trees, on as many host threads as are sensible (tree 2b: left image of frame b, 2b + 1: right)
+  std::vector<HostTree>& tree = hs.tree;
+  {
+    std::atomic<int> next(0);
+    auto work = [&]() {
+      for (int k = next.fetch_add(1); k < 2 * C; k = next.fetch_add(1)) {
+        HostTree& t = tree[k];
+        const int b = k >> 1, side = k & 1;
+        t.seq.resize(N); t.child_ptr.resize(N + 1); t.child.resize(N); t.child_c.resize(N);
+        t.rc = svo_msa_tree(h_med[k].data(), h_gra[b].data() + 2 * side * N, h_gra[b].data() + (2 * side + 1) * N, m, n, t.seq.data(),
+                            t.child_ptr.data(), t.child.data(), t.child_c.data(), &t.root);
+        if (t.rc == SVO_OK) t.levels((int)N);
+      }
+    };
+    const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
+    const int T = std::max(1, std::min(std::min(2 * C, 32), (int)(hw / 2)));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; ++t) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+  }
+  mark("trees");
+  for (int k = 0; k < 2 * C; ++k)
+    if (tree[k].rc) { ctx->last_error = "svo_msa (batched): tree construction failed"; return tree[k].rc; }
+  // 3. trees to the device: tabs[side * C + b]
+  std::vector<MsaTreeTab> h_tabs(2 * C);
+  int Lmax[2] = {0, 0};
+  for (int k = 0; k < 2 * C; ++k) {
+    const HostTree& t = tree[k];
+    const int b = k >> 1, side = k & 1;
+    int32_t* ip = d_int + (size_t)k * (5 * N + 4);
+    uint8_t* bp = d_byte + (size_t)k * 2 * N;
+    const int levels = (int)t.level_ptr.size() - 1;
+    SVO_HIP(ctx, hipMemcpyAsync(ip, t.nodes.data(), N * 4, hipMemcpyHostToDevice, s));
+    SVO_HIP(ctx, hipMemcpyAsync(ip + N, t.level_ptr.data(), (size_t)(levels + 1) * 4, hipMemcpyHostToDevice, s));
+    SVO_HIP(ctx, hipMemcpyAsync(ip + 2 * N + 2, t.child_ptr.data(), (N + 1) * 4, hipMemcpyHostToDevice, s));
+    SVO_HIP(ctx, hipMemcpyAsync(ip + 3 * N + 3, t.child.data(), (N - 1) * 4, hipMemcpyHostToDevice, s));
+    SVO_HIP(ctx, hipMemcpyAsync(ip + 4 * N + 3, t.parent.data(), N * 4, hipMemcpyHostToDevice, s));
+    SVO_HIP(ctx, hipMemcpyAsync(bp, t.child_c.data(), N - 1, hipMemcpyHostToDevice, s));
+    SVO_HIP(ctx, hipMemcpyAsync(bp + N, t.parent_c.data(), N, hipMemcpyHostToDevice, s));
+    h_tabs[side * C + b] = MsaTreeTab{ip, ip + N, ip + 2 * N + 2, ip + 3 * N + 3, ip + 4 * N + 3, bp, bp + N, levels};
+    Lmax[side] = std::max(Lmax[side], levels);
+  }
+  SVO_HIP(ctx, hipMemcpyAsync(d_tabs, h_tabs.data(), sizeof(MsaTreeTab) * 2 * C, hipMemcpyHostToDevice, s));
+  double Exp[512];
+  for (int i = 0; i <= 255; ++i) { Exp[i] = exp(-i * 1.0 / 0.1 / 255); Exp[256 + i] = exp(-i * 1.0 / (0.1 / 2) / 255); }
+  SVO_HIP(ctx, hipMemcpyAsync(d_Exp, Exp, sizeof Exp, hipMemcpyHostToDevice, s));
+  mark("tree upload (enqueue)");
+  // widest level over the frames, per level and side: the grid of that level's launch
+  std::vector<int> width[2];
+  for (int side = 0; side < 2; ++side) {
+    width[side].assign(Lmax[side], 0);
+    for (int b = 0; b < C; ++b) {
+      const HostTree& t = tree[2 * b + side];
+      for (int l = 0; l + 1 < (int)t.level_ptr.size(); ++l) width[side][l] = std::max(width[side][l], t.level_ptr[l + 1] - t.level_ptr[l]);
+    }
+  }
+  // 4. TreeDp + WTA for the right images, the left images, L/R check, TreeDp + WTA again with the sharper weights
+  auto aggregate = [&](int side, const float* c, const double* E, uint8_t* out_disp) -> int {
+    const MsaTreeTab* tabs = d_tabs + side * C;
+    SVO_HIP(ctx, hipMemcpyAsync(d_up, c, V * C * sizeof(float), hipMemcpyDeviceToDevice, s));
+    for (int l = Lmax[side] - 1; l >= 0; --l)
+      hipLaunchKernelGGL(k_msa_dp_up_many, dim3((unsigned)(((size_t)width[side][l] * D + 255) / 256), C), dim3(256), 0, s, tabs, l, D, E,
+                         d_up, V);
+    for (int l = 0; l < Lmax[side]; ++l)
+      hipLaunchKernelGGL(k_msa_dp_down_many, dim3((unsigned)(((size_t)width[side][l] * D + 255) / 256), C), dim3(256), 0, s, tabs, l, D,
+                         E, d_up, d_A, V);
+    hipLaunchKernelGGL(k_msa_argmin, dim3((unsigned)((N * C + 255) / 256)), dim3(256), 0, s, d_A, (int)(N * C), D, d_raw);
+    for (int b = 0; b < C; ++b)
+      hipLaunchKernelGGL(k_ctmf<2>, dim3((m + 255) / 256, n), dim3(256), 0, s, d_raw + (size_t)b * N, out_disp + (size_t)b * N, m, n, m, m, 1);
+    return SVO_OK;
+  };
+  int rc;
+  if ((rc = aggregate(1, cost[1], d_Exp, d_disp[1]))) return rc;
+  if ((rc = aggregate(0, cost[0], d_Exp, d_disp[0]))) return rc;
+  hipLaunchKernelGGL(k_msa_lrcheck, dim3((unsigned)((V * C + 255) / 256)), dim3(256), 0, s, d_disp[0], d_disp[1], n * C, m, D, cost[0],
+                     d_mask);   // the C maps as one tall image: the check only looks along a row
+  if ((rc = aggregate(0, cost[0], d_Exp + 256, d_disp[0]))) return rc;
+  hipLaunchKernelGGL(k_msa_to_float, dim3((unsigned)((N * C + 255) / 256)), dim3(256), 0, s, d_disp[0], (int)(N * C), d_disp_out);
+  mark("aggregation (enqueue)");
+  SVO_HIP(ctx, hipStreamSynchronize(s));
+  mark("aggregation (wait)");   // host trees and tables are read by copies until here
+  SVO_HIP(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
+// B frames (frame b at dL + b * frame_stride bytes, map b at d_disp + b * W * H floats), solved in chunks that share
+// their launches and build their trees side by side.
 int svo_msa_run_many_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int pitch, size_t frame_stride, int W, int H, int d,
                          int B, float* d_disp) {
   const size_t N = (size_t)W * H;
-  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));   // whatever produced the frames
-  const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
-  const char* env = getenv("SVO_MSA_INFLIGHT");
-  const int cap = env ? atoi(env) : 8;
-  const int T = ctx->profiling ? 1 : std::max(1, std::min(std::min(B, cap), (int)(hw / 2)));
-  if (T == 1) {
+  if (B <= 1 || ctx->profiling || (int64_t)N * (d + 1) * 16 > ((int64_t)1 << 31) || getenv("SVO_MSA_FRAME_BY_FRAME")) {
     for (int b = 0; b < B; ++b) {
       const int rc = svo_msa_run_dev(ctx, dL + b * frame_stride, dR + b * frame_stride, pitch, W, H, d, d_disp + b * N);
       if (rc) return rc;
     }
     return SVO_OK;
   }
-  std::vector<hipStream_t> streams(T, nullptr);
-  for (int t = 0; t < T; ++t) SVO_HIP(ctx, hipStreamCreateWithFlags(&streams[t], hipStreamNonBlocking));
-  std::vector<int> rcs(T, SVO_OK);
-  std::atomic<int> next(0);
-  auto worker = [&](int t) {
-    if (hipSetDevice(ctx->device) != hipSuccess) { rcs[t] = SVO_E_HIP; return; }
-    for (int b = next.fetch_add(1); b < B; b = next.fetch_add(1)) {
-      const int rc = msa_run_on_stream(ctx, streams[t], 1 + t, dL + b * frame_stride, dR + b * frame_stride, pitch, W, H, d, d_disp + b * N);
-      if (rc) { rcs[t] = rc; return; }
-    }
-  };
-  std::vector<std::thread> pool;
-  for (int t = 1; t < T; ++t) pool.emplace_back(worker, t);
-  worker(0);
-  for (auto& th : pool) th.join();
-  for (int t = 0; t < T; ++t) hipStreamDestroy(streams[t]);
-  for (int t = 0; t < T; ++t)
-    if (rcs[t]) return rcs[t];
+  // chunks of up to 16 frames: ~0.4 GB of HBM per frame at KITTI size (four cost volumes)
+  for (int b0 = 0; b0 < B; b0 += 16) {
+    const int C = std::min(16, B - b0);
+    const int rc = msa_many_device(ctx, ctx->stream, dL + b0 * frame_stride, dR + b0 * frame_stride, pitch, frame_stride, W, H, d, C,
+                                   d_disp + b0 * N);
+    if (rc) return rc;
+  }
   return SVO_OK;
 }
 
@@ -678,6 +855,7 @@ void svo_msa_release(svo_ctx* ctx) {
   if (!ctx || !ctx->msa_arenas) return;
   MsaArenas* A = static_cast<MsaArenas*>(ctx->msa_arenas);
   for (DevBuf* b : A->a) delete b;
+  delete A->host;
   delete A;
   ctx->msa_arenas = nullptr;
 }

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -25,6 +26,8 @@
 #include "svo_internal.h"
 
 namespace {
+
+std::atomic<int> g_active_builders{0};
 
 // The directed graph is implicit: pixel p owns five arc slots e = 5p + k for the arcs INTO p - k = 0 from the
 // super-root (weight 1e9), 1 from its left neighbour, 2 right, 3 up, 4 down (present or not) - which is also the
@@ -216,7 +219,8 @@ class TreeBuilder {
             incoming[p] = h;
           }
       };
-      const int nthr = std::max(1, std::min(4, n_ / 64));
+      // (alone: four threads; with many builders running side by side the cores are taken already)
+      const int nthr = std::max(1, std::min(g_active_builders.load() > 4 ? 1 : 4, n_ / 64));
       std::vector<std::thread> pool;
       for (int t = 1; t < nthr; ++t) pool.emplace_back(band, n_ * t / nthr, n_ * (t + 1) / nthr);
       band(0, n_ / nthr);
@@ -378,7 +382,7 @@ extern "C" int svo_msa_tree(const uint8_t* m_img3, const double* r_gra, const do
   if (!m_img3 || !r_gra || !c_gra || !seq || !child_ptr || !child || !child_w || !root || width < 2 || height < 2 ||
       (int64_t)width * height > (1 << 24))
     return SVO_E_INVALID;
-  // builders are kept (at most four) for their allocations; concurrent callers each get their own
+  // builders are kept (at most 32) for their allocations; concurrent callers each get their own
   static std::mutex pool_mutex;
   static std::vector<std::unique_ptr<TreeBuilder>> pool;
   std::unique_ptr<TreeBuilder> tb;
@@ -388,10 +392,12 @@ extern "C" int svo_msa_tree(const uint8_t* m_img3, const double* r_gra, const do
   }
   if (!tb) tb.reset(new TreeBuilder());
   tb->reshape(height, width);
+  g_active_builders.fetch_add(1);
   const int rt = tb->run(m_img3, r_gra, c_gra, seq, child_ptr, child, child_w);
+  g_active_builders.fetch_sub(1);
   {
     std::lock_guard<std::mutex> lock(pool_mutex);
-    if (pool.size() < 4) pool.push_back(std::move(tb));
+    if (pool.size() < 32) pool.push_back(std::move(tb));
   }
   if (rt < 0) return SVO_E_INVALID;
   *root = rt;

@@ -128,6 +128,23 @@ def test_stereo_real_pair_bit_exact(svo_kitti, orc, pkg):
     assert (g["depth"] > 0).sum() > 150
 
 
+@pytest.mark.parametrize("W,H", [(1242, 375), (1226, 370), (752, 480), (643, 241)])
+def test_stereo_other_image_sizes_bit_exact(orc, pkg, W, H):
+    """The other KITTI odometry sizes, a EuRoC-sized frame and an odd size: every width / height residue the tile and
+    row-staging code (clamped border dwords, partial tiles, level widths) has to handle, stride != width included."""
+    L, R = util.shifted_pair(W * 7 + H, W, H, disparity=9)
+    cam = pkg.Camera(**pkg.KITTI_00_02)
+    s = pkg.Svo(W, H, max_batch=1)
+    g = s.stereo_frame(L, R, cam)
+    s.close()
+    r = orc.stereo_frame(L, R, cam.bf, cam.fx)
+    same_kp(g["kpL"], r["kpL"]); same_kp(g["kpR"], r["kpR"])
+    assert np.array_equal(g["dL"], r["dL"]) and np.array_equal(g["dR"], r["dR"])
+    assert np.array_equal(g["uR"].view(np.uint32), r["uR"].view(np.uint32))
+    assert np.array_equal(g["depth"].view(np.uint32), r["depth"].view(np.uint32))
+    assert len(g["kpL"]) > 300 and (g["depth"] > 0).sum() > 100
+
+
 def test_stereo_constant_disparity(svo_small, orc, pkg):
     L, R = util.shifted_pair(5, 640, 240, disparity=12)
     cam = pkg.Camera(**pkg.KITTI_00_02)

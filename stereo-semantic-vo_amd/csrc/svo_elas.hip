@@ -296,9 +296,15 @@ __device__ __forceinline__ void d_elas_match(bool right, const uint4* desc1, con
       // the cell's disparity candidates: a 256-bit set, visited in ascending order like the reference's list
       const uint32_t* cell = reinterpret_cast<const uint32_t*>(right ? grid1 : grid0) + (size_t)(gy * gw + gx) * 8;
       int min_val = 10000, min_d = -1;
-#pragma unroll 1
+      // the whole 256-bit set at once (two 16-byte loads in flight) instead of one dependent dword load per word
+      uint32_t cw[8];
+      {
+        const uint4 c0 = *reinterpret_cast<const uint4*>(cell), c1 = *reinterpret_cast<const uint4*>(cell + 4);
+        cw[0] = c0.x; cw[1] = c0.y; cw[2] = c0.z; cw[3] = c0.w; cw[4] = c1.x; cw[5] = c1.y; cw[6] = c1.z; cw[7] = c1.w;
+      }
+#pragma unroll
       for (int q = 0; q < 8; ++q) {
-        uint32_t m = cell[q];
+        uint32_t m = cw[q];
         while (m) {
           const int d = 32 * q + __ffs(m) - 1;
           m &= m - 1;

@@ -672,20 +672,19 @@ __global__ __launch_bounds__(64) void k_describe(SvoGeom g, ImgSrc s, const SvoS
   const uint8_t* img_p = level_ptr(g, s, img, l, &pitch);
   const uint8_t* org = img_p + (size_t)(y - 18) * pitch + (x - 19);
   {
-    // all six loads of a lane in flight together (one memory round trip, not six)
-    constexpr int NSLOT = (PW * PROW + 63) / 64;
+    // a lane keeps one dword column (6 row groups x 10 columns = 60 lanes) and walks down the rows: its seven loads
+    // are in flight together (one memory round trip) and need no per-load index arithmetic
+    constexpr int NROWG = 64 / PROW, NSLOT = (PW + NROWG - 1) / NROWG;
+    const int rg = lane / PROW, d = lane - rg * PROW;
+    const uint8_t* col = org + 4 * d;
     uint32_t v[NSLOT];
 #pragma unroll
-    for (int k = 0; k < NSLOT; ++k) {
-      const int i = min(lane + 64 * k, PW * PROW - 1);
-      const int r = i / PROW, d = i - r * PROW;
-      v[k] = *reinterpret_cast<const u32_unaligned*>(org + (size_t)r * pitch + 4 * d);
-    }
+    for (int k = 0; k < NSLOT; ++k) v[k] = *reinterpret_cast<const u32_unaligned*>(col + (size_t)min(rg + NROWG * k, PW - 1) * pitch);
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k)
-      if (lane + 64 * k < PW * PROW) patch[lane + 64 * k] = v[k];
+      if (rg < NROWG && rg + NROWG * k < PW) patch[(rg + NROWG * k) * PROW + d] = v[k];
   }
-  for (int i = lane; i < 31 * 20; i += 64) hbT[i] = 0;   // rows 37..39 of each column stay zero
+  if (lane < 62) hbT[(lane >> 1) * 20 + 18 + (lane & 1)] = 0;   // rows 37..39 of each column stay zero (36 is written below)
   __syncthreads();
   // intensity centroid: lane = disc row v+15; m10 = sum u*I (via I-128, the row weights sum to 0),
   // m01 = v * sum I

@@ -166,88 +166,112 @@ __global__ __launch_bounds__(512) void k_tk_begin(TrackState* st, const svo_kp* 
 // Also decides, in parallel, which rows the serial pass must visit: a row can only be accepted
 // if its best distance over the unclaimed columns is < max_dist; the minimum over ALL columns
 // bounds that from below, so rows failing it never claim a column and are dropped.
+// TKD_ROWS map-point rows per workgroup: 4 (one per wave) for a single sequence, where the chain's latency counts and
+// every row should get its own wave at once; 16 when many sequences are advanced together and the staging of the
+// keypoint descriptors is worth sharing
+template <int TKD_ROWS>
 __global__ __launch_bounds__(256) void k_tk_dist(TrackState* st, const uint32_t* desc, int pass, int kstride) {
-  __shared__ uint32_t td[TRK_MAXKP * 8];
+  // descriptors of the frame's keypoints, TRANSPOSED: word k of keypoint j at td[k * TRK_MAXKP + j], so that the 64 lanes
+  // of a wave (64 consecutive keypoints) read 64 consecutive LDS words
+  __shared__ uint32_t td[8 * TRK_MAXKP];
   st += blockIdx.y; desc += (size_t)blockIdx.y * kstride * 8;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int M = st->skip_match ? 0 : (pass == 1 ? st->m1 : st->m2);
-  const int row = blockIdx.x * 4 + wv;
-  if ((int)blockIdx.x * 4 >= M) {
-    if (lane == 0 && row < TRK_CAP) st->active[row] = 0;
+  const int row0 = blockIdx.x * TKD_ROWS;
+  if (row0 >= M) {
+    if (tid < TKD_ROWS && row0 + tid < TRK_CAP) st->active[row0 + tid] = 0;
     return;
   }
   const int nkp = st->nkp, id = st->frame_num;
   const int max_dist = pass == 1 ? 15 : 30;
   const TrackPool& P = st->pool[st->cur];
-  for (int i = tid; i < nkp * 8; i += 256) td[i] = desc[i];
+  {
+    // 16-byte loads, all four of a thread in flight together
+    const uint4* d4 = reinterpret_cast<const uint4*>(desc);
+    uint4 v[TRK_MAXKP * 2 / 256];
+#pragma unroll
+    for (int k = 0; k < TRK_MAXKP * 2 / 256; ++k) v[k] = d4[min(tid + 256 * k, max(2 * nkp - 1, 0))];
+#pragma unroll
+    for (int k = 0; k < TRK_MAXKP * 2 / 256; ++k) {
+      const int i = tid + 256 * k;   // 16-byte piece i: keypoint i / 2, words 4 * (i & 1) ..
+      if (i < 2 * nkp) {
+        const int j = i >> 1, w = 4 * (i & 1);
+        td[(w + 0) * TRK_MAXKP + j] = v[k].x; td[(w + 1) * TRK_MAXKP + j] = v[k].y;
+        td[(w + 2) * TRK_MAXKP + j] = v[k].z; td[(w + 3) * TRK_MAXKP + j] = v[k].w;
+      }
+    }
+  }
   __syncthreads();
-  bool valid = row < M;
-  int m = row;
-  if (valid) {
-    if (pass == 1) {
-      m = st->last_mp[row];
-      valid = m >= 0 && !P.bad[m];
-    } else {
-      valid = P.in_local[m] && !P.bad[m] && P.obs_frame[m] != id;
+  for (int rr = 0; rr < TKD_ROWS / 4; ++rr) {
+    const int row = row0 + wv * (TKD_ROWS / 4) + rr;
+    if (row >= TRK_CAP) break;
+    bool valid = row < M;
+    int m = row;
+    if (valid) {
+      if (pass == 1) {
+        m = st->last_mp[row];
+        valid = m >= 0 && !P.bad[m];
+      } else {
+        valid = P.in_local[m] && !P.bad[m] && P.obs_frame[m] != id;
+      }
     }
-  }
-  if (!valid) {
-    if (lane == 0) st->active[row] = 0;
-    return;
-  }
-  uint32_t qd[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) qd[k] = P.desc[8 * m + k];
-  uint32_t mn = 0x7fff;
-  for (int j = lane; j < 512; j += 64) {
-    int d = 0x7fff;
-    if (j < nkp) {
-      d = 0;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) d += __popc(qd[k] ^ td[j * 8 + k]);
+    if (!valid) {
+      if (lane == 0) st->active[row] = 0;
+      continue;
     }
-    mn = min(mn, (uint32_t)d);
-    st->D[(size_t)row * 512 + j] = (uint16_t)d;
-  }
-  mn = tk_wmin(mn);
-  if (lane == 0) {
-    st->rowmin[row] = (uint16_t)mn;
-    st->active[row] = (int)mn < max_dist ? 1 : 0;
-  }
-  if ((int)mn >= max_dist) return;
-  // Speculative result of this row under the claims at the START of the pass (pass 1: none,
-  // pass 2: what pass 1 claimed).  Keys (dist<<16 | j) order by distance, then by column, so the
-  // wave minimum is the reference's strict-`<` scan result (first minimum) and the minimum over
-  // the columns before it is the "runner-up" (src/pnpmatch.cc:89-94) together with its column.
-  uint32_t kb = 0xffffffffu;
-  uint32_t keys[8];
+    uint32_t qd[8];
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const int j = lane + 64 * t;
-    uint32_t key = 0xffffffffu;
-    if (j < nkp && !(pass == 2 && st->assigned[j])) {
-      int d = 0;
+    for (int k = 0; k < 8; ++k) qd[k] = P.desc[8 * m + k];
+    uint32_t mn = 0x7fff;
+    int dcol[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) d += __popc(qd[k] ^ td[j * 8 + k]);
-      key = ((uint32_t)d << 16) | (uint32_t)j;
+    for (int t = 0; t < 8; ++t) {
+      const int j = lane + 64 * t;
+      int d = 0x7fff;
+      if (j < nkp) {
+        d = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d += __popc(qd[k] ^ td[k * TRK_MAXKP + j]);
+      }
+      dcol[t] = d;
+      mn = min(mn, (uint32_t)d);
+      st->D[(size_t)row * 512 + j] = (uint16_t)d;
     }
-    keys[t] = key;
-    kb = min(kb, key);
-  }
-  kb = tk_wmin(kb);
-  uint32_t ks = 0xffffffffu;
-  const uint32_t bj = kb & 0xffffu;
+    mn = tk_wmin(mn);
+    if (lane == 0) {
+      st->rowmin[row] = (uint16_t)mn;
+      st->active[row] = (int)mn < max_dist ? 1 : 0;
+    }
+    if ((int)mn >= max_dist) continue;
+    // Speculative result of this row under the claims at the START of the pass (pass 1: none,
+    // pass 2: what pass 1 claimed).  Keys (dist<<16 | j) order by distance, then by column, so the
+    // wave minimum is the reference's strict-`<` scan result (first minimum) and the minimum over
+    // the columns before it is the "runner-up" (src/pnpmatch.cc:89-94) together with its column.
+    uint32_t kb = 0xffffffffu;
+    uint32_t keys[8];
 #pragma unroll
-  for (int t = 0; t < 8; ++t)
-    if ((keys[t] & 0xffffu) < bj) ks = min(ks, keys[t]);
-  ks = tk_wmin(ks);
-  if (lane == 0) {
-    const uint32_t y = ks == 0xffffffffu ? ((256u << 16) | 0xffffu) : ks;
-    // bit 31 of x: the row would be accepted with this (speculative) result
-    const int bd = (int)(kb >> 16), sec = (int)(y >> 16);
-    bool ok = (kb & 0xffffu) != 0xffffu && bd < max_dist;
-    if (ok && pass == 2) ok = (float)sec / (float)bd > 2.f;
-    st->pre[row] = make_uint2(kb | (ok ? 0x80000000u : 0u), y);
+    for (int t = 0; t < 8; ++t) {
+      const int j = lane + 64 * t;
+      uint32_t key = 0xffffffffu;
+      if (j < nkp && !(pass == 2 && st->assigned[j])) key = ((uint32_t)dcol[t] << 16) | (uint32_t)j;
+      keys[t] = key;
+      kb = min(kb, key);
+    }
+    kb = tk_wmin(kb);
+    uint32_t ks = 0xffffffffu;
+    const uint32_t bj = kb & 0xffffu;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      if ((keys[t] & 0xffffu) < bj) ks = min(ks, keys[t]);
+    ks = tk_wmin(ks);
+    if (lane == 0) {
+      const uint32_t y = ks == 0xffffffffu ? ((256u << 16) | 0xffffu) : ks;
+      // bit 31 of x: the row would be accepted with this (speculative) result
+      const int bd = (int)(kb >> 16), sec = (int)(y >> 16);
+      bool ok = (kb & 0xffffu) != 0xffffu && bd < max_dist;
+      if (ok && pass == 2) ok = (float)sec / (float)bd > 2.f;
+      st->pre[row] = make_uint2(kb | (ok ? 0x80000000u : 0u), y);
+    }
   }
 }
 
@@ -558,9 +582,11 @@ static int tail_launch(svo_ctx* ctx, int slot, svo_track_result* d_res, int nseq
   }
   {
     SvoTimer t(ctx, "k_tk_match");
-    hipLaunchKernelGGL(k_tk_dist, dim3(TRK_MAXKP / 4, ny), dim3(256), 0, s, st, desc, 1, ks);
+    if (ny >= 8) hipLaunchKernelGGL(k_tk_dist<16>, dim3(TRK_MAXKP / 16, ny), dim3(256), 0, s, st, desc, 1, ks);
+    else hipLaunchKernelGGL(k_tk_dist<4>, dim3(TRK_MAXKP / 4, ny), dim3(256), 0, s, st, desc, 1, ks);
     hipLaunchKernelGGL(k_tk_greedy, dim3(1, ny), dim3(64), 0, s, st, 1, kp, ks);
-    hipLaunchKernelGGL(k_tk_dist, dim3(TRK_CAP / 4, ny), dim3(256), 0, s, st, desc, 2, ks);
+    if (ny >= 8) hipLaunchKernelGGL(k_tk_dist<16>, dim3(TRK_CAP / 16, ny), dim3(256), 0, s, st, desc, 2, ks);
+    else hipLaunchKernelGGL(k_tk_dist<4>, dim3(TRK_CAP / 4, ny), dim3(256), 0, s, st, desc, 2, ks);
     hipLaunchKernelGGL(k_tk_greedy, dim3(1, ny), dim3(64), 0, s, st, 2, kp, ks);
   }
   {

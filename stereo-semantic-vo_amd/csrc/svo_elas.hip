@@ -266,15 +266,7 @@ __device__ __forceinline__ void d_elas_match(bool right, const uint4* desc1, con
   const int u_first = sub ? 2 * (int)(blockIdx.x * 256) : (int)(blockIdx.x * 256);
   const int u_last = min(sub ? u_first + 510 : u_first + 255, W - 1);
   const int w0 = max(right ? u_first : u_first - 255, 0), w1 = min(right ? u_last + 255 : u_last, W - 1);
-  {
-    // all three loads of a thread in flight together (a load inside the loop was waited for at once)
-    uint4 wv[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) wv[k] = Io[line + w0 + min((int)threadIdx.x + 256 * k, w1 - w0)];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-      if ((int)threadIdx.x + 256 * k <= w1 - w0) win[threadIdx.x + 256 * k] = wv[k];
-  }
+  for (int i = threadIdx.x; i <= w1 - w0; i += 256) win[i] = Io[line + w0 + i];
   __syncthreads();
   if (x >= Wd) return;
   const int addr = y * Wd + x;

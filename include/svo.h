@@ -398,6 +398,15 @@ int svo_msa_lrcheck(svo_ctx* ctx, const uint8_t* d1, const uint8_t* d2, int widt
 int svo_msa_solve(svo_ctx* ctx, const uint8_t* bgrL, const uint8_t* bgrR, int width, int height, int step, int d, int scale,
                   uint8_t* disparity);
 
+/* Throughput mode of the same solver (no counterpart in the reference): B gray stereo pairs already in HBM (pair b at
+ * d_L / d_R + b * stride * height, `stride` bytes per row; a gray frame stands for the B = G = R colour image the
+ * reference gets from a grayscale file), disparity maps as floats - `disp_img.convertTo(disp_32f, CV_32F, 1)` of
+ * frame::MB - into d_disp (HBM, map b at + b * width * height).  Frames are solved 16 at a time: their aggregation
+ * trees are built side by side on host threads and their level sweeps share launches.  Results are identical to B
+ * calls of svo_msa_solve with scale 1.  Synchronises before it returns. */
+int svo_msa_batch_dev(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d_R, int stride, int width, int height, int B, int d,
+                      float* d_disp);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "svo_frontend_batch_dev", "svo_track_batch_dev", "svo_profile_enable", "svo_profile_reset",
     "svo_profile_get",
     "svo_elas_default_params", "svo_elas_process", "svo_elas_process_ex", "svo_elas_delaunay",
-    "svo_ctmf", "svo_track_multi_reset", "svo_track_multi_step_dev", "svo_elas_batch_dev", "svo_msa_init", "svo_msa_tree", "svo_msa_tree_dp", "svo_msa_wta", "svo_msa_lrcheck", "svo_msa_solve",
+    "svo_ctmf", "svo_track_multi_reset", "svo_track_multi_step_dev", "svo_elas_batch_dev", "svo_msa_init", "svo_msa_tree", "svo_msa_tree_dp", "svo_msa_wta", "svo_msa_lrcheck", "svo_msa_solve", "svo_msa_batch_dev",
 ]
 
 
@@ -386,6 +386,11 @@ class Svo:
         self._chk(self.lib.svo_elas_batch_dev(self.h, C.c_void_p(d_L), C.c_void_p(d_R), int(stride), int(W), int(H),
                                               int(B), C.byref(params), C.c_void_p(d_D1), C.c_void_p(d_D2), _p(produced)))
         return produced
+
+    def msa_batch_dev(self, d_L, d_R, stride, W, H, B, d_disp, d=48):
+        """B device-resident gray pairs -> B device-resident float disparity maps (MSA::solve, scale 1)."""
+        self._chk(self.lib.svo_msa_batch_dev(self.h, C.c_void_p(d_L), C.c_void_p(d_R), int(stride), int(W), int(H), int(B),
+                                             int(d), C.c_void_p(d_disp)))
 
     def msa_init(self, bgrL, bgrR, disp=49):
         """MSA::init on two H x W x 3 uint8 images: cost volumes, median images, gradients (dict)."""

@@ -851,6 +851,18 @@ int svo_msa_run_many_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int
   return SVO_OK;
 }
 
+extern "C" int svo_msa_batch_dev(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d_R, int stride, int width, int height, int B,
+                                 int d, float* d_disp) {
+  if (!ctx) return SVO_E_INVALID;
+  if (!d_L || !d_R || !d_disp || B < 1 || width < 5 || height < 5 || stride < width || d < 0 || d > 255 ||
+      (int64_t)width * height > (1 << 24)) {
+    ctx->last_error = "svo_msa_batch_dev: invalid argument";
+    return SVO_E_INVALID;
+  }
+  SVO_HIP(ctx, hipSetDevice(ctx->device));
+  return svo_msa_run_many_dev(ctx, d_L, d_R, stride, (size_t)height * stride, width, height, d, B, d_disp);
+}
+
 void svo_msa_release(svo_ctx* ctx) {
   if (!ctx || !ctx->msa_arenas) return;
   MsaArenas* A = static_cast<MsaArenas*>(ctx->msa_arenas);

@@ -235,3 +235,32 @@ def test_gpu_solve_equals_oracle(pkg, W, H, d, shift):
     with pytest.raises(pkg.SvoError):
         s.msa_solve(L, R, 256, 1)
     s.close()
+
+
+@pytest.mark.gpu
+def test_gpu_batch_equals_single_solves(pkg):
+    """svo_msa_batch_dev (frames solved together: shared level sweeps, stacked per-pixel stages) == svo_msa_solve per
+    frame on the B = G = R colour images, for frames of different content (different tree depths in one chunk)."""
+    import torch
+    W, H, B, d = 200, 120, 5, 32
+    dev = torch.device("cuda", 0)
+    pitch = 256
+    Ls, Rs = [], []
+    for b in range(B):
+        L, R = util.urban_pair(W, H, 100 + 150 * b, 40 + 30 * b)
+        Ls.append(L); Rs.append(R)
+    Ls[3] = np.full((H, W), 80, np.uint8); Rs[3] = np.full((H, W), 80, np.uint8)     # a flat frame: a very different tree
+    dL = torch.zeros((B, H, pitch), dtype=torch.uint8, device=dev); dR = torch.zeros_like(dL)
+    dL[:, :, :W] = torch.from_numpy(np.stack(Ls)).to(dev); dR[:, :, :W] = torch.from_numpy(np.stack(Rs)).to(dev)
+    out = torch.zeros((B, H, W), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    s = pkg.Svo(640, 240)
+    s.msa_batch_dev(dL.data_ptr(), dR.data_ptr(), pitch, W, H, B, out.data_ptr(), d)
+    got = out.cpu().numpy()
+    g2c = lambda g: np.ascontiguousarray(np.repeat(g[:, :, None], 3, 2))
+    for b in range(B):
+        want = s.msa_solve(g2c(Ls[b]), g2c(Rs[b]), d, 1).astype(np.float32)
+        assert np.array_equal(got[b], want), b
+    with pytest.raises(pkg.SvoError):
+        s.msa_batch_dev(dL.data_ptr(), dR.data_ptr(), W - 1, W, H, B, out.data_ptr(), d)
+    s.close()

@@ -200,7 +200,7 @@ struct DevBuf {   // device allocations of one solve; reset() hands the same buf
 // the buffers of svo_msa_solve / the tracker's MSA mode live as long as the ctx (index 0: the ctx stream; 1..: the
 // streams of svo_msa_run_many_dev) - a solve allocates ~0.5 GB at KITTI size and hipFree synchronises the device
 struct MsaHostStore;   // host-side buffers of the batched solve (kept for the same reason: page faults)
-struct MsaArenas { std::vector<DevBuf*> a; std::mutex m; MsaHostStore* host = nullptr; };
+struct MsaArenas { std::vector<DevBuf*> a; std::mutex m; MsaHostStore* host[2] = {nullptr, nullptr}; };
 DevBuf& msa_arena(svo_ctx* ctx, int idx) {
   if (!ctx->msa_arenas) ctx->msa_arenas = new MsaArenas();
   MsaArenas* A = static_cast<MsaArenas*>(ctx->msa_arenas);
@@ -680,8 +680,12 @@ int svo_msa_run_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int pitc
 // MSA::solve for C frames together (gray frames on the device, float maps out): init per frame, all 2C trees on host
 // threads, then every stage of the aggregation once for the whole chunk - the level sweeps as one launch per level for
 // all frames, the per-pixel stages over the C maps stacked into one tall image.
+// `lane` (0 / 1) selects the device arena and host store; with two lanes alternating over the chunks, host_phase is held
+// from the first kernel to the last tree and gpu_phase from the tree upload to the end, so that the trees of one chunk
+// grow while the GPU aggregates the previous one.
 static int msa_many_device(svo_ctx* ctx, hipStream_t s, const uint8_t* dL, const uint8_t* dR, int pitch, size_t frame_stride,
-                           int m, int n, int d, int C, float* d_disp_out) {
+                           int m, int n, int d, int C, float* d_disp_out, int lane, std::mutex* host_phase,
+                           std::mutex* gpu_phase) {
   const bool dbg = getenv("SVO_MSA_DEBUG") != nullptr;
   auto t_last = std::chrono::steady_clock::now();
   auto mark = [&](const char* what) {
@@ -691,7 +695,9 @@ static int msa_many_device(svo_ctx* ctx, hipStream_t s, const uint8_t* dL, const
   };
   const int D = d + 1;
   const size_t N = (size_t)n * m, V = N * D;
-  DevBuf& buf = msa_arena(ctx, 1);
+  std::unique_lock<std::mutex> host_lock;
+  if (host_phase) host_lock = std::unique_lock<std::mutex>(*host_phase);
+  DevBuf& buf = msa_arena(ctx, 1 + lane);
   uint8_t* img3[2] = {buf.get<uint8_t>(3 * N), buf.get<uint8_t>(3 * N)};
   uint8_t* med3[2] = {buf.get<uint8_t>(3 * N), buf.get<uint8_t>(3 * N)};
   uint8_t* gray = buf.get<uint8_t>(N);
@@ -714,8 +720,8 @@ static int msa_many_device(svo_ctx* ctx, hipStream_t s, const uint8_t* dL, const
   const unsigned nbN = (unsigned)((N + 255) / 256), nbV = (unsigned)((V + 255) / 256);
   // 1. MSA::init per frame; the median images and their gradients go to the host for the tree builders
   MsaArenas* arenas = static_cast<MsaArenas*>(ctx->msa_arenas);
-  if (!arenas->host) arenas->host = new MsaHostStore();
-  MsaHostStore& hs = *arenas->host;
+  if (!arenas->host[lane]) arenas->host[lane] = new MsaHostStore();
+  MsaHostStore& hs = *arenas->host[lane];
   if ((int)hs.tree.size() < 2 * C) { hs.tree.resize(2 * C); hs.med.resize(2 * C); }
   if ((int)hs.gra.size() < C) hs.gra.resize(C);
   for (int k = 0; k < 2 * C; ++k) hs.med[k].resize(3 * N);
@@ -767,6 +773,9 @@ static int msa_many_device(svo_ctx* ctx, hipStream_t s, const uint8_t* dL, const
   mark("trees");
   for (int k = 0; k < 2 * C; ++k)
     if (tree[k].rc) { ctx->last_error = "svo_msa (batched): tree construction failed"; return tree[k].rc; }
+  if (host_lock.owns_lock()) host_lock.unlock();
+  std::unique_lock<std::mutex> gpu_lock;
+  if (gpu_phase) gpu_lock = std::unique_lock<std::mutex>(*gpu_phase);
   // 3. trees to the device: tabs[side * C + b]
   std::vector<MsaTreeTab> h_tabs(2 * C);
   int Lmax[2] = {0, 0};
@@ -842,13 +851,31 @@ int svo_msa_run_many_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int
     return SVO_OK;
   }
   // chunks of up to 16 frames: ~0.4 GB of HBM per frame at KITTI size (four cost volumes)
-  for (int b0 = 0; b0 < B; b0 += 16) {
-    const int C = std::min(16, B - b0);
-    const int rc = msa_many_device(ctx, ctx->stream, dL + b0 * frame_stride, dR + b0 * frame_stride, pitch, frame_stride, W, H, d, C,
-                                   d_disp + b0 * N);
-    if (rc) return rc;
+  const int nchunk = (B + 15) / 16;
+  if (nchunk == 1)
+    return msa_many_device(ctx, ctx->stream, dL, dR, pitch, frame_stride, W, H, d, B, d_disp, 0, nullptr, nullptr);
+  // two lanes (threads, streams, arenas) take the chunks alternately
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));   // whatever produced the frames
+  std::mutex host_phase, gpu_phase;
+  hipStream_t st[2] = {nullptr, nullptr};
+  for (int t = 0; t < 2; ++t) SVO_HIP(ctx, hipStreamCreateWithFlags(&st[t], hipStreamNonBlocking));
+  int rcs[2] = {SVO_OK, SVO_OK};
+  auto lane_work = [&](int t) {
+    if (hipSetDevice(ctx->device) != hipSuccess) { rcs[t] = SVO_E_HIP; return; }
+    for (int c = t; c < nchunk; c += 2) {
+      const int b0 = 16 * c, C = std::min(16, B - b0);
+      const int rc = msa_many_device(ctx, st[t], dL + b0 * frame_stride, dR + b0 * frame_stride, pitch, frame_stride, W, H, d, C,
+                                     d_disp + b0 * N, t, &host_phase, &gpu_phase);
+      if (rc) { rcs[t] = rc; return; }
+    }
+  };
+  {
+    std::thread other(lane_work, 1);
+    lane_work(0);
+    other.join();
   }
-  return SVO_OK;
+  for (int t = 0; t < 2; ++t) hipStreamDestroy(st[t]);
+  return rcs[0] ? rcs[0] : rcs[1];
 }
 
 extern "C" int svo_msa_batch_dev(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d_R, int stride, int width, int height, int B,
@@ -867,7 +894,8 @@ void svo_msa_release(svo_ctx* ctx) {
   if (!ctx || !ctx->msa_arenas) return;
   MsaArenas* A = static_cast<MsaArenas*>(ctx->msa_arenas);
   for (DevBuf* b : A->a) delete b;
-  delete A->host;
+  delete A->host[0];
+  delete A->host[1];
   delete A;
   ctx->msa_arenas = nullptr;
 }

@@ -238,16 +238,17 @@ def test_gpu_solve_equals_oracle(pkg, W, H, d, shift):
 
 
 @pytest.mark.gpu
-def test_gpu_batch_equals_single_solves(pkg):
+@pytest.mark.parametrize("B", [5, 20])       # one chunk; two chunks on two lanes (16 + 4 frames)
+def test_gpu_batch_equals_single_solves(pkg, B):
     """svo_msa_batch_dev (frames solved together: shared level sweeps, stacked per-pixel stages) == svo_msa_solve per
     frame on the B = G = R colour images, for frames of different content (different tree depths in one chunk)."""
     import torch
-    W, H, B, d = 200, 120, 5, 32
+    W, H, d = 200, 120, 32
     dev = torch.device("cuda", 0)
     pitch = 256
     Ls, Rs = [], []
     for b in range(B):
-        L, R = util.urban_pair(W, H, 100 + 150 * b, 40 + 30 * b)
+        L, R = util.urban_pair(W, H, 100 + 45 * b, 40 + 10 * b)
         Ls.append(L); Rs.append(R)
     Ls[3] = np.full((H, W), 80, np.uint8); Rs[3] = np.full((H, W), 80, np.uint8)     # a flat frame: a very different tree
     dL = torch.zeros((B, H, pitch), dtype=torch.uint8, device=dev); dR = torch.zeros_like(dL)

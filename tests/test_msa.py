@@ -219,10 +219,14 @@ def test_oracle_solve_recovers_a_known_shift():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("W,H,d,shift", [(120, 64, 16, 7), (200, 120, 48, 11), (321, 97, 31, 0)])
+@pytest.mark.parametrize("W,H,d,shift", [(120, 64, 16, 7), (200, 120, 48, 11), (321, 97, 31, 0), (1241, 376, 48, 0)])
 def test_gpu_solve_equals_oracle(pkg, W, H, d, shift):
     """svo_msa_solve (GPU stages + host trees, volumes resident in HBM) is bit-identical to orc_msa_solve."""
-    L, R = shifted_colour_pair(W, H, shift) if shift else colour_pair(W, H)
+    if W > 1000:      # the full KITTI frame (the urban fixture is exactly that big): trees ~1000 levels deep
+        gl, gr = util.urban_pair(W, H, 0, 0)
+        L = np.ascontiguousarray(np.repeat(gl[:, :, None], 3, 2)); R = np.ascontiguousarray(np.repeat(gr[:, :, None], 3, 2))
+    else:
+        L, R = shifted_colour_pair(W, H, shift) if shift else colour_pair(W, H)
     s = pkg.Svo(640, 240)
     g = s.msa_solve(L, R, d, 1)
     r = ob.msa_solve(L, R, d, 1)

@@ -1298,13 +1298,14 @@ int elas_phase_b(svo_ctx* ctx, hipStream_t s, const ElasTab* d_tab, int B, int m
   const int nb = (int)((n + 255) / 256);
   // strips in LDS when two strip-sized arrays fit (more than the default 64 KB of dynamic LDS needs an opt-in)
   const size_t strip_lds = (size_t)2 * CCS_ROWS * Wd * sizeof(int32_t);
-  static bool strip_ok = false, strip_tried = false;
-  if (!strip_tried) {
-    strip_tried = true;
-    strip_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_cc_strip), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   150 * 1024) == hipSuccess;
+  // the opt-in is a per-device function attribute: remembered per context (a context is bound to one device and is not
+  // shared between threads), never in a process-wide static
+  if (ctx->elas_strip_state == 0) {
+    ctx->elas_strip_state = hipFuncSetAttribute(reinterpret_cast<const void*>(k_cc_strip), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                150 * 1024) == hipSuccess ? 1 : -1;
     (void)hipGetLastError();
   }
+  const bool strip_ok = ctx->elas_strip_state > 0;
   const char* cc_env = getenv("SVO_ELAS_CC_STRIPS");
   const bool use_strips = strip_ok && strip_lds <= 150 * 1024 && Hd > CCS_ROWS && (!cc_env || atoi(cc_env) != 0);
   for (int side = 0; side < nsides; ++side) {
@@ -1527,8 +1528,16 @@ extern "C" int svo_elas_batch_dev(svo_ctx* ctx, const uint8_t* d_L, const uint8_
   // host threads work on chunk c, the GPU runs phase A of chunk c+1 and phase B of chunk c-1.
   const char* chunk_env = getenv("SVO_ELAS_CHUNK");   // tuning knob, default ELAS_BATCH_CHUNK
   const int C = std::min(B, chunk_env && atoi(chunk_env) > 0 ? atoi(chunk_env) : ELAS_BATCH_CHUNK), NC = (B + C - 1) / C;
-  std::vector<hipEvent_t> evA(NC, nullptr);
+  // every fallible set-up step comes BEFORE the worker pool exists (returning past joinable threads would terminate
+  // the process); the events are owned by a guard so that no return path leaks them
+  struct EventSet {
+    std::vector<hipEvent_t> ev;
+    ~EventSet() { for (hipEvent_t e : ev) if (e) hipEventDestroy(e); }
+  } evs;
+  evs.ev.assign(NC, nullptr);
+  std::vector<hipEvent_t>& evA = evs.ev;
   for (int c = 0; c < NC; ++c) SVO_HIP(ctx, hipEventCreateWithFlags(&evA[c], hipEventDisableTiming));
+  if ((rc = eb->grow_lists(ctx, (size_t)B * 49152))) return rc;   // ~2x the typical 90 KB of lists per pair
   int32_t P[256];
   fill_prior(p, P);
   for (int b = 0; b < B; ++b)
@@ -1587,7 +1596,6 @@ extern "C" int svo_elas_batch_dev(svo_ctx* ctx, const uint8_t* d_L, const uint8_
   };
   double t_sync_copy = 0;
   size_t lists_used = 0;
-  if ((rc = eb->grow_lists(ctx, (size_t)B * 49152))) return rc;   // ~2x the typical 90 KB of lists per pair
   auto enqueue_b = [&](int c) -> int {   // counts into the table, then the whole phase B of the chunk
     const int b0 = c * C, nb = std::min(C, B - b0);
     int max_nsp = 0, max_nt = 0;
@@ -1667,7 +1675,6 @@ extern "C" int svo_elas_batch_dev(svo_ctx* ctx, const uint8_t* d_L, const uint8_
   hipStreamSynchronize(s);   // the pinned table and list arena are read by copies until here
   if (dbg) fprintf(stderr, "elas batch B=%d chunk=%d: enqueue %.2f ms (of it packing the lists %.2f), wait for A %.2f, host stages %.2f, tail wait %.2f, total %.2f\n",
                    B, C, t_enq, t_sync_copy, t_wait, t_host, ms(t_loop, tnow()), ms(t_start, tnow()));
-  for (hipEvent_t e : evA) hipEventDestroy(e);
   if (rc == SVO_OK) SVO_HIP(ctx, hipGetLastError());
   return rc;
 }

@@ -95,6 +95,7 @@ struct svo_ctx {
   int n_seq = 0;
   void* elas = nullptr;     // ElasState (svo_elas.hip), allocated on first svo_elas_process
   void* elas_batch = nullptr;   // ElasBatch: per-pair states of svo_elas_batch_dev
+  int elas_strip_state = 0;     // k_cc_strip's > 64 KB dynamic-LDS opt-in on this ctx's device: 0 untried, 1 granted, -1 refused
   void* msa_arenas = nullptr;   // MsaArenas: device buffers of svo_msa_solve and of the tracker's MSA mode
   float* d_dense = nullptr;     // dense maps of svo_track_batch_dev with depth_source 1: 2 x dense_cap x W*H
   int dense_cap = 0;

@@ -593,9 +593,12 @@ static int tail_launch(svo_ctx* ctx, int slot, svo_track_result* d_res, int nseq
     SvoTimer t(ctx, "k_tk_gather");
     hipLaunchKernelGGL(k_tk_gather, dim3(1, ny), dim3(512), 0, s, st, kp, ks);
   }
-  svo_launch_pnp_dev(ctx, st->Xw, st->obs, &st->n_edges, st->K, st->Tprior, st->T, &st->pnp,
-                     &st->skip_match, &st->frame_num, nseq, sizeof(TrackState));
-  svo_launch_pose_opt_dev(ctx, st->Xw, st->obs, &st->n_edges, st->K, st->T, &st->lm, 1, nseq, sizeof(TrackState));
+  int rc;
+  if ((rc = svo_launch_pnp_dev(ctx, st->Xw, st->obs, &st->n_edges, st->K, st->Tprior, st->T, &st->pnp,
+                               &st->skip_match, &st->frame_num, nseq, sizeof(TrackState))))
+    return rc;
+  if ((rc = svo_launch_pose_opt_dev(ctx, st->Xw, st->obs, &st->n_edges, st->K, st->T, &st->lm, 1, nseq, sizeof(TrackState))))
+    return rc;
   {
     SvoTimer t(ctx, "k_tk_end");
     hipLaunchKernelGGL(k_tk_end, dim3(1, ny), dim3(512), 0, s, st, kp, desc, depth, d_res, ks);
@@ -769,6 +772,10 @@ extern "C" int svo_track_multi_step_dev(svo_ctx* ctx, const uint8_t* d_grayL, co
                                         int stride, int n_seq, svo_track_result* d_results) {
   if (!ctx || !d_grayL || !d_grayR || !d_results || stride < ctx->g.W) return SVO_E_INVALID;
   if (!ctx->d_track || n_seq != ctx->n_seq) return SVO_E_INVALID;   // svo_track_multi_reset(n_seq) first
+  if (ctx->opt_depth_source != 0) {   // the many-sequence mode has the sparse matcher only
+    ctx->last_error = "svo_track_multi_step_dev: depth_source must be 0";
+    return SVO_E_INVALID;
+  }
   hipSetDevice(ctx->device);
   int rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, n_seq, 2 * n_seq);
   if (rc) return rc;

@@ -30,7 +30,8 @@ inline bool read_pgm(const std::string& path, GrayImage& img) {
     c = fgetc(f);
   }
   ungetc(c, f);
-  if (fscanf(f, "%d %d %d", &w, &h, &mx) != 3 || mx > 255) { fclose(f); return false; }
+  // sizes are bounded like svo_create's (a header is untrusted input: no negative or huge allocation)
+  if (fscanf(f, "%d %d %d", &w, &h, &mx) != 3 || mx > 255 || mx < 1 || w <= 0 || h <= 0 || w > 4095 || h > 4095) { fclose(f); return false; }
   fgetc(f);
   img.cols = w; img.rows = h;
   img.data.resize((size_t)w * h);

@@ -35,12 +35,15 @@ inline bool read_png(const std::string& path, GrayImage& img) {
     const char* type = (const char*)&file[pos + 4];
     const uint8_t* d = &file[pos + 8];
     if (pos + 12 + len > file.size()) return false;
-    if (!memcmp(type, "IHDR", 4)) { w = be32(d); h = be32(d + 4); depth = d[8]; ctype = d[9]; interlace = d[12]; }
+    if (!memcmp(type, "IHDR", 4)) {
+      if (len != 13) return false;   // a short IHDR would be read past its end
+      w = be32(d); h = be32(d + 4); depth = d[8]; ctype = d[9]; interlace = d[12];
+    }
     else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), d, d + len);
     else if (!memcmp(type, "IEND", 4)) break;
     pos += 12 + len;
   }
-  if (!w || !h || depth != 8 || interlace || (ctype != 0 && ctype != 2 && ctype != 6)) return false;
+  if (!w || !h || w > 4095 || h > 4095 || depth != 8 || interlace || (ctype != 0 && ctype != 2 && ctype != 6)) return false;
   const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : 4;
   const size_t stride = (size_t)w * ch;
   std::vector<uint8_t> raw((stride + 1) * h);

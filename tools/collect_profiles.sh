@@ -9,7 +9,9 @@ set -u
 TAG=${1:-r01}; shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out; mkdir -p $OUT
-ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-profile --no-track-leg $*"
+# front-end kernels only in the profiled process: no ELAS / MSA legs (their host thread pools, oracle loading and
+# `make` children do not belong under rocprofv3), no CPU baseline, no tracking leg
+ARGS="--workload frontend --steps 10 --warmup 3 --no-cpu-baseline --no-profile --no-track-leg --no-elas-leg $*"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_*
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py $ARGS > /tmp/prof_stats.log 2>&1

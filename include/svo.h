@@ -116,6 +116,9 @@ void svo_destroy(svo_ctx* ctx);
  * v_mfma_f64_16x16x4_f64; 0 selects the VALU + DPP reduction (same results to round-off).
  * "fast_cand_cap" (default 2048, the maximum): length of the per-tile list of scored pixels in the FAST kernel; tiles
  * with more fall back to scanning the score tile - same results, the switch exists so that tests can force that path.
+ * "track_lcap" (default 16, the maximum): entries of a map point's sparse candidate list in the tracker's matching
+ * passes; rows with more candidates keep their full distance row instead - same results, the switch exists so that tests
+ * can force that path.
  * "depth_source" (default 0): where svo_track_frame / svo_track_batch_dev take keypoint depth from - 0 the sparse
  * epipolar matcher (north star), 1 a dense ELAS map (svo_elas_*), 2 a dense MSA map (svo_msa_solve with d = 48: the
  * reference's live configuration, src/Tracking.cc:225-228 + src/frame.cc:82-91), both read per keypoint as
@@ -270,6 +273,20 @@ int svo_frontend_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* 
  * svo_track_result records in HBM.  Does not synchronise. */
 int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR,
                         int stride, int B, svo_track_result* d_results);
+
+/* The ordered tracking tail ALONE, for front-end results that already lie in HBM - e.g. produced by
+ * svo_frontend_batch_dev of OTHER contexts / GPUs and copied here (pair k -> GPU k mod G, then the
+ * strict chain of src/Tracking.cc:231-250 in frame order on one GPU).  Frame f of the call: keypoints at
+ * d_kp + f * kp_stride, descriptors at d_desc + f * kp_stride * 32, keypoint count d_n[f], per-keypoint depths
+ * (<= 0: none) at d_depth + f * kp_stride.  Records are identical to svo_track_batch_dev on the same frames.
+ * No detection boxes in this mode.  Does not synchronise. */
+int svo_track_tail_dev(svo_ctx* ctx, const svo_kp* d_kp, const uint8_t* d_desc, const int32_t* d_n,
+                       const float* d_depth, int kp_stride, int B, svo_track_result* d_results);
+/* Sticky capacity flag of the device tracker (synchronises): *flag != 0 once a frame needed more than the 4096 live
+ * map points the pool holds, or a map point stayed alive for more than 2^20 creations (its slot in the position table
+ * was about to be reused).  Neither can happen with the reference's 500 keypoints per frame on sequences of KITTI
+ * length; results after the flag is set are not the reference's. */
+int svo_track_overflowed(svo_ctx* ctx, int32_t* flag);
 
 /* Many independent sequences on one GPU ("G independent sequences" for pure
  * throughput; no counterpart in the reference, whose tracker is one static chain per process,

@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "svo_frontend_batch_dev", "svo_track_batch_dev", "svo_profile_enable", "svo_profile_reset",
     "svo_profile_get",
     "svo_elas_default_params", "svo_elas_process", "svo_elas_process_ex", "svo_elas_delaunay",
-    "svo_ctmf", "svo_track_multi_reset", "svo_track_multi_step_dev", "svo_elas_batch_dev", "svo_msa_init", "svo_msa_tree", "svo_msa_tree_dp", "svo_msa_wta", "svo_msa_lrcheck", "svo_msa_solve", "svo_msa_batch_dev",
+    "svo_ctmf", "svo_track_multi_reset", "svo_track_multi_step_dev", "svo_track_tail_dev", "svo_track_overflowed", "svo_elas_batch_dev", "svo_msa_init", "svo_msa_tree", "svo_msa_tree_dp", "svo_msa_wta", "svo_msa_lrcheck", "svo_msa_solve", "svo_msa_batch_dev",
 ]
 
 
@@ -315,7 +315,16 @@ class Svo:
         self._chk(self.lib.svo_track_batch_dev(self.h, _p(d_grayL), _p(d_grayR), int(stride), int(B),
                                                _p(d_results)))
 
-    # ---- profiling ----------------------------------------------------------------------------
+    def track_tail_dev(self, d_kp, d_desc, d_n, d_depth, kp_stride, B, d_results):
+        """svo_track_tail_dev: the ordered tail over front-end results already in HBM (device pointers)."""
+        self._chk(self.lib.svo_track_tail_dev(self.h, _p(d_kp), _p(d_desc), _p(d_n), _p(d_depth), int(kp_stride),
+                                              int(B), _p(d_results)))
+
+    def track_overflowed(self):
+        f = C.c_int32(0)
+        self._chk(self.lib.svo_track_overflowed(self.h, C.byref(f)))
+        return f.value
+
     def track_multi_reset(self, n_seq, cam):
         self._chk(self.lib.svo_track_multi_reset(self.h, int(n_seq), C.byref(cam)))
 

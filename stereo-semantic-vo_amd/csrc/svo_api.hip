@@ -42,7 +42,7 @@ static hipEvent_t prof_event(SvoProfState* ps) {
   hipEventCreate(&e);
   return e;
 }
-SvoTimer::SvoTimer(svo_ctx* c, const char* n) : ctx(c), name(n) {
+SvoTimer::SvoTimer(svo_ctx* c, const char* n, hipStream_t s) : ctx(c), name(n), stream(s ? s : c->stream) {
   if (!ctx->profiling) return;
   SvoProfState* ps = prof_state(ctx);
   if (ps->pending.size() > 8192) prof_resolve(ctx);
@@ -56,13 +56,13 @@ SvoTimer::SvoTimer(svo_ctx* c, const char* n) : ctx(c), name(n) {
     entry = (int)ctx->prof.size() - 1;
   }
   PendingEvt p{entry, prof_event(ps), prof_event(ps)};
-  hipEventRecord(p.a, ctx->stream);
+  hipEventRecord(p.a, stream);
   ps->pending.push_back(p);
 }
 SvoTimer::~SvoTimer() {
   if (!ctx->profiling) return;
   SvoProfState* ps = prof_state(ctx);
-  hipEventRecord(ps->pending.back().b, ctx->stream);
+  hipEventRecord(ps->pending.back().b, stream);
 }
 
 // ---- geometry + tables ---------------------------------------------------------------
@@ -249,7 +249,9 @@ extern "C" int svo_create(svo_ctx** out, int device, int W, int H, int max_kp, i
 extern "C" void svo_destroy(svo_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
+  if (ctx->stream_idx) hipStreamSynchronize(ctx->stream_idx);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  svo_track_release(ctx);
   svo_elas_release(ctx);
   svo_msa_release(ctx);
   if (ctx->d_dense) hipFree(ctx->d_dense);
@@ -277,6 +279,11 @@ extern "C" int svo_set_option(svo_ctx* ctx, const char* key, int value) {
   if (!strcmp(key, "fast_cand_cap")) {
     if (value < 0 || value > 2048) return SVO_E_INVALID;
     ctx->opt_fast_cand_cap = value;
+    return SVO_OK;
+  }
+  if (!strcmp(key, "track_lcap")) {
+    if (value < 1 || value > 16) return SVO_E_INVALID;
+    ctx->opt_track_lcap = value;
     return SVO_OK;
   }
   if (!strcmp(key, "depth_source")) {

@@ -93,6 +93,14 @@ struct svo_ctx {
   // tracker state (svo_track.hip)
   void* d_track = nullptr;      // n_seq TrackState records
   int n_seq = 0;
+  void* d_work = nullptr;       // TrackWork records (index chain -> pose chain), work_cap of them
+  int work_cap = 0;
+  hipStream_t stream_idx = nullptr;        // the pose-free index chain of the tracking tail runs here, ahead of the pose chain
+  hipEvent_t ev_frontend = nullptr;        // front end of a call finished (recorded on `stream`)
+  std::vector<hipEvent_t> ev_frame;        // index chain of frame f finished (recorded on `stream_idx`)
+  int pose_lds_state = 0;       // > 64 KB dynamic-LDS opt-in of the pose kernels: 0 untried, 1 granted, -1 refused
+  int track_lds_state = 0;      // same for the tracker's kernels
+  int opt_track_lcap = 16;      // svo_set_option("track_lcap"): entries of a map point's sparse candidate list (1..16)
   void* elas = nullptr;     // ElasState (svo_elas.hip), allocated on first svo_elas_process
   void* elas_batch = nullptr;   // ElasBatch: per-pair states of svo_elas_batch_dev
   int elas_strip_state = 0;     // k_cc_strip's > 64 KB dynamic-LDS opt-in on this ctx's device: 0 untried, 1 granted, -1 refused
@@ -145,13 +153,7 @@ int svo_launch_pose_opt(svo_ctx* ctx, const double* Xw, const double* obs, int n
 int svo_launch_pnp(svo_ctx* ctx, const double* Xw, const double* obs, int n, const double* K,
                    const double* Tprior, uint64_t seed, double* T, uint8_t* mask,
                    svo_pnp_stats* stats);
-// nseq > 1: one workgroup per sequence, operands of sequence q at byte offset q * seq_stride
-int svo_launch_pose_opt_dev(svo_ctx* ctx, const double* Xw, const double* obs, const int* n_ptr,
-                            const double* K, double* T, svo_lm_stats* stats, int round_in_f32,
-                            int nseq = 1, size_t seq_stride = 0);
-int svo_launch_pnp_dev(svo_ctx* ctx, const double* Xw, const double* obs, const int* n_ptr,
-                       const double* K, const double* Tprior, double* T, svo_pnp_stats* stats,
-                       const int* skip_ptr, const int* frame_ptr, int nseq = 1, size_t seq_stride = 0);
+int svo_pose_lds_optin(svo_ctx* ctx);   // dynamic-LDS opt-in of the pose kernels (PoseLds > 64 KB)
 template <typename T>
 __host__ __device__ inline T* svo_byte_offset(T* p, size_t bytes) {
   return p ? reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + bytes) : p;
@@ -162,6 +164,7 @@ int svo_launch_unproject(svo_ctx* ctx, const float* uvz, int n, const svo_camera
 
 extern "C" void svo_elas_release(svo_ctx* ctx);
 void svo_msa_release(svo_ctx* ctx);
+void svo_track_release(svo_ctx* ctx);   // tracker states, work records, second stream, events
 int svo_upload_image(svo_ctx* ctx, const uint8_t* gray, int stride, int slot);
 // dense ELAS stereo on images already in HBM; the two maps stay in HBM (valid until the next call)
 // wall-clock profile entry for the host stages (reported next to the HIP-event kernel entries)
@@ -188,6 +191,7 @@ int svo_elas_run_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int pit
 struct SvoTimer {
   svo_ctx* ctx;
   const char* name;
-  SvoTimer(svo_ctx* c, const char* n);
+  hipStream_t stream;
+  SvoTimer(svo_ctx* c, const char* n, hipStream_t s = nullptr);   // s == nullptr: the ctx stream
   ~SvoTimer();
 };

@@ -1,0 +1,665 @@
+// svo_pose_dev.h - device-side pose stages for gfx950, float64 throughout; shared by the stand-alone kernels of
+// svo_pose.hip (svo_pose_opt, svo_pnp_ransac) and by the tracker's fused per-frame pose kernel (svo_track.hip).
+//
+//   pose_opt_block   <- Optimizer::PoseOptimization (reference src/Optimizer.cc:15-86) as g2o executes it: one SE3
+//                       vertex, n unary reprojection edges, Huber delta=(double)(float)sqrt(5.991), Levenberg-
+//                       Marquardt x10 (Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:61-164).
+//   pnp_ransac_block <- the cv::solvePnPRansac call of pnpmatch::poseEstimationPnP (src/pnpmatch.cc:212-247).
+//
+// Both are called by ALL 256 threads of a workgroup (they contain barriers).  Per-edge residuals / Jacobians live in
+// registers; the 6x6 J^T W J, J^T W e and chi2 are reduced on f64 MFMA (or wave shuffles + one LDS hop); lane 0 runs
+// the scalar LM logic (LDLT, exp map, lambda schedule) so every accept/reject branch is taken in float64 exactly once.
+#pragma once
+#include "svo_internal.h"
+#include "svo_wave.h"
+
+struct Se3 { double q[4]; double t[3]; };
+
+// Eigen Quaternion(Matrix3): the three "largest diagonal" cases are written out so that nothing is
+// indexed dynamically (dynamic indices would push the matrix into scratch memory).
+__device__ __forceinline__ void quat_from_R(const double m[9], double q[4]) {
+  double t = m[0] + m[4] + m[8];
+  if (t > 0.0) {
+    t = sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (m[7] - m[5]) * t;
+    q[1] = (m[2] - m[6]) * t;
+    q[2] = (m[3] - m[1]) * t;
+  } else {
+    int i = 0;
+    if (m[4] > m[0]) i = 1;
+    if (m[8] > (i == 1 ? m[4] : m[0])) i = 2;
+    if (i == 0) {            // j = 1, k = 2
+      t = sqrt(m[0] - m[4] - m[8] + 1.0);
+      q[0] = 0.5 * t; t = 0.5 / t;
+      q[3] = (m[7] - m[5]) * t; q[1] = (m[3] + m[1]) * t; q[2] = (m[6] + m[2]) * t;
+    } else if (i == 1) {     // j = 2, k = 0
+      t = sqrt(m[4] - m[8] - m[0] + 1.0);
+      q[1] = 0.5 * t; t = 0.5 / t;
+      q[3] = (m[2] - m[6]) * t; q[2] = (m[7] + m[5]) * t; q[0] = (m[1] + m[3]) * t;
+    } else {                 // j = 0, k = 1
+      t = sqrt(m[8] - m[0] - m[4] + 1.0);
+      q[2] = 0.5 * t; t = 0.5 / t;
+      q[3] = (m[3] - m[1]) * t; q[0] = (m[2] + m[6]) * t; q[1] = (m[5] + m[7]) * t;
+    }
+  }
+}
+__device__ __forceinline__ void normalize_rotation(Se3& s) {
+  if (s.q[3] < 0) { s.q[0] = -s.q[0]; s.q[1] = -s.q[1]; s.q[2] = -s.q[2]; s.q[3] = -s.q[3]; }
+  const double n = sqrt(s.q[0] * s.q[0] + s.q[1] * s.q[1] + s.q[2] * s.q[2] + s.q[3] * s.q[3]);
+  s.q[0] /= n; s.q[1] /= n; s.q[2] /= n; s.q[3] /= n;
+}
+__device__ __forceinline__ void quat_mul(const double a[4], const double b[4], double o[4]) {
+  const double w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+  const double x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  const double y = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+  const double z = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z; o[3] = w;
+}
+__device__ __forceinline__ void quat_rot(const double q[4], const double v[3], double o[3]) {
+  double uv0 = q[1] * v[2] - q[2] * v[1], uv1 = q[2] * v[0] - q[0] * v[2], uv2 = q[0] * v[1] - q[1] * v[0];
+  uv0 += uv0; uv1 += uv1; uv2 += uv2;
+  o[0] = v[0] + q[3] * uv0 + (q[1] * uv2 - q[2] * uv1);
+  o[1] = v[1] + q[3] * uv1 + (q[2] * uv0 - q[0] * uv2);
+  o[2] = v[2] + q[3] * uv2 + (q[0] * uv1 - q[1] * uv0);
+}
+__device__ __forceinline__ void quat_to_R(const double q[4], double R[9]) {
+  const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+  const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+  const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+  const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+  R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+__device__ __forceinline__ void se3_from_T(const double* T, Se3& s) {
+  const double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
+  quat_from_R(R, s.q);
+  s.t[0] = T[3]; s.t[1] = T[7]; s.t[2] = T[11];
+  normalize_rotation(s);
+}
+__device__ __forceinline__ void se3_to_T(const Se3& s, double* T) {
+  double R[9];
+  quat_to_R(s.q, R);
+  T[0] = R[0]; T[1] = R[1]; T[2] = R[2]; T[3] = s.t[0];
+  T[4] = R[3]; T[5] = R[4]; T[6] = R[5]; T[7] = s.t[1];
+  T[8] = R[6]; T[9] = R[7]; T[10] = R[8]; T[11] = s.t[2];
+  T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+}
+// SE3Quat::exp (se3quat.h:223-257)
+__device__ void se3_exp(const double u[6], Se3& out) {
+  const double om0 = u[0], om1 = u[1], om2 = u[2];
+  const double theta = sqrt(om0 * om0 + om1 * om1 + om2 * om2);
+  const double Om[9] = {0, -om2, om1, om2, 0, -om0, -om1, om0, 0};
+  double Om2[9], R[9], V[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      Om2[3 * r + c] = Om[3 * r] * Om[c] + Om[3 * r + 1] * Om[3 + c] + Om[3 * r + 2] * Om[6 + c];
+  if (theta < 0.00001) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + Om[i] + Om2[i]; V[i] = R[i]; }
+  } else {
+    const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta),
+                 c = (theta - sin(theta)) / (theta * theta * theta);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const double I = (i % 4 == 0 ? 1.0 : 0.0);
+      R[i] = I + a * Om[i] + b * Om2[i];
+      V[i] = I + b * Om[i] + c * Om2[i];
+    }
+  }
+  quat_from_R(R, out.q);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) out.t[r] = V[3 * r] * u[3] + V[3 * r + 1] * u[4] + V[3 * r + 2] * u[5];
+  normalize_rotation(out);
+}
+__device__ void se3_oplus(const double u[6], Se3& est) {
+  Se3 e, r;
+  se3_exp(u, e);
+  double rt[3];
+  quat_rot(e.q, est.t, rt);
+  r.t[0] = e.t[0] + rt[0]; r.t[1] = e.t[1] + rt[1]; r.t[2] = e.t[2] + rt[2];
+  quat_mul(e.q, est.q, r.q);
+  normalize_rotation(r);
+  est = r;
+}
+__device__ __forceinline__ void huber(double e, double delta, double dsqr, double& rho0, double& rho1) {
+  if (e <= dsqr) { rho0 = e; rho1 = 1.; }
+  else { const double sq = sqrt(e); rho0 = 2 * sq * delta - dsqr; rho1 = delta / sq; }
+}
+// 6x6 LDL^T solve, fully unrolled so L, D and y stay in registers (dynamically indexed local arrays
+// would be placed in scratch memory, and this sits on the serial path of every LM / RANSAC step).
+// Returns 0 if a pivot is not positive (Eigen LDLT::isPositive() false).
+__device__ __forceinline__ int ldlt6_solve(const double* Hin, const double* b, double* x) {
+  double L[6][6], D[6], y[6];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double d = Hin[6 * j + j];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      if (k < j) d -= L[j][k] * L[j][k] * D[k];
+    ok = ok && (d > 0.0);
+    D[j] = d;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (i > j) {
+        double sacc = Hin[6 * i + j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          if (k < j) sacc -= L[i][k] * L[j][k] * D[k];
+        L[i][j] = sacc / d;
+      }
+    }
+  }
+  if (!ok) return 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double sacc = b[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      if (k < i) sacc -= L[i][k] * y[k];
+    y[i] = sacc;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) y[i] /= D[i];
+  double xs[6];
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double sacc = y[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      if (k > i) sacc -= L[k][i] * xs[k];
+    xs[i] = sacc;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) x[i] = xs[i];
+  return 1;
+}
+__device__ __forceinline__ void edge_error(const Se3& est, const double* Xw, const double* obs,
+                                           const double* K, double e[2], double pc[3]) {
+  quat_rot(est.q, Xw, pc);
+  pc[0] += est.t[0]; pc[1] += est.t[1]; pc[2] += est.t[2];
+  e[0] = obs[0] - (pc[0] / pc[2] * K[0] + K[2]);
+  e[1] = obs[1] - (pc[1] / pc[2] * K[1] + K[3]);
+}
+__device__ __forceinline__ void edge_jacobian(const double pc[3], const double* K, double J[12]) {
+  const double x = pc[0], y = pc[1], invz = 1.0 / pc[2], invz_2 = invz * invz;
+  J[0] = x * y * invz_2 * K[0];
+  J[1] = -(1 + (x * x * invz_2)) * K[0];
+  J[2] = y * invz * K[0];
+  J[3] = -invz * K[0];
+  J[4] = 0;
+  J[5] = x * invz_2 * K[0];
+  J[6] = (1 + y * y * invz_2) * K[1];
+  J[7] = -x * y * invz_2 * K[1];
+  J[8] = -x * invz * K[1];
+  J[9] = 0;
+  J[10] = -invz * K[1];
+  J[11] = y * invz_2 * K[1];
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) { return wave_sum_f64_dpp(v); }
+// block reduction of NV doubles per thread (256 threads = 4 waves); result in red[0..NV)
+template <int NV>
+__device__ __forceinline__ void block_reduce(double* acc, double* red /* [4][NV] + [NV] */) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) acc[k] = wave_sum_d(acc[k]);
+  __syncthreads();
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) red[(1 + wv) * NV + k] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < NV)
+    red[threadIdx.x] = red[NV + threadIdx.x] + red[2 * NV + threadIdx.x] + red[3 * NV + threadIdx.x] +
+                       red[4 * NV + threadIdx.x];
+  __syncthreads();
+}
+
+// accumulate (optionally Huber-weighted) normal equations + chi2 over edges listed by `use`.
+// acc layout: [0..20] upper-triangular H (row-major, r<=c), [21..26] b, [27] chi2
+template <bool ROBUST>
+__device__ __forceinline__ void accum_system(const Se3& est, const double* Xw, const double* obs,
+                                             int n, const uint8_t* use, const double* K,
+                                             double delta, double dsqr, double acc[28]) {
+#pragma unroll
+  for (int k = 0; k < 28; ++k) acc[k] = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    if (use && !use[i]) continue;
+    double e[2], pc[3], J[12];
+    edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc);
+    double rho0 = e[0] * e[0] + e[1] * e[1], rho1 = 1.;
+    if (ROBUST) huber(rho0, delta, dsqr, rho0, rho1);
+    edge_jacobian(pc, K, J);
+    int k = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = r; c < 6; ++c) acc[k++] += rho1 * (J[r] * J[c] + J[6 + r] * J[6 + c]);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) acc[21 + r] -= rho1 * (J[r] * e[0] + J[6 + r] * e[1]);
+    acc[27] += rho0;
+  }
+}
+// ---- MFMA variant of the system build ---------------------------------------------------------
+// The normal equations are a Gram matrix: with A~ = sqrt(w) [J | e]  (2n rows x 7 columns)
+//   A~^T A~ = [ H  -b ; -b^T  sum w e^2 ],   H = J^T W J,  b = -J^T W e
+// - the one dense contraction on the path.  Rows are written to LDS once per LM iteration by all
+// 256 lanes (one edge each); every wave then feeds 4 rows per v_mfma_f64_16x16x4_f64 (A = B = the
+// row block, so each lane loads ONE double per instruction) and the four per-wave 16x16 tiles are
+// summed through LDS.  Only the leading 7x7 of the tile is meaningful.
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+#define GRAM_MAXN 512
+#define GRAM_STRIDE 7
+
+template <bool ROBUST>
+__device__ __forceinline__ void build_system_mfma(const Se3& est, const double* Xw, const double* obs,
+                                                  int n, const uint8_t* use, const double* K,
+                                                  double delta, double dsqr, double* arow /*[2*512*7]*/,
+                                                  double* gram /*[4][8][8]*/, double* red) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int rows = (2 * n + 63) & ~63;           // 4 waves x whole groups of four 4-row steps
+  double chi = 0;
+  for (int i = tid; 2 * i < rows; i += 256) {
+    double r0[7] = {0, 0, 0, 0, 0, 0, 0}, r1[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (i < n && !(use && !use[i])) {
+      double e[2], pc[3], J[12];
+      edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc);
+      double rho0 = e[0] * e[0] + e[1] * e[1], rho1 = 1.;
+      if (ROBUST) huber(rho0, delta, dsqr, rho0, rho1);
+      edge_jacobian(pc, K, J);
+      const double sw = sqrt(rho1);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) { r0[c] = sw * J[c]; r1[c] = sw * J[6 + c]; }
+      r0[6] = sw * e[0]; r1[6] = sw * e[1];
+      chi += rho0;
+    }
+#pragma unroll
+    for (int c = 0; c < 7; ++c) { arow[(2 * i) * GRAM_STRIDE + c] = r0[c]; arow[(2 * i + 1) * GRAM_STRIDE + c] = r1[c]; }
+  }
+  __syncthreads();
+  const int c = lane & 15, kk = lane >> 4;
+  const int per_wave = rows >> 2;
+  // four independent accumulators: a dependent chain of f64 MFMAs would serialise on the
+  // instruction's own latency
+  v4f64 acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+  for (int r = wv * per_wave; r < (wv + 1) * per_wave; r += 16) {
+    const double* p = &arow[(r + kk) * GRAM_STRIDE + c];
+    const double v0 = c < 7 ? p[0] : 0.0, v1 = c < 7 ? p[4 * GRAM_STRIDE] : 0.0,
+                 v2 = c < 7 ? p[8 * GRAM_STRIDE] : 0.0, v3 = c < 7 ? p[12 * GRAM_STRIDE] : 0.0;
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, acc1, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(v2, v2, acc2, 0, 0, 0);
+    acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(v3, v3, acc3, 0, 0, 0);
+  }
+  const v4f64 acc = (acc0 + acc1) + (acc2 + acc3);
+  // C/D layout of the f64 16x16x4 form: col = lane & 15, row = (lane >> 4) + 4 * reg
+  if (c < 8) {
+    gram[(wv * 8 + kk) * 8 + c] = acc[0];
+    gram[(wv * 8 + kk + 4) * 8 + c] = acc[1];
+  }
+  chi = wave_sum_d(chi);
+  if (lane == 0) gram[256 + wv] = chi;
+  __syncthreads();
+  if (tid < 28) {
+    double out;
+    if (tid < 21) {
+      int r = 0, k = tid;                        // upper-triangular index -> (r, cc)
+      while (k >= 6 - r) { k -= 6 - r; ++r; }
+      const int cc = r + k;
+      out = gram[(0 * 8 + r) * 8 + cc] + gram[(1 * 8 + r) * 8 + cc] + gram[(2 * 8 + r) * 8 + cc] + gram[(3 * 8 + r) * 8 + cc];
+    } else if (tid < 27) {
+      const int r = tid - 21;
+      out = -(gram[(0 * 8 + r) * 8 + 6] + gram[(1 * 8 + r) * 8 + 6] + gram[(2 * 8 + r) * 8 + 6] + gram[(3 * 8 + r) * 8 + 6]);
+    } else {
+      out = gram[256] + gram[257] + gram[258] + gram[259];
+    }
+    red[tid] = out;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ double partial_chi2(const Se3& est, const double* Xw, const double* obs,
+                                               int n, const double* K, double delta, double dsqr) {
+  double chi = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    double e[2], pc[3];
+    edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc);
+    double rho0 = e[0] * e[0] + e[1] * e[1], rho1;
+    huber(rho0, delta, dsqr, rho0, rho1);
+    chi += rho0;
+  }
+  return chi;
+}
+__device__ __forceinline__ void unpack_system(const double* red, double H[36], double b[6]) {
+  int k = 0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = r; c < 6; ++c) { H[6 * r + c] = red[k]; H[6 * c + r] = red[k]; ++k; }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) b[r] = red[21 + r];
+}
+
+struct LmShared {
+  Se3 est;       // current estimate (all threads read)
+  Se3 backup;
+  double x[6];
+  int go;        // 1: evaluate trial chi2 ; 0: iteration finished
+  int done;
+};
+
+#define PNP_HYP 100
+#define PNP_MAXN 2048
+#define PNP_GRAM_MAXN 256   // refit uses the MFMA Gram build up to this many points
+
+// LDS workspace of one pose workgroup (dynamic shared memory: > 64 KB, needs the per-function opt-in)
+struct PoseLds {
+  double arow[(2 * GRAM_MAXN + 64) * GRAM_STRIDE];
+  double gram[4 * 64 + 4];
+  double red[5 * 28];
+  LmShared sh;
+  double K[4];
+  // PnP
+  Se3 hyp[PNP_HYP];
+  int hcnt[PNP_HYP];
+  uint8_t use[PNP_MAXN];
+  Se3 cur;
+  int s_best, s_ok, s_stop, s_nin;
+};
+
+// Pose-only LM.  T: row-major 4x4 in/out (global or LDS); stats may be null.
+__device__ __forceinline__ void pose_opt_block(PoseLds& L, const double* __restrict__ Xw, const double* __restrict__ obs, int n,
+                                               const double* __restrict__ Kp, double* T, svo_lm_stats* stats,
+                                               int round_in_f32, int use_mfma) {
+  if (n > GRAM_MAXN) use_mfma = 0;
+  double* arow = L.arow; double* gram = L.gram; double* red = L.red; LmShared& sh = L.sh; double* K = L.K;
+  const int tid = threadIdx.x;
+  const double delta = (double)(float)sqrt(5.991);
+  const double dsqr = delta * delta;
+  __syncthreads();
+  if (tid < 4) K[tid] = Kp[tid];
+  if (tid == 0) {
+    if (round_in_f32) {  // the reference stores the PnP pose as CV_32F before optimising it
+      double Tf[16];
+      for (int j = 0; j < 16; ++j) Tf[j] = (double)(float)T[j];
+      se3_from_T(Tf, sh.est);
+    } else {
+      se3_from_T(T, sh.est);
+    }
+    for (int j = 0; j < 6; ++j) sh.x[j] = 0;
+    sh.done = 0;
+  }
+  __syncthreads();
+  // scalar LM state lives in thread 0's registers
+  double lambda = -1., ni = 2., currentChi = 0, chi_init = 0;
+  int nBad = 0, iters = 0, trials_total = 0, terminated = 0;
+  if (n <= 0) {
+    if (tid == 0 && stats) {
+      stats->n_edges = 0; stats->iterations = 0; stats->trials_total = 0; stats->terminated = 0;
+      stats->chi2_initial = 0; stats->chi2_final = 0; stats->lambda_final = 0;
+    }
+    return;
+  }
+  for (int it = 0; it < 10; ++it) {
+    double acc[28];
+    const Se3 est = sh.est;
+    if (use_mfma) {
+      build_system_mfma<true>(est, Xw, obs, n, nullptr, K, delta, dsqr, arow, gram, red);
+    } else {
+      accum_system<true>(est, Xw, obs, n, nullptr, K, delta, dsqr, acc);
+      block_reduce<28>(acc, red);
+    }
+    double H[36], b[6], iniChi = 0, rho = 0;
+    int qmax = 0;
+    if (tid == 0) {
+      unpack_system(red, H, b);
+      currentChi = red[27];
+      iniChi = currentChi;
+      if (it == 0) {
+        chi_init = currentChi;
+        double maxDiag = 0;
+        for (int j = 0; j < 6; ++j) maxDiag = fmax(fabs(H[7 * j]), maxDiag);
+        lambda = 1e-5 * maxDiag;
+        ni = 2;
+        nBad = 0;
+      }
+    }
+    // inner trial loop: thread 0 proposes, everyone evaluates chi2
+    for (int trial = 0; trial < 10; ++trial) {
+      int ok2 = 0;
+      if (tid == 0) {
+        sh.backup = sh.est;
+        double Hl[36];
+#pragma unroll
+        for (int j = 0; j < 36; ++j) Hl[j] = H[j];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) Hl[7 * j] += lambda;
+        double xloc[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) xloc[j] = sh.x[j];
+        ok2 = ldlt6_solve(Hl, b, xloc);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) sh.x[j] = xloc[j];
+        Se3 e2 = sh.est;
+        se3_oplus(xloc, e2);
+        sh.est = e2;
+      }
+      __syncthreads();
+      const Se3 trial_est = sh.est;
+      double c1[1] = {partial_chi2(trial_est, Xw, obs, n, K, delta, dsqr)};
+      block_reduce<1>(c1, red);
+      if (tid == 0) {
+        double tempChi = red[0];
+        if (!ok2) tempChi = 1.7976931348623157e308;
+        rho = currentChi - tempChi;
+        double scale = 0;
+        for (int j = 0; j < 6; ++j) scale += sh.x[j] * (lambda * sh.x[j] + b[j]);
+        scale += 1e-3;
+        rho /= scale;
+        if (rho > 0 && isfinite(tempChi)) {
+          const double v = 2 * rho - 1;
+          double alpha = 1. - v * v * v;
+          alpha = fmin(alpha, 2. / 3.);
+          const double scaleFactor = fmax(1. / 3., alpha);
+          lambda *= scaleFactor;
+          ni = 2;
+          currentChi = tempChi;
+        } else {
+          lambda *= ni;
+          ni *= 2;
+          sh.est = sh.backup;
+        }
+        ++qmax;
+        ++trials_total;
+        sh.go = (rho < 0 && qmax < 10) ? 1 : 0;
+      }
+      __syncthreads();
+      if (!sh.go) break;
+    }
+    if (tid == 0) {
+      ++iters;
+      int stop = 0;
+      if (qmax == 10 || rho == 0) stop = 1;
+      else {
+        if ((iniChi - currentChi) * 1e3 < iniChi) ++nBad; else nBad = 0;
+        if (nBad >= 3) stop = 1;
+      }
+      if (stop) terminated = 1;
+      sh.done = stop;
+    }
+    __syncthreads();
+    if (sh.done) break;
+  }
+  if (tid == 0) {
+    se3_to_T(sh.est, T);
+    if (stats) {
+      stats->n_edges = n; stats->iterations = iters; stats->trials_total = trials_total;
+      stats->terminated = terminated; stats->chi2_initial = chi_init;
+      stats->chi2_final = currentChi; stats->lambda_final = lambda;
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t lcg_next(uint64_t& s) {
+  s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+  return (uint32_t)(s >> 33);
+}
+
+// PnP-RANSAC.  Tprior / T: row-major 4x4; inlier_mask (n bytes) and stats may be null.
+__device__ __forceinline__ void pnp_ransac_block(PoseLds& L, const double* __restrict__ Xw, const double* __restrict__ obs, int n,
+                                                 const double* __restrict__ Kp, const double* Tprior, uint64_t seed, double* T,
+                                                 uint8_t* inlier_mask, svo_pnp_stats* stats, int use_mfma) {
+  Se3* hyp = L.hyp; int* hcnt = L.hcnt; double* arow = L.arow; double* gram = L.gram; uint8_t* use = L.use;
+  double* red = L.red; Se3& cur = L.cur; double* K = L.K;
+  int& s_best = L.s_best; int& s_ok = L.s_ok; int& s_stop = L.s_stop; int& s_nin = L.s_nin;
+  const int tid = threadIdx.x;
+  __syncthreads();
+  if (tid < 4) K[tid] = Kp[tid];
+  if (tid < PNP_HYP) hcnt[tid] = -1;
+  __syncthreads();
+  Se3 prior;
+  se3_from_T(Tprior, prior);
+  // one thread per hypothesis: sample 5 points, 6 Gauss-Newton steps from the prior
+  if (tid < PNP_HYP && n >= 5) {
+    uint64_t s = seed ^ ((uint64_t)(tid + 1) * 0x9E3779B97F4A7C15ULL);
+    lcg_next(s);
+    int idx[5] = {-1, -1, -1, -1, -1}, got = 0, draws = 0;
+    while (got < 5 && draws < 64) {
+      const int c = (int)(lcg_next(s) % (uint32_t)n);
+      ++draws;
+      bool dup = false;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) dup |= (j < got) && idx[j] == c;
+      if (!dup) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+          if (j == got) idx[j] = c;
+        ++got;
+      }
+    }
+    if (got == 5) {
+      Se3 est = prior;
+      bool active = true;   // per-hypothesis early stop (max|dx| < 1e-10), same rule as the refit
+      for (int it = 0; it < 6 && active; ++it) {
+        double H[36], b[6], x[6];
+#pragma unroll
+        for (int j = 0; j < 36; ++j) H[j] = 0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) b[j] = 0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const int i = idx[k];
+          double e[2], pc[3], J[12];
+          edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc);
+          edge_jacobian(pc, K, J);
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            b[r] -= J[r] * e[0] + J[6 + r] * e[1];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) H[6 * r + c] += J[r] * J[c] + J[6 + r] * J[6 + c];
+          }
+        }
+        if (!ldlt6_solve(H, b, x)) break;
+        bool fin = true;
+        double xmax = 0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { fin = fin && isfinite(x[j]); xmax = fmax(xmax, fabs(x[j])); }
+        if (!fin) break;
+        se3_oplus(x, est);
+        if (xmax < 1e-10) active = false;
+      }
+      hyp[tid] = est;
+      hcnt[tid] = 0;
+    }
+  }
+  __syncthreads();
+  // consensus: all threads score (hypothesis, point) pairs
+  if (n >= 5) {
+    for (int p = tid; p < PNP_HYP * n; p += 256) {
+      const int k = p / n, i = p - k * n;
+      if (hcnt[k] < 0) continue;
+      double e[2], pc[3];
+      edge_error(hyp[k], Xw + 3 * i, obs + 2 * i, K, e, pc);
+      if (pc[2] > 0.0 && e[0] * e[0] + e[1] * e[1] <= 64.0) atomicAdd(&hcnt[k], 1);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int best = -1, bk = -1;
+    for (int k = 0; k < PNP_HYP; ++k)
+      if (hcnt[k] > best) { best = hcnt[k]; bk = k; }
+    s_best = bk;
+    s_ok = best >= 5 ? 1 : 0;
+    cur = s_ok ? hyp[bk] : prior;
+  }
+  __syncthreads();
+  if (s_ok) {
+    const Se3 be = cur;
+    for (int i = tid; i < n; i += 256) {
+      double e[2], pc[3];
+      edge_error(be, Xw + 3 * i, obs + 2 * i, K, e, pc);
+      use[i] = (pc[2] > 0.0 && e[0] * e[0] + e[1] * e[1] <= 64.0) ? 1 : 0;
+    }
+    __syncthreads();
+    for (int it = 0; it < 10; ++it) {
+      double acc[28];
+      const Se3 est = cur;
+      if (use_mfma && n <= PNP_GRAM_MAXN) {
+        build_system_mfma<false>(est, Xw, obs, n, use, K, 0, 0, arow, gram, red);
+      } else {
+        accum_system<false>(est, Xw, obs, n, use, K, 0, 0, acc);
+        block_reduce<28>(acc, red);
+      }
+      if (tid == 0) {
+        double H[36], b[6], x[6];
+        unpack_system(red, H, b);
+        int stop = 0;
+        if (!ldlt6_solve(H, b, x)) stop = 1;
+        else {
+          bool fin = true;
+          double xmax = 0;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) { fin = fin && isfinite(x[j]); xmax = fmax(xmax, fabs(x[j])); }
+          if (!fin) stop = 1;
+          else {
+            Se3 e2 = cur; se3_oplus(x, e2); cur = e2;
+            if (xmax < 1e-10) stop = 1;   // converged
+          }
+        }
+        s_stop = stop;
+      }
+      __syncthreads();
+      if (s_stop) break;
+    }
+  }
+  if (tid == 0) s_nin = 0;
+  __syncthreads();
+  {
+    const Se3 fe = cur;
+    int c = 0;
+    for (int i = tid; i < n; i += 256) {
+      int in = 0;
+      if (s_ok) {
+        double e[2], pc[3];
+        edge_error(fe, Xw + 3 * i, obs + 2 * i, K, e, pc);
+        in = (pc[2] > 0.0 && e[0] * e[0] + e[1] * e[1] <= 64.0) ? 1 : 0;
+      }
+      if (inlier_mask) inlier_mask[i] = (uint8_t)in;
+      c += in;
+    }
+    if (c) atomicAdd(&s_nin, c);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    se3_to_T(cur, T);
+    if (stats) {
+      stats->n_points = n; stats->n_inliers = s_nin; stats->best_hypothesis = s_ok ? s_best : -1;
+      stats->ok = s_ok;
+    }
+  }
+}

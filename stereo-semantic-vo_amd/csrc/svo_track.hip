@@ -1,86 +1,126 @@
 // svo_track.hip - Tracking::Track (reference src/Tracking.cc:180-252) with all state in HBM.
 //
-// The ordered tail of a frame - Tracking::init / pnpmatch::poseEstimationPnP passes 1 and 2
-// (src/pnpmatch.cc:61-199), the PnP initial pose (:212-247), Optimizer::PoseOptimization
-// (src/Optimizer.cc:15-86), frame::createmappoint (src/frame.cc:182-238) and the local-map
-// cull (src/Tracking.cc:239-250) - runs as nine small launches per frame with no host
-// round trip: sizes, the frame counter and the map-point pool all live in one TrackState
-// block.  The map-point pool is a structure of arrays kept in creation order (the
-// deterministic stand-in for the reference's std::set<mappoint*> address order); after each
-// frame it is stably compacted into the other half of a ping-pong buffer, so "local map
-// point r" is simply row r and the pass-2 distance matrix needs no gather.
-// The reference also stores match_score[i] = second/best for every pass-1 row
-// (src/pnpmatch.cc:99); nothing ever reads it (its only use is commented out at
-// src/Optimizer.cc:54), so the tracker does not materialise it - svo_match_greedy does.
-// Offline detection boxes (main.cpp:82-95) gate the path exactly where the reference uses them:
-// the +-5 px creation gates (src/Tracking.cc:61-66 with its never-reset flag, src/frame.cc:198-203)
-// and the +-10 px epipolar veto of pass 1 (src/pnpmatch.cc:101-144) with F from the 8-point
-// algorithm over brute-force matches (src/pnpmatch.cc:302-337; svo_fmat.hip, host side).
+// The ordered tail of a frame is TWO chains that meet only through map-point identities:
+//
+//   index chain (pose-free)                         pose chain
+//   -----------------------                         ----------
+//   Tracking::init            src/Tracking.cc:42-97   gather 3D-2D correspondences   src/pnpmatch.cc:216-224
+//   pnpmatch pass 1 + veto    src/pnpmatch.cc:61-156  cv::solvePnPRansac             src/pnpmatch.cc:227
+//   pnpmatch pass 2           src/pnpmatch.cc:159-199 Optimizer::PoseOptimization    src/Optimizer.cc:15-86
+//   frame::createmappoint     src/frame.cc:182-238    SetPose, UnprojectStereo of    src/frame.cc:66-73,166-180
+//   local-map cull            src/Tracking.cc:239-250   the points created this frame
+//
+// In the reference, matching never reads the pose: pnpmatch::poseEstimationPnP compares descriptors and
+// `MapPoints[j]` only (Rcw/tcw at src/pnpmatch.cc:56-57 are unused), the epipolar veto takes F from brute-force
+// matches, and which map points exist / are culled depends on descriptors, depth > 0, boxes and frame ids.  The pose
+// only decides WHERE a new map point lies - which only later PnP / LM calls consume.  So the index chain runs ahead
+// on its own HIP stream (two launches per frame: k_ti_lists, k_ti_resolve) and hands each frame's correspondences to
+// the pose chain as map-point ids (`TrackWork`); the pose chain (ONE launch per frame: k_tp_frame) follows on the
+// context stream and keeps the positions in a table indexed by map-point id.  Results are what the single ordered
+// chain produces, record for record.
+//
+// Index chain, per frame:
+//   k_ti_lists    every live map point (pool row) against the frame's keypoints: Hamming distances, and per row a
+//                 SPARSE candidate list - the columns with distance < 60 in column order.  Nothing else can matter:
+//                 a row is accepted only with best < 30 (pass 2; < 15 in pass 1), and the runner-up only decides the
+//                 ratio test `second / best > 2`, i.e. only while second <= 2 * best <= 58.
+//   k_ti_resolve  one workgroup: frame begin, both order-dependent greedy passes, createmappoint, cull, compaction.
+//                 The greedy passes (rows in order, each claims its best unclaimed column) are resolved in ROUNDS:
+//                 every unresolved row evaluates its list against the claims made so far and publishes the columns
+//                 it could still claim; a row is final as soon as no EARLIER unresolved row can claim a column its
+//                 result depends on.  The first unresolved row is always final, so the rounds terminate; on real
+//                 frames a pass takes 2-5 rounds instead of hundreds of serial steps.
+// The map-point pool is a structure of arrays kept in creation order (the deterministic stand-in for the reference's
+// std::set<mappoint*> address order); after each frame it is stably compacted into the other half of a ping-pong
+// buffer, so "local map point r" is simply row r.
+// The reference also stores match_score[i] = second/best for every pass-1 row (src/pnpmatch.cc:99); nothing ever
+// reads it (its only use is commented out at src/Optimizer.cc:54), so the tracker does not materialise it -
+// svo_match_greedy does.
+// Offline detection boxes (main.cpp:82-95) gate the path exactly where the reference uses them: the +-5 px creation
+// gates (src/Tracking.cc:61-66 with its never-reset flag, src/frame.cc:198-203) and the +-10 px epipolar veto of
+// pass 1 (src/pnpmatch.cc:101-144) with F from the 8-point algorithm over brute-force matches
+// (src/pnpmatch.cc:302-337; svo_fmat.hip, host side).
 #include <cstddef>
 
 #include "svo_internal.h"
 #include "svo_wave.h"
 #include "svo_gate.h"
+#include "svo_pose_dev.h"
 
 #define TRK_MAXKP 512
 #define TRK_CAP 4096
+#define TRK_ROWS_MAX 3072        // live rows k_ti_lists can meet: 4 frames of local points + the last frame's, + slack
+#define TRK_LCAP 16              // entries of a row's sparse candidate list
+#define TRK_LIST_T 60            // list threshold: distances >= 60 cannot influence any decision (see above)
+#define TRK_GPOS (1 << 20)       // map-point position table: ring over map-point ids
+#define TRK_DENSE 0xFF           // ncand marker: more than `lcap` candidates, the row's distances are in D
 
 struct TrackPool {
-  float pos[TRK_CAP * 3];
   uint32_t desc[TRK_CAP * 8];
   int32_t create_id[TRK_CAP];
-  int32_t obs_frame[TRK_CAP];
+  int32_t gid[TRK_CAP];          // map-point id = creation sequence number; positions live in gpos[gid % TRK_GPOS]
   uint8_t bad[TRK_CAP];
   uint8_t in_local[TRK_CAP];
 };
 
+// What the index chain hands to the pose chain for one frame.
+struct TrackWork {
+  int32_t frame_id, nkp, n_stereo, n_pass1, n_pass2, n_new, n_local, skip_match;
+  int32_t diag[2];               // [0] rows of pass 1 | rounds << 16, [1] rows of pass 2 | rows resolved after round 1 << 16
+  int32_t edge_gid[TRK_MAXKP];   // per keypoint: id of the map point matched to it (CurrentFrame->MapPoints[j]) or -1
+  int32_t new_gid[TRK_MAXKP];    // per keypoint: id of the map point created from it at the frame's end, or -1
+};
+
 struct TrackState {
+  // ---- index chain -------------------------------------------------------------------------
   int32_t frame_num, npool, lastN, cur;      // cur: active half of the pool ping-pong
-  int32_t nkp, m1, m2, n_edges, skip_match;
-  int32_t n_pass1, n_pass2, n_new, n_stereo;
-  int32_t n_rows1, n_rows2, n_slow2;         // rows the serial passes visited / re-scanned (diagnostics)
-  float lastTcw[16];
+  int32_t next_gid, overflow, n_vetoed, n_boxes;
   int32_t last_mp[TRK_MAXKP];
-  int32_t cur_mp[TRK_MAXKP];
   int32_t dbg_cur_mp[TRK_MAXKP];
-  uint8_t assigned[TRK_MAXKP];
-  double Xw[TRK_MAXKP * 3], obs[TRK_MAXKP * 2], K[4], Tprior[16], T[16];
-  svo_lm_stats lm;
-  svo_pnp_stats pnp;
   svo_camera cam;
-  // semantic gating state
-  int32_t n_boxes, n_vetoed;
   int32_t boxes[SVO_MAX_BOXES * 4];    // {left, right, top, bottom} of the current frame
   double F[9];                         // fundamental matrix cur <- last (row-major)
   float last_xy[TRK_MAXKP * 2];        // LastFrame.keypoints_l[i].pt
   uint32_t last_desc[TRK_MAXKP * 8];   // LastFrame.f_descriptor
   int32_t bf_idx[TRK_MAXKP], bf_dist[TRK_MAXKP], bf_min;
   uint8_t bf_keep[TRK_MAXKP];
+  // ---- pose chain --------------------------------------------------------------------------
+  float lastTcw[16];
+  double Xw[TRK_MAXKP * 3], obs[TRK_MAXKP * 2], K[4], Tprior[16], T[16];
+  svo_lm_stats lm;
+  svo_pnp_stats pnp;
+  // ---- large arrays (not cleared by a reset) -----------------------------------------------
   TrackPool pool[2];
-  uint16_t rowmin[TRK_CAP];    // min over ALL current keypoints of the row's distances
-  uint8_t active[TRK_CAP];     // row takes part in the greedy pass (valid && rowmin < threshold)
-  uint2 pre[TRK_CAP];          // speculative row result under the claims at pass start:
-                               //   x = best<<16 | idx, y = second<<16 | idx_of_second (0xffff: none)
-  uint16_t D[(size_t)TRK_CAP * 512];
+  uint16_t rowmin[TRK_CAP];                // min over ALL current keypoints of the row's distances
+  uint8_t ncand[TRK_CAP];                  // entries in the row's candidate list, or TRK_DENSE
+  uint32_t cand[(size_t)TRK_CAP * TRK_LCAP];   // dist << 16 | column, columns ascending
+  uint16_t D[(size_t)TRK_CAP * 512];       // full distance rows of the (rare) rows whose list overflowed
+  float gpos[(size_t)TRK_GPOS * 3];        // pose chain: world position of map point gid
 };
 
-__device__ __forceinline__ uint32_t tk_wmin(uint32_t v) { return wave_min_u32_dpp(v); }
-
-// exclusive scan of one int per thread over a 512-thread block; returns the total in *total
-__device__ __forceinline__ int block_excl_scan512(int v, int* sm /*[512]*/, int* total) {
-  const int tid = threadIdx.x;
-  sm[tid] = v;
-  __syncthreads();
-  for (int o = 1; o < 512; o <<= 1) {
-    const int t = tid >= o ? sm[tid - o] : 0;
-    __syncthreads();
-    sm[tid] += t;
-    __syncthreads();
+// ---- block-wide exclusive scan (blockDim.x = 256 or 1024) -------------------------------------
+__device__ __forceinline__ int tk_wave_incl_scan(int v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(v, o, 64);
+    if ((int)(threadIdx.x & 63) >= o) v += t;
   }
-  const int incl = sm[tid];
-  *total = sm[511];
+  return v;
+}
+__device__ __forceinline__ int block_excl_scan(int v, int* sm /*[16]*/, int* total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int incl = tk_wave_incl_scan(v);
   __syncthreads();
-  return incl - v;
+  if (lane == 63) sm[wv] = incl;
+  __syncthreads();
+  int off = 0, tot = 0;
+  for (int w = 0; w < nw; ++w) {
+    const int s = sm[w];
+    off += w < wv ? s : 0;
+    tot += s;
+  }
+  *total = tot;
+  return off + incl - v;
 }
 
 __device__ __forceinline__ void tk_unproject(const svo_camera& cam, float u, float v, float z,
@@ -95,95 +135,24 @@ __device__ __forceinline__ void tk_unproject(const svo_camera& cam, float u, flo
   }
 }
 
-// ---- 1. frame begin: reset per-frame state; frame 0 runs Tracking::init -------------------
-// Every tail kernel serves one sequence per blockIdx.y: TrackState number blockIdx.y and frame slot
-// blockIdx.y of the front-end buffers (`kstride` keypoints per slot).  A single sequence is grid.y = 1.
-#define TK_SEQ_SELECT(kstride)                                   \
-  st += blockIdx.y;                                              \
-  kp += (size_t)blockIdx.y * (kstride);
-
-__global__ __launch_bounds__(512) void k_tk_begin(TrackState* st, const svo_kp* kp,
-                                                  const uint32_t* desc, const int32_t* nkp_p,
-                                                  const float* depth, int kstride) {
-  __shared__ int sm[512];
-  TK_SEQ_SELECT(kstride)
-  desc += (size_t)blockIdx.y * kstride * 8; nkp_p += blockIdx.y; depth += (size_t)blockIdx.y * kstride;
-  const int tid = threadIdx.x;
-  const int nkp = min(*nkp_p, TRK_MAXKP);
-  TrackPool& P = st->pool[st->cur];
-  st->cur_mp[tid] = -1;
-  st->assigned[tid] = 0;
-  const bool has_depth = tid < nkp && depth[tid] > 0.f;
-  int n_stereo;
-  block_excl_scan512(has_depth ? 1 : 0, sm, &n_stereo);
-  // Tracking::init's `dynamic` flag is declared outside the keypoint loop and never reset
-  // (src/Tracking.cc:44): once a keypoint falls into a padded box, every later one is skipped.
-  bool create0 = has_depth;
-  if (st->frame_num == 0 && st->n_boxes > 0) {
-    const svo_kp k = kp[min(tid, max(nkp - 1, 0))];
-    const bool inb = tid < nkp && svo_in_boxes(k.x, k.y, st->boxes, st->n_boxes, 5);
-    int tot_in;
-    const int before = block_excl_scan512(inb ? 1 : 0, sm, &tot_in);
-    if (before + (inb ? 1 : 0) > 0) create0 = false;
-  }
-  int total;
-  const int rank = block_excl_scan512(create0 ? 1 : 0, sm, &total);
-  if (tid == 0) {
-    st->nkp = nkp;
-    st->n_stereo = n_stereo;
-    st->n_pass1 = 0; st->n_pass2 = 0; st->n_new = 0; st->n_vetoed = 0;
-    for (int i = 0; i < 4; ++i) st->K[i] = (double)((const float*)&st->cam)[i];
-    for (int i = 0; i < 16; ++i) st->Tprior[i] = (double)st->lastTcw[i];
-  }
-  if (st->frame_num == 0) {
-    // Tracking::init (src/Tracking.cc:42-97): pose I, one map point per keypoint with depth
-    if (create0) {
-      const int m = st->npool + rank;
-      const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3[3] = {0, 0, 0};
-      const svo_kp k = kp[tid];
-      tk_unproject(st->cam, k.x, k.y, depth[tid], I3, z3, &P.pos[3 * m]);
-#pragma unroll
-      for (int w = 0; w < 8; ++w) P.desc[8 * m + w] = desc[8 * tid + w];
-      P.bad[m] = 0; P.in_local[m] = 1; P.create_id[m] = 0; P.obs_frame[m] = -1;
-      st->cur_mp[tid] = m;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      st->npool += total;
-      st->n_new = total;
-      st->skip_match = 1; st->m1 = 0; st->m2 = 0;
-      for (int i = 0; i < 16; ++i) st->Tprior[i] = (i % 5 == 0) ? 1.0 : 0.0;
-    }
-  } else if (tid == 0) {
-    st->skip_match = 0;
-    st->m1 = st->lastN;
-    st->m2 = st->npool;
-  }
-}
-
-// ---- 2/4. distance matrix rows of one pass ------------------------------------------------
-// pass 1: row i <-> last frame's keypoint i (map point last_mp[i]); pass 2: row r <-> pool row r.
-// Also decides, in parallel, which rows the serial pass must visit: a row can only be accepted
-// if its best distance over the unclaimed columns is < max_dist; the minimum over ALL columns
-// bounds that from below, so rows failing it never claim a column and are dropped.
-// TKD_ROWS map-point rows per workgroup: 4 (one per wave) for a single sequence, where the chain's latency counts and
-// every row should get its own wave at once; 16 when many sequences are advanced together and the staging of the
-// keypoint descriptors is worth sharing
-template <int TKD_ROWS>
-__global__ __launch_bounds__(256) void k_tk_dist(TrackState* st, const uint32_t* desc, int pass, int kstride) {
+// ================================================================================================
+// Index chain 1/2: distances of every live pool row to the frame's keypoints -> sparse candidate lists
+// ================================================================================================
+// One wave per row.  ROWS map-point rows per workgroup: 4 (one per wave) for a single sequence, where the chain's
+// latency counts; 16 when many sequences are advanced together and the staging of the keypoint descriptors is worth
+// sharing.  blockIdx.y = sequence (TrackState number, frame slot of the front-end buffers).
+template <int ROWS>
+__global__ __launch_bounds__(256) void k_ti_lists(TrackState* st, const uint32_t* desc, const int32_t* nkp_p, int kstride,
+                                                  int lcap) {
   // descriptors of the frame's keypoints, TRANSPOSED: word k of keypoint j at td[k * TRK_MAXKP + j], so that the 64 lanes
   // of a wave (64 consecutive keypoints) read 64 consecutive LDS words
   __shared__ uint32_t td[8 * TRK_MAXKP];
-  st += blockIdx.y; desc += (size_t)blockIdx.y * kstride * 8;
+  st += blockIdx.y; desc += (size_t)blockIdx.y * kstride * 8; nkp_p += blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int M = st->skip_match ? 0 : (pass == 1 ? st->m1 : st->m2);
-  const int row0 = blockIdx.x * TKD_ROWS;
-  if (row0 >= M) {
-    if (tid < TKD_ROWS && row0 + tid < TRK_CAP) st->active[row0 + tid] = 0;
-    return;
-  }
-  const int nkp = st->nkp, id = st->frame_num;
-  const int max_dist = pass == 1 ? 15 : 30;
+  const int npool = st->npool;
+  const int row0 = blockIdx.x * ROWS;
+  if (row0 >= npool) return;
+  const int nkp = min(*nkp_p, TRK_MAXKP);
   const TrackPool& P = st->pool[st->cur];
   {
     // 16-byte loads, all four of a thread in flight together
@@ -202,26 +171,17 @@ __global__ __launch_bounds__(256) void k_tk_dist(TrackState* st, const uint32_t*
     }
   }
   __syncthreads();
-  for (int rr = 0; rr < TKD_ROWS / 4; ++rr) {
-    const int row = row0 + wv * (TKD_ROWS / 4) + rr;
-    if (row >= TRK_CAP) break;
-    bool valid = row < M;
-    int m = row;
-    if (valid) {
-      if (pass == 1) {
-        m = st->last_mp[row];
-        valid = m >= 0 && !P.bad[m];
-      } else {
-        valid = P.in_local[m] && !P.bad[m] && P.obs_frame[m] != id;
-      }
-    }
-    if (!valid) {
-      if (lane == 0) st->active[row] = 0;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  for (int rr = 0; rr < ROWS / 4; ++rr) {
+    const int row = row0 + wv * (ROWS / 4) + rr;
+    if (row >= npool) break;
+    if (P.bad[row]) {
+      if (lane == 0) { st->rowmin[row] = 0x7fff; st->ncand[row] = 0; }
       continue;
     }
     uint32_t qd[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) qd[k] = P.desc[8 * m + k];
+    for (int k = 0; k < 8; ++k) qd[k] = P.desc[8 * row + k];
     uint32_t mn = 0x7fff;
     int dcol[8];
 #pragma unroll
@@ -235,373 +195,506 @@ __global__ __launch_bounds__(256) void k_tk_dist(TrackState* st, const uint32_t*
       }
       dcol[t] = d;
       mn = min(mn, (uint32_t)d);
-      st->D[(size_t)row * 512 + j] = (uint16_t)d;
     }
-    mn = tk_wmin(mn);
-    if (lane == 0) {
-      st->rowmin[row] = (uint16_t)mn;
-      st->active[row] = (int)mn < max_dist ? 1 : 0;
-    }
-    if ((int)mn >= max_dist) continue;
-    // Speculative result of this row under the claims at the START of the pass (pass 1: none,
-    // pass 2: what pass 1 claimed).  Keys (dist<<16 | j) order by distance, then by column, so the
-    // wave minimum is the reference's strict-`<` scan result (first minimum) and the minimum over
-    // the columns before it is the "runner-up" (src/pnpmatch.cc:89-94) together with its column.
-    uint32_t kb = 0xffffffffu;
-    uint32_t keys[8];
+    mn = wave_min_u32_dpp(mn);
+    // candidates in column order: piece t holds columns 64 t .. 64 t + 63, lanes ascending
+    int base = 0;
+    uint32_t* lst = st->cand + (size_t)row * TRK_LCAP;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      const int j = lane + 64 * t;
-      uint32_t key = 0xffffffffu;
-      if (j < nkp && !(pass == 2 && st->assigned[j])) key = ((uint32_t)dcol[t] << 16) | (uint32_t)j;
-      keys[t] = key;
-      kb = min(kb, key);
+      const bool c = dcol[t] < TRK_LIST_T;
+      const uint64_t m = __ballot(c);
+      const int pos = base + __popcll(m & lt_mask);
+      if (c && pos < lcap) lst[pos] = ((uint32_t)dcol[t] << 16) | (uint32_t)(lane + 64 * t);
+      base += __popcll(m);
     }
-    kb = tk_wmin(kb);
-    uint32_t ks = 0xffffffffu;
-    const uint32_t bj = kb & 0xffffu;
+    if (base > lcap) {   // rare: keep the whole row instead
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
-      if ((keys[t] & 0xffffu) < bj) ks = min(ks, keys[t]);
-    ks = tk_wmin(ks);
+      for (int t = 0; t < 8; ++t) st->D[(size_t)row * 512 + lane + 64 * t] = (uint16_t)dcol[t];
+    }
     if (lane == 0) {
-      const uint32_t y = ks == 0xffffffffu ? ((256u << 16) | 0xffffu) : ks;
-      // bit 31 of x: the row would be accepted with this (speculative) result
-      const int bd = (int)(kb >> 16), sec = (int)(y >> 16);
-      bool ok = (kb & 0xffffu) != 0xffffu && bd < max_dist;
-      if (ok && pass == 2) ok = (float)sec / (float)bd > 2.f;
-      st->pre[row] = make_uint2(kb | (ok ? 0x80000000u : 0u), y);
+      st->rowmin[row] = (uint16_t)mn;
+      st->ncand[row] = (uint8_t)(base > lcap ? TRK_DENSE : base);
     }
   }
 }
 
-// ---- 3/5. the order-dependent greedy assignment, one wave -----------------------------------
-// The row flags written by k_tk_dist are loaded in ONE round trip (64 bytes per lane), compacted
-// in order into LDS with a wave prefix sum, and the surviving rows are walked with an 8-deep
-// register prefetch of their distance rows, so the serial chain pays ALU time, not an L2 round
-// trip, per row.  Lane L owns columns 8L..8L+7 and keeps their claim bits in a register.
-__device__ __forceinline__ int tk_wave_incl_scan(int v) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(v, o, 64);
-    if ((int)(threadIdx.x & 63) >= o) v += t;
-  }
-  return v;
-}
+// ================================================================================================
+// Index chain 2/2: everything order-dependent of one frame, one 1024-thread workgroup per sequence
+// ================================================================================================
+struct TiLds {
+  int sm[32];
+  int32_t cur_mp[TRK_MAXKP];       // CurrentFrame->MapPoints as pool rows
+  uint32_t minrow[TRK_MAXKP];      // per column: lowest unresolved row that could still claim it
+  uint16_t claimer[TRK_MAXKP];     // who took the column: 0 = taken before the pass (or beyond nkp), k + 1 = active row k of
+                                   // this pass, 0xffff = free.  Row k sees a column as free iff claimer > k + 1: a LATER row's
+                                   // claim must stay invisible to the earlier rows that are still unresolved
+  uint16_t pend[TRK_MAXKP];        // claims of the running round (k + 1)
+  uint16_t act_m[TRK_CAP];         // active row k -> pool row
+  uint16_t act_i[TRK_MAXKP];       // pass 1: active row k -> last-frame keypoint index
+  uint8_t act_n[TRK_CAP];          // its list length / TRK_DENSE
+  uint8_t fin[TRK_CAP];            // row resolved
+  uint8_t observed[TRK_CAP];       // pool row matched in pass 1 (observations.count(CurrentFrame))
+  uint8_t ref[TRK_CAP];            // pool row referenced by the frame's keypoints (kept alive for the next pass 1)
+  int16_t remap[TRK_CAP];          // pool row -> row after compaction
+  int cnt_acc, cnt_veto, cnt_late;
+  uint32_t ll[1024 * TRK_LCAP];    // candidate lists of the first 1024 active rows
+};
 
-__global__ __launch_bounds__(64) void k_tk_greedy(TrackState* st, int pass, const svo_kp* kp, int kstride) {
-  TK_SEQ_SELECT(kstride)
-  __shared__ int16_t rows[TRK_CAP];
-  __shared__ int16_t rowmp[TRK_CAP];
-  __shared__ uint4 drow[32 * 64];   // distance rows of the current 32-row chunk (32 KB)
-  __shared__ uint8_t claimedB[512]; // columns claimed during THIS pass
-  const int lane = threadIdx.x;
-  const int M = pass == 1 ? st->m1 : st->m2;
-  if (M <= 0 || st->skip_match) return;
-  TrackPool& P = st->pool[st->cur];
-  const int nkp = st->nkp, id = st->frame_num;
-  const int max_dist = pass == 1 ? 15 : 30;
-  const float ratio = pass == 1 ? 0.f : 2.f;
-  // flags of rows 64*lane .. 64*lane+63
-  uint4 fl[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    fl[k] = make_uint4(0, 0, 0, 0);
-    if (64 * lane + 16 * k < M) fl[k] = *reinterpret_cast<const uint4*>(&st->active[64 * lane + 16 * k]);
-  }
-  const uint32_t fw[16] = {fl[0].x, fl[0].y, fl[0].z, fl[0].w, fl[1].x, fl[1].y, fl[1].z, fl[1].w,
-                           fl[2].x, fl[2].y, fl[2].z, fl[2].w, fl[3].x, fl[3].y, fl[3].z, fl[3].w};
-  int cnt = 0;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) cnt += __popc(fw[k] & 0x01010101u);
-  const int incl = tk_wave_incl_scan(cnt);
-  const int n = __shfl(incl, 63, 64);
-  int pos = incl - cnt;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int r = 64 * lane + 4 * k + b;
-      if (((fw[k] >> (8 * b)) & 1u) && r < M) rows[pos++] = (int16_t)r;
+// Visit the candidates of active row k in column order: f(column, distance).
+template <int PASS, typename F>
+__device__ __forceinline__ void ti_for_entries(const TiLds& S, const TrackState* st, int k, int nkp, F&& f) {
+  const int nc = S.act_n[k];
+  if (nc == TRK_DENSE) {
+    const uint16_t* Dr = st->D + (size_t)S.act_m[k] * 512;
+    for (int j = 0; j < nkp; ++j) {
+      const int d = Dr[j];
+      if (d < (PASS == 1 ? 15 : TRK_LIST_T)) f(j, d);
+    }
+  } else if (k < 1024) {
+    const uint32_t* e = &S.ll[k * TRK_LCAP];
+    for (int q = 0; q < nc; ++q) {
+      const uint32_t v = e[q];
+      if (PASS == 2 || (v >> 16) < 15u) f((int)(v & 0xffffu), (int)(v >> 16));
+    }
+  } else {
+    const uint32_t* e = st->cand + (size_t)S.act_m[k] * TRK_LCAP;
+    for (int q = 0; q < nc; ++q) {
+      const uint32_t v = e[q];
+      if (PASS == 2 || (v >> 16) < 15u) f((int)(v & 0xffffu), (int)(v >> 16));
     }
   }
-  __syncthreads();
-  for (int a = lane; a < n; a += 64) rowmp[a] = (int16_t)(pass == 1 ? st->last_mp[rows[a]] : rows[a]);
-  __syncthreads();
-  uint32_t claimed = 0;       // all claims (initial + this pass), columns 8*lane .. 8*lane+7
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int j = lane * 8 + k;
-    if (j >= nkp || st->assigned[j]) claimed |= 1u << k;
+}
+
+// The reference's scan `if (dist < best) { second = best; best = dist; idx = j; }` over the unclaimed columns in
+// index order (src/pnpmatch.cc:75-94), restricted to the candidates (see the file header for why that is exact).
+template <int PASS>
+__device__ __forceinline__ void ti_eval(const TiLds& S, const TrackState* st, int k, int nkp, int& bj, int& bd, int& sec) {
+  int b = 256, s2 = 256, j0 = -1;
+  ti_for_entries<PASS>(S, st, k, nkp, [&](int j, int d) {
+    if ((int)S.claimer[j] <= k + 1) return;
+    if (d < b) { s2 = b; b = d; j0 = j; }
+  });
+  bj = j0; bd = b; sec = s2;
+}
+
+// One greedy pass over the n_act active rows (S.act_*), in rounds.  Returns the number of rounds.
+template <int PASS>
+__device__ __forceinline__ int ti_resolve_pass(TiLds& S, TrackState* st, TrackPool& P, int n_act, int nkp,
+                                               const svo_kp* kp, int n_boxes) {
+  const int tid = threadIdx.x;
+  const int max_dist = PASS == 1 ? 15 : 30;
+  // lists of the first 1024 active rows into LDS (coalesced: 16 consecutive words per row)
+  for (int x = tid; x < min(n_act, 1024) * TRK_LCAP; x += 1024) {
+    const int k = x / TRK_LCAP, e = x % TRK_LCAP;
+    const int nc = S.act_n[k];
+    if (nc != TRK_DENSE && e < nc) S.ll[x] = st->cand[(size_t)S.act_m[k] * TRK_LCAP + e];
   }
-  const uint16_t* Dl = st->D + lane * 8;
-  int accepted_total = 0, n_slow = 0, n_veto = 0;
-  const int n_boxes = st->n_boxes;
-  // A row's speculative result (st->pre) stays valid unless one of the two columns it depends on -
-  // its best column or the column of its runner-up - was claimed during this pass: removing any
-  // other column cannot change a minimum that is still present.  So the only rows that can change
-  // any state are EVENTS: rows that would be accepted, and rows whose result went stale.  Each
-  // 32-row chunk is evaluated by 32 lanes in parallel against the claim bytes in LDS; the wave
-  // then jumps from event to event (ballot + ffs) instead of walking every row.
-  for (int j = lane; j < 512; j += 64) claimedB[j] = 0;
-  for (int a0 = 0; a0 < n; a0 += 32) {
-    const int cntb = min(32, n - a0);
-    const int mine = a0 + lane;
-    uint2 pv = make_uint2(0x0000ffffu, 0xffffffffu);
-    if (lane < cntb) pv = st->pre[rows[mine]];
-    __syncthreads();
-#pragma unroll 8
-    for (int k = 0; k < cntb; ++k) drow[k * 64 + lane] = *reinterpret_cast<const uint4*>(Dl + (size_t)rows[a0 + k] * 512);
-    __syncthreads();
-    const int my_bj = (int)(pv.x & 0xffffu), my_js = (int)(pv.y & 0xffffu);
-    const bool my_ok = (pv.x >> 31) != 0;
-    int start = 0;
-    for (;;) {
-      bool my_stale = false;
-      if (lane >= start && lane < cntb && my_bj != 0xffff)
-        my_stale = claimedB[my_bj] != 0 || (my_js != 0xffff && claimedB[my_js] != 0);
-      const bool my_event = lane >= start && lane < cntb && (my_stale || my_ok);
-      const uint64_t em = __ballot(my_event);
-      if (em == 0) break;
-      const int k = __ffsll((long long)em) - 1;              // first event row of the chunk
-      const bool stale = (__ballot(my_stale) >> k) & 1ull;
-      const uint32_t kb = __builtin_amdgcn_readlane((int)pv.x, k);
-      const uint32_t ks = __builtin_amdgcn_readlane((int)pv.y, k);
-      int bj = (int)(kb & 0xffffu), bd = (int)((kb >> 16) & 0x7fffu), sec = (int)(ks >> 16);
-      bool ok = (kb >> 31) != 0;
-      if (stale) {
-        ++n_slow;
-        const uint4 v = drow[k * 64 + lane];
-        const uint32_t cur[8] = {v.x & 0xffff, v.x >> 16, v.y & 0xffff, v.y >> 16,
-                                 v.z & 0xffff, v.z >> 16, v.w & 0xffff, v.w >> 16};
-        uint32_t lp = (256u << 16) | 0xffffu;
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-          if (!((claimed >> c) & 1u)) lp = min(lp, (cur[c] << 16) | (uint32_t)(lane * 8 + c));
-        const uint32_t bp = tk_wmin(lp);
-        bj = (int)(bp & 0xffffu); bd = (int)(bp >> 16);
-        uint32_t ls = 256;
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-          if (!((claimed >> c) & 1u) && lane * 8 + c < bj) ls = min(ls, cur[c]);
-        sec = (int)tk_wmin(ls);
-        ok = bj != 0xffff && bd < max_dist;
-        if (ok && ratio > 0.f) ok = (float)sec / (float)bd > ratio;
+  for (int k = tid; k < n_act; k += 1024) S.fin[k] = 0;
+  if (tid < TRK_MAXKP) { S.minrow[tid] = 0xffffffffu; S.pend[tid] = 0; }
+  __syncthreads();
+  int rounds = 0;
+  for (;;) {
+    // phase 1: every unresolved row publishes the columns it could still claim
+    int any = 0;
+    for (int k = tid; k < n_act; k += 1024) {
+      if (S.fin[k]) continue;
+      any = 1;
+      ti_for_entries<PASS>(S, st, k, nkp, [&](int j, int d) {
+        if ((int)S.claimer[j] > k + 1 && d < max_dist) atomicMin(&S.minrow[j], (uint32_t)k);
+      });
+    }
+    if (!__syncthreads_or(any)) break;
+    // phase 2: a row whose result no earlier unresolved row can change is final
+    for (int k = tid; k < n_act; k += 1024) {
+      if (S.fin[k]) continue;
+      int bj, bd, sec;
+      ti_eval<PASS>(S, st, k, nkp, bj, bd, sec);
+      if (bj < 0 || bd >= max_dist) { S.fin[k] = 1; continue; }   // claims only remove columns: never accepted
+      // accept rule: best < max_dist [&& (float)second / (float)best > 2, i.e. second > 2 * best in integers]
+      const bool ok = PASS == 1 || sec > 2 * bd;
+      bool safe = S.minrow[bj] >= (uint32_t)k;
+      if (safe && !ok) {
+        // rejected by the ratio test: becomes acceptable if the columns that hold `second` down get claimed
+        ti_for_entries<PASS>(S, st, k, nkp, [&](int j, int d) {
+          if (j < bj && (int)S.claimer[j] > k + 1 && d <= 2 * bd && S.minrow[j] < (uint32_t)k) safe = false;
+        });
       }
-      if (ok && pass == 1 && n_boxes > 0) {
-        // epipolar veto (src/pnpmatch.cc:103-144): the match lands in a padded box and is off
-        // the epipolar line -> the map point is marked bad and claims nothing
+      if (!safe) continue;
+      S.fin[k] = 1;
+      if (rounds > 0) atomicAdd(&S.cnt_late, 1);
+      if (!ok) continue;
+      const int m = S.act_m[k];
+      if (PASS == 1 && n_boxes > 0) {
+        // epipolar veto (src/pnpmatch.cc:103-144): the match lands in a padded box and is off the epipolar
+        // line -> the map point is marked bad and claims nothing
         const svo_kp kc = kp[bj];
-        const int i_last = rows[a0 + k];
+        const int i_last = S.act_i[k];
         if (svo_in_boxes(kc.x, kc.y, st->boxes, n_boxes, 10) &&
             svo_epipolar_distance(st->F, st->last_xy[2 * i_last], st->last_xy[2 * i_last + 1], kc.x, kc.y) > 0.1) {
-          if (lane == 0) P.bad[rowmp[a0 + k]] = 1;
-          ++n_veto;
-          ok = false;
+          P.bad[m] = 1;
+          atomicAdd(&S.cnt_veto, 1);
+          continue;
         }
       }
-      if (ok) {
-        if ((bj >> 3) == lane) claimed |= 1u << (bj & 7);
-        if (lane == 0) {
-          claimedB[bj] = 1;
-          const int m = rowmp[a0 + k];
-          st->cur_mp[bj] = m;
-          P.obs_frame[m] = id;
-        }
-        ++accepted_total;
-        __syncthreads();   // claimedB visible to the re-evaluation below
-      }
-      start = k + 1;
+      S.cur_mp[bj] = m;     // distinct rows finalised in one round never share a best column
+      S.pend[bj] = (uint16_t)(k + 1);
+      S.observed[m] = 1;
+      atomicAdd(&S.cnt_acc, 1);
     }
+    __syncthreads();
+    if (tid < TRK_MAXKP) {
+      if (S.pend[tid]) { S.claimer[tid] = S.pend[tid]; S.pend[tid] = 0; }
+      S.minrow[tid] = 0xffffffffu;
+    }
+    __syncthreads();
+    ++rounds;
   }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int j = lane * 8 + k;
-    if (j < nkp) st->assigned[j] = (uint8_t)((claimed >> k) & 1u);
-  }
-  if (lane == 0) {
-    if (pass == 1) { st->n_pass1 = accepted_total; st->n_rows1 = n; st->n_vetoed = n_veto; }
-    else { st->n_pass2 = accepted_total; st->n_rows2 = n; st->n_slow2 = n_slow; }
-  }
+  // what this pass claimed is simply taken for the next pass
+  if (tid < TRK_MAXKP && S.claimer[tid] != 0xffffu) S.claimer[tid] = 0;
+  __syncthreads();
+  return rounds;
 }
 
-// ---- 6. gather the 3D-2D correspondences (ordered by keypoint index) -----------------------
-__global__ __launch_bounds__(512) void k_tk_gather(TrackState* st, const svo_kp* kp, int kstride) {
-  TK_SEQ_SELECT(kstride)
-  __shared__ int sm[512];
-  const int tid = threadIdx.x;
-  const TrackPool& P = st->pool[st->cur];
-  const int m = tid < st->nkp ? st->cur_mp[tid] : -1;
-  st->dbg_cur_mp[tid] = m;
-  int total;
-  const int pos = block_excl_scan512(m >= 0 ? 1 : 0, sm, &total);
-  if (m >= 0) {
-    st->Xw[3 * pos] = (double)P.pos[3 * m];
-    st->Xw[3 * pos + 1] = (double)P.pos[3 * m + 1];
-    st->Xw[3 * pos + 2] = (double)P.pos[3 * m + 2];
-    const svo_kp k = kp[tid];
-    st->obs[2 * pos] = (double)k.x;
-    st->obs[2 * pos + 1] = (double)k.y;
-  }
-  if (tid == 0) st->n_edges = total;
-}
+extern __shared__ __attribute__((aligned(16))) unsigned char tk_smem[];
 
-// ---- 9. frame end: SetPose, result record, createmappoint, cull, compaction ----------------
-__global__ __launch_bounds__(512) void k_tk_end(TrackState* st, const svo_kp* kp,
-                                                const uint32_t* desc, const float* depth,
-                                                svo_track_result* res_out, int kstride) {
-  TK_SEQ_SELECT(kstride)
-  desc += (size_t)blockIdx.y * kstride * 8; depth += (size_t)blockIdx.y * kstride; res_out += blockIdx.y;
-  __shared__ int sm[512];
-  __shared__ float sT[16], sRwc[9], stwc[3];
+__global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* work, const svo_kp* kp,
+                                                     const uint32_t* desc, const int32_t* nkp_p, const float* depth,
+                                                     int kstride) {
+  TiLds& S = *reinterpret_cast<TiLds*>(tk_smem);
+  st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
+  desc += (size_t)blockIdx.y * kstride * 8; nkp_p += blockIdx.y; depth += (size_t)blockIdx.y * kstride;
   const int tid = threadIdx.x;
-  const int nkp = st->nkp, id = st->frame_num;
+  const int nkp = min(*nkp_p, TRK_MAXKP);
+  const int id = st->frame_num, n_boxes = st->n_boxes;
+  const int np_start = st->npool, lastN = st->lastN, gid0 = st->next_gid;
   TrackPool& P = st->pool[st->cur];
   TrackPool& Q = st->pool[st->cur ^ 1];
-  if (tid < 16) sT[tid] = (float)st->T[tid];   // SetPose(pose) stores CV_32F (src/Optimizer.cc:82-83)
-  __syncthreads();
-  if (tid < 9) sRwc[tid] = sT[4 * (tid % 3) + tid / 3];
-  __syncthreads();
-  if (tid < 3) {
-    const double acc = (double)sRwc[3 * tid] * (double)sT[3] + (double)sRwc[3 * tid + 1] * (double)sT[7] +
-                       (double)sRwc[3 * tid + 2] * (double)sT[11];
-    stwc[tid] = (float)(-acc);
+  // ---- frame begin ---------------------------------------------------------------------------
+  if (tid < TRK_MAXKP) { S.cur_mp[tid] = -1; S.claimer[tid] = tid >= nkp ? 0 : 0xffffu; }
+  for (int r = tid; r < TRK_CAP; r += 1024) { S.observed[r] = 0; S.ref[r] = 0; }
+  if (tid == 0) { S.cnt_acc = 0; S.cnt_veto = 0; S.cnt_late = 0; }
+  const bool has_depth = tid < nkp && depth[tid] > 0.f;
+  const int n_stereo = __syncthreads_count(has_depth);
+  int edge_gid = -1;          // map-point id matched to keypoint `tid`
+  int npool = np_start, n_new0 = 0, next_gid = gid0;
+  int n_pass1 = 0, n_pass2 = 0, n_act1 = 0, n_act2 = 0, rounds1 = 0, late2 = 0, n_veto = 0;
+  if (id == 0) {
+    // Tracking::init (src/Tracking.cc:42-97): one map point per keypoint with depth.  Its `dynamic` flag is declared
+    // outside the keypoint loop and never reset (:44): once a keypoint falls into a padded box, every later one is
+    // skipped as well.
+    bool create0 = has_depth;
+    if (n_boxes > 0) {
+      const svo_kp k = kp[min(tid, max(nkp - 1, 0))];
+      const bool inb = tid < nkp && svo_in_boxes(k.x, k.y, st->boxes, n_boxes, 5);
+      int tot_in;
+      const int before = block_excl_scan(inb ? 1 : 0, S.sm, &tot_in);
+      if (before + (inb ? 1 : 0) > 0) create0 = false;
+    }
+    int total;
+    const int rank = block_excl_scan(create0 ? 1 : 0, S.sm, &total);
+    if (create0) {
+      const int m = npool + rank;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) P.desc[8 * m + w] = desc[8 * tid + w];
+      P.bad[m] = 0; P.in_local[m] = 1; P.create_id[m] = 0; P.gid[m] = next_gid + rank;
+      S.cur_mp[tid] = m;
+      edge_gid = next_gid + rank;    // the pose chain places these with the identity pose before frame 0's LM
+    }
+    npool += total; next_gid += total; n_new0 = total;
+    __syncthreads();
+  } else {
+    // ---- pass 1 (src/pnpmatch.cc:61-156): last frame's map points, in keypoint order --------
+    {
+      int m = -1;
+      bool act = false;
+      if (tid < lastN) {
+        m = st->last_mp[tid];
+        act = m >= 0 && !P.bad[m] && st->rowmin[m] < 15;
+      }
+      const int k = block_excl_scan(act ? 1 : 0, S.sm, &n_act1);
+      if (act) { S.act_m[k] = (uint16_t)m; S.act_i[k] = (uint16_t)tid; S.act_n[k] = st->ncand[m]; }
+      __syncthreads();
+      rounds1 = ti_resolve_pass<1>(S, st, P, n_act1, nkp, kp, n_boxes);
+      n_pass1 = S.cnt_acc; n_veto = S.cnt_veto;
+      __syncthreads();
+      if (tid == 0) { S.cnt_acc = 0; S.cnt_late = 0; }
+    }
+    // ---- pass 2 (src/pnpmatch.cc:159-199): local map points not observed by this frame -------
+    {
+      int cnt = 0;
+      uint32_t bits = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 4 * tid + q;
+        if (r < npool && P.in_local[r] && !P.bad[r] && !S.observed[r] && st->rowmin[r] < 30) { bits |= 1u << q; ++cnt; }
+      }
+      int k = block_excl_scan(cnt, S.sm, &n_act2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if ((bits >> q) & 1u) {
+          const int r = 4 * tid + q;
+          S.act_m[k] = (uint16_t)r; S.act_n[k] = st->ncand[r];
+          ++k;
+        }
+      __syncthreads();
+      ti_resolve_pass<2>(S, st, P, n_act2, nkp, kp, 0);
+      n_pass2 = S.cnt_acc; late2 = S.cnt_late;
+      __syncthreads();
+    }
+    if (tid < nkp && S.cur_mp[tid] >= 0) edge_gid = P.gid[S.cur_mp[tid]];
   }
-  __syncthreads();
-  // frame::createmappoint for keypoints without a map point and with depth
-  int m_cur = tid < nkp ? st->cur_mp[tid] : -1;
-  bool create = tid < nkp && m_cur < 0 && depth[tid] > 0.f;
+  if (tid < TRK_MAXKP) {
+    st->dbg_cur_mp[tid] = tid < nkp ? S.cur_mp[tid] : -1;
+    work->edge_gid[tid] = edge_gid;
+  }
+  // ---- frame end: createmappoint (src/frame.cc:182-238) for keypoints without a map point ------
+  int m_cur = tid < nkp ? S.cur_mp[tid] : -1;
+  bool create = tid < nkp && m_cur < 0 && has_depth;
   if (tid < nkp) {
     const svo_kp k = kp[tid];
-    if (create && st->n_boxes > 0 && svo_in_boxes(k.x, k.y, st->boxes, st->n_boxes, 5)) create = false;
+    if (create && n_boxes > 0 && svo_in_boxes(k.x, k.y, st->boxes, n_boxes, 5)) create = false;
     st->last_xy[2 * tid] = k.x; st->last_xy[2 * tid + 1] = k.y;
 #pragma unroll
     for (int w = 0; w < 8; ++w) st->last_desc[8 * tid + w] = desc[8 * tid + w];
   }
   int n_new;
-  const int rank = block_excl_scan512(create ? 1 : 0, sm, &n_new);
-  const int np0 = st->npool;
-  if (create && np0 + rank < TRK_CAP) {
-    const int m = np0 + rank;
-    const svo_kp k = kp[tid];
-    tk_unproject(st->cam, k.x, k.y, depth[tid], sRwc, stwc, &P.pos[3 * m]);
+  const int rank = block_excl_scan(create ? 1 : 0, S.sm, &n_new);
+  int new_gid = -1;
+  if (create && npool + rank < TRK_CAP) {
+    const int m = npool + rank;
 #pragma unroll
     for (int w = 0; w < 8; ++w) P.desc[8 * m + w] = desc[8 * tid + w];
-    P.bad[m] = 0; P.in_local[m] = 1; P.create_id[m] = id; P.obs_frame[m] = -1;
+    P.bad[m] = 0; P.in_local[m] = 1; P.create_id[m] = id; P.gid[m] = next_gid + rank;
+    new_gid = next_gid + rank;
     m_cur = m;
   }
+  if (tid < TRK_MAXKP) work->new_gid[tid] = new_gid;
+  const int np1 = min(npool + n_new, TRK_CAP);
+  const bool overflow = npool + n_new > TRK_CAP;
+  next_gid += n_new;
+  if (tid < nkp && m_cur >= 0) S.ref[m_cur] = 1;
   __syncthreads();
-  const int np1 = min(np0 + n_new, TRK_CAP);
-  // cull + liveness: thread t owns pool rows 8t .. 8t+7
-  if (tid < TRK_MAXKP) st->last_mp[tid] = m_cur;   // pre-compaction indices
-  __syncthreads();
-  // mark rows referenced by the (new) last frame: reuse obs_frame sign? use a flag pass in Q.bad
-  for (int r = tid; r < TRK_CAP; r += 512) Q.bad[r] = 0;
-  __syncthreads();
-  if (tid < nkp && m_cur >= 0) Q.bad[m_cur] = 1;   // Q.bad is scratch here: "referenced" flag
-  __syncthreads();
-  int live_cnt = 0;
+  // ---- cull (src/Tracking.cc:239-250) + stable compaction into the other pool half -------------
+  // live = still in the local map, or referenced by this frame's keypoints (next frame's pass 1 needs it)
+  int live_cnt = 0, oldest = 0x7fffffff;
   uint32_t live_bits = 0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int r = tid * 8 + k;
+  for (int q = 0; q < 4; ++q) {
+    const int r = tid * 4 + q;
     if (r < np1) {
       bool loc = P.in_local[r] != 0;
-      if (id >= 4 && P.create_id[r] <= id - 4) loc = false;   // cull (src/Tracking.cc:239-250)
+      if (id >= 4 && P.create_id[r] <= id - 4) loc = false;
       P.in_local[r] = loc ? 1 : 0;
-      if (loc || Q.bad[r]) { live_bits |= 1u << k; ++live_cnt; }
+      if (loc || S.ref[r]) { live_bits |= 1u << q; ++live_cnt; oldest = min(oldest, P.gid[r]); }
     }
   }
   int total_live;
-  int base = block_excl_scan512(live_cnt, sm, &total_live);
-  __syncthreads();
-  for (int r = tid; r < TRK_CAP; r += 512) Q.bad[r] = 0;
-  __syncthreads();
-  // remap table lives in Q.obs_frame temporarily (rows of P -> rows of Q)
+  int base = block_excl_scan(live_cnt, S.sm, &total_live);
   int nl = 0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int r = tid * 8 + k;
-    if ((live_bits >> k) & 1u) {
-      const int q = base++;
-      Q.pos[3 * q] = P.pos[3 * r]; Q.pos[3 * q + 1] = P.pos[3 * r + 1]; Q.pos[3 * q + 2] = P.pos[3 * r + 2];
-#pragma unroll
-      for (int w = 0; w < 8; ++w) Q.desc[8 * q + w] = P.desc[8 * r + w];
-      Q.create_id[q] = P.create_id[r];
-      Q.bad[q] = P.bad[r];
-      Q.in_local[q] = P.in_local[r];
+  for (int q = 0; q < 4; ++q) {
+    const int r = tid * 4 + q;
+    if ((live_bits >> q) & 1u) {
+      const int d = base++;
+      const uint4* src = reinterpret_cast<const uint4*>(&P.desc[8 * r]);
+      uint4* dst = reinterpret_cast<uint4*>(&Q.desc[8 * d]);
+      dst[0] = src[0]; dst[1] = src[1];
+      Q.create_id[d] = P.create_id[r];
+      Q.gid[d] = P.gid[r];
+      Q.bad[d] = P.bad[r];
+      Q.in_local[d] = P.in_local[r];
       nl += P.in_local[r];
-      P.obs_frame[r] = q;            // remap (P is dead after this kernel)
+      S.remap[r] = (int16_t)d;
     } else if (r < np1) {
-      P.obs_frame[r] = -1;
+      S.remap[r] = -1;
     }
   }
   int nl_total;
-  block_excl_scan512(nl, sm, &nl_total);
-  __syncthreads();
-  if (tid < TRK_MAXKP) {
-    const int m = st->last_mp[tid];
-    st->last_mp[tid] = (tid < nkp && m >= 0) ? P.obs_frame[m] : -1;
-  }
-  for (int q = tid; q < total_live; q += 512) Q.obs_frame[q] = -1;
+  block_excl_scan(nl, S.sm, &nl_total);
+  // a live point whose id is about to be lapped by the position ring would alias a newer one: flag it (sticky)
+  const int lapped = __syncthreads_or(oldest != 0x7fffffff && next_gid - oldest > TRK_GPOS - 2 * TRK_MAXKP);
+  if (tid < TRK_MAXKP) st->last_mp[tid] = (tid < nkp && m_cur >= 0) ? S.remap[m_cur] : -1;
   if (tid == 0) {
-    svo_track_result r;
-    for (int i = 0; i < 16; ++i) { r.Tcw[i] = sT[i]; st->lastTcw[i] = sT[i]; }
-    r.frame_id = id; r.n_kp = nkp; r.n_stereo = st->n_stereo;
-    r.n_match_pass1 = st->n_pass1; r.n_match_pass2 = st->n_pass2;
-    r.n_pnp_inliers = st->skip_match ? 0 : st->pnp.n_inliers;
-    r.n_lm_edges = st->n_edges;
-    r.n_new_mappoints = (id == 0 ? st->n_new : 0) + n_new;
-    r.n_local_map = nl_total;
-    r.lm_iterations = st->lm.iterations;
-    r.reserved[0] = st->skip_match ? 0 : st->n_rows1;   // diagnostics: rows visited by pass 1; [1]: pass 2 | rescanned<<16
-    r.reserved[1] = st->skip_match ? 0 : (st->n_rows2 | (st->n_slow2 << 16));
-    *res_out = r;
+    work->frame_id = id; work->nkp = nkp; work->n_stereo = n_stereo;
+    work->n_pass1 = n_pass1; work->n_pass2 = n_pass2;
+    work->n_new = n_new0 + n_new; work->n_local = nl_total; work->skip_match = id == 0 ? 1 : 0;
+    work->diag[0] = n_act1 | (rounds1 << 16);
+    work->diag[1] = n_act2 | (late2 << 16);
+    st->n_vetoed = n_veto;
     st->lastN = nkp;
     st->npool = total_live;
+    st->next_gid = next_gid;
+    if (overflow || lapped) st->overflow = 1;
     st->cur ^= 1;
     st->frame_num = id + 1;
   }
 }
 
+// ================================================================================================
+// Pose chain: one launch per frame and sequence
+// ================================================================================================
+struct TpLds {
+  PoseLds pose;
+  int sm[16];
+  float sT[16], sRwc[9], stwc[3];
+};
+
+__global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, const TrackWork* work, const svo_kp* kp,
+                                                  const float* depth, svo_track_result* res_out, int kstride,
+                                                  int use_mfma) {
+  TpLds& S = *reinterpret_cast<TpLds*>(tk_smem);
+  st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
+  depth += (size_t)blockIdx.y * kstride; res_out += blockIdx.y;
+  const int tid = threadIdx.x;
+  const int id = work->frame_id, nkp = work->nkp, skip = work->skip_match;
+  float* gpos = st->gpos;
+  // ---- 3D-2D correspondences, ordered by keypoint index (src/pnpmatch.cc:216-224) ---------------
+  const int j0 = 2 * tid;
+  const int g0 = j0 < nkp ? work->edge_gid[j0] : -1, g1 = j0 + 1 < nkp ? work->edge_gid[j0 + 1] : -1;
+  int n_edges;
+  int pos = block_excl_scan((g0 >= 0 ? 1 : 0) + (g1 >= 0 ? 1 : 0), S.sm, &n_edges);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int g = q ? g1 : g0, j = j0 + q;
+    if (g < 0) continue;
+    const svo_kp k = kp[j];
+    float* gp = gpos + 3 * (size_t)(g & (TRK_GPOS - 1));
+    float xyz[3];
+    if (id == 0) {   // Tracking::init: the points of frame 0 are placed with the identity pose, before its LM
+      const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3[3] = {0, 0, 0};
+      tk_unproject(st->cam, k.x, k.y, depth[j], I3, z3, xyz);
+      gp[0] = xyz[0]; gp[1] = xyz[1]; gp[2] = xyz[2];
+    } else {
+      xyz[0] = gp[0]; xyz[1] = gp[1]; xyz[2] = gp[2];
+    }
+    st->Xw[3 * pos] = (double)xyz[0]; st->Xw[3 * pos + 1] = (double)xyz[1]; st->Xw[3 * pos + 2] = (double)xyz[2];
+    st->obs[2 * pos] = (double)k.x; st->obs[2 * pos + 1] = (double)k.y;
+    ++pos;
+  }
+  if (tid < 4) st->K[tid] = (double)((const float*)&st->cam)[tid];
+  if (tid < 16) { st->Tprior[tid] = (double)st->lastTcw[tid]; if (skip) st->T[tid] = (double)st->lastTcw[tid]; }
+  __syncthreads();
+  // ---- PnP initial pose (src/pnpmatch.cc:212-247), then Optimizer::PoseOptimization --------------
+  if (!skip)
+    pnp_ransac_block(S.pose, st->Xw, st->obs, n_edges, st->K, st->Tprior, 0x5EED0000ULL + (uint64_t)id, st->T,
+                     (uint8_t*)nullptr, &st->pnp, use_mfma);
+  pose_opt_block(S.pose, st->Xw, st->obs, n_edges, st->K, st->T, &st->lm, 1, use_mfma);
+  __syncthreads();
+  // ---- SetPose (CV_32F, src/Optimizer.cc:82-83), positions of the points created this frame -------
+  if (tid < 16) S.sT[tid] = (float)st->T[tid];
+  __syncthreads();
+  if (tid < 9) S.sRwc[tid] = S.sT[4 * (tid % 3) + tid / 3];
+  __syncthreads();
+  if (tid < 3) {
+    const double acc = (double)S.sRwc[3 * tid] * (double)S.sT[3] + (double)S.sRwc[3 * tid + 1] * (double)S.sT[7] +
+                       (double)S.sRwc[3 * tid + 2] * (double)S.sT[11];
+    S.stwc[tid] = (float)(-acc);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int j = j0 + q;
+    const int g = j < nkp ? work->new_gid[j] : -1;
+    if (g < 0) continue;
+    const svo_kp k = kp[j];
+    float xyz[3];
+    tk_unproject(st->cam, k.x, k.y, depth[j], S.sRwc, S.stwc, xyz);
+    float* gp = gpos + 3 * (size_t)(g & (TRK_GPOS - 1));
+    gp[0] = xyz[0]; gp[1] = xyz[1]; gp[2] = xyz[2];
+  }
+  if (tid == 0) {
+    svo_track_result r;
+    for (int i = 0; i < 16; ++i) { r.Tcw[i] = S.sT[i]; st->lastTcw[i] = S.sT[i]; }
+    r.frame_id = id; r.n_kp = nkp; r.n_stereo = work->n_stereo;
+    r.n_match_pass1 = work->n_pass1; r.n_match_pass2 = work->n_pass2;
+    r.n_pnp_inliers = skip ? 0 : st->pnp.n_inliers;
+    r.n_lm_edges = n_edges;
+    r.n_new_mappoints = work->n_new;
+    r.n_local_map = work->n_local;
+    r.lm_iterations = st->lm.iterations;
+    r.reserved[0] = work->diag[0];   // diagnostics: rows of pass 1 | rounds << 16; [1]: rows of pass 2 | late rows << 16
+    r.reserved[1] = work->diag[1];
+    *res_out = r;
+  }
+}
+
 // --------------------------------------------------------------------------------------------
-// One frame of `nseq` sequences at once: sequence q uses TrackState q, frame slot `slot + q` and result
-// record d_res[q].  nseq = 1 is the ordinary single chain.
-static int tail_launch(svo_ctx* ctx, int slot, svo_track_result* d_res, int nseq = 1) {
+// Host side
+// --------------------------------------------------------------------------------------------
+void svo_track_release(svo_ctx* ctx) {
+  if (ctx->d_track) { hipFree(ctx->d_track); ctx->d_track = nullptr; }
+  if (ctx->d_work) { hipFree(ctx->d_work); ctx->d_work = nullptr; }
+  ctx->n_seq = 0; ctx->work_cap = 0;
+  for (hipEvent_t e : ctx->ev_frame) hipEventDestroy(e);
+  ctx->ev_frame.clear();
+  if (ctx->ev_frontend) { hipEventDestroy(ctx->ev_frontend); ctx->ev_frontend = nullptr; }
+  if (ctx->stream_idx) { hipStreamDestroy(ctx->stream_idx); ctx->stream_idx = nullptr; }
+}
+
+// streams, events, work records and the kernels' LDS opt-ins for `frames` frames per call of `nseq` sequences
+static int track_resources(svo_ctx* ctx, int frames, int nseq) {
+  if (!ctx->stream_idx) SVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_idx, hipStreamNonBlocking));
+  if (!ctx->ev_frontend) SVO_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_frontend, hipEventDisableTiming));
+  while ((int)ctx->ev_frame.size() < frames) {
+    hipEvent_t e;
+    SVO_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->ev_frame.push_back(e);
+  }
+  const int need = std::max(frames, nseq);
+  if (ctx->work_cap < need) {
+    SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_work) hipFree(ctx->d_work);
+    ctx->d_work = nullptr; ctx->work_cap = 0;
+    if (hipMalloc(&ctx->d_work, sizeof(TrackWork) * (size_t)need) != hipSuccess) return SVO_E_NOMEM;
+    ctx->work_cap = need;
+  }
+  if (ctx->track_lds_state == 0) {
+    bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ti_resolve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)sizeof(TiLds)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_frame), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)sizeof(TpLds)) == hipSuccess;
+    ctx->track_lds_state = ok ? 1 : -1;
+    if (!ok) ctx->last_error = std::string("hipFuncSetAttribute(tracker kernels): ") + hipGetErrorString(hipGetLastError());
+  }
+  return ctx->track_lds_state > 0 ? SVO_OK : SVO_E_HIP;
+}
+
+// The ordered tail for front-end results that are already in HBM (`kstride` keypoints per frame slot):
+//   nseq == 1: `frames` consecutive frames of the one sequence, record f into d_res[f];
+//   nseq  > 1: one frame of each of nseq sequences (frames == 1), sequence q from frame slot q into d_res[q].
+// The index chain is enqueued on ctx->stream_idx and runs ahead; the pose chain follows on ctx->stream.
+static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, const int32_t* nkp, const float* depth,
+                        int kstride, int frames, int nseq, svo_track_result* d_res) {
+  int rc = track_resources(ctx, frames, nseq);
+  if (rc) return rc;
   TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
-  hipStream_t s = ctx->stream;
-  const size_t K = ctx->max_kp;
-  const int ks = (int)K;
+  TrackWork* work = reinterpret_cast<TrackWork*>(ctx->d_work);
+  hipStream_t s0 = ctx->stream, s1 = ctx->stream_idx;
   const unsigned ny = (unsigned)nseq;
-  const svo_kp* kp = ctx->d_kp + slot * K;
-  const uint32_t* desc = reinterpret_cast<const uint32_t*>(ctx->d_desc + slot * K * 32);
-  const float* depth = ctx->d_depth + slot * K;
-  {
-    SvoTimer t(ctx, "k_tk_begin");
-    hipLaunchKernelGGL(k_tk_begin, dim3(1, ny), dim3(512), 0, s, st, kp, desc, ctx->d_nkp + slot, depth, ks);
-  }
-  {
-    SvoTimer t(ctx, "k_tk_match");
-    if (ny >= 8) hipLaunchKernelGGL(k_tk_dist<16>, dim3(TRK_MAXKP / 16, ny), dim3(256), 0, s, st, desc, 1, ks);
-    else hipLaunchKernelGGL(k_tk_dist<4>, dim3(TRK_MAXKP / 4, ny), dim3(256), 0, s, st, desc, 1, ks);
-    hipLaunchKernelGGL(k_tk_greedy, dim3(1, ny), dim3(64), 0, s, st, 1, kp, ks);
-    if (ny >= 8) hipLaunchKernelGGL(k_tk_dist<16>, dim3(TRK_CAP / 16, ny), dim3(256), 0, s, st, desc, 2, ks);
-    else hipLaunchKernelGGL(k_tk_dist<4>, dim3(TRK_CAP / 4, ny), dim3(256), 0, s, st, desc, 2, ks);
-    hipLaunchKernelGGL(k_tk_greedy, dim3(1, ny), dim3(64), 0, s, st, 2, kp, ks);
-  }
-  {
-    SvoTimer t(ctx, "k_tk_gather");
-    hipLaunchKernelGGL(k_tk_gather, dim3(1, ny), dim3(512), 0, s, st, kp, ks);
-  }
-  int rc;
-  if ((rc = svo_launch_pnp_dev(ctx, st->Xw, st->obs, &st->n_edges, st->K, st->Tprior, st->T, &st->pnp,
-                               &st->skip_match, &st->frame_num, nseq, sizeof(TrackState))))
-    return rc;
-  if ((rc = svo_launch_pose_opt_dev(ctx, st->Xw, st->obs, &st->n_edges, st->K, st->T, &st->lm, 1, nseq, sizeof(TrackState))))
-    return rc;
-  {
-    SvoTimer t(ctx, "k_tk_end");
-    hipLaunchKernelGGL(k_tk_end, dim3(1, ny), dim3(512), 0, s, st, kp, desc, depth, d_res, ks);
+  const uint32_t* desc = reinterpret_cast<const uint32_t*>(desc8);
+  SVO_HIP(ctx, hipEventRecord(ctx->ev_frontend, s0));            // keypoints, descriptors, depths are ready ...
+  SVO_HIP(ctx, hipStreamWaitEvent(s1, ctx->ev_frontend, 0));    // ... and the previous call's pose chain has read its records
+  for (int f = 0; f < frames; ++f) {
+    const svo_kp* kpf = kp + (size_t)f * kstride;
+    const uint32_t* descf = desc + (size_t)f * kstride * 8;
+    const float* depf = depth + (size_t)f * kstride;
+    {
+      SvoTimer t(ctx, "k_ti_lists", s1);
+      if (ny >= 8) hipLaunchKernelGGL(k_ti_lists<16>, dim3(TRK_ROWS_MAX / 16, ny), dim3(256), 0, s1, st, descf, nkp + f, kstride, ctx->opt_track_lcap);
+      else hipLaunchKernelGGL(k_ti_lists<4>, dim3(TRK_ROWS_MAX / 4, ny), dim3(256), 0, s1, st, descf, nkp + f, kstride, ctx->opt_track_lcap);
+    }
+    {
+      SvoTimer t(ctx, "k_ti_resolve", s1);
+      hipLaunchKernelGGL(k_ti_resolve, dim3(1, ny), dim3(1024), sizeof(TiLds), s1, st, work + f, kpf, descf, nkp + f, depf, kstride);
+    }
+    SVO_HIP(ctx, hipEventRecord(ctx->ev_frame[f], s1));
+    SVO_HIP(ctx, hipStreamWaitEvent(s0, ctx->ev_frame[f], 0));
+    {
+      SvoTimer t(ctx, "k_tp_frame");
+      hipLaunchKernelGGL(k_tp_frame, dim3(1, ny), dim3(256), sizeof(TpLds), s0, st, work + f, kpf, depf, d_res + f, kstride,
+                         ctx->opt_pose_mfma);
+    }
   }
   SVO_HIP(ctx, hipGetLastError());
   return SVO_OK;
@@ -612,8 +705,10 @@ static int track_reset_n(svo_ctx* ctx, const svo_camera* cam, int nseq) {
   if (!ctx || !cam || nseq < 1) return SVO_E_INVALID;
   if (ctx->max_kp > TRK_MAXKP) return SVO_E_CAPACITY;
   hipSetDevice(ctx->device);
+  if (ctx->stream_idx) SVO_HIP(ctx, hipStreamSynchronize(ctx->stream_idx));
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (!ctx->d_track || ctx->n_seq != nseq) {
-    if (ctx->d_track) { hipStreamSynchronize(ctx->stream); hipFree(ctx->d_track); ctx->d_track = nullptr; }
+    if (ctx->d_track) { hipFree(ctx->d_track); ctx->d_track = nullptr; }
     void* p = nullptr;
     if (hipMalloc(&p, sizeof(TrackState) * (size_t)nseq) != hipSuccess) return SVO_E_NOMEM;
     ctx->d_track = p;
@@ -759,7 +854,7 @@ extern "C" int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL,
     if (rc) return rc;
   }
   svo_track_result* d_res = reinterpret_cast<svo_track_result*>(ctx->d_scratch);
-  rc = tail_launch(ctx, 0, d_res);
+  rc = tail_enqueue(ctx, ctx->d_kp, ctx->d_desc, ctx->d_nkp, ctx->d_depth, ctx->max_kp, 1, 1, d_res);
   if (rc) return rc;
   SVO_HIP(ctx, hipMemcpyAsync(res, d_res, sizeof *res, hipMemcpyDeviceToHost, ctx->stream));
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -780,7 +875,7 @@ extern "C" int svo_track_multi_step_dev(svo_ctx* ctx, const uint8_t* d_grayL, co
   int rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, n_seq, 2 * n_seq);
   if (rc) return rc;
   if ((rc = svo_launch_stereo(ctx, d_grayL, d_grayR, stride, n_seq, &ctx->cam))) return rc;
-  if ((rc = tail_launch(ctx, 0, d_results, n_seq))) return rc;
+  if ((rc = tail_enqueue(ctx, ctx->d_kp, ctx->d_desc, ctx->d_nkp, ctx->d_depth, ctx->max_kp, 1, n_seq, d_results))) return rc;
   ctx->track_frame++;
   return SVO_OK;
 }
@@ -824,11 +919,38 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
     if ((rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, B, 2 * B))) return rc;
     if ((rc = svo_launch_stereo(ctx, d_grayL, d_grayR, stride, B, &ctx->cam))) return rc;
   }
-  for (int f = 0; f < B; ++f) {
-    rc = tail_launch(ctx, f, d_results + f);
-    if (rc) return rc;
-  }
+  if ((rc = tail_enqueue(ctx, ctx->d_kp, ctx->d_desc, ctx->d_nkp, ctx->d_depth, ctx->max_kp, B, 1, d_results))) return rc;
   ctx->track_frame += B;
+  return SVO_OK;
+}
+
+// The ordered tail alone, for front-end results produced elsewhere (another context, another GPU): frame f's keypoints
+// at d_kp + f * kp_stride, descriptors at d_desc + f * kp_stride * 32, count d_n[f], depths d_depth + f * kp_stride.
+extern "C" int svo_track_tail_dev(svo_ctx* ctx, const svo_kp* d_kp, const uint8_t* d_desc, const int32_t* d_n,
+                                  const float* d_depth, int kp_stride, int B, svo_track_result* d_results) {
+  if (!ctx || !d_kp || !d_desc || !d_n || !d_depth || !d_results || B < 1 || kp_stride < 1) return SVO_E_INVALID;
+  if (!ctx->d_track || ctx->n_seq != 1) return SVO_E_INVALID;   // svo_track_reset first
+  hipSetDevice(ctx->device);
+  SVO_HIP(ctx, hipMemsetAsync(&reinterpret_cast<TrackState*>(ctx->d_track)->n_boxes, 0, 4, ctx->stream));
+  int rc = tail_enqueue(ctx, d_kp, d_desc, d_n, d_depth, kp_stride, B, 1, d_results);
+  if (rc) return rc;
+  ctx->track_frame += B;
+  return SVO_OK;
+}
+
+// Sticky capacity flag of the tracker (0 = fine): set when a frame wanted more than 4096 live map points or a map
+// point outlived the position table (2^20 ids); results after that are not the reference's.
+extern "C" int svo_track_overflowed(svo_ctx* ctx, int32_t* flag) {
+  if (!ctx || !flag || !ctx->d_track) return SVO_E_INVALID;
+  TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int32_t any = 0;
+  for (int q = 0; q < ctx->n_seq; ++q) {
+    int32_t v = 0;
+    SVO_HIP(ctx, hipMemcpy(&v, &st[q].overflow, 4, hipMemcpyDeviceToHost));
+    any |= v;
+  }
+  *flag = any;
   return SVO_OK;
 }
 

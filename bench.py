@@ -388,8 +388,8 @@ def main():
                         "frames_tracked": int(len(res)), "ate_rmse_m_vs_ground_truth": rmse,
                         "final_position_error_m": last, "path_length_m": float(len(res) - 1),
                         "mean_lm_edges": float(res["n_lm_edges"][1:].mean()),
-                        "mean_rows_visited_pass1_pass2": [float(res["reserved"][1:, 0].mean()), float((res["reserved"][1:, 1] & 0xffff).mean())],
-                        "mean_rows_rescanned_pass2": float((res["reserved"][1:, 1] >> 16).mean()),
+                        "mean_active_rows_pass1_pass2": [float((res["reserved"][1:, 0] & 0xffff).mean()), float((res["reserved"][1:, 1] & 0xffff).mean())],
+                        "mean_rounds_pass1_pass2": [float((res["reserved"][1:, 0] >> 16).mean()), float((res["reserved"][1:, 1] >> 16).mean())],
                         "mean_local_map": float(res["n_local_map"][1:].mean())})
         else:
             n_kp = d_n.cpu().numpy()

@@ -116,9 +116,11 @@ void svo_destroy(svo_ctx* ctx);
  * v_mfma_f64_16x16x4_f64; 0 selects the VALU + DPP reduction (same results to round-off).
  * "fast_cand_cap" (default 2048, the maximum): length of the per-tile list of scored pixels in the FAST kernel; tiles
  * with more fall back to scanning the score tile - same results, the switch exists so that tests can force that path.
- * "track_lcap" (default 16, the maximum): entries of a map point's sparse candidate list in the tracker's matching
- * passes; rows with more candidates keep their full distance row instead - same results, the switch exists so that tests
+ * "track_lcap" (default 8, the maximum): claimable keypoints (Hamming distance < 30) a map point keeps as packed
+ * entries in the tracker's matching passes; rows with more are evaluated on their full distance row instead - same results, the switch exists so that tests
  * can force that path.
+ * "track_nblk" (default 3, the maximum): runner-up blockers stored with each packed entry; with fewer the matching passes
+ * consult the full distance row more often - same results, a test switch like "track_lcap".
  * "depth_source" (default 0): where svo_track_frame / svo_track_batch_dev take keypoint depth from - 0 the sparse
  * epipolar matcher (north star), 1 a dense ELAS map (svo_elas_*), 2 a dense MSA map (svo_msa_solve with d = 48: the
  * reference's live configuration, src/Tracking.cc:225-228 + src/frame.cc:82-91), both read per keypoint as

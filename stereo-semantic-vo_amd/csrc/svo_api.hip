@@ -281,8 +281,13 @@ extern "C" int svo_set_option(svo_ctx* ctx, const char* key, int value) {
     ctx->opt_fast_cand_cap = value;
     return SVO_OK;
   }
+  if (!strcmp(key, "track_nblk")) {
+    if (value < 0 || value > 3) return SVO_E_INVALID;
+    ctx->opt_track_nblk = value;
+    return SVO_OK;
+  }
   if (!strcmp(key, "track_lcap")) {
-    if (value < 1 || value > 16) return SVO_E_INVALID;
+    if (value < 1 || value > 8) return SVO_E_INVALID;
     ctx->opt_track_lcap = value;
     return SVO_OK;
   }

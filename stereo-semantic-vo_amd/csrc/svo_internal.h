@@ -100,7 +100,8 @@ struct svo_ctx {
   std::vector<hipEvent_t> ev_frame;        // index chain of frame f finished (recorded on `stream_idx`)
   int pose_lds_state = 0;       // > 64 KB dynamic-LDS opt-in of the pose kernels: 0 untried, 1 granted, -1 refused
   int track_lds_state = 0;      // same for the tracker's kernels
-  int opt_track_lcap = 16;      // svo_set_option("track_lcap"): entries of a map point's sparse candidate list (1..16)
+  int opt_track_nblk = 3;       // svo_set_option("track_nblk"): runner-up blockers stored per packed entry (0..3)
+  int opt_track_lcap = 8;       // svo_set_option("track_lcap"): packed entries a map point keeps before it goes "dense" (1..8)
   void* elas = nullptr;     // ElasState (svo_elas.hip), allocated on first svo_elas_process
   void* elas_batch = nullptr;   // ElasBatch: per-pair states of svo_elas_batch_dev
   int elas_strip_state = 0;     // k_cc_strip's > 64 KB dynamic-LDS opt-in on this ctx's device: 0 untried, 1 granted, -1 refused

@@ -20,16 +20,14 @@
 // chain produces, record for record.
 //
 // Index chain, per frame:
-//   k_ti_lists    every live map point (pool row) against the frame's keypoints: Hamming distances, and per row a
-//                 SPARSE candidate list - the columns with distance < 60 in column order.  Nothing else can matter:
-//                 a row is accepted only with best < 30 (pass 2; < 15 in pass 1), and the runner-up only decides the
-//                 ratio test `second / best > 2`, i.e. only while second <= 2 * best <= 58.
+//   k_ti_lists    every live map point (pool row) against the frame's keypoints: Hamming distances, and per row its
+//                 packed ENTRIES - the columns with distance < 30 in column order (the only ones the row can ever
+//                 claim: pass 2 accepts best < 30, pass 1 best < 15), each with up to three columns before it whose
+//                 distance can hold its runner-up at or below 2 x best (the ratio test `second / best > 2`).  On
+//                 synthetic KITTI-like frames a row has 0.6 entries on average.
 //   k_ti_resolve  one workgroup: frame begin, both order-dependent greedy passes, createmappoint, cull, compaction.
-//                 The greedy passes (rows in order, each claims its best unclaimed column) are resolved in ROUNDS:
-//                 every unresolved row evaluates its list against the claims made so far and publishes the columns
-//                 it could still claim; a row is final as soon as no EARLIER unresolved row can claim a column its
-//                 result depends on.  The first unresolved row is always final, so the rounds terminate; on real
-//                 frames a pass takes 2-5 rounds instead of hundreds of serial steps.
+//                 The greedy passes (rows in order, each claims its best unclaimed column) are resolved in ROUNDS,
+//                 see ti_resolve_pass; on real frames a pass takes 2-5 rounds instead of hundreds of serial steps.
 // The map-point pool is a structure of arrays kept in creation order (the deterministic stand-in for the reference's
 // std::set<mappoint*> address order); after each frame it is stably compacted into the other half of a ping-pong
 // buffer, so "local map point r" is simply row r.
@@ -50,9 +48,9 @@
 #define TRK_MAXKP 512
 #define TRK_CAP 4096
 #define TRK_ROWS_MAX 3072        // live rows k_ti_lists can meet: 4 frames of local points + the last frame's, + slack
-#define TRK_LCAP 16              // entries of a row's sparse candidate list
-#define TRK_LIST_T 60            // list threshold: distances >= 60 cannot influence any decision (see above)
+#define TRK_LCAP 8               // packed entries (claimable columns) a pool row keeps; more -> the row is "dense"
 #define TRK_GPOS (1 << 20)       // map-point position table: ring over map-point ids
+#define TRK_DNC 24                // dense rows whose distance row is cached in LDS during a pass
 #define TRK_DENSE 0xFF           // ncand marker: more than `lcap` candidates, the row's distances are in D
 
 struct TrackPool {
@@ -66,7 +64,8 @@ struct TrackPool {
 // What the index chain hands to the pose chain for one frame.
 struct TrackWork {
   int32_t frame_id, nkp, n_stereo, n_pass1, n_pass2, n_new, n_local, skip_match;
-  int32_t diag[2];               // [0] rows of pass 1 | rounds << 16, [1] rows of pass 2 | rows resolved after round 1 << 16
+  long long ts[8];               // diagnostics: s_memtime at begin / pass 1 / pass 2 / frame end / done, dense rows, late rows
+  int32_t diag[2];               // [0] rows of pass 1 | rounds << 16, [1] rows of pass 2 | rounds << 16
   int32_t edge_gid[TRK_MAXKP];   // per keypoint: id of the map point matched to it (CurrentFrame->MapPoints[j]) or -1
   int32_t new_gid[TRK_MAXKP];    // per keypoint: id of the map point created from it at the frame's end, or -1
 };
@@ -92,32 +91,38 @@ struct TrackState {
   // ---- large arrays (not cleared by a reset) -----------------------------------------------
   TrackPool pool[2];
   uint16_t rowmin[TRK_CAP];                // min over ALL current keypoints of the row's distances
-  uint8_t ncand[TRK_CAP];                  // entries in the row's candidate list, or TRK_DENSE
-  uint32_t cand[(size_t)TRK_CAP * TRK_LCAP];   // dist << 16 | column, columns ascending
-  uint16_t D[(size_t)TRK_CAP * 512];       // full distance rows of the (rare) rows whose list overflowed
+  uint8_t ncand[TRK_CAP];                  // packed entries of the row, or TRK_DENSE
+  uint32_t cand[(size_t)TRK_CAP * 2 * TRK_LCAP];   // packed entries, two words each (k_ti_lists), columns ascending
+  uint16_t D[(size_t)TRK_CAP * 512];       // full distance rows (written for every row that has an entry)
   float gpos[(size_t)TRK_GPOS * 3];        // pose chain: world position of map point gid
 };
 
 // ---- block-wide exclusive scan (blockDim.x = 256 or 1024) -------------------------------------
+// wave64 inclusive scan on DPP (gfx9 row shifts + row broadcasts): six dependent VALU steps, no LDS crossbar
 __device__ __forceinline__ int tk_wave_incl_scan(int v) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(v, o, 64);
-    if ((int)(threadIdx.x & 63) >= o) v += t;
-  }
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8  -> scan inside each row of 16
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
   return v;
 }
-__device__ __forceinline__ int block_excl_scan(int v, int* sm /*[16]*/, int* total) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+__device__ __forceinline__ int block_excl_scan(int v, int* sm /*[16], 16-byte aligned*/, int* total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int incl = tk_wave_incl_scan(v);
+  const int nw = blockDim.x >> 6;
   __syncthreads();
   if (lane == 63) sm[wv] = incl;
   __syncthreads();
+  const int4 a = reinterpret_cast<const int4*>(sm)[0], b = reinterpret_cast<const int4*>(sm)[1],
+             c = reinterpret_cast<const int4*>(sm)[2], d = reinterpret_cast<const int4*>(sm)[3];
+  const int t[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
   int off = 0, tot = 0;
-  for (int w = 0; w < nw; ++w) {
-    const int s = sm[w];
-    off += w < wv ? s : 0;
-    tot += s;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    off += w < wv ? t[w] : 0;
+    tot += w < nw ? t[w] : 0;
   }
   *total = tot;
   return off + incl - v;
@@ -143,10 +148,12 @@ __device__ __forceinline__ void tk_unproject(const svo_camera& cam, float u, flo
 // sharing.  blockIdx.y = sequence (TrackState number, frame slot of the front-end buffers).
 template <int ROWS>
 __global__ __launch_bounds__(256) void k_ti_lists(TrackState* st, const uint32_t* desc, const int32_t* nkp_p, int kstride,
-                                                  int lcap) {
+                                                  int lcap, int nblk) {
   // descriptors of the frame's keypoints, TRANSPOSED: word k of keypoint j at td[k * TRK_MAXKP + j], so that the 64 lanes
   // of a wave (64 consecutive keypoints) read 64 consecutive LDS words
   __shared__ uint32_t td[8 * TRK_MAXKP];
+  __shared__ uint16_t acol[4][TRK_LCAP];
+  __shared__ uint8_t adist[4][TRK_LCAP];
   st += blockIdx.y; desc += (size_t)blockIdx.y * kstride * 8; nkp_p += blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int npool = st->npool;
@@ -197,24 +204,52 @@ __global__ __launch_bounds__(256) void k_ti_lists(TrackState* st, const uint32_t
       mn = min(mn, (uint32_t)d);
     }
     mn = wave_min_u32_dpp(mn);
-    // candidates in column order: piece t holds columns 64 t .. 64 t + 63, lanes ascending
-    int base = 0;
-    uint32_t* lst = st->cand + (size_t)row * TRK_LCAP;
+    // A entries: the columns this row could ever claim (distance < 30), in column order - piece t holds columns
+    // 64 t .. 64 t + 63, lanes ascending
+    int nA = 0;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      const bool c = dcol[t] < TRK_LIST_T;
+      const bool c = dcol[t] < 30;
       const uint64_t m = __ballot(c);
-      const int pos = base + __popcll(m & lt_mask);
-      if (c && pos < lcap) lst[pos] = ((uint32_t)dcol[t] << 16) | (uint32_t)(lane + 64 * t);
-      base += __popcll(m);
+      const int pos = nA + __popcll(m & lt_mask);
+      if (c && pos < TRK_LCAP) { acol[wv][pos] = (uint16_t)(lane + 64 * t); adist[wv][pos] = (uint8_t)dcol[t]; }
+      nA += __popcll(m);
     }
-    if (base > lcap) {   // rare: keep the whole row instead
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the wave reads back what its lanes just stored
+    __builtin_amdgcn_wave_barrier();
+    const bool dense = nA > lcap;
+    uint32_t* lst = st->cand + (size_t)row * (2 * TRK_LCAP);
+    if (!dense) {
+      // per entry with distance >= 15: up to three columns BEFORE it whose distance lies in [30, 2 d] - the columns
+      // outside the A list that can hold its runner-up at or below 2 d (ratio test); `more` says there are others
+      for (int i = 0; i < nA; ++i) {
+        const int c = acol[wv][i], d = adist[wv][i];
+        uint32_t w0 = (uint32_t)c | ((uint32_t)d << 9), w1 = 0;
+        if (d >= 15) {
+          int nb = 0, total = 0;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            uint64_t m = __ballot(lane + 64 * t < c && dcol[t] >= 30 && dcol[t] <= 2 * d);
+            total += __popcll(m);
+            while (m && nb < nblk) {
+              const int bcol = 64 * t + __ffsll((long long)m) - 1;
+              w1 |= (uint32_t)bcol << (9 * nb);
+              ++nb;
+              m &= m - 1;
+            }
+          }
+          w0 |= ((uint32_t)nb << 14) | (total > nb ? 1u << 16 : 0u);
+        }
+        if (lane == 0) { lst[2 * i] = w0; lst[2 * i + 1] = w1; }
+      }
+    }
+    if (nA > 0) {   // the whole row, for the (rare) evaluations the packed entries cannot answer
 #pragma unroll
       for (int t = 0; t < 8; ++t) st->D[(size_t)row * 512 + lane + 64 * t] = (uint16_t)dcol[t];
     }
     if (lane == 0) {
       st->rowmin[row] = (uint16_t)mn;
-      st->ncand[row] = (uint8_t)(base > lcap ? TRK_DENSE : base);
+      st->ncand[row] = (uint8_t)(dense ? TRK_DENSE : nA);
     }
   }
 }
@@ -223,7 +258,7 @@ __global__ __launch_bounds__(256) void k_ti_lists(TrackState* st, const uint32_t
 // Index chain 2/2: everything order-dependent of one frame, one 1024-thread workgroup per sequence
 // ================================================================================================
 struct TiLds {
-  int sm[32];
+  alignas(16) int sm[32];
   int32_t cur_mp[TRK_MAXKP];       // CurrentFrame->MapPoints as pool rows
   uint32_t minrow[TRK_MAXKP];      // per column: lowest unresolved row that could still claim it
   uint16_t claimer[TRK_MAXKP];     // who took the column: 0 = taken before the pass (or beyond nkp), k + 1 = active row k of
@@ -237,117 +272,215 @@ struct TiLds {
   uint8_t observed[TRK_CAP];       // pool row matched in pass 1 (observations.count(CurrentFrame))
   uint8_t ref[TRK_CAP];            // pool row referenced by the frame's keypoints (kept alive for the next pass 1)
   int16_t remap[TRK_CAP];          // pool row -> row after compaction
-  int cnt_acc, cnt_veto, cnt_late;
-  uint32_t ll[1024 * TRK_LCAP];    // candidate lists of the first 1024 active rows
+  int cnt_acc, cnt_veto, cnt_late, nd, flag;
+  uint16_t dn[TRK_CAP];            // dense active rows of the running pass
+  uint16_t dnD[TRK_DNC][512];      // distance rows of the first TRK_DNC of them (fetched once per pass)
 };
 
-// Visit the candidates of active row k in column order: f(column, distance).
-template <int PASS, typename F>
-__device__ __forceinline__ void ti_for_entries(const TiLds& S, const TrackState* st, int k, int nkp, F&& f) {
-  const int nc = S.act_n[k];
-  if (nc == TRK_DENSE) {
-    const uint16_t* Dr = st->D + (size_t)S.act_m[k] * 512;
-    for (int j = 0; j < nkp; ++j) {
-      const int d = Dr[j];
-      if (d < (PASS == 1 ? 15 : TRK_LIST_T)) f(j, d);
-    }
-  } else if (k < 1024) {
-    const uint32_t* e = &S.ll[k * TRK_LCAP];
-    for (int q = 0; q < nc; ++q) {
-      const uint32_t v = e[q];
-      if (PASS == 2 || (v >> 16) < 15u) f((int)(v & 0xffffu), (int)(v >> 16));
-    }
-  } else {
-    const uint32_t* e = st->cand + (size_t)S.act_m[k] * TRK_LCAP;
-    for (int q = 0; q < nc; ++q) {
-      const uint32_t v = e[q];
-      if (PASS == 2 || (v >> 16) < 15u) f((int)(v & 0xffffu), (int)(v >> 16));
+// ---- one greedy pass, resolved in rounds -----------------------------------------------------------
+// A row's packed entries (k_ti_lists): the columns it could claim (distance < 30, column order), each with up to three
+// columns outside that list that can hold its runner-up down.  The reference's scan
+//   `if (dist < best) { second = best; best = dist; idx = j; }`  over the unclaimed columns in index order
+// (src/pnpmatch.cc:75-94) ends with best = the first minimum and second = the minimum over the unclaimed columns
+// BEFORE it; the accept rule `best < max_dist [&& (float)second / (float)best > 2]` therefore reads: the best entry
+// has no unclaimed column before it with distance <= 2 * best ("blocker").  Blockers with distance < 30 are entries
+// of the same list; the others are what k_ti_lists stored next to the entry (or, rarely, found in the full row D).
+//
+// Round: (1) every unresolved row publishes the columns it could still claim (minrow[column] = lowest such row);
+// (2) a row is FINAL when no earlier unresolved row can change its outcome: its best column cannot be claimed by an
+// earlier row, and - if the ratio test rejects it - one of its blockers cannot be claimed by an earlier row either (the
+// row then stays rejected whatever else happens).  Accepted rows claim their column; the claim carries the row's rank,
+// and a row only sees the claims of EARLIER rows (ti_avail): a later row that is resolved first must not change what
+// an earlier, still unresolved row sees.  The first unresolved row is always final, so every round makes progress.
+//
+// Thread k owns active row k (its entries live in registers for the whole pass).  Rows with more claimable columns than
+// entries, and active rows beyond 1024, are "dense": a whole wave evaluates such a row from its distance row in D.
+__device__ __forceinline__ bool ti_avail(const TiLds& S, int j, int k) { return (int)S.claimer[j] > k + 1; }
+
+// resolve row k given its evaluation; returns true when the row is final
+template <int PASS>
+__device__ __forceinline__ bool ti_finalize(TiLds& S, TrackState* st, TrackPool& P, int k, int bj, uint32_t minrow_bj,
+                                            bool ok, bool perm, int rounds, const svo_kp* kp, int n_boxes) {
+  if (minrow_bj < (uint32_t)k) return false;   // an earlier unresolved row may still take the best column
+  if (!ok && !perm) return false;                 // rejected, but every blocker may still be claimed away
+  if (rounds > 0) atomicAdd(&S.cnt_late, 1);
+  if (!ok) return true;
+  const int m = S.act_m[k];
+  if (PASS == 1 && n_boxes > 0) {
+    // epipolar veto (src/pnpmatch.cc:103-144): the match lands in a padded box and is off the epipolar
+    // line -> the map point is marked bad and claims nothing
+    const svo_kp kc = kp[bj];
+    const int i_last = S.act_i[k];
+    if (svo_in_boxes(kc.x, kc.y, st->boxes, n_boxes, 10) &&
+        svo_epipolar_distance(st->F, st->last_xy[2 * i_last], st->last_xy[2 * i_last + 1], kc.x, kc.y) > 0.1) {
+      P.bad[m] = 1;
+      atomicAdd(&S.cnt_veto, 1);
+      return true;
     }
   }
+  S.cur_mp[bj] = m;     // rows finalised in one round never share a best column
+  S.pend[bj] = (uint16_t)(k + 1);
+  S.observed[m] = 1;
+  atomicAdd(&S.cnt_acc, 1);
+  return true;
 }
 
-// The reference's scan `if (dist < best) { second = best; best = dist; idx = j; }` over the unclaimed columns in
-// index order (src/pnpmatch.cc:75-94), restricted to the candidates (see the file header for why that is exact).
-template <int PASS>
-__device__ __forceinline__ void ti_eval(const TiLds& S, const TrackState* st, int k, int nkp, int& bj, int& bd, int& sec) {
-  int b = 256, s2 = 256, j0 = -1;
-  ti_for_entries<PASS>(S, st, k, nkp, [&](int j, int d) {
-    if ((int)S.claimer[j] <= k + 1) return;
-    if (d < b) { s2 = b; b = d; j0 = j; }
-  });
-  bj = j0; bd = b; sec = s2;
+// lane's eight columns (8 lane .. 8 lane + 7) of dense-list row q (pool row m): from the LDS cache once filled
+__device__ __forceinline__ uint4 ti_dense_piece(TiLds& S, const TrackState* st, int q, int m, int lane, int ncached) {
+  if (q < ncached) return *reinterpret_cast<const uint4*>(&S.dnD[q][lane * 8]);
+  const uint4 v = *reinterpret_cast<const uint4*>(st->D + (size_t)m * 512 + lane * 8);
+  if (q < TRK_DNC) *reinterpret_cast<uint4*>(&S.dnD[q][lane * 8]) = v;   // only this wave touches row q until the next barrier
+  return v;
 }
 
-// One greedy pass over the n_act active rows (S.act_*), in rounds.  Returns the number of rounds.
 template <int PASS>
 __device__ __forceinline__ int ti_resolve_pass(TiLds& S, TrackState* st, TrackPool& P, int n_act, int nkp,
                                                const svo_kp* kp, int n_boxes) {
-  const int tid = threadIdx.x;
-  const int max_dist = PASS == 1 ? 15 : 30;
-  // lists of the first 1024 active rows into LDS (coalesced: 16 consecutive words per row)
-  for (int x = tid; x < min(n_act, 1024) * TRK_LCAP; x += 1024) {
-    const int k = x / TRK_LCAP, e = x % TRK_LCAP;
-    const int nc = S.act_n[k];
-    if (nc != TRK_DENSE && e < nc) S.ll[x] = st->cand[(size_t)S.act_m[k] * TRK_LCAP + e];
-  }
-  for (int k = tid; k < n_act; k += 1024) S.fin[k] = 0;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int max_dist = PASS == 1 ? 15 : 30;
+  // ---- set-up: my row's entries into registers; dense rows into a list ------------------------
+  const int k = tid;
+  int nc = 0;
+  uint32_t w0[TRK_LCAP], w1[TRK_LCAP];
+#pragma unroll
+  for (int i = 0; i < TRK_LCAP; ++i) { w0[i] = 0; w1[i] = 0; }
+  bool unresolved = false;
+  if (tid == 0) { S.nd = 0; S.flag = 0; }
   if (tid < TRK_MAXKP) { S.minrow[tid] = 0xffffffffu; S.pend[tid] = 0; }
   __syncthreads();
-  int rounds = 0;
-  for (;;) {
-    // phase 1: every unresolved row publishes the columns it could still claim
-    int any = 0;
-    for (int k = tid; k < n_act; k += 1024) {
-      if (S.fin[k]) continue;
-      any = 1;
-      ti_for_entries<PASS>(S, st, k, nkp, [&](int j, int d) {
-        if ((int)S.claimer[j] > k + 1 && d < max_dist) atomicMin(&S.minrow[j], (uint32_t)k);
-      });
+  for (int kk = tid; kk < n_act; kk += 1024) {
+    const int n = S.act_n[kk];
+    if (n == TRK_DENSE || kk >= 1024) {
+      S.dn[atomicAdd(&S.nd, 1)] = (uint16_t)kk;
+      S.fin[kk] = 0;
+    } else if (kk == k) {
+      nc = n;
+      const uint4* src = reinterpret_cast<const uint4*>(st->cand + (size_t)S.act_m[kk] * 2 * TRK_LCAP);
+      uint4 v[TRK_LCAP / 2];
+#pragma unroll
+      for (int q = 0; q < TRK_LCAP / 2; ++q) v[q] = src[q];
+#pragma unroll
+      for (int q = 0; q < TRK_LCAP / 2; ++q) { w0[2 * q] = v[q].x; w1[2 * q] = v[q].y; w0[2 * q + 1] = v[q].z; w1[2 * q + 1] = v[q].w; }
+      unresolved = true;
     }
-    if (!__syncthreads_or(any)) break;
-    // phase 2: a row whose result no earlier unresolved row can change is final
-    for (int k = tid; k < n_act; k += 1024) {
-      if (S.fin[k]) continue;
-      int bj, bd, sec;
-      ti_eval<PASS>(S, st, k, nkp, bj, bd, sec);
-      if (bj < 0 || bd >= max_dist) { S.fin[k] = 1; continue; }   // claims only remove columns: never accepted
-      // accept rule: best < max_dist [&& (float)second / (float)best > 2, i.e. second > 2 * best in integers]
-      const bool ok = PASS == 1 || sec > 2 * bd;
-      bool safe = S.minrow[bj] >= (uint32_t)k;
-      if (safe && !ok) {
-        // rejected by the ratio test: becomes acceptable if the columns that hold `second` down get claimed
-        ti_for_entries<PASS>(S, st, k, nkp, [&](int j, int d) {
-          if (j < bj && (int)S.claimer[j] > k + 1 && d <= 2 * bd && S.minrow[j] < (uint32_t)k) safe = false;
-        });
+  }
+  __syncthreads();
+  int rounds = 0;
+  int ncached = 0;
+  for (;;) {
+    const int nd = S.nd;   // rows may join the dense list during a round
+    const int nd1 = min(nd, TRK_DNC);   // cached once phase 1 of this round has run
+    // ---- phase 1: every unresolved row publishes the columns it could still claim -------------
+    uint32_t avail = 0;   // bit i: entry i not claimed by an earlier row (and below max_dist)
+    if (unresolved) {
+      uint32_t cl[TRK_LCAP];
+#pragma unroll
+      for (int i = 0; i < TRK_LCAP; ++i) cl[i] = S.claimer[w0[i] & 511u];   // all reads in flight together
+#pragma unroll
+      for (int i = 0; i < TRK_LCAP; ++i) {
+        const int d = (int)((w0[i] >> 9) & 31u);
+        if (i < nc && d < max_dist && (int)cl[i] > k + 1) avail |= 1u << i;
       }
-      if (!safe) continue;
-      S.fin[k] = 1;
-      if (rounds > 0) atomicAdd(&S.cnt_late, 1);
-      if (!ok) continue;
-      const int m = S.act_m[k];
-      if (PASS == 1 && n_boxes > 0) {
-        // epipolar veto (src/pnpmatch.cc:103-144): the match lands in a padded box and is off the epipolar
-        // line -> the map point is marked bad and claims nothing
-        const svo_kp kc = kp[bj];
-        const int i_last = S.act_i[k];
-        if (svo_in_boxes(kc.x, kc.y, st->boxes, n_boxes, 10) &&
-            svo_epipolar_distance(st->F, st->last_xy[2 * i_last], st->last_xy[2 * i_last + 1], kc.x, kc.y) > 0.1) {
-          P.bad[m] = 1;
-          atomicAdd(&S.cnt_veto, 1);
-          continue;
+#pragma unroll
+      for (int i = 0; i < TRK_LCAP; ++i)
+        if ((avail >> i) & 1u) atomicMin(&S.minrow[w0[i] & 511u], (uint32_t)k);
+      S.flag = 1;
+    }
+    for (int q = wv; q < nd; q += 16) {
+      const int kk = S.dn[q];
+      if (S.fin[kk]) continue;
+      const uint4 v = ti_dense_piece(S, st, q, S.act_m[kk], lane, ncached);
+      const uint32_t dd[8] = {v.x & 0xffff, v.x >> 16, v.y & 0xffff, v.y >> 16, v.z & 0xffff, v.z >> 16, v.w & 0xffff, v.w >> 16};
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int col = lane * 8 + c;
+        if (col < nkp && (int)dd[c] < max_dist && ti_avail(S, col, kk)) atomicMin(&S.minrow[col], (uint32_t)kk);
+      }
+      if (lane == 0) S.flag = 1;
+    }
+    __syncthreads();
+    if (!S.flag) break;
+    // ---- phase 2: rows whose outcome no earlier unresolved row can change are final -------------
+    if (unresolved) {
+      int bd = 256, bj = -1;
+      uint32_t w0b = 0, w1b = 0;
+#pragma unroll
+      for (int i = 0; i < TRK_LCAP; ++i) {
+        const int d = (int)((w0[i] >> 9) & 31u);
+        if (((avail >> i) & 1u) && d < bd) { bd = d; bj = (int)(w0[i] & 511u); w0b = w0[i]; w1b = w1[i]; }
+      }
+      if (bj < 0) {
+        unresolved = false;    // claims only remove columns: never accepted
+      } else {
+        bool ok = true, perm = false;
+        const uint32_t mrbj = S.minrow[bj];
+        if (PASS == 2) {
+          // everything the decision may need from LDS, requested together: minrow of the entries, claimer and minrow
+          // of the best entry's stored blockers
+          uint32_t mr[TRK_LCAP], bc[3], bm[3];
+#pragma unroll
+          for (int i = 0; i < TRK_LCAP; ++i) mr[i] = S.minrow[w0[i] & 511u];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) { const uint32_t j = (w1b >> (9 * q)) & 511u; bc[q] = S.claimer[j]; bm[q] = S.minrow[j]; }
+#pragma unroll
+          for (int i = 0; i < TRK_LCAP; ++i) {   // blockers inside the list (entries are in column order)
+            const int j = (int)(w0[i] & 511u), d = (int)((w0[i] >> 9) & 31u);
+            if (((avail >> i) & 1u) && j < bj && d <= 2 * bd) { ok = false; perm = perm || mr[i] >= (uint32_t)k; }
+          }
+          const int nb = (int)((w0b >> 14) & 3u);
+          bool all_taken = true;
+#pragma unroll
+          for (int q = 0; q < 3; ++q)   // stored blockers outside the list (distance in [30, 2 * best])
+            if (q < nb && (int)bc[q] > k + 1) { all_taken = false; ok = false; perm = perm || bm[q] >= (uint32_t)k; }
+          if (ok && all_taken && ((w0b >> 16) & 1u)) {
+            // every stored blocker has been claimed and there were more (rare): from now on a wave evaluates this row
+            // from its full distance row
+            S.fin[k] = 0;
+            S.dn[atomicAdd(&S.nd, 1)] = (uint16_t)k;
+            unresolved = false;
+            bj = -1;
+          }
+        }
+        if (bj >= 0 && ti_finalize<PASS>(S, st, P, k, bj, mrbj, ok, perm, rounds, kp, n_boxes)) unresolved = false;
+      }
+    }
+    for (int q = wv; q < nd; q += 16) {
+      const int kk = S.dn[q];
+      if (S.fin[kk]) continue;
+      const uint4 v = ti_dense_piece(S, st, q, S.act_m[kk], lane, nd1);
+      const uint32_t dd[8] = {v.x & 0xffff, v.x >> 16, v.y & 0xffff, v.y >> 16, v.z & 0xffff, v.z >> 16, v.w & 0xffff, v.w >> 16};
+      uint32_t key = 0xffffffffu;
+      uint32_t am = 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int col = lane * 8 + c;
+        if (col < nkp && ti_avail(S, col, kk)) {
+          am |= 1u << c;
+          if ((int)dd[c] < max_dist) key = min(key, (dd[c] << 16) | (uint32_t)col);
         }
       }
-      S.cur_mp[bj] = m;     // distinct rows finalised in one round never share a best column
-      S.pend[bj] = (uint16_t)(k + 1);
-      S.observed[m] = 1;
-      atomicAdd(&S.cnt_acc, 1);
+      key = wave_min_u32_dpp(key);
+      if (key == 0xffffffffu) { if (lane == 0) S.fin[kk] = 1; continue; }
+      const int bj = (int)(key & 0xffffu), bd = (int)(key >> 16);
+      bool blk = false, pb = false;
+      if (PASS == 2) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int col = lane * 8 + c;
+          if (((am >> c) & 1u) && col < bj && (int)dd[c] <= 2 * bd) { blk = true; pb = pb || S.minrow[col] >= (uint32_t)kk; }
+        }
+      }
+      const bool ok = __ballot(blk) == 0, perm = __ballot(pb) != 0;
+      if (lane == 0 && ti_finalize<PASS>(S, st, P, kk, bj, S.minrow[bj], ok, perm, rounds, kp, n_boxes)) S.fin[kk] = 1;
     }
     __syncthreads();
     if (tid < TRK_MAXKP) {
       if (S.pend[tid]) { S.claimer[tid] = S.pend[tid]; S.pend[tid] = 0; }
       S.minrow[tid] = 0xffffffffu;
     }
+    if (tid == 0) S.flag = 0;
     __syncthreads();
+    ncached = nd1;
     ++rounds;
   }
   // what this pass claimed is simply taken for the next pass
@@ -370,6 +503,7 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
   const int np_start = st->npool, lastN = st->lastN, gid0 = st->next_gid;
   TrackPool& P = st->pool[st->cur];
   TrackPool& Q = st->pool[st->cur ^ 1];
+  long long ts0 = clock64(), ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
   // ---- frame begin ---------------------------------------------------------------------------
   if (tid < TRK_MAXKP) { S.cur_mp[tid] = -1; S.claimer[tid] = tid >= nkp ? 0 : 0xffffu; }
   for (int r = tid; r < TRK_CAP; r += 1024) { S.observed[r] = 0; S.ref[r] = 0; }
@@ -378,7 +512,7 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
   const int n_stereo = __syncthreads_count(has_depth);
   int edge_gid = -1;          // map-point id matched to keypoint `tid`
   int npool = np_start, n_new0 = 0, next_gid = gid0;
-  int n_pass1 = 0, n_pass2 = 0, n_act1 = 0, n_act2 = 0, rounds1 = 0, late2 = 0, n_veto = 0;
+  int n_pass1 = 0, n_pass2 = 0, n_act1 = 0, n_act2 = 0, rounds1 = 0, rounds2v = 0, late2 = 0, n_veto = 0;
   if (id == 0) {
     // Tracking::init (src/Tracking.cc:42-97): one map point per keypoint with depth.  Its `dynamic` flag is declared
     // outside the keypoint loop and never reset (:44): once a keypoint falls into a padded box, every later one is
@@ -405,6 +539,7 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
     __syncthreads();
   } else {
     // ---- pass 1 (src/pnpmatch.cc:61-156): last frame's map points, in keypoint order --------
+    ts1 = clock64();
     {
       int m = -1;
       bool act = false;
@@ -421,25 +556,34 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
       if (tid == 0) { S.cnt_acc = 0; S.cnt_late = 0; }
     }
     // ---- pass 2 (src/pnpmatch.cc:159-199): local map points not observed by this frame -------
+    ts2 = clock64();
     {
+      // rows 4 tid .. 4 tid + 3: flags as 4-byte / 8-byte vector loads, all in flight together
+      const uint32_t loc4 = *reinterpret_cast<const uint32_t*>(&P.in_local[4 * tid]);
+      const uint32_t bad4 = *reinterpret_cast<const uint32_t*>(&P.bad[4 * tid]);
+      const uint32_t obs4 = *reinterpret_cast<const uint32_t*>(&S.observed[4 * tid]);
+      const uint2 rm4 = *reinterpret_cast<const uint2*>(&st->rowmin[4 * tid]);
+      const uint32_t nc4 = *reinterpret_cast<const uint32_t*>(&st->ncand[4 * tid]);
+      const uint32_t rmv[4] = {rm4.x & 0xffffu, rm4.x >> 16, rm4.y & 0xffffu, rm4.y >> 16};
       int cnt = 0;
       uint32_t bits = 0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int r = 4 * tid + q;
-        if (r < npool && P.in_local[r] && !P.bad[r] && !S.observed[r] && st->rowmin[r] < 30) { bits |= 1u << q; ++cnt; }
+        if (r < npool && ((loc4 >> (8 * q)) & 0xffu) && !((bad4 >> (8 * q)) & 0xffu) && !((obs4 >> (8 * q)) & 0xffu) && rmv[q] < 30u) {
+          bits |= 1u << q; ++cnt;
+        }
       }
       int k = block_excl_scan(cnt, S.sm, &n_act2);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if ((bits >> q) & 1u) {
-          const int r = 4 * tid + q;
-          S.act_m[k] = (uint16_t)r; S.act_n[k] = st->ncand[r];
+          S.act_m[k] = (uint16_t)(4 * tid + q); S.act_n[k] = (uint8_t)((nc4 >> (8 * q)) & 0xffu);
           ++k;
         }
       __syncthreads();
-      ti_resolve_pass<2>(S, st, P, n_act2, nkp, kp, 0);
-      n_pass2 = S.cnt_acc; late2 = S.cnt_late;
+      const int rounds2 = ti_resolve_pass<2>(S, st, P, n_act2, nkp, kp, 0);
+      n_pass2 = S.cnt_acc; late2 = S.cnt_late; rounds2v = rounds2;
       __syncthreads();
     }
     if (tid < nkp && S.cur_mp[tid] >= 0) edge_gid = P.gid[S.cur_mp[tid]];
@@ -448,6 +592,7 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
     st->dbg_cur_mp[tid] = tid < nkp ? S.cur_mp[tid] : -1;
     work->edge_gid[tid] = edge_gid;
   }
+  ts3 = clock64();
   // ---- frame end: createmappoint (src/frame.cc:182-238) for keypoints without a map point ------
   int m_cur = tid < nkp ? S.cur_mp[tid] : -1;
   bool create = tid < nkp && m_cur < 0 && has_depth;
@@ -477,34 +622,41 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
   __syncthreads();
   // ---- cull (src/Tracking.cc:239-250) + stable compaction into the other pool half -------------
   // live = still in the local map, or referenced by this frame's keypoints (next frame's pass 1 needs it)
-  int live_cnt = 0, oldest = 0x7fffffff;
-  uint32_t live_bits = 0;
+  int live_cnt = 0, oldest = 0x7fffffff, nl = 0;
+  uint32_t live_bits = 0, loc_bits = 0;
+  // rows 4 tid .. 4 tid + 3 of the pool, every field as one vector load, the descriptors (8 x 16 bytes) with them
+  const uint32_t loc4 = *reinterpret_cast<const uint32_t*>(&P.in_local[4 * tid]);
+  const uint32_t bad4 = *reinterpret_cast<const uint32_t*>(&P.bad[4 * tid]);
+  const uint32_t ref4 = *reinterpret_cast<const uint32_t*>(&S.ref[4 * tid]);
+  const int4 cid4 = *reinterpret_cast<const int4*>(&P.create_id[4 * tid]);
+  const int4 gid4 = *reinterpret_cast<const int4*>(&P.gid[4 * tid]);
+  uint4 dsc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) dsc[q] = reinterpret_cast<const uint4*>(&P.desc[32 * tid])[q];
+  const int cidv[4] = {cid4.x, cid4.y, cid4.z, cid4.w}, gidv[4] = {gid4.x, gid4.y, gid4.z, gid4.w};
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int r = tid * 4 + q;
     if (r < np1) {
-      bool loc = P.in_local[r] != 0;
-      if (id >= 4 && P.create_id[r] <= id - 4) loc = false;
-      P.in_local[r] = loc ? 1 : 0;
-      if (loc || S.ref[r]) { live_bits |= 1u << q; ++live_cnt; oldest = min(oldest, P.gid[r]); }
+      bool loc = ((loc4 >> (8 * q)) & 0xffu) != 0;
+      if (id >= 4 && cidv[q] <= id - 4) loc = false;   // cull
+      if (loc) { loc_bits |= 1u << q; }
+      if (loc || ((ref4 >> (8 * q)) & 0xffu)) { live_bits |= 1u << q; ++live_cnt; oldest = min(oldest, gidv[q]); nl += loc ? 1 : 0; }
     }
   }
   int total_live;
   int base = block_excl_scan(live_cnt, S.sm, &total_live);
-  int nl = 0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int r = tid * 4 + q;
     if ((live_bits >> q) & 1u) {
       const int d = base++;
-      const uint4* src = reinterpret_cast<const uint4*>(&P.desc[8 * r]);
       uint4* dst = reinterpret_cast<uint4*>(&Q.desc[8 * d]);
-      dst[0] = src[0]; dst[1] = src[1];
-      Q.create_id[d] = P.create_id[r];
-      Q.gid[d] = P.gid[r];
-      Q.bad[d] = P.bad[r];
-      Q.in_local[d] = P.in_local[r];
-      nl += P.in_local[r];
+      dst[0] = dsc[2 * q]; dst[1] = dsc[2 * q + 1];
+      Q.create_id[d] = cidv[q];
+      Q.gid[d] = gidv[q];
+      Q.bad[d] = (uint8_t)((bad4 >> (8 * q)) & 0xffu);
+      Q.in_local[d] = (uint8_t)((loc_bits >> q) & 1u);
       S.remap[r] = (int16_t)d;
     } else if (r < np1) {
       S.remap[r] = -1;
@@ -519,8 +671,11 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
     work->frame_id = id; work->nkp = nkp; work->n_stereo = n_stereo;
     work->n_pass1 = n_pass1; work->n_pass2 = n_pass2;
     work->n_new = n_new0 + n_new; work->n_local = nl_total; work->skip_match = id == 0 ? 1 : 0;
+    ts4 = clock64();
+    work->ts[0] = ts0; work->ts[1] = ts1; work->ts[2] = ts2; work->ts[3] = ts3; work->ts[4] = ts4;
+    work->ts[5] = S.nd; work->ts[6] = late2; work->ts[7] = 0;
     work->diag[0] = n_act1 | (rounds1 << 16);
-    work->diag[1] = n_act2 | (late2 << 16);
+    work->diag[1] = n_act2 | (rounds2v << 16);
     st->n_vetoed = n_veto;
     st->lastN = nkp;
     st->npool = total_live;
@@ -536,7 +691,7 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
 // ================================================================================================
 struct TpLds {
   PoseLds pose;
-  int sm[16];
+  alignas(16) int sm[16];
   float sT[16], sRwc[9], stwc[3];
 };
 
@@ -613,7 +768,7 @@ __global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, const TrackWor
     r.n_new_mappoints = work->n_new;
     r.n_local_map = work->n_local;
     r.lm_iterations = st->lm.iterations;
-    r.reserved[0] = work->diag[0];   // diagnostics: rows of pass 1 | rounds << 16; [1]: rows of pass 2 | late rows << 16
+    r.reserved[0] = work->diag[0];   // diagnostics: rows of pass 1 | rounds << 16; [1]: rows of pass 2 | rounds << 16
     r.reserved[1] = work->diag[1];
     *res_out = r;
   }
@@ -681,8 +836,8 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
     const float* depf = depth + (size_t)f * kstride;
     {
       SvoTimer t(ctx, "k_ti_lists", s1);
-      if (ny >= 8) hipLaunchKernelGGL(k_ti_lists<16>, dim3(TRK_ROWS_MAX / 16, ny), dim3(256), 0, s1, st, descf, nkp + f, kstride, ctx->opt_track_lcap);
-      else hipLaunchKernelGGL(k_ti_lists<4>, dim3(TRK_ROWS_MAX / 4, ny), dim3(256), 0, s1, st, descf, nkp + f, kstride, ctx->opt_track_lcap);
+      if (ny >= 8) hipLaunchKernelGGL(k_ti_lists<16>, dim3(TRK_ROWS_MAX / 16, ny), dim3(256), 0, s1, st, descf, nkp + f, kstride, ctx->opt_track_lcap, ctx->opt_track_nblk);
+      else hipLaunchKernelGGL(k_ti_lists<4>, dim3(TRK_ROWS_MAX / 4, ny), dim3(256), 0, s1, st, descf, nkp + f, kstride, ctx->opt_track_lcap, ctx->opt_track_nblk);
     }
     {
       SvoTimer t(ctx, "k_ti_resolve", s1);
@@ -969,5 +1124,15 @@ extern "C" int svo_debug_track_gate(svo_ctx* ctx, double F[9], int32_t* n_vetoed
   if (F) SVO_HIP(ctx, hipMemcpyAsync(F, st->F, 72, hipMemcpyDeviceToHost, ctx->stream));
   if (n_vetoed) SVO_HIP(ctx, hipMemcpyAsync(n_vetoed, &st->n_vetoed, 4, hipMemcpyDeviceToHost, ctx->stream));
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SVO_OK;
+}
+
+// Diagnostics: s_memtime stamps (shader clock) of k_ti_resolve's phases for work slot `slot` of the last call:
+// begin, pass 1, pass 2, frame end, done.
+extern "C" int svo_debug_track_stamps(svo_ctx* ctx, int slot, int64_t ts[8]) {
+  if (!ctx || !ts || !ctx->d_work || slot < 0 || slot >= ctx->work_cap) return SVO_E_INVALID;
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  TrackWork* w = reinterpret_cast<TrackWork*>(ctx->d_work) + slot;
+  SVO_HIP(ctx, hipMemcpy(ts, w->ts, sizeof(long long) * 8, hipMemcpyDeviceToHost));
   return SVO_OK;
 }

@@ -7,7 +7,7 @@ configs[4]  "semantic mask + libelas dense stereo fused": depth_source = 1 TOGET
             (reference src/Tracking.cc:225-228 + src/frame.cc:198-203 + src/pnpmatch.cc:101-144), against the
             oracle tracker fed with the maps of the reference's own compiled libelas.
 Long run    >= 64 full-size frames GPU vs oracle, frame by frame: culling (from frame 4 on), pool compaction,
-            the re-scan path of the greedy passes, and a no-match sequence that drives the map-point pool to its
+            the re-evaluation rounds of the greedy passes, and a no-match sequence that drives the map-point pool to its
             largest reachable size.
 """
 import importlib
@@ -184,7 +184,7 @@ def test_64_frames_gpu_tracker_equals_oracle(pkg, orc):
     rec = np.array([g[0] for g in gpu])
     assert rec["n_local_map"][8:].max() > 800                 # four frames of new points
     assert (rec["n_match_pass2"][4:] > 0).sum() > 40          # pass 2 contributes on most frames
-    assert ((rec["reserved"][:, 1] >> 16) > 0).sum() > 10     # re-evaluated rows in pass 2
+    assert ((rec["reserved"][:, 1] >> 16) > 1).sum() > 10     # pass 2 needed more than one round: rows were re-evaluated
     Twc = np.linalg.inv(rec[-1]["Tcw"].reshape(4, 4).astype(np.float64))
     assert np.linalg.norm(Twc[:3, 3] - T[-1][:3, 3].numpy()) < 3.0
 

@@ -61,9 +61,15 @@ def test_local_map_window(oracle_run):
 
 
 @pytest.mark.gpu
-def test_gpu_tracker_matches_oracle(pkg, sequence, oracle_run):
+@pytest.mark.parametrize("lcap,nblk", [(8, 3), (1, 3), (8, 0), (2, 1)])
+def test_gpu_tracker_matches_oracle(pkg, sequence, oracle_run, lcap, nblk):
+    """(8, 3) is the product's configuration; the others force the matching passes onto their fall-back paths - rows
+    with more claimable keypoints than packed entries (evaluated on the full distance row) and entries whose stored
+    runner-up blockers do not suffice (looked up in the row)."""
     L, R, _ = sequence
     svo = pkg.Svo(L.shape[2], L.shape[1], max_batch=1)
+    svo.set_option("track_lcap", lcap)
+    svo.set_option("track_nblk", nblk)
     svo.track_reset(pkg.Camera(**pkg.KITTI_00_02))
     for k in range(N_FRAMES):
         res = svo.track_frame(L[k], R[k])

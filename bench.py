@@ -1,18 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py - stereo pairs/s through the MI355X-native tracking front end.
+"""bench.py - stereo frames/s through the MI355X-native tracking path.
 
-One "step" = one pass of the hot path over one batch of B synthetic KITTI-00-shaped
-stereo pairs (1241x376 gray, synth-kitti renderer) that are already resident in HBM.
-  --workload frontend (default, BASELINE.json configs[1], batched): ORB pyramid
-        extraction on both images + sparse epipolar stereo for B pairs per step.
-  --workload track    (configs[2]): the same front end + the ordered tracking tail
-        (matching passes, PnP-RANSAC, pose-only LM, map-point lifecycle) over B
-        consecutive frames of ONE sequence per step; reports ATE vs ground truth.
-The default run also times a bounded `track` leg and reports it under "track".
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL, used ONLY for the
-barrier and the max-over-ranks clock); stereo pairs are sharded with no data-path
-collective (frontend: pair k -> rank k mod N; track: rank r tracks its own sequence,
-seed + r), weak scaling.  Prints ONE JSON line on rank 0.
+The headline is BASELINE.json's metric on its configuration: the FULL Tracking::Track chain
+(configs[2]) over a KITTI-00-sized sequence - 4541 DISTINCT synthetic stereo pairs (1241x376
+gray, synth-kitti renderer), all resident in HBM before the clock starts.
+  --workload track (default): one "step" = svo_track_batch_dev over B consecutive frames of the
+        ONE sequence (front end batched over the B pairs, then the ordered tail frame by frame);
+        B = 4541 // (warmup + steps), the remainder rides in the first warm-up step so that the
+        whole sequence is tracked and ATE is over all of it.
+  --workload frontend (BASELINE configs[1], batched): ORB on both images + sparse epipolar
+        stereo for B pairs per step, rotating through the resident sequence (every step reads
+        B new pairs: the inputs do not stay in the 256 MiB Infinity Cache).
+The default line also carries named legs: "frontend", "multi_sequence", "elas", "msa", and the
+CPU baseline (the oracle's single-thread port on a bounded prefix, with the GPU-vs-CPU ATE).
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL, used ONLY for the barrier and
+the max-over-ranks clock).  The tracking chain of one sequence does not shard (replicas only:
+rank r tracks its own sequence, seed + r); the front-end workload shards by stereo pair with no
+data-path collective (pair k -> rank k mod N).  Weak scaling.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import importlib
@@ -40,7 +44,22 @@ KERNEL_BYTES_PER_IMAGE = {
     "k_fast": S_PYR * W * H,                      # "S [FAST read]"
     "k_pyr_level": (1 + (S_PYR - 1)) * W * H,     # "1 [src read] + (S-1) [pyramid write]"
     "k_pyr_fast": (1 + (S_PYR - 1) + S_PYR) * W * H,
+    "k_select": 2 * 500 * 81,                     # Harris: 2N 9x9 windows
+    "k_describe": 500 * 37 * 37 + 500 * 60,       # patch gathers + keypoint / descriptor records
 }
+KERNEL_BYTES_PER_PAIR = {"k_stereo_match": 500 * (11 * 11 + 11 * 21) + 2 * 500 * 32, "k_stereo_median": 500 * 12}
+
+
+def tail_kernel_bytes(kernel, mean_pool_rows, mean_kp, mean_edges, mean_lm_iters):
+    """Algorithmic bytes per FRAME of the three kernels of the ordered tail (SURVEY 8d's
+    Hamming and pose-opt terms): what the stage has to touch once, not what the implementation moves."""
+    if kernel == "k_ti_lists":      # Hamming: (M + N) descriptors of 32 bytes
+        return (mean_pool_rows + mean_kp) * 32.0
+    if kernel == "k_ti_resolve":    # packed entries of the M rows in, the compacted pool (descriptor + 10 bytes) out and in
+        return mean_pool_rows * (64.0 + 2 * 42.0) + mean_kp * 60.0
+    if kernel == "k_tp_frame":      # n correspondences of 40 bytes: once per PnP hypothesis batch + once per LM iteration
+        return mean_edges * 40.0 * (2.0 + mean_lm_iters)
+    return None
 
 
 def pmc_traffic(kernel):
@@ -74,22 +93,27 @@ def pmc_valu(kernel):
 
 def render_frames(synth, n, dev, seed, start=0):
     """n consecutive frames resident on `dev`, padded to PITCH; + ground truth.  synth-kitti by
-    default; real KITTI 00 frames when KITTI_ROOT is set (layout of the reference's main.cpp:20-57)."""
+    default; real KITTI 00 frames when KITTI_ROOT is set (layout of the reference's main.cpp:20-57).
+    Rendered / loaded in chunks so that only the padded uint8 frames stay resident."""
     root = os.environ.get("KITTI_ROOT")
-    if root:
-        kio = importlib.import_module("stereo_semantic_vo_amd.kitti_io")
-        Ln, Rn = kio.load_frames(root, "00", start, n)
-        assert Ln.shape[1:] == (H, W), "KITTI 00 frames are expected to be %dx%d" % (W, H)
-        gt = kio.load_poses(root, "00")
-        T = torch.from_numpy(gt[start:start + n] if gt is not None else np.tile(np.eye(4), (n, 1, 1)))
-        L, R = torch.from_numpy(Ln).to(dev), torch.from_numpy(Rn).to(dev)
-    else:
-        L, R, T = synth.render_sequence(n, seed=seed, device=dev, start=start)
     dL = torch.zeros((n, H, PITCH), dtype=torch.uint8, device=dev)
     dR = torch.zeros_like(dL)
-    dL[:, :, :W] = L
-    dR[:, :, :W] = R
-    return dL, dR, T
+    Ts = []
+    kio = importlib.import_module("stereo_semantic_vo_amd.kitti_io") if root else None
+    gt = kio.load_poses(root, "00") if root else None
+    for c0 in range(0, n, 64):
+        c = min(64, n - c0)
+        if root:
+            Ln, Rn = kio.load_frames(root, "00", start + c0, c)
+            assert Ln.shape[1:] == (H, W), "KITTI 00 frames are expected to be %dx%d" % (W, H)
+            T = torch.from_numpy(gt[start + c0:start + c0 + c] if gt is not None else np.tile(np.eye(4), (c, 1, 1)))
+            L, R = torch.from_numpy(Ln).to(dev), torch.from_numpy(Rn).to(dev)
+        else:
+            L, R, T = synth.render_sequence(c, seed=seed, device=dev, start=start + c0)
+        dL[c0:c0 + c, :, :W] = L
+        dR[c0:c0 + c, :, :W] = R
+        Ts.append(T)
+    return dL, dR, torch.cat(Ts)
 
 
 def ate_rmse(res, T_gt):
@@ -154,10 +178,16 @@ def elas_leg(pkg, W, H, device, d_L, d_R, pitch, B, iters=4):
     ctx.elas_batch_dev(d_L.data_ptr(), d_R.data_ptr(), pitch, W, H, B, D1.data_ptr(), D2.data_ptr(), p)
     ctx.profile_enable(False)
     P = W * H
+    #   k_elas_support 2*16P descriptor bytes read once (HBM-compulsory; the reference's loops re-read 16 KB per lattice
+    #                  point and direction - 0.6 GB per pair - which is what the kernel's L1 actually serves)
+    #   k_elas_lr / k_elas_mean  two 4P maps read and written
+    #   k_elas_planes / k_elas_grid  support-point and triangle lists (tens of KB)
     algo = {"k_elas_desc": 34 * P, "k_elas_match": 48 * P, "k_elas_raster": 8 * P, "k_cc_segments": 28 * P,
-            "k_elas_gap": 16 * P}
+            "k_elas_gap": 16 * P, "k_elas_support": 32 * P, "k_elas_lr": 16 * P, "k_elas_mean": 16 * P,
+            "k_elas_planes": 2 * 8000 * 36, "k_elas_grid": 2 * (W // 20 + 1) * (H // 20 + 1) * 32 * 2}
     kern = {k: v[0] * 1e3 / B for k, v in ctx.profile().items() if k.startswith("k_")}
-    dom = max((k for k in kern if k in algo), key=lambda k: kern[k])
+    dom = max(kern, key=lambda k: kern[k])
+    algo.setdefault(dom, 0)
     ach = algo[dom] / (kern[dom] * 1e-6) / 1e9
     roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": None, "algorithmic_bytes_per_pair": algo[dom],
@@ -268,14 +298,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="stereo pairs per step per GPU")
-    ap.add_argument("--workload", default="frontend", choices=["frontend", "track"])
+    ap.add_argument("--workload", default="track", choices=["track", "frontend"])
+    ap.add_argument("--frames", type=int, default=4541, help="length of the resident sequence (KITTI 00: 4541)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="pairs per step per GPU: track default frames // (warmup + steps), frontend default 128")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--no-track-leg", action="store_true")
-    ap.add_argument("--no-elas-leg", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="only the main workload (no frontend / multi_sequence / elas / msa legs)")
+    ap.add_argument("--no-elas-leg", action="store_true", help="skip the elas and msa legs")
+    ap.add_argument("--no-track-leg", action="store_true", help="(kept for scripts) same as --no-legs for the frontend workload")
     ap.add_argument("--depth-source", type=int, default=0, choices=[0, 1, 2],
-                    help="track workload: 0 sparse epipolar stereo (north star), 1 dense ELAS map (BASELINE configs[4] without YOLO)")
+                    help="track workload: 0 sparse epipolar stereo (north star), 1 dense ELAS map, 2 dense MSA map")
     ap.add_argument("--sequences", type=int, default=1,
                     help="track workload: S concurrent sequences per GPU (svo_track_multi_step_dev), one frame of each per step")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (single-GPU dry runs)")
@@ -300,50 +333,64 @@ def main():
         dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     cam = pkg.Camera(**pkg.KITTI_00_02)
-    B = args.batch
     track = args.workload == "track"
     multi = track and args.sequences > 1
+    nsteps = args.warmup + args.steps
+    extra = 0
     if multi:
-        B = args.sequences                               # one frame of each of the S sequences per step
-    svo = pkg.Svo(W, H, device=local, max_kp=500, max_batch=B)
+        B = args.sequences                              # one frame of each of the S sequences per step
+        n_frames = B + nsteps
+    elif track:
+        B = args.batch if args.batch > 0 else max(1, args.frames // nsteps)
+        # the remainder of the sequence rides in the first warm-up step, so the whole sequence is tracked
+        extra = args.frames - B * nsteps if (args.batch <= 0 and args.warmup > 0 and args.frames > B * nsteps) else 0
+        n_frames = B * nsteps + extra
+    else:
+        B = args.batch if args.batch > 0 else 128
+        n_frames = max(args.frames if world == 1 else B * nsteps, 2 * B)
+    # the resident sequence: rank r renders its own (tracking: replicas; frontend: pair k -> rank k mod N of ONE sequence)
     seed = shard.sequence_seed_for_rank(synth.BASE_SEED, rank) if track else synth.BASE_SEED
-    if multi:
-        # sequence q = the rank's synthetic sequence delayed by q frames: step t hands over frames t .. t+S-1
-        n_frames = B + args.warmup + args.steps
+    t_r = time.perf_counter()
+    if track or world == 1:
         dL, dR, T_gt = render_frames(synth, n_frames, dev, seed)
-        d_res = torch.zeros(((args.warmup + args.steps) * B, pkg.TRACK_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    else:
+        dL = torch.zeros((n_frames, H, PITCH), dtype=torch.uint8, device=dev)
+        dR = torch.zeros_like(dL)
+        T_gt = None
+        for i, k in enumerate(shard.pairs_for_rank(rank, world, n_frames)):
+            fl, fr, _ = render_frames(synth, 1, dev, seed, start=k)
+            dL[i] = fl[0]
+            dR[i] = fr[0]
+    torch.cuda.synchronize()
+    render_s = time.perf_counter() - t_r
+    frame_bytes = H * PITCH
+    rec = pkg.TRACK_DTYPE.itemsize
+    svo = pkg.Svo(W, H, device=local, max_kp=500, max_batch=B + extra)
+    if multi:
+        d_res = torch.zeros((nsteps * B, rec), dtype=torch.uint8, device=dev)
         svo.track_multi_reset(B, cam)
     elif track:
         if args.depth_source:
             svo.set_option("depth_source", args.depth_source)
-        n_frames = B * (args.warmup + args.steps)       # one continuous sequence per rank
-        dL, dR, T_gt = render_frames(synth, n_frames, dev, seed)
-        d_res = torch.zeros((n_frames, pkg.TRACK_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+        d_res = torch.zeros((n_frames, rec), dtype=torch.uint8, device=dev)
         svo.track_reset(cam)
     else:
-        # B pairs per rank: global pair k -> rank k mod N (frame index k of one sequence)
-        dL = torch.zeros((B, H, PITCH), dtype=torch.uint8, device=dev)
-        dR = torch.zeros_like(dL)
-        for i, k in enumerate(shard.pairs_for_rank(rank, world, B)):
-            fl, fr, _ = render_frames(synth, 1, dev, seed, start=k)
-            dL[i] = fl[0]
-            dR[i] = fr[0]
         d_n = torch.zeros(B, dtype=torch.int32, device=dev)
         d_depth = torch.zeros((B, 500), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
-    frame_bytes = H * PITCH
-    rec = pkg.TRACK_DTYPE.itemsize
 
     def step(s):
         if multi:
             svo.track_multi_step_dev(dL.data_ptr() + s * frame_bytes, dR.data_ptr() + s * frame_bytes, PITCH, B,
                                      d_res.data_ptr() + s * B * rec)
         elif track:
-            off = s * B
+            off = s * B + (extra if s > 0 else 0)
+            nb = B + (extra if s == 0 else 0)
             svo.track_batch_dev(dL.data_ptr() + off * frame_bytes, dR.data_ptr() + off * frame_bytes,
-                                PITCH, B, d_res.data_ptr() + off * rec)
+                                PITCH, nb, d_res.data_ptr() + off * rec)
         else:
-            svo.frontend_batch_dev(dL.data_ptr(), dR.data_ptr(), PITCH, B, cam,
+            off = (s * B) % (n_frames - B + 1)           # every step reads B pairs it has not touched for a long time
+            svo.frontend_batch_dev(dL.data_ptr() + off * frame_bytes, dR.data_ptr() + off * frame_bytes, PITCH, B, cam,
                                    d_nL=d_n.data_ptr(), d_depth=d_depth.data_ptr())
 
     def fence():
@@ -359,7 +406,7 @@ def main():
         svo.profile_reset()
         svo.profile_enable(True)
     t0 = time.perf_counter()
-    for s in range(args.warmup, args.warmup + args.steps):
+    for s in range(args.warmup, nsteps):
         step(s)
     fence()
     dt = time.perf_counter() - t0
@@ -371,114 +418,167 @@ def main():
 
     if rank == 0:
         pairs = world * B * args.steps
-        cfg = {"pairs_per_step_per_gpu": B}
+        cfg = {"pairs_per_step_per_gpu": B, "resident_pairs_per_gpu": int(n_frames),
+               "resident_input_bytes_per_gpu": int(2 * n_frames * frame_bytes), "render_seconds": round(render_s, 1)}
+        res = None
         if track:
             res = d_res.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(-1)
             if multi:                                    # accuracy figures from sequence 0 (starts at frame 0)
                 res = res.reshape(-1, B)[:, 0]
                 cfg["concurrent_sequences_per_gpu"] = B
             rmse, last = ate_rmse(res, T_gt.numpy()[:len(res)])
-            cfg.update({"depth_source": "dense ELAS map (svo_elas_batch_dev) -> disp2Depth -> per-keypoint lookups" if args.depth_source
-                        else "sparse epipolar stereo",
-                        "workload": "synth-kitti00 sequence 1241x376, full Tracking::Track loop per frame: ORB on L and R, "
-                                    "sparse stereo, matching passes 1+2, PnP-RANSAC, pose-only LM, map-point "
-                                    "lifecycle (BASELINE configs[2]); " +
+            depth_names = {0: "sparse epipolar stereo", 1: "dense ELAS map (svo_elas_batch_dev) -> disp2Depth -> per-keypoint lookups",
+                           2: "dense MSA map (svo_msa_batch_dev) -> disp2Depth -> per-keypoint lookups"}
+            cfg.update({"depth_source": depth_names[args.depth_source],
+                        "workload": "BASELINE configs[2]: synth-kitti00 sequence of %d distinct 1241x376 stereo pairs, full "
+                                    "Tracking::Track loop per frame (ORB on L and R, sparse stereo, matching passes 1+2, "
+                                    "PnP-RANSAC, pose-only LM, map-point lifecycle); " % len(res) +
                                     ("%d concurrent staggered sequences per GPU, one frame of each per step" % B if multi
-                                     else "one sequence per GPU"),
+                                     else "ONE sequence per GPU in strict frame order (replicas across GPUs)"),
                         "frames_tracked": int(len(res)), "ate_rmse_m_vs_ground_truth": rmse,
                         "final_position_error_m": last, "path_length_m": float(len(res) - 1),
                         "mean_lm_edges": float(res["n_lm_edges"][1:].mean()),
                         "mean_active_rows_pass1_pass2": [float((res["reserved"][1:, 0] & 0xffff).mean()), float((res["reserved"][1:, 1] & 0xffff).mean())],
                         "mean_rounds_pass1_pass2": [float((res["reserved"][1:, 0] >> 16).mean()), float((res["reserved"][1:, 1] >> 16).mean())],
-                        "mean_local_map": float(res["n_local_map"][1:].mean())})
+                        "mean_local_map": float(res["n_local_map"][1:].mean()),
+                        "tracker_capacity_flag": int(svo.track_overflowed())})
         else:
             n_kp = d_n.cpu().numpy()
-            cfg.update({"workload": "synth-kitti00 stereo pairs 1241x376: ORB pyramid (8 levels, 500 kp) on L and R "
-                                    "+ sparse epipolar stereo, HBM-resident (BASELINE configs[1], batched)",
+            cfg.update({"workload": "BASELINE configs[1], batched: synth-kitti00 stereo pairs 1241x376, ORB pyramid (8 levels, 500 kp) "
+                                    "on L and R + sparse epipolar stereo, HBM-resident, every step on %d pairs not touched since "
+                                    "%d steps" % (B, max(1, (n_frames - B + 1) // B)),
                         "sharding": "pair k -> rank k mod N, no collective",
                         "mean_keypoints_left": float(n_kp.mean()),
                         "mean_stereo_depths": int((d_depth > 0).sum().item()) / B})
         out = {
-            "metric": "stereo frames/sec on KITTI 00 (tracking front end)",
-            "value": pairs / dt, "unit": "stereo pairs/s", "n_gpus": world, "steps": args.steps,
+            "metric": "stereo frames/sec on KITTI 00 (full Tracking::Track chain)" if track
+                      else "stereo frames/sec on KITTI 00 (tracking front end only)",
+            "value": pairs / dt, "unit": "stereo frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "kitti00" if os.environ.get("KITTI_ROOT") else "synthetic", "config": cfg,
         }
         if prof:
-            kern = {k: {"avg_ms": v[0] / max(v[1], 1), "launches": v[1]} for k, v in prof.items()}
-            cand = {k: v for k, v in prof.items() if k in KERNEL_BYTES_PER_IMAGE}
-            dom = max(cand.items(), key=lambda kv: kv[1][0])[0]
+            kern = {k: {"avg_ms": v[0] / max(v[1], 1), "launches": v[1], "total_ms": v[0]} for k, v in prof.items()}
+            dom = max(prof.items(), key=lambda kv: kv[1][0])[0]          # the kernel the timed region spends most time in
             dom_s = prof[dom][0] / max(prof[dom][1], 1) * 1e-3
-            algo = KERNEL_BYTES_PER_IMAGE[dom] * 2 * B
+            units = "images"
+            if dom in KERNEL_BYTES_PER_IMAGE:
+                algo = KERNEL_BYTES_PER_IMAGE[dom] * 2 * B
+            elif dom in KERNEL_BYTES_PER_PAIR:
+                algo = KERNEL_BYTES_PER_PAIR[dom] * B
+            else:
+                units = "frames"
+                mp = float(res["n_local_map"][1:].mean()) + 500.0 if res is not None else 0.0
+                algo = tail_kernel_bytes(dom, mp, float(res["n_kp"].mean()), float(res["n_lm_edges"][1:].mean()),
+                                         float(res["lm_iterations"][1:].mean())) * (B if multi else 1)
             ach = algo / dom_s / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": pmc_traffic(dom) if (B == 128 and not track) else None,
-                               "algorithmic_bytes_per_launch": algo,
-                               "valu": pmc_valu(dom) if (B == 128 and not track) else None,
-                               "pipeline_frac": ALGO_BYTES_PER_PAIR * (pairs / dt / world) / 1e9 / HBM_PEAK_GBS}
+                               "traffic": pmc_traffic(dom),
+                               "algorithmic_bytes_per_launch": algo, "launch_covers": "%s of one launch" % units,
+                               "share_of_timed_kernel_time": prof[dom][0] / max(sum(v[0] for v in prof.values()), 1e-9),
+                               "valu": pmc_valu(dom),
+                               "pipeline_frac": ALGO_BYTES_PER_PAIR * (pairs / dt / world) / 1e9 / HBM_PEAK_GBS,
+                               "note": "the ordered tail is a dependent chain of single-workgroup kernels: latency-bound, far "
+                                       "from the HBM roof by construction (DESIGN.md section 5)" if units == "frames" else None}
             out["kernels"] = kern
         if world == 1 and not args.no_cpu_baseline:
-            ns = min(B * (args.warmup + args.steps) if track else B, 64)
+            ns = min(n_frames, 64)
             Lh = dL[:ns, :, :W].cpu().numpy()
             Rh = dR[:ns, :, :W].cpu().numpy()
             out["cpu_baseline"], cpu_poses = cpu_baseline(Lh, Rh, cam, args.workload)
-            if not track:
-                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(Lh, Rh, cam)
-            if track and cpu_poses:
-                k = len(cpu_poses) - 1
-                a = np.linalg.inv(res[k]["Tcw"].reshape(4, 4).astype(np.float64))[:3, 3]
-                b = np.linalg.inv(cpu_poses[k]["Tcw"].reshape(4, 4).astype(np.float64))[:3, 3]
-                out["cpu_baseline"]["gpu_vs_cpu_position_diff_m_at_frame_%d" % k] = float(np.linalg.norm(a - b))
-        if world == 1 and not track and not args.no_track_leg:
-            # bounded full-tracking leg (configs[2]) so the default line also carries it
+            if track and not multi and cpu_poses:
+                # ATE of the GPU trajectory against the CPU port's on the same frames (BASELINE metric: "ATE vs CPU reference")
+                k = len(cpu_poses)
+                ca = np.array([np.linalg.inv(res[i]["Tcw"].reshape(4, 4).astype(np.float64))[:3, 3] for i in range(k)])
+                cb = np.array([np.linalg.inv(cpu_poses[i]["Tcw"].reshape(4, 4).astype(np.float64))[:3, 3] for i in range(k)])
+                d = np.linalg.norm(ca - cb, axis=1)
+                out["ate_vs_cpu_m"] = {"rmse": float(np.sqrt(np.mean(d * d))), "max": float(d.max()), "frames": int(k)}
+                out["cpu_baseline"]["counters_identical_to_gpu"] = bool(all(
+                    all(int(res[i][f]) == int(cpu_poses[i][f]) for f in ("n_kp", "n_stereo", "n_match_pass1", "n_match_pass2",
+                                                                       "n_lm_edges", "n_new_mappoints", "n_local_map"))
+                    for i in range(k)))
+        legs = world == 1 and not args.no_legs and not multi and args.depth_source == 0
+        if legs and track:
             svo.profile_enable(False)
-            nt = 256
-            tL, tR, tT = render_frames(synth, nt, dev, synth.BASE_SEED)
-            tres = torch.zeros((nt, rec), dtype=torch.uint8, device=dev)
-            tb = min(B, 128)
-            svo.track_reset(cam)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for off in range(0, nt, tb):
-                svo.track_batch_dev(tL.data_ptr() + off * frame_bytes, tR.data_ptr() + off * frame_bytes,
-                                    PITCH, min(tb, nt - off), tres.data_ptr() + off * rec)
-            svo.sync()
-            tdt = time.perf_counter() - t1
-            r = tres.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(-1)
-            rmse, last = ate_rmse(r, tT.numpy())
-            out["track"] = {"value": nt / tdt, "unit": "stereo pairs/s", "frames": nt,
-                            "ate_rmse_m_vs_ground_truth": rmse, "final_position_error_m": last,
-                            "note": "one sequence, strict frame order (BASELINE configs[2]); includes the front end"}
-            # the same loop for S staggered sequences advanced together (one workgroup per sequence in the tail)
-            S = min(B, 64)
-            msteps = min(48, nt - S)
-            mres = torch.zeros((msteps * S, rec), dtype=torch.uint8, device=dev)
-            svo.track_multi_reset(S, cam)
-            for t in range(2):
-                svo.track_multi_step_dev(tL.data_ptr() + t * frame_bytes, tR.data_ptr() + t * frame_bytes, PITCH, S,
-                                         mres.data_ptr() + t * S * rec)
-            svo.track_multi_reset(S, cam)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for t in range(msteps):
-                svo.track_multi_step_dev(tL.data_ptr() + t * frame_bytes, tR.data_ptr() + t * frame_bytes, PITCH, S,
-                                         mres.data_ptr() + t * S * rec)
-            svo.sync()
-            mdt = time.perf_counter() - t1
-            m = mres.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(msteps, S)
-            same = all(m[t, 0].tobytes() == r[t].tobytes() for t in range(msteps))
-            out["track"]["multi_sequence"] = {"value": msteps * S / mdt, "unit": "stereo pairs/s", "sequences": S,
-                                              "steps": msteps, "sequence0_equals_single_chain": bool(same)}
-        if world == 1 and not track and not args.no_elas_leg:
-            out["elas"] = elas_leg(pkg, W, H, dev.index or 0, dL, dR, PITCH, min(B, 128))
+            out["frontend"] = frontend_leg(pkg, svo, cam, dL, dR, n_frames, frame_bytes, dev,
+                                           None if args.no_cpu_baseline else cpu_baseline_all_cores)
+            out["multi_sequence"] = multi_sequence_leg(pkg, svo, cam, dL, dR, frame_bytes, rec, dev, res)
+        if legs and not args.no_elas_leg:
+            out["elas"] = elas_leg(pkg, W, H, dev.index or 0, dL, dR, PITCH, 128)
             out["msa"] = msa_leg(pkg, W, H, dev.index or 0, dL, dR)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     svo.close()
+
+
+def frontend_leg(pkg, svo, cam, dL, dR, n_frames, frame_bytes, dev, all_cores):
+    """BASELINE configs[1], batched: ORB on both images + sparse stereo, 128 pairs per step, every step on pairs the
+    GPU has not touched for thousands of frames (the sequence is far larger than the Infinity Cache)."""
+    B, steps = 128, 24
+    fe = pkg.Svo(W, H, device=dev.index or 0, max_kp=500, max_batch=B)
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_depth = torch.zeros((B, 500), dtype=torch.float32, device=dev)
+
+    def run(s):
+        off = (s * B) % (n_frames - B + 1)
+        fe.frontend_batch_dev(dL.data_ptr() + off * frame_bytes, dR.data_ptr() + off * frame_bytes, PITCH, B, cam,
+                              d_nL=d_n.data_ptr(), d_depth=d_depth.data_ptr())
+    for s in range(3):
+        run(s)
+    fe.sync()
+    fe.profile_reset(); fe.profile_enable(True)
+    t0 = time.perf_counter()
+    for s in range(3, 3 + steps):
+        run(s)
+    fe.sync()
+    dt = time.perf_counter() - t0
+    fe.profile_enable(False)
+    prof = fe.profile()
+    fe.close()
+    kern = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}
+    dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
+    algo = KERNEL_BYTES_PER_IMAGE.get(dom, 0) * 2 * B if dom in KERNEL_BYTES_PER_IMAGE else KERNEL_BYTES_PER_PAIR.get(dom, 0) * B
+    ach = algo / (prof[dom][0] / max(prof[dom][1], 1) * 1e-3) / 1e9
+    out = {"value": B * steps / dt, "unit": "stereo pairs/s", "pairs_per_step": B, "steps": steps,
+           "distinct_input_bytes_read": int(2 * B * steps * frame_bytes), "kernel_avg_ms": kern,
+           "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom), "valu": pmc_valu(dom),
+                        "algorithmic_bytes_per_launch": algo,
+                        "pipeline_frac": ALGO_BYTES_PER_PAIR * (B * steps / dt) / 1e9 / HBM_PEAK_GBS}}
+    if all_cores is not None:
+        Lh = dL[:64, :, :W].cpu().numpy(); Rh = dR[:64, :, :W].cpu().numpy()
+        out["cpu_baseline_all_cores"] = all_cores(Lh, Rh, cam)
+    return out
+
+
+def multi_sequence_leg(pkg, svo, cam, dL, dR, frame_bytes, rec, dev, single):
+    """S staggered sequences advanced together (one workgroup per sequence in every tail kernel); sequence 0 must
+    reproduce the single chain's records."""
+    S, msteps = 64, 48
+    ms = pkg.Svo(W, H, device=dev.index or 0, max_kp=500, max_batch=S)
+    mres = torch.zeros((msteps * S, rec), dtype=torch.uint8, device=dev)
+    ms.track_multi_reset(S, cam)
+    for t in range(2):
+        ms.track_multi_step_dev(dL.data_ptr() + t * frame_bytes, dR.data_ptr() + t * frame_bytes, PITCH, S,
+                                mres.data_ptr() + t * S * rec)
+    ms.track_multi_reset(S, cam)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for t in range(msteps):
+        ms.track_multi_step_dev(dL.data_ptr() + t * frame_bytes, dR.data_ptr() + t * frame_bytes, PITCH, S,
+                                mres.data_ptr() + t * S * rec)
+    ms.sync()
+    mdt = time.perf_counter() - t1
+    m = mres.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(msteps, S)
+    ms.close()
+    same = all(m[t, 0].tobytes() == single[t].tobytes() for t in range(msteps))
+    return {"value": msteps * S / mdt, "unit": "stereo frames/s", "sequences": S, "steps": msteps,
+            "sequence0_equals_single_chain": bool(same),
+            "note": "SURVEY 8e's 'G independent sequences' variant on ONE GPU: full Tracking::Track per frame"}
 
 
 if __name__ == "__main__":

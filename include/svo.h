@@ -284,6 +284,16 @@ int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_g
  * No detection boxes in this mode.  Does not synchronise. */
 int svo_track_tail_dev(svo_ctx* ctx, const svo_kp* d_kp, const uint8_t* d_desc, const int32_t* d_n,
                        const float* d_depth, int kp_stride, int B, svo_track_result* d_results);
+/* ONE sequence tracked with G contexts in one process, typically one per GPU (BASELINE configs[3]
+ * "pair k -> GPU k mod 8 ... ordered tail"): the stateless front end of stereo pair k runs on ctxs[k mod G], the strict
+ * temporal chain of src/Tracking.cc:231-250 runs in frame order on ctxs[0], which pulls each frame's keypoints /
+ * descriptors / depths (~34 KB) with device-to-device copies on its own stream - no collective, no host round trip.
+ * d_grayL[g] / d_grayR[g]: the pairs of context g, resident on ITS device, k ascending (pair k at local index k / G),
+ * `stride` bytes per row.  All contexts: same W, H, max_kp; ctxs[g] needs max_batch >= ceil(B / G).  svo_track_reset on
+ * ctxs[0] first; B frames per call; d_results: B records on ctxs[0]'s device.  Records are identical to
+ * svo_track_batch_dev on a single context.  Does not synchronise (svo_sync(ctxs[0]) does). */
+int svo_track_sharded_dev(svo_ctx* const* ctxs, int G, const uint8_t* const* d_grayL, const uint8_t* const* d_grayR,
+                          int stride, int B, svo_track_result* d_results);
 /* Sticky capacity flag of the device tracker (synchronises): *flag != 0 once a frame needed more than the 4096 live
  * map points the pool holds, or a map point stayed alive for more than 2^20 creations (its slot in the position table
  * was about to be reused).  Neither can happen with the reference's 500 keypoints per frame on sequences of KITTI

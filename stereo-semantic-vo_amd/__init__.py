@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "svo_frontend_batch_dev", "svo_track_batch_dev", "svo_profile_enable", "svo_profile_reset",
     "svo_profile_get",
     "svo_elas_default_params", "svo_elas_process", "svo_elas_process_ex", "svo_elas_delaunay",
-    "svo_ctmf", "svo_track_multi_reset", "svo_track_multi_step_dev", "svo_track_tail_dev", "svo_track_overflowed", "svo_elas_batch_dev", "svo_msa_init", "svo_msa_tree", "svo_msa_tree_dp", "svo_msa_wta", "svo_msa_lrcheck", "svo_msa_solve", "svo_msa_batch_dev",
+    "svo_ctmf", "svo_track_multi_reset", "svo_track_multi_step_dev", "svo_track_tail_dev", "svo_track_overflowed", "svo_track_sharded_dev", "svo_elas_batch_dev", "svo_msa_init", "svo_msa_tree", "svo_msa_tree_dp", "svo_msa_wta", "svo_msa_lrcheck", "svo_msa_solve", "svo_msa_batch_dev",
 ]
 
 
@@ -319,6 +319,15 @@ class Svo:
         """svo_track_tail_dev: the ordered tail over front-end results already in HBM (device pointers)."""
         self._chk(self.lib.svo_track_tail_dev(self.h, _p(d_kp), _p(d_desc), _p(d_n), _p(d_depth), int(kp_stride),
                                               int(B), _p(d_results)))
+
+    @staticmethod
+    def track_sharded_dev(ctxs, d_grayL, d_grayR, stride, B, d_results):
+        """svo_track_sharded_dev: ONE sequence, pair k on ctxs[k % G], ordered tail on ctxs[0]."""
+        G = len(ctxs)
+        hs = (C.c_void_p * G)(*[c.h for c in ctxs])
+        pl = (C.c_void_p * G)(*[C.c_void_p(int(p)) for p in d_grayL])
+        pr = (C.c_void_p * G)(*[C.c_void_p(int(p)) for p in d_grayR])
+        ctxs[0]._chk(ctxs[0].lib.svo_track_sharded_dev(hs, G, pl, pr, int(stride), int(B), _p(d_results)))
 
     def track_overflowed(self):
         f = C.c_int32(0)

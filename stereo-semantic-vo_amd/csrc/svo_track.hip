@@ -777,7 +777,9 @@ __global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, const TrackWor
 // --------------------------------------------------------------------------------------------
 // Host side
 // --------------------------------------------------------------------------------------------
+static void shard_gather_free(svo_ctx* ctx);
 void svo_track_release(svo_ctx* ctx) {
+  shard_gather_free(ctx);
   if (ctx->d_track) { hipFree(ctx->d_track); ctx->d_track = nullptr; }
   if (ctx->d_work) { hipFree(ctx->d_work); ctx->d_work = nullptr; }
   ctx->n_seq = 0; ctx->work_cap = 0;
@@ -1135,4 +1137,108 @@ extern "C" int svo_debug_track_stamps(svo_ctx* ctx, int slot, int64_t ts[8]) {
   TrackWork* w = reinterpret_cast<TrackWork*>(ctx->d_work) + slot;
   SVO_HIP(ctx, hipMemcpy(ts, w->ts, sizeof(long long) * 8, hipMemcpyDeviceToHost));
   return SVO_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// ONE sequence over G GPUs in one process (BASELINE configs[3]): stereo pair k goes to context
+// k mod G - the stateless front end (ORB on both images + sparse stereo) shards by pair with nothing to exchange - and
+// the strict temporal chain (src/Tracking.cc:231-250) runs in frame order on context 0, which pulls every frame's
+// ~34 KB of keypoints / descriptors / depths from where they were produced (device-to-device copies on its own
+// stream, no collective, no host round trip).  d_grayL[g] / d_grayR[g]: the pairs of context g, on ITS device, in
+// order of increasing k (local index k / G).  B frames per call, records into d_results (on context 0's device).
+// Records are identical to svo_track_batch_dev on one context.  Does not synchronise.
+struct ShardGather {
+  svo_kp* kp = nullptr; uint8_t* desc = nullptr; int32_t* n = nullptr; float* depth = nullptr;
+  int cap = 0;
+  std::vector<hipEvent_t> ev;
+};
+static std::vector<std::pair<svo_ctx*, ShardGather*>> g_gathers;   // per tail context, freed by svo_track_release
+
+static ShardGather* shard_gather(svo_ctx* ctx) {
+  for (auto& p : g_gathers)
+    if (p.first == ctx) return p.second;
+  g_gathers.emplace_back(ctx, new ShardGather());
+  return g_gathers.back().second;
+}
+static void shard_gather_free(svo_ctx* ctx) {
+  for (size_t i = 0; i < g_gathers.size(); ++i)
+    if (g_gathers[i].first == ctx) {
+      ShardGather* g = g_gathers[i].second;
+      if (g->kp) hipFree(g->kp);
+      if (g->desc) hipFree(g->desc);
+      if (g->n) hipFree(g->n);
+      if (g->depth) hipFree(g->depth);
+      for (hipEvent_t e : g->ev) hipEventDestroy(e);
+      delete g;
+      g_gathers.erase(g_gathers.begin() + i);
+      return;
+    }
+}
+
+extern "C" int svo_track_sharded_dev(svo_ctx* const* ctxs, int G, const uint8_t* const* d_grayL, const uint8_t* const* d_grayR,
+                                     int stride, int B, svo_track_result* d_results) {
+  if (!ctxs || G < 1 || !d_grayL || !d_grayR || B < 1 || !d_results) return SVO_E_INVALID;
+  svo_ctx* c0 = ctxs[0];
+  if (!c0 || !c0->d_track || c0->n_seq != 1) return SVO_E_INVALID;   // svo_track_reset(ctxs[0]) first
+  const int K = c0->max_kp;
+  for (int g = 0; g < G; ++g) {
+    if (!ctxs[g] || !d_grayL[g] || !d_grayR[g] || ctxs[g]->max_kp != K || ctxs[g]->g.W != c0->g.W || ctxs[g]->g.H != c0->g.H)
+      return SVO_E_INVALID;
+    if ((B - g + G - 1) / G > ctxs[g]->max_batch) return SVO_E_CAPACITY;
+  }
+  ShardGather* sg = shard_gather(c0);
+  SVO_HIP(c0, hipSetDevice(c0->device));
+  if (sg->cap < B) {
+    SVO_HIP(c0, hipStreamSynchronize(c0->stream));
+    if (sg->kp) { hipFree(sg->kp); hipFree(sg->desc); hipFree(sg->n); hipFree(sg->depth); sg->kp = nullptr; }
+    sg->cap = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&sg->kp), sizeof(svo_kp) * (size_t)K * B) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&sg->desc), 32 * (size_t)K * B) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&sg->n), 4 * (size_t)B) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&sg->depth), 4 * (size_t)K * B) != hipSuccess)
+      return SVO_E_NOMEM;
+    sg->cap = B;
+  }
+  while ((int)sg->ev.size() < G) {
+    hipEvent_t e;
+    SVO_HIP(c0, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    sg->ev.push_back(e);
+    // direct device-to-device reads from the producing GPU (xGMI) where the platform allows it; otherwise the
+    // runtime stages the copies
+    const int g = (int)sg->ev.size() - 1;
+    if (g < G && ctxs[g] && ctxs[g]->device != c0->device) { (void)hipDeviceEnablePeerAccess(ctxs[g]->device, 0); (void)hipGetLastError(); }
+  }
+  // front ends: context g extracts and matches its pairs k = g, g + G, ... on its own device and stream.  A context's
+  // result buffers may still be read by the previous call's gather copies: its stream waits for context 0's stream first.
+  hipEvent_t ev_prev = nullptr;
+  if (G > 1) {
+    SVO_HIP(c0, hipEventCreateWithFlags(&ev_prev, hipEventDisableTiming));
+    SVO_HIP(c0, hipEventRecord(ev_prev, c0->stream));
+  }
+  int rc = SVO_OK;
+  for (int g = 0; g < G && rc == SVO_OK; ++g) {
+    const int nb = (B - g + G - 1) / G;
+    if (nb <= 0) continue;
+    svo_ctx* c = ctxs[g];
+    hipSetDevice(c->device);
+    if (g > 0 && hipStreamWaitEvent(c->stream, ev_prev, 0) != hipSuccess) { rc = SVO_E_HIP; break; }
+    rc = svo_frontend_batch_dev(c, d_grayL[g], d_grayR[g], stride, nb, &c0->cam, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (rc == SVO_OK && hipEventRecord(sg->ev[g], c->stream) != hipSuccess) rc = SVO_E_HIP;
+  }
+  hipSetDevice(c0->device);
+  if (ev_prev) hipEventDestroy(ev_prev);   // destruction is deferred until the recorded work has completed
+  if (rc) return rc;
+  // ordered gather on context 0's stream: frame k = g + G i  <-  slot i of context g (row-interleaving 2-D copies)
+  for (int g = 0; g < G; ++g) {
+    const int nb = (B - g + G - 1) / G;
+    if (nb <= 0) continue;
+    svo_ctx* c = ctxs[g];
+    SVO_HIP(c0, hipStreamWaitEvent(c0->stream, sg->ev[g], 0));
+    const size_t wk = sizeof(svo_kp) * (size_t)K, wd = 32 * (size_t)K, wf = 4 * (size_t)K;
+    SVO_HIP(c0, hipMemcpy2DAsync(sg->kp + (size_t)g * K, wk * G, c->d_kp, wk, wk, nb, hipMemcpyDeviceToDevice, c0->stream));
+    SVO_HIP(c0, hipMemcpy2DAsync(sg->desc + (size_t)g * wd, wd * G, c->d_desc, wd, wd, nb, hipMemcpyDeviceToDevice, c0->stream));
+    SVO_HIP(c0, hipMemcpy2DAsync(sg->depth + (size_t)g * K, wf * G, c->d_depth, wf, wf, nb, hipMemcpyDeviceToDevice, c0->stream));
+    SVO_HIP(c0, hipMemcpy2DAsync(sg->n + g, 4 * (size_t)G, c->d_nkp, 4, 4, nb, hipMemcpyDeviceToDevice, c0->stream));
+  }
+  return svo_track_tail_dev(c0, sg->kp, sg->desc, sg->n, sg->depth, K, B, d_results);
 }

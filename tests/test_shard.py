@@ -1,0 +1,114 @@
+"""SURVEY.md section 8e / BASELINE configs[3]: ONE sequence whose stateless front end is sharded by stereo pair while
+the strict temporal chain runs in order on one context.
+  * svo_track_tail_dev: the ordered tail over front-end results produced by ANOTHER context;
+  * svo_track_sharded_dev: pair k -> context k mod G, ordered gather + tail on context 0 (here: G contexts on the one
+    GPU of the box - the multi-GPU code path with every device index equal);
+  * bench.py's N = 2 path as the driver launches it (torch.distributed.run, two ranks), over gloo with both ranks on
+    cuda:0.
+Everything must reproduce svo_track_batch_dev on a single context record for record."""
+import importlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N = 16
+PITCH = 1280
+
+
+@pytest.fixture(scope="module")
+def frames(pkg):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    synth = importlib.import_module("stereo_semantic_vo_amd.synth")
+    dev = torch.device("cuda", 0)
+    L, R, _ = synth.render_sequence(N, device=dev)
+    H, W = L.shape[1], L.shape[2]
+    dL = torch.zeros((N, H, PITCH), dtype=torch.uint8, device=dev); dR = torch.zeros_like(dL)
+    dL[:, :, :W] = L; dR[:, :, :W] = R
+    cam = pkg.Camera(**pkg.KITTI_00_02)
+    s = pkg.Svo(W, H, max_batch=N)
+    s.track_reset(cam)
+    res = torch.zeros((N, pkg.TRACK_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    s.track_batch_dev(dL.data_ptr(), dR.data_ptr(), PITCH, N, res.data_ptr())
+    s.sync(); s.close()
+    return dL, dR, W, H, cam, res.cpu().numpy().tobytes()
+
+
+@pytest.mark.gpu
+def test_track_tail_dev_on_another_contexts_front_end(pkg, frames):
+    import torch
+    dL, dR, W, H, cam, want = frames
+    dev = dL.device
+    K = 500
+    fe = pkg.Svo(W, H, max_batch=N)
+    kp = torch.zeros((N, K, pkg.KP_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    desc = torch.zeros((N, K, 32), dtype=torch.uint8, device=dev)
+    n = torch.zeros(N, dtype=torch.int32, device=dev)
+    depth = torch.zeros((N, K), dtype=torch.float32, device=dev)
+    fe.frontend_batch_dev(dL.data_ptr(), dR.data_ptr(), PITCH, N, cam, d_kpL=kp.data_ptr(), d_descL=desc.data_ptr(),
+                          d_nL=n.data_ptr(), d_depth=depth.data_ptr())
+    fe.sync()
+    tail = pkg.Svo(W, H, max_batch=1)          # never sees an image
+    tail.track_reset(cam)
+    res = torch.zeros((N, pkg.TRACK_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    half = N // 2                               # two calls: the chain continues across calls
+    rec = pkg.TRACK_DTYPE.itemsize
+    tail.track_tail_dev(kp.data_ptr(), desc.data_ptr(), n.data_ptr(), depth.data_ptr(), K, half, res.data_ptr())
+    tail.track_tail_dev(kp[half:].data_ptr(), desc[half:].data_ptr(), n[half:].data_ptr(), depth[half:].data_ptr(), K,
+                        N - half, res.data_ptr() + half * rec)
+    tail.sync()
+    assert tail.track_overflowed() == 0
+    got = res.cpu().numpy().tobytes()
+    fe.close(); tail.close()
+    assert got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G", [2, 3])
+def test_track_sharded_contexts_equal_single_context(pkg, frames, G):
+    import torch
+    dL, dR, W, H, cam, want = frames
+    dev = dL.device
+    rec = pkg.TRACK_DTYPE.itemsize
+    ctxs = [pkg.Svo(W, H, max_batch=(N + G - 1) // G) for _ in range(G)]
+    ctxs[0].track_reset(cam)
+    res = torch.zeros((N, rec), dtype=torch.uint8, device=dev)
+    B = N // 2                                  # two calls of B frames each
+    for call in range(2):
+        ks = range(call * B, (call + 1) * B)
+        # context g gets the pairs with (k - first) % G == g, packed in order
+        Ls = [torch.stack([dL[k] for k in ks if (k - ks[0]) % G == g]).contiguous() for g in range(G)]
+        Rs = [torch.stack([dR[k] for k in ks if (k - ks[0]) % G == g]).contiguous() for g in range(G)]
+        torch.cuda.synchronize()
+        pkg.Svo.track_sharded_dev(ctxs, [t.data_ptr() for t in Ls], [t.data_ptr() for t in Rs], PITCH, B,
+                                  res.data_ptr() + call * B * rec)
+        ctxs[0].sync()
+    got = res.cpu().numpy().tobytes()
+    for c in ctxs:
+        c.close()
+    assert got == want
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_as_the_driver_launches_it():
+    """python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...: both ranks on cuda:0 over gloo (the box
+    has one GPU).  The line must be rank 0's, claim 2 GPUs, and carry the whole job's frames."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--frames", "48", "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["frames_tracked"] == 48 and d["value"] > 0
+    # whole-job throughput: both ranks' frames over the slowest rank's time
+    assert abs(d["value"] - 2 * d["config"]["pairs_per_step_per_gpu"] * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]

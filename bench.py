@@ -57,9 +57,11 @@ def tail_kernel_bytes(kernel, mean_pool_rows, mean_kp, mean_edges, mean_lm_iters
         return (mean_pool_rows + mean_kp) * 32.0
     if kernel == "k_ti_resolve":    # packed entries of the M rows in, the compacted pool (descriptor + 10 bytes) out and in
         return mean_pool_rows * (64.0 + 2 * 42.0) + mean_kp * 60.0
-    if kernel == "k_tp_frame":      # n correspondences of 40 bytes: once per PnP hypothesis batch + once per LM iteration
-        return mean_edges * 40.0 * (2.0 + mean_lm_iters)
-    return None
+    if kernel == "k_tp_hyp":        # the n correspondences (40 bytes each) in, 100 sample records (112 bytes) out
+        return mean_edges * 40.0 + 100 * 112.0
+    if kernel == "k_tp_frame":      # n correspondences of 40 bytes: once for the gather + once per LM iteration and trial
+        return mean_edges * 40.0 * (1.0 + 2.0 * mean_lm_iters)
+    return 0.0
 
 
 def pmc_traffic(kernel):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SVO_ABI_VERSION 1
+#define SVO_ABI_VERSION 2
 
 typedef enum svo_status {
   SVO_OK = 0,
@@ -73,13 +73,13 @@ typedef struct svo_lm_stats {
   double lambda_final;
 } svo_lm_stats;
 
-/* Result of the PnP-RANSAC initial pose (replaces cv::solvePnPRansac call,
- * src/pnpmatch.cc:227). */
+/* Result of cv::solvePnPRansac (src/pnpmatch.cc:227). */
 typedef struct svo_pnp_stats {
   int32_t n_points;
-  int32_t n_inliers;
+  int32_t n_inliers;       /* consensus of the winning sample (rows of `inliers`, src/pnpmatch.cc:229) */
   int32_t best_hypothesis; /* index 0..99 of the winning minimal sample, -1 if none */
-  int32_t ok;              /* 0 => fewer than 5 points / no consensus: pose = prior  */
+  int32_t ok;              /* 0 => OpenCV would return false (fewer than 5 points / no consensus of 5): pose = fallback */
+  int32_t iterations;      /* samples the adaptive RANSAC loop visited (<= 100) */
 } svo_pnp_stats;
 
 /* Per-frame record produced by the tracker (what Tracking::Track leaves behind:
@@ -228,12 +228,23 @@ int svo_bf_match(svo_ctx* ctx, const uint8_t* q, int M, const uint8_t* t, int N,
 int svo_fundamental_8point(const double* pts1, const double* pts2, int n, double F[9]);
 
 /* ---- a-10: PnP-RANSAC initial pose (src/pnpmatch.cc:212-247) ---------------- */
-/* Xw n x 3, obs n x 2 (doubles); K = {fx,fy,cx,cy}; T_prior_cw / T_cw row-major 4x4.
- * 100 five-point hypotheses (seeded sampler), 8 px threshold, refit on inliers.
- * inlier_mask: n bytes (may be NULL). */
+/* cv::solvePnPRansac(pts3d, pts2d, K, Mat(), rvec, tvec, false, 100, 8.0, 0.99, inliers) as OpenCV 3.2 runs it (the
+ * version the reference links): NO extrinsic guess - every RANSAC sample is five correspondences
+ * drawn by cv::RNG((uint64)-1) and solved by EPnP alone; squared reprojection error <= 8^2 (evaluated in float) counts
+ * an inlier; a sample replaces the best one iff its consensus is larger, and the iteration bound then drops to
+ * log(1 - 0.99) / log(1 - w^5) for inlier ratio w; the pose returned is the winning sample's (3.2 discards the refit it
+ * computes on the inliers).  Xw n x 3, obs n x 2 (doubles holding the reference's float values), n <= 512;
+ * K = {fx,fy,cx,cy}; T_cw row-major 4x4.  T_fallback_cw is what T_cw receives when OpenCV would return false (the
+ * reference would carry on with unset rvec / tvec there).  rng_state: 0 = OpenCV's (uint64)-1.  inlier_mask: n bytes
+ * (may be NULL).  All 100 samples are solved at once, one wavefront each (csrc/svo_epnp_dev.h). */
 int svo_pnp_ransac(svo_ctx* ctx, const double* Xw, const double* obs, int n, const double K[4],
-                   const double T_prior_cw[16], uint64_t seed, double T_cw[16],
+                   const double T_fallback_cw[16], uint64_t rng_state, double T_cw[16],
                    uint8_t* inlier_mask, svo_pnp_stats* stats);
+
+/* Parity probe: the EPnP solve of ONE five-point sample (what every RANSAC sample of svo_pnp_ransac runs): R row-major,
+ * t, and (optionally) the mean reprojection errors of the three beta candidates N = 1, 2, 3 (epnp.cpp compute_pose). */
+int svo_debug_epnp5(svo_ctx* ctx, const double Xw5[15], const double uv5[10], const double K[4], double R[9],
+                    double t[3], double rep_err[3]);
 
 /* ---- a-5: Optimizer::PoseOptimization (src/Optimizer.cc:15-86) -------------- */
 /* Pose-only Levenberg-Marquardt exactly as g2o runs it for this graph: one SE3
@@ -260,6 +271,10 @@ int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL, const uint8
 int svo_debug_track_matches(svo_ctx* ctx, int32_t* cur_mp);
 /* Parity probe: the F matrix and the number of epipolar vetoes of the frame just tracked. */
 int svo_debug_track_gate(svo_ctx* ctx, double F[9], int32_t* n_vetoed);
+
+/* Parity probe: cv::solvePnPRansac's outcome for the frame just tracked, and the pose (row-major 4x4, before the CV_32F
+ * rounding of SetPose) it handed to PoseOptimization.  Either pointer may be NULL. */
+int svo_debug_track_pnp(svo_ctx* ctx, svo_pnp_stats* stats, double T_pnp[16]);
 
 /* ---- throughput mode: batched, device-resident ------------------------------ */
 /* B stereo pairs already in HBM: d_grayL/d_grayR are B images of H rows x `stride`

@@ -22,9 +22,9 @@ class LmStats(C.Structure):
                 ("lambda_final", C.c_double)]
 
 
-class PnpStats(C.Structure):
+class PnpStats(C.Structure):  # orc_pnp_stats
     _fields_ = [("n_points", C.c_int32), ("n_inliers", C.c_int32), ("best_hypothesis", C.c_int32),
-                ("ok", C.c_int32)]
+                ("ok", C.c_int32), ("iterations", C.c_int32)]
 
 
 def build(force=False):
@@ -180,13 +180,21 @@ def pose_opt(Xw, obs, K, T, trace_cap=128):
     return T.reshape(4, 4), st, trace[:nt].copy()
 
 
-def pnp_ransac(Xw, obs, K, T_prior, seed):
+def pnp_ransac(Xw, obs, K, T_fallback, rng_state=0, refine=0):
+    """cv::solvePnPRansac(..., false, 100, 8.0, 0.99) restated; rng_state 0 = OpenCV's (uint64)-1."""
     Xw = np.ascontiguousarray(Xw, np.float64); obs = np.ascontiguousarray(obs, np.float64)
-    K = np.ascontiguousarray(K, np.float64); Tp = np.ascontiguousarray(T_prior, np.float64).reshape(16)
-    T = np.zeros(16); mask = np.zeros(len(Xw), np.uint8); st = PnpStats()
-    lib().orc_pnp_ransac(_p(Xw), _p(obs), len(Xw), _p(K), _p(Tp), C.c_uint64(seed), _p(T), _p(mask),
-                         C.byref(st))
-    return T.reshape(4, 4), mask, st
+    K = np.ascontiguousarray(K, np.float64); Tp = np.ascontiguousarray(T_fallback, np.float64).reshape(16)
+    T = np.zeros(16); mask = np.zeros(max(len(Xw), 1), np.uint8); st = PnpStats()
+    lib().orc_solvepnp_ransac(_p(Xw), _p(obs), len(Xw), _p(K), _p(Tp), C.c_uint64(rng_state), int(refine), _p(T), _p(mask),
+                              C.byref(st))
+    return T.reshape(4, 4), mask[:len(Xw)], st
+
+
+def epnp5(Xw5, uv5, K):
+    Xw5 = np.ascontiguousarray(Xw5, np.float64).reshape(15); uv5 = np.ascontiguousarray(uv5, np.float64).reshape(10)
+    K = np.ascontiguousarray(K, np.float64); R = np.zeros(9); t = np.zeros(3)
+    lib().orc_epnp5(_p(Xw5), _p(uv5), _p(K), _p(R), _p(t))
+    return R.reshape(3, 3), t
 
 
 def disp2depth(disp, bf):

@@ -22,12 +22,7 @@
  * Eigen's published formulas; LDLT is restated without pivoting, so solutions
  * agree to round-off, not bitwise (PARITY UNPINNED at that boundary).
  *
- * orc_pnp_ransac stands in for cv::solvePnPRansac (src/pnpmatch.cc:227;
- * 100 iterations, 8 px, confidence 0.99, EPnP on 5-point minimal sets
- * [upstream-memory]).  OpenCV is absent, so the algorithm is this framework's
- * own: 100 seeded 5-point hypotheses, each solved by up to 6 Gauss-Newton steps from
- * the prior pose (stopping once max|dx| < 1e-10), scored at 8 px, best refit on its inliers
- * (up to 10 steps, same stop rule).  PARITY UNPINNED.
+ * cv::solvePnPRansac (src/pnpmatch.cc:227) is restated in orc_pnp_cv.c.
  */
 #include <float.h>
 #include <math.h>
@@ -341,98 +336,4 @@ int orc_pose_opt(const double* Xw, const double* obs, int n, const double K[4], 
   return ntrace;
 }
 
-/* ---- PnP RANSAC --------------------------------------------------------------- */
-
-static inline uint32_t lcg_next(uint64_t* s) {
-  *s = *s * 6364136223846793005ULL + 1442695040888963407ULL;
-  return (uint32_t)(*s >> 33);
-}
-
-/* `iters` plain Gauss-Newton steps on the listed points. */
-static void gn_refine(se3_t* est, const double* Xw, const double* obs, const int* idx, int m,
-                      const double K[4], int iters) {
-  for (int it = 0; it < iters; ++it) {
-    double H[36], b[6], x[6];
-    memset(H, 0, sizeof H);
-    memset(b, 0, sizeof b);
-    for (int k = 0; k < m; ++k) {
-      const int i = idx[k];
-      double e[2], pc[3], J[12];
-      edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc);
-      edge_jacobian(pc, K, J);
-      for (int r = 0; r < 6; ++r) {
-        b[r] -= J[r] * e[0] + J[6 + r] * e[1];
-        for (int c = 0; c < 6; ++c) H[6 * r + c] += J[r] * J[c] + J[6 + r] * J[6 + c];
-      }
-    }
-    if (!ldlt6_solve(H, b, x)) return;
-    int fin = 1;
-    double xmax = 0;
-    for (int j = 0; j < 6; ++j) { fin &= isfinite(x[j]) ? 1 : 0; xmax = fmax(xmax, fabs(x[j])); }
-    if (!fin) return;
-    se3_oplus(x, est);
-    if (xmax < 1e-10) return; /* converged: further steps would not move the pose */
-  }
-}
-static int count_inliers(const se3_t* est, const double* Xw, const double* obs, int n,
-                         const double K[4], uint8_t* mask) {
-  int c = 0;
-  for (int i = 0; i < n; ++i) {
-    double e[2], pc[3];
-    edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc);
-    const int in = (pc[2] > 0.0) && (e[0] * e[0] + e[1] * e[1] <= 64.0);
-    if (mask) mask[i] = (uint8_t)in;
-    c += in;
-  }
-  return c;
-}
-
-int orc_pnp_ransac(const double* Xw, const double* obs, int n, const double K[4],
-                   const double T_prior[16], uint64_t seed, double T[16], uint8_t* inlier_mask,
-                   orc_pnp_stats* stats) {
-  se3_t prior;
-  se3_from_T(T_prior, &prior);
-  int best_cnt = -1, best_k = -1;
-  se3_t best_est = prior;
-  if (n >= 5) {
-    for (int k = 0; k < 100; ++k) {
-      uint64_t s = seed ^ ((uint64_t)(k + 1) * 0x9E3779B97F4A7C15ULL);
-      lcg_next(&s);
-      int idx[5], got = 0, draws = 0;
-      while (got < 5 && draws < 64) {
-        int c = (int)(lcg_next(&s) % (uint32_t)n);
-        ++draws;
-        int dup = 0;
-        for (int j = 0; j < got; ++j) dup |= idx[j] == c;
-        if (!dup) idx[got++] = c;
-      }
-      if (got < 5) continue;
-      se3_t est = prior;
-      gn_refine(&est, Xw, obs, idx, 5, K, 6);
-      const int cnt = count_inliers(&est, Xw, obs, n, K, NULL);
-      if (cnt > best_cnt) { best_cnt = cnt; best_k = k; best_est = est; }
-    }
-  }
-  int ok = best_cnt >= 5;
-  se3_t fin = prior;
-  int nin = 0;
-  if (ok) {
-    uint8_t* mask = (uint8_t*)malloc((size_t)n);
-    int* idx = (int*)malloc(sizeof(int) * (size_t)n);
-    count_inliers(&best_est, Xw, obs, n, K, mask);
-    int m = 0;
-    for (int i = 0; i < n; ++i) if (mask[i]) idx[m++] = i;
-    fin = best_est;
-    gn_refine(&fin, Xw, obs, idx, m, K, 10);
-    nin = count_inliers(&fin, Xw, obs, n, K, inlier_mask);
-    free(mask); free(idx);
-  } else if (inlier_mask) {
-    memset(inlier_mask, 0, (size_t)(n > 0 ? n : 0));
-  }
-  se3_to_T(&fin, T);
-  if (stats) {
-    stats->n_points = n; stats->n_inliers = nin; stats->best_hypothesis = ok ? best_k : -1;
-    stats->ok = ok;
-  }
-  return ok;
-}
+/* cv::solvePnPRansac is restated in orc_pnp_cv.c. */

@@ -12,8 +12,8 @@
  *   local-map culling               src/Tracking.cc:239-250
  * with the north-star substitutions already made by the other oracle files: ORB
  * from orc_orb.c, per-keypoint sparse-stereo depth (orc_stereo.c) instead of the
- * dense depthimg lookup, orc_pnp_ransac instead of cv::solvePnPRansac (prior = last
- * frame's pose, seed 0x5EED0000 + frame id).  Deterministic orders replace the
+ * dense depthimg lookup, cv::solvePnPRansac as restated in orc_pnp_cv.c (no prior pose; if it
+ * fails the pose stays at the last frame's).  Deterministic orders replace the
  * reference's run-dependent ones: LocalMapPoints (a std::set<mappoint*> ordered by
  * heap address, include/Tracking.h:41) is iterated in creation order.
  * Offline detection boxes (semantic gating, SURVEY f-3; main.cpp:82-95 format) are honoured
@@ -223,7 +223,7 @@ int orc_track_frame_dense(orc_tracker* t, const uint8_t* grayL, int strideL, con
     double Tp[16], Td[16];
     for (int i = 0; i < 16; ++i) Tp[i] = t->lastTcw[i];
     orc_pnp_stats ps;
-    orc_pnp_ransac(Xw, ob, n, K, Tp, 0x5EED0000ULL + (uint64_t)id, Td, NULL, &ps);
+    orc_pnp_ransac(Xw, ob, n, K, Tp, 0, Td, NULL, &ps);   /* fails -> the pose stays at the last frame's */
     res->n_pnp_inliers = ps.n_inliers;
     for (int i = 0; i < 16; ++i) Tcw[i] = (float)Td[i];
     free(Xw); free(ob);

@@ -35,7 +35,7 @@ typedef struct orc_lm_stats {
 } orc_lm_stats;
 
 typedef struct orc_pnp_stats {
-  int32_t n_points, n_inliers, best_hypothesis, ok;
+  int32_t n_points, n_inliers, best_hypothesis, ok, iterations;
 } orc_pnp_stats;
 
 /* geometry */
@@ -94,9 +94,15 @@ void orc_se3_exp_matrix(const double upd[6], double T[16]);
 void orc_se3_update(const double upd[6], double T[16]);
 int orc_pose_opt(const double* Xw, const double* obs, int n, const double K[4], double T[16],
                  orc_lm_stats* stats, double* trace, int trace_cap);
+/* cv::solvePnPRansac(..., false, 100, 8.0, 0.99, inliers) restated (orc_pnp_cv.c).  T_fallback: the pose reported when
+ * OpenCV returns false; rng_state 0 = (uint64)-1, what RANSACPointSetRegistrator::run seeds its cv::RNG with. */
 int orc_pnp_ransac(const double* Xw, const double* obs, int n, const double K[4],
-                   const double T_prior[16], uint64_t seed, double T[16], uint8_t* inlier_mask,
+                   const double T_fallback[16], uint64_t rng_state, double T[16], uint8_t* inlier_mask,
                    orc_pnp_stats* stats);
+int orc_solvepnp_ransac(const double* Xw, const double* obs, int n, const double K[4], const double T_fallback[16],
+                        uint64_t rng_state, int refine, double T[16], uint8_t* inlier_mask, orc_pnp_stats* stats);
+/* epnp::compute_pose on five correspondences: R (row-major 3x3), t */
+void orc_epnp5(const double Xw5[15], const double uv5[10], const double K[4], double R_out[9], double t_out[3]);
 
 /* fundamental matrix + semantic gating (orc_fmat.c) */
 int orc_fundamental_8point(const double* pts1, const double* pts2, int n, double F[9]);

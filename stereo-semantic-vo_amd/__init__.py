@@ -41,8 +41,8 @@ ABI_SYMBOLS = [
     "svo_debug_fast_corners", "svo_stereo_frame", "svo_stereo_frame_ex", "svo_disp2depth",
     "svo_unproject", "svo_descriptor_distance", "svo_hamming_argmin", "svo_match_greedy",
     "svo_match_greedy_gated",
-    "svo_bf_match", "svo_pnp_ransac", "svo_pose_opt", "svo_track_reset", "svo_track_frame",
-    "svo_debug_track_matches", "svo_debug_track_gate", "svo_fundamental_8point",
+    "svo_bf_match", "svo_pnp_ransac", "svo_debug_epnp5", "svo_pose_opt", "svo_track_reset", "svo_track_frame",
+    "svo_debug_track_matches", "svo_debug_track_gate", "svo_debug_track_pnp", "svo_fundamental_8point",
     "svo_frontend_batch_dev", "svo_track_batch_dev", "svo_profile_enable", "svo_profile_reset",
     "svo_profile_get",
     "svo_elas_default_params", "svo_elas_process", "svo_elas_process_ex", "svo_elas_delaunay",
@@ -67,7 +67,7 @@ class LmStats(C.Structure):
 
 class PnpStats(C.Structure):
     _fields_ = [("n_points", C.c_int32), ("n_inliers", C.c_int32), ("best_hypothesis", C.c_int32),
-                ("ok", C.c_int32)]
+                ("ok", C.c_int32), ("iterations", C.c_int32)]
 
 
 # KITTI intrinsics of the reference's settings files (Stereo/KITTI00-02.yaml:8-11,25 and
@@ -251,15 +251,22 @@ class Svo:
         self._chk(self.lib.svo_bf_match(self.h, _p(q), M, _p(t), N, _p(ti), _p(d), _p(keep)))
         return ti, d, keep
 
-    def pnp_ransac(self, Xw, obs, K, T_prior, seed):
+    def pnp_ransac(self, Xw, obs, K, T_fallback, rng_state=0):
+        """cv::solvePnPRansac(..., false, 100, 8.0, 0.99) (svo_pnp_ransac); rng_state 0 = OpenCV's (uint64)-1."""
         Xw = np.ascontiguousarray(Xw, np.float64).reshape(-1, 3)
         obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 2)
         K = np.ascontiguousarray(K, np.float64)
-        Tp = np.ascontiguousarray(T_prior, np.float64).reshape(16)
+        Tp = np.ascontiguousarray(T_fallback, np.float64).reshape(16)
         T = np.zeros(16); mask = np.zeros(max(len(Xw), 1), np.uint8); st = PnpStats()
         self._chk(self.lib.svo_pnp_ransac(self.h, _p(Xw), _p(obs), len(Xw), _p(K), _p(Tp),
-                                          C.c_uint64(seed), _p(T), _p(mask), C.byref(st)))
+                                          C.c_uint64(rng_state), _p(T), _p(mask), C.byref(st)))
         return T.reshape(4, 4), mask[:len(Xw)], st
+
+    def debug_epnp5(self, Xw5, uv5, K):
+        Xw5 = np.ascontiguousarray(Xw5, np.float64).reshape(15); uv5 = np.ascontiguousarray(uv5, np.float64).reshape(10)
+        K = np.ascontiguousarray(K, np.float64); R = np.zeros(9); t = np.zeros(3); rep = np.zeros(3)
+        self._chk(self.lib.svo_debug_epnp5(self.h, _p(Xw5), _p(uv5), _p(K), _p(R), _p(t), _p(rep)))
+        return R.reshape(3, 3), t, rep
 
     # ---- Optimizer::PoseOptimization ------------------------------------------------------
     def pose_opt(self, Xw, obs, K, T):

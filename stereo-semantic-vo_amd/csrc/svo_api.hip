@@ -224,6 +224,7 @@ extern "C" int svo_create(svo_ctx** out, int device, int W, int H, int max_kp, i
   TRY(dalloc(ctx, &ctx->d_depth, (size_t)max_batch * max_kp));
   TRY(dalloc(ctx, &ctx->d_sad, (size_t)max_batch * max_kp));
   TRY(dalloc(ctx, &ctx->d_scratch, ctx->scratch_bytes));
+  TRY(dalloc(ctx, &ctx->d_pnp_subsets, (size_t)513 * 500));
 #undef TRY
   if (rc == SVO_OK && hipHostMalloc((void**)&ctx->h_stage, 2 * (size_t)H * ctx->stage_pitch) != hipSuccess)
     rc = SVO_E_HIP;
@@ -236,6 +237,11 @@ extern "C" int svo_create(svo_ctx** out, int device, int W, int H, int max_kp, i
     hipMemcpy(ctx->d_yofs, yofs.data(), yofs.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(ctx->d_ybeta, ybeta.data(), ybeta.size() * 4, hipMemcpyHostToDevice);
     hipMemset(ctx->d_nkp, 0, I * 4);
+    {   // RANSAC sample indices of cv::solvePnPRansac for every possible point count (they depend on nothing else)
+      std::vector<uint16_t> sub((size_t)513 * 500, 0);
+      for (int n = 5; n <= 512; ++n) svo_pnp_subsets(0, n, &sub[(size_t)n * 500]);
+      hipMemcpy(ctx->d_pnp_subsets, sub.data(), sub.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    }
     hipMemset(ctx->d_selcnt, 0, I * SVO_NLEVELS * 4);
   }
   if (rc != SVO_OK) {
@@ -258,7 +264,7 @@ extern "C" void svo_destroy(svo_ctx* ctx) {
   void* ptrs[] = {ctx->d_xofs, ctx->d_xalpha, ctx->d_yofs, ctx->d_ybeta, ctx->d_stage, ctx->d_pyr,
                   ctx->d_corners, ctx->d_counters, ctx->d_hist, ctx->d_sel, ctx->d_selcnt,
                   ctx->d_kp, ctx->d_desc, ctx->d_nkp, ctx->d_uR, ctx->d_depth, ctx->d_sad,
-                  ctx->d_scratch, ctx->d_track};
+                  ctx->d_scratch, ctx->d_track, ctx->d_pnp_subsets};
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
@@ -668,9 +674,10 @@ extern "C" int svo_pose_opt(svo_ctx* ctx, const double* Xw, const double* obs, i
 }
 
 extern "C" int svo_pnp_ransac(svo_ctx* ctx, const double* Xw, const double* obs, int n,
-                              const double K[4], const double T_prior_cw[16], uint64_t seed,
+                              const double K[4], const double T_fallback_cw[16], uint64_t rng_state,
                               double T_cw[16], uint8_t* inlier_mask, svo_pnp_stats* stats) {
-  if (!ctx || n < 0 || (n > 0 && (!Xw || !obs)) || !K || !T_prior_cw || !T_cw) return SVO_E_INVALID;
+  if (!ctx || n < 0 || (n > 0 && (!Xw || !obs)) || !K || !T_fallback_cw || !T_cw) return SVO_E_INVALID;
+  if (n > 512) return SVO_E_CAPACITY;
   hipSetDevice(ctx->device);
   Bump bm{ctx};
   double* dX = bm.take<double>(3 * (size_t)std::max(n, 1));
@@ -680,17 +687,47 @@ extern "C" int svo_pnp_ransac(svo_ctx* ctx, const double* Xw, const double* obs,
   double* dT = bm.take<double>(16);
   uint8_t* dM = bm.take<uint8_t>(std::max(n, 1));
   svo_pnp_stats* dS = bm.take<svo_pnp_stats>(1);
+  uint16_t* dSub = bm.take<uint16_t>(512);
+  void* dHyp = bm.take<uint8_t>(svo_pnp_hyp_bytes());
   if (!bm.ok()) return SVO_E_CAPACITY;
   if (n > 0) { H2D(dX, Xw, 24 * (size_t)n); H2D(dO, obs, 16 * (size_t)n); }
   H2D(dK, K, 32);
-  H2D(dTp, T_prior_cw, 128);
-  int rc = svo_launch_pnp(ctx, dX, dO, n, dK, dTp, seed, dT, dM, dS);
+  H2D(dTp, T_fallback_cw, 128);
+  const uint16_t* sub = ctx->d_pnp_subsets + (size_t)std::min(n, 512) * 500;   // cv::RNG((uint64)-1): the table made at svo_create
+  uint16_t hsub[500];
+  if (rng_state != 0 && rng_state != ~0ull) {   // another RNG state: this call's own samples
+    svo_pnp_subsets(rng_state, n, hsub);
+    H2D(dSub, hsub, sizeof hsub);
+    SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));   // hsub lives on this stack frame
+    sub = dSub;
+  }
+  int rc = svo_launch_pnp(ctx, dX, dO, n, dK, dTp, sub, dHyp, dT, dM, dS);
   if (rc) return rc;
   D2H(T_cw, dT, 128);
   if (inlier_mask && n > 0) D2H(inlier_mask, dM, n);
   if (stats) D2H(stats, dS, sizeof(svo_pnp_stats));
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SVO_OK;
+}
+
+extern "C" int svo_debug_epnp5(svo_ctx* ctx, const double Xw5[15], const double uv5[10], const double K[4], double R[9],
+                               double t[3], double rep_err[3]) {
+  if (!ctx || !Xw5 || !uv5 || !K || !R || !t) return SVO_E_INVALID;
+  hipSetDevice(ctx->device);
+  Bump bm{ctx};
+  double* dX = bm.take<double>(15); double* dU = bm.take<double>(10); double* dK = bm.take<double>(4);
+  double* dO = bm.take<double>(24);
+  if (!bm.ok()) return SVO_E_CAPACITY;
+  H2D(dX, Xw5, 120); H2D(dU, uv5, 80); H2D(dK, K, 32);
+  int rc = svo_launch_epnp5_probe(ctx, dX, dU, dK, dO);
+  if (rc) return rc;
+  double o[24];
+  D2H(o, dO, sizeof o);
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(R, o, 72); memcpy(t, o + 9, 24);
+  if (rep_err) memcpy(rep_err, o + 13, 24);
+  if (getenv("SVO_EPNP_STAMPS")) fprintf(stderr, "epnp5 cycles: setup+MtM %.0f, eigen %.0f (%d sweeps), L/rho %.0f, branches %.0f\n", o[16], o[17], (int)o[20], o[18], o[19]);
+  return o[12] != 0.0 ? SVO_OK : SVO_E_INVALID;
 }
 
 // ---- throughput mode ---------------------------------------------------------------------

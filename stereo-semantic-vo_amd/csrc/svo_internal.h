@@ -98,6 +98,7 @@ struct svo_ctx {
   hipStream_t stream_idx = nullptr;        // the pose-free index chain of the tracking tail runs here, ahead of the pose chain
   hipEvent_t ev_frontend = nullptr;        // front end of a call finished (recorded on `stream`)
   std::vector<hipEvent_t> ev_frame;        // index chain of frame f finished (recorded on `stream_idx`)
+  uint16_t* d_pnp_subsets = nullptr;   // [513][100][5]: RANSAC sample indices of cv::RNG((uint64)-1) for every point count
   int pose_lds_state = 0;       // > 64 KB dynamic-LDS opt-in of the pose kernels: 0 untried, 1 granted, -1 refused
   int track_lds_state = 0;      // same for the tracker's kernels
   int opt_track_nblk = 3;       // svo_set_option("track_nblk"): runner-up blockers stored per packed entry (0..3)
@@ -151,9 +152,13 @@ int svo_launch_bf_match_dev(svo_ctx* ctx, const uint8_t* q, const int* M_ptr, co
                             uint8_t* keep, int32_t* gmin);
 int svo_launch_pose_opt(svo_ctx* ctx, const double* Xw, const double* obs, int n, const double* K,
                         double* T, svo_lm_stats* stats);
+// cv::solvePnPRansac on device arrays: `subset` = 100 x 5 sample indices for this n, `hyp` = scratch of svo_pnp_hyp_bytes()
 int svo_launch_pnp(svo_ctx* ctx, const double* Xw, const double* obs, int n, const double* K,
-                   const double* Tprior, uint64_t seed, double* T, uint8_t* mask,
+                   const double* Tfallback, const uint16_t* subset, void* hyp, double* T, uint8_t* mask,
                    svo_pnp_stats* stats);
+size_t svo_pnp_hyp_bytes();
+int svo_launch_epnp5_probe(svo_ctx* ctx, const double* X5, const double* u5, const double* K, double* Rt);
+void svo_pnp_subsets(uint64_t state, int n, uint16_t* out /*[100 * 5]*/);
 int svo_pose_lds_optin(svo_ctx* ctx);   // dynamic-LDS opt-in of the pose kernels (PoseLds > 64 KB)
 template <typename T>
 __host__ __device__ inline T* svo_byte_offset(T* p, size_t bytes) {

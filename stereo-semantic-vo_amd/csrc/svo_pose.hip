@@ -22,29 +22,80 @@ __global__ __launch_bounds__(256) void k_pose_opt(const double* __restrict__ Xw,
   pose_opt_block(L, Xw, obs, n, Kp, T, stats, round_in_f32, use_mfma);
 }
 
-__global__ __launch_bounds__(256) void k_pnp_ransac(const double* __restrict__ Xw,
-                                                    const double* __restrict__ obs, int n,
-                                                    const double* __restrict__ Kp,
-                                                    const double* __restrict__ Tprior, uint64_t seed,
-                                                    double* T, uint8_t* inlier_mask,
-                                                    svo_pnp_stats* stats, const int* n_ptr,
-                                                    const int* skip_ptr, const int* frame_ptr,
-                                                    int use_mfma, size_t seq_stride) {
-  if (blockIdx.y) {
-    const size_t off = (size_t)blockIdx.y * seq_stride;
-    Xw = svo_byte_offset(Xw, off); obs = svo_byte_offset(obs, off); Kp = svo_byte_offset(Kp, off);
-    Tprior = svo_byte_offset(Tprior, off); T = svo_byte_offset(T, off); stats = svo_byte_offset(stats, off);
-    n_ptr = svo_byte_offset(n_ptr, off); skip_ptr = svo_byte_offset(skip_ptr, off);
-    frame_ptr = svo_byte_offset(frame_ptr, off);
+// ---- cv::solvePnPRansac on plain arrays (svo_pnp_ransac) --------------------------------------------------------
+// k_pnp_hyp: 25 workgroups x 4 waves = the 100 RANSAC samples, one EPnP per wave, each with its consensus.
+// k_pnp_select: the sequential acceptance rule over those samples, the winner's pose, inlier mask and stats.
+struct PnpHypLds {
+  double Xw[PNP_MAXN * 3], uv[PNP_MAXN * 2];
+  EpnpWaveLds ws[4];
+};
+
+__global__ __launch_bounds__(256) void k_pnp_hyp(const double* __restrict__ Xw, const double* __restrict__ obs, int n,
+                                                 const double* __restrict__ Kp, const uint16_t* __restrict__ subset,
+                                                 PnpHyp* hyp) {
+  PnpHypLds& L = *reinterpret_cast<PnpHypLds*>(pose_smem);
+  for (int i = threadIdx.x; i < 3 * n; i += 256) L.Xw[i] = Xw[i];
+  for (int i = threadIdx.x; i < 2 * n; i += 256) L.uv[i] = obs[i];
+  __syncthreads();
+  const double K[4] = {Kp[0], Kp[1], Kp[2], Kp[3]};
+  pnp_hyp_block(L.ws, L.Xw, L.uv, n, K, subset, hyp, blockIdx.x * 4);
+}
+
+__global__ __launch_bounds__(256) void k_pnp_select(const double* __restrict__ Xw, const double* __restrict__ obs, int n,
+                                                    const double* __restrict__ Kp, const double* __restrict__ Tfallback,
+                                                    const PnpHyp* hyp, double* T, uint8_t* inlier_mask,
+                                                    svo_pnp_stats* stats) {
+  __shared__ int cnt[PNP_HYP], ok[PNP_HYP], s_best, s_good, s_iters;
+  const int tid = threadIdx.x;
+  if (tid < PNP_HYP) { cnt[tid] = n >= 5 ? hyp[tid].cnt : 0; ok[tid] = n >= 5 ? hyp[tid].ok : 0; }
+  __syncthreads();
+  if (tid == 0) {
+    int good = 0, iters = 0;
+    s_best = n >= 5 ? pnp_select(cnt, ok, n, &good, &iters) : -1;
+    s_good = good; s_iters = iters;
   }
-  if (n_ptr) n = *n_ptr;
-  if (frame_ptr) seed = 0x5EED0000ULL + (uint64_t)*frame_ptr;
-  if (skip_ptr && *skip_ptr) {   // frame 0: no PnP, the pose stays at the prior
-    if (threadIdx.x < 16) T[threadIdx.x] = Tprior[threadIdx.x];
-    return;
+  __syncthreads();
+  const int best = s_best;
+  if (best >= 0) {
+    const PnpHyp h = hyp[best];
+    const double K[4] = {Kp[0], Kp[1], Kp[2], Kp[3]};
+    if (inlier_mask)
+      for (int e = tid; e < n; e += 256)
+        inlier_mask[e] = n == 5 ? 1 : (pnp_inlier(h.R, h.t, Xw + 3 * e, obs + 2 * e, K) ? 1 : 0);
+    if (tid < 16) {
+      const int r = tid >> 2, c = tid & 3;
+      T[tid] = r == 3 ? (c == 3 ? 1.0 : 0.0) : (c == 3 ? h.t[r] : h.R[3 * r + c]);
+    }
+  } else {
+    if (inlier_mask)
+      for (int e = tid; e < n; e += 256) inlier_mask[e] = 0;
+    if (tid < 16) T[tid] = Tfallback[tid];
   }
-  PoseLds& L = *reinterpret_cast<PoseLds*>(pose_smem);
-  pnp_ransac_block(L, Xw, obs, n, Kp, Tprior, seed, T, inlier_mask, stats, use_mfma);
+  if (tid == 0 && stats) {
+    stats->n_points = n; stats->n_inliers = best >= 0 ? s_good : 0; stats->best_hypothesis = best;
+    stats->ok = best >= 0 ? 1 : 0; stats->iterations = s_iters;
+  }
+}
+
+// parity probe: one EPnP on five correspondences, one wave
+__global__ __launch_bounds__(64) void k_epnp5_probe(const double* X5, const double* u5, const double* Kp, double* Rt) {
+  __shared__ EpnpWaveLds ws;
+  double X[15], u[10], K[4] = {Kp[0], Kp[1], Kp[2], Kp[3]}, R[9], t[3];
+  for (int i = 0; i < 15; ++i) X[i] = X5[i];
+  for (int i = 0; i < 10; ++i) u[i] = u5[i];
+  const bool ok = epnp5_wave(ws, X, u, K, R, t);
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 9; ++i) Rt[i] = R[i];
+    Rt[9] = t[0]; Rt[10] = t[1]; Rt[11] = t[2]; Rt[12] = ok ? 1.0 : 0.0;
+    for (int b = 0; b < 3; ++b) Rt[13 + b] = ws.out[b][12];
+    for (int b = 0; b < 4; ++b) Rt[16 + b] = (double)(ws.stamp[b + 1] - ws.stamp[b]);
+    Rt[20] = ws.sweeps;
+  }
+}
+int svo_launch_epnp5_probe(svo_ctx* ctx, const double* X5, const double* u5, const double* K, double* Rt) {
+  hipLaunchKernelGGL(k_epnp5_probe, dim3(1), dim3(64), 0, ctx->stream, X5, u5, K, Rt);
+  SVO_HIP(ctx, hipGetLastError());
+  return SVO_OK;
 }
 
 // PoseLds is larger than the 64 KB a kernel gets by default: opt in once per context (per-device attribute)
@@ -52,12 +103,37 @@ int svo_pose_lds_optin(svo_ctx* ctx) {
   if (ctx->pose_lds_state == 0) {
     bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pose_opt), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)sizeof(PoseLds)) == hipSuccess;
-    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_ransac), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)sizeof(PoseLds)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_hyp), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)sizeof(PnpHypLds)) == hipSuccess;
     ctx->pose_lds_state = ok ? 1 : -1;
     if (!ok) ctx->last_error = std::string("hipFuncSetAttribute(pose kernels): ") + hipGetErrorString(hipGetLastError());
   }
   return ctx->pose_lds_state > 0 ? SVO_OK : SVO_E_HIP;
+}
+
+// The sample indices cv::RNG(state) hands RANSACPointSetRegistrator::getSubset for `n` points: 100 samples of 5 distinct
+// indices, each index redrawn until it differs from the sample's earlier ones (OpenCV 3.2 ptsetreg.cpp).  The RNG is
+// re-seeded with (uint64)-1 inside every run(), so the table depends on n only.
+void svo_pnp_subsets(uint64_t state, int n, uint16_t* out /*[100 * 5]*/) {
+  if (!state) state = ~0ull;
+  auto next = [&]() -> unsigned {
+    state = (uint64_t)(unsigned)state * 4164903690U + (unsigned)(state >> 32);
+    return (unsigned)state;
+  };
+  for (int k = 0; k < PNP_HYP; ++k) {
+    int idx[5];
+    for (int i = 0; i < 5; ++i) {
+      if (n <= 5) { idx[i] = i < n ? i : 0; continue; }   // count == modelPoints: the points themselves, no draw
+      for (;;) {
+        const int c = idx[i] = (int)(next() % (unsigned)n);
+        int j = 0;
+        for (; j < i; ++j)
+          if (c == idx[j]) break;
+        if (j == i) break;
+      }
+    }
+    for (int i = 0; i < 5; ++i) out[5 * k + i] = (uint16_t)idx[i];
+  }
 }
 
 int svo_launch_pose_opt(svo_ctx* ctx, const double* Xw, const double* obs, int n, const double* K,
@@ -71,17 +147,20 @@ int svo_launch_pose_opt(svo_ctx* ctx, const double* Xw, const double* obs, int n
   return SVO_OK;
 }
 
+// device arrays in, device results out; `subset`: 100 x 5 sample indices for this n (device), `hyp`: 100 records scratch
+size_t svo_pnp_hyp_bytes() { return sizeof(PnpHyp) * PNP_HYP; }
+
 int svo_launch_pnp(svo_ctx* ctx, const double* Xw, const double* obs, int n, const double* K,
-                   const double* Tprior, uint64_t seed, double* T, uint8_t* mask,
+                   const double* Tfallback, const uint16_t* subset, void* hyp_v, double* T, uint8_t* mask,
                    svo_pnp_stats* stats) {
+  PnpHyp* hyp = reinterpret_cast<PnpHyp*>(hyp_v);
   if (n > PNP_MAXN) return SVO_E_CAPACITY;
   int rc = svo_pose_lds_optin(ctx);
   if (rc) return rc;
   SvoTimer tm(ctx, "k_pnp_ransac");
-  hipLaunchKernelGGL(k_pnp_ransac, dim3(1), dim3(256), sizeof(PoseLds), ctx->stream, Xw, obs, n, K, Tprior, seed,
-                     T, mask, stats, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr,
-                     ctx->opt_pose_mfma, (size_t)0);
+  if (n >= 5)
+    hipLaunchKernelGGL(k_pnp_hyp, dim3(PNP_HYP / 4), dim3(256), sizeof(PnpHypLds), ctx->stream, Xw, obs, n, K, subset, hyp);
+  hipLaunchKernelGGL(k_pnp_select, dim3(1), dim3(256), 0, ctx->stream, Xw, obs, n, K, Tfallback, hyp, T, mask, stats);
   SVO_HIP(ctx, hipGetLastError());
   return SVO_OK;
 }
-

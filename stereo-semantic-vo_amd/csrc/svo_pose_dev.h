@@ -353,23 +353,16 @@ struct LmShared {
   int done;
 };
 
-#define PNP_HYP 100
-#define PNP_MAXN 2048
-#define PNP_GRAM_MAXN 256   // refit uses the MFMA Gram build up to this many points
+#define PNP_HYP 100        // cv::solvePnPRansac(..., iterationsCount = 100, ...) (reference src/pnpmatch.cc:227)
+#define PNP_MAXN 512       // correspondences per problem (one per keypoint at most)
 
-// LDS workspace of one pose workgroup (dynamic shared memory: > 64 KB, needs the per-function opt-in)
+// LDS workspace of the pose-only LM (dynamic shared memory: > 64 KB, needs the per-function opt-in)
 struct PoseLds {
   double arow[(2 * GRAM_MAXN + 64) * GRAM_STRIDE];
   double gram[4 * 64 + 4];
   double red[5 * 28];
   LmShared sh;
   double K[4];
-  // PnP
-  Se3 hyp[PNP_HYP];
-  int hcnt[PNP_HYP];
-  uint8_t use[PNP_MAXN];
-  Se3 cur;
-  int s_best, s_ok, s_stop, s_nin;
 };
 
 // Pose-only LM.  T: row-major 4x4 in/out (global or LDS); stats may be null.
@@ -505,161 +498,89 @@ __device__ __forceinline__ void pose_opt_block(PoseLds& L, const double* __restr
   }
 }
 
-__device__ __forceinline__ uint32_t lcg_next(uint64_t& s) {
-  s = s * 6364136223846793005ULL + 1442695040888963407ULL;
-  return (uint32_t)(s >> 33);
+// ---- cv::solvePnPRansac: hypotheses + the sequential acceptance rule ---------------------------------------------
+// (OpenCV 3.2 modules/calib3d/src/solvepnp.cpp + ptsetreg.cpp)
+#include "svo_epnp_dev.h"
+
+struct PnpHyp {          // one RANSAC sample: EPnP pose of its five points and its consensus
+  double R[9], t[3];
+  int32_t cnt, ok;
+};
+
+// PnPRansacCallback::computeError for one point: projectPoints in double, rounded once to float, squared distance to
+// the float image point in float.  Inlier iff <= (float)(8 * 8).
+__device__ __forceinline__ bool pnp_inlier(const double* R, const double* t, const double* X, const double* uv, const double* K) {
+  double x = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0];
+  double y = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + t[1];
+  double z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2];
+  z = z != 0.0 ? 1. / z : 1.;
+  x *= z; y *= z;
+  const float px = (float)(x * K[0] + K[2]), py = (float)(y * K[1] + K[3]);
+  const float dx = (float)uv[0] - px, dy = (float)uv[1] - py;
+  const float err = dx * dx + dy * dy;
+  return err <= 64.0f;
 }
 
-// PnP-RANSAC.  Tprior / T: row-major 4x4; inlier_mask (n bytes) and stats may be null.
-__device__ __forceinline__ void pnp_ransac_block(PoseLds& L, const double* __restrict__ Xw, const double* __restrict__ obs, int n,
-                                                 const double* __restrict__ Kp, const double* Tprior, uint64_t seed, double* T,
-                                                 uint8_t* inlier_mask, svo_pnp_stats* stats, int use_mfma) {
-  Se3* hyp = L.hyp; int* hcnt = L.hcnt; double* arow = L.arow; double* gram = L.gram; uint8_t* use = L.use;
-  double* red = L.red; Se3& cur = L.cur; double* K = L.K;
-  int& s_best = L.s_best; int& s_ok = L.s_ok; int& s_stop = L.s_stop; int& s_nin = L.s_nin;
-  const int tid = threadIdx.x;
-  __syncthreads();
-  if (tid < 4) K[tid] = Kp[tid];
-  if (tid < PNP_HYP) hcnt[tid] = -1;
-  __syncthreads();
-  Se3 prior;
-  se3_from_T(Tprior, prior);
-  // one thread per hypothesis: sample 5 points, 6 Gauss-Newton steps from the prior
-  if (tid < PNP_HYP && n >= 5) {
-    uint64_t s = seed ^ ((uint64_t)(tid + 1) * 0x9E3779B97F4A7C15ULL);
-    lcg_next(s);
-    int idx[5] = {-1, -1, -1, -1, -1}, got = 0, draws = 0;
-    while (got < 5 && draws < 64) {
-      const int c = (int)(lcg_next(s) % (uint32_t)n);
-      ++draws;
-      bool dup = false;
+// Hypotheses hyp_base .. hyp_base + (waves of the block) - 1, one wave each.  Xw / uv: the n correspondences in LDS (or
+// anywhere), subset: the 100 x 5 sample indices cv::RNG((uint64)-1) yields for this n (svo_pnp_subsets).
+__device__ __forceinline__ void pnp_hyp_block(EpnpWaveLds* ws, const double* Xw, const double* uv, int n, const double* K,
+                                              const uint16_t* subset, PnpHyp* out, int hyp_base) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int k = hyp_base + wv;
+  if (k >= PNP_HYP) return;
+  double X5[15], u5[10];
 #pragma unroll
-      for (int j = 0; j < 5; ++j) dup |= (j < got) && idx[j] == c;
-      if (!dup) {
+  for (int i = 0; i < 5; ++i) {
+    const int e = min((int)subset[5 * k + i], n - 1);
+    X5[3 * i] = Xw[3 * e]; X5[3 * i + 1] = Xw[3 * e + 1]; X5[3 * i + 2] = Xw[3 * e + 2];
+    u5[2 * i] = uv[2 * e]; u5[2 * i + 1] = uv[2 * e + 1];
+  }
+  double R[9], t[3];
+  const bool ok = epnp5_wave(ws[wv], X5, u5, K, R, t);
+  int cnt = 0;
+  if (ok)
+    for (int e = lane; e < n; e += 64) cnt += pnp_inlier(R, t, Xw + 3 * e, uv + 2 * e, K) ? 1 : 0;
+  cnt = wave_sum_i32_dpp(cnt);
+  if (lane == 0) {
+    PnpHyp h;
 #pragma unroll
-        for (int j = 0; j < 5; ++j)
-          if (j == got) idx[j] = c;
-        ++got;
-      }
-    }
-    if (got == 5) {
-      Se3 est = prior;
-      bool active = true;   // per-hypothesis early stop (max|dx| < 1e-10), same rule as the refit
-      for (int it = 0; it < 6 && active; ++it) {
-        double H[36], b[6], x[6];
-#pragma unroll
-        for (int j = 0; j < 36; ++j) H[j] = 0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) b[j] = 0;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-          const int i = idx[k];
-          double e[2], pc[3], J[12];
-          edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc);
-          edge_jacobian(pc, K, J);
-#pragma unroll
-          for (int r = 0; r < 6; ++r) {
-            b[r] -= J[r] * e[0] + J[6 + r] * e[1];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) H[6 * r + c] += J[r] * J[c] + J[6 + r] * J[6 + c];
-          }
-        }
-        if (!ldlt6_solve(H, b, x)) break;
-        bool fin = true;
-        double xmax = 0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) { fin = fin && isfinite(x[j]); xmax = fmax(xmax, fabs(x[j])); }
-        if (!fin) break;
-        se3_oplus(x, est);
-        if (xmax < 1e-10) active = false;
-      }
-      hyp[tid] = est;
-      hcnt[tid] = 0;
+    for (int i = 0; i < 9; ++i) h.R[i] = R[i];
+    h.t[0] = t[0]; h.t[1] = t[1]; h.t[2] = t[2];
+    h.cnt = cnt; h.ok = ok ? 1 : 0;
+    out[k] = h;
+  }
+}
+
+// RANSACUpdateNumIters(p = 0.99, ep, modelPoints = 5, maxIters)
+__device__ __forceinline__ int pnp_update_iters(double ep, int maxIters) {
+  const double p = 0.99;
+  ep = fmax(ep, 0.); ep = fmin(ep, 1.);
+  double num = fmax(1. - p, 2.2250738585072014e-308);
+  double denom = 1. - pow(1. - ep, 5.0);
+  if (denom < 2.2250738585072014e-308) return 0;
+  num = log(num);
+  denom = log(denom);
+  return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)rint(num / denom);
+}
+
+// RANSACPointSetRegistrator::run over the precomputed samples (one thread): sample `iter` replaces the best one iff its
+// consensus is larger (and > 4), and the iteration bound shrinks with the inlier ratio.  Returns the winning sample
+// (-1: none), *good its consensus, *iters the samples visited.
+__device__ __forceinline__ int pnp_select(const int* cnt, const int* ok, int n, int* good, int* iters) {
+  int niters = PNP_HYP, maxGood = 0, best = -1, run = 0;
+  if (n == 5) {   // count == modelPoints: the one model, every point an inlier
+    *good = ok[0] ? 5 : 0; *iters = 1;
+    return ok[0] ? 0 : -1;
+  }
+  for (int iter = 0; iter < niters; ++iter) {
+    ++run;
+    if (!ok[iter]) continue;
+    const int g = cnt[iter];
+    if (g > max(maxGood, 4)) {
+      maxGood = g; best = iter;
+      niters = pnp_update_iters((double)(n - g) / n, niters);
     }
   }
-  __syncthreads();
-  // consensus: all threads score (hypothesis, point) pairs
-  if (n >= 5) {
-    for (int p = tid; p < PNP_HYP * n; p += 256) {
-      const int k = p / n, i = p - k * n;
-      if (hcnt[k] < 0) continue;
-      double e[2], pc[3];
-      edge_error(hyp[k], Xw + 3 * i, obs + 2 * i, K, e, pc);
-      if (pc[2] > 0.0 && e[0] * e[0] + e[1] * e[1] <= 64.0) atomicAdd(&hcnt[k], 1);
-    }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    int best = -1, bk = -1;
-    for (int k = 0; k < PNP_HYP; ++k)
-      if (hcnt[k] > best) { best = hcnt[k]; bk = k; }
-    s_best = bk;
-    s_ok = best >= 5 ? 1 : 0;
-    cur = s_ok ? hyp[bk] : prior;
-  }
-  __syncthreads();
-  if (s_ok) {
-    const Se3 be = cur;
-    for (int i = tid; i < n; i += 256) {
-      double e[2], pc[3];
-      edge_error(be, Xw + 3 * i, obs + 2 * i, K, e, pc);
-      use[i] = (pc[2] > 0.0 && e[0] * e[0] + e[1] * e[1] <= 64.0) ? 1 : 0;
-    }
-    __syncthreads();
-    for (int it = 0; it < 10; ++it) {
-      double acc[28];
-      const Se3 est = cur;
-      if (use_mfma && n <= PNP_GRAM_MAXN) {
-        build_system_mfma<false>(est, Xw, obs, n, use, K, 0, 0, arow, gram, red);
-      } else {
-        accum_system<false>(est, Xw, obs, n, use, K, 0, 0, acc);
-        block_reduce<28>(acc, red);
-      }
-      if (tid == 0) {
-        double H[36], b[6], x[6];
-        unpack_system(red, H, b);
-        int stop = 0;
-        if (!ldlt6_solve(H, b, x)) stop = 1;
-        else {
-          bool fin = true;
-          double xmax = 0;
-#pragma unroll
-          for (int j = 0; j < 6; ++j) { fin = fin && isfinite(x[j]); xmax = fmax(xmax, fabs(x[j])); }
-          if (!fin) stop = 1;
-          else {
-            Se3 e2 = cur; se3_oplus(x, e2); cur = e2;
-            if (xmax < 1e-10) stop = 1;   // converged
-          }
-        }
-        s_stop = stop;
-      }
-      __syncthreads();
-      if (s_stop) break;
-    }
-  }
-  if (tid == 0) s_nin = 0;
-  __syncthreads();
-  {
-    const Se3 fe = cur;
-    int c = 0;
-    for (int i = tid; i < n; i += 256) {
-      int in = 0;
-      if (s_ok) {
-        double e[2], pc[3];
-        edge_error(fe, Xw + 3 * i, obs + 2 * i, K, e, pc);
-        in = (pc[2] > 0.0 && e[0] * e[0] + e[1] * e[1] <= 64.0) ? 1 : 0;
-      }
-      if (inlier_mask) inlier_mask[i] = (uint8_t)in;
-      c += in;
-    }
-    if (c) atomicAdd(&s_nin, c);
-  }
-  __syncthreads();
-  if (tid == 0) {
-    se3_to_T(cur, T);
-    if (stats) {
-      stats->n_points = n; stats->n_inliers = s_nin; stats->best_hypothesis = s_ok ? s_best : -1;
-      stats->ok = s_ok;
-    }
-  }
+  *good = maxGood; *iters = run;
+  return best;
 }

@@ -66,7 +66,9 @@ struct TrackWork {
   int32_t frame_id, nkp, n_stereo, n_pass1, n_pass2, n_new, n_local, skip_match;
   long long ts[8];               // diagnostics: s_memtime at begin / pass 1 / pass 2 / frame end / done, dense rows, late rows
   int32_t diag[2];               // [0] rows of pass 1 | rounds << 16, [1] rows of pass 2 | rounds << 16
-  int32_t edge_gid[TRK_MAXKP];   // per keypoint: id of the map point matched to it (CurrentFrame->MapPoints[j]) or -1
+  int32_t n_edges;               // 3D-2D correspondences of the frame (src/pnpmatch.cc:216-224), in keypoint order:
+  int32_t edge_gid[TRK_MAXKP];   //   id of the map point (CurrentFrame->MapPoints[j]->...) ...
+  int16_t edge_kp[TRK_MAXKP];    //   ... and the keypoint j it is matched to
   int32_t new_gid[TRK_MAXKP];    // per keypoint: id of the map point created from it at the frame's end, or -1
 };
 
@@ -88,6 +90,7 @@ struct TrackState {
   double Xw[TRK_MAXKP * 3], obs[TRK_MAXKP * 2], K[4], Tprior[16], T[16];
   svo_lm_stats lm;
   svo_pnp_stats pnp;
+  PnpHyp hyp[PNP_HYP];                 // the frame's RANSAC samples (k_tp_hyp)
   // ---- large arrays (not cleared by a reset) -----------------------------------------------
   TrackPool pool[2];
   uint16_t rowmin[TRK_CAP];                // min over ALL current keypoints of the row's distances
@@ -588,9 +591,11 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
     }
     if (tid < nkp && S.cur_mp[tid] >= 0) edge_gid = P.gid[S.cur_mp[tid]];
   }
-  if (tid < TRK_MAXKP) {
-    st->dbg_cur_mp[tid] = tid < nkp ? S.cur_mp[tid] : -1;
-    work->edge_gid[tid] = edge_gid;
+  if (tid < TRK_MAXKP) st->dbg_cur_mp[tid] = tid < nkp ? S.cur_mp[tid] : -1;
+  int n_edges;
+  {
+    const int e = block_excl_scan(edge_gid >= 0 ? 1 : 0, S.sm, &n_edges);
+    if (edge_gid >= 0) { work->edge_gid[e] = edge_gid; work->edge_kp[e] = (int16_t)tid; }
   }
   ts3 = clock64();
   // ---- frame end: createmappoint (src/frame.cc:182-238) for keypoints without a map point ------
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
   const int lapped = __syncthreads_or(oldest != 0x7fffffff && next_gid - oldest > TRK_GPOS - 2 * TRK_MAXKP);
   if (tid < TRK_MAXKP) st->last_mp[tid] = (tid < nkp && m_cur >= 0) ? S.remap[m_cur] : -1;
   if (tid == 0) {
-    work->frame_id = id; work->nkp = nkp; work->n_stereo = n_stereo;
+    work->frame_id = id; work->nkp = nkp; work->n_stereo = n_stereo; work->n_edges = n_edges;
     work->n_pass1 = n_pass1; work->n_pass2 = n_pass2;
     work->n_new = n_new0 + n_new; work->n_local = nl_total; work->skip_match = id == 0 ? 1 : 0;
     ts4 = clock64();
@@ -689,10 +694,38 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
 // ================================================================================================
 // Pose chain: one launch per frame and sequence
 // ================================================================================================
+// k_tp_hyp: the 100 RANSAC samples of cv::solvePnPRansac (src/pnpmatch.cc:227), 25 workgroups x 4 waves, one EPnP and one
+// consensus count per wave (svo_pose_dev.h, svo_epnp_dev.h).  Every workgroup gathers the frame's correspondences itself.
+struct TpHypLds {
+  double Xw[TRK_MAXKP * 3], uv[TRK_MAXKP * 2];
+  EpnpWaveLds ws[4];
+};
+
+__global__ __launch_bounds__(256) void k_tp_hyp(TrackState* st, const TrackWork* work, const svo_kp* kp, const uint16_t* subsets,
+                                                int kstride) {
+  TpHypLds& S = *reinterpret_cast<TpHypLds*>(tk_smem);
+  st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
+  const int n = work->n_edges;
+  if (work->skip_match || n < 5) return;
+  const float* gpos = st->gpos;
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const float* gp = gpos + 3 * (size_t)(work->edge_gid[e] & (TRK_GPOS - 1));
+    const svo_kp k = kp[work->edge_kp[e]];
+    S.Xw[3 * e] = (double)gp[0]; S.Xw[3 * e + 1] = (double)gp[1]; S.Xw[3 * e + 2] = (double)gp[2];
+    S.uv[2 * e] = (double)k.x; S.uv[2 * e + 1] = (double)k.y;
+  }
+  __syncthreads();
+  const double K[4] = {(double)st->cam.fx, (double)st->cam.fy, (double)st->cam.cx, (double)st->cam.cy};
+  pnp_hyp_block(S.ws, S.Xw, S.uv, n, K, subsets + (size_t)min(n, 512) * 500, st->hyp, blockIdx.x * 4);
+}
+
+// k_tp_frame: RANSAC's acceptance rule over the samples, Optimizer::PoseOptimization, SetPose, the positions of the
+// map points created this frame, the frame's record.
 struct TpLds {
   PoseLds pose;
   alignas(16) int sm[16];
   float sT[16], sRwc[9], stwc[3];
+  int cnt[PNP_HYP], ok[PNP_HYP], best, good, iters;
 };
 
 __global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, const TrackWork* work, const svo_kp* kp,
@@ -702,19 +735,13 @@ __global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, const TrackWor
   st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
   depth += (size_t)blockIdx.y * kstride; res_out += blockIdx.y;
   const int tid = threadIdx.x;
-  const int id = work->frame_id, nkp = work->nkp, skip = work->skip_match;
+  const int id = work->frame_id, nkp = work->nkp, skip = work->skip_match, n_edges = work->n_edges;
   float* gpos = st->gpos;
   // ---- 3D-2D correspondences, ordered by keypoint index (src/pnpmatch.cc:216-224) ---------------
-  const int j0 = 2 * tid;
-  const int g0 = j0 < nkp ? work->edge_gid[j0] : -1, g1 = j0 + 1 < nkp ? work->edge_gid[j0 + 1] : -1;
-  int n_edges;
-  int pos = block_excl_scan((g0 >= 0 ? 1 : 0) + (g1 >= 0 ? 1 : 0), S.sm, &n_edges);
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int g = q ? g1 : g0, j = j0 + q;
-    if (g < 0) continue;
+  for (int e = tid; e < n_edges; e += 256) {
+    const int j = work->edge_kp[e];
     const svo_kp k = kp[j];
-    float* gp = gpos + 3 * (size_t)(g & (TRK_GPOS - 1));
+    float* gp = gpos + 3 * (size_t)(work->edge_gid[e] & (TRK_GPOS - 1));
     float xyz[3];
     if (id == 0) {   // Tracking::init: the points of frame 0 are placed with the identity pose, before its LM
       const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3[3] = {0, 0, 0};
@@ -723,17 +750,35 @@ __global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, const TrackWor
     } else {
       xyz[0] = gp[0]; xyz[1] = gp[1]; xyz[2] = gp[2];
     }
-    st->Xw[3 * pos] = (double)xyz[0]; st->Xw[3 * pos + 1] = (double)xyz[1]; st->Xw[3 * pos + 2] = (double)xyz[2];
-    st->obs[2 * pos] = (double)k.x; st->obs[2 * pos + 1] = (double)k.y;
-    ++pos;
+    st->Xw[3 * e] = (double)xyz[0]; st->Xw[3 * e + 1] = (double)xyz[1]; st->Xw[3 * e + 2] = (double)xyz[2];
+    st->obs[2 * e] = (double)k.x; st->obs[2 * e + 1] = (double)k.y;
   }
   if (tid < 4) st->K[tid] = (double)((const float*)&st->cam)[tid];
-  if (tid < 16) { st->Tprior[tid] = (double)st->lastTcw[tid]; if (skip) st->T[tid] = (double)st->lastTcw[tid]; }
+  // ---- PnP initial pose (src/pnpmatch.cc:212-247): no prior; if solvePnPRansac fails the last pose stays ----------
+  const bool ran = !skip && n_edges >= 5;
+  if (ran && tid < PNP_HYP) { S.cnt[tid] = st->hyp[tid].cnt; S.ok[tid] = st->hyp[tid].ok; }
   __syncthreads();
-  // ---- PnP initial pose (src/pnpmatch.cc:212-247), then Optimizer::PoseOptimization --------------
-  if (!skip)
-    pnp_ransac_block(S.pose, st->Xw, st->obs, n_edges, st->K, st->Tprior, 0x5EED0000ULL + (uint64_t)id, st->T,
-                     (uint8_t*)nullptr, &st->pnp, use_mfma);
+  if (tid == 0) {
+    int good = 0, iters = 0;
+    S.best = ran ? pnp_select(S.cnt, S.ok, n_edges, &good, &iters) : -1;
+    S.good = good; S.iters = iters;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    double v = (double)st->lastTcw[tid];
+    if (S.best >= 0) {
+      const PnpHyp& h = st->hyp[S.best];
+      const int r = tid >> 2, c = tid & 3;
+      v = r == 3 ? (c == 3 ? 1.0 : 0.0) : (c == 3 ? h.t[r] : h.R[3 * r + c]);
+    }
+    st->T[tid] = v;
+  }
+  if (tid == 0) {
+    st->pnp.n_points = n_edges; st->pnp.n_inliers = S.best >= 0 ? S.good : 0; st->pnp.best_hypothesis = S.best;
+    st->pnp.ok = S.best >= 0 ? 1 : 0; st->pnp.iterations = S.iters;
+  }
+  __syncthreads();
+  // ---- Optimizer::PoseOptimization (src/Optimizer.cc:15-86) from the CV_32F-stored PnP pose ----------------------
   pose_opt_block(S.pose, st->Xw, st->obs, n_edges, st->K, st->T, &st->lm, 1, use_mfma);
   __syncthreads();
   // ---- SetPose (CV_32F, src/Optimizer.cc:82-83), positions of the points created this frame -------
@@ -747,10 +792,8 @@ __global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, const TrackWor
     S.stwc[tid] = (float)(-acc);
   }
   __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int j = j0 + q;
-    const int g = j < nkp ? work->new_gid[j] : -1;
+  for (int j = tid; j < nkp; j += 256) {
+    const int g = work->new_gid[j];
     if (g < 0) continue;
     const svo_kp k = kp[j];
     float xyz[3];
@@ -811,6 +854,8 @@ static int track_resources(svo_ctx* ctx, int frames, int nseq) {
                                   (int)sizeof(TiLds)) == hipSuccess;
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_frame), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)sizeof(TpLds)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_hyp), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)sizeof(TpHypLds)) == hipSuccess;
     ctx->track_lds_state = ok ? 1 : -1;
     if (!ok) ctx->last_error = std::string("hipFuncSetAttribute(tracker kernels): ") + hipGetErrorString(hipGetLastError());
   }
@@ -847,6 +892,10 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
     }
     SVO_HIP(ctx, hipEventRecord(ctx->ev_frame[f], s1));
     SVO_HIP(ctx, hipStreamWaitEvent(s0, ctx->ev_frame[f], 0));
+    {
+      SvoTimer t(ctx, "k_tp_hyp");
+      hipLaunchKernelGGL(k_tp_hyp, dim3(PNP_HYP / 4, ny), dim3(256), sizeof(TpHypLds), s0, st, work + f, kpf, ctx->d_pnp_subsets, kstride);
+    }
     {
       SvoTimer t(ctx, "k_tp_frame");
       hipLaunchKernelGGL(k_tp_frame, dim3(1, ny), dim3(256), sizeof(TpLds), s0, st, work + f, kpf, depf, d_res + f, kstride,
@@ -1241,4 +1290,23 @@ extern "C" int svo_track_sharded_dev(svo_ctx* const* ctxs, int G, const uint8_t*
     SVO_HIP(c0, hipMemcpy2DAsync(sg->n + g, 4 * (size_t)G, c->d_nkp, 4, 4, nb, hipMemcpyDeviceToDevice, c0->stream));
   }
   return svo_track_tail_dev(c0, sg->kp, sg->desc, sg->n, sg->depth, K, B, d_results);
+}
+
+// Parity probe: cv::solvePnPRansac's outcome for the frame just tracked (winning sample, consensus, samples visited)
+// and the pose it handed to PoseOptimization (before the CV_32F rounding), row-major 4x4.
+extern "C" int svo_debug_track_pnp(svo_ctx* ctx, svo_pnp_stats* stats, double T_pnp[16]) {
+  if (!ctx || !ctx->d_track) return SVO_E_INVALID;
+  TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (stats) SVO_HIP(ctx, hipMemcpy(stats, &st->pnp, sizeof *stats, hipMemcpyDeviceToHost));
+  if (T_pnp) {
+    PnpHyp h;
+    svo_pnp_stats s;
+    SVO_HIP(ctx, hipMemcpy(&s, &st->pnp, sizeof s, hipMemcpyDeviceToHost));
+    if (s.best_hypothesis < 0) return SVO_E_INVALID;
+    SVO_HIP(ctx, hipMemcpy(&h, &st->hyp[s.best_hypothesis], sizeof h, hipMemcpyDeviceToHost));
+    for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T_pnp[4 * r + c] = h.R[3 * r + c]; T_pnp[4 * r + 3] = h.t[r]; }
+    T_pnp[12] = 0; T_pnp[13] = 0; T_pnp[14] = 0; T_pnp[15] = 1;
+  }
+  return SVO_OK;
 }

@@ -54,6 +54,11 @@ int main(int argc, char** argv) {
     svo_track_result res;
     if (svo_track_frame(dev, L.ptr(), L.cols, R.ptr(), R.cols, 0.1 * k, flat.empty() ? nullptr : flat.data(),
                         (int)boxes.size(), &res) != SVO_OK) return 4;
+    if (getenv("SVO_HOST_DEBUG") && k > 0) {
+      svo_pnp_stats ps; double Tp[16];
+      if (svo_debug_track_pnp(dev, &ps, Tp) == SVO_OK)
+        fprintf(stderr, "dev  pnp: n %d best %d inliers %d iters %d t %.9g %.9g %.9g\n", ps.n_points, ps.best_hypothesis, ps.n_inliers, ps.iterations, Tp[3], Tp[7], Tp[11]);
+    }
     double d = 0;
     for (int i = 0; i < 16; ++i) d = std::max(d, (double)std::fabs(res.Tcw[i] - host->lastframe.Tcw.m[i]));
     worst = std::max(worst, d);

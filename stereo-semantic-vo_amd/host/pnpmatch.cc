@@ -1,3 +1,5 @@
+#include <cstdio>
+#include <cstdlib>
 #include "pnpmatch.h"
 
 #include <vector>
@@ -112,7 +114,8 @@ int pnpmatch::poseEstimationPnP(frame* Cur, frame& Last, std::set<mappoint*, map
   double Tp[16], T[16];
   for (int i = 0; i < 16; ++i) Tp[i] = Last.Tcw.m[i];
   svo_pnp_stats st{};
-  svo_pnp_ransac(ctx, pts3d.data(), pts2d.data(), n, Kd, Tp, 0x5EED0000ULL + (uint64_t)Cur->id, T, nullptr, &st);
+  svo_pnp_ransac(ctx, pts3d.data(), pts2d.data(), n, Kd, Tp, 0, T, nullptr, &st);   // cv::solvePnPRansac(..., false, 100, 8.0, 0.99)
+  if (getenv("SVO_HOST_DEBUG")) fprintf(stderr, "host pnp: n %d best %d inliers %d iters %d t %.9g %.9g %.9g\n", n, st.best_hypothesis, st.n_inliers, st.iterations, T[3], T[7], T[11]);
   Mat44f Tcl;
   for (int i = 0; i < 16; ++i) Tcl.m[i] = (float)T[i];
   Cur->SetPose(Tcl);   // Tcl * I

@@ -24,13 +24,14 @@
 #include <stdint.h>
 
 struct EpnpWaveLds {
-  double A[12 * 12];      // M^T M, diagonalised in place
-  double V[12 * 12];      // accumulated rotations: columns = eigenvectors
-  double rc[12], rs[12];  // per index: cos and signed sin of the rotation its pair gets in the running step
+  alignas(16) double A[12 * 12];      // M^T M, diagonalised in place
+  alignas(16) double V[12 * 12];      // accumulated rotations: columns = eigenvectors
+  alignas(16) double cs[6][2];  // per pair of the running step: cos, sin of its rotation
   double v4[4][12];       // eigenvectors of the four smallest eigenvalues, v4[0] = smallest (OpenCV's ut + 12 * 11)
   double L[6 * 10], rho[6];
   double alphas[5 * 4];
   double cws[4][3];
+  double x5[15], u5[10];  // the sample's object / image points
   double out[3][16];      // per branch: R (9), t (3), reprojection error
   int order[12];
   long long stamp[8];     // s_memtime after each stage (diagnostics)
@@ -43,23 +44,22 @@ struct EpnpWaveLds {
     __builtin_amdgcn_wave_barrier();                      \
   } while (0)
 
-// float64 reciprocal square root / reciprocal from the float32 hardware approximations + three Newton steps each
-// (1e-7 -> 1e-14 -> full precision); far fewer dependent instructions than the IEEE division / sqrt sequences, and the
-// Jacobi rotations only need c^2 + s^2 = 1 to rounding.
+// float64 reciprocal square root / reciprocal: the hardware's own f64 approximation (v_rsq_f64 / v_rcp_f64) plus one
+// Newton step - a handful of dependent instructions instead of the IEEE sqrt / division sequences.  The Jacobi
+// rotations only need c^2 + s^2 = 1 to rounding.
 __device__ __forceinline__ double epnp_rsqrt(double x) {
-  double y = (double)__frsqrt_rn((float)x);
-  const double hx = 0.5 * x;
-  y = y * (1.5 - hx * y * y);
-  y = y * (1.5 - hx * y * y);
-  y = y * (1.5 - hx * y * y);
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - (0.5 * x) * y * y);
   return y;
 }
 __device__ __forceinline__ double epnp_rcp(double x) {
-  double r = (double)__frcp_rn((float)x);
-  r = r * (2.0 - x * r);
-  r = r * (2.0 - x * r);
+  double r = __builtin_amdgcn_rcp(x);
   r = r * (2.0 - x * r);
   return r;
+}
+// where position x moves after a step of the systolic tournament: 0 stays; 2 -> 4 -> 6 -> 8 -> 10 -> 11 -> 9 -> 7 -> 5 -> 3 -> 1 -> 2
+__device__ __forceinline__ int epnp_pi(int x) {
+  return x == 0 ? 0 : (x == 1 ? 2 : (x == 10 ? 11 : ((x & 1) ? x - 2 : x + 2)));
 }
 // partner of index x in step r of the tournament below
 __device__ __forceinline__ int epnp_partner(int x, int r) {
@@ -94,12 +94,12 @@ __device__ inline void epnp_svd3(const double* A, double* w, double* Ut, double*
       double* Ai = At + 3 * i; double* Aj = At + 3 * j;
       double a = W[i], b = W[j];
       double p = Ai[0] * Aj[0] + Ai[1] * Aj[1] + Ai[2] * Aj[2];
-      if (fabs(p) <= eps * sqrt(a * b)) continue;
+      if (p * p <= eps * eps * a * b) continue;
       p *= 2;
-      const double beta = a - b, gamma = hypot(p, beta);
+      const double beta = a - b, g2 = p * p + beta * beta, ig = epnp_rsqrt(g2), gamma = g2 * ig;
       double c, s;
-      if (beta < 0) { const double delta = (gamma - beta) * 0.5; s = sqrt(delta / gamma); c = p / (gamma * s * 2); }
-      else { c = sqrt((gamma + beta) / (gamma * 2)); s = p / (gamma * c * 2); }
+      if (beta < 0) { const double delta = (gamma - beta) * 0.5, dg = delta * ig; s = dg * epnp_rsqrt(dg); c = p * ig * 0.5 * epnp_rcp(s); }
+      else { const double cg = (gamma + beta) * ig * 0.5; c = cg * epnp_rsqrt(cg); s = p * ig * 0.5 * epnp_rcp(c); }
       a = b = 0;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
@@ -140,14 +140,17 @@ __device__ inline void epnp_svd3(const double* A, double* w, double* Ut, double*
   }
 }
 
-// least squares min |A x - b| for a 6 x NC system through the normal equations (pivoted Gauss-Jordan on NC x NC)
+// least squares min |A x - b| for a 6 x NC system through the normal equations, solved by an unpivoted LDL^T
+// (the Gram matrix of a full-rank A is positive definite; a rank-deficient candidate produces non-finite betas and
+// loses the comparison of reprojection errors)
 template <int NC>
 __device__ inline void epnp_lsq6(const double* A /*6 x NC row-major*/, const double* b, double* x) {
-  double N[NC][NC + 1];
+  double N[NC][NC], y[NC], Lm[NC][NC], D[NC];
 #pragma unroll
   for (int r = 0; r < NC; ++r) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
+      if (c < r) continue;
       double s = 0;
 #pragma unroll
       for (int k = 0; k < 6; ++k) s += A[NC * k + r] * A[NC * k + c];
@@ -156,43 +159,55 @@ __device__ inline void epnp_lsq6(const double* A /*6 x NC row-major*/, const dou
     double s = 0;
 #pragma unroll
     for (int k = 0; k < 6; ++k) s += A[NC * k + r] * b[k];
-    N[r][NC] = s;
+    y[r] = s;
   }
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    int piv = c;
-    double best = fabs(N[c][c]);
+  for (int j = 0; j < NC; ++j) {
+    double d = N[j][j];
 #pragma unroll
-    for (int r = 0; r < NC; ++r)
-      if (r > c && fabs(N[r][c]) > best) { best = fabs(N[r][c]); piv = r; }
+    for (int k = 0; k < NC; ++k)
+      if (k < j) d -= Lm[j][k] * Lm[j][k] * D[k];
+    D[j] = d;
+    const double inv = 1.0 / d;
 #pragma unroll
-    for (int r = 0; r < NC; ++r)
-      if (r == piv && r != c) {
+    for (int i = 0; i < NC; ++i) {
+      if (i <= j) continue;
+      double sacc = N[j][i];
 #pragma unroll
-        for (int k = 0; k <= NC; ++k) { const double t = N[c][k]; N[c][k] = N[r][k]; N[r][k] = t; }
-      }
-    const double inv = N[c][c] != 0 ? 1.0 / N[c][c] : 0.0;
-#pragma unroll
-    for (int k = 0; k <= NC; ++k) N[c][k] *= inv;
-#pragma unroll
-    for (int r = 0; r < NC; ++r)
-      if (r != c) {
-        const double f = N[r][c];
-#pragma unroll
-        for (int k = 0; k <= NC; ++k) N[r][k] -= f * N[c][k];
-      }
+      for (int k = 0; k < NC; ++k)
+        if (k < j) sacc -= Lm[i][k] * Lm[j][k] * D[k];
+      Lm[i][j] = sacc * inv;
+    }
   }
 #pragma unroll
-  for (int r = 0; r < NC; ++r) x[r] = N[r][NC];
+  for (int i = 0; i < NC; ++i) {
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+      if (k < i) y[i] -= Lm[i][k] * y[k];
+  }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) y[i] /= D[i];
+#pragma unroll
+  for (int i = NC - 1; i >= 0; --i) {
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+      if (k > i) y[i] -= Lm[k][i] * y[k];
+  }
+#pragma unroll
+  for (int r = 0; r < NC; ++r) x[r] = y[r];
 }
 
 __device__ __forceinline__ double epnp_dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 
-// One hypothesis.  Called by all 64 lanes of a wave with the same arguments; the result (R row-major, t) is returned
-// in every lane.  Xw: 5 x 3, uv: 5 x 2 (doubles holding float values), K = {fu, fv, uc, vc}.
-__device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* Xw, const double* uv, const double* K, double* R_out,
-                                  double* t_out) {
+// One hypothesis.  Called by all 64 lanes of a wave; the result (R row-major, t) is returned in every lane.  The sample
+// is expected in S.x5 (5 x 3) / S.u5 (5 x 2) (doubles holding float values); K = {fu, fv, uc, vc}.
+__device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* K, double* R_out, double* t_out) {
   const int lane = threadIdx.x & 63;
+  // the sample lives in LDS, S.x5 / S.u5, filled by the caller (uniform reads broadcast): keeps ~50 registers free
+  // across the eigen-solver
+  EPNP_WAVE_SYNC();
+  const double* Xw = S.x5;
+  const double* uv = S.u5;
   const double fu = K[0], fv = K[1], uc = K[2], vc = K[3];
   if (lane == 0) S.stamp[0] = clock64();
   // ---- choose_control_points + compute_barycentric_coordinates (every lane, same scalar code) -------------------
@@ -211,24 +226,31 @@ __device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* Xw, const double
   }
   double dc[3], uct[9], vt3[9];
   epnp_svd3(cov, dc, uct, vt3);
-  double kk[3], cw[4][3];
+  double kk[3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) cw[0][j] = cw0[j];
-#pragma unroll
-  for (int i = 1; i < 4; ++i) {
-    kk[i - 1] = sqrt(dc[i - 1] / 5);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) cw[i][j] = cw0[j] + kk[i - 1] * uct[3 * (i - 1) + j];
+  for (int i = 0; i < 3; ++i) kk[i] = sqrt(dc[i] / 5);
+  // control points cws[0] = centroid, cws[i] = centroid + k_i u_i; CC = [k1 u1 | k2 u2 | k3 u3] has orthogonal columns: its
+  // inverse (OpenCV: cvInvert through an SVD) is diag(1/k) U^T.  Both go to LDS: later stages index them dynamically.
+  if (lane < 12) {
+    const int i = lane / 3, j = lane % 3;
+    const double ki = i == 1 ? kk[0] : (i == 2 ? kk[1] : kk[2]);
+    const double uij = i == 0 ? 0.0 : (i == 1 ? (j == 0 ? uct[0] : (j == 1 ? uct[1] : uct[2]))
+                                               : (i == 2 ? (j == 0 ? uct[3] : (j == 1 ? uct[4] : uct[5]))
+                                                         : (j == 0 ? uct[6] : (j == 1 ? uct[7] : uct[8]))));
+    const double c0 = j == 0 ? cw0[0] : (j == 1 ? cw0[1] : cw0[2]);
+    S.cws[i][j] = i == 0 ? c0 : c0 + ki * uij;
   }
-  // CC = [k1 u1 | k2 u2 | k3 u3] has orthogonal columns: its inverse (OpenCV: cvInvert through an SVD) is diag(1/k) U^T
-  double alphas[20];
+  if (lane < 5) {
+    const double d[3] = {Xw[3 * lane] - cw0[0], Xw[3 * lane + 1] - cw0[1], Xw[3 * lane + 2] - cw0[2]};
+    double a[4];
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const double d[3] = {Xw[3 * i] - cw0[0], Xw[3 * i + 1] - cw0[1], Xw[3 * i + 2] - cw0[2]};
+    for (int j = 0; j < 3; ++j) a[1 + j] = kk[j] > 0 ? epnp_dot3(&uct[3 * j], d) / kk[j] : 0.0;
+    a[0] = 1.0 - a[1] - a[2] - a[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) alphas[4 * i + 1 + j] = kk[j] > 0 ? epnp_dot3(&uct[3 * j], d) / kk[j] : 0.0;
-    alphas[4 * i] = 1.0 - alphas[4 * i + 1] - alphas[4 * i + 2] - alphas[4 * i + 3];
+    for (int j = 0; j < 4; ++j) S.alphas[4 * lane + j] = a[j];
   }
+  EPNP_WAVE_SYNC();
+  const double* alphas = S.alphas;
   // ---- M^T M: entry (a, b) = sum over the 10 rows of M; M row pair of point i = alpha (x) (fu, 0, uc - u), (0, fv, vc - v)
   for (int e = lane; e < 144; e += 64) {
     const int a = e / 12, b = e % 12, ia = a / 3, ca = a % 3, ib = b / 3, cb = b % 3;
@@ -245,61 +267,79 @@ __device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* Xw, const double
   }
   EPNP_WAVE_SYNC();
   if (lane == 0) S.stamp[1] = clock64();
-  // ---- eigen-decomposition: parallel-order two-sided Jacobi --------------------------------------------------
+  // ---- eigen-decomposition: parallel-order two-sided Jacobi in its SYSTOLIC form (Brent & Luk) -----------------------
+  // The six pairs of a step always sit at the adjacent POSITIONS (0,1) (2,3) ... (10,11); after the rotations the rows
+  // and columns of A and the columns of V are moved by the fixed permutation `epnp_pi` (the circle method's rotation of
+  // the players around position 0), which brings the next step's pairs side by side.  Every LDS address a lane touches
+  // is therefore the same in every step - no index arithmetic inside the loop.
   double trace = 0;
 #pragma unroll
   for (int i = 0; i < 12; ++i) trace += S.A[13 * i];
   const double tau = 1e-15 * trace;
-  int ei[3], ej[3];
-#pragma unroll
-  for (int u = 0; u < 3; ++u) { const int e = min(lane + 64 * u, 143); ei[u] = e / 12; ej[u] = e % 12; }
+  // work split of a step: lane b < 36 owns the 2 x 2 block (gi, gj) = (b / 6, b % 6) of A - the four entries two rotations
+  // mix among themselves; task t < 72 = (row k, pair gj) = (t / 6, t % 6) owns the two entries of row k of V that pair gj's
+  // rotation mixes (lane t, and lanes 0..7 a second task 64 + t).  Operands are adjacent in memory: 16-byte LDS accesses.
+  typedef double epnp_d2 __attribute__((ext_vector_type(2)));
+  const int gi = min(lane, 35) / 6, gj = min(lane, 35) % 6;
+  const int pi0 = epnp_pi(2 * gi), pi1 = epnp_pi(2 * gi + 1), pj0 = epnp_pi(2 * gj), pj1 = epnp_pi(2 * gj + 1);
+  const int vk0 = lane / 6, vg0 = lane % 6, vk1 = (64 + min(lane, 7)) / 6, vg1 = (64 + min(lane, 7)) % 6;
+  const int v0a = 12 * vk0 + epnp_pi(2 * vg0), v0b = 12 * vk0 + epnp_pi(2 * vg0 + 1);
+  const int v1a = 12 * vk1 + epnp_pi(2 * vg1), v1b = 12 * vk1 + epnp_pi(2 * vg1 + 1);
   for (int sweep = 0; sweep < 14; ++sweep) {
     double maxoff = 0;
     for (int r = 0; r < 11; ++r) {
       if (lane < 6) {
-        const int a = lane == 0 ? 11 : (r + lane >= 11 ? r + lane - 11 : r + lane);
-        const int b = lane == 0 ? r : (r - lane < 0 ? r - lane + 11 : r - lane);
-        const int p = a < b ? a : b, q = a < b ? b : a;
-        const double apq = S.A[12 * p + q], app = S.A[13 * p], aqq = S.A[13 * q];
+        const int p = 2 * lane, q = p + 1;
+        const epnp_d2 row = *reinterpret_cast<const epnp_d2*>(&S.A[12 * p + p]);   // app, apq
+        const double apq = row.y, app = row.x, aqq = S.A[13 * q];
         double c = 1.0, s = 0.0;
         maxoff = fmax(maxoff, fabs(apq));
         if (fabs(apq) > tau) {
-          // t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), without forming theta
+          // classical Jacobi: t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), c = 1 / sqrt(t^2 + 1),
+          // s = t c.  With d = aqq - app, h = sqrt(d^2 + 4 apq^2), w = |d| + h:  t = sgn(d) 2 apq / w,  w^2 + 4 apq^2 = 2 h w,
+          // so  c = w / sqrt(2 h w),  s = sgn(d) 2 apq / sqrt(2 h w)  - two reciprocal square roots, no division.
           const double d = aqq - app, two = apq + apq;
           const double x = d * d + two * two;
           const double h = x * epnp_rsqrt(x);
-          const double t = (d >= 0 ? two : -two) * epnp_rcp(fabs(d) + h);
-          c = epnp_rsqrt(t * t + 1.0);
-          s = t * c;
+          const double w = fabs(d) + h;
+          const double q2 = epnp_rsqrt((h + h) * w);
+          c = w * q2;
+          s = (d >= 0 ? two : -two) * q2;
         }
         // column p' = c col_p - s col_q ; column q' = s col_p + c col_q
-        S.rc[p] = c; S.rs[p] = -s; S.rc[q] = c; S.rs[q] = s;
+        epnp_d2 o; o.x = c; o.y = s;
+        *reinterpret_cast<epnp_d2*>(S.cs[lane]) = o;
       }
       EPNP_WAVE_SYNC();
-      double na[3], nv[3];
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        const int i = ei[u], j = ej[u], yi = epnp_partner(i, r), yj = epnp_partner(j, r);
-        // every operand's address is known up front: one LDS round trip for all ten
-        const double ci = S.rc[i], si = S.rs[i], cj = S.rc[j], sj = S.rs[j];
-        const double a_ij = S.A[12 * i + j], a_yj = S.A[12 * yi + j], a_iy = S.A[12 * i + yj], a_yy = S.A[12 * yi + yj];
-        const double v_ij = S.V[12 * i + j], v_iy = S.V[12 * i + yj];
-        na[u] = ci * (a_ij * cj + a_iy * sj) + si * (a_yj * cj + a_yy * sj);
-        if (yi == j) na[u] = 0.0;       // the rotated pair's own off-diagonal entry
-        nv[u] = v_ij * cj + v_iy * sj;
+      // every operand address is fixed: all loads of the step in one round trip
+      const epnp_d2 ci = *reinterpret_cast<const epnp_d2*>(S.cs[gi]), cj = *reinterpret_cast<const epnp_d2*>(S.cs[gj]);
+      const epnp_d2 a0 = *reinterpret_cast<const epnp_d2*>(&S.A[12 * (2 * gi) + 2 * gj]);
+      const epnp_d2 a1 = *reinterpret_cast<const epnp_d2*>(&S.A[12 * (2 * gi + 1) + 2 * gj]);
+      const epnp_d2 cv0 = *reinterpret_cast<const epnp_d2*>(S.cs[vg0]), cv1 = *reinterpret_cast<const epnp_d2*>(S.cs[vg1]);
+      const epnp_d2 w0 = *reinterpret_cast<const epnp_d2*>(&S.V[12 * vk0 + 2 * vg0]);
+      const epnp_d2 w1 = *reinterpret_cast<const epnp_d2*>(&S.V[12 * vk1 + 2 * vg1]);
+      // B = A_blk J_j, A' = J_i^T B
+      const double b00 = a0.x * cj.x - a0.y * cj.y, b01 = a0.x * cj.y + a0.y * cj.x;
+      const double b10 = a1.x * cj.x - a1.y * cj.y, b11 = a1.x * cj.y + a1.y * cj.x;
+      double n00 = ci.x * b00 - ci.y * b10, n01 = ci.x * b01 - ci.y * b11;
+      double n10 = ci.y * b00 + ci.x * b10, n11 = ci.y * b01 + ci.x * b11;
+      if (gi == gj) { n01 = 0.0; n10 = 0.0; }      // the rotated pair's own off-diagonal entry
+      const double x0a = w0.x * cv0.x - w0.y * cv0.y, x0b = w0.x * cv0.y + w0.y * cv0.x;
+      const double x1a = w1.x * cv1.x - w1.y * cv1.y, x1b = w1.x * cv1.y + w1.y * cv1.x;
+      __builtin_amdgcn_wave_barrier();   // all reads above are issued before any write below (one wave, in-order LDS)
+      if (lane < 36) {
+        S.A[12 * pi0 + pj0] = n00; S.A[12 * pi0 + pj1] = n01;
+        S.A[12 * pi1 + pj0] = n10; S.A[12 * pi1 + pj1] = n11;
       }
-      EPNP_WAVE_SYNC();
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        const int e = lane + 64 * u;
-        if (e < 144) { S.A[e] = na[u]; S.V[e] = nv[u]; }
-      }
+      S.V[v0a] = x0a; S.V[v0b] = x0b;
+      if (lane < 8) { S.V[v1a] = x1a; S.V[v1b] = x1b; }
       EPNP_WAVE_SYNC();
     }
     if (lane == 0) S.sweeps = sweep + 1;
-    // quadratic convergence: once a sweep met no off-diagonal entry above 1e-9 * trace, what it leaves behind is below
-    // rounding - no confirming sweep needed
-    const uint64_t big = __ballot(lane < 6 && maxoff > 1e-9 * trace);
+    // quadratic convergence: once a sweep met no off-diagonal entry above 1e-7 * trace, what it leaves behind is of the
+    // order of 1e-14 * trace - below what the eigenvectors of the well separated small eigenvalues can resolve; no
+    // confirming sweep needed
+    const uint64_t big = __ballot(lane < 6 && maxoff > 1e-7 * trace);
     if (big == 0) break;
   }
   if (lane == 0) S.stamp[2] = clock64();
@@ -322,8 +362,6 @@ __device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* Xw, const double
     for (int j = 0; j < 12; ++j) src = S.order[j] == which ? j : src;
     S.v4[which][col] = S.V[12 * col + src];
   }
-  if (lane < 12) { S.cws[lane / 3][lane % 3] = cw[lane / 3][lane % 3]; }
-  if (lane < 20) S.alphas[lane] = alphas[lane];
   EPNP_WAVE_SYNC();
   // ---- compute_L_6x10 (lanes 0..59) and compute_rho -------------------------------------------------------------
   if (lane < 60) {
@@ -331,8 +369,7 @@ __device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* Xw, const double
     // pair i of the control points: (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
     const int pa = i < 3 ? 0 : (i < 5 ? 1 : 2), pb = i < 3 ? i + 1 : (i < 5 ? i - 1 : 3);
     // column c <-> (x, y) of betas10 = [B11 B12 B22 B13 B23 B33 B14 B24 B34 B44]
-    const int cx[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3}, cy[10] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3};
-    const int x = cx[c], y = cy[c];
+    const int y = c >= 6 ? 3 : (c >= 3 ? 2 : (c >= 1 ? 1 : 0)), x = c - y * (y + 1) / 2;
     double dx[3], dy[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -343,7 +380,7 @@ __device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* Xw, const double
   }
   if (lane < 6) {
     const int pa = lane < 3 ? 0 : (lane < 5 ? 1 : 2), pb = lane < 3 ? lane + 1 : (lane < 5 ? lane - 1 : 3);
-    const double d[3] = {cw[pa][0] - cw[pb][0], cw[pa][1] - cw[pb][1], cw[pa][2] - cw[pb][2]};
+    const double d[3] = {S.cws[pa][0] - S.cws[pb][0], S.cws[pa][1] - S.cws[pb][1], S.cws[pa][2] - S.cws[pb][2]};
     S.rho[lane] = epnp_dot3(d, d);
   }
   EPNP_WAVE_SYNC();

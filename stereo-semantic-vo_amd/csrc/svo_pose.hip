@@ -80,10 +80,10 @@ __global__ __launch_bounds__(256) void k_pnp_select(const double* __restrict__ X
 // parity probe: one EPnP on five correspondences, one wave
 __global__ __launch_bounds__(64) void k_epnp5_probe(const double* X5, const double* u5, const double* Kp, double* Rt) {
   __shared__ EpnpWaveLds ws;
-  double X[15], u[10], K[4] = {Kp[0], Kp[1], Kp[2], Kp[3]}, R[9], t[3];
-  for (int i = 0; i < 15; ++i) X[i] = X5[i];
-  for (int i = 0; i < 10; ++i) u[i] = u5[i];
-  const bool ok = epnp5_wave(ws, X, u, K, R, t);
+  double K[4] = {Kp[0], Kp[1], Kp[2], Kp[3]}, R[9], t[3];
+  if (threadIdx.x < 15) ws.x5[threadIdx.x] = X5[threadIdx.x];
+  if (threadIdx.x < 10) ws.u5[threadIdx.x] = u5[threadIdx.x];
+  const bool ok = epnp5_wave(ws, K, R, t);
   if (threadIdx.x == 0) {
     for (int i = 0; i < 9; ++i) Rt[i] = R[i];
     Rt[9] = t[0]; Rt[10] = t[1]; Rt[11] = t[2]; Rt[12] = ok ? 1.0 : 0.0;

@@ -528,15 +528,13 @@ __device__ __forceinline__ void pnp_hyp_block(EpnpWaveLds* ws, const double* Xw,
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int k = hyp_base + wv;
   if (k >= PNP_HYP) return;
-  double X5[15], u5[10];
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int e = min((int)subset[5 * k + i], n - 1);
-    X5[3 * i] = Xw[3 * e]; X5[3 * i + 1] = Xw[3 * e + 1]; X5[3 * i + 2] = Xw[3 * e + 2];
-    u5[2 * i] = uv[2 * e]; u5[2 * i + 1] = uv[2 * e + 1];
+  if (lane < 5) {   // the sample's five correspondences into the wave's workspace
+    const int e = min((int)subset[5 * k + lane], n - 1);
+    ws[wv].x5[3 * lane] = Xw[3 * e]; ws[wv].x5[3 * lane + 1] = Xw[3 * e + 1]; ws[wv].x5[3 * lane + 2] = Xw[3 * e + 2];
+    ws[wv].u5[2 * lane] = uv[2 * e]; ws[wv].u5[2 * lane + 1] = uv[2 * e + 1];
   }
   double R[9], t[3];
-  const bool ok = epnp5_wave(ws[wv], X5, u5, K, R, t);
+  const bool ok = epnp5_wave(ws[wv], K, R, t);
   int cnt = 0;
   if (ok)
     for (int e = lane; e < n; e += 64) cnt += pnp_inlier(R, t, Xw + 3 * e, uv + 2 * e, K) ? 1 : 0;

@@ -91,6 +91,7 @@ struct TrackState {
   svo_lm_stats lm;
   svo_pnp_stats pnp;
   PnpHyp hyp[PNP_HYP];                 // the frame's RANSAC samples (k_tp_hyp)
+  long long pose_ts[16];               // diagnostics: s_memtime stamps of k_tp_hyp (0..7) and k_tp_frame (8..15)
   // ---- large arrays (not cleared by a reset) -----------------------------------------------
   TrackPool pool[2];
   uint16_t rowmin[TRK_CAP];                // min over ALL current keypoints of the row's distances
@@ -705,6 +706,7 @@ __global__ __launch_bounds__(256) void k_tp_hyp(TrackState* st, const TrackWork*
                                                 int kstride) {
   TpHypLds& S = *reinterpret_cast<TpHypLds*>(tk_smem);
   st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
+  const long long t_start = clock64();
   const int n = work->n_edges;
   if (work->skip_match || n < 5) return;
   const float* gpos = st->gpos;
@@ -716,7 +718,12 @@ __global__ __launch_bounds__(256) void k_tp_hyp(TrackState* st, const TrackWork*
   }
   __syncthreads();
   const double K[4] = {(double)st->cam.fx, (double)st->cam.fy, (double)st->cam.cx, (double)st->cam.cy};
+  const long long t_gather = clock64();
   pnp_hyp_block(S.ws, S.Xw, S.uv, n, K, subsets + (size_t)min(n, 512) * 500, st->hyp, blockIdx.x * 4);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->pose_ts[0] = t_start; st->pose_ts[1] = t_gather; st->pose_ts[2] = S.ws[0].stamp[0]; st->pose_ts[3] = S.ws[0].stamp[4];
+    st->pose_ts[4] = clock64();
+  }
 }
 
 // k_tp_frame: RANSAC's acceptance rule over the samples, Optimizer::PoseOptimization, SetPose, the positions of the
@@ -735,6 +742,7 @@ __global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, const TrackWor
   st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
   depth += (size_t)blockIdx.y * kstride; res_out += blockIdx.y;
   const int tid = threadIdx.x;
+  const long long tf0 = clock64();
   const int id = work->frame_id, nkp = work->nkp, skip = work->skip_match, n_edges = work->n_edges;
   float* gpos = st->gpos;
   // ---- 3D-2D correspondences, ordered by keypoint index (src/pnpmatch.cc:216-224) ---------------
@@ -778,9 +786,11 @@ __global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, const TrackWor
     st->pnp.ok = S.best >= 0 ? 1 : 0; st->pnp.iterations = S.iters;
   }
   __syncthreads();
+  const long long tf1 = clock64();
   // ---- Optimizer::PoseOptimization (src/Optimizer.cc:15-86) from the CV_32F-stored PnP pose ----------------------
   pose_opt_block(S.pose, st->Xw, st->obs, n_edges, st->K, st->T, &st->lm, 1, use_mfma);
   __syncthreads();
+  const long long tf2 = clock64();
   // ---- SetPose (CV_32F, src/Optimizer.cc:82-83), positions of the points created this frame -------
   if (tid < 16) S.sT[tid] = (float)st->T[tid];
   __syncthreads();
@@ -814,6 +824,7 @@ __global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, const TrackWor
     r.reserved[0] = work->diag[0];   // diagnostics: rows of pass 1 | rounds << 16; [1]: rows of pass 2 | rounds << 16
     r.reserved[1] = work->diag[1];
     *res_out = r;
+    st->pose_ts[8] = tf0; st->pose_ts[9] = tf1; st->pose_ts[10] = tf2; st->pose_ts[11] = clock64();
   }
 }
 
@@ -877,10 +888,14 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
   const uint32_t* desc = reinterpret_cast<const uint32_t*>(desc8);
   SVO_HIP(ctx, hipEventRecord(ctx->ev_frontend, s0));            // keypoints, descriptors, depths are ready ...
   SVO_HIP(ctx, hipStreamWaitEvent(s1, ctx->ev_frontend, 0));    // ... and the previous call's pose chain has read its records
+  // per-kernel HIP-event timing (svo_profile_enable) costs ~2.5 us per event pair on the host - more than a tail kernel's
+  // launch; the tail is therefore SAMPLED: every 8th frame of a call is timed, the others run untimed
+  const bool prof = ctx->profiling;
   for (int f = 0; f < frames; ++f) {
     const svo_kp* kpf = kp + (size_t)f * kstride;
     const uint32_t* descf = desc + (size_t)f * kstride * 8;
     const float* depf = depth + (size_t)f * kstride;
+    ctx->profiling = prof && (f % 8 == 0 || frames < 8);
     {
       SvoTimer t(ctx, "k_ti_lists", s1);
       if (ny >= 8) hipLaunchKernelGGL(k_ti_lists<16>, dim3(TRK_ROWS_MAX / 16, ny), dim3(256), 0, s1, st, descf, nkp + f, kstride, ctx->opt_track_lcap, ctx->opt_track_nblk);
@@ -890,8 +905,8 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
       SvoTimer t(ctx, "k_ti_resolve", s1);
       hipLaunchKernelGGL(k_ti_resolve, dim3(1, ny), dim3(1024), sizeof(TiLds), s1, st, work + f, kpf, descf, nkp + f, depf, kstride);
     }
-    SVO_HIP(ctx, hipEventRecord(ctx->ev_frame[f], s1));
-    SVO_HIP(ctx, hipStreamWaitEvent(s0, ctx->ev_frame[f], 0));
+    hipEventRecord(ctx->ev_frame[f], s1);
+    hipStreamWaitEvent(s0, ctx->ev_frame[f], 0);
     {
       SvoTimer t(ctx, "k_tp_hyp");
       hipLaunchKernelGGL(k_tp_hyp, dim3(PNP_HYP / 4, ny), dim3(256), sizeof(TpHypLds), s0, st, work + f, kpf, ctx->d_pnp_subsets, kstride);
@@ -902,6 +917,7 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
                          ctx->opt_pose_mfma);
     }
   }
+  ctx->profiling = prof;
   SVO_HIP(ctx, hipGetLastError());
   return SVO_OK;
 }
@@ -1308,5 +1324,16 @@ extern "C" int svo_debug_track_pnp(svo_ctx* ctx, svo_pnp_stats* stats, double T_
     for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T_pnp[4 * r + c] = h.R[3 * r + c]; T_pnp[4 * r + 3] = h.t[r]; }
     T_pnp[12] = 0; T_pnp[13] = 0; T_pnp[14] = 0; T_pnp[15] = 1;
   }
+  return SVO_OK;
+}
+
+// Diagnostics: s_memtime stamps of the pose chain for the frame just tracked: [0] k_tp_hyp start, [1] correspondences
+// gathered, [2] EPnP start, [3] EPnP done, [4] consensus counted; [8] k_tp_frame start, [9] RANSAC rule applied,
+// [10] PoseOptimization done, [11] record written.
+extern "C" int svo_debug_track_pose_stamps(svo_ctx* ctx, int64_t ts[16]) {
+  if (!ctx || !ts || !ctx->d_track) return SVO_E_INVALID;
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
+  SVO_HIP(ctx, hipMemcpy(ts, st->pose_ts, sizeof(long long) * 16, hipMemcpyDeviceToHost));
   return SVO_OK;
 }

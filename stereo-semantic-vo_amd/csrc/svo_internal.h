@@ -96,6 +96,8 @@ struct svo_ctx {
   void* d_work = nullptr;       // TrackWork records (index chain -> pose chain), work_cap of them
   int work_cap = 0;
   hipStream_t stream_idx = nullptr;        // the pose-free index chain of the tracking tail runs here, ahead of the pose chain
+  hipStream_t stream_fe = nullptr;         // svo_track_batch_dev: the front end of later sub-batches runs here, beside the tail
+  std::vector<hipEvent_t> ev_sub;          // front end of sub-batch j finished (recorded on `stream_fe`)
   hipEvent_t ev_frontend = nullptr;        // front end of a call finished (recorded on `stream`)
   std::vector<hipEvent_t> ev_frame;        // index chain of frame f finished (recorded on `stream_idx`)
   uint16_t* d_pnp_subsets = nullptr;   // [513][100][5]: RANSAC sample indices of cv::RNG((uint64)-1) for every point count

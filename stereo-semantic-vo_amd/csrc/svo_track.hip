@@ -841,6 +841,9 @@ void svo_track_release(svo_ctx* ctx) {
   ctx->ev_frame.clear();
   if (ctx->ev_frontend) { hipEventDestroy(ctx->ev_frontend); ctx->ev_frontend = nullptr; }
   if (ctx->stream_idx) { hipStreamDestroy(ctx->stream_idx); ctx->stream_idx = nullptr; }
+  for (hipEvent_t e : ctx->ev_sub) hipEventDestroy(e);
+  ctx->ev_sub.clear();
+  if (ctx->stream_fe) { hipStreamDestroy(ctx->stream_fe); ctx->stream_fe = nullptr; }
 }
 
 // streams, events, work records and the kernels' LDS opt-ins for `frames` frames per call of `nseq` sequences
@@ -877,8 +880,10 @@ static int track_resources(svo_ctx* ctx, int frames, int nseq) {
 //   nseq == 1: `frames` consecutive frames of the one sequence, record f into d_res[f];
 //   nseq  > 1: one frame of each of nseq sequences (frames == 1), sequence q from frame slot q into d_res[q].
 // The index chain is enqueued on ctx->stream_idx and runs ahead; the pose chain follows on ctx->stream.
+// `fe_events` (may be null): fe_events[f] != nullptr is an event the index chain must wait for before frame f (its front-end
+// results are produced on another stream, in sub-batches).
 static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, const int32_t* nkp, const float* depth,
-                        int kstride, int frames, int nseq, svo_track_result* d_res) {
+                        int kstride, int frames, int nseq, svo_track_result* d_res, const hipEvent_t* fe_events = nullptr) {
   int rc = track_resources(ctx, frames, nseq);
   if (rc) return rc;
   TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
@@ -896,6 +901,7 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
     const uint32_t* descf = desc + (size_t)f * kstride * 8;
     const float* depf = depth + (size_t)f * kstride;
     ctx->profiling = prof && (f % 8 == 0 || frames < 8);
+    if (fe_events && fe_events[f]) hipStreamWaitEvent(s1, fe_events[f], 0);
     {
       SvoTimer t(ctx, "k_ti_lists", s1);
       if (ny >= 8) hipLaunchKernelGGL(k_ti_lists<16>, dim3(TRK_ROWS_MAX / 16, ny), dim3(256), 0, s1, st, descf, nkp + f, kstride, ctx->opt_track_lcap, ctx->opt_track_nblk);
@@ -1138,8 +1144,43 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
     hipLaunchKernelGGL(k_tk_dense_depth, dim3((ctx->max_kp + 255) / 256, B), dim3(256), 0, ctx->stream, ctx->d_kp, ctx->d_nkp,
                        ctx->d_dense, ctx->g.W, ctx->cam.bf, ctx->d_uR, ctx->d_depth, ctx->max_kp, n, (const int32_t*)nullptr);
   } else {
-    if ((rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, B, 2 * B))) return rc;
-    if ((rc = svo_launch_stereo(ctx, d_grayL, d_grayR, stride, B, &ctx->cam))) return rc;
+    // The front end runs in sub-batches on its own stream, so that only the first sub-batch stands in front of the
+    // ordered tail: while the tail works through sub-batch j, the front end of j + 1 runs beside it.  Sub-batch j writes the
+    // keypoints of its LEFT images to frame slots f0 .. f0 + b - 1 (what the tail reads); its right images use the slots
+    // behind them, which the next sub-batch's left images overwrite later on the same stream.
+    rc = track_resources(ctx, B, 1);
+    if (rc) return rc;
+    const int SUB = 32, nsub = (B + SUB - 1) / SUB;
+    if (!ctx->stream_fe) SVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_fe, hipStreamNonBlocking));
+    while ((int)ctx->ev_sub.size() < nsub) {
+      hipEvent_t e;
+      SVO_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      ctx->ev_sub.push_back(e);
+    }
+    // everything enqueued on the ctx stream so far - the previous call's pose chain included - comes first
+    SVO_HIP(ctx, hipEventRecord(ctx->ev_frontend, ctx->stream));
+    SVO_HIP(ctx, hipStreamWaitEvent(ctx->stream_fe, ctx->ev_frontend, 0));
+    std::vector<hipEvent_t> wait(B, nullptr);
+    svo_kp* kp0 = ctx->d_kp; uint8_t* desc0 = ctx->d_desc; int32_t* nkp0 = ctx->d_nkp;
+    float* uR0 = ctx->d_uR; float* depth0 = ctx->d_depth; int32_t* sad0 = ctx->d_sad;
+    hipStream_t s_main = ctx->stream;
+    const size_t K = ctx->max_kp, img = (size_t)ctx->g.H * stride;
+    ctx->stream = ctx->stream_fe;
+    for (int j = 0; j < nsub && rc == SVO_OK; ++j) {
+      const int f0 = j * SUB, b = std::min(SUB, B - f0);
+      ctx->d_kp = kp0 + f0 * K; ctx->d_desc = desc0 + f0 * K * 32; ctx->d_nkp = nkp0 + f0;
+      ctx->d_uR = uR0 + f0 * K; ctx->d_depth = depth0 + f0 * K; ctx->d_sad = sad0 + f0 * K;
+      rc = svo_launch_orb(ctx, d_grayL + f0 * img, d_grayR + f0 * img, stride, b, 2 * b);
+      if (rc == SVO_OK) rc = svo_launch_stereo(ctx, d_grayL + f0 * img, d_grayR + f0 * img, stride, b, &ctx->cam);
+      if (rc == SVO_OK && hipEventRecord(ctx->ev_sub[j], ctx->stream_fe) != hipSuccess) rc = SVO_E_HIP;
+      wait[f0] = ctx->ev_sub[j];
+    }
+    ctx->stream = s_main;
+    ctx->d_kp = kp0; ctx->d_desc = desc0; ctx->d_nkp = nkp0; ctx->d_uR = uR0; ctx->d_depth = depth0; ctx->d_sad = sad0;
+    if (rc) return rc;
+    if ((rc = tail_enqueue(ctx, ctx->d_kp, ctx->d_desc, ctx->d_nkp, ctx->d_depth, ctx->max_kp, B, 1, d_results, wait.data()))) return rc;
+    ctx->track_frame += B;
+    return SVO_OK;
   }
   if ((rc = tail_enqueue(ctx, ctx->d_kp, ctx->d_desc, ctx->d_nkp, ctx->d_depth, ctx->max_kp, B, 1, d_results))) return rc;
   ctx->track_frame += B;

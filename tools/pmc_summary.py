@@ -15,7 +15,10 @@ def main(dirs, out):
             with open(path) as f:
                 for row in csv.DictReader(f):
                     name = row["Kernel_Name"].split("(")[0]
-                    if not (name.startswith("k_") or name.startswith("void k_")):
+                    if name.startswith("void "):
+                        name = name[5:]
+                    name = name.split("<")[0]          # template instances of one kernel under its name
+                    if not name.startswith("k_"):
                         continue
                     c = agg[name][row["Counter_Name"]]
                     c[0] += float(row["Counter_Value"])

@@ -590,8 +590,57 @@ static int msa_solve_device(svo_ctx* ctx, hipStream_t s, DevBuf& buf, uint8_t* c
     return SVO_OK;
   };
   int rc;
-  if ((rc = aggregate(1, cost[1], Exp[0], d_disp[1]))) return rc;   // right image as base image
-  if ((rc = aggregate(0, cost[0], Exp[0], d_disp[0]))) return rc;   // left image as base image
+  // The first two aggregations (right image as base image, left image as base image) are independent until the L/R
+  // check: their level sweeps - two chains of ~2 x 1000 small dependent launches - run side by side on two streams, with
+  // their own work volumes, instead of one after the other.
+  {
+    float* d_up1 = buf.get<float>(V); float* d_A1 = buf.get<float>(V); uint8_t* d_raw1 = buf.get<uint8_t>(N);
+    if (!d_up1 || !d_A1 || !d_raw1) { ctx->last_error = "svo_msa_solve: hipMalloc"; return SVO_E_NOMEM; }
+    if (!ctx->stream_fe) SVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_fe, hipStreamNonBlocking));
+    hipStream_t s2 = ctx->stream_fe;
+    hipEvent_t e0, e1;
+    SVO_HIP(ctx, hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+    SVO_HIP(ctx, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+    SVO_HIP(ctx, hipMemcpyAsync(d_Exp, Exp[0], 256 * sizeof(double), hipMemcpyHostToDevice, s));
+    SVO_HIP(ctx, hipMemcpyAsync(d_up, cost[0], V * sizeof(float), hipMemcpyDeviceToDevice, s));
+    SVO_HIP(ctx, hipEventRecord(e0, s));
+    SVO_HIP(ctx, hipStreamWaitEvent(s2, e0, 0));
+    SVO_HIP(ctx, hipMemcpyAsync(d_up1, cost[1], V * sizeof(float), hipMemcpyDeviceToDevice, s2));
+    const int lv[2] = {(int)tree[0].level_ptr.size() - 1, (int)tree[1].level_ptr.size() - 1};
+    float* ups[2] = {d_up, d_up1}; float* As[2] = {d_A, d_A1};
+    hipStream_t st2[2] = {s, s2};
+    {
+      SvoTimer tm(ctx, "k_msa_tree_dp");
+      const int lmax = std::max(lv[0], lv[1]);
+      for (int l = lmax - 1; l >= 0; --l)
+        for (int side = 0; side < 2; ++side) {
+          if (l >= lv[side]) continue;
+          const HostTree& t = tree[side];
+          const int cnt = t.level_ptr[l + 1] - t.level_ptr[l];
+          hipLaunchKernelGGL(k_msa_dp_up, dim3((unsigned)(((size_t)cnt * D + 255) / 256)), dim3(256), 0, st2[side],
+                             dt[side].nodes + t.level_ptr[l], cnt, D, dt[side].child_ptr, dt[side].child, dt[side].child_c, d_Exp, ups[side]);
+        }
+      for (int l = 0; l < lmax; ++l)
+        for (int side = 0; side < 2; ++side) {
+          if (l >= lv[side]) continue;
+          const HostTree& t = tree[side];
+          const int cnt = t.level_ptr[l + 1] - t.level_ptr[l];
+          hipLaunchKernelGGL(k_msa_dp_down, dim3((unsigned)(((size_t)cnt * D + 255) / 256)), dim3(256), 0, st2[side],
+                             dt[side].nodes + t.level_ptr[l], cnt, D, dt[side].parent, dt[side].parent_c, d_Exp, ups[side], As[side]);
+        }
+    }
+    {
+      SvoTimer tm(ctx, "k_msa_wta");
+      hipLaunchKernelGGL(k_msa_argmin, dim3(nbN), dim3(256), 0, s2, d_A1, (int)N, D, d_raw1);
+      hipLaunchKernelGGL(k_ctmf<2>, dim3((m + 255) / 256, n), dim3(256), 0, s2, d_raw1, d_disp[1], m, n, m, m, 1);
+      hipLaunchKernelGGL(k_msa_argmin, dim3(nbN), dim3(256), 0, s, d_A, (int)N, D, d_raw);
+      hipLaunchKernelGGL(k_ctmf<2>, dim3((m + 255) / 256, n), dim3(256), 0, s, d_raw, d_disp[0], m, n, m, m, 1);
+    }
+    SVO_HIP(ctx, hipEventRecord(e1, s2));
+    SVO_HIP(ctx, hipStreamWaitEvent(s, e1, 0));
+    hipEventDestroy(e0); hipEventDestroy(e1);   // destruction is deferred until the recorded work has completed
+    (void)rc;
+  }
   {
     SvoTimer tm(ctx, "k_msa_lrcheck");
     hipLaunchKernelGGL(k_msa_lrcheck, dim3(nbV), dim3(256), 0, s, d_disp[0], d_disp[1], n, m, D, cost[0], d_mask);

@@ -561,6 +561,19 @@ __device__ __forceinline__ int pnp_update_iters(double ep, int maxIters) {
   return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)rint(num / denom);
 }
 
+// The iteration bound of RANSACPointSetRegistrator::run after its first m samples: samples at or beyond it can never be
+// visited (the bound only shrinks), so they need not be solved.
+__device__ __forceinline__ int pnp_bound_after(const int* cnt, const int* ok, int n, int m) {
+  int niters = PNP_HYP, maxGood = 0;
+  if (n == 5) return 1;
+  for (int iter = 0; iter < m && iter < niters; ++iter) {
+    if (!ok[iter]) continue;
+    const int g = cnt[iter];
+    if (g > max(maxGood, 4)) { maxGood = g; niters = pnp_update_iters((double)(n - g) / n, niters); }
+  }
+  return niters;
+}
+
 // RANSACPointSetRegistrator::run over the precomputed samples (one thread): sample `iter` replaces the best one iff its
 // consensus is larger (and > 4), and the iteration bound shrinks with the inlier ratio.  Returns the winning sample
 // (-1: none), *good its consensus, *iters the samples visited.

@@ -719,14 +719,15 @@ extern "C" int svo_debug_epnp5(svo_ctx* ctx, const double Xw5[15], const double 
   double* dO = bm.take<double>(24);
   if (!bm.ok()) return SVO_E_CAPACITY;
   H2D(dX, Xw5, 120); H2D(dU, uv5, 80); H2D(dK, K, 32);
-  int rc = svo_launch_epnp5_probe(ctx, dX, dU, dK, dO);
+  const char* reps_env = getenv("SVO_EPNP_REPS");   // diagnostics: repeat inside the kernel, stamps of the last pass
+  int rc = svo_launch_epnp5_probe(ctx, dX, dU, dK, dO, reps_env ? atoi(reps_env) : 1);
   if (rc) return rc;
   double o[24];
   D2H(o, dO, sizeof o);
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   memcpy(R, o, 72); memcpy(t, o + 9, 24);
   if (rep_err) memcpy(rep_err, o + 13, 24);
-  if (getenv("SVO_EPNP_STAMPS")) fprintf(stderr, "epnp5 cycles: setup+MtM %.0f, eigen %.0f (%d sweeps), L/rho %.0f, branches %.0f\n", o[16], o[17], (int)o[20], o[18], o[19]);
+  if (getenv("SVO_EPNP_STAMPS")) fprintf(stderr, "epnp5 cycles: setup+MtM %.0f, eigen %.0f (%d sweeps), L/rho %.0f, branches %.0f (initial betas %.0f, Gauss-Newton %.0f, to the last SVD %.0f)\n", o[16], o[17], (int)o[20], o[18], o[19], o[21], o[22], o[23]);
   return o[12] != 0.0 ? SVO_OK : SVO_E_INVALID;
 }
 

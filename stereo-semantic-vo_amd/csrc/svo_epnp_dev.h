@@ -18,6 +18,8 @@
 //   * the small linear least-squares problems (cvSolve(..., CV_SVD) on 6x3 / 6x4 / 6x5, epnp::qr_solve on 6x4) are
 //     solved through their normal equations with a pivoted Gauss-Jordan - same solutions for the full-rank systems
 //     EPnP produces, far fewer dependent operations than a Jacobi SVD.
+// Multiply-adds are contracted to FMAs in this file (the rest of the library is built with -ffp-contract=off): half the
+// dependent instructions of the scalar stages, and nothing downstream depends on the rounding of a RANSAC sample's pose.
 // A CPU restatement that follows OpenCV's own loops is kept with the tests; the two are compared to a stated tolerance.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -48,11 +50,13 @@ struct EpnpWaveLds {
 // Newton step - a handful of dependent instructions instead of the IEEE sqrt / division sequences.  The Jacobi
 // rotations only need c^2 + s^2 = 1 to rounding.
 __device__ __forceinline__ double epnp_rsqrt(double x) {
+#pragma clang fp contract(fast)
   double y = __builtin_amdgcn_rsq(x);
   y = y * (1.5 - (0.5 * x) * y * y);
   return y;
 }
 __device__ __forceinline__ double epnp_rcp(double x) {
+#pragma clang fp contract(fast)
   double r = __builtin_amdgcn_rcp(x);
   r = r * (2.0 - x * r);
   return r;
@@ -78,6 +82,7 @@ __device__ __forceinline__ void epnp_pair(int r, int g, int& p, int& q) {
 // cyclic one-sided Jacobi SVD of a 3x3 (rows of At = columns of A), as OpenCV's SVD::compute on a 3x3: w descending,
 // Ut rows = left, Vt rows = right singular vectors.  Scalar code (one lane).
 __device__ inline void epnp_svd3(const double* A, double* w, double* Ut, double* Vt) {
+#pragma clang fp contract(fast)
   double At[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, W[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -145,6 +150,7 @@ __device__ inline void epnp_svd3(const double* A, double* w, double* Ut, double*
 // loses the comparison of reprojection errors)
 template <int NC>
 __device__ inline void epnp_lsq6(const double* A /*6 x NC row-major*/, const double* b, double* x) {
+#pragma clang fp contract(fast)
   double N[NC][NC], y[NC], Lm[NC][NC], D[NC];
 #pragma unroll
   for (int r = 0; r < NC; ++r) {
@@ -197,11 +203,14 @@ __device__ inline void epnp_lsq6(const double* A /*6 x NC row-major*/, const dou
   for (int r = 0; r < NC; ++r) x[r] = y[r];
 }
 
-__device__ __forceinline__ double epnp_dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ double epnp_dot3(const double* a, const double* b) { 
+#pragma clang fp contract(fast)
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 
 // One hypothesis.  Called by all 64 lanes of a wave; the result (R row-major, t) is returned in every lane.  The sample
 // is expected in S.x5 (5 x 3) / S.u5 (5 x 2) (doubles holding float values); K = {fu, fv, uc, vc}.
 __device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* K, double* R_out, double* t_out) {
+#pragma clang fp contract(fast)
   const int lane = threadIdx.x & 63;
   // the sample lives in LDS, S.x5 / S.u5, filled by the caller (uniform reads broadcast): keeps ~50 registers free
   // across the eigen-solver
@@ -420,6 +429,7 @@ __device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* K, double* R_out
       betas[2] = b5[3] / betas[0];
       betas[3] = 0.0;
     }
+    if (lane == 0) S.stamp[5] = clock64();
     // gauss_newton: five steps on the six distance constraints
     for (int it = 0; it < 5; ++it) {
       double A[24], b[6], x[4];
@@ -439,6 +449,7 @@ __device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* K, double* R_out
 #pragma unroll
       for (int i = 0; i < 4; ++i) betas[i] += x[i];
     }
+    if (lane == 0) S.stamp[6] = clock64();
     // compute_R_and_t: control points in the camera frame, the five points, sign, absolute orientation
     double ccs[4][3], pcs[15];
 #pragma unroll
@@ -470,6 +481,7 @@ __device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* K, double* R_out
 #pragma unroll
         for (int k = 0; k < 3; ++k) abt[3 * j + k] += (pcs[3 * i + j] - pc0[j]) * (Xw[3 * i + k] - pw0[k]);
     double d3[3], Ut[9], Vt[9], R[9];
+    if (lane == 0) S.stamp[7] = clock64();
     epnp_svd3(abt, d3, Ut, Vt);
 #pragma unroll
     for (int i = 0; i < 3; ++i)

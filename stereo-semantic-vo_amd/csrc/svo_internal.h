@@ -159,7 +159,7 @@ int svo_launch_pnp(svo_ctx* ctx, const double* Xw, const double* obs, int n, con
                    const double* Tfallback, const uint16_t* subset, void* hyp, double* T, uint8_t* mask,
                    svo_pnp_stats* stats);
 size_t svo_pnp_hyp_bytes();
-int svo_launch_epnp5_probe(svo_ctx* ctx, const double* X5, const double* u5, const double* K, double* Rt);
+int svo_launch_epnp5_probe(svo_ctx* ctx, const double* X5, const double* u5, const double* K, double* Rt, int reps);
 void svo_pnp_subsets(uint64_t state, int n, uint16_t* out /*[100 * 5]*/);
 int svo_pose_lds_optin(svo_ctx* ctx);   // dynamic-LDS opt-in of the pose kernels (PoseLds > 64 KB)
 template <typename T>

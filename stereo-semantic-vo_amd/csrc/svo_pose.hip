@@ -23,7 +23,9 @@ __global__ __launch_bounds__(256) void k_pose_opt(const double* __restrict__ Xw,
 }
 
 // ---- cv::solvePnPRansac on plain arrays (svo_pnp_ransac) --------------------------------------------------------
-// k_pnp_hyp: 25 workgroups x 4 waves = the 100 RANSAC samples, one EPnP per wave, each with its consensus.
+// k_pnp_hyp: the 100 RANSAC samples, one EPnP per wave, each with its consensus.  ONE wave per workgroup, i.e. one per
+// compute unit: the float64 pipeline is shared by the four SIMDs of a CU (measured: the scalar float64 stage of the solve
+// takes 18 k cycles with one wave on the CU, 50 k with four), and with 256 CUs there is no reason to share it.
 // k_pnp_select: the sequential acceptance rule over those samples, the winner's pose, inlier mask and stats.
 struct PnpHypLds {
   double Xw[PNP_MAXN * 3], uv[PNP_MAXN * 2];
@@ -34,11 +36,11 @@ __global__ __launch_bounds__(256) void k_pnp_hyp(const double* __restrict__ Xw, 
                                                  const double* __restrict__ Kp, const uint16_t* __restrict__ subset,
                                                  PnpHyp* hyp) {
   PnpHypLds& L = *reinterpret_cast<PnpHypLds*>(pose_smem);
-  for (int i = threadIdx.x; i < 3 * n; i += 256) L.Xw[i] = Xw[i];
-  for (int i = threadIdx.x; i < 2 * n; i += 256) L.uv[i] = obs[i];
+  for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) L.Xw[i] = Xw[i];
+  for (int i = threadIdx.x; i < 2 * n; i += blockDim.x) L.uv[i] = obs[i];
   __syncthreads();
   const double K[4] = {Kp[0], Kp[1], Kp[2], Kp[3]};
-  pnp_hyp_block(L.ws, L.Xw, L.uv, n, K, subset, hyp, blockIdx.x * 4);
+  pnp_hyp_block(L.ws, L.Xw, L.uv, n, K, subset, hyp, blockIdx.x * (blockDim.x >> 6));
 }
 
 __global__ __launch_bounds__(256) void k_pnp_select(const double* __restrict__ Xw, const double* __restrict__ obs, int n,
@@ -77,23 +79,31 @@ __global__ __launch_bounds__(256) void k_pnp_select(const double* __restrict__ X
   }
 }
 
-// parity probe: one EPnP on five correspondences, one wave
-__global__ __launch_bounds__(64) void k_epnp5_probe(const double* X5, const double* u5, const double* Kp, double* Rt) {
-  __shared__ EpnpWaveLds ws;
+// parity probe: one EPnP on five correspondences, one wave (timing experiments: `waves` waves solve the same sample side
+// by side, `reps` times each; wave 0 reports)
+__global__ __launch_bounds__(256) void k_epnp5_probe(const double* X5, const double* u5, const double* Kp, double* Rt, int reps) {
+  __shared__ EpnpWaveLds wsv[4];
+  EpnpWaveLds& ws = wsv[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63;
   double K[4] = {Kp[0], Kp[1], Kp[2], Kp[3]}, R[9], t[3];
-  if (threadIdx.x < 15) ws.x5[threadIdx.x] = X5[threadIdx.x];
-  if (threadIdx.x < 10) ws.u5[threadIdx.x] = u5[threadIdx.x];
-  const bool ok = epnp5_wave(ws, K, R, t);
-  if (threadIdx.x == 0) {
+  if (lane < 15) ws.x5[lane] = X5[lane];
+  if (lane < 10) ws.u5[lane] = u5[lane];
+  bool ok = false;
+  for (int rep = 0; rep < reps; ++rep) ok = epnp5_wave(ws, K, R, t);   // reps > 1: timing with a warm instruction cache
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
     for (int i = 0; i < 9; ++i) Rt[i] = R[i];
     Rt[9] = t[0]; Rt[10] = t[1]; Rt[11] = t[2]; Rt[12] = ok ? 1.0 : 0.0;
     for (int b = 0; b < 3; ++b) Rt[13 + b] = ws.out[b][12];
     for (int b = 0; b < 4; ++b) Rt[16 + b] = (double)(ws.stamp[b + 1] - ws.stamp[b]);
     Rt[20] = ws.sweeps;
+    Rt[21] = (double)(ws.stamp[5] - ws.stamp[3]); Rt[22] = (double)(ws.stamp[6] - ws.stamp[5]); Rt[23] = (double)(ws.stamp[7] - ws.stamp[6]);
   }
 }
-int svo_launch_epnp5_probe(svo_ctx* ctx, const double* X5, const double* u5, const double* K, double* Rt) {
-  hipLaunchKernelGGL(k_epnp5_probe, dim3(1), dim3(64), 0, ctx->stream, X5, u5, K, Rt);
+int svo_launch_epnp5_probe(svo_ctx* ctx, const double* X5, const double* u5, const double* K, double* Rt, int reps) {
+  const char* wv = getenv("SVO_EPNP_WAVES");
+  const char* gv = getenv("SVO_EPNP_GRID");
+  const int waves = wv ? std::min(std::max(atoi(wv), 1), 4) : 1, grid = gv ? std::max(atoi(gv), 1) : 1;
+  hipLaunchKernelGGL(k_epnp5_probe, dim3(grid), dim3(64 * waves), 0, ctx->stream, X5, u5, K, Rt, reps < 1 ? 1 : reps);
   SVO_HIP(ctx, hipGetLastError());
   return SVO_OK;
 }
@@ -159,7 +169,7 @@ int svo_launch_pnp(svo_ctx* ctx, const double* Xw, const double* obs, int n, con
   if (rc) return rc;
   SvoTimer tm(ctx, "k_pnp_ransac");
   if (n >= 5)
-    hipLaunchKernelGGL(k_pnp_hyp, dim3(PNP_HYP / 4), dim3(256), sizeof(PnpHypLds), ctx->stream, Xw, obs, n, K, subset, hyp);
+    hipLaunchKernelGGL(k_pnp_hyp, dim3(PNP_HYP), dim3(64), sizeof(PnpHypLds), ctx->stream, Xw, obs, n, K, subset, hyp);
   hipLaunchKernelGGL(k_pnp_select, dim3(1), dim3(256), 0, ctx->stream, Xw, obs, n, K, Tfallback, hyp, T, mask, stats);
   SVO_HIP(ctx, hipGetLastError());
   return SVO_OK;

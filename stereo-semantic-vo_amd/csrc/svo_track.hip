@@ -698,7 +698,8 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
 // ================================================================================================
 // k_tp_hyp: RANSAC samples of cv::solvePnPRansac (src/pnpmatch.cc:227), 4 waves per workgroup, one EPnP and one consensus
 // count per wave (svo_pose_dev.h, svo_epnp_dev.h).  Every workgroup gathers the frame's correspondences itself.
-// One sequence: all 100 samples in one launch (25 workgroups; the chip is idle, latency counts).  Many sequences together:
+// One sequence: all 100 samples in one launch, one single-wave workgroup each (the chip is idle, latency counts, and a
+// CU's float64 pipeline serves one wave 2.7x faster than each of four).  Many sequences together:
 // two launches per step - samples 0..15 first; then samples 16..99, whose workgroups first replay the adaptive rule over
 // the first sixteen and leave at once when the iteration bound (log 0.01 / log(1 - w^5): 12 at 80 % inliers) says the loop
 // can never reach their samples - six times less EPnP work on ordinary frames (61 k -> 74 k frames/s with 64 sequences).
@@ -716,7 +717,7 @@ __global__ __launch_bounds__(256) void k_tp_hyp(TrackState* st, const TrackWork*
   const long long t_start = clock64();
   const int n = work->n_edges;
   if (work->skip_match || n < 5) return;
-  const int first = hyp_base + (int)blockIdx.x * 4;
+  const int first = hyp_base + (int)blockIdx.x * (int)(blockDim.x >> 6);
   if (hyp_base > 0) {
     if (threadIdx.x < TP_HYP_FIRST) { S.cnt[threadIdx.x] = st->hyp[threadIdx.x].cnt; S.ok[threadIdx.x] = st->hyp[threadIdx.x].ok; }
     __syncthreads();
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(256) void k_tp_hyp(TrackState* st, const TrackWork*
     if (first >= S.bound) return;
   }
   const float* gpos = st->gpos;
-  for (int e = threadIdx.x; e < n; e += 256) {
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
     const float* gp = gpos + 3 * (size_t)(work->edge_gid[e] & (TRK_GPOS - 1));
     const svo_kp k = kp[work->edge_kp[e]];
     S.Xw[3 * e] = (double)gp[0]; S.Xw[3 * e + 1] = (double)gp[1]; S.Xw[3 * e + 2] = (double)gp[2];
@@ -738,6 +739,8 @@ __global__ __launch_bounds__(256) void k_tp_hyp(TrackState* st, const TrackWork*
   if (first == 0 && threadIdx.x == 0) {
     st->pose_ts[0] = t_start; st->pose_ts[1] = t_gather; st->pose_ts[2] = S.ws[0].stamp[0]; st->pose_ts[3] = S.ws[0].stamp[4];
     st->pose_ts[4] = clock64();
+    st->pose_ts[5] = S.ws[0].stamp[1]; st->pose_ts[6] = S.ws[0].stamp[2]; st->pose_ts[7] = S.ws[0].stamp[3]; st->pose_ts[12] = S.ws[0].sweeps;
+    st->pose_ts[13] = S.ws[0].stamp[5]; st->pose_ts[14] = S.ws[0].stamp[6]; st->pose_ts[15] = S.ws[0].stamp[7];
   }
 }
 
@@ -937,8 +940,9 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
         hipLaunchKernelGGL(k_tp_hyp, dim3((PNP_HYP - TP_HYP_FIRST) / 4, ny), dim3(256), sizeof(TpHypLds), s0, st, work + f, kpf,
                            ctx->d_pnp_subsets, kstride, TP_HYP_FIRST);
       } else {
-        // one sequence: latency counts and the chip is idle - all 100 samples at once, no second launch on the chain
-        hipLaunchKernelGGL(k_tp_hyp, dim3(PNP_HYP / 4, ny), dim3(256), sizeof(TpHypLds), s0, st, work + f, kpf, ctx->d_pnp_subsets,
+        // one sequence: latency counts and the chip is idle - all 100 samples at once, ONE wave per workgroup (= per CU: the
+        // four SIMDs of a CU share its float64 pipeline, four solves side by side on a CU run 2.7x slower each)
+        hipLaunchKernelGGL(k_tp_hyp, dim3(PNP_HYP, ny), dim3(64), sizeof(TpHypLds), s0, st, work + f, kpf, ctx->d_pnp_subsets,
                            kstride, 0);
       }
     }

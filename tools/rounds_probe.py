@@ -34,3 +34,5 @@ print("dense rows at the end of pass 2:", ts[:,5], "rows resolved after round 1:
 pts=np.zeros(16,np.int64)
 s.lib.svo_debug_track_pose_stamps(s.h, pts.ctypes.data_as(C.c_void_p))
 print("k_tp_hyp cycles: gather %d, to EPnP %d, EPnP %d, count %d | k_tp_frame: gather+select %d, LM %d, end %d" % (pts[1]-pts[0], pts[2]-pts[1], pts[3]-pts[2], pts[4]-pts[3], pts[9]-pts[8], pts[10]-pts[9], pts[11]-pts[10]))
+print("EPnP stages: setup %d, Jacobi %d (%d sweeps), L/rho %d, betas+R,t %d" % (pts[5]-pts[2], pts[6]-pts[5], pts[12], pts[7]-pts[6], pts[3]-pts[7]))
+print("  betas stage: initial %d, Gauss-Newton %d, to last SVD %d, SVD+rest %d" % (pts[13]-pts[7], pts[14]-pts[13], pts[15]-pts[14], pts[3]-pts[15]))

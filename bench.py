@@ -368,6 +368,9 @@ def main():
     frame_bytes = H * PITCH
     rec = pkg.TRACK_DTYPE.itemsize
     svo = pkg.Svo(W, H, device=local, max_kp=500, max_batch=B + extra)
+    for kv in filter(None, os.environ.get("SVO_BENCH_OPTIONS", "").split(",")):   # experiments: "track_group=8,..."
+        k, v = kv.split("=")
+        svo.set_option(k, int(v))
     if multi:
         d_res = torch.zeros((nsteps * B, rec), dtype=torch.uint8, device=dev)
         svo.track_multi_reset(B, cam)

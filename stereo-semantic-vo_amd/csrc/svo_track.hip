@@ -265,11 +265,11 @@ __global__ __launch_bounds__(256) void k_ti_lists(TrackState* st, const uint32_t
 struct TiLds {
   alignas(16) int sm[32];
   int32_t cur_mp[TRK_MAXKP];       // CurrentFrame->MapPoints as pool rows
-  uint32_t minrow[TRK_MAXKP];      // per column: lowest unresolved row that could still claim it
+  uint32_t minrow[2][TRK_MAXKP];   // per column: lowest unresolved row that could still claim it (rounds alternate between
+                                   // the two copies: the idle one is wiped while the other is read)
   uint16_t claimer[TRK_MAXKP];     // who took the column: 0 = taken before the pass (or beyond nkp), k + 1 = active row k of
                                    // this pass, 0xffff = free.  Row k sees a column as free iff claimer > k + 1: a LATER row's
                                    // claim must stay invisible to the earlier rows that are still unresolved
-  uint16_t pend[TRK_MAXKP];        // claims of the running round (k + 1)
   uint16_t act_m[TRK_CAP];         // active row k -> pool row
   uint16_t act_i[TRK_MAXKP];       // pass 1: active row k -> last-frame keypoint index
   uint8_t act_n[TRK_CAP];          // its list length / TRK_DENSE
@@ -277,7 +277,7 @@ struct TiLds {
   uint8_t observed[TRK_CAP];       // pool row matched in pass 1 (observations.count(CurrentFrame))
   uint8_t ref[TRK_CAP];            // pool row referenced by the frame's keypoints (kept alive for the next pass 1)
   int16_t remap[TRK_CAP];          // pool row -> row after compaction
-  int cnt_acc, cnt_veto, cnt_late, nd, flag;
+  int cnt_acc, cnt_veto, cnt_late, nd, flag[2];
   uint16_t dn[TRK_CAP];            // dense active rows of the running pass
   uint16_t dnD[TRK_DNC][512];      // distance rows of the first TRK_DNC of them (fetched once per pass)
 };
@@ -302,15 +302,16 @@ struct TiLds {
 // entries, and active rows beyond 1024, are "dense": a whole wave evaluates such a row from its distance row in D.
 __device__ __forceinline__ bool ti_avail(const TiLds& S, int j, int k) { return (int)S.claimer[j] > k + 1; }
 
-// resolve row k given its evaluation; returns true when the row is final
+// resolve row k (pool row m) given its evaluation; returns true when the row is final.  tally: three 10-bit counters of
+// the calling lane - accepted, vetoed, resolved after the first round (summed per wave at the end of the pass; a lane
+// resolves at most 1 + TRK_CAP / 16 rows)
 template <int PASS>
-__device__ __forceinline__ bool ti_finalize(TiLds& S, TrackState* st, TrackPool& P, int k, int bj, uint32_t minrow_bj,
-                                            bool ok, bool perm, int rounds, const svo_kp* kp, int n_boxes) {
+__device__ __forceinline__ bool ti_finalize(TiLds& S, TrackState* st, TrackPool& P, int k, int m, int bj, uint32_t minrow_bj,
+                                            bool ok, bool perm, int rounds, const svo_kp* kp, int n_boxes, int& tally) {
   if (minrow_bj < (uint32_t)k) return false;   // an earlier unresolved row may still take the best column
   if (!ok && !perm) return false;                 // rejected, but every blocker may still be claimed away
-  if (rounds > 0) atomicAdd(&S.cnt_late, 1);
+  if (rounds > 0) tally += 1 << 20;
   if (!ok) return true;
-  const int m = S.act_m[k];
   if (PASS == 1 && n_boxes > 0) {
     // epipolar veto (src/pnpmatch.cc:103-144): the match lands in a padded box and is off the epipolar
     // line -> the map point is marked bad and claims nothing
@@ -319,15 +320,66 @@ __device__ __forceinline__ bool ti_finalize(TiLds& S, TrackState* st, TrackPool&
     if (svo_in_boxes(kc.x, kc.y, st->boxes, n_boxes, 10) &&
         svo_epipolar_distance(st->F, st->last_xy[2 * i_last], st->last_xy[2 * i_last + 1], kc.x, kc.y) > 0.1) {
       P.bad[m] = 1;
-      atomicAdd(&S.cnt_veto, 1);
+      tally += 1 << 10;
       return true;
     }
   }
   S.cur_mp[bj] = m;     // rows finalised in one round never share a best column
-  S.pend[bj] = (uint16_t)(k + 1);
+  S.claimer[bj] = (uint16_t)(k + 1);   // visible at once: earlier rows ignore it by rank, later rows may use it (it is final)
   S.observed[m] = 1;
-  atomicAdd(&S.cnt_acc, 1);
+  tally += 1;
   return true;
+}
+
+// ---- a dense row (active row kk, pool row m), evaluated by one wave: lane l holds the distances of columns 8 l .. 8 l + 7
+// phase 1: which of my columns are still free for this row (returned as a mask: claims only change between rounds, so
+// phase 2 reuses it), and the claimable ones published in minrow
+__device__ __forceinline__ uint32_t ti_dense_publish(TiLds& S, uint32_t* minrow, const uint32_t (&dd)[8], int kk, int lane, int nkp, int max_dist) {
+  uint32_t cl[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) cl[c] = S.claimer[lane * 8 + c];     // all eight reads in flight together
+  uint32_t am = 0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    if (lane * 8 + c < nkp && (int)cl[c] > kk + 1) am |= 1u << c;
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    if (((am >> c) & 1u) && (int)dd[c] < max_dist) atomicMin(&minrow[lane * 8 + c], (uint32_t)kk);
+  return am;
+}
+// phase 2: best free column, ratio test against the free columns before it, finality.  Returns (wave-uniform) whether
+// the row is resolved.
+template <int PASS>
+__device__ __forceinline__ bool ti_dense_decide(TiLds& S, const uint32_t* minrow, TrackState* st, TrackPool& P, const uint32_t (&dd)[8], uint32_t am,
+                                                int kk, int m, int lane, int rounds, const svo_kp* kp, int n_boxes, int& tally) {
+  constexpr int max_dist = PASS == 1 ? 15 : 30;
+  uint32_t mr[8];
+  if (PASS == 2) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) mr[c] = minrow[lane * 8 + c];    // requested before the reduction below needs the wave
+  }
+  uint32_t key = 0xffffffffu;
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    if (((am >> c) & 1u) && (int)dd[c] < max_dist) key = min(key, (dd[c] << 16) | (uint32_t)(lane * 8 + c));
+  key = wave_min_u32_dpp(key);
+  if (key == 0xffffffffu) return true;      // claims only remove columns: never accepted
+  const int bj = (int)(key & 0xffffu), bd = (int)(key >> 16);
+  const uint32_t mrbj = minrow[bj];
+  bool blk = false, pb = false;
+  if (PASS == 2) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (((am >> c) & 1u) && lane * 8 + c < bj && (int)dd[c] <= 2 * bd) { blk = true; pb = pb || mr[c] >= (uint32_t)kk; }
+  }
+  const bool ok = __ballot(blk) == 0, perm = __ballot(pb) != 0;
+  bool fin = false;
+  if (lane == 0) fin = ti_finalize<PASS>(S, st, P, kk, m, bj, mrbj, ok, perm, rounds, kp, n_boxes, tally);
+  return __ballot(fin) != 0;
+}
+__device__ __forceinline__ void ti_unpack8(const uint4& v, uint32_t (&dd)[8]) {
+  dd[0] = v.x & 0xffff; dd[1] = v.x >> 16; dd[2] = v.y & 0xffff; dd[3] = v.y >> 16;
+  dd[4] = v.z & 0xffff; dd[5] = v.z >> 16; dd[6] = v.w & 0xffff; dd[7] = v.w >> 16;
 }
 
 // lane's eight columns (8 lane .. 8 lane + 7) of dense-list row q (pool row m): from the LDS cache once filled
@@ -338,20 +390,24 @@ __device__ __forceinline__ uint4 ti_dense_piece(TiLds& S, const TrackState* st, 
   return v;
 }
 
+// Dense rows are dealt round-robin to the 16 waves (list position q -> wave q % 16).  A wave keeps its FIRST dense row
+// (q = wave id: all of them on ordinary frames) in registers for the whole pass - row ids, the 16 bytes of distances per
+// lane, the resolved flag - so that a round costs it one LDS round trip per phase; the rows after that go through the
+// LDS cache dnD (list positions 16 .. 16 + TRK_DNC - 1) or, beyond it, the distance rows in HBM.
 template <int PASS>
 __device__ __forceinline__ int ti_resolve_pass(TiLds& S, TrackState* st, TrackPool& P, int n_act, int nkp,
-                                               const svo_kp* kp, int n_boxes) {
+                                               const svo_kp* kp, int n_boxes, int* n_acc, int* n_veto, int* n_late) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   constexpr int max_dist = PASS == 1 ? 15 : 30;
   // ---- set-up: my row's entries into registers; dense rows into a list ------------------------
   const int k = tid;
-  int nc = 0;
+  int nc = 0, my_m = 0;
   uint32_t w0[TRK_LCAP], w1[TRK_LCAP];
 #pragma unroll
   for (int i = 0; i < TRK_LCAP; ++i) { w0[i] = 0; w1[i] = 0; }
   bool unresolved = false;
-  if (tid == 0) { S.nd = 0; S.flag = 0; }
-  if (tid < TRK_MAXKP) { S.minrow[tid] = 0xffffffffu; S.pend[tid] = 0; }
+  if (tid == 0) { S.nd = 0; S.flag[0] = 0; S.flag[1] = 0; S.cnt_acc = 0; S.cnt_veto = 0; S.cnt_late = 0; }
+  if (tid < TRK_MAXKP) { S.minrow[0][tid] = 0xffffffffu; S.minrow[1][tid] = 0xffffffffu; }
   __syncthreads();
   for (int kk = tid; kk < n_act; kk += 1024) {
     const int n = S.act_n[kk];
@@ -360,7 +416,8 @@ __device__ __forceinline__ int ti_resolve_pass(TiLds& S, TrackState* st, TrackPo
       S.fin[kk] = 0;
     } else if (kk == k) {
       nc = n;
-      const uint4* src = reinterpret_cast<const uint4*>(st->cand + (size_t)S.act_m[kk] * 2 * TRK_LCAP);
+      my_m = S.act_m[kk];
+      const uint4* src = reinterpret_cast<const uint4*>(st->cand + (size_t)my_m * 2 * TRK_LCAP);
       uint4 v[TRK_LCAP / 2];
 #pragma unroll
       for (int q = 0; q < TRK_LCAP / 2; ++q) v[q] = src[q];
@@ -370,11 +427,18 @@ __device__ __forceinline__ int ti_resolve_pass(TiLds& S, TrackState* st, TrackPo
     }
   }
   __syncthreads();
-  int rounds = 0;
-  int ncached = 0;
+  int rounds = 0, tally = 0;
+  int ncached = 0;                 // list positions 16 .. 16 + ncached - 1 are in dnD
+  int r_kk = -1, r_m = 0;          // the wave's register-resident dense row (list position wv): active row, pool row
+  bool r_fin = false;
+  uint32_t r_dd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, r_am = 0;
+  // A round = phase 1, barrier, phase 2, barrier.  Claims are written straight into `claimer` in phase 2 (see
+  // ti_finalize); minrow and the continue-flag exist twice, the copy of the NEXT round being wiped during phase 2 (last
+  // read one barrier ago, next written one barrier ahead).
   for (;;) {
+    uint32_t* minrow = S.minrow[rounds & 1];
     const int nd = S.nd;   // rows may join the dense list during a round
-    const int nd1 = min(nd, TRK_DNC);   // cached once phase 1 of this round has run
+    const int nd1 = min(max(nd - 16, 0), TRK_DNC);   // cached once phase 1 of this round has run
     // ---- phase 1: every unresolved row publishes the columns it could still claim -------------
     uint32_t avail = 0;   // bit i: entry i not claimed by an earlier row (and below max_dist)
     if (unresolved) {
@@ -388,108 +452,114 @@ __device__ __forceinline__ int ti_resolve_pass(TiLds& S, TrackState* st, TrackPo
       }
 #pragma unroll
       for (int i = 0; i < TRK_LCAP; ++i)
-        if ((avail >> i) & 1u) atomicMin(&S.minrow[w0[i] & 511u], (uint32_t)k);
-      S.flag = 1;
+        if ((avail >> i) & 1u) atomicMin(&minrow[w0[i] & 511u], (uint32_t)k);
+      S.flag[rounds & 1] = 1;
     }
-    for (int q = wv; q < nd; q += 16) {
+    if (wv < nd) {
+      if (r_kk < 0) {   // first sight of the wave's own dense row: fetch it once
+        r_kk = S.dn[wv];
+        r_m = S.act_m[r_kk];
+        const uint4 v = *reinterpret_cast<const uint4*>(st->D + (size_t)r_m * 512 + lane * 8);
+        ti_unpack8(v, r_dd);
+      }
+      if (!r_fin) {
+        r_am = ti_dense_publish(S, minrow, r_dd, r_kk, lane, nkp, max_dist);
+        if (lane == 0) S.flag[rounds & 1] = 1;
+      }
+    }
+    for (int q = wv + 16; q < nd; q += 16) {
       const int kk = S.dn[q];
       if (S.fin[kk]) continue;
-      const uint4 v = ti_dense_piece(S, st, q, S.act_m[kk], lane, ncached);
-      const uint32_t dd[8] = {v.x & 0xffff, v.x >> 16, v.y & 0xffff, v.y >> 16, v.z & 0xffff, v.z >> 16, v.w & 0xffff, v.w >> 16};
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const int col = lane * 8 + c;
-        if (col < nkp && (int)dd[c] < max_dist && ti_avail(S, col, kk)) atomicMin(&S.minrow[col], (uint32_t)kk);
-      }
-      if (lane == 0) S.flag = 1;
+      uint32_t dd[8];
+      ti_unpack8(ti_dense_piece(S, st, q - 16, S.act_m[kk], lane, ncached), dd);
+      ti_dense_publish(S, minrow, dd, kk, lane, nkp, max_dist);
+      if (lane == 0) S.flag[rounds & 1] = 1;
     }
     __syncthreads();
-    if (!S.flag) break;
+    if (!S.flag[rounds & 1]) break;
+    if (tid < TRK_MAXKP) S.minrow[(rounds & 1) ^ 1][tid] = 0xffffffffu;
+    if (tid == 0) S.flag[(rounds & 1) ^ 1] = 0;
     // ---- phase 2: rows whose outcome no earlier unresolved row can change are final -------------
     if (unresolved) {
-      int bd = 256, bj = -1;
-      uint32_t w0b = 0, w1b = 0;
+      // the best free entry (first minimum in column order); everything the decision may need from LDS is requested
+      // together: minrow of the entries, claimer and minrow of the best entry's stored blockers
+      uint32_t bd = 255u, w0b = 0, w1b = 0;
 #pragma unroll
       for (int i = 0; i < TRK_LCAP; ++i) {
-        const int d = (int)((w0[i] >> 9) & 31u);
-        if (((avail >> i) & 1u) && d < bd) { bd = d; bj = (int)(w0[i] & 511u); w0b = w0[i]; w1b = w1[i]; }
+        const uint32_t d = ((avail >> i) & 1u) ? ((w0[i] >> 9) & 31u) : 255u;
+        const bool better = d < bd;
+        bd = better ? d : bd; w0b = better ? w0[i] : w0b; w1b = better ? w1[i] : w1b;
       }
-      if (bj < 0) {
-        unresolved = false;    // claims only remove columns: never accepted
-      } else {
-        bool ok = true, perm = false;
-        const uint32_t mrbj = S.minrow[bj];
-        if (PASS == 2) {
-          // everything the decision may need from LDS, requested together: minrow of the entries, claimer and minrow
-          // of the best entry's stored blockers
-          uint32_t mr[TRK_LCAP], bc[3], bm[3];
-#pragma unroll
-          for (int i = 0; i < TRK_LCAP; ++i) mr[i] = S.minrow[w0[i] & 511u];
-#pragma unroll
-          for (int q = 0; q < 3; ++q) { const uint32_t j = (w1b >> (9 * q)) & 511u; bc[q] = S.claimer[j]; bm[q] = S.minrow[j]; }
-#pragma unroll
-          for (int i = 0; i < TRK_LCAP; ++i) {   // blockers inside the list (entries are in column order)
-            const int j = (int)(w0[i] & 511u), d = (int)((w0[i] >> 9) & 31u);
-            if (((avail >> i) & 1u) && j < bj && d <= 2 * bd) { ok = false; perm = perm || mr[i] >= (uint32_t)k; }
-          }
-          const int nb = (int)((w0b >> 14) & 3u);
-          bool all_taken = true;
-#pragma unroll
-          for (int q = 0; q < 3; ++q)   // stored blockers outside the list (distance in [30, 2 * best])
-            if (q < nb && (int)bc[q] > k + 1) { all_taken = false; ok = false; perm = perm || bm[q] >= (uint32_t)k; }
-          if (ok && all_taken && ((w0b >> 16) & 1u)) {
-            // every stored blocker has been claimed and there were more (rare): from now on a wave evaluates this row
-            // from its full distance row
-            S.fin[k] = 0;
-            S.dn[atomicAdd(&S.nd, 1)] = (uint16_t)k;
-            unresolved = false;
-            bj = -1;
-          }
-        }
-        if (bj >= 0 && ti_finalize<PASS>(S, st, P, k, bj, mrbj, ok, perm, rounds, kp, n_boxes)) unresolved = false;
-      }
-    }
-    for (int q = wv; q < nd; q += 16) {
-      const int kk = S.dn[q];
-      if (S.fin[kk]) continue;
-      const uint4 v = ti_dense_piece(S, st, q, S.act_m[kk], lane, nd1);
-      const uint32_t dd[8] = {v.x & 0xffff, v.x >> 16, v.y & 0xffff, v.y >> 16, v.z & 0xffff, v.z >> 16, v.w & 0xffff, v.w >> 16};
-      uint32_t key = 0xffffffffu;
-      uint32_t am = 0;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const int col = lane * 8 + c;
-        if (col < nkp && ti_avail(S, col, kk)) {
-          am |= 1u << c;
-          if ((int)dd[c] < max_dist) key = min(key, (dd[c] << 16) | (uint32_t)col);
-        }
-      }
-      key = wave_min_u32_dpp(key);
-      if (key == 0xffffffffu) { if (lane == 0) S.fin[kk] = 1; continue; }
-      const int bj = (int)(key & 0xffffu), bd = (int)(key >> 16);
-      bool blk = false, pb = false;
+      const uint32_t bj = w0b & 511u;
+      const uint32_t mrbj = minrow[bj];
+      uint32_t mr[TRK_LCAP], bc[3], bm[3];
       if (PASS == 2) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const int col = lane * 8 + c;
-          if (((am >> c) & 1u) && col < bj && (int)dd[c] <= 2 * bd) { blk = true; pb = pb || S.minrow[col] >= (uint32_t)kk; }
-        }
+        for (int i = 0; i < TRK_LCAP; ++i) mr[i] = minrow[w0[i] & 511u];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const uint32_t j = (w1b >> (9 * q)) & 511u; bc[q] = S.claimer[j]; bm[q] = minrow[j]; }
       }
-      const bool ok = __ballot(blk) == 0, perm = __ballot(pb) != 0;
-      if (lane == 0 && ti_finalize<PASS>(S, st, P, kk, bj, S.minrow[bj], ok, perm, rounds, kp, n_boxes)) S.fin[kk] = 1;
+      // integer 0 / 1 logic on purpose: no divergent branches in here
+      uint32_t blocked = 0, perm = 0, all_taken = 1;
+      if (PASS == 2) {
+#pragma unroll
+        for (int i = 0; i < TRK_LCAP; ++i) {   // blockers inside the list (entries are in column order)
+          const uint32_t j = w0[i] & 511u, d = (w0[i] >> 9) & 31u;
+          const uint32_t c = ((avail >> i) & 1u) & (uint32_t)(j < bj) & (uint32_t)(d <= 2 * bd);
+          blocked |= c; perm |= c & (uint32_t)(mr[i] >= (uint32_t)k);
+        }
+        const uint32_t nb = (w0b >> 14) & 3u;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {   // stored blockers outside the list (distance in [30, 2 * best])
+          const uint32_t c = (uint32_t)((uint32_t)q < nb) & (uint32_t)((int)bc[q] > k + 1);
+          blocked |= c; perm |= c & (uint32_t)(bm[q] >= (uint32_t)k);
+        }
+        all_taken = blocked ^ 1u;   // (no list blocker either: only consulted when the row would be accepted)
+      }
+      const bool none = bd == 255u;                       // claims only remove columns: never accepted
+      const bool to_dense = PASS == 2 && !none && !blocked && all_taken && ((w0b >> 16) & 1u);
+      if (to_dense) {
+        // every stored blocker has been claimed and there were more (rare): from now on a wave evaluates this row
+        // from its full distance row
+        S.fin[k] = 0;
+        S.dn[atomicAdd(&S.nd, 1)] = (uint16_t)k;
+      }
+      if (none || to_dense) unresolved = false;
+      else if (ti_finalize<PASS>(S, st, P, k, my_m, (int)bj, mrbj, !blocked, perm != 0, rounds, kp, n_boxes, tally)) unresolved = false;
     }
-    __syncthreads();
-    if (tid < TRK_MAXKP) {
-      if (S.pend[tid]) { S.claimer[tid] = S.pend[tid]; S.pend[tid] = 0; }
-      S.minrow[tid] = 0xffffffffu;
+    if (wv < nd && r_kk >= 0 && !r_fin)
+      r_fin = ti_dense_decide<PASS>(S, minrow, st, P, r_dd, r_am, r_kk, r_m, lane, rounds, kp, n_boxes, tally);
+    for (int q = wv + 16; q < nd; q += 16) {
+      const int kk = S.dn[q];
+      if (S.fin[kk]) continue;
+      const int m = S.act_m[kk];
+      uint32_t dd[8], cl[8];
+      ti_unpack8(ti_dense_piece(S, st, q - 16, m, lane, nd1), dd);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) cl[c] = S.claimer[lane * 8 + c];
+      uint32_t am = 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (lane * 8 + c < nkp && (int)cl[c] > kk + 1) am |= 1u << c;
+      if (ti_dense_decide<PASS>(S, minrow, st, P, dd, am, kk, m, lane, rounds, kp, n_boxes, tally) && lane == 0) S.fin[kk] = 1;
     }
-    if (tid == 0) S.flag = 0;
     __syncthreads();
     ncached = nd1;
     ++rounds;
   }
   // what this pass claimed is simply taken for the next pass
   if (tid < TRK_MAXKP && S.claimer[tid] != 0xffffu) S.claimer[tid] = 0;
+  // tallies: one LDS atomic per wave and counter
+  {
+    const int a = wave_sum_i32_dpp(tally & 1023), v = wave_sum_i32_dpp((tally >> 10) & 1023), l = wave_sum_i32_dpp(tally >> 20);
+    if (lane == 0) {
+      if (a) atomicAdd(&S.cnt_acc, a);
+      if (v) atomicAdd(&S.cnt_veto, v);
+      if (l) atomicAdd(&S.cnt_late, l);
+    }
+  }
+  __syncthreads();
+  *n_acc = S.cnt_acc; *n_veto = S.cnt_veto; *n_late = S.cnt_late;
   __syncthreads();
   return rounds;
 }
@@ -512,7 +582,6 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
   // ---- frame begin ---------------------------------------------------------------------------
   if (tid < TRK_MAXKP) { S.cur_mp[tid] = -1; S.claimer[tid] = tid >= nkp ? 0 : 0xffffu; }
   for (int r = tid; r < TRK_CAP; r += 1024) { S.observed[r] = 0; S.ref[r] = 0; }
-  if (tid == 0) { S.cnt_acc = 0; S.cnt_veto = 0; S.cnt_late = 0; }
   const bool has_depth = tid < nkp && depth[tid] > 0.f;
   const int n_stereo = __syncthreads_count(has_depth);
   int edge_gid = -1;          // map-point id matched to keypoint `tid`
@@ -555,10 +624,8 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
       const int k = block_excl_scan(act ? 1 : 0, S.sm, &n_act1);
       if (act) { S.act_m[k] = (uint16_t)m; S.act_i[k] = (uint16_t)tid; S.act_n[k] = st->ncand[m]; }
       __syncthreads();
-      rounds1 = ti_resolve_pass<1>(S, st, P, n_act1, nkp, kp, n_boxes);
-      n_pass1 = S.cnt_acc; n_veto = S.cnt_veto;
-      __syncthreads();
-      if (tid == 0) { S.cnt_acc = 0; S.cnt_late = 0; }
+      int late1;
+      rounds1 = ti_resolve_pass<1>(S, st, P, n_act1, nkp, kp, n_boxes, &n_pass1, &n_veto, &late1);
     }
     // ---- pass 2 (src/pnpmatch.cc:159-199): local map points not observed by this frame -------
     ts2 = clock64();
@@ -587,9 +654,8 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
           ++k;
         }
       __syncthreads();
-      const int rounds2 = ti_resolve_pass<2>(S, st, P, n_act2, nkp, kp, 0);
-      n_pass2 = S.cnt_acc; late2 = S.cnt_late; rounds2v = rounds2;
-      __syncthreads();
+      int veto2;
+      rounds2v = ti_resolve_pass<2>(S, st, P, n_act2, nkp, kp, 0, &n_pass2, &veto2, &late2);
     }
     if (tid < nkp && S.cur_mp[tid] >= 0) edge_gid = P.gid[S.cur_mp[tid]];
   }

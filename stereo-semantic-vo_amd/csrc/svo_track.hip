@@ -66,6 +66,8 @@ struct TrackPool {
 struct TrackWork {
   int32_t frame_id, nkp, n_stereo, n_pass1, n_pass2, n_new, n_local, skip_match;
   long long ts[8];               // diagnostics: s_memtime at begin / pass 1 / pass 2 / frame end / done, dense rows, late rows
+  long long rt[4];               // diagnostics: s_memrealtime (100 MHz, one clock for the chip) at k_ti_resolve start / end,
+                                 // k_tp_hyp start (its workgroup 0), k_tp_frame end
   int32_t diag[2];               // [0] rows of pass 1 | rounds << 16, [1] rows of pass 2 | rounds << 16
   int32_t n_edges;               // 3D-2D correspondences of the frame (src/pnpmatch.cc:216-224), in keypoint order:
   int32_t edge_gid[TRK_MAXKP];   //   id of the map point (CurrentFrame->MapPoints[j]->...) ...
@@ -579,6 +581,7 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
   TrackPool& P = st->pool[st->cur];
   TrackPool& Q = st->pool[st->cur ^ 1];
   long long ts0 = clock64(), ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
+  const long long rt0 = wall_clock64();
   // ---- frame begin ---------------------------------------------------------------------------
   if (tid < TRK_MAXKP) { S.cur_mp[tid] = -1; S.claimer[tid] = tid >= nkp ? 0 : 0xffffu; }
   for (int r = tid; r < TRK_CAP; r += 1024) { S.observed[r] = 0; S.ref[r] = 0; }
@@ -747,6 +750,7 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
     ts4 = clock64();
     work->ts[0] = ts0; work->ts[1] = ts1; work->ts[2] = ts2; work->ts[3] = ts3; work->ts[4] = ts4;
     work->ts[5] = S.nd; work->ts[6] = late2; work->ts[7] = 0;
+    work->rt[0] = rt0; work->rt[1] = wall_clock64();
     work->diag[0] = n_act1 | (rounds1 << 16);
     work->diag[1] = n_act2 | (rounds2v << 16);
     st->n_vetoed = n_veto;
@@ -781,6 +785,7 @@ __global__ __launch_bounds__(256) void k_tp_hyp(TrackState* st, const TrackWork*
   TpHypLds& S = *reinterpret_cast<TpHypLds*>(tk_smem);
   st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
   const long long t_start = clock64();
+  if (hyp_base == 0 && blockIdx.x == 0 && threadIdx.x == 0) const_cast<TrackWork*>(work)->rt[2] = wall_clock64();
   const int n = work->n_edges;
   if (work->skip_match || n < 5) return;
   const int first = hyp_base + (int)blockIdx.x * (int)(blockDim.x >> 6);
@@ -909,6 +914,7 @@ __global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, const TrackWor
     r.reserved[1] = work->diag[1];
     *res_out = r;
     st->pose_ts[8] = tf0; st->pose_ts[9] = tf1; st->pose_ts[10] = tf2; st->pose_ts[11] = clock64();
+    const_cast<TrackWork*>(work)->rt[3] = wall_clock64();
   }
 }
 
@@ -978,13 +984,13 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
   SVO_HIP(ctx, hipEventRecord(ctx->ev_frontend, s0));            // keypoints, descriptors, depths are ready ...
   SVO_HIP(ctx, hipStreamWaitEvent(s1, ctx->ev_frontend, 0));    // ... and the previous call's pose chain has read its records
   // per-kernel HIP-event timing (svo_profile_enable) costs ~2.5 us per event pair on the host - more than a tail kernel's
-  // launch; the tail is therefore SAMPLED: every 8th frame of a call is timed, the others run untimed
+  // launch; the tail is therefore SAMPLED: every 32nd frame of a call is timed (an event pair around a kernel also holds the chain up by ~5 us), the others run untimed
   const bool prof = ctx->profiling;
   for (int f = 0; f < frames; ++f) {
     const svo_kp* kpf = kp + (size_t)f * kstride;
     const uint32_t* descf = desc + (size_t)f * kstride * 8;
     const float* depf = depth + (size_t)f * kstride;
-    ctx->profiling = prof && (f % 8 == 0 || frames < 8);
+    ctx->profiling = prof && (f % 32 == 0 || frames < 32);
     if (fe_events && fe_events[f]) hipStreamWaitEvent(s1, fe_events[f], 0);
     {
       SvoTimer t(ctx, "k_ti_lists", s1);
@@ -1337,6 +1343,16 @@ extern "C" int svo_debug_track_stamps(svo_ctx* ctx, int slot, int64_t ts[8]) {
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   TrackWork* w = reinterpret_cast<TrackWork*>(ctx->d_work) + slot;
   SVO_HIP(ctx, hipMemcpy(ts, w->ts, sizeof(long long) * 8, hipMemcpyDeviceToHost));
+  return SVO_OK;
+}
+
+// Diagnostics: s_memrealtime stamps (100 MHz) of work slot `slot` of the last batched call: k_ti_resolve start / end,
+// k_tp_hyp start, k_tp_frame end - where the two chains of the tail wait for each other (tools/chain_times.py).
+extern "C" int svo_debug_track_realtime(svo_ctx* ctx, int slot, int64_t rt[4]) {
+  if (!ctx || !rt || !ctx->d_work || slot < 0 || slot >= ctx->work_cap) return SVO_E_INVALID;
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  TrackWork* w = reinterpret_cast<TrackWork*>(ctx->d_work) + slot;
+  SVO_HIP(ctx, hipMemcpy(rt, w->rt, sizeof(long long) * 4, hipMemcpyDeviceToHost));
   return SVO_OK;
 }
 

@@ -39,3 +39,12 @@ for i, (a, b) in enumerate(zip(seq, seq[1:])):
                 inside[k[2]] = inside.get(k[2], 0) + (min(k[1], b[0]) - max(k[0], a[1])) / 1e3
         top = sorted(inside.items(), key=lambda kv: -kv[1])[:5]
         print("gap %7.1f us after dispatch %5d (frame %d) at t=%.2f ms: %s" % (g / 1e3, i, i // 2, (a[1] - t0) / 1e6, ", ".join("%s %.0f" % kv for kv in top)))
+# timeline of everything inside the first long gap
+first = None
+for a, b in zip(seq, seq[1:]):
+    if b[0] - a[1] > 1000000: first = (a[1], b[0]); break
+if first and len(sys.argv) > 2:
+    print("kernels inside the first gap > 1 ms (start us after the gap opens, duration us):")
+    for k in allk:
+        if k[1] > first[0] and k[0] < first[1] and "k_tp_" not in k[2]:
+            print("  %8.1f %7.1f  %s" % ((k[0] - first[0]) / 1e3, (k[1] - k[0]) / 1e3, k[2]))

@@ -101,6 +101,7 @@ struct svo_ctx {
   hipEvent_t ev_frontend = nullptr;        // front end of a call finished (recorded on `stream`)
   std::vector<hipEvent_t> ev_frame;        // index chain of frame f finished (recorded on `stream_idx`)
   uint16_t* d_pnp_subsets = nullptr;   // [513][100][5]: RANSAC sample indices of cv::RNG((uint64)-1) for every point count
+  int msa_lds_state = 0;         // k_msa_dp_bfs opted into > 64 KB of dynamic LDS: 0 not tried, 1 yes, -1 refused
   int pose_lds_state = 0;       // > 64 KB dynamic-LDS opt-in of the pose kernels: 0 untried, 1 granted, -1 refused
   int track_lds_state = 0;      // same for the tracker's kernels
   int opt_track_nblk = 3;       // svo_set_option("track_nblk"): runner-up blockers stored per packed entry (0..3)

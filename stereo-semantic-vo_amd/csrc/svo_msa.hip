@@ -160,6 +160,101 @@ __global__ void k_msa_dp_down_many(const MsaTreeTab* tabs, int l, int D, const d
   const double w = Exp[t.parent_c[v]];
   A[(size_t)v * D + d] = (float)(w * (double)A[(size_t)u * D + d] + (1 - w * w) * (double)up[(size_t)v * D + d]);
 }
+
+// ---- TreeDp as ONE launch per aggregation -------------------------------------------------------------------------
+// The recurrences run per disparity: nothing couples A[.][d] to A[.][d'].  So one workgroup takes ONE disparity of one
+// tree and walks all ~2000 levels itself - leaves to root, then root to leaves - with a workgroup barrier per level
+// instead of a kernel launch per level (2 x 2000 launches per aggregation before).  Nodes are addressed by their
+// position g in level order (children of a node are consecutive there, MsaBfsRec::cpos), the per-disparity values live in
+// a transposed slab upT[d][g] (coalesced), and the values of the level just finished - all the next level needs -
+// stay in LDS: a level costs one LDS round trip and a barrier, the HBM reads of the next level's own terms are issued a
+// level ahead.  Arithmetic and its order are those of k_msa_dp_up / k_msa_dp_down (the child's weighted term
+// Exp[c] * (double)up[child] is formed by the child, added by the parent in child order).
+struct MsaBfsRec { int32_t cpos, meta, ppos, node; };   // first child's position | weight to parent + (children << 8) | parent's position | pixel
+struct MsaBfsTab {   // one tree and the volumes of one aggregation over it
+  const MsaBfsRec* rec; const int32_t* level_ptr; int32_t levels, N;
+  const float* cost;   // [pixel][D] in
+  float* upT;          // [D][position] work
+  float* A;            // [pixel][D] out
+};
+
+// upT[d][g] = cost[node(g)][d]  (64 positions x D disparities per workgroup, transposed through LDS)
+__global__ __launch_bounds__(256) void k_msa_bfs_gather(const MsaBfsTab* tabs, int D) {
+  extern __shared__ float msa_tile[];   // 64 x (D + 1)
+  const MsaBfsTab t = tabs[blockIdx.y];
+  const int g0 = blockIdx.x * 64;
+  if (g0 >= t.N) return;
+  const float* cost = t.cost;
+  float* upT = t.upT;
+  for (int idx = threadIdx.x; idx < 64 * D; idx += 256) {
+    const int gi = idx / D, d = idx - gi * D;
+    if (g0 + gi < t.N) msa_tile[gi * (D + 1) + d] = cost[(size_t)t.rec[g0 + gi].node * D + d];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 64 * D; idx += 256) {
+    const int d = idx >> 6, gi = idx & 63;
+    if (g0 + gi < t.N) upT[(size_t)d * t.N + g0 + gi] = msa_tile[gi * (D + 1) + d];
+  }
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void k_msa_dp_bfs(const MsaBfsTab* tabs, int D, const double* Exp, int maxw, int maxl) {
+  extern __shared__ double msa_lds[];   // Exp[256] | two level buffers of maxw doubles | level_ptr (maxl + 2 ints)
+  const MsaBfsTab t = tabs[blockIdx.y];
+  const int d = blockIdx.x, tid = threadIdx.x, L = t.levels;
+  double* E = msa_lds;
+  double* cur = msa_lds + 256;
+  double* prev = cur + maxw;
+  int* lp = reinterpret_cast<int*>(prev + maxw);
+  for (int i = tid; i < 256; i += T) E[i] = Exp[i];
+  for (int i = tid; i <= L; i += T) lp[i] = t.level_ptr[i];
+  __syncthreads();
+  float* up = t.upT + (size_t)d * t.N;
+  float* A = t.A;
+  const MsaBfsRec* rec = t.rec;
+  MsaBfsRec r_n = {0, 0, -1, 0};
+  float own_n = 0.f;
+  // ---- leaves -> root ------------------------------------------------------------------------------------------
+  if (L > 0 && tid < lp[L] - lp[L - 1]) { r_n = rec[lp[L - 1] + tid]; own_n = up[lp[L - 1] + tid]; }
+  for (int l = L - 1; l >= 0; --l) {
+    const int beg = lp[l], cbeg = lp[l + 1], cnt = cbeg - beg;
+    MsaBfsRec r = r_n;
+    float own = own_n;
+    if (l > 0 && tid < beg - lp[l - 1]) { r_n = rec[lp[l - 1] + tid]; own_n = up[lp[l - 1] + tid]; }   // next level's terms: in flight now
+    for (int i = tid; i < cnt; i += T) {
+      if (i != tid) { r = rec[beg + i]; own = up[beg + i]; }
+      float acc = own;
+      const int c0 = r.cpos - cbeg, nch = (r.meta >> 8) & 255;
+      for (int c = 0; c < nch; ++c) acc = (float)((double)acc + prev[c0 + c]);
+      up[beg + i] = acc;
+      cur[i] = E[r.meta & 255] * (double)acc;
+    }
+    __syncthreads();
+    double* x = cur; cur = prev; prev = x;
+  }
+  // ---- root -> leaves ------------------------------------------------------------------------------------------
+  float* curA = reinterpret_cast<float*>(cur);
+  float* prevA = reinterpret_cast<float*>(prev);
+  if (L > 0 && tid < lp[1] - lp[0]) { r_n = rec[lp[0] + tid]; own_n = up[lp[0] + tid]; }
+  for (int l = 0; l < L; ++l) {
+    const int beg = lp[l], cnt = lp[l + 1] - beg, pbeg = l > 0 ? lp[l - 1] : 0;
+    MsaBfsRec r = r_n;
+    float upv = own_n;
+    if (l + 1 < L && tid < lp[l + 2] - lp[l + 1]) { r_n = rec[lp[l + 1] + tid]; own_n = up[lp[l + 1] + tid]; }
+    for (int i = tid; i < cnt; i += T) {
+      if (i != tid) { r = rec[beg + i]; upv = up[beg + i]; }
+      float a = upv;
+      if (r.ppos >= 0) {
+        const double w = E[r.meta & 255];
+        a = (float)(w * (double)prevA[r.ppos - pbeg] + (1 - w * w) * (double)upv);
+      }
+      A[(size_t)r.node * D + d] = a;
+      curA[i] = a;
+    }
+    __syncthreads();
+    float* x = curA; curA = prevA; prevA = x;
+  }
+}
 __global__ void k_msa_argmin(const float* costA, int N, int D, uint8_t* disp) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
@@ -212,6 +307,48 @@ DevBuf& msa_arena(svo_ctx* ctx, int idx) {
 
 }  // namespace
 
+// Level-order records of a tree for k_msa_dp_bfs.  nodes: pixels in level order; returns false when some node's children are
+// not consecutive positions in child order (cannot happen for a breadth-first `seq`; the caller then keeps the
+// level-by-level launches).
+static bool msa_bfs_records(int N, const int32_t* nodes, const std::vector<int32_t>& level_ptr, const int32_t* child_ptr,
+                            const int32_t* child, const int32_t* parent, const uint8_t* parent_c, std::vector<int32_t>& pos,
+                            std::vector<MsaBfsRec>& rec, int* maxw) {
+  pos.resize(N);
+  for (int g = 0; g < N; ++g) pos[nodes[g]] = g;
+  rec.resize(N);
+  int cpos = 1;
+  bool ok = true;
+  for (int g = 0; g < N; ++g) {
+    const int u = nodes[g], nch = child_ptr[u + 1] - child_ptr[u];
+    for (int j = 0; j < nch && ok; ++j) ok = cpos + j < N && nodes[cpos + j] == child[child_ptr[u] + j];
+    rec[g] = MsaBfsRec{cpos, (int32_t)parent_c[u] | (nch << 8), parent[u] >= 0 ? pos[parent[u]] : -1, u};
+    if (nch > 255) ok = false;
+    cpos += nch;
+  }
+  int w = 0;
+  for (size_t l = 0; l + 1 < level_ptr.size(); ++l) w = std::max(w, level_ptr[l + 1] - level_ptr[l]);
+  *maxw = w;
+  return ok && cpos == N;
+}
+
+// k_msa_dp_bfs applicable?  (levels fit its LDS buffers, opt-in above 64 KB granted; SVO_MSA_LEVEL_LAUNCHES forces the old path)
+constexpr int kMsaDpThreads = 512;
+static size_t msa_dp_bfs_lds(int maxw, int maxl) { return sizeof(double) * (256 + 2 * (size_t)maxw) + sizeof(int) * ((size_t)maxl + 2); }
+static bool msa_dp_bfs_ok(svo_ctx* ctx, int D, int maxw, int maxl) {
+  const size_t lds = msa_dp_bfs_lds(maxw, maxl);
+  if (getenv("SVO_MSA_LEVEL_LAUNCHES") || lds > 150 * 1024 || (size_t)64 * (D + 1) * sizeof(float) > 64 * 1024) return false;
+  if (ctx->msa_lds_state == 0)
+    ctx->msa_lds_state = hipFuncSetAttribute(reinterpret_cast<const void*>(k_msa_dp_bfs<kMsaDpThreads>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess ? 1 : -1;
+  return ctx->msa_lds_state > 0 || lds <= 64 * 1024;
+}
+// One aggregation (both sweeps) of `ntrees` trees: two launches
+static void msa_dp_bfs_launch(hipStream_t s, const MsaBfsTab* d_tabs, int ntrees, int N, int D, const double* d_Exp, int maxw, int maxl) {
+  hipLaunchKernelGGL(k_msa_bfs_gather, dim3((unsigned)((N + 63) / 64), ntrees), dim3(256), (size_t)64 * (D + 1) * sizeof(float), s, d_tabs, D);
+  hipLaunchKernelGGL(k_msa_dp_bfs<kMsaDpThreads>, dim3(D, ntrees), dim3(kMsaDpThreads), msa_dp_bfs_lds(maxw, maxl), s, d_tabs, D, d_Exp,
+                     maxw, maxl);
+}
+
 extern "C" int svo_msa_tree_dp(svo_ctx* ctx, const float* cost, int N, int D, const int32_t* seq, const int32_t* child_ptr,
                                const int32_t* child, const uint8_t* child_c, int root, double o, float* costA) {
   if (!ctx) return SVO_E_INVALID;
@@ -248,6 +385,36 @@ extern "C" int svo_msa_tree_dp(svo_ctx* ctx, const float* cost, int N, int D, co
   DevBuf buf;
   const size_t V = (size_t)N * D;
   float* d_up = buf.get<float>(V); float* d_A = buf.get<float>(V);
+  {
+    // both sweeps in one launch (k_msa_dp_bfs) whenever the tree's levels fit its LDS buffers
+    std::vector<MsaBfsRec> rec;
+    std::vector<int32_t> pos;
+    int maxw = 0;
+    if (msa_bfs_records(N, nodes.data(), level_ptr, child_ptr, child, parent.data(), parent_c.data(), pos, rec, &maxw) &&
+        msa_dp_bfs_ok(ctx, D, maxw, max_depth + 1)) {
+      float* d_cost = buf.get<float>(V);
+      MsaBfsRec* d_rec = buf.get<MsaBfsRec>(N);
+      int32_t* d_lp = buf.get<int32_t>(level_ptr.size());
+      MsaBfsTab* d_tab = buf.get<MsaBfsTab>(1);
+      double* d_E = buf.get<double>(256);
+      if (!d_up || !d_A || !d_cost || !d_rec || !d_lp || !d_tab || !d_E) { ctx->last_error = "svo_msa_tree_dp: hipMalloc"; return SVO_E_NOMEM; }
+      hipStream_t s = ctx->stream;
+      const MsaBfsTab tab{d_rec, d_lp, max_depth + 1, N, d_cost, d_up, d_A};
+      SVO_HIP(ctx, hipMemcpyAsync(d_cost, cost, V * sizeof(float), hipMemcpyHostToDevice, s));
+      SVO_HIP(ctx, hipMemcpyAsync(d_rec, rec.data(), (size_t)N * sizeof(MsaBfsRec), hipMemcpyHostToDevice, s));
+      SVO_HIP(ctx, hipMemcpyAsync(d_lp, level_ptr.data(), level_ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+      SVO_HIP(ctx, hipMemcpyAsync(d_tab, &tab, sizeof tab, hipMemcpyHostToDevice, s));
+      SVO_HIP(ctx, hipMemcpyAsync(d_E, Exp, sizeof Exp, hipMemcpyHostToDevice, s));
+      {
+        SvoTimer t(ctx, "k_msa_tree_dp");
+        msa_dp_bfs_launch(s, d_tab, 1, N, D, d_E, maxw, max_depth + 1);
+      }
+      SVO_HIP(ctx, hipMemcpyAsync(costA, d_A, V * sizeof(float), hipMemcpyDeviceToHost, s));
+      SVO_HIP(ctx, hipStreamSynchronize(s));
+      SVO_HIP(ctx, hipGetLastError());
+      return SVO_OK;
+    }
+  }
   int32_t* d_nodes = buf.get<int32_t>(N); int32_t* d_cptr = buf.get<int32_t>(N + 1); int32_t* d_child = buf.get<int32_t>(N);
   int32_t* d_parent = buf.get<int32_t>(N);
   uint8_t* d_cc = buf.get<uint8_t>(N); uint8_t* d_pc = buf.get<uint8_t>(N);
@@ -459,7 +626,11 @@ struct HostTree {                       // what svo_msa_tree returns, plus what 
     fill_.assign(level_ptr.begin(), level_ptr.end() - 1);
     nodes.resize(N);
     for (int k = 0; k < N; ++k) nodes[fill_[depth[seq[k]]]++] = seq[k];
+    bfs_ok = msa_bfs_records(N, nodes.data(), level_ptr, child_ptr.data(), child.data(), parent.data(), parent_c.data(), fill_, rec, &maxw);
   }
+  std::vector<MsaBfsRec> rec;   // the tree by level-order position (k_msa_dp_bfs)
+  int maxw = 0;                 // widest level
+  bool bfs_ok = false;          // children are consecutive in level order (always, for a breadth-first seq)
 };
 
 struct DevTree { int32_t *nodes, *child_ptr, *child, *parent; uint8_t *child_c, *parent_c; };
@@ -504,8 +675,14 @@ static int msa_solve_device(svo_ctx* ctx, hipStream_t s, DevBuf& buf, uint8_t* c
     dt[s2].nodes = buf.get<int32_t>(N); dt[s2].child_ptr = buf.get<int32_t>(N + 1); dt[s2].child = buf.get<int32_t>(N);
     dt[s2].parent = buf.get<int32_t>(N); dt[s2].child_c = buf.get<uint8_t>(N); dt[s2].parent_c = buf.get<uint8_t>(N);
   }
+  MsaBfsRec* d_rec[2] = {buf.get<MsaBfsRec>(N), buf.get<MsaBfsRec>(N)};     // the trees in level order (k_msa_dp_bfs)
+  int32_t* d_lp[2] = {buf.get<int32_t>(N + 1), buf.get<int32_t>(N + 1)};
+  MsaBfsTab* d_tabs = buf.get<MsaBfsTab>(2);
+  double* d_Exp2 = buf.get<double>(256);
+  float* d_up1 = buf.get<float>(V); float* d_A1 = buf.get<float>(V); uint8_t* d_raw1 = buf.get<uint8_t>(N);   // second work volume
   if (!g || !cost[0] || !cost[1] || !d_up || !d_A || !med3[0] || !med3[1] || !gray || !d_disp[0] || !d_disp[1] || !d_raw ||
-      !d_mask || !d_Exp || !dt[1].parent_c) {
+      !d_mask || !d_Exp || !dt[1].parent_c || !d_rec[0] || !d_rec[1] || !d_lp[0] || !d_lp[1] || !d_tabs || !d_Exp2 ||
+      !d_up1 || !d_A1 || !d_raw1) {
     ctx->last_error = "svo_msa_solve: hipMalloc";
     return SVO_E_NOMEM;
   }
@@ -553,8 +730,20 @@ static int msa_solve_device(svo_ctx* ctx, hipStream_t s, DevBuf& buf, uint8_t* c
   mark("host_msa_trees");
   for (int side = 0; side < 2; ++side)
     if (tree[side].rc) { ctx->last_error = "svo_msa_solve: tree construction failed"; return tree[side].rc; }
+  // one launch per aggregation (k_msa_dp_bfs) when the widest level fits its LDS buffers - always, on real images
+  int maxw = 0, maxl = 0;
+  for (int side = 0; side < 2; ++side) { maxw = std::max(maxw, tree[side].maxw); maxl = std::max(maxl, (int)tree[side].level_ptr.size() - 1); }
+  const bool bfs = tree[0].bfs_ok && tree[1].bfs_ok && msa_dp_bfs_ok(ctx, D, maxw, maxl);
+  MsaBfsTab h_tabs[2];
   for (int side = 0; side < 2; ++side) {
     const HostTree& t = tree[side];
+    if (bfs) {
+      SVO_HIP(ctx, hipMemcpyAsync(d_rec[side], t.rec.data(), N * sizeof(MsaBfsRec), hipMemcpyHostToDevice, s));
+      SVO_HIP(ctx, hipMemcpyAsync(d_lp[side], t.level_ptr.data(), t.level_ptr.size() * 4, hipMemcpyHostToDevice, s));
+      h_tabs[side] = MsaBfsTab{d_rec[side], d_lp[side], (int32_t)t.level_ptr.size() - 1, (int32_t)N, cost[side], side ? d_up1 : d_up,
+                               side ? d_A1 : d_A};
+      continue;
+    }
     SVO_HIP(ctx, hipMemcpyAsync(dt[side].nodes, t.nodes.data(), N * 4, hipMemcpyHostToDevice, s));
     SVO_HIP(ctx, hipMemcpyAsync(dt[side].child_ptr, t.child_ptr.data(), (N + 1) * 4, hipMemcpyHostToDevice, s));
     SVO_HIP(ctx, hipMemcpyAsync(dt[side].child, t.child.data(), (N - 1) * 4, hipMemcpyHostToDevice, s));
@@ -562,6 +751,7 @@ static int msa_solve_device(svo_ctx* ctx, hipStream_t s, DevBuf& buf, uint8_t* c
     SVO_HIP(ctx, hipMemcpyAsync(dt[side].child_c, t.child_c.data(), N - 1, hipMemcpyHostToDevice, s));
     SVO_HIP(ctx, hipMemcpyAsync(dt[side].parent_c, t.parent_c.data(), N, hipMemcpyHostToDevice, s));
   }
+  if (bfs) SVO_HIP(ctx, hipMemcpyAsync(d_tabs, h_tabs, sizeof h_tabs, hipMemcpyHostToDevice, s));
 
   // 3. TreeDp + WTA per image, L/R check, TreeDp + WTA again with the sharper weights
   double Exp[2][256];
@@ -590,12 +780,40 @@ static int msa_solve_device(svo_ctx* ctx, hipStream_t s, DevBuf& buf, uint8_t* c
     return SVO_OK;
   };
   int rc;
+  if (bfs) {
+    // the two first aggregations (right image as base, left image as base) in ONE launch pair, the refinement in another
+    SVO_HIP(ctx, hipMemcpyAsync(d_Exp, Exp[0], 256 * sizeof(double), hipMemcpyHostToDevice, s));
+    SVO_HIP(ctx, hipMemcpyAsync(d_Exp2, Exp[1], 256 * sizeof(double), hipMemcpyHostToDevice, s));
+    {
+      SvoTimer tm(ctx, "k_msa_tree_dp");
+      msa_dp_bfs_launch(s, d_tabs, 2, (int)N, D, d_Exp, maxw, maxl);
+    }
+    {
+      SvoTimer tm(ctx, "k_msa_wta");
+      hipLaunchKernelGGL(k_msa_argmin, dim3(nbN), dim3(256), 0, s, d_A1, (int)N, D, d_raw1);
+      hipLaunchKernelGGL(k_ctmf<2>, dim3((m + 255) / 256, n), dim3(256), 0, s, d_raw1, d_disp[1], m, n, m, m, 1);
+      hipLaunchKernelGGL(k_msa_argmin, dim3(nbN), dim3(256), 0, s, d_A, (int)N, D, d_raw);
+      hipLaunchKernelGGL(k_ctmf<2>, dim3((m + 255) / 256, n), dim3(256), 0, s, d_raw, d_disp[0], m, n, m, m, 1);
+    }
+    {
+      SvoTimer tm(ctx, "k_msa_lrcheck");
+      hipLaunchKernelGGL(k_msa_lrcheck, dim3(nbV), dim3(256), 0, s, d_disp[0], d_disp[1], n, m, D, cost[0], d_mask);
+    }
+    {
+      SvoTimer tm(ctx, "k_msa_tree_dp");
+      msa_dp_bfs_launch(s, d_tabs, 1, (int)N, D, d_Exp2, maxw, maxl);   // refine: left tree, sharper weights, checked costs
+    }
+    {
+      SvoTimer tm(ctx, "k_msa_wta");
+      hipLaunchKernelGGL(k_msa_argmin, dim3(nbN), dim3(256), 0, s, d_A, (int)N, D, d_raw);
+      hipLaunchKernelGGL(k_ctmf<2>, dim3((m + 255) / 256, n), dim3(256), 0, s, d_raw, d_disp[0], m, n, m, m, 1);
+    }
+  } else {
+  // (levels too wide for k_msa_dp_bfs: one launch per level)
   // The first two aggregations (right image as base image, left image as base image) are independent until the L/R
   // check: their level sweeps - two chains of ~2 x 1000 small dependent launches - run side by side on two streams, with
   // their own work volumes, instead of one after the other.
   {
-    float* d_up1 = buf.get<float>(V); float* d_A1 = buf.get<float>(V); uint8_t* d_raw1 = buf.get<uint8_t>(N);
-    if (!d_up1 || !d_A1 || !d_raw1) { ctx->last_error = "svo_msa_solve: hipMalloc"; return SVO_E_NOMEM; }
     if (!ctx->stream_fe) SVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_fe, hipStreamNonBlocking));
     hipStream_t s2 = ctx->stream_fe;
     hipEvent_t e0, e1;
@@ -646,6 +864,7 @@ static int msa_solve_device(svo_ctx* ctx, hipStream_t s, DevBuf& buf, uint8_t* c
     hipLaunchKernelGGL(k_msa_lrcheck, dim3(nbV), dim3(256), 0, s, d_disp[0], d_disp[1], n, m, D, cost[0], d_mask);
   }
   if ((rc = aggregate(0, cost[0], Exp[1], d_disp[0]))) return rc;   // refine
+  }
   hipLaunchKernelGGL(k_msa_scale, dim3(nbN), dim3(256), 0, s, d_disp[0], (int)N, scale, d_out);
   mark("host_msa_enqueue_aggregation");
   SVO_HIP(ctx, hipStreamSynchronize(s));
@@ -759,6 +978,9 @@ static int msa_many_device(svo_ctx* ctx, hipStream_t s, const uint8_t* dL, const
   int32_t* d_int = buf.get<int32_t>((size_t)2 * C * (5 * N + 4));     // nodes, level_ptr, child_ptr, child, parent per tree
   uint8_t* d_byte = buf.get<uint8_t>((size_t)2 * C * 2 * N);          // child_c, parent_c per tree
   MsaTreeTab* d_tabs = buf.get<MsaTreeTab>((size_t)2 * C);
+  MsaBfsRec* d_rec = buf.get<MsaBfsRec>((size_t)2 * C * N);           // the trees in level order (k_msa_dp_bfs)
+  MsaBfsTab* d_btabs = buf.get<MsaBfsTab>((size_t)2 * C);
+  if (!d_rec || !d_btabs) { ctx->last_error = "svo_msa (batched): hipMalloc"; return SVO_E_NOMEM; }
   if (!img3[0] || !img3[1] || !med3[0] || !med3[1] || !gray || !g || !cost[0] || !cost[1] || !d_up || !d_A || !d_disp[0] ||
       !d_disp[1] || !d_raw || !d_mask || !d_Exp || !d_int || !d_byte || !d_tabs) {
     ctx->last_error = "svo_msa (batched): hipMalloc";
@@ -827,23 +1049,35 @@ static int msa_many_device(svo_ctx* ctx, hipStream_t s, const uint8_t* dL, const
   if (gpu_phase) gpu_lock = std::unique_lock<std::mutex>(*gpu_phase);
   // 3. trees to the device: tabs[side * C + b]
   std::vector<MsaTreeTab> h_tabs(2 * C);
+  std::vector<MsaBfsTab> h_btabs(2 * C);
   int Lmax[2] = {0, 0};
+  int maxw = 0, maxl = 0;
+  bool bfs = true;
+  for (int k = 0; k < 2 * C; ++k) { bfs = bfs && tree[k].bfs_ok; maxw = std::max(maxw, tree[k].maxw); maxl = std::max(maxl, (int)tree[k].level_ptr.size() - 1); }
+  bfs = bfs && msa_dp_bfs_ok(ctx, D, maxw, maxl);
   for (int k = 0; k < 2 * C; ++k) {
     const HostTree& t = tree[k];
     const int b = k >> 1, side = k & 1;
     int32_t* ip = d_int + (size_t)k * (5 * N + 4);
     uint8_t* bp = d_byte + (size_t)k * 2 * N;
     const int levels = (int)t.level_ptr.size() - 1;
-    SVO_HIP(ctx, hipMemcpyAsync(ip, t.nodes.data(), N * 4, hipMemcpyHostToDevice, s));
     SVO_HIP(ctx, hipMemcpyAsync(ip + N, t.level_ptr.data(), (size_t)(levels + 1) * 4, hipMemcpyHostToDevice, s));
+    Lmax[side] = std::max(Lmax[side], levels);
+    if (bfs) {
+      SVO_HIP(ctx, hipMemcpyAsync(d_rec + (size_t)k * N, t.rec.data(), N * sizeof(MsaBfsRec), hipMemcpyHostToDevice, s));
+      h_btabs[side * C + b] = MsaBfsTab{d_rec + (size_t)k * N, ip + N, levels, (int32_t)N, cost[side] + (size_t)b * V, d_up + (size_t)b * V,
+                                        d_A + (size_t)b * V};
+      continue;
+    }
+    SVO_HIP(ctx, hipMemcpyAsync(ip, t.nodes.data(), N * 4, hipMemcpyHostToDevice, s));
     SVO_HIP(ctx, hipMemcpyAsync(ip + 2 * N + 2, t.child_ptr.data(), (N + 1) * 4, hipMemcpyHostToDevice, s));
     SVO_HIP(ctx, hipMemcpyAsync(ip + 3 * N + 3, t.child.data(), (N - 1) * 4, hipMemcpyHostToDevice, s));
     SVO_HIP(ctx, hipMemcpyAsync(ip + 4 * N + 3, t.parent.data(), N * 4, hipMemcpyHostToDevice, s));
     SVO_HIP(ctx, hipMemcpyAsync(bp, t.child_c.data(), N - 1, hipMemcpyHostToDevice, s));
     SVO_HIP(ctx, hipMemcpyAsync(bp + N, t.parent_c.data(), N, hipMemcpyHostToDevice, s));
     h_tabs[side * C + b] = MsaTreeTab{ip, ip + N, ip + 2 * N + 2, ip + 3 * N + 3, ip + 4 * N + 3, bp, bp + N, levels};
-    Lmax[side] = std::max(Lmax[side], levels);
   }
+  if (bfs) SVO_HIP(ctx, hipMemcpyAsync(d_btabs, h_btabs.data(), sizeof(MsaBfsTab) * 2 * C, hipMemcpyHostToDevice, s));
   SVO_HIP(ctx, hipMemcpyAsync(d_tabs, h_tabs.data(), sizeof(MsaTreeTab) * 2 * C, hipMemcpyHostToDevice, s));
   double Exp[512];
   for (int i = 0; i <= 255; ++i) { Exp[i] = exp(-i * 1.0 / 0.1 / 255); Exp[256 + i] = exp(-i * 1.0 / (0.1 / 2) / 255); }
@@ -861,6 +1095,9 @@ static int msa_many_device(svo_ctx* ctx, hipStream_t s, const uint8_t* dL, const
   // 4. TreeDp + WTA for the right images, the left images, L/R check, TreeDp + WTA again with the sharper weights
   auto aggregate = [&](int side, const float* c, const double* E, uint8_t* out_disp) -> int {
     const MsaTreeTab* tabs = d_tabs + side * C;
+    if (bfs) {
+      msa_dp_bfs_launch(s, d_btabs + side * C, C, (int)N, D, E, maxw, maxl);   // reads the costs from where they are
+    } else {
     SVO_HIP(ctx, hipMemcpyAsync(d_up, c, V * C * sizeof(float), hipMemcpyDeviceToDevice, s));
     for (int l = Lmax[side] - 1; l >= 0; --l)
       hipLaunchKernelGGL(k_msa_dp_up_many, dim3((unsigned)(((size_t)width[side][l] * D + 255) / 256), C), dim3(256), 0, s, tabs, l, D, E,
@@ -868,6 +1105,7 @@ static int msa_many_device(svo_ctx* ctx, hipStream_t s, const uint8_t* dL, const
     for (int l = 0; l < Lmax[side]; ++l)
       hipLaunchKernelGGL(k_msa_dp_down_many, dim3((unsigned)(((size_t)width[side][l] * D + 255) / 256), C), dim3(256), 0, s, tabs, l, D,
                          E, d_up, d_A, V);
+    }
     hipLaunchKernelGGL(k_msa_argmin, dim3((unsigned)((N * C + 255) / 256)), dim3(256), 0, s, d_A, (int)(N * C), D, d_raw);
     for (int b = 0; b < C; ++b)
       hipLaunchKernelGGL(k_ctmf<2>, dim3((m + 255) / 256, n), dim3(256), 0, s, d_raw + (size_t)b * N, out_disp + (size_t)b * N, m, n, m, m, 1);

@@ -3,6 +3,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "svo_internal.h"
 
@@ -780,4 +783,27 @@ extern "C" int svo_profile_get(svo_ctx* ctx, int index, char* name, int name_cap
   if (total_ms) *total_ms = e.total_ms;
   if (launches) *launches = e.launches;
   return SVO_OK;
+}
+
+int svo_host_cpus() {
+  static const int cached = []() {
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    // cgroup v2: "<quota> <period>" or "max <period>"; cgroup v1: cpu.cfs_quota_us / cpu.cfs_period_us (-1 = none)
+    long long quota = -1, period = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[32] = {0};
+      if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+      fclose(f);
+    } else {
+      FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r");
+      FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+      if (fq && fp && fscanf(fq, "%lld", &quota) == 1 && fscanf(fp, "%lld", &period) == 1) {}
+      if (fq) fclose(fq);
+      if (fp) fclose(fp);
+    }
+    if (quota > 0 && period > 0) n = std::min(n, (int)std::max(1LL, (quota + period / 2) / period));
+    if (const char* e = getenv("SVO_HOST_CPUS")) { if (atoi(e) > 0) n = atoi(e); }
+    return n;
+  }();
+  return cached;
 }

@@ -23,6 +23,8 @@
 #include <algorithm>
 #include <cstdint>
 #include <vector>
+#include <atomic>
+#include <chrono>
 
 #include "svo_internal.h"
 
@@ -183,10 +185,17 @@ struct Builder {
 
 // xy: n points as (x, y) int32 pairs.  tri: up to cap (c1, c2, c3) index triples into xy.
 // Returns the number of triangles (which may exceed cap: nothing is written beyond cap), < 0 on error.
+std::atomic<long long> g_dly_us[4];   // diagnostics: sort points, build, emit, sort triangles
+std::atomic<long long> g_dly_pts;
 extern "C" int svo_elas_delaunay(const int32_t* xy, int32_t n, int32_t* tri, int32_t cap, int32_t* n_tri) {
+  auto T0 = std::chrono::steady_clock::now();
+  auto lap = [&](int k) { auto t = std::chrono::steady_clock::now(); g_dly_us[k] += (long long)std::chrono::duration<double, std::micro>(t - T0).count(); T0 = t; };
   if (!xy || !n_tri || n < 0 || cap < 0 || (cap > 0 && !tri)) return SVO_E_INVALID;
   *n_tri = 0;
-  Builder b;
+  // one builder per host thread, its arrays keep their capacity: fresh 100 KB+ vectors per call are mmap / munmap pairs,
+  // and those serialise the worker threads of svo_elas_batch_dev on the process's address-space lock
+  static thread_local Builder b;
+  b.q.nxt.clear(); b.q.org.clear(); b.q.dead.clear();
   b.pts.resize(n);
   for (int i = 0; i < n; ++i) {
     if (xy[2 * i] < -32768 || xy[2 * i] > 32767 || xy[2 * i + 1] < -32768 || xy[2 * i + 1] > 32767)
@@ -203,16 +212,19 @@ extern "C" int svo_elas_delaunay(const int32_t* xy, int32_t n, int32_t* tri, int
               b.pts.end());
   const int m = (int)b.pts.size();
   if (m < 3) return SVO_OK;
+  lap(0); g_dly_pts += m;
   b.q.nxt.reserve(16 * m); b.q.org.reserve(16 * m); b.q.dead.reserve(4 * m);
   b.q.p = b.pts.data();
   b.build(0, m, 0);
+  lap(1);
   b.q.p = b.pts.data();
   // canonical order = lexicographic (a, b, c); with fewer than 2^21 points the triple packs into one 64-bit
   // key, and sorting plain integers is several times cheaper than sorting structs with a comparator
   const bool packed = n < (1 << 21);
   struct T { int32_t a, b, c; };
   std::vector<T> out;
-  std::vector<uint64_t> keys;
+  static thread_local std::vector<uint64_t> keys;
+  keys.clear();
   if (packed) keys.reserve(2 * m); else out.reserve(2 * m);
   const QuadEdge& q = b.q;
   for (int e = 0; e < (int)q.nxt.size(); e += 2) {   // primal directed edges
@@ -232,7 +244,29 @@ extern "C" int svo_elas_delaunay(const int32_t* xy, int32_t n, int32_t* tri, int
     else out.push_back({ia, ib, ic});
   }
   if (packed) {
-    std::sort(keys.begin(), keys.end());
+    lap(2);
+    {
+      // keys ascending = (a, b, c) lexicographic.  A triangle is listed under its smallest corner a, a vertex has ~2 of
+      // those: counting sort on a, then an insertion sort inside each (tiny) bucket - linear, against ~13 compare
+      // levels of std::sort
+      static thread_local std::vector<uint64_t> sorted;
+      static thread_local std::vector<int32_t> start, cursor;
+      sorted.resize(keys.size());
+      start.assign((size_t)n + 1, 0);
+      for (uint64_t k : keys) ++start[(size_t)(k >> 42) + 1];
+      for (int a = 0; a < n; ++a) start[a + 1] += start[a];      // start[a] .. start[a + 1]: bucket a
+      cursor.assign(start.begin(), start.end() - 1);
+      for (uint64_t k : keys) sorted[cursor[(size_t)(k >> 42)]++] = k;
+      for (int a = 0; a < n; ++a)
+        for (int i = start[a] + 1; i < start[a + 1]; ++i) {
+          const uint64_t k = sorted[i];
+          int j = i - 1;
+          while (j >= start[a] && sorted[j] > k) { sorted[j + 1] = sorted[j]; --j; }
+          sorted[j + 1] = k;
+        }
+      keys.swap(sorted);
+    }
+    lap(3);
     *n_tri = (int32_t)keys.size();
     for (int i = 0; i < std::min<int>((int)keys.size(), cap); ++i) {
       tri[3 * i] = (int32_t)(keys[i] >> 42); tri[3 * i + 1] = (int32_t)((keys[i] >> 21) & 0x1fffff);

@@ -1176,13 +1176,20 @@ int elas_phase_a(svo_ctx* ctx, hipStream_t s, const ElasTab* d_tab, int B, int p
   return SVO_OK;
 }
 
+extern "C" int svo_elas_filter_lattice(int16_t* D, int Wc, int Hc, int incon_window, int incon_threshold, int incon_min_support,
+                                       int red_max_dist, int red_threshold);
+
 // Host stage 1: the order-dependent clean-up of the lattice candidates -> support point list.
 void elas_filter(const int16_t* h_can, int Wc, int Hc, int W, int H, const svo_elas_params& p, ElasWork& w) {
   const int step = p.candidate_stepsize + (p.subsampling ? p.candidate_stepsize % 2 : 0);
-  std::vector<int16_t> can(h_can, h_can + (size_t)Wc * Hc);
-  remove_inconsistent(can, Wc, Hc, p);
-  remove_redundant(can, Wc, Hc, 5, 1, true);
-  remove_redundant(can, Wc, Hc, 5, 1, false);
+  static thread_local std::vector<int16_t> can;   // (per-thread scratch: see svo_elas_delaunay on why nothing big is allocated per pair)
+  can.assign(h_can, h_can + (size_t)Wc * Hc);
+  // the three passes, eight lattice cells per instruction (svo_elas_filter.cc); the scalar loops serve unusual parameters
+  if (svo_elas_filter_lattice(can.data(), Wc, Hc, p.incon_window_size, p.incon_threshold, p.incon_min_support, 5, 1)) {
+    remove_inconsistent(can, Wc, Hc, p);
+    remove_redundant(can, Wc, Hc, 5, 1, true);
+    remove_redundant(can, Wc, Hc, 5, 1, false);
+  }
   for (int u = 1; u < Wc; ++u)
     for (int v = 1; v < Hc; ++v)
       if (can[v * Wc + u] >= 0) w.sp.push_back({u * step, v * step, can[v * Wc + u]});
@@ -1191,9 +1198,9 @@ void elas_filter(const int16_t* h_can, int Wc, int Hc, int W, int H, const svo_e
   for (size_t i = 0; i < w.sp.size(); ++i) { w.spflat[3 * i] = w.sp[i].u; w.spflat[3 * i + 1] = w.sp[i].v; w.spflat[3 * i + 2] = w.sp[i].d; }
 }
 
-// Host stage 2: the two Delaunay triangulations (or the lists a test injects).
-void elas_triangulate(int cap_tri, const svo_elas_taps* taps, ElasWork& w, bool two_threads) {
-  auto do_side = [&](int side) {
+// Host stage 2: the Delaunay triangulation of one image's support points (or the list a test injects).
+void elas_triangulate_side(int cap_tri, const svo_elas_taps* taps, ElasWork& w, int side) {
+  {
     const int32_t* tin = taps ? (side ? taps->tri2_in : taps->tri1_in) : nullptr;
     if (tin) {
       const int nt = side ? taps->n_tri2_in : taps->n_tri1_in;
@@ -1203,14 +1210,20 @@ void elas_triangulate(int cap_tri, const svo_elas_taps* taps, ElasWork& w, bool 
       w.tri[side].assign(tin, tin + 3 * (size_t)nt);
       return;
     }
-    std::vector<int32_t> xy(2 * w.sp.size());
+    static thread_local std::vector<int32_t> xy;
+    xy.resize(2 * w.sp.size());
     for (size_t i = 0; i < w.sp.size(); ++i) { xy[2 * i] = side ? w.sp[i].u - w.sp[i].d : w.sp[i].u; xy[2 * i + 1] = w.sp[i].v; }
     w.tri[side].resize((size_t)cap_tri * 3);
     int32_t nt = 0;
     const int r = svo_elas_delaunay(xy.data(), (int32_t)w.sp.size(), w.tri[side].data(), cap_tri, &nt);
     if (r || nt > cap_tri) { w.err = "svo_elas_process: triangulation failed"; w.tri[side].clear(); return; }
     w.tri[side].resize((size_t)nt * 3);
-  };
+  }
+}
+
+// Both of them.
+void elas_triangulate(int cap_tri, const svo_elas_taps* taps, ElasWork& w, bool two_threads) {
+  auto do_side = [&](int side) { elas_triangulate_side(cap_tri, taps, w, side); };
   if (two_threads) {   // the two images are independent: the right one runs on a second host thread
     std::thread right_side(do_side, 1);
     do_side(0);
@@ -1431,6 +1444,7 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
 // packed, one copy per chunk.
 struct ElasBatch {
   std::vector<ElasState*> slots;
+  std::vector<ElasWork> work;    // host results per pair (support points, triangle lists), vectors reused
   int cap = 0, can_elems = 0;
   ElasTab* d_tab = nullptr;
   ElasTab* h_tab = nullptr;      // pinned
@@ -1557,18 +1571,31 @@ extern "C" int svo_elas_batch_dev(svo_ctx* ctx, const uint8_t* d_L, const uint8_
   };
 
   // persistent pool: the two host stages of one pair per task
-  std::vector<ElasWork> work(B);
+  // the host results of a pair keep their vectors from call to call (same reason)
+  if ((int)eb->work.size() < B) eb->work.resize(B);
+  std::vector<ElasWork>& work = eb->work;
+  for (int b = 0; b < B; ++b) { work[b].sp.clear(); work[b].spflat.clear(); work[b].tri[0].clear(); work[b].tri[1].clear(); work[b].err = nullptr; }
   std::vector<int> prc(B, SVO_OK);
   std::mutex mu;
   std::condition_variable cv_go, cv_done;
   int task_begin = 0, task_end = 0, next_task = 0, running = 0;
   bool quit = false;
-  auto do_pair = [&](int b) {
-    ElasWork& w = work[b];
-    ElasState* st = eb->slots[b];
-    elas_filter(eb->h_can + (size_t)b * wh, Wc, Hc, W, H, p, w);
-    const bool ok = w.sp.size() >= 3;
-    if (ok) elas_triangulate(st->cap_tri, nullptr, w, false);
+  // persistent pool.  The host stage of a chunk runs as two waves of tasks: the filter of every pair, then the two
+  // triangulations of every pair as separate tasks - a pair's ~3 ms of host work (0.9 + 2 x 1.0) would otherwise be the
+  // latency of the whole chunk, and the chunk's GPU phases take less than that.
+  std::atomic<long long> dbg_filter_us{0}, dbg_tri_us{0};
+  int task_mode = 0, task_b0 = 0;
+  auto do_task = [&](int t) {
+    const auto ta = std::chrono::steady_clock::now();
+    if (task_mode == 0) {
+      const int b = task_b0 + t;
+      elas_filter(eb->h_can + (size_t)b * wh, Wc, Hc, W, H, p, work[b]);
+      dbg_filter_us += (long long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ta).count();
+    } else {
+      const int b = task_b0 + (t >> 1);
+      if (work[b].sp.size() >= 3) elas_triangulate_side(eb->slots[b]->cap_tri, nullptr, work[b], t & 1);
+      dbg_tri_us += (long long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ta).count();
+    }
   };
   auto worker = [&]() {
     hipSetDevice(ctx->device);   // the current device is per-thread state
@@ -1576,23 +1603,29 @@ extern "C" int svo_elas_batch_dev(svo_ctx* ctx, const uint8_t* d_L, const uint8_
     for (;;) {
       cv_go.wait(lk, [&] { return quit || next_task < task_end; });
       if (quit) return;
-      const int b = next_task++;
+      const int t = next_task++;
       ++running;
       lk.unlock();
-      do_pair(b);
+      do_task(t);
       lk.lock();
       if (--running == 0 && next_task >= task_end) cv_done.notify_all();
     }
   };
-  const int nthreads = std::max(1, std::min<int>(C, std::min(32u, std::max(1u, std::thread::hardware_concurrency() / 2))));
+  const char* thr_env = getenv("SVO_ELAS_THREADS");   // tuning knob
+  // (measured on a 16-CPU quota, 512 pairs: 12 threads 5.8 k pairs/s, 16: 7.8 k, 24: 9.0 k, 32: 8.4 k - part of a task is waiting)
+  const int thr_cap = thr_env && atoi(thr_env) > 0 ? atoi(thr_env) : (3 * svo_host_cpus() + 1) / 2;
+  const int nthreads = std::max(1, std::min(2 * C, thr_cap));
   std::vector<std::thread> pool;
   for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker);
   auto host_stage = [&](int c) {
     const int b0 = c * C, nb = std::min(C, B - b0);
     std::unique_lock<std::mutex> lk(mu);
-    task_begin = b0; next_task = b0; task_end = b0 + nb;
-    cv_go.notify_all();
-    cv_done.wait(lk, [&] { return next_task >= task_end && running == 0; });
+    for (int mode = 0; mode < 2; ++mode) {
+      task_mode = mode; task_b0 = b0;
+      task_begin = 0; next_task = 0; task_end = mode == 0 ? nb : 2 * nb;
+      cv_go.notify_all();
+      cv_done.wait(lk, [&] { return next_task >= task_end && running == 0; });
+    }
   };
   double t_sync_copy = 0;
   size_t lists_used = 0;
@@ -1673,6 +1706,10 @@ extern "C" int svo_elas_batch_dev(svo_ctx* ctx, const uint8_t* d_L, const uint8_
   }
   for (std::thread& t : pool) t.join();
   hipStreamSynchronize(s);   // the pinned table and list arena are read by copies until here
+  if (dbg) { extern std::atomic<long long> g_dly_us[4]; extern std::atomic<long long> g_dly_pts;
+    fprintf(stderr, "   delaunay per call: sort pts %.0f us, build %.0f, emit %.0f, sort triangles %.0f; points %.0f\n", (double)g_dly_us[0] / (2 * B), (double)g_dly_us[1] / (2 * B), (double)g_dly_us[2] / (2 * B), (double)g_dly_us[3] / (2 * B), (double)g_dly_pts / (2 * B));
+    for (int k = 0; k < 4; ++k) g_dly_us[k] = 0; g_dly_pts = 0; }
+  if (dbg) fprintf(stderr, "   host work per pair: filter %.0f us, triangulations %.0f us (thread time)\n", (double)dbg_filter_us / B, (double)dbg_tri_us / B);
   if (dbg) fprintf(stderr, "elas batch B=%d chunk=%d: enqueue %.2f ms (of it packing the lists %.2f), wait for A %.2f, host stages %.2f, tail wait %.2f, total %.2f\n",
                    B, C, t_enq, t_sync_copy, t_wait, t_host, ms(t_loop, tnow()), ms(t_start, tnow()));
   if (rc == SVO_OK) SVO_HIP(ctx, hipGetLastError());

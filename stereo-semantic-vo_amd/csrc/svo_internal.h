@@ -204,3 +204,8 @@ struct SvoTimer {
   SvoTimer(svo_ctx* c, const char* n, hipStream_t s = nullptr);   // s == nullptr: the ctx stream
   ~SvoTimer();
 };
+// Host CPUs this process may actually use at once: hardware threads, cut down to the cgroup CPU quota when there is one
+// (a container with `cpu.max = 1600000 100000` gets 16 however many cores the machine shows; worker pools larger than
+// that only buy throttling stalls - for every thread of the process, the one that feeds the GPU included).
+int svo_host_cpus();
+

@@ -17,6 +17,7 @@ import torch  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, nargs="+", default=[8, 32, 64])
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--synth", action="store_true", help="distinct synth-kitti frames (bench.py's elas leg) instead of one replicated pair")
 a = ap.parse_args()
 svo = svo_loader.load()
 L, R = util.urban_pair()
@@ -28,6 +29,14 @@ for B in a.batch:
     ctx = svo.Svo(W, H)
     dL = torch.zeros((B, H, stride), dtype=torch.uint8, device=dev); dR = torch.zeros_like(dL)
     dL[:, :, :W] = torch.from_numpy(L).to(dev); dR[:, :, :W] = torch.from_numpy(R).to(dev)
+    if a.synth:
+        import importlib
+        synth = importlib.import_module("stereo_semantic_vo_amd.synth")
+        for c0 in range(0, B, 64):
+            c = min(64, B - c0)
+            Ls, Rs, _ = synth.render_sequence(c, device=dev, start=c0)
+            dL[c0:c0 + c, :, :W] = Ls; dR[c0:c0 + c, :, :W] = Rs
+        L = dL[B - 1, :, :W].cpu().numpy(); R = dR[B - 1, :, :W].cpu().numpy()
     D1 = torch.zeros((B, H, W), dtype=torch.float32, device=dev); D2 = torch.zeros_like(D1)
     torch.cuda.synchronize()
     ctx.elas_batch_dev(dL.data_ptr(), dR.data_ptr(), stride, W, H, B, D1.data_ptr(), D2.data_ptr())

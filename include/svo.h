@@ -121,6 +121,8 @@ void svo_destroy(svo_ctx* ctx);
  * can force that path.
  * "track_nblk" (default 3, the maximum): runner-up blockers stored with each packed entry; with fewer the matching passes
  * consult the full distance row more often - same results, a test switch like "track_lcap".
+ * "frontend_overlap" (default 1): svo_frontend_batch_dev runs the two halves of a batch on two streams (scheduling only;
+ * off while svo_profile_enable is on, so that per-kernel times are those of kernels running alone).
  * "depth_source" (default 0): where svo_track_frame / svo_track_batch_dev take keypoint depth from - 0 the sparse
  * epipolar matcher (north star), 1 a dense ELAS map (svo_elas_*), 2 a dense MSA map (svo_msa_solve with d = 48: the
  * reference's live configuration, src/Tracking.cc:225-228 + src/frame.cc:82-91), both read per keypoint as

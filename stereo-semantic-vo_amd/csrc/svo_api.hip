@@ -202,6 +202,30 @@ extern "C" int svo_create(svo_ctx** out, int device, int W, int H, int max_kp, i
   }
   std::vector<int32_t> xofs, xalpha, yofs, ybeta;
   build_resize_tables(g, xofs, xalpha, yofs, ybeta);
+  {
+    // the pyramid in three launches: levels (1, 2), (3, 4), (5, 6, 7) - each group's rows of the intermediate levels stay
+    // in LDS (k_pyr_fused).  cap = the most rows of an intermediate level any strip needs.
+    const int groups[3][3] = {{1, 2, 16}, {3, 2, 16}, {5, 3, 12}};   // first level, levels, rows of the last level per strip
+    for (const auto& gr : groups) {
+      SvoPyrGroup pg{gr[0], gr[1], gr[2], 0, 0, 0};
+      if (pg.l0 + pg.nl > SVO_NLEVELS) continue;
+      const int lt = pg.l0 + pg.nl - 1;
+      for (int r0 = 0; r0 < g.h[lt]; r0 += pg.rt) {
+        int lo = r0, hi = std::min(g.h[lt], r0 + pg.rt);
+        for (int k = pg.nl - 2; k >= 0; --k) {
+          const int child = pg.l0 + k + 1;
+          const int nlo = lo == 0 ? 0 : yofs[g.ytab_off[child] + lo];
+          const int nhi = hi == g.h[child] ? g.h[pg.l0 + k] : std::min(yofs[g.ytab_off[child] + hi - 1] + 2, g.h[pg.l0 + k]);
+          lo = nlo; hi = nhi;
+          (k == 0 ? pg.cap0 : pg.cap1) = std::max(k == 0 ? pg.cap0 : pg.cap1, hi - lo);
+        }
+      }
+      pg.lds = 4 * ((size_t)pg.cap0 * (g.pitch[pg.l0] / 4) + 4 + (pg.nl == 3 ? (size_t)pg.cap1 * (g.pitch[pg.l0 + 1] / 4) + 4 : 0));
+      ctx->pyr_plan.push_back(pg);
+    }
+    for (const SvoPyrGroup& pg : ctx->pyr_plan)
+      if (pg.lds > 64 * 1024) { ctx->pyr_plan.clear(); break; }   // (very wide images: one launch per level)
+  }
   const size_t I = (size_t)ctx->max_images;
   ctx->stage_pitch = (W + 63) / 64 * 64;
   ctx->scratch_bytes = 16u << 20;
@@ -278,6 +302,8 @@ extern "C" void svo_destroy(svo_ctx* ctx) {
     for (auto e : ps->pool) hipEventDestroy(e);
     delete ps;
   }
+  for (hipStream_t st : ctx->fe_streams) hipStreamDestroy(st);
+  for (hipEvent_t e : ctx->fe_events) hipEventDestroy(e);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -288,6 +314,12 @@ extern "C" int svo_set_option(svo_ctx* ctx, const char* key, int value) {
   if (!strcmp(key, "fast_cand_cap")) {
     if (value < 0 || value > 2048) return SVO_E_INVALID;
     ctx->opt_fast_cand_cap = value;
+    return SVO_OK;
+  }
+  if (!strcmp(key, "pyr_fused")) { ctx->opt_pyr_fused = value != 0; return SVO_OK; }
+  if (!strcmp(key, "frontend_overlap")) {
+    if (value < 0 || value > 8) return SVO_E_INVALID;
+    ctx->opt_frontend_overlap = value;
     return SVO_OK;
   }
   if (!strcmp(key, "track_nblk")) {
@@ -735,6 +767,41 @@ extern "C" int svo_debug_epnp5(svo_ctx* ctx, const double Xw5[15], const double 
 }
 
 // ---- throughput mode ---------------------------------------------------------------------
+// The front end of pairs p0 .. p0 + b - 1 of a batch on stream `st`, in image slots 2 p0 .. 2 p0 + 2 b - 1 of the working
+// set (left images first, then the right ones), results copied to the caller's arrays.  The launchers read the
+// context's working-set pointers and stream: they are pointed at the slice for the duration of the call.
+static int frontend_slice(svo_ctx* ctx, hipStream_t st, const uint8_t* d_grayL, const uint8_t* d_grayR, int stride, int p0, int b,
+                          const svo_camera* cam, svo_kp* d_kpL, uint8_t* d_descL, int32_t* d_nL, float* d_uR, float* d_depth) {
+  const SvoGeom& g = ctx->g;
+  const size_t K = ctx->max_kp, base = 2 * (size_t)p0, img = (size_t)g.H * stride;
+  struct Saved {
+    uint8_t* pyr; uint32_t* corners; int32_t *counters, *hist; SvoSel* sel; int32_t* selcnt; svo_kp* kp; uint8_t* desc; int32_t* nkp;
+    float *uR, *depth; int32_t* sad; hipStream_t stream;
+  } sv{ctx->d_pyr, ctx->d_corners, ctx->d_counters, ctx->d_hist, ctx->d_sel, ctx->d_selcnt, ctx->d_kp, ctx->d_desc, ctx->d_nkp,
+       ctx->d_uR, ctx->d_depth, ctx->d_sad, ctx->stream};
+  ctx->d_pyr += base * g.pyr_bytes; ctx->d_corners += base * g.corner_entries; ctx->d_counters += base * SVO_NLEVELS;
+  ctx->d_hist += base * SVO_NLEVELS * 256; ctx->d_sel += base * SVO_NLEVELS * SVO_QMAX; ctx->d_selcnt += base * SVO_NLEVELS;
+  ctx->d_kp += base * K; ctx->d_desc += base * K * 32; ctx->d_nkp += base;
+  ctx->d_uR += (size_t)p0 * K; ctx->d_depth += (size_t)p0 * K; ctx->d_sad += (size_t)p0 * K;
+  ctx->stream = st;
+  int rc = svo_launch_orb(ctx, d_grayL + p0 * img, d_grayR + p0 * img, stride, b, 2 * b);
+  if (rc == SVO_OK) rc = svo_launch_stereo(ctx, d_grayL + p0 * img, d_grayR + p0 * img, stride, b, cam);
+  if (rc == SVO_OK) {
+    auto d2d = [&](void* dst, const void* src, size_t bytes) {
+      if (dst && hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = SVO_E_HIP;
+    };
+    d2d(d_kpL ? d_kpL + (size_t)p0 * K : nullptr, ctx->d_kp, sizeof(svo_kp) * K * b);
+    d2d(d_descL ? d_descL + (size_t)p0 * K * 32 : nullptr, ctx->d_desc, 32 * K * b);
+    d2d(d_nL ? d_nL + p0 : nullptr, ctx->d_nkp, 4 * (size_t)b);
+    d2d(d_uR ? d_uR + (size_t)p0 * K : nullptr, ctx->d_uR, 4 * K * b);
+    d2d(d_depth ? d_depth + (size_t)p0 * K : nullptr, ctx->d_depth, 4 * K * b);
+  }
+  ctx->d_pyr = sv.pyr; ctx->d_corners = sv.corners; ctx->d_counters = sv.counters; ctx->d_hist = sv.hist; ctx->d_sel = sv.sel;
+  ctx->d_selcnt = sv.selcnt; ctx->d_kp = sv.kp; ctx->d_desc = sv.desc; ctx->d_nkp = sv.nkp; ctx->d_uR = sv.uR; ctx->d_depth = sv.depth;
+  ctx->d_sad = sv.sad; ctx->stream = sv.stream;
+  return rc;
+}
+
 extern "C" int svo_frontend_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR,
                                       int stride, int B, const svo_camera* cam, svo_kp* d_kpL,
                                       uint8_t* d_descL, int32_t* d_nL, float* d_uR,
@@ -742,19 +809,33 @@ extern "C" int svo_frontend_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, cons
   if (!ctx || !d_grayL || !d_grayR || !cam || B < 1 || stride < ctx->g.W) return SVO_E_INVALID;
   if (B > ctx->max_batch) return SVO_E_CAPACITY;
   hipSetDevice(ctx->device);
-  int rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, B, 2 * B);
-  if (rc) return rc;
-  rc = svo_launch_stereo(ctx, d_grayL, d_grayR, stride, B, cam);
-  if (rc) return rc;
-  const size_t K = ctx->max_kp;
-#define D2D(dst, src, bytes) if (dst) SVO_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream))
-  D2D(d_kpL, ctx->d_kp, sizeof(svo_kp) * K * B);
-  D2D(d_descL, ctx->d_desc, 32 * K * B);
-  D2D(d_nL, ctx->d_nkp, 4 * (size_t)B);
-  D2D(d_uR, ctx->d_uR, 4 * K * B);
-  D2D(d_depth, ctx->d_depth, 4 * K * B);
-#undef D2D
-  return SVO_OK;
+  // Slices of the batch side by side on their own streams: the kernels of the chain are a mix of arithmetic-bound ones (k_fast: the
+  // vector ALUs 88 % busy) and latency-bound ones (k_select, k_stereo_*, the small pyramid levels: a few waves per CU
+  // waiting on memory) - side by side they fill each other's gaps.  With the per-kernel timers on (svo_profile_enable)
+  // the batch runs as one chain on one stream, so that a kernel's time is its own.
+  const int ns = std::min(ctx->opt_frontend_overlap, B / 8);
+  if (ns < 2 || ctx->profiling)
+    return frontend_slice(ctx, ctx->stream, d_grayL, d_grayR, stride, 0, B, cam, d_kpL, d_descL, d_nL, d_uR, d_depth);
+  while ((int)ctx->fe_streams.size() < ns - 1) {
+    hipStream_t st;
+    hipEvent_t e;
+    SVO_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    ctx->fe_streams.push_back(st);
+    SVO_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->fe_events.push_back(e);
+  }
+  if (!ctx->ev_frontend) SVO_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_frontend, hipEventDisableTiming));
+  SVO_HIP(ctx, hipEventRecord(ctx->ev_frontend, ctx->stream));            // whatever the ctx stream holds comes first
+  int rc = SVO_OK;
+  for (int k = ns - 1; k >= 0 && rc == SVO_OK; --k) {   // slice k: pairs [k B / ns, (k + 1) B / ns); slice 0 on the ctx stream
+    const int p0 = (int)((int64_t)k * B / ns), p1 = (int)((int64_t)(k + 1) * B / ns);
+    hipStream_t st = k ? ctx->fe_streams[k - 1] : ctx->stream;
+    if (k) SVO_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_frontend, 0));
+    rc = frontend_slice(ctx, st, d_grayL, d_grayR, stride, p0, p1 - p0, cam, d_kpL, d_descL, d_nL, d_uR, d_depth);
+    if (k) SVO_HIP(ctx, hipEventRecord(ctx->fe_events[k - 1], st));
+  }
+  for (int k = 1; k < ns; ++k) SVO_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->fe_events[k - 1], 0));   // callers order against the ctx stream
+  return rc;
 }
 
 // ---- profiling API -------------------------------------------------------------------------

@@ -48,6 +48,9 @@ struct SvoSel {
   int32_t pad;
 };
 
+// One launch of k_pyr_fused: levels l0 .. l0 + nl - 1 from level l0 - 1, strips of rt rows of the last level
+struct SvoPyrGroup { int l0, nl, rt, cap0, cap1; size_t lds; };
+
 struct SvoProfileEntry {
   std::string name;
   double total_ms = 0;
@@ -104,6 +107,11 @@ struct svo_ctx {
   int msa_lds_state = 0;         // k_msa_dp_bfs opted into > 64 KB of dynamic LDS: 0 not tried, 1 yes, -1 refused
   int pose_lds_state = 0;       // > 64 KB dynamic-LDS opt-in of the pose kernels: 0 untried, 1 granted, -1 refused
   int track_lds_state = 0;      // same for the tracker's kernels
+  std::vector<SvoPyrGroup> pyr_plan;  // the pyramid as fused launches (svo_create); empty: one launch per level
+  bool opt_pyr_fused = true;          // svo_set_option("pyr_fused")
+  int opt_frontend_overlap = 2;      // svo_set_option("frontend_overlap"): slices of a batch svo_frontend_batch_dev runs side by side (0 / 1: none)
+  std::vector<hipStream_t> fe_streams;   // their streams (slice 0 uses `stream`) ...
+  std::vector<hipEvent_t> fe_events;     // ... and completion events
   int opt_track_nblk = 3;       // svo_set_option("track_nblk"): runner-up blockers stored per packed entry (0..3)
   int opt_track_lcap = 8;       // svo_set_option("track_lcap"): packed entries a map point keeps before it goes "dense" (1..8)
   void* elas = nullptr;     // ElasState (svo_elas.hip), allocated on first svo_elas_process

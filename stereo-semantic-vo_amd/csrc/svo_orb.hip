@@ -151,6 +151,150 @@ __global__ __launch_bounds__(256) void k_pyr_level(SvoGeom g, ImgSrc s, int l, u
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Two or three consecutive levels per launch.  One workgroup = (image, strip of rows of the LAST of its levels, full
+// width): it computes the rows of the first level that strip depends on from the stored level below (HBM), keeps them in
+// LDS - and stores them: they are part of the pyramid - then the next level from LDS, and so on.  Neighbouring strips
+// recompute the one or two rows they share (identical values, stored twice).  Against one launch per level: every level
+// but the first is read from LDS instead of HBM / L2, and the seven dependent launches of a batch - the last of them a
+// few waves per CU - become three.  Arithmetic: k_pyr_level's, bit for bit.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pyr_four(uint32_t lo0, uint32_t hi0, uint32_t lo1, uint32_t hi1, const int (&sx)[4],
+                                             const int (&al)[4], int base, int bb) {
+  const int b0 = (int)(int16_t)(bb & 0xffff), b1 = bb >> 16;
+  const uint32_t B0 = (uint32_t)b0 << 12, B1 = (uint32_t)b1 << 12;
+  auto vterm = [](uint32_t Bs, uint32_t S) { return (uint32_t)(((uint64_t)(Bs & 0xffffffu) * ((S & ~15u) & 0xffffffu)) >> 32); };
+  uint32_t out = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t sel = 0x0c010c00u + (uint32_t)(sx[k] - base) * 0x00010001u;
+    const v2u16 p0 = __builtin_bit_cast(v2u16, __builtin_amdgcn_perm(hi0, lo0, sel));
+    const v2u16 p1 = __builtin_bit_cast(v2u16, __builtin_amdgcn_perm(hi1, lo1, sel));
+    const v2u16 al2 = __builtin_bit_cast(v2u16, (uint32_t)al[k]);
+    const uint32_t S0 = __builtin_amdgcn_udot2(p0, al2, 0u, false);
+    const uint32_t S1 = __builtin_amdgcn_udot2(p1, al2, 0u, false);
+    out |= ((vterm(B0, S0) + vterm(B1, S1) + 2) >> 2) << (8 * k);
+  }
+  return out;
+}
+
+template <int NL>
+__global__ __launch_bounds__(256) void k_pyr_fused(SvoGeom g, ImgSrc s, int l0, int RT, int cap0, int cap1, uint8_t* pyr,
+                                                   const int32_t* __restrict__ xofs, const int32_t* __restrict__ xalpha,
+                                                   const int32_t* __restrict__ yofs, const int32_t* __restrict__ ybeta) {
+  extern __shared__ uint32_t pyr_lds[];   // rows of level l0 (cap0 rows of pitch[l0]), then (NL == 3) of level l0 + 1; 16 bytes of slack each
+  const int img = blockIdx.y, lt = l0 + NL - 1;
+  const int r0 = blockIdx.x * RT, r1 = min(g.h[lt], r0 + RT);
+  if (r0 >= g.h[lt]) return;
+  int lo[NL], hi[NL];
+  lo[NL - 1] = r0; hi[NL - 1] = r1;
+#pragma unroll
+  for (int k = NL - 2; k >= 0; --k) {   // rows of level l0 + k that rows lo .. hi - 1 of level l0 + k + 1 read
+    const int child = l0 + k + 1;
+    lo[k] = lo[k + 1] == 0 ? 0 : yofs[g.ytab_off[child] + lo[k + 1]];
+    hi[k] = hi[k + 1] == g.h[child] ? g.h[l0 + k] : min(yofs[g.ytab_off[child] + hi[k + 1] - 1] + 2, g.h[l0 + k]);
+  }
+  uint32_t* buf[2] = {pyr_lds, pyr_lds + (size_t)cap0 * (g.pitch[l0] >> 2) + 4};
+  (void)cap1;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int l = l0 + k, dw = g.w[l], sw = g.w[l - 1], sh = g.h[l - 1], ncol = (dw + 3) >> 2;
+    const int rows = hi[k] - lo[k], nrb = (rows + 3) >> 2, dpw = g.pitch[l] >> 2;
+    uint8_t* dst = pyr + (size_t)img * g.pyr_bytes + g.loff[l];
+    int sp = 0;
+    const uint8_t* src = k == 0 ? level_ptr(g, s, img, l - 1, &sp) : nullptr;
+    const int spw = k > 0 ? g.pitch[l - 1] >> 2 : 0;
+    const uint32_t* lsrc = k > 0 ? buf[k - 1] : nullptr;
+    const bool rows_aligned = k == 0 && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)sp) & 3) == 0;
+    // one item = 4 (wide) x 4 (tall) output pixels, as in k_pyr_level: the x coefficients are fetched once for four rows
+    // and all eight source rows are requested before any is used
+    for (int idx = threadIdx.x; idx < nrb * ncol; idx += 256) {
+      const int rb = idx / ncol, c4 = idx - rb * ncol, dx4 = 4 * c4, ry0 = 4 * rb;
+      const int4 so = *reinterpret_cast<const int4*>(xofs + g.xtab_off[l] + dx4);
+      const int4 sa = *reinterpret_cast<const int4*>(xalpha + g.xtab_off[l] + dx4);
+      int syv[4], bbv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int y = min(lo[k] + ry0 + r, hi[k] - 1);
+        syv[r] = yofs[g.ytab_off[l] + y];
+        bbv[r] = ybeta[g.ytab_off[l] + y];
+      }
+      const int sx[4] = {so.x, so.y, so.z, so.w};
+      const int al[4] = {sa.x, sa.y, sa.z, sa.w};
+      const int base = sx[0], base_al = base & ~3;
+      const uint32_t shb = (uint32_t)(base & 3) * 8u;
+      uint32_t out[4] = {0, 0, 0, 0};
+      if (k > 0) {
+        // from LDS: three aligned words per source row (reads past the row's width land in its padding / the next row and
+        // are never selected: a tap beyond the last column only occurs with weight 0)
+        uint32_t a[4][3], b[4][3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t* q0 = lsrc + (size_t)(syv[r] - lo[k - 1]) * spw + (base_al >> 2);
+          const uint32_t* q1 = lsrc + (size_t)(min(syv[r] + 1, sh - 1) - lo[k - 1]) * spw + (base_al >> 2);
+          a[r][0] = q0[0]; a[r][1] = q0[1]; a[r][2] = q0[2]; b[r][0] = q1[0]; b[r][1] = q1[1]; b[r][2] = q1[2];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          out[r] = pyr_four(__builtin_amdgcn_alignbit(a[r][1], a[r][0], shb), __builtin_amdgcn_alignbit(a[r][2], a[r][1], shb),
+                            __builtin_amdgcn_alignbit(b[r][1], b[r][0], shb), __builtin_amdgcn_alignbit(b[r][2], b[r][1], shb), sx, al,
+                            base, bbv[r]);
+      } else {
+        struct __attribute__((aligned(4))) u96 { uint32_t a, b, c; };
+        if (rows_aligned && base_al + 12 <= sw) {
+          u96 q0[4], q1[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            q0[r] = *reinterpret_cast<const u96*>(src + (size_t)syv[r] * sp + base_al);
+            q1[r] = *reinterpret_cast<const u96*>(src + (size_t)min(syv[r] + 1, sh - 1) * sp + base_al);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            out[r] = pyr_four(__builtin_amdgcn_alignbit(q0[r].b, q0[r].a, shb), __builtin_amdgcn_alignbit(q0[r].c, q0[r].b, shb),
+                              __builtin_amdgcn_alignbit(q1[r].b, q1[r].a, shb), __builtin_amdgcn_alignbit(q1[r].c, q1[r].b, shb), sx, al,
+                              base, bbv[r]);
+        } else if (base + 8 <= sw) {
+          uint64_t w0[4], w1[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            w0[r] = *reinterpret_cast<const u64_unaligned*>(src + (size_t)syv[r] * sp + base);
+            w1[r] = *reinterpret_cast<const u64_unaligned*>(src + (size_t)min(syv[r] + 1, sh - 1) * sp + base);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            out[r] = pyr_four((uint32_t)w0[r], (uint32_t)(w0[r] >> 32), (uint32_t)w1[r], (uint32_t)(w1[r] >> 32), sx, al, base, bbv[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const uint8_t* p0 = src + (size_t)syv[r] * sp;
+            const uint8_t* p1 = src + (size_t)min(syv[r] + 1, sh - 1) * sp;
+            const int b0 = (int)(int16_t)(bbv[r] & 0xffff), b1 = bbv[r] >> 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (dx4 + q < dw) {
+                const int sx0 = sx[q], sx1 = min(sx0 + 1, sw - 1);
+                const int a0 = (int)(int16_t)(al[q] & 0xffff), a1 = al[q] >> 16;
+                const int S0 = p0[sx0] * a0 + p0[sx1] * a1;
+                const int S1 = p1[sx0] * a0 + p1[sx1] * a1;
+                int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+                v = min(max(v, 0), 255);
+                out[r] |= (uint32_t)v << (8 * q);
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (ry0 + r >= rows) break;
+        *reinterpret_cast<uint32_t*>(dst + (size_t)(lo[k] + ry0 + r) * g.pitch[l] + dx4) = out[r];
+        if (k < NL - 1) buf[k][(size_t)(ry0 + r) * dpw + c4] = out[r];
+      }
+    }
+    if (k < NL - 1) __syncthreads();
+  }
+}
+
 // Corner score of TWO horizontally adjacent pixels at once in packed 16-bit lanes
 // (v_pk_sub/min/max_i16): d[i] = centre - ring[i]; score = max over the 16 arcs of 9 of
 // min(d) (dark ring) and of min(-d) (bright ring), minus 1; 0 unless that exceeds the
@@ -785,10 +929,23 @@ int svo_launch_orb(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR,
   SVO_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(int32_t) * (size_t)nimg * SVO_NLEVELS, st));
   {
     SvoTimer t(ctx, "k_pyr_level");
-    for (int l = 1; l < SVO_NLEVELS; ++l) {
-      dim3 grid((g.w[l] / 4 + 64) / 64, (g.h[l] + 15) / 16, nimg);
-      hipLaunchKernelGGL(k_pyr_level, grid, dim3(64, 4, 1), 0, st, g, s, l, ctx->d_pyr, ctx->d_xofs,
-                         ctx->d_xalpha, ctx->d_yofs, ctx->d_ybeta);
+    if (ctx->opt_pyr_fused && !ctx->pyr_plan.empty()) {
+      for (const SvoPyrGroup& pg : ctx->pyr_plan) {
+        const int lt = pg.l0 + pg.nl - 1;
+        const dim3 grid((g.h[lt] + pg.rt - 1) / pg.rt, nimg);
+        if (pg.nl == 2)
+          hipLaunchKernelGGL(k_pyr_fused<2>, grid, dim3(256), pg.lds, st, g, s, pg.l0, pg.rt, pg.cap0, pg.cap1, ctx->d_pyr, ctx->d_xofs,
+                             ctx->d_xalpha, ctx->d_yofs, ctx->d_ybeta);
+        else
+          hipLaunchKernelGGL(k_pyr_fused<3>, grid, dim3(256), pg.lds, st, g, s, pg.l0, pg.rt, pg.cap0, pg.cap1, ctx->d_pyr, ctx->d_xofs,
+                             ctx->d_xalpha, ctx->d_yofs, ctx->d_ybeta);
+      }
+    } else {
+      for (int l = 1; l < SVO_NLEVELS; ++l) {
+        dim3 grid((g.w[l] / 4 + 64) / 64, (g.h[l] + 15) / 16, nimg);
+        hipLaunchKernelGGL(k_pyr_level, grid, dim3(64, 4, 1), 0, st, g, s, l, ctx->d_pyr, ctx->d_xofs,
+                           ctx->d_xalpha, ctx->d_yofs, ctx->d_ybeta);
+      }
     }
   }
   {

@@ -388,6 +388,58 @@ def test_frontend_batch_dev_equals_per_pair(pkg, orc):
     svo.close()
 
 
+def test_pyramid_one_launch_per_level_path_bit_exact(pkg, orc):
+    """The pyramid is built by three fused launches by default (levels kept in LDS); the launch-per-level kernel stays as
+    the fallback for images too wide for that - both must give the oracle's levels."""
+    img = util.urban_pair()[0]
+    levels = orc.pyramid_levels(orc.build_pyramid(img), util.KITTI_W, util.KITTI_H)
+    for fused in (0, 1):
+        svo = pkg.Svo(util.KITTI_W, util.KITTI_H)
+        svo.set_option("pyr_fused", fused)
+        svo.orb_extract(img)
+        for l in range(8):
+            assert np.array_equal(svo.debug_pyramid_level(0, l), levels[l]), "fused %d level %d" % (fused, l)
+        svo.close()
+
+
+@pytest.mark.parametrize("slices", [1, 2, 3])
+def test_frontend_batch_slices_on_streams_equal_oracle(pkg, orc, slices):
+    """svo_frontend_batch_dev runs slices of a batch side by side on their own streams (scheduling only): every pair's
+    outputs must still be the oracle's, whatever the number of slices."""
+    import torch
+    W, H, B, pitch = 640, 240, 24, 704
+    cam = pkg.Camera(**pkg.KITTI_00_02)
+    pairs = [util.shifted_pair(70 + i, W, H, disparity=4 + (5 * i) % 40) for i in range(B)]
+    dev = torch.device("cuda", 0)
+    dL = torch.zeros((B, H, pitch), dtype=torch.uint8, device=dev)
+    dR = torch.zeros_like(dL)
+    for i, (L, R) in enumerate(pairs):
+        dL[i, :, :W] = torch.from_numpy(L).to(dev); dR[i, :, :W] = torch.from_numpy(R).to(dev)
+    kp = torch.zeros((B, 500, 28), dtype=torch.uint8, device=dev)
+    desc = torch.zeros((B, 500, 32), dtype=torch.uint8, device=dev)
+    n = torch.zeros(B, dtype=torch.int32, device=dev)
+    uR = torch.zeros((B, 500), dtype=torch.float32, device=dev)
+    depth = torch.zeros((B, 500), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    svo = pkg.Svo(W, H, max_batch=B)
+    svo.set_option("frontend_overlap", slices)
+    for _ in range(2):   # the second call reuses streams / working set slices
+        svo.frontend_batch_dev(dL.data_ptr(), dR.data_ptr(), pitch, B, cam, kp.data_ptr(), desc.data_ptr(),
+                               n.data_ptr(), uR.data_ptr(), depth.data_ptr())
+    svo.sync()
+    n_h = n.cpu().numpy(); kp_h = kp.cpu().numpy().view(pkg.KP_DTYPE).reshape(B, 500)
+    desc_h = desc.cpu().numpy(); depth_h = depth.cpu().numpy()
+    for i in (0, 7, 8, 11, 12, 15, 16, 23):
+        L, R = pairs[i]
+        r = orc.stereo_frame(L, R, cam.bf, cam.fx)
+        m = len(r["kpL"])
+        assert n_h[i] == m, "pair %d" % i
+        same_kp(kp_h[i][:m], r["kpL"])
+        assert np.array_equal(desc_h[i][:m], r["dL"])
+        assert np.array_equal(depth_h[i][:m].view(np.uint32), r["depth"].view(np.uint32))
+    svo.close()
+
+
 @pytest.mark.parametrize("W,H", [(1344, 391), (333, 207), (96, 96), (2048, 96)])
 def test_orb_other_image_sizes(pkg, orc, W, H):
     if (W, H) == (1344, 391):

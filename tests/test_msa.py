@@ -154,6 +154,22 @@ def test_gpu_tree_dp_equals_oracle(pkg, N, D, chain):
 
 
 @pytest.mark.gpu
+def test_gpu_tree_dp_level_launch_path_equals_oracle(pkg, monkeypatch):
+    """TreeDp runs as one launch per aggregation (a workgroup per disparity walks the levels, k_msa_dp_bfs); the kernels
+    with one launch per level stay for trees whose widest level does not fit LDS - forced here."""
+    monkeypatch.setenv("SVO_MSA_LEVEL_LAUNCHES", "1")
+    rng = np.random.default_rng(77)
+    seq, cp, ch, cc = random_tree(rng, 6000, 0.7)
+    cost = rng.random((6000, 33), np.float32) * 3
+    s = pkg.Svo(640, 240)
+    g = s.msa_tree_dp(cost, seq, cp, ch, cc, 0, 0.1)
+    assert g.tobytes() == ob.msa_tree_dp(cost, seq, cp, ch, cc, 0, ob.msa_exp_table(0.1)).tobytes()
+    monkeypatch.delenv("SVO_MSA_LEVEL_LAUNCHES")
+    assert s.msa_tree_dp(cost, seq, cp, ch, cc, 0, 0.1).tobytes() == g.tobytes()
+    s.close()
+
+
+@pytest.mark.gpu
 def test_gpu_wta_and_lrcheck_equal_oracle(pkg):
     rng = np.random.default_rng(9)
     H, W, D = 60, 97, 49

@@ -46,6 +46,11 @@ struct EpnpWaveLds {
     __builtin_amdgcn_wave_barrier();                      \
   } while (0)
 
+// Inside the eigen-solver's loop the wave is alone with its LDS workspace: LDS instructions of one wave execute in issue
+// order, so a write is visible to the reads issued after it without waiting for its completion - only the compiler must
+// not reorder them.  (The full fence costs the write's latency twice per Jacobi step.)
+#define EPNP_WAVE_ORDER() __builtin_amdgcn_wave_barrier()
+
 // float64 reciprocal square root / reciprocal: the hardware's own f64 approximation (v_rsq_f64 / v_rcp_f64) plus one
 // Newton step - a handful of dependent instructions instead of the IEEE sqrt / division sequences.  The Jacobi
 // rotations only need c^2 + s^2 = 1 to rounding.
@@ -58,6 +63,15 @@ __device__ __forceinline__ double epnp_rsqrt(double x) {
 __device__ __forceinline__ double epnp_rcp(double x) {
 #pragma clang fp contract(fast)
   double r = __builtin_amdgcn_rcp(x);
+  r = r * (2.0 - x * r);
+  return r;
+}
+// the same with a second Newton step: full double precision (the pivots of the small normal-equation solves), still a
+// third of the dependent instructions of an IEEE division
+__device__ __forceinline__ double epnp_rcp2(double x) {
+#pragma clang fp contract(fast)
+  double r = __builtin_amdgcn_rcp(x);
+  r = r * (2.0 - x * r);
   r = r * (2.0 - x * r);
   return r;
 }
@@ -148,10 +162,12 @@ __device__ inline void epnp_svd3(const double* A, double* w, double* Ut, double*
 // least squares min |A x - b| for a 6 x NC system through the normal equations, solved by an unpivoted LDL^T
 // (the Gram matrix of a full-rank A is positive definite; a rank-deficient candidate produces non-finite betas and
 // loses the comparison of reprojection errors)
+// `active` < NC: only the first `active` columns are unknowns (the others must be zero columns): their diagonal is set to
+// 1, which leaves the leading block's factorisation - every operation of it - as it is and makes the padding solve to 0.
 template <int NC>
-__device__ inline void epnp_lsq6(const double* A /*6 x NC row-major*/, const double* b, double* x) {
+__device__ inline void epnp_lsq6(const double* A /*6 x NC row-major*/, const double* b, double* x, int active = NC) {
 #pragma clang fp contract(fast)
-  double N[NC][NC], y[NC], Lm[NC][NC], D[NC];
+  double N[NC][NC], y[NC], Lm[NC][NC], D[NC], Dinv[NC];
 #pragma unroll
   for (int r = 0; r < NC; ++r) {
 #pragma unroll
@@ -166,6 +182,7 @@ __device__ inline void epnp_lsq6(const double* A /*6 x NC row-major*/, const dou
 #pragma unroll
     for (int k = 0; k < 6; ++k) s += A[NC * k + r] * b[k];
     y[r] = s;
+    if (r >= active) N[r][r] = 1.0;
   }
 #pragma unroll
   for (int j = 0; j < NC; ++j) {
@@ -174,7 +191,8 @@ __device__ inline void epnp_lsq6(const double* A /*6 x NC row-major*/, const dou
     for (int k = 0; k < NC; ++k)
       if (k < j) d -= Lm[j][k] * Lm[j][k] * D[k];
     D[j] = d;
-    const double inv = 1.0 / d;
+    const double inv = epnp_rcp2(d);
+    Dinv[j] = inv;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       if (i <= j) continue;
@@ -192,7 +210,7 @@ __device__ inline void epnp_lsq6(const double* A /*6 x NC row-major*/, const dou
       if (k < i) y[i] -= Lm[i][k] * y[k];
   }
 #pragma unroll
-  for (int i = 0; i < NC; ++i) y[i] /= D[i];
+  for (int i = 0; i < NC; ++i) y[i] *= Dinv[i];
 #pragma unroll
   for (int i = NC - 1; i >= 0; --i) {
 #pragma unroll
@@ -319,7 +337,7 @@ __device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* K, double* R_out
         epnp_d2 o; o.x = c; o.y = s;
         *reinterpret_cast<epnp_d2*>(S.cs[lane]) = o;
       }
-      EPNP_WAVE_SYNC();
+      EPNP_WAVE_ORDER();
       // every operand address is fixed: all loads of the step in one round trip
       const epnp_d2 ci = *reinterpret_cast<const epnp_d2*>(S.cs[gi]), cj = *reinterpret_cast<const epnp_d2*>(S.cs[gj]);
       const epnp_d2 a0 = *reinterpret_cast<const epnp_d2*>(&S.A[12 * (2 * gi) + 2 * gj]);
@@ -342,7 +360,7 @@ __device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* K, double* R_out
       }
       S.V[v0a] = x0a; S.V[v0b] = x0b;
       if (lane < 8) { S.V[v1a] = x1a; S.V[v1b] = x1b; }
-      EPNP_WAVE_SYNC();
+      EPNP_WAVE_ORDER();
     }
     if (lane == 0) S.sweeps = sweep + 1;
     // quadratic convergence: once a sweep met no off-diagonal entry above 1e-7 * trace, what it leaves behind is of the
@@ -400,34 +418,29 @@ __device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* K, double* R_out
     double rho[6], betas[4];
 #pragma unroll
     for (int k = 0; k < 6; ++k) rho[k] = S.rho[k];
-    if (lane == 0) {          // find_betas_approx_1: [B11 B12 B13 B14]
-      double l[24], b4[4];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) { l[4 * i] = L[10 * i]; l[4 * i + 1] = L[10 * i + 1]; l[4 * i + 2] = L[10 * i + 3]; l[4 * i + 3] = L[10 * i + 6]; }
-      epnp_lsq6<4>(l, rho, b4);
-      if (b4[0] < 0) { betas[0] = sqrt(-b4[0]); betas[1] = -b4[1] / betas[0]; betas[2] = -b4[2] / betas[0]; betas[3] = -b4[3] / betas[0]; }
-      else { betas[0] = sqrt(b4[0]); betas[1] = b4[1] / betas[0]; betas[2] = b4[2] / betas[0]; betas[3] = b4[3] / betas[0]; }
-    } else if (lane == 1) {   // find_betas_approx_2: [B11 B12 B22]
-      double l[18], b3[3];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) { l[3 * i] = L[10 * i]; l[3 * i + 1] = L[10 * i + 1]; l[3 * i + 2] = L[10 * i + 2]; }
-      epnp_lsq6<3>(l, rho, b3);
-      if (b3[0] < 0) { betas[0] = sqrt(-b3[0]); betas[1] = (b3[2] < 0) ? sqrt(-b3[2]) : 0.0; }
-      else { betas[0] = sqrt(b3[0]); betas[1] = (b3[2] > 0) ? sqrt(b3[2]) : 0.0; }
-      if (b3[1] < 0) betas[0] = -betas[0];
-      betas[2] = 0.0; betas[3] = 0.0;
-    } else {                  // find_betas_approx_3: [B11 B12 B22 B13 B23]
+    // The three initialisations solve 6 x 4, 6 x 3 and 6 x 5 systems over different columns of L: one padded 6 x 5
+    // solve for all three lanes (same operations on the active block as the small solves), so that the lanes do not
+    // run three different code paths one after the other.
+    {
+      const int nc = lane == 0 ? 4 : (lane == 1 ? 3 : 5);
       double l[30], b5[5];
 #pragma unroll
-      for (int i = 0; i < 6; ++i)
+      for (int k = 0; k < 5; ++k) {
+        const int col = lane == 0 ? (k == 2 ? 3 : (k == 3 ? 6 : k)) : k;   // approx_1: [B11 B12 B13 B14] = columns 0 1 3 6
 #pragma unroll
-        for (int c = 0; c < 5; ++c) l[5 * i + c] = L[10 * i + c];
-      epnp_lsq6<5>(l, rho, b5);
-      if (b5[0] < 0) { betas[0] = sqrt(-b5[0]); betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0; }
-      else { betas[0] = sqrt(b5[0]); betas[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0; }
-      if (b5[1] < 0) betas[0] = -betas[0];
-      betas[2] = b5[3] / betas[0];
-      betas[3] = 0.0;
+        for (int i = 0; i < 6; ++i) l[5 * i + k] = k < nc ? L[10 * i + col] : 0.0;
+      }
+      epnp_lsq6<5>(l, rho, b5, nc);
+      if (lane == 0) {          // find_betas_approx_1
+        if (b5[0] < 0) { betas[0] = sqrt(-b5[0]); betas[1] = -b5[1] / betas[0]; betas[2] = -b5[2] / betas[0]; betas[3] = -b5[3] / betas[0]; }
+        else { betas[0] = sqrt(b5[0]); betas[1] = b5[1] / betas[0]; betas[2] = b5[2] / betas[0]; betas[3] = b5[3] / betas[0]; }
+      } else {                  // find_betas_approx_2: [B11 B12 B22], approx_3: [B11 B12 B22 B13 B23]
+        if (b5[0] < 0) { betas[0] = sqrt(-b5[0]); betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0; }
+        else { betas[0] = sqrt(b5[0]); betas[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0; }
+        if (b5[1] < 0) betas[0] = -betas[0];
+        betas[2] = lane == 2 ? b5[3] / betas[0] : 0.0;
+        betas[3] = 0.0;
+      }
     }
     if (lane == 0) S.stamp[5] = clock64();
     // gauss_newton: five steps on the six distance constraints

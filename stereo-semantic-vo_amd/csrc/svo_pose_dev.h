@@ -574,6 +574,41 @@ __device__ __forceinline__ int pnp_bound_after(const int* cnt, const int* ok, in
   return niters;
 }
 
+// pnp_update_iters's transcendental part for a sample with consensus g of n, computed by the sample's own thread ahead of the
+// sequential rule below: *ld = log(1 - (1 - ep)^5) (or +1: "denominator below DBL_MIN", the function returns 0 then),
+// *r = rint(log(0.01) / *ld).
+__device__ __forceinline__ void pnp_update_terms(int g, int n, double* ld, int* r) {
+  double ep = (double)(n - g) / n;
+  ep = fmax(ep, 0.); ep = fmin(ep, 1.);
+  const double denom = 1. - pow(1. - ep, 5.0);
+  if (denom < 2.2250738585072014e-308) { *ld = 1.0; *r = 0; return; }
+  const double num = log(fmax(1. - 0.99, 2.2250738585072014e-308));
+  *ld = log(denom);
+  *r = *ld < 0 ? (int)rint(num / *ld) : 0;
+}
+// the sequential rule with those terms at hand (same decisions as pnp_select)
+__device__ __forceinline__ int pnp_select_pre(const int* cnt, const int* ok, const double* ld, const int* r, int n, int* good, int* iters) {
+  int niters = PNP_HYP, maxGood = 0, best = -1, run = 0;
+  if (n == 5) {
+    *good = ok[0] ? 5 : 0; *iters = 1;
+    return ok[0] ? 0 : -1;
+  }
+  const double num = log(fmax(1. - 0.99, 2.2250738585072014e-308));
+  for (int iter = 0; iter < niters; ++iter) {
+    ++run;
+    if (!ok[iter]) continue;
+    const int g = cnt[iter];
+    if (g > max(maxGood, 4)) {
+      maxGood = g; best = iter;
+      const double d = ld[iter];
+      if (d == 1.0) niters = 0;
+      else niters = d >= 0 || -num >= niters * (-d) ? niters : r[iter];
+    }
+  }
+  *good = maxGood; *iters = run;
+  return best;
+}
+
 // RANSACPointSetRegistrator::run over the precomputed samples (one thread): sample `iter` replaces the best one iff its
 // consensus is larger (and > 4), and the iteration bound shrinks with the inlier ratio.  Returns the winning sample
 // (-1: none), *good its consensus, *iters the samples visited.

@@ -821,7 +821,8 @@ struct TpLds {
   PoseLds pose;
   alignas(16) int sm[16];
   float sT[16], sRwc[9], stwc[3];
-  int cnt[PNP_HYP], ok[PNP_HYP], best, good, iters;
+  int cnt[PNP_HYP], ok[PNP_HYP], upd_r[PNP_HYP], best, good, iters;
+  double upd_ld[PNP_HYP];
 };
 
 __global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, const TrackWork* work, const svo_kp* kp,
@@ -853,11 +854,18 @@ __global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, const TrackWor
   if (tid < 4) st->K[tid] = (double)((const float*)&st->cam)[tid];
   // ---- PnP initial pose (src/pnpmatch.cc:212-247): no prior; if solvePnPRansac fails the last pose stays ----------
   const bool ran = !skip && n_edges >= 5;
-  if (ran && tid < PNP_HYP) { S.cnt[tid] = st->hyp[tid].cnt; S.ok[tid] = st->hyp[tid].ok; }
+  if (ran && tid < PNP_HYP) {
+    // every sample's thread prepares the pow / log terms the iteration bound would need if that sample became the best
+    const int c = st->hyp[tid].cnt, o = st->hyp[tid].ok;
+    S.cnt[tid] = c; S.ok[tid] = o;
+    double ld = 1.0; int r = 0;
+    if (o && c > 4 && n_edges > 5) pnp_update_terms(c, n_edges, &ld, &r);
+    S.upd_ld[tid] = ld; S.upd_r[tid] = r;
+  }
   __syncthreads();
   if (tid == 0) {
     int good = 0, iters = 0;
-    S.best = ran ? pnp_select(S.cnt, S.ok, n_edges, &good, &iters) : -1;
+    S.best = ran ? pnp_select_pre(S.cnt, S.ok, S.upd_ld, S.upd_r, n_edges, &good, &iters) : -1;
     S.good = good; S.iters = iters;
   }
   __syncthreads();

@@ -15,14 +15,68 @@
 
 struct Se3 { double q[4]; double t[3]; };
 
+// The scalar float64 path of the LM (thread 0: LDL^T, exp map, quaternion updates) is a chain of ~20 divisions, 5 square
+// roots, a sine and a cosine per trial; as IEEE sequences they were 6.6 k of the 14 k cycles of an LM iteration.  These
+// are the hardware's reciprocal / reciprocal square root refined by two Newton steps on FMAs (<= 1-2 ulp: below what
+// libm's sin / cos already differ by from the CPU's), and the two series of the exponential map for small angles.
+__device__ __forceinline__ double pose_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+  r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+  return r;
+}
+__device__ __forceinline__ double pose_sqrt(double x) {   // x >= 0
+  if (!(x > 0.0)) return 0.0;
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;                      // Goldschmidt: g -> sqrt(x), h -> 1 / (2 sqrt(x))
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+  r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+  return __builtin_fma(__builtin_fma(-g, g, x), h, g);   // one correction with the exact residual x - g^2
+}
+// sin(t) / t, (1 - cos t) / t^2, (t - sin t) / t^3 for |t| < 0.5 (every LM step; larger rotations take libm's sin / cos):
+// alternating series in t^2, truncated below 1e-17 relative
+__device__ __forceinline__ void pose_exp_coeffs(double t, double* a, double* b, double* c) {
+  const double x = t * t;
+  // a = 1 - x/3! + x^2/5! - ... ;  b = 1/2! - x/4! + x^2/6! - ... ;  c = 1/3! - x/5! + x^2/7! - ...
+  double pa = -1.0 / 121645100408832000.0, pb = 1.0 / 6402373705728000.0, pc = 1.0 / 121645100408832000.0;   // 1/19!, 1/18!, 1/19!
+  pa = __builtin_fma(pa, x, 1.0 / 355687428096000.0);      // 1/17!
+  pa = __builtin_fma(pa, x, -1.0 / 1307674368000.0);       // 1/15!
+  pa = __builtin_fma(pa, x, 1.0 / 6227020800.0);           // 1/13!
+  pa = __builtin_fma(pa, x, -1.0 / 39916800.0);            // 1/11!
+  pa = __builtin_fma(pa, x, 1.0 / 362880.0);               // 1/9!
+  pa = __builtin_fma(pa, x, -1.0 / 5040.0);                // 1/7!
+  pa = __builtin_fma(pa, x, 1.0 / 120.0);                  // 1/5!
+  pa = __builtin_fma(pa, x, -1.0 / 6.0);                   // 1/3!
+  pa = __builtin_fma(pa, x, 1.0);
+  pb = __builtin_fma(pb, x, -1.0 / 20922789888000.0);      // 1/16!
+  pb = __builtin_fma(pb, x, 1.0 / 87178291200.0);          // 1/14!
+  pb = __builtin_fma(pb, x, -1.0 / 479001600.0);           // 1/12!
+  pb = __builtin_fma(pb, x, 1.0 / 3628800.0);              // 1/10!
+  pb = __builtin_fma(pb, x, -1.0 / 40320.0);               // 1/8!
+  pb = __builtin_fma(pb, x, 1.0 / 720.0);                  // 1/6!
+  pb = __builtin_fma(pb, x, -1.0 / 24.0);                  // 1/4!
+  pb = __builtin_fma(pb, x, 0.5);
+  pc = __builtin_fma(pc, x, -1.0 / 355687428096000.0);     // 1/17!
+  pc = __builtin_fma(pc, x, 1.0 / 1307674368000.0);        // 1/15!
+  pc = __builtin_fma(pc, x, -1.0 / 6227020800.0);          // 1/13!
+  pc = __builtin_fma(pc, x, 1.0 / 39916800.0);             // 1/11!
+  pc = __builtin_fma(pc, x, -1.0 / 362880.0);              // 1/9!
+  pc = __builtin_fma(pc, x, 1.0 / 5040.0);                 // 1/7!
+  pc = __builtin_fma(pc, x, -1.0 / 120.0);                 // 1/5!
+  pc = __builtin_fma(pc, x, 1.0 / 6.0);                    // 1/3!
+  *a = pa; *b = pb; *c = pc;
+}
+
 // Eigen Quaternion(Matrix3): the three "largest diagonal" cases are written out so that nothing is
 // indexed dynamically (dynamic indices would push the matrix into scratch memory).
 __device__ __forceinline__ void quat_from_R(const double m[9], double q[4]) {
   double t = m[0] + m[4] + m[8];
   if (t > 0.0) {
-    t = sqrt(t + 1.0);
+    t = pose_sqrt(t + 1.0);
     q[3] = 0.5 * t;
-    t = 0.5 / t;
+    t = 0.5 * pose_rcp(t);
     q[0] = (m[7] - m[5]) * t;
     q[1] = (m[2] - m[6]) * t;
     q[2] = (m[3] - m[1]) * t;
@@ -31,24 +85,25 @@ __device__ __forceinline__ void quat_from_R(const double m[9], double q[4]) {
     if (m[4] > m[0]) i = 1;
     if (m[8] > (i == 1 ? m[4] : m[0])) i = 2;
     if (i == 0) {            // j = 1, k = 2
-      t = sqrt(m[0] - m[4] - m[8] + 1.0);
-      q[0] = 0.5 * t; t = 0.5 / t;
+      t = pose_sqrt(m[0] - m[4] - m[8] + 1.0);
+      q[0] = 0.5 * t; t = 0.5 * pose_rcp(t);
       q[3] = (m[7] - m[5]) * t; q[1] = (m[3] + m[1]) * t; q[2] = (m[6] + m[2]) * t;
     } else if (i == 1) {     // j = 2, k = 0
-      t = sqrt(m[4] - m[8] - m[0] + 1.0);
-      q[1] = 0.5 * t; t = 0.5 / t;
+      t = pose_sqrt(m[4] - m[8] - m[0] + 1.0);
+      q[1] = 0.5 * t; t = 0.5 * pose_rcp(t);
       q[3] = (m[2] - m[6]) * t; q[2] = (m[7] + m[5]) * t; q[0] = (m[1] + m[3]) * t;
     } else {                 // j = 0, k = 1
-      t = sqrt(m[8] - m[0] - m[4] + 1.0);
-      q[2] = 0.5 * t; t = 0.5 / t;
+      t = pose_sqrt(m[8] - m[0] - m[4] + 1.0);
+      q[2] = 0.5 * t; t = 0.5 * pose_rcp(t);
       q[3] = (m[3] - m[1]) * t; q[0] = (m[2] + m[6]) * t; q[1] = (m[5] + m[7]) * t;
     }
   }
 }
 __device__ __forceinline__ void normalize_rotation(Se3& s) {
   if (s.q[3] < 0) { s.q[0] = -s.q[0]; s.q[1] = -s.q[1]; s.q[2] = -s.q[2]; s.q[3] = -s.q[3]; }
-  const double n = sqrt(s.q[0] * s.q[0] + s.q[1] * s.q[1] + s.q[2] * s.q[2] + s.q[3] * s.q[3]);
-  s.q[0] /= n; s.q[1] /= n; s.q[2] /= n; s.q[3] /= n;
+  const double n2 = s.q[0] * s.q[0] + s.q[1] * s.q[1] + s.q[2] * s.q[2] + s.q[3] * s.q[3];
+  const double in = pose_rcp(pose_sqrt(n2));
+  s.q[0] *= in; s.q[1] *= in; s.q[2] *= in; s.q[3] *= in;
 }
 __device__ __forceinline__ void quat_mul(const double a[4], const double b[4], double o[4]) {
   const double w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
@@ -90,7 +145,7 @@ __device__ __forceinline__ void se3_to_T(const Se3& s, double* T) {
 // SE3Quat::exp (se3quat.h:223-257)
 __device__ void se3_exp(const double u[6], Se3& out) {
   const double om0 = u[0], om1 = u[1], om2 = u[2];
-  const double theta = sqrt(om0 * om0 + om1 * om1 + om2 * om2);
+  const double theta = pose_sqrt(om0 * om0 + om1 * om1 + om2 * om2);
   const double Om[9] = {0, -om2, om1, om2, 0, -om0, -om1, om0, 0};
   double Om2[9], R[9], V[9];
 #pragma unroll
@@ -102,8 +157,12 @@ __device__ void se3_exp(const double u[6], Se3& out) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) { R[i] = (i % 4 == 0 ? 1.0 : 0.0) + Om[i] + Om2[i]; V[i] = R[i]; }
   } else {
-    const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta),
-                 c = (theta - sin(theta)) / (theta * theta * theta);
+    double a, b, c;
+    if (theta < 0.5) {
+      pose_exp_coeffs(theta, &a, &b, &c);
+    } else {
+      a = sin(theta) / theta; b = (1 - cos(theta)) / (theta * theta); c = (theta - sin(theta)) / (theta * theta * theta);
+    }
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
       const double I = (i % 4 == 0 ? 1.0 : 0.0);
@@ -134,7 +193,7 @@ __device__ __forceinline__ void huber(double e, double delta, double dsqr, doubl
 // would be placed in scratch memory, and this sits on the serial path of every LM / RANSAC step).
 // Returns 0 if a pivot is not positive (Eigen LDLT::isPositive() false).
 __device__ __forceinline__ int ldlt6_solve(const double* Hin, const double* b, double* x) {
-  double L[6][6], D[6], y[6];
+  double L[6][6], D[6], Dinv[6], y[6];
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -144,6 +203,8 @@ __device__ __forceinline__ int ldlt6_solve(const double* Hin, const double* b, d
       if (k < j) d -= L[j][k] * L[j][k] * D[k];
     ok = ok && (d > 0.0);
     D[j] = d;
+    const double inv = pose_rcp(d);
+    Dinv[j] = inv;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       if (i > j) {
@@ -151,7 +212,7 @@ __device__ __forceinline__ int ldlt6_solve(const double* Hin, const double* b, d
 #pragma unroll
         for (int k = 0; k < 6; ++k)
           if (k < j) sacc -= L[i][k] * L[j][k] * D[k];
-        L[i][j] = sacc / d;
+        L[i][j] = sacc * inv;
       }
     }
   }
@@ -165,7 +226,7 @@ __device__ __forceinline__ int ldlt6_solve(const double* Hin, const double* b, d
     y[i] = sacc;
   }
 #pragma unroll
-  for (int i = 0; i < 6; ++i) y[i] /= D[i];
+  for (int i = 0; i < 6; ++i) y[i] *= Dinv[i];
   double xs[6];
 #pragma unroll
   for (int i = 5; i >= 0; --i) {

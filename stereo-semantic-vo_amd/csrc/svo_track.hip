@@ -55,7 +55,7 @@
 #define TRK_DENSE 0xFF           // ncand marker: more than `lcap` candidates, the row's distances are in D
 
 struct TrackPool {
-  uint32_t desc[TRK_CAP * 8];
+  alignas(16) uint32_t desc[TRK_CAP * 8];
   int32_t create_id[TRK_CAP];
   int32_t gid[TRK_CAP];          // map-point id = creation sequence number; positions live in gpos[gid % TRK_GPOS]
   uint8_t bad[TRK_CAP];
@@ -85,7 +85,7 @@ struct TrackState {
   int32_t boxes[SVO_MAX_BOXES * 4];    // {left, right, top, bottom} of the current frame
   double F[9];                         // fundamental matrix cur <- last (row-major)
   float last_xy[TRK_MAXKP * 2];        // LastFrame.keypoints_l[i].pt
-  uint32_t last_desc[TRK_MAXKP * 8];   // LastFrame.f_descriptor
+  alignas(16) uint32_t last_desc[TRK_MAXKP * 8];   // LastFrame.f_descriptor
   int32_t bf_idx[TRK_MAXKP], bf_dist[TRK_MAXKP], bf_min;
   uint8_t bf_keep[TRK_MAXKP];
   // ---- pose chain --------------------------------------------------------------------------
@@ -672,20 +672,20 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
   // ---- frame end: createmappoint (src/frame.cc:182-238) for keypoints without a map point ------
   int m_cur = tid < nkp ? S.cur_mp[tid] : -1;
   bool create = tid < nkp && m_cur < 0 && has_depth;
+  uint4 dk0 = {0, 0, 0, 0}, dk1 = dk0;   // this keypoint's descriptor: two 16-byte loads, used twice below
   if (tid < nkp) {
     const svo_kp k = kp[tid];
+    dk0 = reinterpret_cast<const uint4*>(desc + 8 * tid)[0]; dk1 = reinterpret_cast<const uint4*>(desc + 8 * tid)[1];
     if (create && n_boxes > 0 && svo_in_boxes(k.x, k.y, st->boxes, n_boxes, 5)) create = false;
     st->last_xy[2 * tid] = k.x; st->last_xy[2 * tid + 1] = k.y;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) st->last_desc[8 * tid + w] = desc[8 * tid + w];
+    reinterpret_cast<uint4*>(st->last_desc + 8 * tid)[0] = dk0; reinterpret_cast<uint4*>(st->last_desc + 8 * tid)[1] = dk1;
   }
   int n_new;
   const int rank = block_excl_scan(create ? 1 : 0, S.sm, &n_new);
   int new_gid = -1;
   if (create && npool + rank < TRK_CAP) {
     const int m = npool + rank;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) P.desc[8 * m + w] = desc[8 * tid + w];
+    reinterpret_cast<uint4*>(&P.desc[8 * m])[0] = dk0; reinterpret_cast<uint4*>(&P.desc[8 * m])[1] = dk1;
     P.bad[m] = 0; P.in_local[m] = 1; P.create_id[m] = id; P.gid[m] = next_gid + rank;
     new_gid = next_gid + rank;
     m_cur = m;
@@ -701,14 +701,23 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
   int live_cnt = 0, oldest = 0x7fffffff, nl = 0;
   uint32_t live_bits = 0, loc_bits = 0;
   // rows 4 tid .. 4 tid + 3 of the pool, every field as one vector load, the descriptors (8 x 16 bytes) with them
-  const uint32_t loc4 = *reinterpret_cast<const uint32_t*>(&P.in_local[4 * tid]);
-  const uint32_t bad4 = *reinterpret_cast<const uint32_t*>(&P.bad[4 * tid]);
-  const uint32_t ref4 = *reinterpret_cast<const uint32_t*>(&S.ref[4 * tid]);
-  const int4 cid4 = *reinterpret_cast<const int4*>(&P.create_id[4 * tid]);
-  const int4 gid4 = *reinterpret_cast<const int4*>(&P.gid[4 * tid]);
+  // (only by the threads whose rows exist: the pool holds ~1,300 of its 4,096 rows on these frames, and one CU pulls
+  // 172 bytes per thread at ~11 bytes per clock)
+  const bool mine = 4 * tid < np1;
+  uint32_t loc4 = 0, bad4 = 0;
+  int4 cid4 = {0, 0, 0, 0}, gid4 = {0, 0, 0, 0};
   uint4 dsc[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) dsc[q] = reinterpret_cast<const uint4*>(&P.desc[32 * tid])[q];
+  for (int q = 0; q < 8; ++q) dsc[q] = uint4{0, 0, 0, 0};
+  if (mine) {
+    loc4 = *reinterpret_cast<const uint32_t*>(&P.in_local[4 * tid]);
+    bad4 = *reinterpret_cast<const uint32_t*>(&P.bad[4 * tid]);
+    cid4 = *reinterpret_cast<const int4*>(&P.create_id[4 * tid]);
+    gid4 = *reinterpret_cast<const int4*>(&P.gid[4 * tid]);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dsc[q] = reinterpret_cast<const uint4*>(&P.desc[32 * tid])[q];
+  }
+  const uint32_t ref4 = *reinterpret_cast<const uint32_t*>(&S.ref[4 * tid]);
   const int cidv[4] = {cid4.x, cid4.y, cid4.z, cid4.w}, gidv[4] = {gid4.x, gid4.y, gid4.z, gid4.w};
 #pragma unroll
   for (int q = 0; q < 4; ++q) {

@@ -588,6 +588,7 @@ def multi_sequence_leg(pkg, svo, cam, dL, dR, frame_bytes, rec, dev, single):
     reproduce the single chain's records."""
     S, msteps = 64, 48
     ms = pkg.Svo(W, H, device=dev.index or 0, max_kp=500, max_batch=S)
+    ms.set_option("multi_pipeline", int(os.environ.get("SVO_BENCH_MULTI_PIPELINE", "1")))   # front end of step t + 1 beside the tail of step t
     mres = torch.zeros((msteps * S, rec), dtype=torch.uint8, device=dev)
     ms.track_multi_reset(S, cam)
     for t in range(2):
@@ -606,7 +607,9 @@ def multi_sequence_leg(pkg, svo, cam, dL, dR, frame_bytes, rec, dev, single):
     same = all(m[t, 0].tobytes() == single[t].tobytes() for t in range(msteps))
     return {"value": msteps * S / mdt, "unit": "stereo frames/s", "sequences": S, "steps": msteps,
             "sequence0_equals_single_chain": bool(same),
-            "note": "SURVEY 8e's 'G independent sequences' variant on ONE GPU: full Tracking::Track per frame"}
+            "pipelined_steps": bool(int(os.environ.get("SVO_BENCH_MULTI_PIPELINE", "1"))),
+            "note": "SURVEY 8e's 'G independent sequences' variant on ONE GPU: full Tracking::Track per frame; with "
+                    "pipelined_steps the stateless front end of step t + 1 runs beside the tail of step t (multi_pipeline option)"}
 
 
 if __name__ == "__main__":

@@ -121,8 +121,13 @@ void svo_destroy(svo_ctx* ctx);
  * can force that path.
  * "track_nblk" (default 3, the maximum): runner-up blockers stored with each packed entry; with fewer the matching passes
  * consult the full distance row more often - same results, a test switch like "track_lcap".
- * "frontend_overlap" (default 1): svo_frontend_batch_dev runs the two halves of a batch on two streams (scheduling only;
- * off while svo_profile_enable is on, so that per-kernel times are those of kernels running alone).
+ * "frontend_overlap" (default 2, 0..8): slices of a batch svo_frontend_batch_dev runs side by side on their own streams
+ * (scheduling only; 0 / 1: one chain; also one chain while svo_profile_enable is on, so that per-kernel times are those of
+ * kernels running alone).
+ * "pyr_fused" (default 1): the pyramid as three fused launches (levels kept in LDS); 0: one launch per level - same levels.
+ * "multi_pipeline" (default 0): svo_track_multi_step_dev runs the front end of a step beside the tail of the previous
+ * step (its own stream, two alternating private output sets) - same records.  Contract while it is on: between consecutive
+ * steps nothing else is enqueued on the context (svo_sync and reading results are fine); svo_track_multi_reset restarts it.
  * "depth_source" (default 0): where svo_track_frame / svo_track_batch_dev take keypoint depth from - 0 the sparse
  * epipolar matcher (north star), 1 a dense ELAS map (svo_elas_*), 2 a dense MSA map (svo_msa_solve with d = 48: the
  * reference's live configuration, src/Tracking.cc:225-228 + src/frame.cc:82-91), both read per keypoint as

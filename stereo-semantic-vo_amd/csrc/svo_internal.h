@@ -96,6 +96,15 @@ struct svo_ctx {
   // tracker state (svo_track.hip)
   void* d_track = nullptr;      // n_seq TrackState records
   int n_seq = 0;
+  // svo_track_multi_step_dev with svo_set_option("multi_pipeline", 1): the front end of step t + 1 runs beside the tail of
+  // step t; its outputs alternate between two private sets (ms_*[parity])
+  int opt_multi_pipeline = 0, ms_parity = 0, ms_cap = 0;
+  bool ms_tail_recorded[2] = {false, false};
+  svo_kp* ms_kp[2] = {nullptr, nullptr};
+  uint8_t* ms_desc[2] = {nullptr, nullptr};
+  int32_t* ms_nkp[2] = {nullptr, nullptr};
+  float* ms_depth[2] = {nullptr, nullptr};
+  hipEvent_t ms_fe_done[2] = {nullptr, nullptr}, ms_tail_done[2] = {nullptr, nullptr};
   void* d_work = nullptr;       // TrackWork records (index chain -> pose chain), work_cap of them
   int work_cap = 0;
   hipStream_t stream_idx = nullptr;        // the pose-free index chain of the tracking tail runs here, ahead of the pose chain

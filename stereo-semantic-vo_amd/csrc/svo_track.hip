@@ -951,6 +951,17 @@ void svo_track_release(svo_ctx* ctx) {
   for (hipEvent_t e : ctx->ev_sub) hipEventDestroy(e);
   ctx->ev_sub.clear();
   if (ctx->stream_fe) { hipStreamDestroy(ctx->stream_fe); ctx->stream_fe = nullptr; }
+  for (int p = 0; p < 2; ++p) {
+    if (ctx->ms_kp[p]) hipFree(ctx->ms_kp[p]);
+    if (ctx->ms_desc[p]) hipFree(ctx->ms_desc[p]);
+    if (ctx->ms_nkp[p]) hipFree(ctx->ms_nkp[p]);
+    if (ctx->ms_depth[p]) hipFree(ctx->ms_depth[p]);
+    ctx->ms_kp[p] = nullptr; ctx->ms_desc[p] = nullptr; ctx->ms_nkp[p] = nullptr; ctx->ms_depth[p] = nullptr;
+    if (ctx->ms_fe_done[p]) { hipEventDestroy(ctx->ms_fe_done[p]); ctx->ms_fe_done[p] = nullptr; }
+    if (ctx->ms_tail_done[p]) { hipEventDestroy(ctx->ms_tail_done[p]); ctx->ms_tail_done[p] = nullptr; }
+    ctx->ms_tail_recorded[p] = false;
+  }
+  ctx->ms_cap = 0; ctx->ms_parity = 0;
 }
 
 // streams, events, work records and the kernels' LDS opt-ins for `frames` frames per call of `nseq` sequences
@@ -1052,7 +1063,9 @@ static int track_reset_n(svo_ctx* ctx, const svo_camera* cam, int nseq) {
   if (ctx->max_kp > TRK_MAXKP) return SVO_E_CAPACITY;
   hipSetDevice(ctx->device);
   if (ctx->stream_idx) SVO_HIP(ctx, hipStreamSynchronize(ctx->stream_idx));
+  if (ctx->stream_fe) SVO_HIP(ctx, hipStreamSynchronize(ctx->stream_fe));
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->ms_parity = 0; ctx->ms_tail_recorded[0] = false; ctx->ms_tail_recorded[1] = false;
   if (!ctx->d_track || ctx->n_seq != nseq) {
     if (ctx->d_track) { hipFree(ctx->d_track); ctx->d_track = nullptr; }
     void* p = nullptr;
@@ -1218,7 +1231,58 @@ extern "C" int svo_track_multi_step_dev(svo_ctx* ctx, const uint8_t* d_grayL, co
     return SVO_E_INVALID;
   }
   hipSetDevice(ctx->device);
-  int rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, n_seq, 2 * n_seq);
+  int rc;
+  if (ctx->opt_multi_pipeline) {
+    // Pipelined steps (svo_set_option("multi_pipeline", 1)): the front end is stateless, so step t + 1's may run while
+    // step t's tail is still busy - on its own stream, into the other of two private output sets.  Contract: between
+    // consecutive steps nothing else is enqueued on this context (svo_sync and reading results are fine).
+    const size_t K = ctx->max_kp, I = 2 * (size_t)n_seq;
+    if (ctx->ms_cap < n_seq) {
+      SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->stream_fe) SVO_HIP(ctx, hipStreamSynchronize(ctx->stream_fe));
+      for (int p = 0; p < 2; ++p) {
+        if (ctx->ms_kp[p]) hipFree(ctx->ms_kp[p]);
+        if (ctx->ms_desc[p]) hipFree(ctx->ms_desc[p]);
+        if (ctx->ms_nkp[p]) hipFree(ctx->ms_nkp[p]);
+        if (ctx->ms_depth[p]) hipFree(ctx->ms_depth[p]);
+        SVO_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->ms_kp[p]), sizeof(svo_kp) * I * K));
+        SVO_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->ms_desc[p]), 32 * I * K));
+        SVO_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->ms_nkp[p]), sizeof(int32_t) * I));
+        SVO_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->ms_depth[p]), sizeof(float) * (size_t)n_seq * K));
+        if (!ctx->ms_fe_done[p]) SVO_HIP(ctx, hipEventCreateWithFlags(&ctx->ms_fe_done[p], hipEventDisableTiming));
+        if (!ctx->ms_tail_done[p]) SVO_HIP(ctx, hipEventCreateWithFlags(&ctx->ms_tail_done[p], hipEventDisableTiming));
+        ctx->ms_tail_recorded[p] = false;
+      }
+      ctx->ms_cap = n_seq;
+    }
+    if ((rc = track_resources(ctx, 1, n_seq))) return rc;   // streams and events exist from here on
+    if (!ctx->stream_fe) SVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_fe, hipStreamNonBlocking));
+    const int p = ctx->ms_parity;
+    if (ctx->ms_tail_recorded[p]) {
+      SVO_HIP(ctx, hipStreamWaitEvent(ctx->stream_fe, ctx->ms_tail_done[p], 0));   // the tail that read this set two steps ago
+    } else {
+      SVO_HIP(ctx, hipEventRecord(ctx->ev_frontend, ctx->stream));                  // first use: after whatever came before
+      SVO_HIP(ctx, hipStreamWaitEvent(ctx->stream_fe, ctx->ev_frontend, 0));
+    }
+    svo_kp* kp0 = ctx->d_kp; uint8_t* desc0 = ctx->d_desc; int32_t* nkp0 = ctx->d_nkp; float* depth0 = ctx->d_depth;
+    hipStream_t s_main = ctx->stream;
+    ctx->d_kp = ctx->ms_kp[p]; ctx->d_desc = ctx->ms_desc[p]; ctx->d_nkp = ctx->ms_nkp[p]; ctx->d_depth = ctx->ms_depth[p];
+    ctx->stream = ctx->stream_fe;
+    rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, n_seq, 2 * n_seq);
+    if (rc == SVO_OK) rc = svo_launch_stereo(ctx, d_grayL, d_grayR, stride, n_seq, &ctx->cam);
+    ctx->stream = s_main;
+    ctx->d_kp = kp0; ctx->d_desc = desc0; ctx->d_nkp = nkp0; ctx->d_depth = depth0;
+    if (rc) return rc;
+    SVO_HIP(ctx, hipEventRecord(ctx->ms_fe_done[p], ctx->stream_fe));
+    SVO_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ms_fe_done[p], 0));
+    if ((rc = tail_enqueue(ctx, ctx->ms_kp[p], ctx->ms_desc[p], ctx->ms_nkp[p], ctx->ms_depth[p], ctx->max_kp, 1, n_seq, d_results))) return rc;
+    SVO_HIP(ctx, hipEventRecord(ctx->ms_tail_done[p], ctx->stream));
+    ctx->ms_tail_recorded[p] = true;
+    ctx->ms_parity ^= 1;
+    ctx->track_frame++;
+    return SVO_OK;
+  }
+  rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, n_seq, 2 * n_seq);
   if (rc) return rc;
   if ((rc = svo_launch_stereo(ctx, d_grayL, d_grayR, stride, n_seq, &ctx->cam))) return rc;
   if ((rc = tail_enqueue(ctx, ctx->d_kp, ctx->d_desc, ctx->d_nkp, ctx->d_depth, ctx->max_kp, 1, n_seq, d_results))) return rc;

@@ -266,6 +266,17 @@ def test_multi_sequence_tracker_equals_independent_chains(pkg, sequence):
         for t in range(STEPS):
             assert multi[t, q].tobytes() == singles[q][t].tobytes(), (q, t)
     assert multi[-1, 0]["n_lm_edges"] > 20
+    # pipelined steps (the front end of step t + 1 beside the tail of step t, alternating output sets): same records,
+    # also across a reset in the middle of a run
+    m.set_option("multi_pipeline", 1)
+    for rep in range(2):
+        m.track_multi_reset(S, cam)
+        out2 = torch.zeros((STEPS, S, rec), dtype=torch.uint8, device=dev)
+        for t in range(STEPS):
+            m.track_multi_step_dev(dL.data_ptr() + t * fb, dR.data_ptr() + t * fb, pitch, S, out2[t].data_ptr())
+        m.sync()
+        assert out2.cpu().numpy().tobytes() == out.cpu().numpy().tobytes(), rep
+    m.set_option("multi_pipeline", 0)
     with pytest.raises(pkg.SvoError):     # single-sequence entry points refuse a multi-sequence state
         m.track_batch_dev(dL.data_ptr(), dR.data_ptr(), pitch, 1, out.data_ptr())
     with pytest.raises(pkg.SvoError):     # a step must advance exactly the sequences that were reset

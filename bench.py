@@ -64,14 +64,17 @@ def tail_kernel_bytes(kernel, mean_pool_rows, mean_kp, mean_edges, mean_lm_iters
     return 0.0
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, pairs_per_launch=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same
     command (profiles/pmc_latest.json; FETCH_SIZE and WRITE_SIZE collected in separate passes,
     KB units, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
         d = json.load(open(path))[kernel]
-        return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+        per_dispatch = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+        if pairs_per_launch and d.get("_pairs_per_dispatch_traffic"):    # counters were taken at another batch size: scale
+            per_dispatch *= pairs_per_launch / d["_pairs_per_dispatch_traffic"]
+        return per_dispatch
     except Exception:
         return None
 
@@ -580,7 +583,7 @@ def frontend_leg(pkg, svo, cam, dL, dR, n_frames, frame_bytes, dev, all_cores):
            "distinct_input_bytes_read": int(2 * B * steps * frame_bytes), "kernel_avg_ms": kern,
            "value_one_stream_with_timers": B * steps / dt_single,
            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom), "valu": pmc_valu(dom),
+                        "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B), "valu": pmc_valu(dom),
                         "algorithmic_bytes_per_launch": algo,
                         "pipeline_frac": ALGO_BYTES_PER_PAIR * (B * steps / dt) / 1e9 / HBM_PEAK_GBS}}
     if all_cores is not None:

@@ -791,7 +791,17 @@ __global__ __launch_bounds__(64) void k_describe(SvoGeom g, ImgSrc s, const SvoS
   __shared__ uint32_t hbT[31 * 20];              // horizontal pass, TRANSPOSED: [column][row] u16, 40 rows pitch
   __shared__ uint32_t blT[31 * 8];               // blurred 31 x 31 patch, TRANSPOSED: [column][row] u8, 32 pitch
   const int lane = threadIdx.x;
-  const int slot = blockIdx.x, img = blockIdx.y;
+  // XCD-aware order (as k_fast): workgroup b runs on XCD b % 8 and every XCD has its own L2 - the linear id is remapped
+  // (bijectively) so that each XCD gets one contiguous eighth of the (image, keypoint) sequence: the 37 x 40-byte windows
+  // of one image's keypoints overlap heavily, and this way they meet in ONE L2 instead of being fetched by eight.
+  int slot, img;
+  {
+    const uint32_t total_wg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t xcd = lin & 7u, idx = lin >> 3, q = total_wg >> 3, r = total_wg & 7u;
+    const uint32_t mapped = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    img = (int)(mapped / gridDim.x);
+    slot = (int)(mapped - (uint32_t)img * gridDim.x);
+  }
   // slot -> (level, rank)
   int l = -1, rank = 0, total = 0;
 #pragma unroll

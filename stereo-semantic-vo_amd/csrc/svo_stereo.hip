@@ -55,7 +55,16 @@ __global__ __launch_bounds__(256) void k_stereo_match(SvoGeom g, StereoSrc s, co
   __shared__ uint64_t winL[4][ST_G][11][2];   // per wave and keypoint: 11 rows x 16 bytes of the left SAD window
   __shared__ uint64_t winR[4][ST_G][11][3];   // per wave and keypoint: 11 rows x 24 bytes of the right search band
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int pair = blockIdx.y;
+  // XCD-aware order (as k_fast / k_describe): the workgroups of one pair - same right-image bands, SAD windows in the same
+  // rows - run on ONE XCD and share its L2
+  int pair, chunk;
+  {
+    const uint32_t total_wg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t xcd = lin & 7u, idx = lin >> 3, q = total_wg >> 3, r = total_wg & 7u;
+    const uint32_t mapped = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    pair = (int)(mapped / gridDim.x);
+    chunk = (int)(mapped - (uint32_t)pair * gridDim.x);
+  }
   const int imgL = pair, imgR = s.B + pair;
   const int nL = nkp[imgL], nR = min(nkp[imgR], MAXKP_LDS);
   const svo_kp* kpL = kp + (size_t)imgL * max_kp;
@@ -75,7 +84,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(SvoGeom g, StereoSrc s, co
   const float maxD = fx;
   typedef uint64_t __attribute__((aligned(1))) u64u;
   for (int q0 = 0; q0 < KP_PER_WG / 4; q0 += ST_G) {
-    const int iL0 = blockIdx.x * KP_PER_WG + wv * (KP_PER_WG / 4) + q0;
+    const int iL0 = chunk * KP_PER_WG + wv * (KP_PER_WG / 4) + q0;
     if (iL0 >= max_kp) break;
     // (1) the group's keypoints and descriptors (indices clamped: every load is unconditional)
     svo_kp kl[ST_G];

@@ -125,6 +125,8 @@ void svo_destroy(svo_ctx* ctx);
  * (scheduling only; 0 / 1: one chain; also one chain while svo_profile_enable is on, so that per-kernel times are those of
  * kernels running alone).
  * "pyr_fused" (default 1): the pyramid as three fused launches (levels kept in LDS); 0: one launch per level - same levels.
+ * "track_group" (default 4, 1..64): most frames the batched tracker's pose chain takes over from its index chain per
+ * stream event (group sizes ramp up 1, 1, 2, 4, ...) - scheduling only, same records.
  * "multi_pipeline" (default 0): svo_track_multi_step_dev runs the front end of a step beside the tail of the previous
  * step (its own stream, two alternating private output sets) - same records.  Contract while it is on: between consecutive
  * steps nothing else is enqueued on the context (svo_sync and reading results are fine); svo_track_multi_reset restarts it.

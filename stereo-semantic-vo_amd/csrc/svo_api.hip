@@ -328,6 +328,11 @@ extern "C" int svo_set_option(svo_ctx* ctx, const char* key, int value) {
     ctx->opt_track_nblk = value;
     return SVO_OK;
   }
+  if (!strcmp(key, "track_group")) {
+    if (value < 1 || value > 64) return SVO_E_INVALID;
+    ctx->opt_track_group = value;
+    return SVO_OK;
+  }
   if (!strcmp(key, "track_lcap")) {
     if (value < 1 || value > 8) return SVO_E_INVALID;
     ctx->opt_track_lcap = value;

@@ -121,6 +121,7 @@ struct svo_ctx {
   int opt_frontend_overlap = 2;      // svo_set_option("frontend_overlap"): slices of a batch svo_frontend_batch_dev runs side by side (0 / 1: none)
   std::vector<hipStream_t> fe_streams;   // their streams (slice 0 uses `stream`) ...
   std::vector<hipEvent_t> fe_events;     // ... and completion events
+  int opt_track_group = 4;      // svo_set_option("track_group"): most frames the pose chain takes over per stream event (1..64)
   int opt_track_nblk = 3;       // svo_set_option("track_nblk"): runner-up blockers stored per packed entry (0..3)
   int opt_track_lcap = 8;       // svo_set_option("track_lcap"): packed entries a map point keeps before it goes "dense" (1..8)
   void* elas = nullptr;     // ElasState (svo_elas.hip), allocated on first svo_elas_process

@@ -1014,7 +1014,7 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
   // per-kernel HIP-event timing (svo_profile_enable) costs ~2.5 us per event pair on the host - more than a tail kernel's
   // launch; the tail is therefore SAMPLED: every 32nd frame of a call is timed (an event pair around a kernel also holds the chain up by ~5 us), the others run untimed
   const bool prof = ctx->profiling;
-  for (int f = 0; f < frames; ++f) {
+  auto enqueue_index = [&](int f) {
     const svo_kp* kpf = kp + (size_t)f * kstride;
     const uint32_t* descf = desc + (size_t)f * kstride * 8;
     const float* depf = depth + (size_t)f * kstride;
@@ -1029,8 +1029,11 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
       SvoTimer t(ctx, "k_ti_resolve", s1);
       hipLaunchKernelGGL(k_ti_resolve, dim3(1, ny), dim3(1024), sizeof(TiLds), s1, st, work + f, kpf, descf, nkp + f, depf, kstride);
     }
-    hipEventRecord(ctx->ev_frame[f], s1);
-    hipStreamWaitEvent(s0, ctx->ev_frame[f], 0);
+  };
+  auto enqueue_pose = [&](int f) {
+    const svo_kp* kpf = kp + (size_t)f * kstride;
+    const float* depf = depth + (size_t)f * kstride;
+    ctx->profiling = prof && (f % 32 == 0 || frames < 32);
     {
       SvoTimer t(ctx, "k_tp_hyp");
       if (ny >= 8) {
@@ -1051,6 +1054,27 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
       hipLaunchKernelGGL(k_tp_frame, dim3(1, ny), dim3(256), sizeof(TpLds), s0, st, work + f, kpf, depf, d_res + f, kstride,
                          ctx->opt_pose_mfma);
     }
+  };
+  // The pose chain takes the frames over in groups: ONE event (a barrier packet on the pose stream, ~3 us even when long
+  // signalled) per group instead of one per frame.  Group sizes ramp up 1, 1, 2, 4, 4, ... (option "track_group": 1 -> 11.80 k, 4 -> 12.01 k, 8 -> 11.94 k, 16 -> 11.69 k frames/s) so that the first poses of
+  // a call do not wait for a long run of the index chain; the index chain is the faster one and stays ahead after that.
+  // The host enqueues the index kernels one group ahead of the pose kernels.
+  int g0 = 0, gsize = 1, prev0 = -1, prev1 = -1, ngroup = 0;
+  while (g0 < frames || prev0 >= 0) {
+    int cur0 = -1, cur1 = -1;
+    if (g0 < frames) {
+      cur0 = g0; cur1 = std::min(frames, g0 + gsize);
+      for (int f = cur0; f < cur1; ++f) enqueue_index(f);
+      hipEventRecord(ctx->ev_frame[cur0], s1);
+      g0 = cur1;
+      ++ngroup;
+      if (ngroup >= 2) gsize = std::min(2 * gsize, ctx->opt_track_group > 0 ? ctx->opt_track_group : 1);
+    }
+    if (prev0 >= 0) {
+      hipStreamWaitEvent(s0, ctx->ev_frame[prev0], 0);
+      for (int f = prev0; f < prev1; ++f) enqueue_pose(f);
+    }
+    prev0 = cur0; prev1 = cur1;
   }
   ctx->profiling = prof;
   SVO_HIP(ctx, hipGetLastError());

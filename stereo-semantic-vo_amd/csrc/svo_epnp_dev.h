@@ -75,6 +75,16 @@ __device__ __forceinline__ double epnp_rcp2(double x) {
   r = r * (2.0 - x * r);
   return r;
 }
+// square root as x * rsqrt(x) with two Newton steps (the scalar stages' IEEE sqrt / division sequences are ~100 dependent
+// cycles each; a sample's pose is compared statistically, an ulp does not matter)
+__device__ __forceinline__ double epnp_sqrt(double x) {
+#pragma clang fp contract(fast)
+  if (!(x > 0.0)) return 0.0;
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - (0.5 * x) * y * y);
+  y = y * (1.5 - (0.5 * x) * y * y);
+  return x * y;
+}
 // where position x moves after a step of the systolic tournament: 0 stays; 2 -> 4 -> 6 -> 8 -> 10 -> 11 -> 9 -> 7 -> 5 -> 3 -> 1 -> 2
 __device__ __forceinline__ int epnp_pi(int x) {
   return x == 0 ? 0 : (x == 1 ? 2 : (x == 10 ? 11 : ((x & 1) ? x - 2 : x + 2)));
@@ -133,7 +143,7 @@ __device__ inline void epnp_svd3(const double* A, double* w, double* Ut, double*
     if (!changed) break;
   }
 #pragma unroll
-  for (int i = 0; i < 3; ++i) W[i] = sqrt(At[3 * i] * At[3 * i] + At[3 * i + 1] * At[3 * i + 1] + At[3 * i + 2] * At[3 * i + 2]);
+  for (int i = 0; i < 3; ++i) W[i] = epnp_sqrt(At[3 * i] * At[3 * i] + At[3 * i + 1] * At[3 * i + 1] + At[3 * i + 2] * At[3 * i + 2]);
   // selection sort, descending
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -153,7 +163,7 @@ __device__ inline void epnp_svd3(const double* A, double* w, double* Ut, double*
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     w[i] = W[i];
-    const double s = W[i] > 2.2250738585072014e-308 ? 1 / W[i] : 0.;
+    const double s = W[i] > 2.2250738585072014e-308 ? epnp_rcp2(W[i]) : 0.;
 #pragma unroll
     for (int k = 0; k < 3; ++k) { Ut[3 * i + k] = At[3 * i + k] * s; Vt[3 * i + k] = V[3 * i + k]; }
   }
@@ -241,7 +251,7 @@ __device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* K, double* R_out
   double cw0[3] = {0, 0, 0};
 #pragma unroll
   for (int i = 0; i < 5; ++i) { cw0[0] += Xw[3 * i]; cw0[1] += Xw[3 * i + 1]; cw0[2] += Xw[3 * i + 2]; }
-  cw0[0] /= 5; cw0[1] /= 5; cw0[2] /= 5;
+  cw0[0] *= 0.2; cw0[1] *= 0.2; cw0[2] *= 0.2;
   double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
@@ -255,7 +265,7 @@ __device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* K, double* R_out
   epnp_svd3(cov, dc, uct, vt3);
   double kk[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) kk[i] = sqrt(dc[i] / 5);
+  for (int i = 0; i < 3; ++i) kk[i] = epnp_sqrt(dc[i] * 0.2);
   // control points cws[0] = centroid, cws[i] = centroid + k_i u_i; CC = [k1 u1 | k2 u2 | k3 u3] has orthogonal columns: its
   // inverse (OpenCV: cvInvert through an SVD) is diag(1/k) U^T.  Both go to LDS: later stages index them dynamically.
   if (lane < 12) {
@@ -271,7 +281,7 @@ __device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* K, double* R_out
     const double d[3] = {Xw[3 * lane] - cw0[0], Xw[3 * lane + 1] - cw0[1], Xw[3 * lane + 2] - cw0[2]};
     double a[4];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) a[1 + j] = kk[j] > 0 ? epnp_dot3(&uct[3 * j], d) / kk[j] : 0.0;
+    for (int j = 0; j < 3; ++j) a[1 + j] = kk[j] > 0 ? epnp_dot3(&uct[3 * j], d) * epnp_rcp2(kk[j]) : 0.0;
     a[0] = 1.0 - a[1] - a[2] - a[3];
 #pragma unroll
     for (int j = 0; j < 4; ++j) S.alphas[4 * lane + j] = a[j];
@@ -432,13 +442,15 @@ __device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* K, double* R_out
       }
       epnp_lsq6<5>(l, rho, b5, nc);
       if (lane == 0) {          // find_betas_approx_1
-        if (b5[0] < 0) { betas[0] = sqrt(-b5[0]); betas[1] = -b5[1] / betas[0]; betas[2] = -b5[2] / betas[0]; betas[3] = -b5[3] / betas[0]; }
-        else { betas[0] = sqrt(b5[0]); betas[1] = b5[1] / betas[0]; betas[2] = b5[2] / betas[0]; betas[3] = b5[3] / betas[0]; }
+        const double sg = b5[0] < 0 ? -1.0 : 1.0;
+        betas[0] = epnp_sqrt(sg * b5[0]);
+        const double ib0 = sg * epnp_rcp2(betas[0]);
+        betas[1] = b5[1] * ib0; betas[2] = b5[2] * ib0; betas[3] = b5[3] * ib0;
       } else {                  // find_betas_approx_2: [B11 B12 B22], approx_3: [B11 B12 B22 B13 B23]
-        if (b5[0] < 0) { betas[0] = sqrt(-b5[0]); betas[1] = (b5[2] < 0) ? sqrt(-b5[2]) : 0.0; }
-        else { betas[0] = sqrt(b5[0]); betas[1] = (b5[2] > 0) ? sqrt(b5[2]) : 0.0; }
+        if (b5[0] < 0) { betas[0] = epnp_sqrt(-b5[0]); betas[1] = (b5[2] < 0) ? epnp_sqrt(-b5[2]) : 0.0; }
+        else { betas[0] = epnp_sqrt(b5[0]); betas[1] = (b5[2] > 0) ? epnp_sqrt(b5[2]) : 0.0; }
         if (b5[1] < 0) betas[0] = -betas[0];
-        betas[2] = lane == 2 ? b5[3] / betas[0] : 0.0;
+        betas[2] = lane == 2 ? b5[3] * epnp_rcp2(betas[0]) : 0.0;
         betas[3] = 0.0;
       }
     }
@@ -485,7 +497,7 @@ __device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* K, double* R_out
 #pragma unroll
       for (int j = 0; j < 3; ++j) { pc0[j] += pcs[3 * i + j]; pw0[j] += Xw[3 * i + j]; }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { pc0[j] /= 5; pw0[j] /= 5; }
+    for (int j = 0; j < 3; ++j) { pc0[j] *= 0.2; pw0[j] *= 0.2; }
     double abt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 5; ++i)
@@ -509,16 +521,16 @@ __device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* K, double* R_out
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const double Xc = epnp_dot3(&R[0], &Xw[3 * i]) + t[0], Yc = epnp_dot3(&R[3], &Xw[3 * i]) + t[1],
-                   inv_Zc = 1.0 / (epnp_dot3(&R[6], &Xw[3 * i]) + t[2]);
+                   inv_Zc = epnp_rcp2(epnp_dot3(&R[6], &Xw[3 * i]) + t[2]);
       const double ue = uc + fu * Xc * inv_Zc, ve = vc + fv * Yc * inv_Zc;
       const double du = uv[2 * i] - ue, dv = uv[2 * i + 1] - ve;
-      sum2 += sqrt(du * du + dv * dv);
+      sum2 += epnp_sqrt(du * du + dv * dv);
     }
     double* o = S.out[lane];
 #pragma unroll
     for (int k = 0; k < 9; ++k) o[k] = R[k];
     o[9] = t[0]; o[10] = t[1]; o[11] = t[2];
-    o[12] = sum2 / 5;
+    o[12] = sum2 * 0.2;
   }
   EPNP_WAVE_SYNC();
   if (lane == 0) S.stamp[4] = clock64();

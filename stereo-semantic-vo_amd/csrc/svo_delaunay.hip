@@ -185,11 +185,11 @@ struct Builder {
 
 // xy: n points as (x, y) int32 pairs.  tri: up to cap (c1, c2, c3) index triples into xy.
 // Returns the number of triangles (which may exceed cap: nothing is written beyond cap), < 0 on error.
-std::atomic<long long> g_dly_us[4];   // diagnostics: sort points, build, emit, sort triangles
-std::atomic<long long> g_dly_pts;
+std::atomic<long long> svo_delaunay_us[4];   // diagnostics (svo_internal.h): sort points, build, emit, sort triangles
+std::atomic<long long> svo_delaunay_pts;
 extern "C" int svo_elas_delaunay(const int32_t* xy, int32_t n, int32_t* tri, int32_t cap, int32_t* n_tri) {
   auto T0 = std::chrono::steady_clock::now();
-  auto lap = [&](int k) { auto t = std::chrono::steady_clock::now(); g_dly_us[k] += (long long)std::chrono::duration<double, std::micro>(t - T0).count(); T0 = t; };
+  auto lap = [&](int k) { auto t = std::chrono::steady_clock::now(); svo_delaunay_us[k] += (long long)std::chrono::duration<double, std::micro>(t - T0).count(); T0 = t; };
   if (!xy || !n_tri || n < 0 || cap < 0 || (cap > 0 && !tri)) return SVO_E_INVALID;
   *n_tri = 0;
   // one builder per host thread, its arrays keep their capacity: fresh 100 KB+ vectors per call are mmap / munmap pairs,
@@ -212,7 +212,7 @@ extern "C" int svo_elas_delaunay(const int32_t* xy, int32_t n, int32_t* tri, int
               b.pts.end());
   const int m = (int)b.pts.size();
   if (m < 3) return SVO_OK;
-  lap(0); g_dly_pts += m;
+  lap(0); svo_delaunay_pts += m;
   b.q.nxt.reserve(16 * m); b.q.org.reserve(16 * m); b.q.dead.reserve(4 * m);
   b.q.p = b.pts.data();
   b.build(0, m, 0);

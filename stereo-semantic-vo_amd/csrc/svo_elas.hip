@@ -1706,9 +1706,9 @@ extern "C" int svo_elas_batch_dev(svo_ctx* ctx, const uint8_t* d_L, const uint8_
   }
   for (std::thread& t : pool) t.join();
   hipStreamSynchronize(s);   // the pinned table and list arena are read by copies until here
-  if (dbg) { extern std::atomic<long long> g_dly_us[4]; extern std::atomic<long long> g_dly_pts;
-    fprintf(stderr, "   delaunay per call: sort pts %.0f us, build %.0f, emit %.0f, sort triangles %.0f; points %.0f\n", (double)g_dly_us[0] / (2 * B), (double)g_dly_us[1] / (2 * B), (double)g_dly_us[2] / (2 * B), (double)g_dly_us[3] / (2 * B), (double)g_dly_pts / (2 * B));
-    for (int k = 0; k < 4; ++k) g_dly_us[k] = 0; g_dly_pts = 0; }
+  if (dbg) {
+    fprintf(stderr, "   delaunay per call: sort pts %.0f us, build %.0f, emit %.0f, sort triangles %.0f; points %.0f\n", (double)svo_delaunay_us[0] / (2 * B), (double)svo_delaunay_us[1] / (2 * B), (double)svo_delaunay_us[2] / (2 * B), (double)svo_delaunay_us[3] / (2 * B), (double)svo_delaunay_pts / (2 * B));
+    for (int k = 0; k < 4; ++k) svo_delaunay_us[k] = 0; svo_delaunay_pts = 0; }
   if (dbg) fprintf(stderr, "   host work per pair: filter %.0f us, triangulations %.0f us (thread time)\n", (double)dbg_filter_us / B, (double)dbg_tri_us / B);
   if (dbg) fprintf(stderr, "elas batch B=%d chunk=%d: enqueue %.2f ms (of it packing the lists %.2f), wait for A %.2f, host stages %.2f, tail wait %.2f, total %.2f\n",
                    B, C, t_enq, t_sync_copy, t_wait, t_host, ms(t_loop, tnow()), ms(t_start, tnow()));

@@ -8,6 +8,7 @@
 
 #include <chrono>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "../../include/svo.h"
@@ -226,4 +227,9 @@ struct SvoTimer {
 // (a container with `cpu.max = 1600000 100000` gets 16 however many cores the machine shows; worker pools larger than
 // that only buy throttling stalls - for every thread of the process, the one that feeds the GPU included).
 int svo_host_cpus();
+
+// Diagnostics of svo_elas_delaunay, summed over calls: microseconds spent sorting the points, building, emitting and
+// ordering the triangles; points triangulated (printed and cleared by svo_elas_batch_dev under SVO_ELAS_BATCH_DEBUG=1)
+extern std::atomic<long long> svo_delaunay_us[4];
+extern std::atomic<long long> svo_delaunay_pts;
 

@@ -200,6 +200,30 @@ def tree_inputs(bgr):
     return o["m3L"], o["r_graL"], o["c_graL"]
 
 
+@pytest.mark.parametrize("W,H,flat", [(64, 48, False), (200, 120, False), (96, 64, True)])
+def test_tree_order_has_the_property_the_one_launch_sweep_relies_on(pkg, W, H, flat):
+    """k_msa_dp_bfs addresses the nodes of a tree by their position in level order and expects every node's children at
+    consecutive positions of the next level, in child-list order (the host checks this per tree and would fall back to the
+    launch-per-level kernels).  The breadth-first `seq` the tree builder returns must give exactly that."""
+    if flat:
+        bgr = np.full((H, W, 3), 90, np.uint8)
+    else:
+        bgr, _ = colour_pair(W, H)
+    m3, rg, cg = tree_inputs(bgr)
+    root, seq, cp, ch, cc = pkg.msa_tree(m3, rg, cg)
+    N = W * H
+    depth = np.zeros(N, np.int64)
+    for u in seq:                                   # parents come before children
+        depth[ch[cp[u]:cp[u + 1]]] = depth[u] + 1
+    order = seq[np.argsort(depth[seq], kind="stable")]          # level order: by depth, seq order inside a level
+    nxt = 1
+    for u in order:
+        kids = ch[cp[u]:cp[u + 1]]
+        assert np.array_equal(order[nxt:nxt + len(kids)], kids)
+        nxt += len(kids)
+    assert nxt == N and order[0] == root
+
+
 @pytest.mark.parametrize("W,H", [(5, 5), (64, 48), (200, 120)])
 def test_product_tree_equals_literal_restatement(pkg, W, H):
     """svo_msa_tree (host code of the product, array heaps and union-find written for speed) against orc_msa_tree,

@@ -25,14 +25,13 @@ d = np.diff(ts[:, :5], axis=1)
 tot = d.sum(1)
 order = np.argsort(-tot)
 print("frames %d; total cycles: median %d mean %d p90 %d max %d" % (N, np.median(tot), tot.mean(), np.percentile(tot, 90), tot.max()))
-print("phase means (begin, pass1, pass2, end):", d.mean(0).astype(int), " medians:", np.median(d, 0).astype(int))
+print("phase means (begin, pass1, pass2, end):", d[1:].mean(0).astype(int), " medians:", np.median(d[1:], 0).astype(int))
 print("slowest frames: frame total | phases | act1 rounds1 act2 rounds2 dense late")
 for f in order[:15]:
     print(f, tot[f], d[f], act1[f], rounds1[f], act2[f], rounds2[f], ts[f, 5], ts[f, 6])
+v = slice(1, None)          # frame 0 runs no passes (its stamps are zero)
 print("correlation of pass-2 cycles with rounds2: %.3f, with dense rows: %.3f, with act2: %.3f" % (
-    np.corrcoef(d[:, 2], rounds2)[0, 1], np.corrcoef(d[:, 2], ts[:, 5])[0, 1], np.corrcoef(d[:, 2], act2)[0, 1]))
-A = np.stack([rounds2, ts[:, 5], act2, np.ones(N)], 1).astype(float)
-coef = np.linalg.lstsq(A, d[:, 2].astype(float), rcond=None)[0]
+    np.corrcoef(d[v, 2], rounds2[v])[0, 1], np.corrcoef(d[v, 2], ts[v, 5])[0, 1], np.corrcoef(d[v, 2], act2[v])[0, 1]))
+A = np.stack([rounds2[v], ts[v, 5], act2[v], np.ones(N - 1)], 1).astype(float)
+coef = np.linalg.lstsq(A, d[v, 2].astype(float), rcond=None)[0]
 print("pass-2 cycles ~ %.0f * rounds + %.0f * dense + %.1f * act2 + %.0f" % tuple(coef))
-print("pass-2 phase sums (phase 1, phase 2, update+setup): mean", ts[1:, 5:8].mean(0).astype(int), "median", np.median(ts[1:, 5:8], 0).astype(int))
-print("per round (median frame):", (np.median(ts[1:, 5:8], 0) / max(np.median(rounds2), 1)).astype(int), "rounds median", np.median(rounds2))

@@ -402,6 +402,40 @@ def test_pyramid_one_launch_per_level_path_bit_exact(pkg, orc):
         svo.close()
 
 
+def test_frontend_batch_full_size_is_independent_of_scheduling_switches(pkg):
+    """KITTI-size batch: keypoints, descriptors and depths from svo_frontend_batch_dev must not depend on how the work is
+    scheduled - the pyramid as three fused launches or one per level, one chain or slices on several streams."""
+    import torch
+    W, H, B, pitch = util.KITTI_W, util.KITTI_H, 16, 1280
+    cam = pkg.Camera(**pkg.KITTI_00_02)
+    dev = torch.device("cuda", 0)
+    L0, R0 = util.urban_pair()
+    dL = torch.zeros((B, H, pitch), dtype=torch.uint8, device=dev)
+    dR = torch.zeros_like(dL)
+    for i in range(B):       # different content per pair: shifted copies of the real crop
+        dL[i, :, :W] = torch.from_numpy(np.roll(L0, 7 * i, axis=1)).to(dev)
+        dR[i, :, :W] = torch.from_numpy(np.roll(R0, 7 * i, axis=1)).to(dev)
+    torch.cuda.synchronize()
+    outs = []
+    for fused, slices in ((1, 2), (0, 1), (1, 1), (0, 2)):
+        kp = torch.zeros((B, 500, 28), dtype=torch.uint8, device=dev)
+        desc = torch.zeros((B, 500, 32), dtype=torch.uint8, device=dev)
+        n = torch.zeros(B, dtype=torch.int32, device=dev)
+        depth = torch.zeros((B, 500), dtype=torch.float32, device=dev)
+        svo = pkg.Svo(W, H, max_batch=B)
+        svo.set_option("pyr_fused", fused)
+        svo.set_option("frontend_overlap", slices)
+        svo.frontend_batch_dev(dL.data_ptr(), dR.data_ptr(), pitch, B, cam, kp.data_ptr(), desc.data_ptr(), n.data_ptr(),
+                               None, depth.data_ptr())
+        svo.sync()
+        n_h = n.cpu().numpy(); kp_h = kp.cpu().numpy(); desc_h = desc.cpu().numpy(); depth_h = depth.cpu().numpy()
+        assert n_h.min() > 300
+        outs.append((n_h.tobytes(),) + tuple(a[i, :n_h[i]].tobytes() for i in range(B) for a in (kp_h, desc_h, depth_h)))
+        svo.close()
+    for o in outs[1:]:
+        assert o == outs[0]
+
+
 @pytest.mark.parametrize("slices", [1, 2, 3])
 def test_frontend_batch_slices_on_streams_equal_oracle(pkg, orc, slices):
     """svo_frontend_batch_dev runs slices of a batch side by side on their own streams (scheduling only): every pair's

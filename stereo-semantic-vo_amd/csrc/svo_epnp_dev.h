@@ -23,12 +23,13 @@
 // A CPU restatement that follows OpenCV's own loops is kept with the tests; the two are compared to a stated tolerance.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 struct EpnpWaveLds {
   alignas(16) double A[12 * 12];      // M^T M, diagonalised in place
   alignas(16) double V[12 * 12];      // accumulated rotations: columns = eigenvectors
-  alignas(16) double cs[6][2];  // per pair of the running step: cos, sin of its rotation
+  alignas(16) double cs[8][2];  // per pair of the running step: cos, sin of its rotation; [6] = (1, 0): the identity, for the lanes that update V
   double v4[4][12];       // eigenvectors of the four smallest eigenvalues, v4[0] = smallest (OpenCV's ut + 12 * 11)
   double L[6 * 10], rho[6];
   double alphas[5 * 4];
@@ -313,15 +314,41 @@ __device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* K, double* R_out
 #pragma unroll
   for (int i = 0; i < 12; ++i) trace += S.A[13 * i];
   const double tau = 1e-15 * trace;
-  // work split of a step: lane b < 36 owns the 2 x 2 block (gi, gj) = (b / 6, b % 6) of A - the four entries two rotations
-  // mix among themselves; task t < 72 = (row k, pair gj) = (t / 6, t % 6) owns the two entries of row k of V that pair gj's
-  // rotation mixes (lane t, and lanes 0..7 a second task 64 + t).  Operands are adjacent in memory: 16-byte LDS accesses.
+  // work split of a step: A' = J^T A J and V' = V J are the SAME instructions on different 2 x 2 blocks.  Lanes 0..20 own the
+  // upper-triangular blocks (gi <= gj) of the symmetric A - B = blk J_j, blk' = J_i^T B - and store every entry at its new
+  // position and at the mirrored one; lanes 21..56 own the blocks (rows 2 ri, 2 ri + 1; pair gj) of V with J_i = the
+  // identity (cs[6]).  One instruction stream instead of one for A and one for V; every LDS address is fixed per lane.
   typedef double epnp_d2 __attribute__((ext_vector_type(2)));
-  const int gi = min(lane, 35) / 6, gj = min(lane, 35) % 6;
-  const int pi0 = epnp_pi(2 * gi), pi1 = epnp_pi(2 * gi + 1), pj0 = epnp_pi(2 * gj), pj1 = epnp_pi(2 * gj + 1);
-  const int vk0 = lane / 6, vg0 = lane % 6, vk1 = (64 + min(lane, 7)) / 6, vg1 = (64 + min(lane, 7)) % 6;
-  const int v0a = 12 * vk0 + epnp_pi(2 * vg0), v0b = 12 * vk0 + epnp_pi(2 * vg0 + 1);
-  const int v1a = 12 * vk1 + epnp_pi(2 * vg1), v1b = 12 * vk1 + epnp_pi(2 * vg1 + 1);
+  double* const AV = S.A;                      // A at [0, 144), V behind it at [144, 288)
+  static_assert(offsetof(EpnpWaveLds, V) == offsetof(EpnpWaveLds, A) + 144 * sizeof(double), "V must follow A");
+  int bi = 0, gj = 0, ci_idx = 6, mbase = 144;
+  bool isA = false;
+  {
+    const int t = min(lane, 56);
+    if (t < 21) {
+      int k = t, r = 0;
+      while (k >= 6 - r) { k -= 6 - r; ++r; }   // row r of the upper triangle has 6 - r blocks
+      bi = r; gj = r + k; ci_idx = r; mbase = 0; isA = true;
+    } else {
+      bi = (t - 21) / 6; gj = (t - 21) % 6;
+    }
+  }
+  const int rd0 = mbase + 12 * (2 * bi) + 2 * gj, rd1 = rd0 + 12;
+  const bool diag = isA && bi == gj;
+  int wr[2][2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int c = epnp_pi(2 * gj + b);
+      if (isA) {
+        const int r = epnp_pi(2 * bi + a);
+        wr[a][b][0] = 12 * r + c; wr[a][b][1] = 12 * c + r;
+      } else {
+        wr[a][b][0] = 144 + 12 * (2 * bi + a) + c; wr[a][b][1] = wr[a][b][0];
+      }
+    }
+  if (lane == 0) { S.cs[6][0] = 1.0; S.cs[6][1] = 0.0; }
   for (int sweep = 0; sweep < 14; ++sweep) {
     double maxoff = 0;
     for (int r = 0; r < 11; ++r) {
@@ -349,27 +376,18 @@ __device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* K, double* R_out
       }
       EPNP_WAVE_ORDER();
       // every operand address is fixed: all loads of the step in one round trip
-      const epnp_d2 ci = *reinterpret_cast<const epnp_d2*>(S.cs[gi]), cj = *reinterpret_cast<const epnp_d2*>(S.cs[gj]);
-      const epnp_d2 a0 = *reinterpret_cast<const epnp_d2*>(&S.A[12 * (2 * gi) + 2 * gj]);
-      const epnp_d2 a1 = *reinterpret_cast<const epnp_d2*>(&S.A[12 * (2 * gi + 1) + 2 * gj]);
-      const epnp_d2 cv0 = *reinterpret_cast<const epnp_d2*>(S.cs[vg0]), cv1 = *reinterpret_cast<const epnp_d2*>(S.cs[vg1]);
-      const epnp_d2 w0 = *reinterpret_cast<const epnp_d2*>(&S.V[12 * vk0 + 2 * vg0]);
-      const epnp_d2 w1 = *reinterpret_cast<const epnp_d2*>(&S.V[12 * vk1 + 2 * vg1]);
-      // B = A_blk J_j, A' = J_i^T B
+      const epnp_d2 ci = *reinterpret_cast<const epnp_d2*>(S.cs[ci_idx]), cj = *reinterpret_cast<const epnp_d2*>(S.cs[gj]);
+      const epnp_d2 a0 = *reinterpret_cast<const epnp_d2*>(&AV[rd0]);
+      const epnp_d2 a1 = *reinterpret_cast<const epnp_d2*>(&AV[rd1]);
+      // B = blk J_j, blk' = J_i^T B
       const double b00 = a0.x * cj.x - a0.y * cj.y, b01 = a0.x * cj.y + a0.y * cj.x;
       const double b10 = a1.x * cj.x - a1.y * cj.y, b11 = a1.x * cj.y + a1.y * cj.x;
       double n00 = ci.x * b00 - ci.y * b10, n01 = ci.x * b01 - ci.y * b11;
       double n10 = ci.y * b00 + ci.x * b10, n11 = ci.y * b01 + ci.x * b11;
-      if (gi == gj) { n01 = 0.0; n10 = 0.0; }      // the rotated pair's own off-diagonal entry
-      const double x0a = w0.x * cv0.x - w0.y * cv0.y, x0b = w0.x * cv0.y + w0.y * cv0.x;
-      const double x1a = w1.x * cv1.x - w1.y * cv1.y, x1b = w1.x * cv1.y + w1.y * cv1.x;
+      if (diag) { n01 = 0.0; n10 = 0.0; }      // the rotated pair's own off-diagonal entry
       __builtin_amdgcn_wave_barrier();   // all reads above are issued before any write below (one wave, in-order LDS)
-      if (lane < 36) {
-        S.A[12 * pi0 + pj0] = n00; S.A[12 * pi0 + pj1] = n01;
-        S.A[12 * pi1 + pj0] = n10; S.A[12 * pi1 + pj1] = n11;
-      }
-      S.V[v0a] = x0a; S.V[v0b] = x0b;
-      if (lane < 8) { S.V[v1a] = x1a; S.V[v1b] = x1b; }
+      AV[wr[0][0][0]] = n00; AV[wr[0][1][0]] = n01; AV[wr[1][0][0]] = n10; AV[wr[1][1][0]] = n11;
+      AV[wr[0][0][1]] = n00; AV[wr[0][1][1]] = n01; AV[wr[1][0][1]] = n10; AV[wr[1][1][1]] = n11;
       EPNP_WAVE_ORDER();
     }
     if (lane == 0) S.sweeps = sweep + 1;

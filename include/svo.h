@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SVO_ABI_VERSION 2
+#define SVO_ABI_VERSION 3
 
 typedef enum svo_status {
   SVO_OK = 0,
@@ -99,6 +99,27 @@ typedef struct svo_track_result {
   int32_t reserved[2];
 } svo_track_result;
 
+/* Offline detection boxes (main.cpp:59-97: one box per line, 4 ints `left right top bottom`) of a device-resident
+ * call, as HBM arrays: frame (or sequence) f of the call has n[f] boxes (0 <= n[f] <= 64) of four int32 each at
+ * boxes + 4 * stride * f.  All pointers are DEVICE pointers; a NULL svo_boxes_dev*, NULL members or n[f] = 0 mean "no boxes". */
+typedef struct svo_boxes_dev {
+  const int32_t* boxes;
+  const int32_t* n;
+  int32_t stride;          /* boxes reserved per frame (>= the largest n[f]) */
+} svo_boxes_dev;
+
+/* Parity probe record of one tracked frame (svo_debug_track_frames). */
+typedef struct svo_track_debug {
+  int32_t match_gid[512];  /* per keypoint: identity (creation sequence number) of the map point matched to it by
+                            * Tracking::init / pass 1 / pass 2 (CurrentFrame->MapPoints[j]), -1 none */
+  int32_t new_gid[512];    /* per keypoint: identity of the map point frame::createmappoint made from it, -1 none */
+  int32_t frame_id;
+  int32_t pnp_best, pnp_iterations, pnp_inliers, pnp_ok;   /* cv::solvePnPRansac: winning sample, samples visited, consensus */
+  int32_t active_rows[2], rounds[2];   /* matching passes 1 / 2: rows that could match at all, resolution rounds */
+  int32_t resolve_us;      /* duration of the frame's k_ti_resolve launch (in-kernel wall clock) */
+  double T_pnp[16];        /* the pose solvePnPRansac returned (row-major 4x4), before the CV_32F rounding and the LM */
+} svo_track_debug;
+
 /* ---- lifecycle ----------------------------------------------------------- */
 
 int svo_abi_version(void);
@@ -133,7 +154,11 @@ void svo_destroy(svo_ctx* ctx);
  * "depth_source" (default 0): where svo_track_frame / svo_track_batch_dev take keypoint depth from - 0 the sparse
  * epipolar matcher (north star), 1 a dense ELAS map (svo_elas_*), 2 a dense MSA map (svo_msa_solve with d = 48: the
  * reference's live configuration, src/Tracking.cc:225-228 + src/frame.cc:82-91), both read per keypoint as
- * frame::computekeypoint_r / disp2Depth do. */
+ * frame::computekeypoint_r / disp2Depth do.
+ * "epnp_exact" (default 0): 1 makes every RANSAC sample's EPnP follow OpenCV's own loops one after the other (cyclic
+ * one-sided Jacobi SVDs, SVD / QR least squares, IEEE division and square root, no FMA contraction), one lane per
+ * sample - the arithmetic of the CPU restatement the tests compare with, an order of magnitude slower than the
+ * wave-parallel solver of the default mode.  A parity switch: the fast mode is validated against it. */
 int svo_set_option(svo_ctx* ctx, const char* key, int value);
 /* Block until everything enqueued on the ctx stream has finished. */
 int svo_sync(svo_ctx* ctx);
@@ -232,9 +257,10 @@ int svo_bf_match(svo_ctx* ctx, const uint8_t* q, int M, const uint8_t* t, int N,
                  int32_t* train_idx, int32_t* dist, uint8_t* keep);
 
 /* a-6: cv::findFundamentalMat(cur_pts, last_pts, CV_FM_8POINT) (src/pnpmatch.cc:336): normalised
- * 8-point algorithm, float64, evaluated on the host (9x9 eigenproblem).  pts1/pts2: n x 2;
- * F row-major with p2^T F p1 = 0, scaled to F[8] = 1.  n < 8 -> F = 0 (OpenCV returns empty). */
-int svo_fundamental_8point(const double* pts1, const double* pts2, int n, double F[9]);
+ * 8-point algorithm in float64 on the device (one wavefront: normal matrix by wave reductions, wave-parallel Jacobi
+ * eigen-solver, rank-2 projection).  pts1 / pts2: n x 2 (HOST arrays, n <= 512); F row-major with p2^T F p1 = 0,
+ * scaled to F[8] = 1.  n < 8 -> F = 0 (OpenCV returns an empty matrix). */
+int svo_fundamental_8point(svo_ctx* ctx, const double* pts1, const double* pts2, int n, double F[9]);
 
 /* ---- a-10: PnP-RANSAC initial pose (src/pnpmatch.cc:212-247) ---------------- */
 /* cv::solvePnPRansac(pts3d, pts2d, K, Mat(), rvec, tvec, false, 100, 8.0, 0.99, inliers) as OpenCV 3.2 runs it (the
@@ -280,6 +306,10 @@ int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL, const uint8
 int svo_debug_track_matches(svo_ctx* ctx, int32_t* cur_mp);
 /* Parity probe: the F matrix and the number of epipolar vetoes of the frame just tracked. */
 int svo_debug_track_gate(svo_ctx* ctx, double F[9], int32_t* n_vetoed);
+/* Parity probe: map-point identities, RANSAC outcome and PnP pose of `n` frames of the LAST device-resident call
+ * (svo_track_batch_dev / _tail_dev / _sharded_dev: frames first .. first + n - 1 of that call; svo_track_multi_step_dev:
+ * sequences first ..; svo_track_frame: first = 0, n = 1).  Synchronises. */
+int svo_debug_track_frames(svo_ctx* ctx, int first, int n, svo_track_debug* out);
 
 /* Parity probe: cv::solvePnPRansac's outcome for the frame just tracked, and the pose (row-major 4x4, before the CV_32F
  * rounding of SetPose) it handed to PoseOptimization.  Either pointer may be NULL. */
@@ -295,29 +325,34 @@ int svo_frontend_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* 
                            int stride, int B, const svo_camera* cam, svo_kp* d_kpL,
                            uint8_t* d_descL, int32_t* d_nL, float* d_uR, float* d_depth);
 /* Batched front end followed by the ordered tracking tail for the same B pairs
- * (frames are consecutive frames of ONE sequence, in order).  d_results: B
+ * (frames are consecutive frames of ONE sequence, in order).  boxes (may be NULL): the frames' offline detection
+ * boxes in HBM, gating the chain exactly as svo_track_frame's host boxes do (creation gates, F from brute-force
+ * matches by the 8-point algorithm, epipolar veto - all on the device).  d_results: B
  * svo_track_result records in HBM.  Does not synchronise. */
 int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR,
-                        int stride, int B, svo_track_result* d_results);
+                        int stride, int B, const svo_boxes_dev* boxes, svo_track_result* d_results);
 
 /* The ordered tracking tail ALONE, for front-end results that already lie in HBM - e.g. produced by
  * svo_frontend_batch_dev of OTHER contexts / GPUs and copied here (pair k -> GPU k mod G, then the
  * strict chain of src/Tracking.cc:231-250 in frame order on one GPU).  Frame f of the call: keypoints at
  * d_kp + f * kp_stride, descriptors at d_desc + f * kp_stride * 32, keypoint count d_n[f], per-keypoint depths
- * (<= 0: none) at d_depth + f * kp_stride.  Records are identical to svo_track_batch_dev on the same frames.
- * No detection boxes in this mode.  Does not synchronise. */
+ * (<= 0: none) at d_depth + f * kp_stride.  boxes (may be NULL): frame f's detection boxes.  Records are identical to
+ * svo_track_batch_dev on the same frames.  Does not synchronise. */
 int svo_track_tail_dev(svo_ctx* ctx, const svo_kp* d_kp, const uint8_t* d_desc, const int32_t* d_n,
-                       const float* d_depth, int kp_stride, int B, svo_track_result* d_results);
+                       const float* d_depth, int kp_stride, int B, const svo_boxes_dev* boxes,
+                       svo_track_result* d_results);
 /* ONE sequence tracked with G contexts in one process, typically one per GPU (BASELINE configs[3]
  * "pair k -> GPU k mod 8 ... ordered tail"): the stateless front end of stereo pair k runs on ctxs[k mod G], the strict
  * temporal chain of src/Tracking.cc:231-250 runs in frame order on ctxs[0], which pulls each frame's keypoints /
- * descriptors / depths (~34 KB) with device-to-device copies on its own stream - no collective, no host round trip.
+ * descriptors / depths (~34 KB) on its own stream - direct peer reads (hipMemcpyPeerAsync over xGMI) where
+ * hipDeviceCanAccessPeer says so, a bounce through pinned host memory otherwise; no collective.
  * d_grayL[g] / d_grayR[g]: the pairs of context g, resident on ITS device, k ascending (pair k at local index k / G),
  * `stride` bytes per row.  All contexts: same W, H, max_kp; ctxs[g] needs max_batch >= ceil(B / G).  svo_track_reset on
  * ctxs[0] first; B frames per call; d_results: B records on ctxs[0]'s device.  Records are identical to
- * svo_track_batch_dev on a single context.  Does not synchronise (svo_sync(ctxs[0]) does). */
+ * svo_track_batch_dev on a single context.  boxes (may be NULL): frame k's detection boxes, on ctxs[0]'s device.
+ * Does not synchronise (svo_sync(ctxs[0]) does). */
 int svo_track_sharded_dev(svo_ctx* const* ctxs, int G, const uint8_t* const* d_grayL, const uint8_t* const* d_grayR,
-                          int stride, int B, svo_track_result* d_results);
+                          int stride, int B, const svo_boxes_dev* boxes, svo_track_result* d_results);
 /* Sticky capacity flag of the device tracker (synchronises): *flag != 0 once a frame needed more than the 4096 live
  * map points the pool holds, or a map point stayed alive for more than 2^20 creations (its slot in the position table
  * was about to be reused).  Neither can happen with the reference's 500 keypoints per frame on sequences of KITTI
@@ -331,10 +366,11 @@ int svo_track_overflowed(svo_ctx* ctx, int32_t* flag);
  * `stride` bytes per row, pairs back to back) is the next frame of sequence q, d_results[q] its record.
  * The front end runs batched over the n_seq pairs and every kernel of the temporal tail runs one
  * workgroup per sequence, so the strictly serial chain of one sequence overlaps with the others'.
- * Results are identical to n_seq separate single-sequence trackers.  No detection boxes in this mode. */
+ * Results are identical to n_seq separate single-sequence trackers.  boxes (may be NULL): entry q = the detection boxes
+ * of sequence q's frame of this step. */
 int svo_track_multi_reset(svo_ctx* ctx, int n_seq, const svo_camera* cam);
 int svo_track_multi_step_dev(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR, int stride,
-                             int n_seq, svo_track_result* d_results);
+                             int n_seq, const svo_boxes_dev* boxes, svo_track_result* d_results);
 
 /* Names + accumulated HIP-event time (ms) and launch count of the kernels the ctx
  * has timed since svo_profile_reset (only when svo_profile_enable(ctx,1)). */

@@ -218,6 +218,11 @@ TRACK_DTYPE = np.dtype([("Tcw", "<f4", (16,)), ("frame_id", "<i4"), ("n_kp", "<i
                         ("n_local_map", "<i4"), ("lm_iterations", "<i4"), ("reserved", "<i4", (2,))])
 
 
+# orc_tail_debug (svo_oracle.h); 4 bytes of padding in front of the doubles
+TAIL_DEBUG_DTYPE = np.dtype([("match_gid", "<i4", (512,)), ("new_gid", "<i4", (512,)), ("pnp", "<i4", (5,)), ("_pad", "<i4"),
+                             ("T_pnp", "<f8", (16,))])
+
+
 class Tracker:
     """orc_track.c: the reference's Tracking::Track loop on the CPU."""
 
@@ -245,6 +250,30 @@ class Tracker:
                                 0 if bx is None else len(bx), _p(res), _p(cur), _p(self.F))
         self.vetoes = l.orc_track_last_vetoes(C.c_void_p(self.h))
         return res[0], cur
+
+    def track_tail(self, kp, desc, depth, boxes=None, Tcw_force=None):
+        """orc_track_tail: the ordered tail for given front-end results (kp: KP_DTYPE records, desc: n x 32, depth: n
+        floats).  Returns (record, cur_mp, pnp stats dict, T_pnp 4x4); self.match_gid / self.new_gid: per-keypoint map-point
+        identities (creation sequence numbers) of the frame."""
+        n = len(kp)
+        kp = np.ascontiguousarray(kp); desc = np.ascontiguousarray(desc, np.uint8); depth = np.ascontiguousarray(depth, np.float32)
+        assert kp.dtype.itemsize == 28 and desc.shape == (n, 32) and depth.shape == (n,)
+        res = np.zeros(1, TRACK_DTYPE); cur = np.full(self.nf, -1, np.int32)
+        bx = None if boxes is None or len(boxes) == 0 else np.ascontiguousarray(boxes, np.int32)
+        tf = None if Tcw_force is None else np.ascontiguousarray(Tcw_force, np.float32).reshape(16)
+        self.F = np.zeros(9)
+        dbg = np.zeros(1, TAIL_DEBUG_DTYPE)
+        l = lib()
+        l.orc_track_tail.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.orc_track_tail(self.h, _p(kp), _p(desc), n, _p(depth), _p(bx), 0 if bx is None else len(bx), _p(tf), _p(res),
+                         _p(cur), _p(self.F), _p(dbg))
+        self.vetoes = l.orc_track_last_vetoes(C.c_void_p(self.h))
+        d = dbg[0]
+        self.match_gid, self.new_gid = d["match_gid"].copy(), d["new_gid"].copy()
+        pnp = dict(n_points=int(d["pnp"][0]), n_inliers=int(d["pnp"][1]), best_hypothesis=int(d["pnp"][2]), ok=int(d["pnp"][3]),
+                   iterations=int(d["pnp"][4]))
+        return res[0], cur, pnp, d["T_pnp"].reshape(4, 4).copy()
 
     def close(self):
         if self.h:

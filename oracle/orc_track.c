@@ -36,6 +36,7 @@ typedef struct {
   uint8_t desc[32];
   uint8_t bad, in_local;
   int32_t create_id;
+  int32_t gid;       /* creation sequence number: the identity the device tracker's records are compared by */
   int32_t obs_frame; /* id of the last frame that observed it (observations.count(cur)) */
 } mp_t;
 
@@ -43,6 +44,7 @@ struct orc_tracker {
   int W, H, nfeatures;
   float fx, fy, cx, cy, bf;
   int frame_num;
+  int next_gid;
   mp_t* pool;
   int npool;
   int lastN;
@@ -89,6 +91,7 @@ static int new_mappoint(orc_tracker* t, const float xyz[3], const uint8_t* desc,
   memcpy(m->pos, xyz, sizeof m->pos);
   memcpy(m->desc, desc, 32);
   m->bad = 0; m->in_local = 1; m->create_id = frame_id; m->obs_frame = -1;
+  m->gid = t->next_gid++;
   return t->npool++;
 }
 
@@ -112,8 +115,6 @@ int orc_track_frame_dense(orc_tracker* t, const uint8_t* grayL, int strideL, con
                           int strideR, const float* dense_disp, const int32_t* boxes, int n_boxes,
                           orc_track_result* res, int32_t* cur_mp_out, double F_out[9]) {
   const int NF = t->nfeatures;
-  double F[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  t->last_vetoes = 0;
   orc_kp* kp = (orc_kp*)calloc((size_t)NF, sizeof(orc_kp));
   uint8_t* desc = (uint8_t*)calloc((size_t)NF, 32);
   float* uR = (float*)calloc((size_t)NF, sizeof(float));
@@ -129,6 +130,36 @@ int orc_track_frame_dense(orc_tracker* t, const uint8_t* grayL, int strideL, con
   } else {
     orc_stereo_frame(grayL, strideL, grayR, strideR, t->W, t->H, NF, t->bf, t->fx, kp, desc, &nkp, uR,
                      depth, NULL, NULL, NULL);
+  }
+  const int rc = orc_track_tail(t, kp, desc, nkp, depth, boxes, n_boxes, NULL, res, cur_mp_out, F_out, NULL);
+  free(kp); free(desc); free(uR); free(depth);
+  return rc;
+}
+
+/* The ordered tail of Tracking::Track ALONE (src/Tracking.cc:231-250 and what it calls: matching passes, PnP, pose
+ * optimisation, createmappoint, cull) for a frame whose front-end results are given: nkp keypoints (cv::KeyPoint layout),
+ * their 32-byte descriptors and per-keypoint depths (<= 0: none).  This is what the full-length parity test feeds with
+ * the device front end's outputs (which are bit-exact against orc_stereo_frame by their own tests), so that all 4,541
+ * frames of a KITTI-00-sized run meet the restatement without 4,541 CPU ORB extractions.
+ *   Tcw_force (nullable, row-major 4x4 float): "teacher forcing" - the frame's own pose is computed and reported in
+ *     res->Tcw as always, but the tracker then CONTINUES from Tcw_force (the pose another implementation found for this
+ *     frame): the positions of the map points created at the frame's end and the fallback pose of the next frame's PnP
+ *     use it.  Each frame's PnP + LM is then compared on identical inputs instead of on a trajectory whose rounding
+ *     differences accumulate.
+ *   dbg (nullable): per keypoint the identity (creation sequence number) of the map point matched to it / created from
+ *     it, cv::solvePnPRansac's outcome for this frame (zeros on frame 0) and the pose it returned, before the CV_32F
+ *     rounding and the LM. */
+int orc_track_tail(orc_tracker* t, const orc_kp* kp, const uint8_t* desc, int nkp, const float* depth,
+                   const int32_t* boxes, int n_boxes, const float* Tcw_force, orc_track_result* res,
+                   int32_t* cur_mp_out, double F_out[9], orc_tail_debug* dbg) {
+  const int NF = t->nfeatures;
+  double F[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  t->last_vetoes = 0;
+  if (nkp > NF) nkp = NF;
+  if (dbg) {
+    memset(dbg, 0, sizeof *dbg);
+    for (int i = 0; i < 16; ++i) dbg->T_pnp[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    for (int i = 0; i < TRK_MAXKP; ++i) dbg->match_gid[i] = dbg->new_gid[i] = -1;
   }
   const int id = t->frame_num;
   int32_t cur_mp[TRK_MAXKP];
@@ -225,6 +256,7 @@ int orc_track_frame_dense(orc_tracker* t, const uint8_t* grayL, int strideL, con
     orc_pnp_stats ps;
     orc_pnp_ransac(Xw, ob, n, K, Tp, 0, Td, NULL, &ps);   /* fails -> the pose stays at the last frame's */
     res->n_pnp_inliers = ps.n_inliers;
+    if (dbg) { dbg->pnp = ps; memcpy(dbg->T_pnp, Td, sizeof Td); }
     for (int i = 0; i < 16; ++i) Tcw[i] = (float)Td[i];
     free(Xw); free(ob);
   }
@@ -251,6 +283,10 @@ int orc_track_frame_dense(orc_tracker* t, const uint8_t* grayL, int strideL, con
     free(Xw); free(ob);
   }
   memcpy(res->Tcw, Tcw, sizeof Tcw);
+  if (dbg)
+    for (int j = 0; j < nkp; ++j)
+      if (cur_mp[j] >= 0) dbg->match_gid[j] = t->pool[cur_mp[j]].gid;
+  if (Tcw_force) memcpy(Tcw, Tcw_force, sizeof Tcw);   /* teacher forcing: carry on from the other implementation's pose */
   if (cur_mp_out) memcpy(cur_mp_out, cur_mp, sizeof(int32_t) * (size_t)NF);
   /* lastframe = frame(currentframe); lastframe.createmappoint (src/frame.cc:182-238) */
   {
@@ -263,6 +299,7 @@ int orc_track_frame_dense(orc_tracker* t, const uint8_t* grayL, int strideL, con
         float uvz[3] = {kp[i].x, kp[i].y, depth[i]}, xyz[3];
         orc_unproject(uvz, 1, t->fx, t->fy, t->cx, t->cy, Rwc, twc, xyz);
         cur_mp[i] = new_mappoint(t, xyz, desc + 32 * (size_t)i, id);
+        if (dbg && cur_mp[i] >= 0) dbg->new_gid[i] = t->pool[cur_mp[i]].gid;
         res->n_new_mappoints++;
       }
     }
@@ -298,6 +335,5 @@ int orc_track_frame_dense(orc_tracker* t, const uint8_t* grayL, int strideL, con
     free(live); free(remap);
   }
   t->frame_num++;
-  free(kp); free(desc); free(uR); free(depth);
   return 0;
 }

@@ -130,6 +130,16 @@ int orc_track_frame_dense(orc_tracker* t, const uint8_t* grayL, int strideL, con
 int orc_track_frame_boxes(orc_tracker* t, const uint8_t* grayL, int strideL, const uint8_t* grayR,
                           int strideR, const int32_t* boxes, int n_boxes, orc_track_result* res,
                           int32_t* cur_mp_out, double F_out[9]);
+/* the ordered tail alone, for given front-end results (see orc_track.c); Tcw_force: teacher forcing (nullable) */
+typedef struct orc_tail_debug {
+  int32_t match_gid[512];   /* per keypoint: creation sequence number of the map point matched to it (frame 0: created by init), -1 none */
+  int32_t new_gid[512];     /* per keypoint: creation sequence number of the map point created from it at the frame's end, -1 none */
+  orc_pnp_stats pnp;        /* cv::solvePnPRansac's outcome (zeros on frame 0) */
+  double T_pnp[16];         /* the pose it returned (row-major 4x4), before the CV_32F rounding and the LM */
+} orc_tail_debug;
+int orc_track_tail(orc_tracker* t, const orc_kp* kp, const uint8_t* desc, int nkp, const float* depth,
+                   const int32_t* boxes, int n_boxes, const float* Tcw_force, orc_track_result* res,
+                   int32_t* cur_mp_out, double F_out[9], orc_tail_debug* dbg);
 
 #ifdef __cplusplus
 }

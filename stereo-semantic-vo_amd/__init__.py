@@ -33,6 +33,12 @@ TRACK_DTYPE = np.dtype([("Tcw", "<f4", (16,)), ("frame_id", "<i4"), ("n_kp", "<i
                         ("n_pnp_inliers", "<i4"), ("n_lm_edges", "<i4"), ("n_new_mappoints", "<i4"),
                         ("n_local_map", "<i4"), ("lm_iterations", "<i4"), ("reserved", "<i4", (2,))])
 
+# svo_track_debug (include/svo.h): parity probe record of one tracked frame
+TRACK_DEBUG_DTYPE = np.dtype([("match_gid", "<i4", (512,)), ("new_gid", "<i4", (512,)), ("frame_id", "<i4"),
+                              ("pnp_best", "<i4"), ("pnp_iterations", "<i4"), ("pnp_inliers", "<i4"), ("pnp_ok", "<i4"),
+                              ("active_rows", "<i4", (2,)), ("rounds", "<i4", (2,)), ("resolve_us", "<i4"),
+                              ("T_pnp", "<f8", (16,))])
+
 # Every symbol include/svo.h declares (checked by tests/test_abi.py without a GPU).
 ABI_SYMBOLS = [
     "svo_abi_version", "svo_strerror", "svo_last_error", "svo_create", "svo_destroy", "svo_sync",
@@ -42,7 +48,7 @@ ABI_SYMBOLS = [
     "svo_unproject", "svo_descriptor_distance", "svo_hamming_argmin", "svo_match_greedy",
     "svo_match_greedy_gated",
     "svo_bf_match", "svo_pnp_ransac", "svo_debug_epnp5", "svo_pose_opt", "svo_track_reset", "svo_track_frame",
-    "svo_debug_track_matches", "svo_debug_track_gate", "svo_debug_track_pnp", "svo_fundamental_8point",
+    "svo_debug_track_matches", "svo_debug_track_gate", "svo_debug_track_pnp", "svo_debug_track_frames", "svo_fundamental_8point",
     "svo_frontend_batch_dev", "svo_track_batch_dev", "svo_profile_enable", "svo_profile_reset",
     "svo_profile_get",
     "svo_elas_default_params", "svo_elas_process", "svo_elas_process_ex", "svo_elas_delaunay",
@@ -57,6 +63,20 @@ class SvoError(RuntimeError):
 class Camera(C.Structure):
     _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
                 ("bf", C.c_float)]
+
+
+class BoxesDev(C.Structure):
+    """svo_boxes_dev: per-frame detection boxes as HBM arrays (device pointers)."""
+    _fields_ = [("boxes", C.c_void_p), ("n", C.c_void_p), ("stride", C.c_int32)]
+
+
+def boxes_dev(d_boxes, d_n, stride):
+    """svo_boxes_dev from two device pointers (e.g. torch int32 tensors' data_ptr()): boxes (F x stride x 4), n (F)."""
+    return BoxesDev(C.c_void_p(int(d_boxes)), C.c_void_p(int(d_n)), int(stride))
+
+
+def _bx(b):
+    return None if b is None else C.byref(b)
 
 
 class LmStats(C.Structure):
@@ -296,15 +316,20 @@ class Svo:
         self._chk(self.lib.svo_debug_track_gate(self.h, _p(F), C.byref(n)))
         return F.reshape(3, 3), n.value
 
-    @staticmethod
-    def fundamental_8point(pts1, pts2):
+    def fundamental_8point(self, pts1, pts2):
+        """cv::findFundamentalMat(pts1, pts2, CV_FM_8POINT) on the device (svo_fundamental_8point)."""
         pts1 = np.ascontiguousarray(pts1, np.float64).reshape(-1, 2)
         pts2 = np.ascontiguousarray(pts2, np.float64).reshape(-1, 2)
         F = np.zeros(9)
-        rc = load_library().svo_fundamental_8point(_p(pts1), _p(pts2), len(pts1), _p(F))
-        if rc != 0:
-            raise SvoError("svo_fundamental_8point failed")
+        self._chk(self.lib.svo_fundamental_8point(self.h, _p(pts1), _p(pts2), len(pts1), _p(F)))
         return F.reshape(3, 3)
+
+    def debug_track_frames(self, first, n):
+        """svo_debug_track_frames: TRACK_DEBUG_DTYPE records of n frames of the last device-resident call."""
+        out = np.zeros(n, TRACK_DEBUG_DTYPE)
+        assert TRACK_DEBUG_DTYPE.itemsize == 4096 + 10 * 4 + 128
+        self._chk(self.lib.svo_debug_track_frames(self.h, int(first), int(n), _p(out)))
+        return out
 
     def debug_track_matches(self):
         out = np.zeros(self.max_kp, np.int32)
@@ -318,23 +343,24 @@ class Svo:
                                                   int(B), C.byref(cam), _p(d_kpL), _p(d_descL),
                                                   _p(d_nL), _p(d_uR), _p(d_depth)))
 
-    def track_batch_dev(self, d_grayL, d_grayR, stride, B, d_results):
-        self._chk(self.lib.svo_track_batch_dev(self.h, _p(d_grayL), _p(d_grayR), int(stride), int(B),
+    def track_batch_dev(self, d_grayL, d_grayR, stride, B, d_results, boxes=None):
+        """boxes: a BoxesDev (boxes_dev(...)) with the frames' offline detection boxes in HBM, or None."""
+        self._chk(self.lib.svo_track_batch_dev(self.h, _p(d_grayL), _p(d_grayR), int(stride), int(B), _bx(boxes),
                                                _p(d_results)))
 
-    def track_tail_dev(self, d_kp, d_desc, d_n, d_depth, kp_stride, B, d_results):
+    def track_tail_dev(self, d_kp, d_desc, d_n, d_depth, kp_stride, B, d_results, boxes=None):
         """svo_track_tail_dev: the ordered tail over front-end results already in HBM (device pointers)."""
         self._chk(self.lib.svo_track_tail_dev(self.h, _p(d_kp), _p(d_desc), _p(d_n), _p(d_depth), int(kp_stride),
-                                              int(B), _p(d_results)))
+                                              int(B), _bx(boxes), _p(d_results)))
 
     @staticmethod
-    def track_sharded_dev(ctxs, d_grayL, d_grayR, stride, B, d_results):
+    def track_sharded_dev(ctxs, d_grayL, d_grayR, stride, B, d_results, boxes=None):
         """svo_track_sharded_dev: ONE sequence, pair k on ctxs[k % G], ordered tail on ctxs[0]."""
         G = len(ctxs)
         hs = (C.c_void_p * G)(*[c.h for c in ctxs])
         pl = (C.c_void_p * G)(*[C.c_void_p(int(p)) for p in d_grayL])
         pr = (C.c_void_p * G)(*[C.c_void_p(int(p)) for p in d_grayR])
-        ctxs[0]._chk(ctxs[0].lib.svo_track_sharded_dev(hs, G, pl, pr, int(stride), int(B), _p(d_results)))
+        ctxs[0]._chk(ctxs[0].lib.svo_track_sharded_dev(hs, G, pl, pr, int(stride), int(B), _bx(boxes), _p(d_results)))
 
     def track_overflowed(self):
         f = C.c_int32(0)
@@ -344,9 +370,9 @@ class Svo:
     def track_multi_reset(self, n_seq, cam):
         self._chk(self.lib.svo_track_multi_reset(self.h, int(n_seq), C.byref(cam)))
 
-    def track_multi_step_dev(self, d_grayL, d_grayR, stride, n_seq, d_results):
+    def track_multi_step_dev(self, d_grayL, d_grayR, stride, n_seq, d_results, boxes=None):
         self._chk(self.lib.svo_track_multi_step_dev(self.h, C.c_void_p(d_grayL), C.c_void_p(d_grayR), int(stride),
-                                                     int(n_seq), C.c_void_p(d_results)))
+                                                     int(n_seq), _bx(boxes), C.c_void_p(d_results)))
 
     def profile_enable(self, on=True):
         self._chk(self.lib.svo_profile_enable(self.h, 1 if on else 0))

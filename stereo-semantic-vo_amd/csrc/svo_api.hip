@@ -808,6 +808,14 @@ static int frontend_slice(svo_ctx* ctx, hipStream_t st, const uint8_t* d_grayL, 
   return rc;
 }
 
+// Slices svo_frontend_batch_dev cuts a batch of B pairs into (1: one chain).  Slice k covers the pairs [k B / ns, (k + 1) B / ns)
+// and keeps the results of its LEFT images at the context's slots 2 p0 .. (its right images behind them) - callers that read
+// the context's own buffers (svo_track_sharded_dev) need the same rule.
+int svo_frontend_nslices(const svo_ctx* ctx, int B) {
+  const int ns = std::min(ctx->opt_frontend_overlap, B / 8);
+  return (ns < 2 || ctx->profiling) ? 1 : ns;
+}
+
 extern "C" int svo_frontend_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR,
                                       int stride, int B, const svo_camera* cam, svo_kp* d_kpL,
                                       uint8_t* d_descL, int32_t* d_nL, float* d_uR,
@@ -819,8 +827,8 @@ extern "C" int svo_frontend_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, cons
   // vector ALUs 88 % busy) and latency-bound ones (k_select, k_stereo_*, the small pyramid levels: a few waves per CU
   // waiting on memory) - side by side they fill each other's gaps.  With the per-kernel timers on (svo_profile_enable)
   // the batch runs as one chain on one stream, so that a kernel's time is its own.
-  const int ns = std::min(ctx->opt_frontend_overlap, B / 8);
-  if (ns < 2 || ctx->profiling)
+  const int ns = svo_frontend_nslices(ctx, B);
+  if (ns < 2)
     return frontend_slice(ctx, ctx->stream, d_grayL, d_grayR, stride, 0, B, cam, d_kpL, d_descL, d_nL, d_uR, d_depth);
   while ((int)ctx->fe_streams.size() < ns - 1) {
     hipStream_t st;

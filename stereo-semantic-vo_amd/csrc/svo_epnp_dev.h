@@ -236,75 +236,12 @@ __device__ __forceinline__ double epnp_dot3(const double* a, const double* b) {
 #pragma clang fp contract(fast)
   return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 
-// One hypothesis.  Called by all 64 lanes of a wave; the result (R row-major, t) is returned in every lane.  The sample
-// is expected in S.x5 (5 x 3) / S.u5 (5 x 2) (doubles holding float values); K = {fu, fv, uc, vc}.
-__device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* K, double* R_out, double* t_out) {
+// Eigen-decomposition of the symmetric 12 x 12 matrix in S.A (V must hold the identity), by the whole wave: on return the
+// diagonal of S.A holds the eigenvalues (in no particular order) and column j of S.V the eigenvector of S.A[13 j].
+// Also used by the 8-point fundamental matrix (svo_track.hip: its 9 x 9 normal matrix padded to 12 x 12).
+__device__ inline void epnp_eig12_wave(EpnpWaveLds& S) {
 #pragma clang fp contract(fast)
   const int lane = threadIdx.x & 63;
-  // the sample lives in LDS, S.x5 / S.u5, filled by the caller (uniform reads broadcast): keeps ~50 registers free
-  // across the eigen-solver
-  EPNP_WAVE_SYNC();
-  const double* Xw = S.x5;
-  const double* uv = S.u5;
-  const double fu = K[0], fv = K[1], uc = K[2], vc = K[3];
-  if (lane == 0) S.stamp[0] = clock64();
-  // ---- choose_control_points + compute_barycentric_coordinates (every lane, same scalar code) -------------------
-  double cw0[3] = {0, 0, 0};
-#pragma unroll
-  for (int i = 0; i < 5; ++i) { cw0[0] += Xw[3 * i]; cw0[1] += Xw[3 * i + 1]; cw0[2] += Xw[3 * i + 2]; }
-  cw0[0] *= 0.2; cw0[1] *= 0.2; cw0[2] *= 0.2;
-  double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const double d[3] = {Xw[3 * i] - cw0[0], Xw[3 * i + 1] - cw0[1], Xw[3 * i + 2] - cw0[2]};
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int b = 0; b < 3; ++b) cov[3 * a + b] += d[a] * d[b];
-  }
-  double dc[3], uct[9], vt3[9];
-  epnp_svd3(cov, dc, uct, vt3);
-  double kk[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) kk[i] = epnp_sqrt(dc[i] * 0.2);
-  // control points cws[0] = centroid, cws[i] = centroid + k_i u_i; CC = [k1 u1 | k2 u2 | k3 u3] has orthogonal columns: its
-  // inverse (OpenCV: cvInvert through an SVD) is diag(1/k) U^T.  Both go to LDS: later stages index them dynamically.
-  if (lane < 12) {
-    const int i = lane / 3, j = lane % 3;
-    const double ki = i == 1 ? kk[0] : (i == 2 ? kk[1] : kk[2]);
-    const double uij = i == 0 ? 0.0 : (i == 1 ? (j == 0 ? uct[0] : (j == 1 ? uct[1] : uct[2]))
-                                               : (i == 2 ? (j == 0 ? uct[3] : (j == 1 ? uct[4] : uct[5]))
-                                                         : (j == 0 ? uct[6] : (j == 1 ? uct[7] : uct[8]))));
-    const double c0 = j == 0 ? cw0[0] : (j == 1 ? cw0[1] : cw0[2]);
-    S.cws[i][j] = i == 0 ? c0 : c0 + ki * uij;
-  }
-  if (lane < 5) {
-    const double d[3] = {Xw[3 * lane] - cw0[0], Xw[3 * lane + 1] - cw0[1], Xw[3 * lane + 2] - cw0[2]};
-    double a[4];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) a[1 + j] = kk[j] > 0 ? epnp_dot3(&uct[3 * j], d) * epnp_rcp2(kk[j]) : 0.0;
-    a[0] = 1.0 - a[1] - a[2] - a[3];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) S.alphas[4 * lane + j] = a[j];
-  }
-  EPNP_WAVE_SYNC();
-  const double* alphas = S.alphas;
-  // ---- M^T M: entry (a, b) = sum over the 10 rows of M; M row pair of point i = alpha (x) (fu, 0, uc - u), (0, fv, vc - v)
-  for (int e = lane; e < 144; e += 64) {
-    const int a = e / 12, b = e % 12, ia = a / 3, ca = a % 3, ib = b / 3, cb = b % 3;
-    double s = 0;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const double du = uc - uv[2 * i], dv = vc - uv[2 * i + 1];
-      const double r1a = ca == 0 ? fu : (ca == 1 ? 0.0 : du), r2a = ca == 0 ? 0.0 : (ca == 1 ? fv : dv);
-      const double r1b = cb == 0 ? fu : (cb == 1 ? 0.0 : du), r2b = cb == 0 ? 0.0 : (cb == 1 ? fv : dv);
-      s += alphas[4 * i + ia] * alphas[4 * i + ib] * (r1a * r1b + r2a * r2b);
-    }
-    S.A[e] = s;
-    S.V[e] = a == b ? 1.0 : 0.0;
-  }
-  EPNP_WAVE_SYNC();
-  if (lane == 0) S.stamp[1] = clock64();
   // ---- eigen-decomposition: parallel-order two-sided Jacobi in its SYSTOLIC form (Brent & Luk) -----------------------
   // The six pairs of a step always sit at the adjacent POSITIONS (0,1) (2,3) ... (10,11); after the rotations the rows
   // and columns of A and the columns of V are moved by the fixed permutation `epnp_pi` (the circle method's rotation of
@@ -397,6 +334,78 @@ __device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* K, double* R_out
     const uint64_t big = __ballot(lane < 6 && maxoff > 1e-7 * trace);
     if (big == 0) break;
   }
+}
+
+// One hypothesis.  Called by all 64 lanes of a wave; the result (R row-major, t) is returned in every lane.  The sample
+// is expected in S.x5 (5 x 3) / S.u5 (5 x 2) (doubles holding float values); K = {fu, fv, uc, vc}.
+__device__ inline bool epnp5_wave(EpnpWaveLds& S, const double* K, double* R_out, double* t_out) {
+#pragma clang fp contract(fast)
+  const int lane = threadIdx.x & 63;
+  // the sample lives in LDS, S.x5 / S.u5, filled by the caller (uniform reads broadcast): keeps ~50 registers free
+  // across the eigen-solver
+  EPNP_WAVE_SYNC();
+  const double* Xw = S.x5;
+  const double* uv = S.u5;
+  const double fu = K[0], fv = K[1], uc = K[2], vc = K[3];
+  if (lane == 0) S.stamp[0] = clock64();
+  // ---- choose_control_points + compute_barycentric_coordinates (every lane, same scalar code) -------------------
+  double cw0[3] = {0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 5; ++i) { cw0[0] += Xw[3 * i]; cw0[1] += Xw[3 * i + 1]; cw0[2] += Xw[3 * i + 2]; }
+  cw0[0] *= 0.2; cw0[1] *= 0.2; cw0[2] *= 0.2;
+  double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const double d[3] = {Xw[3 * i] - cw0[0], Xw[3 * i + 1] - cw0[1], Xw[3 * i + 2] - cw0[2]};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) cov[3 * a + b] += d[a] * d[b];
+  }
+  double dc[3], uct[9], vt3[9];
+  epnp_svd3(cov, dc, uct, vt3);
+  double kk[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) kk[i] = epnp_sqrt(dc[i] * 0.2);
+  // control points cws[0] = centroid, cws[i] = centroid + k_i u_i; CC = [k1 u1 | k2 u2 | k3 u3] has orthogonal columns: its
+  // inverse (OpenCV: cvInvert through an SVD) is diag(1/k) U^T.  Both go to LDS: later stages index them dynamically.
+  if (lane < 12) {
+    const int i = lane / 3, j = lane % 3;
+    const double ki = i == 1 ? kk[0] : (i == 2 ? kk[1] : kk[2]);
+    const double uij = i == 0 ? 0.0 : (i == 1 ? (j == 0 ? uct[0] : (j == 1 ? uct[1] : uct[2]))
+                                               : (i == 2 ? (j == 0 ? uct[3] : (j == 1 ? uct[4] : uct[5]))
+                                                         : (j == 0 ? uct[6] : (j == 1 ? uct[7] : uct[8]))));
+    const double c0 = j == 0 ? cw0[0] : (j == 1 ? cw0[1] : cw0[2]);
+    S.cws[i][j] = i == 0 ? c0 : c0 + ki * uij;
+  }
+  if (lane < 5) {
+    const double d[3] = {Xw[3 * lane] - cw0[0], Xw[3 * lane + 1] - cw0[1], Xw[3 * lane + 2] - cw0[2]};
+    double a[4];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) a[1 + j] = kk[j] > 0 ? epnp_dot3(&uct[3 * j], d) * epnp_rcp2(kk[j]) : 0.0;
+    a[0] = 1.0 - a[1] - a[2] - a[3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) S.alphas[4 * lane + j] = a[j];
+  }
+  EPNP_WAVE_SYNC();
+  const double* alphas = S.alphas;
+  // ---- M^T M: entry (a, b) = sum over the 10 rows of M; M row pair of point i = alpha (x) (fu, 0, uc - u), (0, fv, vc - v)
+  for (int e = lane; e < 144; e += 64) {
+    const int a = e / 12, b = e % 12, ia = a / 3, ca = a % 3, ib = b / 3, cb = b % 3;
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const double du = uc - uv[2 * i], dv = vc - uv[2 * i + 1];
+      const double r1a = ca == 0 ? fu : (ca == 1 ? 0.0 : du), r2a = ca == 0 ? 0.0 : (ca == 1 ? fv : dv);
+      const double r1b = cb == 0 ? fu : (cb == 1 ? 0.0 : du), r2b = cb == 0 ? 0.0 : (cb == 1 ? fv : dv);
+      s += alphas[4 * i + ia] * alphas[4 * i + ib] * (r1a * r1b + r2a * r2b);
+    }
+    S.A[e] = s;
+    S.V[e] = a == b ? 1.0 : 0.0;
+  }
+  EPNP_WAVE_SYNC();
+  if (lane == 0) S.stamp[1] = clock64();
+  epnp_eig12_wave(S);
   if (lane == 0) S.stamp[2] = clock64();
   // ---- the four smallest eigenvalues' vectors: v4[0] = smallest (ut + 12 * 11 of OpenCV's descending order) --------
   if (lane < 12) {

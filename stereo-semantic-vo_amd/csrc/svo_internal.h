@@ -186,6 +186,7 @@ template <typename T>
 __host__ __device__ inline T* svo_byte_offset(T* p, size_t bytes) {
   return p ? reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + bytes) : p;
 }
+int svo_frontend_nslices(const svo_ctx* ctx, int B);   // how svo_frontend_batch_dev slices a batch (svo_api.hip)
 int svo_launch_disp2depth(svo_ctx* ctx, const float* disp, int count, float bf, float* depth);
 int svo_launch_unproject(svo_ctx* ctx, const float* uvz, int n, const svo_camera* cam,
                          const float* Rwc, const float* twc, float* xyz);

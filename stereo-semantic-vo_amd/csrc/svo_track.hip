@@ -37,14 +37,19 @@
 // Offline detection boxes (main.cpp:82-95) gate the path exactly where the reference uses them: the +-5 px creation
 // gates (src/Tracking.cc:61-66 with its never-reset flag, src/frame.cc:198-203) and the +-10 px epipolar veto of
 // pass 1 (src/pnpmatch.cc:101-144) with F from the 8-point algorithm over brute-force matches
-// (src/pnpmatch.cc:302-337; svo_fmat.hip, host side).
+// (src/pnpmatch.cc:302-337): two more launches in front of the index chain of a frame that carries boxes - k_tg_bf
+// (nearest last-frame descriptor of every keypoint) and k_tg_fmat (one wave: match filter, Hartley normalisation, normal
+// matrix, wave-parallel Jacobi, rank-2 projection; svo_fmat_dev.h).  Boxes arrive as HBM arrays in every mode
+// (svo_boxes_dev), nothing of a gated frame touches the host.
 #include <cstddef>
+#include <cstring>
 #include <mutex>
 
 #include "svo_internal.h"
 #include "svo_wave.h"
 #include "svo_gate.h"
 #include "svo_pose_dev.h"
+#include "svo_fmat_dev.h"
 
 #define TRK_MAXKP 512
 #define TRK_CAP 4096
@@ -73,6 +78,9 @@ struct TrackWork {
   int32_t edge_gid[TRK_MAXKP];   //   id of the map point (CurrentFrame->MapPoints[j]->...) ...
   int16_t edge_kp[TRK_MAXKP];    //   ... and the keypoint j it is matched to
   int32_t new_gid[TRK_MAXKP];    // per keypoint: id of the map point created from it at the frame's end, or -1
+  // written by the pose chain (k_tp_frame), for svo_debug_track_frames: cv::solvePnPRansac's outcome and pose
+  int32_t pnp_best, pnp_iterations, pnp_inliers, pnp_ok;
+  double T_pnp[16];
 };
 
 struct TrackState {
@@ -280,6 +288,7 @@ struct TiLds {
   uint8_t ref[TRK_CAP];            // pool row referenced by the frame's keypoints (kept alive for the next pass 1)
   int16_t remap[TRK_CAP];          // pool row -> row after compaction
   int cnt_acc, cnt_veto, cnt_late, nd, flag[2];
+  int32_t boxes[SVO_MAX_BOXES * 4];   // the frame's detection boxes {left, right, top, bottom}
   uint16_t dn[TRK_CAP];            // dense active rows of the running pass
   uint16_t dnD[TRK_DNC][512];      // distance rows of the first TRK_DNC of them (fetched once per pass)
 };
@@ -319,7 +328,7 @@ __device__ __forceinline__ bool ti_finalize(TiLds& S, TrackState* st, TrackPool&
     // line -> the map point is marked bad and claims nothing
     const svo_kp kc = kp[bj];
     const int i_last = S.act_i[k];
-    if (svo_in_boxes(kc.x, kc.y, st->boxes, n_boxes, 10) &&
+    if (svo_in_boxes(kc.x, kc.y, S.boxes, n_boxes, 10) &&
         svo_epipolar_distance(st->F, st->last_xy[2 * i_last], st->last_xy[2 * i_last + 1], kc.x, kc.y) > 0.1) {
       P.bad[m] = 1;
       tally += 1 << 10;
@@ -568,15 +577,18 @@ __device__ __forceinline__ int ti_resolve_pass(TiLds& S, TrackState* st, TrackPo
 
 extern __shared__ __attribute__((aligned(16))) unsigned char tk_smem[];
 
+// boxes / nboxes (nullable): the detection boxes of this frame - of sequence blockIdx.y: `bstride` boxes further on each
 __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* work, const svo_kp* kp,
                                                      const uint32_t* desc, const int32_t* nkp_p, const float* depth,
-                                                     int kstride) {
+                                                     int kstride, const int32_t* boxes, const int32_t* nboxes, int bstride) {
   TiLds& S = *reinterpret_cast<TiLds*>(tk_smem);
   st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
   desc += (size_t)blockIdx.y * kstride * 8; nkp_p += blockIdx.y; depth += (size_t)blockIdx.y * kstride;
   const int tid = threadIdx.x;
   const int nkp = min(*nkp_p, TRK_MAXKP);
-  const int id = st->frame_num, n_boxes = st->n_boxes;
+  const int n_boxes = (boxes && nboxes) ? min(max(nboxes[blockIdx.y], 0), SVO_MAX_BOXES) : 0;
+  if (tid < 4 * n_boxes) S.boxes[tid] = boxes[(size_t)blockIdx.y * bstride * 4 + tid];   // visible after the first barrier below
+  const int id = st->frame_num;
   const int np_start = st->npool, lastN = st->lastN, gid0 = st->next_gid;
   TrackPool& P = st->pool[st->cur];
   TrackPool& Q = st->pool[st->cur ^ 1];
@@ -597,7 +609,7 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
     bool create0 = has_depth;
     if (n_boxes > 0) {
       const svo_kp k = kp[min(tid, max(nkp - 1, 0))];
-      const bool inb = tid < nkp && svo_in_boxes(k.x, k.y, st->boxes, n_boxes, 5);
+      const bool inb = tid < nkp && svo_in_boxes(k.x, k.y, S.boxes, n_boxes, 5);
       int tot_in;
       const int before = block_excl_scan(inb ? 1 : 0, S.sm, &tot_in);
       if (before + (inb ? 1 : 0) > 0) create0 = false;
@@ -676,7 +688,7 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
   if (tid < nkp) {
     const svo_kp k = kp[tid];
     dk0 = reinterpret_cast<const uint4*>(desc + 8 * tid)[0]; dk1 = reinterpret_cast<const uint4*>(desc + 8 * tid)[1];
-    if (create && n_boxes > 0 && svo_in_boxes(k.x, k.y, st->boxes, n_boxes, 5)) create = false;
+    if (create && n_boxes > 0 && svo_in_boxes(k.x, k.y, S.boxes, n_boxes, 5)) create = false;
     st->last_xy[2 * tid] = k.x; st->last_xy[2 * tid + 1] = k.y;
     reinterpret_cast<uint4*>(st->last_desc + 8 * tid)[0] = dk0; reinterpret_cast<uint4*>(st->last_desc + 8 * tid)[1] = dk1;
   }
@@ -773,6 +785,108 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
 }
 
 // ================================================================================================
+// Semantic gating, in front of the index chain of a frame that carries detection boxes
+// ================================================================================================
+// pnpmatch::find_feature_matches (src/pnpmatch.cc:253-300): cv BruteForce-Hamming match(desc_cur, desc_last) - for every
+// keypoint of the current frame the nearest descriptor of the last frame (first minimum).  One wave per current keypoint,
+// the last frame's descriptors transposed in LDS as in k_ti_lists.  blockIdx.y = sequence.
+__global__ __launch_bounds__(256) void k_tg_bf(TrackState* st, const uint32_t* desc, const int32_t* nkp_p, int kstride,
+                                               const int32_t* nboxes) {
+  __shared__ uint32_t td[8 * TRK_MAXKP];
+  st += blockIdx.y; desc += (size_t)blockIdx.y * kstride * 8; nkp_p += blockIdx.y;
+  if (nboxes[blockIdx.y] <= 0 || st->frame_num == 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nkp = min(*nkp_p, TRK_MAXKP), lastN = min(st->lastN, TRK_MAXKP);
+  const int i = blockIdx.x * 4 + wv;
+  if (blockIdx.x * 4 >= nkp) return;
+  {
+    const uint4* d4 = reinterpret_cast<const uint4*>(st->last_desc);
+    uint4 v[TRK_MAXKP * 2 / 256];
+#pragma unroll
+    for (int k = 0; k < TRK_MAXKP * 2 / 256; ++k) v[k] = d4[min(tid + 256 * k, max(2 * lastN - 1, 0))];
+#pragma unroll
+    for (int k = 0; k < TRK_MAXKP * 2 / 256; ++k) {
+      const int q = tid + 256 * k;
+      if (q < 2 * lastN) {
+        const int j = q >> 1, w = 4 * (q & 1);
+        td[(w + 0) * TRK_MAXKP + j] = v[k].x; td[(w + 1) * TRK_MAXKP + j] = v[k].y;
+        td[(w + 2) * TRK_MAXKP + j] = v[k].z; td[(w + 3) * TRK_MAXKP + j] = v[k].w;
+      }
+    }
+  }
+  __syncthreads();
+  if (i >= nkp) return;
+  uint32_t qd[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) qd[k] = desc[8 * i + k];
+  uint32_t key = 0xffffffffu;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int j = lane + 64 * t;
+    if (j < lastN) {
+      uint32_t d = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d += __popc(qd[k] ^ td[k * TRK_MAXKP + j]);
+      key = min(key, (d << 16) | (uint32_t)j);   // ties: the lowest train index
+    }
+  }
+  key = wave_min_u32_dpp(key);
+  if (lane == 0) {
+    st->bf_idx[i] = key == 0xffffffffu ? -1 : (int)(key & 0xffffu);
+    st->bf_dist[i] = key == 0xffffffffu ? -1 : (int)(key >> 16);
+  }
+}
+
+// pnpmatch::poseEstimation2D_2D (src/pnpmatch.cc:302-337) on one wave: keep the matches with distance <= max(2 min, 30)
+// (:281-299), drop those whose CURRENT point lies in a box padded by 10 px (:318-328), 8-point F from the rest (:336).
+__global__ __launch_bounds__(64) void k_tg_fmat(TrackState* st, const svo_kp* kp, const int32_t* nkp_p, int kstride,
+                                                const int32_t* boxes, const int32_t* nboxes, int bstride) {
+  __shared__ EpnpWaveLds S;
+  st += blockIdx.y; kp += (size_t)blockIdx.y * kstride; nkp_p += blockIdx.y;
+  const int lane = threadIdx.x;
+  const int n_boxes = min(max(nboxes[blockIdx.y], 0), SVO_MAX_BOXES);
+  boxes += (size_t)blockIdx.y * bstride * 4;
+  double F[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (n_boxes > 0 && st->frame_num > 0) {
+    const int nkp = min(*nkp_p, TRK_MAXKP);
+    int idx[8], dist[8];
+    uint32_t gmin = 0x7fffffffu;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int i = lane + 64 * t;
+      idx[t] = i < nkp ? st->bf_idx[i] : -1;
+      dist[t] = i < nkp ? st->bf_dist[i] : -1;
+      if (idx[t] >= 0) gmin = min(gmin, (uint32_t)dist[t]);
+    }
+    gmin = wave_min_u32_dpp(gmin);
+    const double md = (double)min(gmin, 10000u);
+    const double thr = 2 * md > 30.0 ? 2 * md : 30.0;
+    uint32_t keep = 0;
+    double x1[8], y1[8], x2[8], y2[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int i = lane + 64 * t;
+      x1[t] = y1[t] = x2[t] = y2[t] = 0.0;
+      if (idx[t] >= 0 && (double)dist[t] <= thr) {
+        const svo_kp k = kp[i];
+        if (!svo_in_boxes(k.x, k.y, boxes, n_boxes, 10)) {
+          keep |= 1u << t;
+          x1[t] = (double)k.x; y1[t] = (double)k.y;
+          x2[t] = (double)st->last_xy[2 * idx[t]]; y2[t] = (double)st->last_xy[2 * idx[t] + 1];
+        }
+      }
+    }
+    fmat8_wave(S, keep, x1, y1, x2, y2, F);
+  }
+  if (lane < 9) {
+    double v = F[0];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) v = lane == k ? F[k] : v;
+    st->F[lane] = v;
+  }
+}
+
+// ================================================================================================
 // Pose chain: one launch per frame and sequence
 // ================================================================================================
 // k_tp_hyp: RANSAC samples of cv::solvePnPRansac (src/pnpmatch.cc:227), 4 waves per workgroup, one EPnP and one consensus
@@ -834,7 +948,7 @@ struct TpLds {
   double upd_ld[PNP_HYP];
 };
 
-__global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, const TrackWork* work, const svo_kp* kp,
+__global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, TrackWork* work, const svo_kp* kp,
                                                   const float* depth, svo_track_result* res_out, int kstride,
                                                   int use_mfma) {
   TpLds& S = *reinterpret_cast<TpLds*>(tk_smem);
@@ -886,10 +1000,13 @@ __global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, const TrackWor
       v = r == 3 ? (c == 3 ? 1.0 : 0.0) : (c == 3 ? h.t[r] : h.R[3 * r + c]);
     }
     st->T[tid] = v;
+    work->T_pnp[tid] = v;
   }
   if (tid == 0) {
     st->pnp.n_points = n_edges; st->pnp.n_inliers = S.best >= 0 ? S.good : 0; st->pnp.best_hypothesis = S.best;
     st->pnp.ok = S.best >= 0 ? 1 : 0; st->pnp.iterations = S.iters;
+    work->pnp_best = S.best; work->pnp_iterations = S.iters; work->pnp_inliers = S.best >= 0 ? S.good : 0;
+    work->pnp_ok = S.best >= 0 ? 1 : 0;
   }
   __syncthreads();
   const long long tf1 = clock64();
@@ -931,7 +1048,7 @@ __global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, const TrackWor
     r.reserved[1] = work->diag[1];
     *res_out = r;
     st->pose_ts[8] = tf0; st->pose_ts[9] = tf1; st->pose_ts[10] = tf2; st->pose_ts[11] = clock64();
-    const_cast<TrackWork*>(work)->rt[3] = wall_clock64();
+    work->rt[3] = wall_clock64();
   }
 }
 
@@ -1000,8 +1117,11 @@ static int track_resources(svo_ctx* ctx, int frames, int nseq) {
 // The index chain is enqueued on ctx->stream_idx and runs ahead; the pose chain follows on ctx->stream.
 // `fe_events` (may be null): fe_events[f] != nullptr is an event the index chain must wait for before frame f (its front-end
 // results are produced on another stream, in sub-batches).
+// `bx` (may be null): detection boxes in HBM - frame f's (nseq == 1) or sequence q's (nseq > 1) at bx->boxes + 4 * bx->stride * f.
 static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, const int32_t* nkp, const float* depth,
-                        int kstride, int frames, int nseq, svo_track_result* d_res, const hipEvent_t* fe_events = nullptr) {
+                        int kstride, int frames, int nseq, svo_track_result* d_res, const svo_boxes_dev* bx,
+                        const hipEvent_t* fe_events = nullptr, const int* row_of_frame = nullptr) {
+  if (bx && (!bx->boxes || !bx->n || bx->stride < 1)) bx = nullptr;
   int rc = track_resources(ctx, frames, nseq);
   if (rc) return rc;
   TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
@@ -1014,25 +1134,43 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
   // per-kernel HIP-event timing (svo_profile_enable) costs ~2.5 us per event pair on the host - more than a tail kernel's
   // launch; the tail is therefore SAMPLED: every 32nd frame of a call is timed (an event pair around a kernel also holds the chain up by ~5 us), the others run untimed
   const bool prof = ctx->profiling;
+  // frame f's front-end results sit in row f of the arrays unless the caller says otherwise (svo_track_sharded_dev)
+  auto row = [&](int f) { return (size_t)(row_of_frame ? row_of_frame[f] : f); };
   auto enqueue_index = [&](int f) {
-    const svo_kp* kpf = kp + (size_t)f * kstride;
-    const uint32_t* descf = desc + (size_t)f * kstride * 8;
-    const float* depf = depth + (size_t)f * kstride;
+    const svo_kp* kpf = kp + row(f) * kstride;
+    const uint32_t* descf = desc + row(f) * kstride * 8;
+    const float* depf = depth + row(f) * kstride;
+    const int32_t* nkpf = nkp + row(f);
     ctx->profiling = prof && (f % 32 == 0 || frames < 32);
     if (fe_events && fe_events[f]) hipStreamWaitEvent(s1, fe_events[f], 0);
+    // frame f's boxes (one sequence) / the sequences' boxes of this step (many): the kernels add blockIdx.y themselves
+    const int32_t* bxf = bx ? bx->boxes + (nseq == 1 ? (size_t)f * bx->stride * 4 : 0) : nullptr;
+    const int32_t* nbf = bx ? bx->n + (nseq == 1 ? f : 0) : nullptr;
+    const int bstride = bx ? bx->stride : 0;
+    if (bx) {   // F for the epipolar veto (src/pnpmatch.cc:302-337): brute-force matches cur -> last, then the 8-point solve
+      {
+        SvoTimer t(ctx, "k_tg_bf", s1);
+        hipLaunchKernelGGL(k_tg_bf, dim3(TRK_MAXKP / 4, ny), dim3(256), 0, s1, st, descf, nkpf, kstride, nbf);
+      }
+      {
+        SvoTimer t(ctx, "k_tg_fmat", s1);
+        hipLaunchKernelGGL(k_tg_fmat, dim3(1, ny), dim3(64), 0, s1, st, kpf, nkpf, kstride, bxf, nbf, bstride);
+      }
+    }
     {
       SvoTimer t(ctx, "k_ti_lists", s1);
-      if (ny >= 8) hipLaunchKernelGGL(k_ti_lists<16>, dim3(TRK_ROWS_MAX / 16, ny), dim3(256), 0, s1, st, descf, nkp + f, kstride, ctx->opt_track_lcap, ctx->opt_track_nblk);
-      else hipLaunchKernelGGL(k_ti_lists<4>, dim3(TRK_ROWS_MAX / 4, ny), dim3(256), 0, s1, st, descf, nkp + f, kstride, ctx->opt_track_lcap, ctx->opt_track_nblk);
+      if (ny >= 8) hipLaunchKernelGGL(k_ti_lists<16>, dim3(TRK_ROWS_MAX / 16, ny), dim3(256), 0, s1, st, descf, nkpf, kstride, ctx->opt_track_lcap, ctx->opt_track_nblk);
+      else hipLaunchKernelGGL(k_ti_lists<4>, dim3(TRK_ROWS_MAX / 4, ny), dim3(256), 0, s1, st, descf, nkpf, kstride, ctx->opt_track_lcap, ctx->opt_track_nblk);
     }
     {
       SvoTimer t(ctx, "k_ti_resolve", s1);
-      hipLaunchKernelGGL(k_ti_resolve, dim3(1, ny), dim3(1024), sizeof(TiLds), s1, st, work + f, kpf, descf, nkp + f, depf, kstride);
+      hipLaunchKernelGGL(k_ti_resolve, dim3(1, ny), dim3(1024), sizeof(TiLds), s1, st, work + f, kpf, descf, nkpf, depf, kstride,
+                         bxf, nbf, bstride);
     }
   };
   auto enqueue_pose = [&](int f) {
-    const svo_kp* kpf = kp + (size_t)f * kstride;
-    const float* depf = depth + (size_t)f * kstride;
+    const svo_kp* kpf = kp + row(f) * kstride;
+    const float* depf = depth + row(f) * kstride;
     ctx->profiling = prof && (f % 32 == 0 || frames < 32);
     {
       SvoTimer t(ctx, "k_tp_hyp");
@@ -1119,41 +1257,6 @@ extern "C" int svo_track_multi_reset(svo_ctx* ctx, int n_seq, const svo_camera* 
   return track_reset_n(ctx, cam, n_seq);
 }
 
-extern "C" int svo_fundamental_8point(const double* pts1, const double* pts2, int n, double F[9]);
-
-// pnpmatch::poseEstimation2D_2D (src/pnpmatch.cc:302-337) for the frame in slot 0: brute-force
-// matches cur -> last on the device, then the (tiny) 8-point solve on the host.
-static int estimate_F(svo_ctx* ctx, const int32_t* boxes, int n_boxes) {
-  TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
-  const int K = ctx->max_kp;
-  int rc = svo_launch_bf_match_dev(ctx, ctx->d_desc, ctx->d_nkp, reinterpret_cast<const uint8_t*>(st->last_desc),
-                                   &st->lastN, K, st->bf_idx, st->bf_dist, st->bf_keep, &st->bf_min);
-  if (rc) return rc;
-  std::vector<int32_t> idx(K);
-  std::vector<uint8_t> keep(K);
-  std::vector<svo_kp> kp(K);
-  std::vector<float> lxy(2 * (size_t)TRK_MAXKP);
-  int32_t nkp = 0;
-  SVO_HIP(ctx, hipMemcpyAsync(idx.data(), st->bf_idx, 4 * (size_t)K, hipMemcpyDeviceToHost, ctx->stream));
-  SVO_HIP(ctx, hipMemcpyAsync(keep.data(), st->bf_keep, (size_t)K, hipMemcpyDeviceToHost, ctx->stream));
-  SVO_HIP(ctx, hipMemcpyAsync(kp.data(), ctx->d_kp, sizeof(svo_kp) * (size_t)K, hipMemcpyDeviceToHost, ctx->stream));
-  SVO_HIP(ctx, hipMemcpyAsync(lxy.data(), st->last_xy, sizeof(float) * lxy.size(), hipMemcpyDeviceToHost, ctx->stream));
-  SVO_HIP(ctx, hipMemcpyAsync(&nkp, ctx->d_nkp, 4, hipMemcpyDeviceToHost, ctx->stream));
-  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  std::vector<double> p1, p2;
-  for (int i = 0; i < nkp && i < K; ++i) {
-    if (!keep[i] || idx[i] < 0) continue;
-    if (svo_in_boxes(kp[i].x, kp[i].y, boxes, n_boxes, 10)) continue;   // :318-328
-    p1.push_back(kp[i].x); p1.push_back(kp[i].y);
-    p2.push_back(lxy[2 * idx[i]]); p2.push_back(lxy[2 * idx[i] + 1]);
-  }
-  double F[9];
-  svo_fundamental_8point(p1.data(), p2.data(), (int)p1.size() / 2, F);
-  SVO_HIP(ctx, hipMemcpyAsync(st->F, F, sizeof F, hipMemcpyHostToDevice, ctx->stream));
-  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));   // F lives on this stack frame
-  return SVO_OK;
-}
-
 // Depth source 1 (svo_set_option "depth_source"): the reference's live data flow - a dense disparity map
 // (src/Tracking.cc:226 `MB`, here the ELAS map D1) -> frame::disp2Depth (src/frame.cc:140-164: depth =
 // bf / disp wherever disp != 0, else -1) -> `depthimg.at<float>(y, x)` at the truncated keypoint position;
@@ -1204,10 +1307,15 @@ extern "C" int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL,
   int rc = svo_upload_image(ctx, grayL, strideL, 0);
   if (rc) return rc;
   if ((rc = svo_upload_image(ctx, grayR, strideR, 1))) return rc;
-  const int32_t nb = n_boxes;
-  SVO_HIP(ctx, hipMemcpyAsync(&st->n_boxes, &nb, 4, hipMemcpyHostToDevice, ctx->stream));
+  // the frame's boxes go to HBM with the images (pinned staging: the copies are asynchronous, the caller's array may be
+  // pageable); from there on a gated frame is device work only
+  int32_t* h_box = reinterpret_cast<int32_t*>(ctx->h_pinned + ctx->pinned_bytes - 4096);   // the buffer's last page: nothing else uses it
+  h_box[0] = n_boxes;
+  if (n_boxes > 0) memcpy(h_box + 4, boxes, 16 * (size_t)n_boxes);
+  SVO_HIP(ctx, hipMemcpyAsync(&st->n_boxes, h_box, 4, hipMemcpyHostToDevice, ctx->stream));
   if (n_boxes > 0)
-    SVO_HIP(ctx, hipMemcpyAsync(st->boxes, boxes, 16 * (size_t)n_boxes, hipMemcpyHostToDevice, ctx->stream));
+    SVO_HIP(ctx, hipMemcpyAsync(st->boxes, h_box + 4, 16 * (size_t)n_boxes, hipMemcpyHostToDevice, ctx->stream));
+  const svo_boxes_dev bx{st->boxes, &st->n_boxes, SVO_MAX_BOXES};
   if (ctx->opt_depth_source == 1) {
     if ((rc = svo_launch_orb(ctx, dL, dR, ctx->stage_pitch, 1, 1))) return rc;   // left image only
     svo_elas_params ep;
@@ -1232,12 +1340,8 @@ extern "C" int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL,
     if ((rc = svo_launch_orb(ctx, dL, dR, ctx->stage_pitch, 1, 2))) return rc;
     if ((rc = svo_launch_stereo(ctx, dL, dR, ctx->stage_pitch, 1, &ctx->cam))) return rc;
   }
-  if (n_boxes > 0 && ctx->track_frame > 0) {
-    rc = estimate_F(ctx, boxes, n_boxes);
-    if (rc) return rc;
-  }
   svo_track_result* d_res = reinterpret_cast<svo_track_result*>(ctx->d_scratch);
-  rc = tail_enqueue(ctx, ctx->d_kp, ctx->d_desc, ctx->d_nkp, ctx->d_depth, ctx->max_kp, 1, 1, d_res);
+  rc = tail_enqueue(ctx, ctx->d_kp, ctx->d_desc, ctx->d_nkp, ctx->d_depth, ctx->max_kp, 1, 1, d_res, n_boxes > 0 ? &bx : nullptr);
   if (rc) return rc;
   SVO_HIP(ctx, hipMemcpyAsync(res, d_res, sizeof *res, hipMemcpyDeviceToHost, ctx->stream));
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1247,7 +1351,7 @@ extern "C" int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL,
 
 // One time step of n_seq independent sequences: pair q is the next frame of sequence q.
 extern "C" int svo_track_multi_step_dev(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR,
-                                        int stride, int n_seq, svo_track_result* d_results) {
+                                        int stride, int n_seq, const svo_boxes_dev* boxes, svo_track_result* d_results) {
   if (!ctx || !d_grayL || !d_grayR || !d_results || stride < ctx->g.W) return SVO_E_INVALID;
   if (!ctx->d_track || n_seq != ctx->n_seq) return SVO_E_INVALID;   // svo_track_multi_reset(n_seq) first
   if (ctx->opt_depth_source != 0) {   // the many-sequence mode has the sparse matcher only
@@ -1269,10 +1373,22 @@ extern "C" int svo_track_multi_step_dev(svo_ctx* ctx, const uint8_t* d_grayL, co
         if (ctx->ms_desc[p]) hipFree(ctx->ms_desc[p]);
         if (ctx->ms_nkp[p]) hipFree(ctx->ms_nkp[p]);
         if (ctx->ms_depth[p]) hipFree(ctx->ms_depth[p]);
-        SVO_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->ms_kp[p]), sizeof(svo_kp) * I * K));
-        SVO_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->ms_desc[p]), 32 * I * K));
-        SVO_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->ms_nkp[p]), sizeof(int32_t) * I));
-        SVO_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->ms_depth[p]), sizeof(float) * (size_t)n_seq * K));
+        ctx->ms_kp[p] = nullptr; ctx->ms_desc[p] = nullptr; ctx->ms_nkp[p] = nullptr; ctx->ms_depth[p] = nullptr;
+        ctx->ms_cap = 0;   // a failed allocation below leaves null pointers and no capacity behind, never freed memory
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->ms_kp[p]), sizeof(svo_kp) * I * K) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&ctx->ms_desc[p]), 32 * I * K) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&ctx->ms_nkp[p]), sizeof(int32_t) * I) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&ctx->ms_depth[p]), sizeof(float) * (size_t)n_seq * K) != hipSuccess) {
+          (void)hipGetLastError();
+          for (int q = 0; q < 2; ++q) {
+            if (ctx->ms_kp[q]) hipFree(ctx->ms_kp[q]);
+            if (ctx->ms_desc[q]) hipFree(ctx->ms_desc[q]);
+            if (ctx->ms_nkp[q]) hipFree(ctx->ms_nkp[q]);
+            if (ctx->ms_depth[q]) hipFree(ctx->ms_depth[q]);
+            ctx->ms_kp[q] = nullptr; ctx->ms_desc[q] = nullptr; ctx->ms_nkp[q] = nullptr; ctx->ms_depth[q] = nullptr;
+          }
+          return SVO_E_NOMEM;
+        }
         if (!ctx->ms_fe_done[p]) SVO_HIP(ctx, hipEventCreateWithFlags(&ctx->ms_fe_done[p], hipEventDisableTiming));
         if (!ctx->ms_tail_done[p]) SVO_HIP(ctx, hipEventCreateWithFlags(&ctx->ms_tail_done[p], hipEventDisableTiming));
         ctx->ms_tail_recorded[p] = false;
@@ -1299,7 +1415,7 @@ extern "C" int svo_track_multi_step_dev(svo_ctx* ctx, const uint8_t* d_grayL, co
     if (rc) return rc;
     SVO_HIP(ctx, hipEventRecord(ctx->ms_fe_done[p], ctx->stream_fe));
     SVO_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ms_fe_done[p], 0));
-    if ((rc = tail_enqueue(ctx, ctx->ms_kp[p], ctx->ms_desc[p], ctx->ms_nkp[p], ctx->ms_depth[p], ctx->max_kp, 1, n_seq, d_results))) return rc;
+    if ((rc = tail_enqueue(ctx, ctx->ms_kp[p], ctx->ms_desc[p], ctx->ms_nkp[p], ctx->ms_depth[p], ctx->max_kp, 1, n_seq, d_results, boxes))) return rc;
     SVO_HIP(ctx, hipEventRecord(ctx->ms_tail_done[p], ctx->stream));
     ctx->ms_tail_recorded[p] = true;
     ctx->ms_parity ^= 1;
@@ -1309,19 +1425,17 @@ extern "C" int svo_track_multi_step_dev(svo_ctx* ctx, const uint8_t* d_grayL, co
   rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, n_seq, 2 * n_seq);
   if (rc) return rc;
   if ((rc = svo_launch_stereo(ctx, d_grayL, d_grayR, stride, n_seq, &ctx->cam))) return rc;
-  if ((rc = tail_enqueue(ctx, ctx->d_kp, ctx->d_desc, ctx->d_nkp, ctx->d_depth, ctx->max_kp, 1, n_seq, d_results))) return rc;
+  if ((rc = tail_enqueue(ctx, ctx->d_kp, ctx->d_desc, ctx->d_nkp, ctx->d_depth, ctx->max_kp, 1, n_seq, d_results, boxes))) return rc;
   ctx->track_frame++;
   return SVO_OK;
 }
 
 extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR,
-                                   int stride, int B, svo_track_result* d_results) {
+                                   int stride, int B, const svo_boxes_dev* boxes, svo_track_result* d_results) {
   if (!ctx || !d_grayL || !d_grayR || !d_results || B < 1 || stride < ctx->g.W) return SVO_E_INVALID;
   if (B > ctx->max_batch) return SVO_E_CAPACITY;
   if (!ctx->d_track || ctx->n_seq != 1) return SVO_E_INVALID;
   hipSetDevice(ctx->device);
-  // the batched mode carries no detection boxes (the offline box files are a per-frame host input)
-  SVO_HIP(ctx, hipMemsetAsync(&reinterpret_cast<TrackState*>(ctx->d_track)->n_boxes, 0, 4, ctx->stream));
   int rc;
   if (ctx->opt_depth_source == 1) {
     // dense ELAS maps for the B frames (svo_elas_batch_dev), then the reference's per-keypoint lookups
@@ -1384,11 +1498,11 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
     ctx->stream = s_main;
     ctx->d_kp = kp0; ctx->d_desc = desc0; ctx->d_nkp = nkp0; ctx->d_uR = uR0; ctx->d_depth = depth0; ctx->d_sad = sad0;
     if (rc) return rc;
-    if ((rc = tail_enqueue(ctx, ctx->d_kp, ctx->d_desc, ctx->d_nkp, ctx->d_depth, ctx->max_kp, B, 1, d_results, wait.data()))) return rc;
+    if ((rc = tail_enqueue(ctx, ctx->d_kp, ctx->d_desc, ctx->d_nkp, ctx->d_depth, ctx->max_kp, B, 1, d_results, boxes, wait.data()))) return rc;
     ctx->track_frame += B;
     return SVO_OK;
   }
-  if ((rc = tail_enqueue(ctx, ctx->d_kp, ctx->d_desc, ctx->d_nkp, ctx->d_depth, ctx->max_kp, B, 1, d_results))) return rc;
+  if ((rc = tail_enqueue(ctx, ctx->d_kp, ctx->d_desc, ctx->d_nkp, ctx->d_depth, ctx->max_kp, B, 1, d_results, boxes))) return rc;
   ctx->track_frame += B;
   return SVO_OK;
 }
@@ -1396,12 +1510,12 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
 // The ordered tail alone, for front-end results produced elsewhere (another context, another GPU): frame f's keypoints
 // at d_kp + f * kp_stride, descriptors at d_desc + f * kp_stride * 32, count d_n[f], depths d_depth + f * kp_stride.
 extern "C" int svo_track_tail_dev(svo_ctx* ctx, const svo_kp* d_kp, const uint8_t* d_desc, const int32_t* d_n,
-                                  const float* d_depth, int kp_stride, int B, svo_track_result* d_results) {
+                                  const float* d_depth, int kp_stride, int B, const svo_boxes_dev* boxes,
+                                  svo_track_result* d_results) {
   if (!ctx || !d_kp || !d_desc || !d_n || !d_depth || !d_results || B < 1 || kp_stride < 1) return SVO_E_INVALID;
   if (!ctx->d_track || ctx->n_seq != 1) return SVO_E_INVALID;   // svo_track_reset first
   hipSetDevice(ctx->device);
-  SVO_HIP(ctx, hipMemsetAsync(&reinterpret_cast<TrackState*>(ctx->d_track)->n_boxes, 0, 4, ctx->stream));
-  int rc = tail_enqueue(ctx, d_kp, d_desc, d_n, d_depth, kp_stride, B, 1, d_results);
+  int rc = tail_enqueue(ctx, d_kp, d_desc, d_n, d_depth, kp_stride, B, 1, d_results, boxes);
   if (rc) return rc;
   ctx->track_frame += B;
   return SVO_OK;
@@ -1441,6 +1555,28 @@ extern "C" int svo_debug_track_gate(svo_ctx* ctx, double F[9], int32_t* n_vetoed
   return SVO_OK;
 }
 
+// Parity probe: map-point identities, RANSAC outcome and PnP pose of n frames of the last batched call (work slots first ..).
+extern "C" int svo_debug_track_frames(svo_ctx* ctx, int first, int n, svo_track_debug* out) {
+  if (!ctx || !out || !ctx->d_work || first < 0 || n < 1 || first + n > ctx->work_cap) return SVO_E_INVALID;
+  hipSetDevice(ctx->device);
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<TrackWork> w((size_t)n);
+  SVO_HIP(ctx, hipMemcpy(w.data(), reinterpret_cast<TrackWork*>(ctx->d_work) + first, sizeof(TrackWork) * (size_t)n, hipMemcpyDeviceToHost));
+  for (int f = 0; f < n; ++f) {
+    const TrackWork& q = w[f];
+    svo_track_debug& o = out[f];
+    for (int j = 0; j < TRK_MAXKP; ++j) { o.match_gid[j] = -1; o.new_gid[j] = q.new_gid[j]; }
+    for (int e = 0; e < q.n_edges && e < TRK_MAXKP; ++e) o.match_gid[q.edge_kp[e]] = q.edge_gid[e];
+    o.frame_id = q.frame_id;
+    o.pnp_best = q.pnp_best; o.pnp_iterations = q.pnp_iterations; o.pnp_inliers = q.pnp_inliers; o.pnp_ok = q.pnp_ok;
+    o.active_rows[0] = q.diag[0] & 0xffff; o.active_rows[1] = q.diag[1] & 0xffff;
+    o.rounds[0] = q.diag[0] >> 16; o.rounds[1] = q.diag[1] >> 16;
+    o.resolve_us = (int32_t)((q.rt[1] - q.rt[0]) / 100);   // s_memrealtime: 100 MHz
+    memcpy(o.T_pnp, q.T_pnp, sizeof o.T_pnp);
+  }
+  return SVO_OK;
+}
+
 // Diagnostics: s_memtime stamps (shader clock) of k_ti_resolve's phases for work slot `slot` of the last call:
 // begin, pass 1, pass 2, frame end, done.
 extern "C" int svo_debug_track_stamps(svo_ctx* ctx, int slot, int64_t ts[8]) {
@@ -1470,9 +1606,14 @@ extern "C" int svo_debug_track_realtime(svo_ctx* ctx, int slot, int64_t rt[4]) {
 // order of increasing k (local index k / G).  B frames per call, records into d_results (on context 0's device).
 // Records are identical to svo_track_batch_dev on one context.  Does not synchronise.
 struct ShardGather {
+  // staging on the tail context's device: region g (frames g, g + G, ... of a call, `per` rows) holds what context g produced
   svo_kp* kp = nullptr; uint8_t* desc = nullptr; int32_t* n = nullptr; float* depth = nullptr;
-  int cap = 0;
-  std::vector<hipEvent_t> ev;
+  int per = 0, G = 0;
+  std::vector<hipEvent_t> ev;         // front end (and staging copies) of context g finished
+  hipEvent_t ev_prev = nullptr;       // what the tail context's stream held when the call began
+  uint8_t* h_stage = nullptr;         // pinned bounce buffer for contexts whose device the tail's device cannot read directly
+  size_t h_bytes = 0;
+  std::vector<int> row_of_frame;
 };
 static std::vector<std::pair<svo_ctx*, ShardGather*>> g_gathers;   // per tail context, freed by svo_track_release
 static std::mutex g_gathers_mu;                                      // contexts may live on different host threads
@@ -1484,16 +1625,23 @@ static ShardGather* shard_gather(svo_ctx* ctx) {
   g_gathers.emplace_back(ctx, new ShardGather());
   return g_gathers.back().second;
 }
+static void shard_gather_buffers_free(ShardGather* g) {
+  if (g->kp) hipFree(g->kp);
+  if (g->desc) hipFree(g->desc);
+  if (g->n) hipFree(g->n);
+  if (g->depth) hipFree(g->depth);
+  g->kp = nullptr; g->desc = nullptr; g->n = nullptr; g->depth = nullptr;
+  g->per = 0; g->G = 0;
+}
 static void shard_gather_free(svo_ctx* ctx) {
   std::lock_guard<std::mutex> lock(g_gathers_mu);
   for (size_t i = 0; i < g_gathers.size(); ++i)
     if (g_gathers[i].first == ctx) {
       ShardGather* g = g_gathers[i].second;
-      if (g->kp) hipFree(g->kp);
-      if (g->desc) hipFree(g->desc);
-      if (g->n) hipFree(g->n);
-      if (g->depth) hipFree(g->depth);
+      shard_gather_buffers_free(g);
       for (hipEvent_t e : g->ev) hipEventDestroy(e);
+      if (g->ev_prev) hipEventDestroy(g->ev_prev);
+      if (g->h_stage) hipHostFree(g->h_stage);
       delete g;
       g_gathers.erase(g_gathers.begin() + i);
       return;
@@ -1501,7 +1649,7 @@ static void shard_gather_free(svo_ctx* ctx) {
 }
 
 extern "C" int svo_track_sharded_dev(svo_ctx* const* ctxs, int G, const uint8_t* const* d_grayL, const uint8_t* const* d_grayR,
-                                     int stride, int B, svo_track_result* d_results) {
+                                     int stride, int B, const svo_boxes_dev* boxes, svo_track_result* d_results) {
   if (!ctxs || G < 1 || !d_grayL || !d_grayR || B < 1 || !d_results) return SVO_E_INVALID;
   svo_ctx* c0 = ctxs[0];
   if (!c0 || !c0->d_track || c0->n_seq != 1) return SVO_E_INVALID;   // svo_track_reset(ctxs[0]) first
@@ -1513,59 +1661,122 @@ extern "C" int svo_track_sharded_dev(svo_ctx* const* ctxs, int G, const uint8_t*
   }
   ShardGather* sg = shard_gather(c0);
   SVO_HIP(c0, hipSetDevice(c0->device));
-  if (sg->cap < B) {
+  const int per = (B + G - 1) / G;
+  const size_t wk = sizeof(svo_kp) * (size_t)K, wd = 32 * (size_t)K, wf = 4 * (size_t)K;
+  if (sg->per < per || sg->G < G) {
     SVO_HIP(c0, hipStreamSynchronize(c0->stream));
-    if (sg->kp) { hipFree(sg->kp); hipFree(sg->desc); hipFree(sg->n); hipFree(sg->depth); sg->kp = nullptr; }
-    sg->cap = 0;
-    if (hipMalloc(reinterpret_cast<void**>(&sg->kp), sizeof(svo_kp) * (size_t)K * B) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&sg->desc), 32 * (size_t)K * B) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&sg->n), 4 * (size_t)B) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&sg->depth), 4 * (size_t)K * B) != hipSuccess)
+    shard_gather_buffers_free(sg);
+    const size_t rows = (size_t)per * G;
+    if (hipMalloc(reinterpret_cast<void**>(&sg->kp), wk * rows) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&sg->desc), wd * rows) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&sg->n), 4 * rows) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&sg->depth), wf * rows) != hipSuccess) {
+      (void)hipGetLastError();
+      shard_gather_buffers_free(sg);
       return SVO_E_NOMEM;
-    sg->cap = B;
+    }
+    sg->per = per; sg->G = G;
   }
+  const int rper = sg->per;   // rows per region (may be larger than this call needs)
   while ((int)sg->ev.size() < G) {
     hipEvent_t e;
     SVO_HIP(c0, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     sg->ev.push_back(e);
-    // direct device-to-device reads from the producing GPU (xGMI) where the platform allows it; otherwise the
-    // runtime stages the copies
-    const int g = (int)sg->ev.size() - 1;
-    if (g < G && ctxs[g] && ctxs[g]->device != c0->device) { (void)hipDeviceEnablePeerAccess(ctxs[g]->device, 0); (void)hipGetLastError(); }
+  }
+  if (!sg->ev_prev) SVO_HIP(c0, hipEventCreateWithFlags(&sg->ev_prev, hipEventDisableTiming));
+  // How the tail's device reaches each producer's results: the same device, a direct peer read over xGMI (checked on every
+  // call - the contexts of a call may change), or a bounce through pinned host memory when the platform offers no peer access.
+  std::vector<int> direct(G, 1);
+  bool need_stage = false;
+  for (int g = 1; g < G; ++g) {
+    if (ctxs[g]->device == c0->device) continue;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, c0->device, ctxs[g]->device) != hipSuccess) { can = 0; (void)hipGetLastError(); }
+    if (can) {
+      const hipError_t e = hipDeviceEnablePeerAccess(ctxs[g]->device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0;
+      (void)hipGetLastError();
+    }
+    direct[g] = can;
+    need_stage = need_stage || !can;
+  }
+  if (getenv("SVO_SHARD_FORCE_STAGED")) {   // test switch: take the bounce path even where a direct read exists
+    for (int g = 1; g < G; ++g) direct[g] = 0;
+    need_stage = G > 1;
+  }
+  const size_t region_bytes = (wk + wd + wf + 4) * (size_t)rper;
+  if (need_stage && sg->h_bytes < region_bytes * G) {
+    SVO_HIP(c0, hipStreamSynchronize(c0->stream));
+    if (sg->h_stage) hipHostFree(sg->h_stage);
+    sg->h_stage = nullptr; sg->h_bytes = 0;
+    if (hipHostMalloc(reinterpret_cast<void**>(&sg->h_stage), region_bytes * G) != hipSuccess) { (void)hipGetLastError(); return SVO_E_NOMEM; }
+    sg->h_bytes = region_bytes * G;
   }
   // front ends: context g extracts and matches its pairs k = g, g + G, ... on its own device and stream.  A context's
-  // result buffers may still be read by the previous call's gather copies: its stream waits for context 0's stream first.
-  hipEvent_t ev_prev = nullptr;
-  if (G > 1) {
-    SVO_HIP(c0, hipEventCreateWithFlags(&ev_prev, hipEventDisableTiming));
-    SVO_HIP(c0, hipEventRecord(ev_prev, c0->stream));
-  }
+  // result buffers (and the bounce buffer) may still be read by the previous call's gather: its stream waits for what
+  // context 0's stream held when this call began.
+  SVO_HIP(c0, hipEventRecord(sg->ev_prev, c0->stream));
   int rc = SVO_OK;
   for (int g = 0; g < G && rc == SVO_OK; ++g) {
     const int nb = (B - g + G - 1) / G;
     if (nb <= 0) continue;
     svo_ctx* c = ctxs[g];
     hipSetDevice(c->device);
-    if (g > 0 && hipStreamWaitEvent(c->stream, ev_prev, 0) != hipSuccess) { rc = SVO_E_HIP; break; }
+    if (g > 0 && hipStreamWaitEvent(c->stream, sg->ev_prev, 0) != hipSuccess) { rc = SVO_E_HIP; break; }
     rc = svo_frontend_batch_dev(c, d_grayL[g], d_grayR[g], stride, nb, &c0->cam, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (rc == SVO_OK && !direct[g]) {
+      // bounce, first half: this context's results into its region of the pinned buffer, on its own stream
+      uint8_t* h = sg->h_stage + region_bytes * g;
+      const int ns = svo_frontend_nslices(c, nb);
+      for (int k = 0; k < ns && rc == SVO_OK; ++k) {   // slice k of the front end keeps its left images' results at slots 2 p0 ..
+        const int p0 = (int)((int64_t)k * nb / ns), p1 = (int)((int64_t)(k + 1) * nb / ns), b = p1 - p0;
+        if (hipMemcpyAsync(h + wk * p0, c->d_kp + (size_t)2 * p0 * K, wk * b, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipMemcpyAsync(h + wk * rper + wd * p0, c->d_desc + (size_t)2 * p0 * wd, wd * b, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipMemcpyAsync(h + (wk + wd) * rper + wf * p0, c->d_depth + (size_t)p0 * K, wf * b, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipMemcpyAsync(h + (wk + wd + wf) * rper + 4 * (size_t)p0, c->d_nkp + 2 * p0, 4 * (size_t)b, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+          rc = SVO_E_HIP;
+      }
+    }
     if (rc == SVO_OK && hipEventRecord(sg->ev[g], c->stream) != hipSuccess) rc = SVO_E_HIP;
   }
   hipSetDevice(c0->device);
-  if (ev_prev) hipEventDestroy(ev_prev);   // destruction is deferred until the recorded work has completed
-  if (rc) return rc;
-  // ordered gather on context 0's stream: frame k = g + G i  <-  slot i of context g (row-interleaving 2-D copies)
+  if (rc) { if (rc == SVO_E_HIP) c0->last_error = std::string("svo_track_sharded_dev: ") + hipGetErrorString(hipGetLastError()); return rc; }
+  // gather on context 0's stream: region g of the staging arrays <- context g's results (contiguous copies, slice by slice)
   for (int g = 0; g < G; ++g) {
     const int nb = (B - g + G - 1) / G;
     if (nb <= 0) continue;
     svo_ctx* c = ctxs[g];
     SVO_HIP(c0, hipStreamWaitEvent(c0->stream, sg->ev[g], 0));
-    const size_t wk = sizeof(svo_kp) * (size_t)K, wd = 32 * (size_t)K, wf = 4 * (size_t)K;
-    SVO_HIP(c0, hipMemcpy2DAsync(sg->kp + (size_t)g * K, wk * G, c->d_kp, wk, wk, nb, hipMemcpyDeviceToDevice, c0->stream));
-    SVO_HIP(c0, hipMemcpy2DAsync(sg->desc + (size_t)g * wd, wd * G, c->d_desc, wd, wd, nb, hipMemcpyDeviceToDevice, c0->stream));
-    SVO_HIP(c0, hipMemcpy2DAsync(sg->depth + (size_t)g * K, wf * G, c->d_depth, wf, wf, nb, hipMemcpyDeviceToDevice, c0->stream));
-    SVO_HIP(c0, hipMemcpy2DAsync(sg->n + g, 4 * (size_t)G, c->d_nkp, 4, 4, nb, hipMemcpyDeviceToDevice, c0->stream));
+    const size_t r0 = (size_t)g * rper;
+    if (!direct[g]) {
+      const uint8_t* h = sg->h_stage + region_bytes * g;
+      SVO_HIP(c0, hipMemcpyAsync(sg->kp + r0 * K, h, wk * nb, hipMemcpyHostToDevice, c0->stream));
+      SVO_HIP(c0, hipMemcpyAsync(sg->desc + r0 * wd, h + wk * rper, wd * nb, hipMemcpyHostToDevice, c0->stream));
+      SVO_HIP(c0, hipMemcpyAsync(sg->depth + r0 * K, h + (wk + wd) * rper, wf * nb, hipMemcpyHostToDevice, c0->stream));
+      SVO_HIP(c0, hipMemcpyAsync(sg->n + r0, h + (wk + wd + wf) * rper, 4 * (size_t)nb, hipMemcpyHostToDevice, c0->stream));
+      continue;
+    }
+    const bool same = c->device == c0->device;
+    auto pull = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+      return same ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c0->stream)
+                  : hipMemcpyPeerAsync(dst, c0->device, src, c->device, bytes, c0->stream);
+    };
+    const int ns = svo_frontend_nslices(c, nb);
+    for (int k = 0; k < ns; ++k) {
+      const int p0 = (int)((int64_t)k * nb / ns), p1 = (int)((int64_t)(k + 1) * nb / ns), b = p1 - p0;
+      SVO_HIP(c0, pull(sg->kp + (r0 + p0) * K, c->d_kp + (size_t)2 * p0 * K, wk * b));
+      SVO_HIP(c0, pull(sg->desc + (r0 + p0) * wd, c->d_desc + (size_t)2 * p0 * wd, wd * b));
+      SVO_HIP(c0, pull(sg->depth + (r0 + p0) * K, c->d_depth + (size_t)p0 * K, wf * b));
+      SVO_HIP(c0, pull(sg->n + r0 + p0, c->d_nkp + 2 * p0, 4 * (size_t)b));
+    }
   }
-  return svo_track_tail_dev(c0, sg->kp, sg->desc, sg->n, sg->depth, K, B, d_results);
+  // the ordered tail reads frame k = g + G i from row g * rper + i
+  sg->row_of_frame.resize(B);
+  for (int k = 0; k < B; ++k) sg->row_of_frame[k] = (k % G) * rper + k / G;
+  rc = tail_enqueue(c0, sg->kp, sg->desc, sg->n, sg->depth, K, B, 1, d_results, boxes, nullptr, sg->row_of_frame.data());
+  if (rc) return rc;
+  c0->track_frame += B;
+  return SVO_OK;
 }
 
 // Parity probe: cv::solvePnPRansac's outcome for the frame just tracked (winning sample, consensus, samples visited)

@@ -37,7 +37,7 @@ int pnpmatch::poseEstimation2D_2D(frame* Cur, frame& Last, double F[9]) {
     p1.push_back(cx); p1.push_back(cy);
     p2.push_back(Last.keypoints_l[matches[i]].x); p2.push_back(Last.keypoints_l[matches[i]].y);
   }
-  return svo_fundamental_8point(p1.data(), p2.data(), (int)p1.size() / 2, F);
+  return svo_fundamental_8point(Cur->ctx, p1.data(), p2.data(), (int)p1.size() / 2, F);
 }
 
 int pnpmatch::poseEstimationPnP(frame* Cur, frame& Last, std::set<mappoint*, mappoint_by_creation>& localmappoints,

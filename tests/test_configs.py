@@ -170,6 +170,26 @@ def test_config4_boxes_with_dense_elas_depth_equals_oracle(pkg, orc):
     assert gpu[-1][0]["n_stereo"] > 250
     # the gates bite: fewer map points than the same frames without boxes would create on frame 0
     assert gpu[0][0]["n_new_mappoints"] < gpu[0][0]["n_stereo"]
+    # the same configuration through the batched, device-resident entry (svo_elas_batch_dev maps + boxes as HBM arrays)
+    dev = torch.device("cuda", 0)
+    pitch = 1280
+    dL = torch.zeros((n, 376, pitch), dtype=torch.uint8, device=dev); dR = torch.zeros_like(dL)
+    dL[:, :, :1241] = torch.from_numpy(L).to(dev); dR[:, :, :1241] = torch.from_numpy(R).to(dev)
+    bb = np.zeros((n, 2, 4), np.int32)
+    for k in range(n):
+        bb[k] = _boxes(k)
+    tb = torch.from_numpy(bb).to(dev); tn = torch.full((n,), 2, dtype=torch.int32, device=dev)
+    res = torch.zeros((n, pkg.TRACK_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    b = pkg.Svo(1241, 376, max_batch=n)
+    b.set_option("depth_source", 1)
+    b.track_reset(pkg.Camera(**pkg.KITTI_00_02))
+    b.track_batch_dev(dL.data_ptr(), dR.data_ptr(), pitch, n, res.data_ptr(), boxes=pkg.boxes_dev(tb.data_ptr(), tn.data_ptr(), 2))
+    b.sync()
+    got = res.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(-1)
+    b.close()
+    for k in range(n):
+        assert got[k].tobytes() == gpu[k][0].tobytes(), k
 
 
 # ---------------------------------------------------------------- long GPU-vs-oracle runs --------------------------

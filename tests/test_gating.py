@@ -41,23 +41,40 @@ def numpy_8point(p1, p2):
 
 
 @pytest.mark.parametrize("noise", [0.0, 0.3])
-def test_oracle_and_product_8point(orc, pkg, noise):
+def test_oracle_8point(orc, noise):
     p1, p2 = two_view(3, 80, noise)
     ref = numpy_8point(p1, p2)
     Fo = orc.fundamental_8point(p1, p2)
-    Fp = pkg.Svo.fundamental_8point(p1, p2)          # host-side code of the C-ABI library: no GPU needed
     assert np.allclose(Fo, ref, rtol=1e-6, atol=1e-9)
-    assert np.allclose(Fp, ref, rtol=1e-6, atol=1e-9)
+    assert not orc.fundamental_8point(*two_view(4, 7)).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("noise,n", [(0.0, 80), (0.3, 80), (0.3, 8), (0.5, 500), (0.2, 65)])
+def test_product_8point_on_the_device(orc, pkg, noise, n):
+    """svo_fundamental_8point: one wavefront (normal matrix by wave reductions, wave-parallel Jacobi padded to 12 x 12,
+    rank-2 projection) against the oracle's cyclic Jacobi and an independent SVD-based implementation."""
+    p1, p2 = two_view(3, n, noise)
+    ref = numpy_8point(p1, p2)
+    Fo = orc.fundamental_8point(p1, p2)
+    svo = pkg.Svo(640, 240, max_batch=1)
+    Fp = svo.fundamental_8point(p1, p2)
+    # n = 8 with noise: the normal matrix has a well separated smallest eigenvalue only to ~1e-4 - compare where it is
+    tol = 1e-6 if n > 8 else 1e-3
+    assert np.allclose(Fp, Fo, rtol=tol, atol=1e-9), np.abs(Fp - Fo).max()
+    assert np.allclose(Fp, ref, rtol=tol, atol=1e-9)
     assert abs(np.linalg.det(Fp)) < 1e-12 and Fp[2, 2] == 1.0
     h1 = np.c_[p1, np.ones(len(p1))]; h2 = np.c_[p2, np.ones(len(p2))]
     resid = np.abs(np.einsum("ni,ij,nj->n", h2, Fp, h1))
-    assert resid.max() < (1e-8 if noise == 0 else 0.05)
-
-
-def test_8point_degenerate_inputs(orc, pkg):
-    p1, p2 = two_view(4, 7)
-    assert not orc.fundamental_8point(p1, p2).any() and not pkg.Svo.fundamental_8point(p1, p2).any()
-    assert not pkg.Svo.fundamental_8point(np.zeros((0, 2)), np.zeros((0, 2))).any()
+    assert resid.max() < (1e-8 if noise == 0 else 0.1)
+    # degenerate inputs: fewer than eight pairs, no pairs, identical points -> F = 0 like OpenCV's empty matrix
+    q1, q2 = two_view(4, 7)
+    assert not svo.fundamental_8point(q1, q2).any()
+    assert not svo.fundamental_8point(np.zeros((0, 2)), np.zeros((0, 2))).any()
+    assert not svo.fundamental_8point(np.ones((20, 2)), np.ones((20, 2))).any()
+    with pytest.raises(pkg.SvoError):
+        svo.fundamental_8point(np.zeros((513, 2)), np.zeros((513, 2)))
+    svo.close()
 
 
 BOX = np.array([[500, 760, 200, 330]], np.int32)      # left right top bottom (main.cpp:82-95 order)
@@ -125,3 +142,90 @@ def test_gpu_gated_tracker_matches_oracle(pkg, gated_oracle_run):
         T, Tr = res["Tcw"].reshape(4, 4), ref["Tcw"].reshape(4, 4)
         assert np.abs(T - Tr).max() < 5e-4, k
     svo.close()
+
+
+def _boxes_hbm(pkg, n_frames, dev, fn=boxes_for, stride=4):
+    """the frames' boxes as the HBM arrays svo_boxes_dev points at (n_frames x stride x 4 int32, n_frames int32)"""
+    import torch
+    b = np.zeros((n_frames, stride, 4), np.int32); n = np.zeros(n_frames, np.int32)
+    for k in range(n_frames):
+        bk = fn(k)
+        b[k, :len(bk)] = bk; n[k] = len(bk)
+    tb, tn = torch.from_numpy(b).to(dev), torch.from_numpy(n).to(dev)
+    return pkg.boxes_dev(tb.data_ptr(), tn.data_ptr(), stride), (tb, tn)
+
+
+@pytest.mark.gpu
+def test_gated_device_resident_modes_equal_frame_by_frame(pkg, gated_oracle_run):
+    """Boxes as HBM arrays through svo_track_batch_dev, svo_track_tail_dev, svo_track_sharded_dev and
+    svo_track_multi_step_dev: records byte-identical to svo_track_frame with the same boxes handed over on the host, and
+    the F matrix / veto count of the last frame too - the gates, the brute-force matches, the 8-point solve and the
+    epipolar veto all run on the device in every mode."""
+    import torch
+    L, R, out = gated_oracle_run
+    N, H, W = L.shape
+    pitch = 1280
+    dev = torch.device("cuda", 0)
+    cam = pkg.Camera(**pkg.KITTI_00_02)
+    a = pkg.Svo(W, H, max_batch=1)
+    a.track_reset(cam)
+    single = [a.track_frame(L[k], R[k], boxes=boxes_for(k)).copy() for k in range(N)]
+    F1, nv1 = a.debug_track_gate()
+    a.close()
+    assert sum(int(o[3]) for o in out) > 0 and nv1 == out[-1][3]
+    want = b"".join(r.tobytes() for r in single)
+    dL = torch.zeros((N, H, pitch), dtype=torch.uint8, device=dev); dR = torch.zeros_like(dL)
+    dL[:, :, :W] = torch.from_numpy(L).to(dev); dR[:, :, :W] = torch.from_numpy(R).to(dev)
+    rec = pkg.TRACK_DTYPE.itemsize
+    bx, keep = _boxes_hbm(pkg, N, dev)
+    torch.cuda.synchronize()
+    # ---- svo_track_batch_dev
+    b = pkg.Svo(W, H, max_batch=N)
+    b.track_reset(cam)
+    res = torch.zeros((N, rec), dtype=torch.uint8, device=dev)
+    b.track_batch_dev(dL.data_ptr(), dR.data_ptr(), pitch, N, res.data_ptr(), boxes=bx)
+    b.sync()
+    assert res.cpu().numpy().tobytes() == want
+    F2, nv2 = b.debug_track_gate()
+    assert nv2 == nv1 and np.array_equal(F1, F2)
+    # without boxes the same frames give other records (the gates bite)
+    b.track_reset(cam)
+    b.track_batch_dev(dL.data_ptr(), dR.data_ptr(), pitch, N, res.data_ptr())
+    b.sync()
+    assert res.cpu().numpy().tobytes() != want
+    # ---- svo_track_tail_dev on this context's front-end results
+    kp = torch.zeros((N, 500, pkg.KP_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    desc = torch.zeros((N, 500, 32), dtype=torch.uint8, device=dev)
+    n = torch.zeros(N, dtype=torch.int32, device=dev); depth = torch.zeros((N, 500), dtype=torch.float32, device=dev)
+    b.frontend_batch_dev(dL.data_ptr(), dR.data_ptr(), pitch, N, cam, d_kpL=kp.data_ptr(), d_descL=desc.data_ptr(),
+                         d_nL=n.data_ptr(), d_depth=depth.data_ptr())
+    b.track_reset(cam)
+    b.track_tail_dev(kp.data_ptr(), desc.data_ptr(), n.data_ptr(), depth.data_ptr(), 500, N, res.data_ptr(), boxes=bx)
+    b.sync()
+    assert res.cpu().numpy().tobytes() == want
+    b.close()
+    # ---- svo_track_sharded_dev, two contexts
+    ctxs = [pkg.Svo(W, H, max_batch=(N + 1) // 2) for _ in range(2)]
+    ctxs[0].track_reset(cam)
+    Ls = [dL[g::2].contiguous() for g in range(2)]; Rs = [dR[g::2].contiguous() for g in range(2)]
+    torch.cuda.synchronize()
+    pkg.Svo.track_sharded_dev(ctxs, [t.data_ptr() for t in Ls], [t.data_ptr() for t in Rs], pitch, N, res.data_ptr(), boxes=bx)
+    ctxs[0].sync()
+    assert res.cpu().numpy().tobytes() == want
+    for c in ctxs:
+        c.close()
+    # ---- svo_track_multi_step_dev: two sequences walking the same frames, each with its own copy of the boxes
+    S = 2
+    m = pkg.Svo(W, H, max_batch=S)
+    m.track_multi_reset(S, cam)
+    out2 = torch.zeros((N, S, rec), dtype=torch.uint8, device=dev)
+    for t in range(N):
+        pl = dL[t:t + 1].repeat(S, 1, 1).contiguous(); pr = dR[t:t + 1].repeat(S, 1, 1).contiguous()
+        bxt, keep_t = _boxes_hbm(pkg, S, dev, fn=lambda q: boxes_for(t))
+        torch.cuda.synchronize()
+        m.track_multi_step_dev(pl.data_ptr(), pr.data_ptr(), pitch, S, out2[t].data_ptr(), boxes=bxt)
+        m.sync()
+    got = out2.cpu().numpy()
+    m.close()
+    for q in range(S):
+        assert got[:, q].tobytes() == want, q

@@ -112,3 +112,44 @@ def test_bench_two_ranks_as_the_driver_launches_it():
     assert d["config"]["frames_tracked"] == 48 and d["value"] > 0
     # whole-job throughput: both ranks' frames over the slowest rank's time
     assert abs(d["value"] - 2 * d["config"]["pairs_per_step_per_gpu"] * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("staged", [False, True])
+def test_sharded_contexts_with_sliced_front_ends(pkg, staged, monkeypatch):
+    """64 frames over 2 contexts in ONE call: 32 pairs per context, which the front end cuts into two slices on two streams
+    (frontend_overlap = 2 from 16 pairs on) - the gather has to follow the slices' slot layout (round 2 read the wrong
+    slots here).  Also with three slices, and through the pinned-host bounce path that stands in when the tail's device
+    cannot read a producer's memory directly (SVO_SHARD_FORCE_STAGED)."""
+    import torch
+    if staged:
+        monkeypatch.setenv("SVO_SHARD_FORCE_STAGED", "1")
+    synth = importlib.import_module("stereo_semantic_vo_amd.synth")
+    dev = torch.device("cuda", 0)
+    M = 64
+    L, R, _ = synth.render_sequence(M, device=dev)
+    H, W = L.shape[1], L.shape[2]
+    dL = torch.zeros((M, H, PITCH), dtype=torch.uint8, device=dev); dR = torch.zeros_like(dL)
+    dL[:, :, :W] = L; dR[:, :, :W] = R
+    cam = pkg.Camera(**pkg.KITTI_00_02)
+    rec = pkg.TRACK_DTYPE.itemsize
+    s = pkg.Svo(W, H, max_batch=M)
+    s.track_reset(cam)
+    res = torch.zeros((M, rec), dtype=torch.uint8, device=dev)
+    s.track_batch_dev(dL.data_ptr(), dR.data_ptr(), PITCH, M, res.data_ptr())
+    s.sync(); s.close()
+    want = res.cpu().numpy().tobytes()
+    for G, overlap in ((2, 2), (2, 3), (3, 2)):
+        ctxs = [pkg.Svo(W, H, max_batch=(M + G - 1) // G) for _ in range(G)]
+        for c in ctxs:
+            c.set_option("frontend_overlap", overlap)
+        ctxs[0].track_reset(cam)
+        Ls = [dL[g::G].contiguous() for g in range(G)]; Rs = [dR[g::G].contiguous() for g in range(G)]
+        out = torch.zeros((M, rec), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        pkg.Svo.track_sharded_dev(ctxs, [t.data_ptr() for t in Ls], [t.data_ptr() for t in Rs], PITCH, M, out.data_ptr())
+        ctxs[0].sync()
+        got = out.cpu().numpy().tobytes()
+        for c in ctxs:
+            c.close()
+        assert got == want, (G, overlap, staged)

@@ -60,6 +60,49 @@ def test_local_map_window(oracle_run):
     assert sizes[3] > sizes[0] and sizes[5] <= sizes[3] + 60
 
 
+def test_oracle_tail_entry_equals_full_frame_entry(orc, pkg, sequence, oracle_run):
+    """orc_track_tail fed with the oracle's own front-end results == orc_track_frame on the images, record for record:
+    the split the full-length GPU parity test relies on (it feeds the tail with the device front end's outputs)."""
+    L, R, _ = sequence
+    cam = pkg.KITTI_00_02
+    trk = orc.Tracker(L.shape[2], L.shape[1], cam)
+    for k in range(N_FRAMES):
+        fe = orc.stereo_frame(L[k], R[k], cam["bf"], cam["fx"])
+        res, cur, pnp, Tp = trk.track_tail(fe["kpL"], fe["dL"], fe["depth"])
+        ref, ref_cur = oracle_run[k]
+        assert res.tobytes() == ref.tobytes(), k
+        assert np.array_equal(cur, ref_cur), k
+        if k > 0:
+            assert pnp["ok"] == 1 and pnp["n_inliers"] == ref["n_pnp_inliers"] and 0 <= pnp["best_hypothesis"] < pnp["iterations"] <= 100
+            assert np.abs(Tp[:3, 3] - ref["Tcw"].reshape(4, 4)[:3, 3]).max() < 0.5       # a five-point minimal solution: the LM moves it by centimetres
+    trk.close()
+
+
+def test_oracle_tail_teacher_forcing(orc, pkg, sequence, oracle_run):
+    """Tcw_force: the frame's own pose is still reported, but the chain continues from the forced pose - forcing the
+    oracle's own poses changes nothing; forcing a shifted pose moves the NEXT frame's result, not this one's."""
+    L, R, _ = sequence
+    cam = pkg.KITTI_00_02
+    fes = [orc.stereo_frame(L[k], R[k], cam["bf"], cam["fx"]) for k in range(4)]
+    a = orc.Tracker(L.shape[2], L.shape[1], cam)
+    b = orc.Tracker(L.shape[2], L.shape[1], cam)
+    for k in range(4):
+        ref = oracle_run[k][0]
+        ra = a.track_tail(fes[k]["kpL"], fes[k]["dL"], fes[k]["depth"], Tcw_force=ref["Tcw"])[0]
+        assert ra.tobytes() == ref.tobytes(), k
+        shifted = ref["Tcw"].copy()
+        shifted[3] += 0.5 if k == 1 else 0.0                     # tx of frame 1 moved by half a metre
+        rb = b.track_tail(fes[k]["kpL"], fes[k]["dL"], fes[k]["depth"], Tcw_force=shifted)[0]
+        if k <= 1:
+            assert rb.tobytes() == ref.tobytes(), k
+        else:
+            # points created at the end of frame 1 sit 0.5 m off: the counters (pose-free) stay, the pose moves
+            for f in ("n_kp", "n_stereo", "n_match_pass1", "n_match_pass2", "n_lm_edges", "n_new_mappoints", "n_local_map"):
+                assert rb[f] == ref[f], (k, f)
+    assert np.abs(rb["Tcw"] - ref["Tcw"]).max() > 1e-3
+    a.close(); b.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("lcap,nblk", [(8, 3), (1, 3), (8, 0), (2, 1)])
 def test_gpu_tracker_matches_oracle(pkg, sequence, oracle_run, lcap, nblk):

@@ -562,6 +562,7 @@ __device__ __forceinline__ void pose_opt_block(PoseLds& L, const double* __restr
 // ---- cv::solvePnPRansac: hypotheses + the sequential acceptance rule ---------------------------------------------
 // (OpenCV 3.2 modules/calib3d/src/solvepnp.cpp + ptsetreg.cpp)
 #include "svo_epnp_dev.h"
+#include "svo_epnp_exact_dev.h"
 
 struct PnpHyp {          // one RANSAC sample: EPnP pose of its five points and its consensus
   double R[9], t[3];
@@ -608,6 +609,26 @@ __device__ __forceinline__ void pnp_hyp_block(EpnpWaveLds* ws, const double* Xw,
     h.cnt = cnt; h.ok = ok ? 1 : 0;
     out[k] = h;
   }
+}
+
+// The same samples in the parity mode (svo_set_option "epnp_exact"): thread k solves sample k on its own with the
+// sequential restatement of OpenCV's loops (svo_epnp_exact_dev.h) and counts its consensus.  Called by >= PNP_HYP threads.
+__device__ inline void pnp_hyp_exact(const double* Xw, const double* uv, int n, const double* K, const uint16_t* subset,
+                                     PnpHyp* out, int k) {
+  if (k >= PNP_HYP) return;
+  double x5[15], u5[10];
+  for (int i = 0; i < 5; ++i) {
+    const int e = min((int)subset[5 * k + i], n - 1);
+    x5[3 * i] = Xw[3 * e]; x5[3 * i + 1] = Xw[3 * e + 1]; x5[3 * i + 2] = Xw[3 * e + 2];
+    u5[2 * i] = uv[2 * e]; u5[2 * i + 1] = uv[2 * e + 1];
+  }
+  PnpHyp h;
+  const bool ok = epnp_exact::solve5(x5, u5, K, h.R, h.t, nullptr);
+  int cnt = 0;
+  if (ok)
+    for (int e = 0; e < n; ++e) cnt += pnp_inlier(h.R, h.t, Xw + 3 * e, uv + 2 * e, K) ? 1 : 0;
+  h.cnt = cnt; h.ok = ok ? 1 : 0;
+  out[k] = h;
 }
 
 // RANSACUpdateNumIters(p = 0.99, ep, modelPoints = 5, maxIters)

@@ -938,6 +938,28 @@ __global__ __launch_bounds__(256) void k_tp_hyp(TrackState* st, const TrackWork*
   }
 }
 
+// The RANSAC samples in the parity mode (svo_set_option "epnp_exact"): one lane per sample, OpenCV's loops in their own
+// order (svo_epnp_exact_dev.h).  One 128-thread workgroup per sequence; the correspondences are gathered into LDS first.
+struct TpHypExactLds { double Xw[TRK_MAXKP * 3], uv[TRK_MAXKP * 2]; };
+__global__ __launch_bounds__(128) void k_tp_hyp_exact(TrackState* st, TrackWork* work, const svo_kp* kp, const uint16_t* subsets,
+                                                      int kstride) {
+  TpHypExactLds& S = *reinterpret_cast<TpHypExactLds*>(tk_smem);
+  st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
+  if (threadIdx.x == 0) work->rt[2] = wall_clock64();
+  const int n = work->n_edges;
+  if (work->skip_match || n < 5) return;
+  const float* gpos = st->gpos;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    const float* gp = gpos + 3 * (size_t)(work->edge_gid[e] & (TRK_GPOS - 1));
+    const svo_kp k = kp[work->edge_kp[e]];
+    S.Xw[3 * e] = (double)gp[0]; S.Xw[3 * e + 1] = (double)gp[1]; S.Xw[3 * e + 2] = (double)gp[2];
+    S.uv[2 * e] = (double)k.x; S.uv[2 * e + 1] = (double)k.y;
+  }
+  __syncthreads();
+  const double K[4] = {(double)st->cam.fx, (double)st->cam.fy, (double)st->cam.cx, (double)st->cam.cy};
+  pnp_hyp_exact(S.Xw, S.uv, n, K, subsets + (size_t)min(n, 512) * 500, st->hyp, threadIdx.x);
+}
+
 // k_tp_frame: RANSAC's acceptance rule over the samples, Optimizer::PoseOptimization, SetPose, the positions of the
 // map points created this frame, the frame's record.
 struct TpLds {
@@ -1172,7 +1194,10 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
     const svo_kp* kpf = kp + row(f) * kstride;
     const float* depf = depth + row(f) * kstride;
     ctx->profiling = prof && (f % 32 == 0 || frames < 32);
-    {
+    if (ctx->opt_epnp_exact) {
+      SvoTimer t(ctx, "k_tp_hyp_exact");
+      hipLaunchKernelGGL(k_tp_hyp_exact, dim3(1, ny), dim3(128), sizeof(TpHypExactLds), s0, st, work + f, kpf, ctx->d_pnp_subsets, kstride);
+    } else {
       SvoTimer t(ctx, "k_tp_hyp");
       if (ny >= 8) {
         // many sequences: throughput counts - solve sixteen samples per sequence, then only those the adaptive bound can reach

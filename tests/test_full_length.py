@@ -153,6 +153,9 @@ def test_every_frame_of_the_kitti00_sized_run_against_the_oracle(pkg, orc, run, 
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
         json.dump(stats, open(os.path.join(out, "full_length_%s.json" % mode), "w"))
+        np.savez_compressed(os.path.join(out, "full_length_%s.npz" % mode), dt=dt, dr=dr, d_inl=d_inl, d_it=d_it,
+                            pnp_best=dbg["pnp_best"], pnp_iterations=dbg["pnp_iterations"], rounds=dbg["rounds"],
+                            resolve_us=dbg["resolve_us"], n_edges=gpu["n_lm_edges"], ate=d)
     if N >= 4541:
         assert stats["last_map_point_id"] > (1 << 20), "the run must take the map-point ids around the position ring"
         assert stats["frames_over_30_rounds"] >= 1, "the run must contain a slow (many-round) frame"

@@ -314,6 +314,69 @@ def test_epnp5_candidates_against_oracle(svo_small, orc):
     assert tight >= 0.6 * total, (tight, total)
 
 
+def test_epnp5_basis_independent_candidates_agree_on_every_sample(svo_small, orc):
+    """The N = 2 and N = 3 beta candidates span the null space instead of picking one of its (arbitrary) basis vectors:
+    where both sides' Gauss-Newton runs stay in the same basin their reprojection errors agree closely - checked
+    candidate by candidate on every sample, not on the minimum only."""
+    import ctypes as C
+    rep_o = (C.c_double * 3).in_dll(orc.lib(), "orc_epnp_last_rep")
+    K = np.array([718.856, 718.856, 607.1928, 185.2157])
+    rng = np.random.default_rng(3)
+    agree = {1: 0, 2: 0}
+    total = 0
+    for sigma in (0.0, 0.5, 1.5):
+        for trial in range(8):
+            Xw, obs, _, _ = util.pose_problem(trial, n=60, outlier_frac=0.0, sigma=sigma)
+            idx = rng.choice(60, 5, replace=False)
+            orc.epnp5(Xw[idx], obs[idx], K)
+            ro = np.array(list(rep_o))
+            _, _, rg = svo_small.debug_epnp5(Xw[idx], obs[idx], K)
+            total += 1
+            for c in (1, 2):
+                if abs(rg[c] - ro[c]) < 1e-6 * (1 + ro[c]):
+                    agree[c] += 1
+    print("epnp5 candidates agreeing with the oracle to 1e-6: N=2 %d, N=3 %d of %d samples" % (agree[1], agree[2], total))
+    assert agree[1] >= 0.6 * total and agree[2] >= 0.6 * total, (agree, total)
+
+
+def test_epnp5_exact_mode_equals_oracle_candidate_by_candidate(pkg, orc):
+    """svo_set_option("epnp_exact", 1): OpenCV's loops in their own order, one lane per sample - every candidate's
+    reprojection error, R and t equal the CPU restatement's to 1e-9 on every sample (what is left is libm's hypot)."""
+    import ctypes as C
+    rep_o = (C.c_double * 3).in_dll(orc.lib(), "orc_epnp_last_rep")
+    K = np.array([718.856, 718.856, 607.1928, 185.2157])
+    rng = np.random.default_rng(3)
+    svo = pkg.Svo(640, 240, max_batch=1)
+    svo.set_option("epnp_exact", 1)
+    worst = 0.0
+    for sigma in (0.0, 0.5, 1.5):
+        for trial in range(8):
+            Xw, obs, _, _ = util.pose_problem(trial, n=60, outlier_frac=0.0, sigma=sigma)
+            idx = rng.choice(60, 5, replace=False)
+            R, t = orc.epnp5(Xw[idx], obs[idx], K)
+            ro = np.array(list(rep_o))
+            Rg, tg, rg = svo.debug_epnp5(Xw[idx], obs[idx], K)
+            assert np.allclose(rg, ro, rtol=1e-9, atol=1e-9), (sigma, trial, rg, ro)
+            assert np.abs(R - Rg).max() < 1e-9 and np.abs(t - tg).max() < 1e-9 * (1 + np.abs(t).max()), (sigma, trial)
+            worst = max(worst, np.abs(R - Rg).max(), np.abs(t - tg).max())
+    svo.close()
+    print("epnp_exact worst |delta| =", worst)
+
+
+@pytest.mark.parametrize("seed,n,outliers", [(7, 500, 0.2), (12, 60, 0.2), (21, 200, 0.5), (33, 300, 0.0), (5, 9, 0.0), (13, 5, 0.0)])
+def test_pnp_ransac_exact_mode_equals_oracle(pkg, orc, seed, n, outliers):
+    """cv::solvePnPRansac in the bit-comparable mode: the discrete outcome AND the pose (to 1e-9) are the oracle's."""
+    Xw, obs, K, T_true = util.pose_problem(seed, n=n, outlier_frac=outliers)
+    svo = pkg.Svo(640, 240, max_batch=1)
+    svo.set_option("epnp_exact", 1)
+    T, mask, st = svo.pnp_ransac(Xw, obs, K, np.eye(4))
+    Tr, mr, sr = orc.pnp_ransac(Xw, obs, K, np.eye(4))
+    svo.close()
+    assert (st.ok, st.best_hypothesis, st.n_inliers, st.iterations) == (sr.ok, sr.best_hypothesis, sr.n_inliers, sr.iterations)
+    assert np.array_equal(mask, mr)
+    assert np.abs(T - Tr).max() < 1e-9 * (1 + np.abs(Tr).max())
+
+
 def test_pnp_ransac_degenerate_counts(svo_small, orc):
     """Fewer than five correspondences: OpenCV returns false - the fallback pose comes back, nothing is an inlier;
     exactly five: the one EPnP model, every point an inlier (RANSACPointSetRegistrator::run, count == modelPoints)."""

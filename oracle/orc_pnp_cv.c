@@ -42,6 +42,21 @@ static unsigned cvrng_next(cvrng_t* r) {
 }
 static int cvrng_uniform(cvrng_t* r, int a, int b) { return a == b ? a : (int)(cvrng_next(r) % (unsigned)(b - a) + a); }
 
+/* ---- cv::hypot (lapack.cpp, the template JacobiSVDImpl_ calls - not libm's): scaled, IEEE operations only ------ */
+static double cv_hypot(double a, double b) {
+  a = fabs(a);
+  b = fabs(b);
+  if (a > b) {
+    b /= a;
+    return a * sqrt(1 + b * b);
+  }
+  if (b > 0) {
+    a /= b;
+    return b * sqrt(1 + a * a);
+  }
+  return 0;
+}
+
 /* ---- JacobiSVDImpl_<double> (lapack.cpp): one-sided Jacobi on the n rows (length m) of At; Vt n x n ---------- */
 static void jacobi_svd(double* At, int astep, double* _W, double* Vt, int vstep, int m, int n, int n1) {
   const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
@@ -65,7 +80,7 @@ static void jacobi_svd(double* At, int astep, double* _W, double* Vt, int vstep,
         for (k = 0; k < m; k++) p += Ai[k] * Aj[k];
         if (fabs(p) <= eps * sqrt(a * b)) continue;
         p *= 2;
-        double beta = a - b, gamma = hypot(p, beta);
+        double beta = a - b, gamma = cv_hypot(p, beta);
         if (beta < 0) {
           double delta = (gamma - beta) * 0.5;
           s = sqrt(delta / gamma);

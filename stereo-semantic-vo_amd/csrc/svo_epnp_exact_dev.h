@@ -10,30 +10,69 @@
 //                                  compute_R_and_t, estimate_R_and_t, reprojection_error
 //   modules/core/src/lapack.cpp    JacobiSVDImpl_<double> (cyclic one-sided Jacobi), SVBkSbImpl_ (cvSolve / cvInvert, CV_SVD)
 // with IEEE division and square root and no FMA contraction (this file is compiled with -ffp-contract=off like the rest
-// of the library; nothing in it opts back in).  What is left to differ from a CPU run of the same loops is libm's hypot
-// (<= 1 ulp) - the discrete outcome of RANSAC (winner, visited samples, consensus) then matches the CPU restatement
+// of the library; nothing in it opts back in) - IEEE operations only, in the same order, so a CPU run of the same loops gives
+// the same bits - the discrete outcome of RANSAC (winner, visited samples, consensus) then matches the CPU restatement
 // sample for sample, which is what tests/test_full_length.py demands over all 4,541 frames of the headline run.
-// Private arrays are indexed dynamically here (they live in scratch memory): an order of magnitude slower than the
-// wave solver, by design only a checker for it - the fast mode is validated against this one.
+// Every array lives in a caller-provided workspace (`Work`, in LDS: one sample per workgroup, lane 0 walks the loops) -
+// nothing is a private array, so no scratch memory and no stack frames are involved; all functions are inlined.  An order
+// of magnitude slower than the wave solver, by design only a checker for it - the fast mode is validated against this one.
 #pragma once
+#ifndef HIP_INCLUDE_HIP_HIP_RUNTIME_H
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
+#ifndef EPNP_X_FN
+#define EPNP_X_FN __device__ __forceinline__
+#endif
+
 namespace epnp_exact {
+
+struct Problem {
+  double uc, vc, fu, fv;
+  double pws[15], us[10], alphas[20], pcs[15];
+  double cws[4][3], ccs[4][3];
+};
+
+// all arrays of one solve
+struct Work {
+  Problem e;
+  double ut[144], vt[144], d[12], M[120], L[60], rho[6];
+  double jW[12];                               // JacobiSVDImpl_'s W
+  double sA[30], sUt[36], sVt[25], sw[6];      // the small systems: A (6 x nc / 3 x 3), their SVD
+  double bx[5], gA[24], gb[6], gx[4], qA1[4], qA2[4];
+  double m33[9], inv33[9], PW0[15];
+  double dv[4][6][3];
+  double Rs[3][9], ts[3][3], errs[3], betas[4], pc0[3], pw0[3];
+};
 
 // cv::RNG of JacobiSVDImpl_'s zero-singular-value branch (seed 0x12345678)
 struct Rng {
   uint64_t state;
-  __device__ unsigned next() {
+  EPNP_X_FN unsigned next() {
     state = (uint64_t)(unsigned)state * 4164903690U + (unsigned)(state >> 32);
     return (unsigned)state;
   }
 };
 
+// cv::hypot (lapack.cpp, the template JacobiSVDImpl_ calls - not libm's): scaled, IEEE operations only
+EPNP_X_FN double cv_hypot(double a, double b) {
+  a = fabs(a);
+  b = fabs(b);
+  if (a > b) {
+    b /= a;
+    return a * sqrt(1 + b * b);
+  }
+  if (b > 0) {
+    a /= b;
+    return b * sqrt(1 + a * a);
+  }
+  return 0;
+}
+
 // JacobiSVDImpl_<double>: one-sided Jacobi on the n rows (length m) of At; Vt n x n; singular values descending
-__device__ inline void jacobi_svd(double* At, int astep, double* _W, double* Vt, int vstep, int m, int n, int n1) {
+EPNP_X_FN void jacobi_svd(double* W /*[12] workspace*/, double* At, int astep, double* _W, double* Vt, int vstep, int m, int n, int n1) {
   const double minval = 2.2250738585072014e-308, eps = 2.220446049250313e-16 * 10;
-  double W[12];
   const int max_iter = m > 30 ? m : 30;
   double c, s, sd;
   for (int i = 0; i < n; i++) {
@@ -53,7 +92,7 @@ __device__ inline void jacobi_svd(double* At, int astep, double* _W, double* Vt,
         for (int k = 0; k < m; k++) p += Ai[k] * Aj[k];
         if (fabs(p) <= eps * sqrt(a * b)) continue;
         p *= 2;
-        const double beta = a - b, gamma = hypot(p, beta);
+        const double beta = a - b, gamma = cv_hypot(p, beta);
         if (beta < 0) {
           const double delta = (gamma - beta) * 0.5;
           s = sqrt(delta / gamma);
@@ -128,13 +167,13 @@ __device__ inline void jacobi_svd(double* At, int astep, double* _W, double* Vt,
 }
 
 // cv::SVD::compute of a row-major m x n matrix (m >= n): w[n], Ut rows = left vectors (n x m), Vt rows = right vectors
-__device__ inline void svd_compute(const double* A, int m, int n, double* w, double* Ut, double* Vt) {
+EPNP_X_FN void svd_compute(double* jW, const double* A, int m, int n, double* w, double* Ut, double* Vt) {
   for (int i = 0; i < n; ++i)
     for (int k = 0; k < m; ++k) Ut[i * m + k] = A[k * n + i];
-  jacobi_svd(Ut, m, w, Vt, n, m, n, n);
+  jacobi_svd(jW, Ut, m, w, Vt, n, m, n, n);
 }
 // SVBkSbImpl_: x = V diag(1/w) U^T b, singular values <= 2 eps sum(w) dropped; b == nullptr: the identity (m x m)
-__device__ inline void svd_backsubst(int m, int n, const double* w, const double* Ut, const double* Vt, const double* b, int nb,
+EPNP_X_FN void svd_backsubst(int m, int n, const double* w, const double* Ut, const double* Vt, const double* b, int nb,
                                      double* x) {
   double threshold = 0;
   if (!b) nb = m;
@@ -155,27 +194,19 @@ __device__ inline void svd_backsubst(int m, int n, const double* w, const double
   }
 }
 // cvSolve(A, b, x, CV_SVD), 6 x nc
-__device__ inline void solve_svd6(const double* A, int nc, const double* b, double* x) {
-  double w[5], Ut[5 * 6], Vt[5 * 5];
-  svd_compute(A, 6, nc, w, Ut, Vt);
-  svd_backsubst(6, nc, w, Ut, Vt, b, 1, x);
+EPNP_X_FN void solve_svd6(Work& W, const double* A, int nc, const double* b, double* x) {
+  svd_compute(W.jW, A, 6, nc, W.sw, W.sUt, W.sVt);
+  svd_backsubst(6, nc, W.sw, W.sUt, W.sVt, b, 1, x);
 }
 
-__device__ inline double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-__device__ inline double dist2(const double* p1, const double* p2) {
+EPNP_X_FN double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+EPNP_X_FN double dist2(const double* p1, const double* p2) {
   return (p1[0] - p2[0]) * (p1[0] - p2[0]) + (p1[1] - p2[1]) * (p1[1] - p2[1]) + (p1[2] - p2[2]) * (p1[2] - p2[2]);
 }
 
-struct Problem {
-  double uc, vc, fu, fv;
-  double pws[15], us[10], alphas[20], pcs[15];
-  double cws[4][3], ccs[4][3];
-};
-
 // epnp::qr_solve, literally (its `eta` scan looks at the diagonal element twice and never at the last row)
-__device__ inline void qr_solve_6x4(double* pA, double* pb, double* pX) {
+EPNP_X_FN void qr_solve_6x4(double* A1, double* A2, double* pA, double* pb, double* pX) {
   const int nr = 6, nc = 4;
-  double A1[4], A2[4];
   double* ppAkk = pA;
   for (int k = 0; k < nc; k++) {
     double* ppAik1 = ppAkk;
@@ -228,8 +259,8 @@ __device__ inline void qr_solve_6x4(double* pA, double* pb, double* pX) {
   }
 }
 
-__device__ inline void gauss_newton(const double* L, const double* rho, double betas[4]) {
-  double A[24], b[6], x[4];
+EPNP_X_FN void gauss_newton(Work& W, const double* L, const double* rho, double* betas) {
+  double* A = W.gA; double* b = W.gb; double* x = W.gx;
   for (int it = 0; it < 5; it++) {
     for (int i = 0; i < 6; i++) {
       const double* rl = L + i * 10;
@@ -244,13 +275,14 @@ __device__ inline void gauss_newton(const double* L, const double* rho, double b
                        rl[9] * betas[3] * betas[3]);
     }
     x[0] = x[1] = x[2] = x[3] = 0;
-    qr_solve_6x4(A, b, x);
+    qr_solve_6x4(W.qA1, W.qA2, A, b, x);
     for (int i = 0; i < 4; i++) betas[i] += x[i];
   }
 }
 
 // compute_ccs, compute_pcs, solve_for_sign, estimate_R_and_t, reprojection_error
-__device__ inline double compute_R_and_t(Problem& e, const double* ut, const double* betas, double R[9], double t[3]) {
+EPNP_X_FN double compute_R_and_t(Work& W, const double* ut, const double* betas, double* R, double* t) {
+  Problem& e = W.e;
   for (int i = 0; i < 4; i++) e.ccs[i][0] = e.ccs[i][1] = e.ccs[i][2] = 0.0;
   for (int i = 0; i < 4; i++) {
     const double* v = ut + 12 * (11 - i);
@@ -267,11 +299,13 @@ __device__ inline double compute_R_and_t(Problem& e, const double* ut, const dou
       for (int j = 0; j < 3; j++) e.ccs[i][j] = -e.ccs[i][j];
     for (int i = 0; i < 15; i++) e.pcs[i] = -e.pcs[i];
   }
-  double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+  double* pc0 = W.pc0; double* pw0 = W.pw0;
+  for (int j = 0; j < 3; j++) { pc0[j] = 0; pw0[j] = 0; }
   for (int i = 0; i < 5; i++)
     for (int j = 0; j < 3; j++) { pc0[j] += e.pcs[3 * i + j]; pw0[j] += e.pws[3 * i + j]; }
   for (int j = 0; j < 3; j++) { pc0[j] /= 5; pw0[j] /= 5; }
-  double abt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, d[3], Ut[9], Vt[9];
+  double* abt = W.m33; double* d = W.sw; double* Ut = W.sUt; double* Vt = W.sVt;
+  for (int i = 0; i < 9; i++) abt[i] = 0;
   for (int i = 0; i < 5; i++) {
     const double* pc = e.pcs + 3 * i;
     const double* pw = e.pws + 3 * i;
@@ -281,7 +315,7 @@ __device__ inline double compute_R_and_t(Problem& e, const double* ut, const dou
       abt[3 * j + 2] += (pc[j] - pc0[j]) * (pw[2] - pw0[2]);
     }
   }
-  svd_compute(abt, 3, 3, d, Ut, Vt);
+  svd_compute(W.jW, abt, 3, 3, d, Ut, Vt);
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) R[3 * i + j] = Ut[0 * 3 + i] * Vt[0 * 3 + j] + Ut[1 * 3 + i] * Vt[1 * 3 + j] + Ut[2 * 3 + i] * Vt[2 * 3 + j];
   const double det = R[0] * R[4] * R[8] + R[1] * R[5] * R[6] + R[2] * R[3] * R[7] - R[2] * R[4] * R[6] - R[1] * R[3] * R[8] - R[0] * R[5] * R[7];
@@ -299,8 +333,8 @@ __device__ inline double compute_R_and_t(Problem& e, const double* ut, const dou
 }
 
 // epnp::compute_pose on five correspondences.  rep (nullable): the three candidates' mean reprojection errors.
-__device__ inline bool solve5(const double* Xw5, const double* uv5, const double* K, double* R_out, double* t_out, double* rep) {
-  Problem e;
+EPNP_X_FN bool solve5(Work& W, const double* Xw5, const double* uv5, const double* K, double* R_out, double* t_out, double* rep) {
+  Problem& e = W.e;
   e.fu = K[0]; e.fv = K[1]; e.uc = K[2]; e.vc = K[3];
   for (int i = 0; i < 15; ++i) e.pws[i] = Xw5[i];
   for (int i = 0; i < 10; ++i) e.us[i] = uv5[i];
@@ -310,7 +344,7 @@ __device__ inline bool solve5(const double* Xw5, const double* uv5, const double
     for (int j = 0; j < 3; j++) e.cws[0][j] += e.pws[3 * i + j];
   for (int j = 0; j < 3; j++) e.cws[0][j] /= 5;
   {
-    double PW0[15], pw0tpw0[9], dc[3], uct[9], vt[9];
+    double* PW0 = W.PW0; double* pw0tpw0 = W.m33; double* dc = W.sw; double* uct = W.sUt; double* vt = W.sVt;
     for (int i = 0; i < 5; i++)
       for (int j = 0; j < 3; j++) PW0[3 * i + j] = e.pws[3 * i + j] - e.cws[0][j];
     for (int a = 0; a < 3; ++a)
@@ -319,7 +353,7 @@ __device__ inline bool solve5(const double* Xw5, const double* uv5, const double
         for (int i = 0; i < 5; ++i) s += PW0[3 * i + a] * PW0[3 * i + b];
         pw0tpw0[3 * a + b] = s;
       }
-    svd_compute(pw0tpw0, 3, 3, dc, uct, vt);
+    svd_compute(W.jW, pw0tpw0, 3, 3, dc, uct, vt);
     for (int i = 1; i < 4; i++) {
       const double k = sqrt(dc[i - 1] / 5);
       for (int j = 0; j < 3; j++) e.cws[i][j] = e.cws[0][j] + k * uct[3 * (i - 1) + j];
@@ -327,10 +361,10 @@ __device__ inline bool solve5(const double* Xw5, const double* uv5, const double
   }
   // compute_barycentric_coordinates
   {
-    double cc[9], cc_inv[9], w[3], Ut[9], Vt[9];
+    double* cc = W.m33; double* cc_inv = W.inv33; double* w = W.sw; double* Ut = W.sUt; double* Vt = W.sVt;
     for (int i = 0; i < 3; i++)
       for (int j = 1; j < 4; j++) cc[3 * i + j - 1] = e.cws[j][i] - e.cws[0][i];
-    svd_compute(cc, 3, 3, w, Ut, Vt);
+    svd_compute(W.jW, cc, 3, 3, w, Ut, Vt);
     svd_backsubst(3, 3, w, Ut, Vt, nullptr, 3, cc_inv);
     for (int i = 0; i < 5; i++) {
       const double* pi = e.pws + 3 * i;
@@ -342,9 +376,9 @@ __device__ inline bool solve5(const double* Xw5, const double* uv5, const double
     }
   }
   // M, M^T M, its SVD (cvSVD(&MtM, &D, &Ut, 0, CV_SVD_MODIFY_A | CV_SVD_U_T))
-  double ut[144], vt[144], d[12];
+  double* ut = W.ut; double* vt = W.vt; double* d = W.d;
   {
-    double M[120];
+    double* M = W.M;
     for (int i = 0; i < 5; i++) {
       double* M1 = M + 2 * i * 12;
       double* M2 = M1 + 12;
@@ -362,19 +396,19 @@ __device__ inline bool solve5(const double* Xw5, const double* uv5, const double
         for (int r = 0; r < 10; ++r) s += M[12 * r + a] * M[12 * r + b];
         ut[12 * b + a] = s;
       }
-    jacobi_svd(ut, 12, d, vt, 12, 12, 12, 12);
+    jacobi_svd(W.jW, ut, 12, d, vt, 12, 12, 12, 12);
   }
   // compute_L_6x10, compute_rho
-  double L[60], rho[6];
+  double* L = W.L; double* rho = W.rho;
   {
-    const double* v[4] = {ut + 12 * 11, ut + 12 * 10, ut + 12 * 9, ut + 12 * 8};
-    double dv[4][6][3];
+    double (*dv)[6][3] = W.dv;
     for (int i = 0; i < 4; i++) {
+      const double* v = ut + 12 * (11 - i);
       int a = 0, b = 1;
       for (int j = 0; j < 6; j++) {
-        dv[i][j][0] = v[i][3 * a] - v[i][3 * b];
-        dv[i][j][1] = v[i][3 * a + 1] - v[i][3 * b + 1];
-        dv[i][j][2] = v[i][3 * a + 2] - v[i][3 * b + 2];
+        dv[i][j][0] = v[3 * a] - v[3 * b];
+        dv[i][j][1] = v[3 * a + 1] - v[3 * b + 1];
+        dv[i][j][2] = v[3 * a + 2] - v[3 * b + 2];
         b++;
         if (b > 3) { a++; b = a + 1; }
       }
@@ -395,17 +429,17 @@ __device__ inline bool solve5(const double* Xw5, const double* uv5, const double
     rho[0] = dist2(e.cws[0], e.cws[1]); rho[1] = dist2(e.cws[0], e.cws[2]); rho[2] = dist2(e.cws[0], e.cws[3]);
     rho[3] = dist2(e.cws[1], e.cws[2]); rho[4] = dist2(e.cws[1], e.cws[3]); rho[5] = dist2(e.cws[2], e.cws[3]);
   }
-  double Rs[3][9], ts[3][3], errs[3];
+  double (*Rs)[9] = W.Rs; double (*ts)[3] = W.ts; double* errs = W.errs;
   for (int cand = 0; cand < 3; ++cand) {
-    double betas[4], l[30], bx[5];
+    double* betas = W.betas; double* l = W.sA; double* bx = W.bx;
     if (cand == 0) {          // find_betas_approx_1: [B11 B12 B13 B14]
       for (int i = 0; i < 6; i++) { l[4 * i] = L[10 * i]; l[4 * i + 1] = L[10 * i + 1]; l[4 * i + 2] = L[10 * i + 3]; l[4 * i + 3] = L[10 * i + 6]; }
-      solve_svd6(l, 4, rho, bx);
+      solve_svd6(W, l, 4, rho, bx);
       if (bx[0] < 0) { betas[0] = sqrt(-bx[0]); betas[1] = -bx[1] / betas[0]; betas[2] = -bx[2] / betas[0]; betas[3] = -bx[3] / betas[0]; }
       else { betas[0] = sqrt(bx[0]); betas[1] = bx[1] / betas[0]; betas[2] = bx[2] / betas[0]; betas[3] = bx[3] / betas[0]; }
     } else if (cand == 1) {   // find_betas_approx_2: [B11 B12 B22]
       for (int i = 0; i < 6; i++) { l[3 * i] = L[10 * i]; l[3 * i + 1] = L[10 * i + 1]; l[3 * i + 2] = L[10 * i + 2]; }
-      solve_svd6(l, 3, rho, bx);
+      solve_svd6(W, l, 3, rho, bx);
       if (bx[0] < 0) { betas[0] = sqrt(-bx[0]); betas[1] = (bx[2] < 0) ? sqrt(-bx[2]) : 0.0; }
       else { betas[0] = sqrt(bx[0]); betas[1] = (bx[2] > 0) ? sqrt(bx[2]) : 0.0; }
       if (bx[1] < 0) betas[0] = -betas[0];
@@ -413,15 +447,15 @@ __device__ inline bool solve5(const double* Xw5, const double* uv5, const double
     } else {                  // find_betas_approx_3: [B11 B12 B22 B13 B23]
       for (int i = 0; i < 6; i++)
         for (int c = 0; c < 5; ++c) l[5 * i + c] = L[10 * i + c];
-      solve_svd6(l, 5, rho, bx);
+      solve_svd6(W, l, 5, rho, bx);
       if (bx[0] < 0) { betas[0] = sqrt(-bx[0]); betas[1] = (bx[2] < 0) ? sqrt(-bx[2]) : 0.0; }
       else { betas[0] = sqrt(bx[0]); betas[1] = (bx[2] > 0) ? sqrt(bx[2]) : 0.0; }
       if (bx[1] < 0) betas[0] = -betas[0];
       betas[2] = bx[3] / betas[0];
       betas[3] = 0.0;
     }
-    gauss_newton(L, rho, betas);
-    errs[cand] = compute_R_and_t(e, ut, betas, Rs[cand], ts[cand]);
+    gauss_newton(W, L, rho, betas);
+    errs[cand] = compute_R_and_t(W, ut, betas, Rs[cand], ts[cand]);
   }
   int N = 0;
   if (errs[1] < errs[0]) N = 1;

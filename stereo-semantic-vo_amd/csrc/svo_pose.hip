@@ -43,12 +43,13 @@ __global__ __launch_bounds__(256) void k_pnp_hyp(const double* __restrict__ Xw, 
   pnp_hyp_block(L.ws, L.Xw, L.uv, n, K, subset, hyp, blockIdx.x * (blockDim.x >> 6));
 }
 
-// parity mode (svo_set_option "epnp_exact"): one lane per sample, OpenCV's loops in order (svo_epnp_exact_dev.h)
-__global__ __launch_bounds__(128) void k_pnp_hyp_exact(const double* __restrict__ Xw, const double* __restrict__ obs, int n,
-                                                       const double* __restrict__ Kp, const uint16_t* __restrict__ subset,
-                                                       PnpHyp* hyp) {
+// parity mode (svo_set_option "epnp_exact"): one single-wave workgroup per sample, OpenCV's loops in order on lane 0
+__global__ __launch_bounds__(64) void k_pnp_hyp_exact(const double* __restrict__ Xw, const double* __restrict__ obs, int n,
+                                                      const double* __restrict__ Kp, const uint16_t* __restrict__ subset,
+                                                      PnpHyp* hyp) {
+  __shared__ PnpExactLds S;
   const double K[4] = {Kp[0], Kp[1], Kp[2], Kp[3]};
-  pnp_hyp_exact(Xw, obs, n, K, subset, hyp, threadIdx.x);
+  pnp_hyp_exact_wave(S, Xw, obs, n, K, subset, hyp, blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void k_pnp_select(const double* __restrict__ Xw, const double* __restrict__ obs, int n,
@@ -107,13 +108,12 @@ __global__ __launch_bounds__(256) void k_epnp5_probe(const double* X5, const dou
     Rt[21] = (double)(ws.stamp[5] - ws.stamp[3]); Rt[22] = (double)(ws.stamp[6] - ws.stamp[5]); Rt[23] = (double)(ws.stamp[7] - ws.stamp[6]);
   }
 }
-__global__ void k_epnp5_probe_exact(const double* X5, const double* u5, const double* Kp, double* Rt) {
+__global__ __launch_bounds__(64) void k_epnp5_probe_exact(const double* X5, const double* u5, const double* Kp, double* Rt) {
+  __shared__ epnp_exact::Work W;
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double K[4] = {Kp[0], Kp[1], Kp[2], Kp[3]}, R[9], t[3], rep[3];
-  const bool ok = epnp_exact::solve5(X5, u5, K, R, t, rep);
-  for (int i = 0; i < 9; ++i) Rt[i] = R[i];
-  Rt[9] = t[0]; Rt[10] = t[1]; Rt[11] = t[2]; Rt[12] = ok ? 1.0 : 0.0;
-  for (int b = 0; b < 3; ++b) Rt[13 + b] = rep[b];
+  double K[4] = {Kp[0], Kp[1], Kp[2], Kp[3]};
+  const bool ok = epnp_exact::solve5(W, X5, u5, K, Rt, Rt + 9, Rt + 13);
+  Rt[12] = ok ? 1.0 : 0.0;
   for (int b = 16; b < 24; ++b) Rt[b] = 0.0;
 }
 int svo_launch_epnp5_probe(svo_ctx* ctx, const double* X5, const double* u5, const double* K, double* Rt, int reps) {
@@ -191,7 +191,7 @@ int svo_launch_pnp(svo_ctx* ctx, const double* Xw, const double* obs, int n, con
   if (rc) return rc;
   SvoTimer tm(ctx, "k_pnp_ransac");
   if (n >= 5 && ctx->opt_epnp_exact)
-    hipLaunchKernelGGL(k_pnp_hyp_exact, dim3(1), dim3(128), 0, ctx->stream, Xw, obs, n, K, subset, hyp);
+    hipLaunchKernelGGL(k_pnp_hyp_exact, dim3(PNP_HYP), dim3(64), 0, ctx->stream, Xw, obs, n, K, subset, hyp);
   else if (n >= 5)
     hipLaunchKernelGGL(k_pnp_hyp, dim3(PNP_HYP), dim3(64), sizeof(PnpHypLds), ctx->stream, Xw, obs, n, K, subset, hyp);
   hipLaunchKernelGGL(k_pnp_select, dim3(1), dim3(256), 0, ctx->stream, Xw, obs, n, K, Tfallback, hyp, T, mask, stats);

@@ -611,24 +611,44 @@ __device__ __forceinline__ void pnp_hyp_block(EpnpWaveLds* ws, const double* Xw,
   }
 }
 
-// The same samples in the parity mode (svo_set_option "epnp_exact"): thread k solves sample k on its own with the
-// sequential restatement of OpenCV's loops (svo_epnp_exact_dev.h) and counts its consensus.  Called by >= PNP_HYP threads.
-__device__ inline void pnp_hyp_exact(const double* Xw, const double* uv, int n, const double* K, const uint16_t* subset,
-                                     PnpHyp* out, int k) {
+// The same samples in the parity mode (svo_set_option "epnp_exact"): ONE sample per wave - lane 0 walks the sequential
+// restatement of OpenCV's loops (svo_epnp_exact_dev.h) with every array in the LDS workspace `W`, then the whole wave
+// counts the sample's consensus.  Called by all 64 lanes of the wave that owns sample k.
+struct PnpExactLds { epnp_exact::Work W; double R[9], t[3]; int ok; };
+__device__ __forceinline__ void pnp_hyp_exact_wave(PnpExactLds& S, const double* Xw, const double* uv, int n, const double* K,
+                                                   const uint16_t* subset, PnpHyp* out, int k) {
+  const int lane = threadIdx.x & 63;
   if (k >= PNP_HYP) return;
-  double x5[15], u5[10];
-  for (int i = 0; i < 5; ++i) {
-    const int e = min((int)subset[5 * k + i], n - 1);
-    x5[3 * i] = Xw[3 * e]; x5[3 * i + 1] = Xw[3 * e + 1]; x5[3 * i + 2] = Xw[3 * e + 2];
-    u5[2 * i] = uv[2 * e]; u5[2 * i + 1] = uv[2 * e + 1];
+  if (lane == 0) {
+    double* x5 = S.W.PW0;        // staging only: solve5 copies the sample into its problem record first
+    double* u5 = S.W.gA;
+    for (int i = 0; i < 5; ++i) {
+      const int e = min((int)subset[5 * k + i], n - 1);
+      x5[3 * i] = Xw[3 * e]; x5[3 * i + 1] = Xw[3 * e + 1]; x5[3 * i + 2] = Xw[3 * e + 2];
+      u5[2 * i] = uv[2 * e]; u5[2 * i + 1] = uv[2 * e + 1];
+    }
+    S.ok = epnp_exact::solve5(S.W, x5, u5, K, S.R, S.t, nullptr) ? 1 : 0;
   }
-  PnpHyp h;
-  const bool ok = epnp_exact::solve5(x5, u5, K, h.R, h.t, nullptr);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  double R[9], t[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = S.R[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) t[i] = S.t[i];
+  const bool ok = S.ok != 0;
   int cnt = 0;
   if (ok)
-    for (int e = 0; e < n; ++e) cnt += pnp_inlier(h.R, h.t, Xw + 3 * e, uv + 2 * e, K) ? 1 : 0;
-  h.cnt = cnt; h.ok = ok ? 1 : 0;
-  out[k] = h;
+    for (int e = lane; e < n; e += 64) cnt += pnp_inlier(R, t, Xw + 3 * e, uv + 2 * e, K) ? 1 : 0;
+  cnt = wave_sum_i32_dpp(cnt);
+  if (lane == 0) {
+    PnpHyp h;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) h.R[i] = R[i];
+    h.t[0] = t[0]; h.t[1] = t[1]; h.t[2] = t[2];
+    h.cnt = cnt; h.ok = ok ? 1 : 0;
+    out[k] = h;
+  }
 }
 
 // RANSACUpdateNumIters(p = 0.99, ep, modelPoints = 5, maxIters)

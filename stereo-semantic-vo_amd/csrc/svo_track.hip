@@ -938,14 +938,15 @@ __global__ __launch_bounds__(256) void k_tp_hyp(TrackState* st, const TrackWork*
   }
 }
 
-// The RANSAC samples in the parity mode (svo_set_option "epnp_exact"): one lane per sample, OpenCV's loops in their own
-// order (svo_epnp_exact_dev.h).  One 128-thread workgroup per sequence; the correspondences are gathered into LDS first.
-struct TpHypExactLds { double Xw[TRK_MAXKP * 3], uv[TRK_MAXKP * 2]; };
-__global__ __launch_bounds__(128) void k_tp_hyp_exact(TrackState* st, TrackWork* work, const svo_kp* kp, const uint16_t* subsets,
-                                                      int kstride) {
+// The RANSAC samples in the parity mode (svo_set_option "epnp_exact"): one single-wave workgroup per sample, lane 0 walks
+// OpenCV's loops in their own order (svo_epnp_exact_dev.h), the wave counts the consensus.  Every workgroup gathers the
+// frame's correspondences into LDS itself, like k_tp_hyp.
+struct TpHypExactLds { double Xw[TRK_MAXKP * 3], uv[TRK_MAXKP * 2]; PnpExactLds ex; };
+__global__ __launch_bounds__(64) void k_tp_hyp_exact(TrackState* st, TrackWork* work, const svo_kp* kp, const uint16_t* subsets,
+                                                     int kstride) {
   TpHypExactLds& S = *reinterpret_cast<TpHypExactLds*>(tk_smem);
   st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
-  if (threadIdx.x == 0) work->rt[2] = wall_clock64();
+  if (threadIdx.x == 0 && blockIdx.x == 0) work->rt[2] = wall_clock64();
   const int n = work->n_edges;
   if (work->skip_match || n < 5) return;
   const float* gpos = st->gpos;
@@ -957,7 +958,7 @@ __global__ __launch_bounds__(128) void k_tp_hyp_exact(TrackState* st, TrackWork*
   }
   __syncthreads();
   const double K[4] = {(double)st->cam.fx, (double)st->cam.fy, (double)st->cam.cx, (double)st->cam.cy};
-  pnp_hyp_exact(S.Xw, S.uv, n, K, subsets + (size_t)min(n, 512) * 500, st->hyp, threadIdx.x);
+  pnp_hyp_exact_wave(S.ex, S.Xw, S.uv, n, K, subsets + (size_t)min(n, 512) * 500, st->hyp, blockIdx.x);
 }
 
 // k_tp_frame: RANSAC's acceptance rule over the samples, Optimizer::PoseOptimization, SetPose, the positions of the
@@ -1196,7 +1197,7 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
     ctx->profiling = prof && (f % 32 == 0 || frames < 32);
     if (ctx->opt_epnp_exact) {
       SvoTimer t(ctx, "k_tp_hyp_exact");
-      hipLaunchKernelGGL(k_tp_hyp_exact, dim3(1, ny), dim3(128), sizeof(TpHypExactLds), s0, st, work + f, kpf, ctx->d_pnp_subsets, kstride);
+      hipLaunchKernelGGL(k_tp_hyp_exact, dim3(PNP_HYP, ny), dim3(64), sizeof(TpHypExactLds), s0, st, work + f, kpf, ctx->d_pnp_subsets, kstride);
     } else {
       SvoTimer t(ctx, "k_tp_hyp");
       if (ny >= 8) {

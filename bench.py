@@ -7,32 +7,38 @@ gray, synth-kitti renderer), all resident in HBM before the clock starts.
   --workload track (default): one "step" = svo_track_batch_dev over B consecutive frames of the
         ONE sequence (front end batched over the B pairs, then the ordered tail frame by frame);
         B = 4541 // (warmup + steps), the remainder rides in the first warm-up step so that the
-        whole sequence is tracked and ATE is over all of it.
+        whole sequence is tracked and ATE is over all of it.  The timed region runs the product's
+        default schedule (no profiling hooks); per-kernel HIP-event times come from a separate,
+        untimed pass over the first frames, the tail's critical path from in-kernel wall-clock
+        stamps of the timed region itself.
   --workload frontend (BASELINE configs[1], batched): ORB on both images + sparse epipolar
-        stereo for B pairs per step, rotating through the resident sequence (every step reads
-        B new pairs: the inputs do not stay in the 256 MiB Infinity Cache).
-The default line also carries named legs: "frontend", "multi_sequence", "elas", "msa", and the
-CPU baseline (the oracle's single-thread port on a bounded prefix, with the GPU-vs-CPU ATE).
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL, used ONLY for the barrier and
-the max-over-ranks clock).  The tracking chain of one sequence does not shard (replicas only:
-rank r tracks its own sequence, seed + r); the front-end workload shards by stereo pair with no
-data-path collective (pair k -> rank k mod N).  Weak scaling.  Prints ONE JSON line on rank 0.
+        stereo for B pairs per step, rotating through the resident sequence.
+  --shard: BASELINE configs[3] as the reference would run it - ONE sequence, ONE process, --gpus G
+        contexts (one per GPU when the box has G GPUs, otherwise all on GPU 0): pair k's front end
+        on context k mod G, the ordered tail on context 0 (svo_track_sharded_dev).
+The default line also carries named legs: "frontend", "multi_sequence", "sharded", "semantic_elas"
+(configs[4] as a whole), "elas", "msa", and the CPU baseline (the oracle's single-thread port on a
+bounded prefix; its tail alone over ALL tracked frames for the counter / ATE comparison).
+N > 1: `python bench.py --gpus N` starts the N ranks itself (torch.distributed.run as a child
+process, before this process touches a GPU) unless it already runs under one; one process per GPU
+(backend nccl = RCCL, used ONLY for the barrier and the max-over-ranks clock).  The tracking chain
+of one sequence does not shard (replicas: rank r tracks its own sequence, seed + r); the front-end
+workload shards by stereo pair with no data-path collective (pair k -> rank k mod N).  Weak
+scaling.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-import svo_loader  # noqa: E402
 
 W, H = 1241, 376
 PITCH = 1280                         # HBM row pitch of the resident images (64-byte multiple)
@@ -43,34 +49,59 @@ ALGO_BYTES_PER_PAIR = 14.0e6         # SURVEY.md section 8d / BASELINE.md sectio
 KERNEL_BYTES_PER_IMAGE = {
     "k_fast": S_PYR * W * H,                      # "S [FAST read]"
     "k_pyr_level": (1 + (S_PYR - 1)) * W * H,     # "1 [src read] + (S-1) [pyramid write]"
-    "k_pyr_fast": (1 + (S_PYR - 1) + S_PYR) * W * H,
+    "k_pyr_fused": (1 + (S_PYR - 1)) * W * H,
     "k_select": 2 * 500 * 81,                     # Harris: 2N 9x9 windows
     "k_describe": 500 * 37 * 37 + 500 * 60,       # patch gathers + keypoint / descriptor records
 }
 KERNEL_BYTES_PER_PAIR = {"k_stereo_match": 500 * (11 * 11 + 11 * 21) + 2 * 500 * 32, "k_stereo_median": 500 * 12}
 
 
+def host_cpus():
+    """CPUs this process may actually use: the machine's, cut down to the cgroup quota (the GPU boxes give a process
+    16 CPUs of a 256-thread machine)."""
+    n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, round(int(q) / int(p))))
+    except Exception:
+        pass
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    return n
+
+
 def tail_kernel_bytes(kernel, mean_pool_rows, mean_kp, mean_edges, mean_lm_iters):
-    """Algorithmic bytes per FRAME of the three kernels of the ordered tail (SURVEY 8d's
+    """Algorithmic bytes per FRAME of the kernels of the ordered tail (SURVEY 8d's
     Hamming and pose-opt terms): what the stage has to touch once, not what the implementation moves."""
     if kernel == "k_ti_lists":      # Hamming: (M + N) descriptors of 32 bytes
         return (mean_pool_rows + mean_kp) * 32.0
     if kernel == "k_ti_resolve":    # packed entries of the M rows in, the compacted pool (descriptor + 10 bytes) out and in
         return mean_pool_rows * (64.0 + 2 * 42.0) + mean_kp * 60.0
-    if kernel == "k_tp_hyp":        # the n correspondences (40 bytes each) in, 100 sample records (112 bytes) out
+    if kernel in ("k_tp_hyp", "k_tp_hyp_exact"):   # the n correspondences (40 bytes each) in, 100 sample records (112 bytes) out
         return mean_edges * 40.0 + 100 * 112.0
     if kernel == "k_tp_frame":      # n correspondences of 40 bytes: once for the gather + once per LM iteration and trial
         return mean_edges * 40.0 * (1.0 + 2.0 * mean_lm_iters)
+    if kernel == "k_tp_pose":       # the fused RANSAC + LM kernel: both of the above
+        return mean_edges * 40.0 * (2.0 + 2.0 * mean_lm_iters) + 100 * 112.0
     return 0.0
+
+
+def pmc_entry(kernel):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))[kernel]
+    except Exception:
+        return None
 
 
 def pmc_traffic(kernel, pairs_per_launch=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same
     command (profiles/pmc_latest.json; FETCH_SIZE and WRITE_SIZE collected in separate passes,
     KB units, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
-    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    d = pmc_entry(kernel)
     try:
-        d = json.load(open(path))[kernel]
         per_dispatch = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
         if pairs_per_launch and d.get("_pairs_per_dispatch_traffic"):    # counters were taken at another batch size: scale
             per_dispatch *= pairs_per_launch / d["_pairs_per_dispatch_traffic"]
@@ -84,9 +115,8 @@ def pmc_valu(kernel):
     instructions per wave and the fraction of SIMD issue time spent on VALU instructions
     (SQ_ACTIVE_INST_VALU counts quad-cycles, 4 per issued wave64 instruction; GRBM_GUI_ACTIVE is summed
     over the 8 XCDs; 1024 SIMDs)."""
-    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    d = pmc_entry(kernel)
     try:
-        d = json.load(open(path))[kernel]
         cycles = d["GRBM_GUI_ACTIVE"] / 8.0
         return {"instr_per_wave": d["SQ_INSTS_VALU"] / d["SQ_WAVES"],
                 "busy_frac": d["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cycles),
@@ -100,6 +130,8 @@ def render_frames(synth, n, dev, seed, start=0):
     """n consecutive frames resident on `dev`, padded to PITCH; + ground truth.  synth-kitti by
     default; real KITTI 00 frames when KITTI_ROOT is set (layout of the reference's main.cpp:20-57).
     Rendered / loaded in chunks so that only the padded uint8 frames stay resident."""
+    import numpy as np
+    import torch
     root = os.environ.get("KITTI_ROOT")
     dL = torch.zeros((n, H, PITCH), dtype=torch.uint8, device=dev)
     dR = torch.zeros_like(dL)
@@ -121,23 +153,43 @@ def render_frames(synth, n, dev, seed, start=0):
     return dL, dR, torch.cat(Ts)
 
 
+def centres(poses):
+    import numpy as np
+    return np.array([np.linalg.inv(p.reshape(4, 4).astype(np.float64))[:3, 3] for p in poses])
+
+
 def ate_rmse(res, T_gt):
     """Translation RMSE of the estimated camera centres vs ground truth (no alignment:
     both start at the identity)."""
-    err = []
-    for k in range(len(res)):
-        Tcw = res[k]["Tcw"].reshape(4, 4).astype(np.float64)
-        Twc = np.linalg.inv(Tcw)
-        err.append(np.linalg.norm(Twc[:3, 3] - T_gt[k][:3, 3]))
+    import numpy as np
+    err = np.linalg.norm(centres(res["Tcw"]) - T_gt[:len(res), :3, 3], axis=1)
     return float(np.sqrt(np.mean(np.square(err)))), float(err[-1])
 
 
+def moving_boxes(k):
+    """Offline detections of frame k in the reference's {left, right, top, bottom} layout (main.cpp:82-95): one box
+    crossing the image at 4 px per frame (a vehicle), one fixed box growing slowly (something approached)."""
+    x = 80 + (4 * k) % 820
+    return [[x, x + 260, 150, 330], [100, 260, 200, 300 + (2 * k) % 60]]
+
+
+def boxes_hbm(pkg, n, dev):
+    import numpy as np
+    import torch
+    b = np.zeros((n, 2, 4), np.int32)
+    for k in range(n):
+        b[k] = moving_boxes(k)
+    tb = torch.from_numpy(b).to(dev)
+    tn = torch.full((n,), 2, dtype=torch.int32, device=dev)
+    return pkg.boxes_dev(tb.data_ptr(), tn.data_ptr(), 2), (tb, tn)
+
+
 def cpu_baseline_all_cores(Lh, Rh, cam, budget_s=8.0):
-    """Same port, frame-parallel over the host cores (the stateless front end shards by stereo pair
-    on the CPU too; ctypes releases the GIL inside the C calls)."""
+    """Same port, frame-parallel over the host cores this process may use (the stateless front end shards by stereo
+    pair on the CPU too; ctypes releases the GIL inside the C calls)."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import binding as orc
-    cores = min(os.cpu_count() or 1, 64)
+    cores = min(host_cpus(), 64)
     deadline = time.perf_counter() + budget_s
     done = [0] * cores
 
@@ -152,15 +204,94 @@ def cpu_baseline_all_cores(Lh, Rh, cam, budget_s=8.0):
         list(ex.map(worker, range(cores)))
     dt = time.perf_counter() - t0
     return {"value": sum(done) / dt, "unit": "stereo pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d pairs in %.1f s, %d threads each running the single-thread port on its own pairs"
-                      % (sum(done), dt, cores)}
+            "sample": "%d pairs in %.1f s, %d threads (= the CPUs this process may use: cgroup quota; the machine shows %d) "
+                      "each running the single-thread port on its own pairs" % (sum(done), dt, cores, os.cpu_count() or 0)}
 
 
-def elas_leg(pkg, W, H, device, d_L, d_R, pitch, B, iters=4):
-    """Dense ELAS stereo (BASELINE configs[4] without YOLO): svo_elas_batch_dev on the B
-    synthetic pairs already resident in HBM (maps stay in HBM: same boundary as `value`), plus the latency of one
-    svo_elas_process call on host buffers.  Beside it the reference's own compiled libelas on one host core
-    when oracle/_ref is present."""
+def cpu_baseline(Lh, Rh, cam, workload, budget_s=15.0):
+    """The oracle (a single-threaded C port of the same path) timed on this box's host
+    cores over a bounded sample of the same workload."""
+    from oracle import binding as orc
+    orc.build()
+    n, t0 = 0, time.perf_counter()
+    trk = orc.Tracker(W, H, dict(fx=cam.fx, fy=cam.fy, cx=cam.cx, cy=cam.cy, bf=cam.bf)) \
+        if workload == "track" else None
+    while n < len(Lh) and (time.perf_counter() - t0) < budget_s:
+        if trk is not None:
+            trk.track(Lh[n], Rh[n])
+        else:
+            orc.stereo_frame(Lh[n], Rh[n], cam.bf, cam.fx)
+        n += 1
+    dt = time.perf_counter() - t0
+    what = "full tracking loop" if workload == "track" else "ORB on L and R + sparse stereo"
+    return {"value": n / dt, "unit": "stereo pairs/s", "cores": 1, "kind": "port",
+            "sample": "first %d pairs of the benchmark frames (%s), %.1f s, oracle/libsvo_oracle.so "
+                      "single thread; this process may use %d CPUs (cgroup quota) of the machine's %d"
+                      % (n, what, dt, host_cpus(), os.cpu_count() or 0)}
+
+
+class OracleTailRun(threading.Thread):
+    """The oracle's ordered tail (orc_track_tail) over ALL tracked frames, fed with the device front end's outputs (bit-exact
+    against the oracle's own front end by the parity tests), free-running on a host thread while the GPU legs run: every
+    counter of every frame against the device's records, and the ATE between the two whole trajectories."""
+
+    def __init__(self, cam, kp, desc, n, depth):
+        super().__init__(daemon=True)
+        self.cam, self.kp, self.desc, self.n, self.depth = cam, kp, desc, n, depth
+        self.records, self.seconds, self.error = [], 0.0, None
+
+    def run(self):
+        try:
+            from oracle import binding as orc
+            orc.build()
+            t0 = time.perf_counter()
+            trk = orc.Tracker(W, H, dict(fx=self.cam.fx, fy=self.cam.fy, cx=self.cam.cx, cy=self.cam.cy, bf=self.cam.bf))
+            for k in range(len(self.n)):
+                nk = int(self.n[k])
+                self.records.append(trk.track_tail(self.kp[k, :nk], self.desc[k, :nk], self.depth[k, :nk])[0].copy())
+            trk.close()
+            self.seconds = time.perf_counter() - t0
+        except Exception as e:  # noqa: BLE001
+            self.error = repr(e)
+
+    def report(self, res):
+        import numpy as np
+        if self.error or not self.records:
+            return {"error": self.error or "no frames"}
+        k = len(self.records)
+        cnt = ("n_kp", "n_stereo", "n_match_pass1", "n_match_pass2", "n_lm_edges", "n_new_mappoints", "n_local_map")
+        same = all(all(int(res[i][f]) == int(self.records[i][f]) for f in cnt) for i in range(k))
+        d = np.linalg.norm(centres(res["Tcw"][:k]) - centres([r["Tcw"] for r in self.records]), axis=1)
+        return {"frames": k, "counters_identical_to_gpu": bool(same), "seconds": round(self.seconds, 1),
+                "ate_vs_cpu_m": {"rmse": float(np.sqrt(np.mean(d * d))), "max": float(d.max()), "frames": int(k)},
+                "what": "oracle/orc_track_tail (free-running, single thread) on the device front end's keypoints / descriptors / depths"}
+
+
+def frontend_outputs(pkg, cam, dL, dR, n_frames, dev):
+    """Keypoints, descriptors, counts and depths of all resident frames (device front end), on the host."""
+    import torch
+    K = 500
+    kp = torch.zeros((n_frames, K, pkg.KP_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    desc = torch.zeros((n_frames, K, 32), dtype=torch.uint8, device=dev)
+    n = torch.zeros(n_frames, dtype=torch.int32, device=dev)
+    depth = torch.zeros((n_frames, K), dtype=torch.float32, device=dev)
+    fe = pkg.Svo(W, H, device=dev.index or 0, max_kp=K, max_batch=128)
+    fb = H * PITCH
+    for c0 in range(0, n_frames, 128):
+        c = min(128, n_frames - c0)
+        fe.frontend_batch_dev(dL.data_ptr() + c0 * fb, dR.data_ptr() + c0 * fb, PITCH, c, cam, d_kpL=kp[c0:].data_ptr(),
+                              d_descL=desc[c0:].data_ptr(), d_nL=n[c0:].data_ptr(), d_depth=depth[c0:].data_ptr())
+    fe.sync()
+    fe.close()
+    return (kp.cpu().numpy().view(pkg.KP_DTYPE).reshape(n_frames, K), desc.cpu().numpy(), n.cpu().numpy(), depth.cpu().numpy())
+
+
+# ------------------------------------------------------------------------------------------------ legs
+def elas_leg(pkg, device, d_L, d_R, pitch, B, iters=4):
+    """Dense ELAS stereo: svo_elas_batch_dev on the B synthetic pairs already resident in HBM (maps
+    stay in HBM: same boundary as `value`), plus the latency of one svo_elas_process call on host buffers.  Beside it
+    the reference's own compiled libelas on one host core when oracle/_ref is present."""
+    import numpy as np
     import torch
     ctx = pkg.Svo(W, H, device=device)
     p = pkg.elas_default_params(0)
@@ -172,21 +303,14 @@ def elas_leg(pkg, W, H, device, d_L, d_R, pitch, B, iters=4):
     for _ in range(iters):
         produced = ctx.elas_batch_dev(d_L.data_ptr(), d_R.data_ptr(), pitch, W, H, B, D1.data_ptr(), D2.data_ptr(), p)
     thr = B * iters / (time.perf_counter() - t0)
-    # per-kernel time per pair (HIP events around every launch on the context's stream) and the HBM roofline of
-    # the dominant kernel among those with a defined compulsory traffic (bytes per pair, P = W*H pixels):
-    #   k_elas_desc   2P image bytes in, 2*16P descriptor bytes out
-    #   k_elas_match  2*16P descriptors + 2*4P owner ids in, 2*4P raw maps out
-    #   k_elas_raster 2*4P owner ids written
-    #   k_cc_segments 4P map + 3*4P label / run-length / size arrays written and read once
-    #   k_elas_gap    2 passes over a 4P map, read + write
     ctx.profile_enable(True); ctx.profile_reset()
     ctx.elas_batch_dev(d_L.data_ptr(), d_R.data_ptr(), pitch, W, H, B, D1.data_ptr(), D2.data_ptr(), p)
     ctx.profile_enable(False)
     P = W * H
-    #   k_elas_support 2*16P descriptor bytes read once (HBM-compulsory; the reference's loops re-read 16 KB per lattice
-    #                  point and direction - 0.6 GB per pair - which is what the kernel's L1 actually serves)
-    #   k_elas_lr / k_elas_mean  two 4P maps read and written
-    #   k_elas_planes / k_elas_grid  support-point and triangle lists (tens of KB)
+    # compulsory traffic per pair (bytes, P = W*H pixels):
+    #   k_elas_desc 2P image bytes in, 2*16P descriptor bytes out; k_elas_match 2*16P descriptors + 2*4P owner ids in,
+    #   2*4P raw maps out; k_elas_raster 2*4P owner ids; k_cc_segments 4P map + 3*4P label arrays; k_elas_gap 2 passes over
+    #   a 4P map; k_elas_support 2*16P descriptors read once; k_elas_lr / k_elas_mean two 4P maps read and written
     algo = {"k_elas_desc": 34 * P, "k_elas_match": 48 * P, "k_elas_raster": 8 * P, "k_cc_segments": 28 * P,
             "k_elas_gap": 16 * P, "k_elas_support": 32 * P, "k_elas_lr": 16 * P, "k_elas_mean": 16 * P,
             "k_elas_planes": 2 * 8000 * 36, "k_elas_grid": 2 * (W // 20 + 1) * (H // 20 + 1) * 32 * 2}
@@ -195,8 +319,11 @@ def elas_leg(pkg, W, H, device, d_L, d_R, pitch, B, iters=4):
     algo.setdefault(dom, 0)
     ach = algo[dom] / (kern[dom] * 1e-6) / 1e9
     roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": None, "algorithmic_bytes_per_pair": algo[dom],
-            "note": "latency / atomic bound, not bandwidth bound: see DESIGN.md section 8"}
+            "traffic": pmc_traffic(dom, 1), "algorithmic_bytes_per_pair": algo[dom],
+            "pipeline_frac": 198.0 * P * thr / 1e9 / HBM_PEAK_GBS,
+            "note": "latency / atomic bound, not bandwidth bound: see DESIGN.md section 8; pipeline_frac = sum of the stages' "
+                    "compulsory bytes (198 P per pair) x pairs/s over the HBM peak; the batch is bound by the host-side support-point "
+                    "filter + Delaunay triangulation under the box's CPU quota"}
     L = d_L[0, :, :W].cpu().numpy(); R = d_R[0, :, :W].cpu().numpy()
     for _ in range(3):
         E1, _ = ctx.elas_process(L, R, p)
@@ -209,7 +336,7 @@ def elas_leg(pkg, W, H, device, d_L, d_R, pitch, B, iters=4):
     out = {"value": thr, "unit": "stereo pairs/s", "pairs_per_call": B, "pairs_with_maps": int(produced.sum()),
            "kernel_us_per_pair": {k: round(v, 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])}, "roofline": roof,
            "latency_ms_per_pair_host_buffers": lat * 1e3, "valid_fraction": float((G1 >= 0).mean()),
-           "batch_equals_single_call": bool(np.array_equal(G1, E1)), "setting": "ROBOTICS",
+           "batch_equals_single_call": bool(np.array_equal(G1, E1)), "setting": "ROBOTICS", "host_cpus": host_cpus(),
            "note": "dense disparity maps D1+D2 per pair; throughput with pairs and maps resident in HBM, latency host to host"}
     try:
         from oracle import binding as ob
@@ -227,12 +354,13 @@ def elas_leg(pkg, W, H, device, d_L, d_R, pitch, B, iters=4):
     return out
 
 
-def msa_leg(pkg, W, H, device, d_L, d_R):
+def msa_leg(pkg, device, d_L, d_R):
     """MSA dense stereo (SURVEY 8 row f-1, the reference's live frame::MB).  value: throughput of svo_msa_batch_dev over 64
     DISTINCT pairs resident in HBM (maps stay in HBM; the aggregation trees are built on host threads, 16 frames' worth
     at a time, while the previous chunk's level sweeps run) - the same definition as the elas leg.  Beside it: the latency
     of one svo_msa_solve with host buffers, its per-stage GPU times, the tracker with MSA depth, and the CPU restatement
     of the same algorithm on one host core."""
+    import numpy as np
     import torch
     ctx = pkg.Svo(W, H, device=device)
     g2c = lambda g: np.ascontiguousarray(np.repeat(g[:, :, None], 3, 2))
@@ -243,7 +371,8 @@ def msa_leg(pkg, W, H, device, d_L, d_R):
         G = ctx.msa_solve(L, R, 48, 1)
     dt = (time.perf_counter() - t0) / 3
     ctx.profile_enable(True); ctx.profile_reset(); ctx.msa_solve(L, R, 48, 1); ctx.profile_enable(False)
-    kern = {k: round(v[0], 3) for k, v in ctx.profile().items() if k.startswith("k_msa")}
+    prof = ctx.profile()
+    kern = {k: round(v[0], 3) for k, v in prof.items() if k.startswith("k_msa")}
     nb = min(64, d_L.shape[0])
     d_disp = torch.zeros((nb, H, W), dtype=torch.float32, device=d_L.device)
     torch.cuda.synchronize()
@@ -268,10 +397,22 @@ def msa_leg(pkg, W, H, device, d_L, d_R):
         trk.track_batch_dev(d_L.data_ptr(), d_R.data_ptr(), d_L.stride(1), nb, res.data_ptr()); trk.sync()
         fps = nb / (time.perf_counter() - t0)
     trk.close()
+    # roofline of the dominant GPU kernel: the tree aggregation (MSA::TreeDp, 3 aggregations per solve, each two sweeps over
+    # a P x 49 float cost volume: read cost, write costUp, read both + parents, write costA ~ 3 volumes read + 2 written)
+    P, D = W * H, 49
+    dom = max(kern, key=lambda k: kern[k]) if kern else None
+    algo = 3 * 5 * P * D * 4.0 if dom and "dp" in dom else 2 * P * D * 4.0
+    roof = None
+    if dom:
+        ach = algo / (kern[dom] * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": pmc_traffic(dom), "algorithmic_bytes_per_solve": algo,
+                "note": "one workgroup per disparity walks ~2000 barrier-separated tree levels: latency bound; the solve as a whole is "
+                        "bound by the host-side tree construction (see `note`)"}
     out = {"value": batch_rate, "unit": "stereo pairs/s", "pairs_per_call": nb, "batch_equals_single_call": batch_equals_single,
            "latency_ms_per_pair_host_buffers": dt * 1e3, "max_disparity": 48,
-           "tracker_frames_per_s_msa_depth_%d_per_call" % nb: fps,
-           "gpu_ms_per_pair": kern, "nonzero_fraction": float((G > 0).mean()), "host_cores": os.cpu_count(),
+           "tracker_frames_per_s_msa_depth_%d_per_call" % nb: fps, "roofline": roof,
+           "gpu_ms_per_pair": kern, "nonzero_fraction": float((G > 0).mean()), "host_cpus": host_cpus(),
            "note": "d = 48, scale = 1 as frame::MB calls it; gray pair as B = G = R colour images; throughput is bound by the "
                    "host-side tree construction (sequential Chu-Liu/Edmonds + region merging per image, ~0.1 s each, 32 builders side by side)"}
     try:
@@ -287,27 +428,243 @@ def msa_leg(pkg, W, H, device, d_L, d_R):
     return out
 
 
-def cpu_baseline(Lh, Rh, cam, workload, budget_s=15.0):
-    """The oracle (a single-threaded C port of the same path) timed on this box's host
-    cores over a bounded sample of the same workload."""
-    from oracle import binding as orc
-    orc.build()
-    n, t0 = 0, time.perf_counter()
-    trk = orc.Tracker(W, H, dict(fx=cam.fx, fy=cam.fy, cx=cam.cx, cy=cam.cy, bf=cam.bf)) \
-        if workload == "track" else None
-    poses = []
-    while n < len(Lh) and (time.perf_counter() - t0) < budget_s:
-        if trk is not None:
-            poses.append(trk.track(Lh[n], Rh[n])[0])
-        else:
-            orc.stereo_frame(Lh[n], Rh[n], cam.bf, cam.fx)
-        n += 1
+def frontend_leg(pkg, cam, dL, dR, n_frames, frame_bytes, dev, all_cores):
+    """BASELINE configs[1], batched: ORB on both images + sparse stereo, 384 pairs per step, every step on pairs the
+    GPU has not touched for thousands of frames (the sequence is far larger than the Infinity Cache)."""
+    import torch
+    B, steps = int(os.environ.get("SVO_BENCH_FE_B", "384")), 16
+    fe = pkg.Svo(W, H, device=dev.index or 0, max_kp=500, max_batch=B)
+    for kv in filter(None, os.environ.get("SVO_BENCH_FE_OPTIONS", "").split(",")):   # experiments: "frontend_overlap=4"
+        k, v = kv.split("=")
+        fe.set_option(k, int(v))
+    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_depth = torch.zeros((B, 500), dtype=torch.float32, device=dev)
+
+    def run(s):
+        off = (s * B) % (n_frames - B + 1)
+        fe.frontend_batch_dev(dL.data_ptr() + off * frame_bytes, dR.data_ptr() + off * frame_bytes, PITCH, B, cam,
+                              d_nL=d_n.data_ptr(), d_depth=d_depth.data_ptr())
+    for s in range(3):
+        run(s)
+    fe.sync()
+    # throughput: the library's normal mode (slices of a batch side by side on their own streams) ...
+    t0 = time.perf_counter()
+    for s in range(3, 3 + steps):
+        run(s)
+    fe.sync()
     dt = time.perf_counter() - t0
-    what = "full tracking loop" if workload == "track" else "ORB on L and R + sparse stereo"
-    out = {"value": n / dt, "unit": "stereo pairs/s", "cores": 1, "kind": "port",
-           "sample": "first %d pairs of the benchmark frames (%s), %.1f s, oracle/libsvo_oracle.so "
-                     "single thread; host has %d cores" % (n, what, dt, os.cpu_count() or 0)}
-    return out, poses
+    # ... per-kernel times: a second pass over other pairs with the timers on - one chain on one stream, each kernel alone
+    fe.profile_reset(); fe.profile_enable(True)
+    t0 = time.perf_counter()
+    for s in range(3 + steps, 3 + 2 * steps):
+        run(s)
+    fe.sync()
+    dt_single = time.perf_counter() - t0
+    fe.profile_enable(False)
+    prof = fe.profile()
+    fe.close()
+    kern = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}
+    dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
+    algo = KERNEL_BYTES_PER_IMAGE.get(dom, 0) * 2 * B if dom in KERNEL_BYTES_PER_IMAGE else KERNEL_BYTES_PER_PAIR.get(dom, 0) * B
+    ach = algo / (prof[dom][0] / max(prof[dom][1], 1) * 1e-3) / 1e9
+    out = {"value": B * steps / dt, "unit": "stereo pairs/s", "pairs_per_step": B, "steps": steps,
+           "distinct_input_bytes_read": int(2 * B * steps * frame_bytes), "kernel_avg_ms": kern,
+           "value_one_stream_with_timers": B * steps / dt_single,
+           "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B), "valu": pmc_valu(dom),
+                        "algorithmic_bytes_per_launch": algo,
+                        "pipeline_frac": ALGO_BYTES_PER_PAIR * (B * steps / dt) / 1e9 / HBM_PEAK_GBS}}
+    if all_cores is not None:
+        Lh = dL[:64, :, :W].cpu().numpy(); Rh = dR[:64, :, :W].cpu().numpy()
+        out["cpu_baseline_all_cores"] = all_cores(Lh, Rh, cam)
+    return out
+
+
+def multi_sequence_leg(pkg, cam, dL, dR, frame_bytes, rec, dev, single):
+    """S staggered sequences advanced together (one workgroup per sequence in every tail kernel); sequence 0 must
+    reproduce the single chain's records."""
+    import torch
+    S, msteps = 64, 48
+    ms = pkg.Svo(W, H, device=dev.index or 0, max_kp=500, max_batch=S)
+    ms.set_option("multi_pipeline", int(os.environ.get("SVO_BENCH_MULTI_PIPELINE", "1")))   # front end of step t + 1 beside the tail of step t
+    mres = torch.zeros((msteps * S, rec), dtype=torch.uint8, device=dev)
+    ms.track_multi_reset(S, cam)
+    for t in range(2):
+        ms.track_multi_step_dev(dL.data_ptr() + t * frame_bytes, dR.data_ptr() + t * frame_bytes, PITCH, S,
+                                mres.data_ptr() + t * S * rec)
+    ms.track_multi_reset(S, cam)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for t in range(msteps):
+        ms.track_multi_step_dev(dL.data_ptr() + t * frame_bytes, dR.data_ptr() + t * frame_bytes, PITCH, S,
+                                mres.data_ptr() + t * S * rec)
+    ms.sync()
+    mdt = time.perf_counter() - t1
+    m = mres.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(msteps, S)
+    ms.close()
+    same = all(m[t, 0].tobytes() == single[t].tobytes() for t in range(msteps))
+    return {"value": msteps * S / mdt, "unit": "stereo frames/s", "sequences": S, "steps": msteps,
+            "sequence0_equals_single_chain": bool(same),
+            "pipelined_steps": bool(int(os.environ.get("SVO_BENCH_MULTI_PIPELINE", "1"))),
+            "note": "SURVEY 8e's 'G independent sequences' variant on ONE GPU: full Tracking::Track per frame; with "
+                    "pipelined_steps the stateless front end of step t + 1 runs beside the tail of step t (multi_pipeline option)"}
+
+
+def sharded_run(pkg, cam, dL, dR, n_frames, G, devices, rec, chunk=512, reference=None):
+    """BASELINE configs[3]: ONE sequence, pair k's front end on context k mod G (context g on devices[g]), the ordered tail
+    on context 0 (svo_track_sharded_dev), `chunk` frames per call.  Returns the leg's dict; `reference`: the single-context
+    records the result must equal byte for byte."""
+    import torch
+    per = (chunk + G - 1) // G
+    dev0 = torch.device("cuda", devices[0])
+    ctxs = [pkg.Svo(W, H, device=devices[g], max_kp=500, max_batch=per) for g in range(G)]
+    # pair k resident where its front end runs: context g gets the pairs k = g (mod G) of every chunk, packed in order
+    chunks = [(c0, min(chunk, n_frames - c0)) for c0 in range(0, n_frames, chunk)]
+    Ls, Rs = [], []
+    for g in range(G):
+        dg = torch.device("cuda", devices[g])
+        idx = torch.cat([torch.arange(c0 + g, c0 + c, G) for c0, c in chunks if c > g])
+        Ls.append(dL[idx.to(dL.device)].to(dg)); Rs.append(dR[idx.to(dR.device)].to(dg))
+    res = torch.zeros((n_frames, rec), dtype=torch.uint8, device=dev0)
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    fb = H * PITCH
+
+    def run_all():
+        ctxs[0].track_reset(cam)
+        off = [0] * G
+        for c0, c in chunks:
+            pl = [Ls[g].data_ptr() + off[g] * fb for g in range(G)]
+            pr = [Rs[g].data_ptr() + off[g] * fb for g in range(G)]
+            pkg.Svo.track_sharded_dev(ctxs, pl, pr, PITCH, c, res.data_ptr() + c0 * rec)
+            for g in range(G):
+                off[g] += (c - g + G - 1) // G
+        ctxs[0].sync()
+    run_all()                                  # warm-up (allocations, peer mappings)
+    t0 = time.perf_counter()
+    run_all()
+    dt = time.perf_counter() - t0
+    got = res.cpu().numpy()
+    for c in ctxs:
+        c.close()
+    out = {"value": n_frames / dt, "unit": "stereo frames/s", "contexts": G, "devices": sorted(set(devices)),
+           "frames": int(n_frames), "frames_per_call": chunk,
+           "note": "ONE sequence: the stateless front end shards by pair (pair k -> context k mod G), the strict chain of "
+                   "src/Tracking.cc:231-250 stays on context 0 and bounds the rate at the tail's per-frame latency whatever G is "
+                   "(the front end is ~7 us per pair, the tail ~65 us per frame): expect a FLAT curve over G - replicas "
+                   "(n_gpus independent sequences) are what scales"}
+    if reference is not None:
+        out["records_identical_to_single_context"] = bool(got.tobytes() == reference.tobytes())
+    return out
+
+
+def semantic_elas_leg(pkg, cam, dL, dR, dev, rec, n=256):
+    """BASELINE configs[4] AS A WHOLE: offline detection boxes (semantic gating: creation gates, brute-force matches ->
+    8-point F -> epipolar veto, all on the device) + dense ELAS depth (svo_elas_batch_dev -> disp2Depth -> per-keypoint
+    lookups) + the full tracking tail, through svo_track_batch_dev on frames resident in HBM."""
+    import numpy as np
+    import torch
+    n = min(n, dL.shape[0])
+    svo = pkg.Svo(W, H, device=dev.index or 0, max_kp=500, max_batch=n)
+    svo.set_option("depth_source", 1)
+    bx, keep = boxes_hbm(pkg, n, dev)
+    res = torch.zeros((n, rec), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    fps = 0.0
+    for _ in range(2):
+        svo.track_reset(cam)
+        t0 = time.perf_counter()
+        svo.track_batch_dev(dL.data_ptr(), dR.data_ptr(), PITCH, n, res.data_ptr(), boxes=bx); svo.sync()
+        fps = n / (time.perf_counter() - t0)
+    r = res.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(-1)
+    # per-kernel times of the same call, one more (untimed) pass with the timers on
+    svo.profile_enable(True); svo.profile_reset()
+    svo.track_reset(cam)
+    svo.track_batch_dev(dL.data_ptr(), dR.data_ptr(), PITCH, n, res.data_ptr(), boxes=bx); svo.sync()
+    svo.profile_enable(False)
+    prof = svo.profile()
+    svo.close()
+    kern = {k: v[0] * 1e3 / n for k, v in prof.items() if k.startswith("k_") and v[1] > 0}
+    P = W * H
+    algo = {"k_elas_desc": 34 * P, "k_elas_match": 48 * P, "k_elas_raster": 8 * P, "k_cc_segments": 28 * P, "k_elas_gap": 16 * P,
+            "k_elas_support": 32 * P, "k_elas_lr": 16 * P, "k_elas_mean": 16 * P}
+    dom = max((k for k in kern if k in algo), key=lambda k: kern[k], default=None)
+    roof = None
+    if dom:
+        ach = algo[dom] / (kern[dom] * 1e-6) / 1e9
+        roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": pmc_traffic(dom, 1), "algorithmic_bytes_per_frame": algo[dom],
+                "pipeline_frac": (198.0 * P + ALGO_BYTES_PER_PAIR / 2) * fps / 1e9 / HBM_PEAK_GBS,
+                "note": "the dense maps dominate: ELAS's compulsory 198 P bytes per pair + ORB on the left image; the leg is bound by "
+                        "ELAS's host stages (support-point filter, Delaunay) under the CPU quota, the gating kernels add "
+                        "k_tg_bf + k_tg_fmat per frame (see kernel_us_per_frame)"}
+    out = {"value": fps, "unit": "stereo frames/s", "frames": int(n), "boxes_per_frame": 2,
+           "mean_lm_edges": float(r["n_lm_edges"][1:].mean()), "mean_new_mappoints": float(r["n_new_mappoints"].mean()),
+           "kernel_us_per_frame": {k: round(v, 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])[:14]},
+           "roofline": roof, "host_cpus": host_cpus(),
+           "workload": "BASELINE configs[4]: synth-kitti00 frames with two moving offline boxes per frame (main.cpp:82-95 format), "
+                       "depth_source = 1 (dense ELAS map -> disp2Depth -> per-keypoint lookups), full Tracking::Track tail"}
+    try:
+        from oracle import binding as ob
+        ob.build()
+        if ob.ref_elas_lib() is not None:
+            m = min(10, n)
+            Lh = dL[:m, :, :W].cpu().numpy(); Rh = dR[:m, :, :W].cpu().numpy()
+            trk = ob.Tracker(W, H, dict(fx=cam.fx, fy=cam.fy, cx=cam.cx, cy=cam.cy, bf=cam.bf))
+            t0 = time.perf_counter()
+            same = True
+            for k in range(m):
+                dmap = ob.ref_elas(Lh[k], Rh[k])[0]
+                rr, _ = trk.track(Lh[k], Rh[k], boxes=np.array(moving_boxes(k), np.int32), dense=dmap)
+                same = same and all(int(rr[f]) == int(r[k][f]) for f in ("n_kp", "n_stereo", "n_match_pass1", "n_match_pass2",
+                                                                          "n_lm_edges", "n_new_mappoints", "n_local_map"))
+            dt = time.perf_counter() - t0
+            trk.close()
+            out["cpu_baseline"] = {"value": m / dt, "unit": "stereo frames/s", "cores": 1, "kind": "reference+port",
+                                   "sample": "first %d frames: the reference's own compiled libelas (oracle/_ref) for the dense map + the "
+                                             "oracle tracker with the same boxes, single thread, %.1f s" % (m, dt),
+                                   "counters_identical_to_gpu": bool(same)}
+    except Exception as e:  # noqa: BLE001
+        out["cpu_baseline_error"] = str(e)
+    return out
+
+
+def tail_chain_from_stamps(dbg):
+    """The ordered tail's critical path from the in-kernel wall-clock stamps (s_memrealtime, 10 ns ticks) the tail kernels
+    leave in every frame's work record: no profiler, no event pairs in the stream."""
+    import numpy as np
+    rt = dbg["rt"].astype(np.int64)
+    ok = (rt[:, 3] > rt[:, 2]) & (rt[:, 1] > rt[:, 0])
+    rt = rt[ok]
+    if len(rt) < 4:
+        return None
+    pose_busy = (rt[:, 3] - rt[:, 2]) * 0.01                       # us: first RANSAC workgroup start -> end of the pose kernel
+    resolve = (rt[:, 1] - rt[:, 0]) * 0.01
+    period = np.diff(rt[:, 3]) * 0.01                              # us between consecutive frames' pose-kernel ends
+    period = period[(period > 0) & (period < 5000)]
+    return {"frames_sampled": int(len(rt)), "pose_chain_busy_us": {"mean": float(pose_busy.mean()), "median": float(np.median(pose_busy))},
+            "k_ti_resolve_us": {"mean": float(resolve.mean()), "median": float(np.median(resolve)), "max": float(resolve.max())},
+            "frame_period_us": {"mean": float(period.mean()), "median": float(np.median(period))},
+            "source": "in-kernel s_memrealtime stamps of the timed region's last step (svo_debug_track_frames)"}
+
+
+# ------------------------------------------------------------------------------------------------ main
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as a CHILD process group before this process makes
+    any GPU call (it never initialises HIP), relay rank 0's JSON line, exit with the child's code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in p.stdout.splitlines():
+        if line.startswith("{"):
+            print(line)
+    sys.stdout.flush()
+    sys.exit(p.returncode)
 
 
 def main():
@@ -320,22 +677,39 @@ def main():
     ap.add_argument("--batch", type=int, default=0,
                     help="pairs per step per GPU: track default frames // (warmup + steps), frontend default 128")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--no-legs", action="store_true", help="only the main workload (no frontend / multi_sequence / elas / msa legs)")
-    ap.add_argument("--no-elas-leg", action="store_true", help="skip the elas and msa legs")
+    ap.add_argument("--no-profile", action="store_true", help="skip the untimed per-kernel profile pass")
+    ap.add_argument("--no-legs", action="store_true", help="only the main workload (no frontend / multi_sequence / sharded / semantic_elas / elas / msa legs)")
+    ap.add_argument("--no-elas-leg", action="store_true", help="skip the semantic_elas, elas and msa legs")
     ap.add_argument("--no-track-leg", action="store_true", help="(kept for scripts) same as --no-legs for the frontend workload")
+    ap.add_argument("--no-shard-leg", action="store_true", help="N > 1: skip rank 0's svo_track_sharded_dev run across the N GPUs")
+    ap.add_argument("--shard", action="store_true",
+                    help="track workload: ONE sequence over --gpus G contexts in ONE process (svo_track_sharded_dev, BASELINE configs[3])")
     ap.add_argument("--depth-source", type=int, default=0, choices=[0, 1, 2],
                     help="track workload: 0 sparse epipolar stereo (north star), 1 dense ELAS map, 2 dense MSA map")
+    ap.add_argument("--boxes", action="store_true", help="track workload: two moving offline detection boxes per frame (semantic gating)")
     ap.add_argument("--sequences", type=int, default=1,
                     help="track workload: S concurrent sequences per GPU (svo_track_multi_step_dev), one frame of each per step")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (single-GPU dry runs)")
-    ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (dry run of the N>1 path on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks / contexts use cuda:0 (dry run of the N>1 path on one GPU)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and not args.shard and env_world is None:
+        spawn_ranks(args)                              # does not return
+    if env_world is not None and int(env_world) != args.gpus and not args.shard:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %s ranks (WORLD_SIZE): refusing to print a line that "
+                         "misstates n_gpus" % (args.gpus, env_world))
 
+    import numpy as np
+    import torch
+    import svo_loader
     pkg = svo_loader.load()
     synth = importlib.import_module("stereo_semantic_vo_amd.synth")
     shard = importlib.import_module("stereo_semantic_vo_amd.shard")
     rank, world, local = shard.env_rank_world()
+    if args.shard:
+        rank, world, local = 0, 1, 0
     if args.share_gpu:
         local = 0
     if not torch.cuda.is_available():
@@ -382,16 +756,46 @@ def main():
     render_s = time.perf_counter() - t_r
     frame_bytes = H * PITCH
     rec = pkg.TRACK_DTYPE.itemsize
+
+    # ---------------------------------------------------------------- --shard: configs[3] in one process
+    if args.shard:
+        G = args.gpus
+        ndev = torch.cuda.device_count()
+        devices = [g if (g < ndev and not args.share_gpu) else 0 for g in range(G)]
+        single = pkg.Svo(W, H, device=0, max_kp=500, max_batch=512)
+        single.track_reset(cam)
+        ref = torch.zeros((n_frames, rec), dtype=torch.uint8, device=dev)
+        for c0 in range(0, n_frames, 512):
+            c = min(512, n_frames - c0)
+            single.track_batch_dev(dL.data_ptr() + c0 * frame_bytes, dR.data_ptr() + c0 * frame_bytes, PITCH, c, ref.data_ptr() + c0 * rec)
+        single.sync(); single.close()
+        leg = sharded_run(pkg, cam, dL, dR, n_frames, G, devices, rec, reference=ref.cpu().numpy())
+        res = ref.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(-1)
+        rmse, last = ate_rmse(res, T_gt.numpy())
+        out = {"metric": "stereo frames/sec on KITTI 00 (full Tracking::Track chain)", "value": leg["value"], "unit": "stereo frames/s",
+               "n_gpus": len(set(devices)), "steps": 1, "warmup": 1, "ms_per_step": 1e3 * n_frames / leg["value"], "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[3]: ONE synth-kitti00 sequence of %d pairs, pair k's front end on context k mod %d, "
+                                      "ordered tail on context 0 (svo_track_sharded_dev), no collective" % (n_frames, G),
+                          "contexts": G, "devices": devices, "frames_tracked": int(n_frames), "ate_rmse_m_vs_ground_truth": rmse,
+                          "parallelism": "front end sharded by pair over %d contexts, tail on one" % G},
+               "sharded": leg}
+        print(json.dumps(out))
+        return
+
     svo = pkg.Svo(W, H, device=local, max_kp=500, max_batch=B + extra)
     for kv in filter(None, os.environ.get("SVO_BENCH_OPTIONS", "").split(",")):   # experiments: "track_group=8,..."
         k, v = kv.split("=")
         svo.set_option(k, int(v))
+    bx = keep_bx = None
     if multi:
         d_res = torch.zeros((nsteps * B, rec), dtype=torch.uint8, device=dev)
         svo.track_multi_reset(B, cam)
     elif track:
         if args.depth_source:
             svo.set_option("depth_source", args.depth_source)
+        if args.boxes:
+            bx, keep_bx = boxes_hbm(pkg, n_frames, dev)
         d_res = torch.zeros((n_frames, rec), dtype=torch.uint8, device=dev)
         svo.track_reset(cam)
     else:
@@ -399,18 +803,24 @@ def main():
         d_depth = torch.zeros((B, 500), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
 
-    def step(s):
+    def step_boxes(off):
+        if bx is None:
+            return None
+        return pkg.boxes_dev(keep_bx[0].data_ptr() + off * 2 * 16, keep_bx[1].data_ptr() + off * 4, 2)
+
+    def step(s, ctx=None, out=None):
+        ctx = ctx or svo
         if multi:
-            svo.track_multi_step_dev(dL.data_ptr() + s * frame_bytes, dR.data_ptr() + s * frame_bytes, PITCH, B,
+            ctx.track_multi_step_dev(dL.data_ptr() + s * frame_bytes, dR.data_ptr() + s * frame_bytes, PITCH, B,
                                      d_res.data_ptr() + s * B * rec)
         elif track:
             off = s * B + (extra if s > 0 else 0)
             nb = B + (extra if s == 0 else 0)
-            svo.track_batch_dev(dL.data_ptr() + off * frame_bytes, dR.data_ptr() + off * frame_bytes,
-                                PITCH, nb, d_res.data_ptr() + off * rec)
+            ctx.track_batch_dev(dL.data_ptr() + off * frame_bytes, dR.data_ptr() + off * frame_bytes,
+                                PITCH, nb, (out if out is not None else d_res).data_ptr() + off * rec, boxes=step_boxes(off))
         else:
             off = (s * B) % (n_frames - B + 1)           # every step reads B pairs it has not touched for a long time
-            svo.frontend_batch_dev(dL.data_ptr() + off * frame_bytes, dR.data_ptr() + off * frame_bytes, PITCH, B, cam,
+            ctx.frontend_batch_dev(dL.data_ptr() + off * frame_bytes, dR.data_ptr() + off * frame_bytes, PITCH, B, cam,
                                    d_nL=d_n.data_ptr(), d_depth=d_depth.data_ptr())
 
     def fence():
@@ -422,25 +832,47 @@ def main():
     for s in range(args.warmup):
         step(s)
     fence()
-    if not args.no_profile:
-        svo.profile_reset()
-        svo.profile_enable(True)
+    # the timed region: the product's default schedule, no profiling hooks
     t0 = time.perf_counter()
     for s in range(args.warmup, nsteps):
         step(s)
     fence()
     dt = time.perf_counter() - t0
     dt = shard.max_over_ranks(dt, dist, dev if args.dist_backend == "nccl" else "cpu")
+    # in-kernel wall-clock stamps of the last timed step's frames (always written, free)
+    chain = None
+    if track and not multi and rank == 0:
+        try:
+            chain = tail_chain_from_stamps(svo.debug_track_frames(0, B))
+        except Exception as e:  # noqa: BLE001
+            chain = {"error": repr(e)}
+    # per-kernel HIP-event times: a separate, UNTIMED pass with the timers on (they change the schedule: one stream for the
+    # front end, an event pair around every 32nd frame's tail kernels) over the first frames of the sequence again
     prof = {}
-    if not args.no_profile:
-        svo.profile_enable(False)
-        prof = svo.profile()
+    if not args.no_profile and rank == 0:
+        psvo = pkg.Svo(W, H, device=local, max_kp=500, max_batch=B + extra)
+        scratch = torch.zeros_like(d_res) if track else None
+        if multi:
+            psvo.track_multi_reset(B, cam)
+        elif track:
+            if args.depth_source:
+                psvo.set_option("depth_source", args.depth_source)
+            psvo.track_reset(cam)
+        psvo.profile_reset(); psvo.profile_enable(True)
+        for s in range(min(nsteps, 3)):
+            step(s, ctx=psvo, out=scratch)
+        psvo.sync()
+        psvo.profile_enable(False)
+        prof = psvo.profile()
+        psvo.close()
+        del scratch
 
     if rank == 0:
         pairs = world * B * args.steps
         cfg = {"pairs_per_step_per_gpu": B, "resident_pairs_per_gpu": int(n_frames),
                "resident_input_bytes_per_gpu": int(2 * n_frames * frame_bytes), "render_seconds": round(render_s, 1)}
         res = None
+        oracle_run = None
         if track:
             res = d_res.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(-1)
             if multi:                                    # accuracy figures from sequence 0 (starts at frame 0)
@@ -449,12 +881,13 @@ def main():
             rmse, last = ate_rmse(res, T_gt.numpy()[:len(res)])
             depth_names = {0: "sparse epipolar stereo", 1: "dense ELAS map (svo_elas_batch_dev) -> disp2Depth -> per-keypoint lookups",
                            2: "dense MSA map (svo_msa_batch_dev) -> disp2Depth -> per-keypoint lookups"}
-            cfg.update({"depth_source": depth_names[args.depth_source],
+            cfg.update({"depth_source": depth_names[args.depth_source], "detection_boxes": "two moving boxes per frame" if args.boxes else "none",
                         "workload": "BASELINE configs[2]: synth-kitti00 sequence of %d distinct 1241x376 stereo pairs, full "
                                     "Tracking::Track loop per frame (ORB on L and R, sparse stereo, matching passes 1+2, "
                                     "PnP-RANSAC, pose-only LM, map-point lifecycle); " % len(res) +
                                     ("%d concurrent staggered sequences per GPU, one frame of each per step" % B if multi
                                      else "ONE sequence per GPU in strict frame order (replicas across GPUs)"),
+                        "parallelism": "replicas: %d independent sequences, one per GPU" % world if world > 1 else "one GPU",
                         "frames_tracked": int(len(res)), "ate_rmse_m_vs_ground_truth": rmse,
                         "final_position_error_m": last, "path_length_m": float(len(res) - 1),
                         "mean_lm_edges": float(res["n_lm_edges"][1:].mean()),
@@ -462,6 +895,10 @@ def main():
                         "mean_rounds_pass1_pass2": [float((res["reserved"][1:, 0] >> 16).mean()), float((res["reserved"][1:, 1] >> 16).mean())],
                         "mean_local_map": float(res["n_local_map"][1:].mean()),
                         "tracker_capacity_flag": int(svo.track_overflowed())})
+            if world == 1 and not multi and not args.no_cpu_baseline and args.depth_source == 0 and not args.boxes:
+                # the oracle's tail over ALL tracked frames, on a host thread while the legs below run
+                oracle_run = OracleTailRun(cam, *frontend_outputs(pkg, cam, dL, dR, len(res), dev))
+                oracle_run.start()
         else:
             n_kp = d_n.cpu().numpy()
             cfg.update({"workload": "BASELINE configs[1], batched: synth-kitti00 stereo pairs 1241x376, ORB pyramid (8 levels, 500 kp) "
@@ -478,21 +915,29 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "kitti00" if os.environ.get("KITTI_ROOT") else "synthetic", "config": cfg,
         }
+        if chain:
+            out["tail_critical_path"] = chain
         if prof:
             kern = {k: {"avg_ms": v[0] / max(v[1], 1), "launches": v[1], "total_ms": v[0]} for k, v in prof.items()}
-            # the kernel the timed region spends most time in.  The tail kernels are timed on every 32nd frame only (an event
-            # pair holds the chain up): their totals are avg x launches actually made = one per frame and sequence step
-            launches_made = {k: (B * args.steps if track and not multi and k.startswith(("k_ti_", "k_tp_")) else v[1]) for k, v in prof.items()}
+            # time per frame of the timed region each kernel accounts for: the tail kernels run once per frame (timed on every
+            # 32nd frame of the profile pass only: an event pair holds the chain up), the front-end kernels once per sub-batch
+            frames_prof = float(sum((B + (extra if s == 0 else 0)) for s in range(min(nsteps, 3)))) if track and not multi else float(B * min(nsteps, 3))
+            per_frame = {k: (kern[k]["avg_ms"] if track and not multi and k.startswith(("k_ti_", "k_tp_", "k_tg_")) else kern[k]["total_ms"] / frames_prof)
+                         for k in kern}
             for k in kern:
-                kern[k]["launches_in_timed_region"] = launches_made[k]
-                kern[k]["total_ms_estimated"] = kern[k]["avg_ms"] * launches_made[k]
-            dom = max(kern.items(), key=lambda kv: kv[1]["total_ms_estimated"])[0]
-            dom_s = prof[dom][0] / max(prof[dom][1], 1) * 1e-3
+                kern[k]["ms_per_frame"] = per_frame[k]
+            dom = max(per_frame.items(), key=lambda kv: kv[1])[0]
+            dom_s = kern[dom]["avg_ms"] * 1e-3
+            timing = "HIP events around the kernel's launches in an untimed profile pass"
+            if chain and "k_ti_resolve_us" in chain and dom == "k_ti_resolve":
+                dom_s = chain["k_ti_resolve_us"]["mean"] * 1e-6
+                timing = "in-kernel wall-clock stamps over the timed region's last step (event pairs inflate a ~40 us kernel)"
             units = "images"
+            ppl = min(B, 32) if track else B     # pairs one front-end launch covers (svo_track_batch_dev: sub-batches of 32)
             if dom in KERNEL_BYTES_PER_IMAGE:
-                algo = KERNEL_BYTES_PER_IMAGE[dom] * 2 * B
+                algo = KERNEL_BYTES_PER_IMAGE[dom] * 2 * ppl
             elif dom in KERNEL_BYTES_PER_PAIR:
-                algo = KERNEL_BYTES_PER_PAIR[dom] * B
+                algo = KERNEL_BYTES_PER_PAIR[dom] * ppl
             else:
                 units = "frames"
                 mp = float(res["n_local_map"][1:].mean()) + 500.0 if res is not None else 0.0
@@ -503,122 +948,62 @@ def main():
                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                "traffic": pmc_traffic(dom),
                                "algorithmic_bytes_per_launch": algo, "launch_covers": "%s of one launch" % units,
-                               "share_of_timed_kernel_time": kern[dom]["total_ms_estimated"] / max(sum(v["total_ms_estimated"] for v in kern.values()), 1e-9),
+                               "kernel_seconds_per_launch": dom_s, "timing": timing,
+                               "share_of_kernel_time_per_frame": per_frame[dom] / max(sum(per_frame.values()), 1e-12),
                                "valu": pmc_valu(dom),
                                "pipeline_frac": ALGO_BYTES_PER_PAIR * (pairs / dt / world) / 1e9 / HBM_PEAK_GBS,
-                               "note": "the ordered tail is a dependent chain of single-workgroup kernels: latency-bound, far "
-                                       "from the HBM roof by construction (DESIGN.md section 5)" if units == "frames" else None}
+                               "note": "the ordered tail is two dependent chains of small kernels (index chain: k_ti_lists -> k_ti_resolve; "
+                                       "pose chain: RANSAC samples -> LM): latency-bound, far from the HBM roof by construction "
+                                       "(DESIGN.md section 5); `tail_critical_path` has the chains' in-kernel times" if units == "frames" else None}
             out["kernels"] = kern
         if world == 1 and not args.no_cpu_baseline:
             ns = min(n_frames, 64)
             Lh = dL[:ns, :, :W].cpu().numpy()
             Rh = dR[:ns, :, :W].cpu().numpy()
-            out["cpu_baseline"], cpu_poses = cpu_baseline(Lh, Rh, cam, args.workload)
-            if track and not multi and cpu_poses:
-                # ATE of the GPU trajectory against the CPU port's on the same frames (BASELINE metric: "ATE vs CPU reference")
-                k = len(cpu_poses)
-                ca = np.array([np.linalg.inv(res[i]["Tcw"].reshape(4, 4).astype(np.float64))[:3, 3] for i in range(k)])
-                cb = np.array([np.linalg.inv(cpu_poses[i]["Tcw"].reshape(4, 4).astype(np.float64))[:3, 3] for i in range(k)])
-                d = np.linalg.norm(ca - cb, axis=1)
-                out["ate_vs_cpu_m"] = {"rmse": float(np.sqrt(np.mean(d * d))), "max": float(d.max()), "frames": int(k)}
-                out["cpu_baseline"]["counters_identical_to_gpu"] = bool(all(
-                    all(int(res[i][f]) == int(cpu_poses[i][f]) for f in ("n_kp", "n_stereo", "n_match_pass1", "n_match_pass2",
-                                                                       "n_lm_edges", "n_new_mappoints", "n_local_map"))
-                    for i in range(k)))
-        legs = world == 1 and not args.no_legs and not multi and args.depth_source == 0
+            out["cpu_baseline"] = cpu_baseline(Lh, Rh, cam, args.workload)
+        legs = world == 1 and not args.no_legs and not multi and args.depth_source == 0 and not args.boxes
         if legs and track:
-            svo.profile_enable(False)
-            out["frontend"] = frontend_leg(pkg, svo, cam, dL, dR, n_frames, frame_bytes, dev,
+            out["frontend"] = frontend_leg(pkg, cam, dL, dR, n_frames, frame_bytes, dev,
                                            None if args.no_cpu_baseline else cpu_baseline_all_cores)
-            out["multi_sequence"] = multi_sequence_leg(pkg, svo, cam, dL, dR, frame_bytes, rec, dev, res)
+            out["multi_sequence"] = multi_sequence_leg(pkg, cam, dL, dR, frame_bytes, rec, dev, res)
+            try:
+                ns = min(n_frames, 1024)
+                out["sharded"] = sharded_run(pkg, cam, dL, dR, ns, 2, [local, local], rec, reference=d_res[:ns].cpu().numpy())
+                out["sharded"]["note"] = "two contexts on this ONE GPU (the driver's multi-GPU run adds the cross-device measurement); " + out["sharded"]["note"]
+            except Exception as e:  # noqa: BLE001
+                out["sharded"] = {"error": repr(e)}
+        if oracle_run is not None:
+            oracle_run.join()
+            rep = oracle_run.report(res)
+            out["cpu_baseline"]["all_frames_tail"] = rep
+            out["cpu_baseline"]["counters_identical_to_gpu"] = rep.get("counters_identical_to_gpu")
+            if "ate_vs_cpu_m" in rep:
+                out["ate_vs_cpu_m"] = rep["ate_vs_cpu_m"]
         if legs and not args.no_elas_leg:
-            out["elas"] = elas_leg(pkg, W, H, dev.index or 0, dL, dR, PITCH, min(512, int(n_frames)), iters=2)
-            out["msa"] = msa_leg(pkg, W, H, dev.index or 0, dL, dR)
+            if track:
+                try:
+                    out["semantic_elas"] = semantic_elas_leg(pkg, cam, dL, dR, dev, rec)
+                except Exception as e:  # noqa: BLE001
+                    out["semantic_elas"] = {"error": repr(e)}
+            out["elas"] = elas_leg(pkg, dev.index or 0, dL, dR, PITCH, min(512, int(n_frames)), iters=2)
+            out["msa"] = msa_leg(pkg, dev.index or 0, dL, dR)
+    # N > 1: after the replicas' timed region rank 0 alone drives ONE sequence over all N GPUs (BASELINE configs[3]);
+    # the other ranks wait at the barrier below
+    if world > 1 and rank == 0 and track and not multi and not args.no_shard_leg:
+        try:
+            ndev = torch.cuda.device_count()
+            devices = [g if (g < ndev and not args.share_gpu) else local for g in range(world)]
+            ns = min(n_frames, 2048)
+            out["sharded"] = sharded_run(pkg, cam, dL, dR, ns, world, devices, rec, reference=d_res[:ns].cpu().numpy())
+        except Exception as e:  # noqa: BLE001
+            out["sharded"] = {"error": repr(e)}
+    if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     svo.close()
-
-
-def frontend_leg(pkg, svo, cam, dL, dR, n_frames, frame_bytes, dev, all_cores):
-    """BASELINE configs[1], batched: ORB on both images + sparse stereo, 384 pairs per step, every step on pairs the
-    GPU has not touched for thousands of frames (the sequence is far larger than the Infinity Cache)."""
-    B, steps = int(os.environ.get("SVO_BENCH_FE_B", "384")), 16
-    fe = pkg.Svo(W, H, device=dev.index or 0, max_kp=500, max_batch=B)
-    for kv in filter(None, os.environ.get("SVO_BENCH_FE_OPTIONS", "").split(",")):   # experiments: "frontend_overlap=4"
-        k, v = kv.split("=")
-        fe.set_option(k, int(v))
-    d_n = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_depth = torch.zeros((B, 500), dtype=torch.float32, device=dev)
-
-    def run(s):
-        off = (s * B) % (n_frames - B + 1)
-        fe.frontend_batch_dev(dL.data_ptr() + off * frame_bytes, dR.data_ptr() + off * frame_bytes, PITCH, B, cam,
-                              d_nL=d_n.data_ptr(), d_depth=d_depth.data_ptr())
-    for s in range(3):
-        run(s)
-    fe.sync()
-    # throughput: the library's normal mode (the two halves of a batch side by side on two streams) ...
-    t0 = time.perf_counter()
-    for s in range(3, 3 + steps):
-        run(s)
-    fe.sync()
-    dt = time.perf_counter() - t0
-    # ... per-kernel times: a second pass over other pairs with the timers on - one chain on one stream, each kernel alone
-    fe.profile_reset(); fe.profile_enable(True)
-    t0 = time.perf_counter()
-    for s in range(3 + steps, 3 + 2 * steps):
-        run(s)
-    fe.sync()
-    dt_single = time.perf_counter() - t0
-    fe.profile_enable(False)
-    prof = fe.profile()
-    fe.close()
-    kern = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}
-    dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
-    algo = KERNEL_BYTES_PER_IMAGE.get(dom, 0) * 2 * B if dom in KERNEL_BYTES_PER_IMAGE else KERNEL_BYTES_PER_PAIR.get(dom, 0) * B
-    ach = algo / (prof[dom][0] / max(prof[dom][1], 1) * 1e-3) / 1e9
-    out = {"value": B * steps / dt, "unit": "stereo pairs/s", "pairs_per_step": B, "steps": steps,
-           "distinct_input_bytes_read": int(2 * B * steps * frame_bytes), "kernel_avg_ms": kern,
-           "value_one_stream_with_timers": B * steps / dt_single,
-           "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B), "valu": pmc_valu(dom),
-                        "algorithmic_bytes_per_launch": algo,
-                        "pipeline_frac": ALGO_BYTES_PER_PAIR * (B * steps / dt) / 1e9 / HBM_PEAK_GBS}}
-    if all_cores is not None:
-        Lh = dL[:64, :, :W].cpu().numpy(); Rh = dR[:64, :, :W].cpu().numpy()
-        out["cpu_baseline_all_cores"] = all_cores(Lh, Rh, cam)
-    return out
-
-
-def multi_sequence_leg(pkg, svo, cam, dL, dR, frame_bytes, rec, dev, single):
-    """S staggered sequences advanced together (one workgroup per sequence in every tail kernel); sequence 0 must
-    reproduce the single chain's records."""
-    S, msteps = 64, 48
-    ms = pkg.Svo(W, H, device=dev.index or 0, max_kp=500, max_batch=S)
-    ms.set_option("multi_pipeline", int(os.environ.get("SVO_BENCH_MULTI_PIPELINE", "1")))   # front end of step t + 1 beside the tail of step t
-    mres = torch.zeros((msteps * S, rec), dtype=torch.uint8, device=dev)
-    ms.track_multi_reset(S, cam)
-    for t in range(2):
-        ms.track_multi_step_dev(dL.data_ptr() + t * frame_bytes, dR.data_ptr() + t * frame_bytes, PITCH, S,
-                                mres.data_ptr() + t * S * rec)
-    ms.track_multi_reset(S, cam)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for t in range(msteps):
-        ms.track_multi_step_dev(dL.data_ptr() + t * frame_bytes, dR.data_ptr() + t * frame_bytes, PITCH, S,
-                                mres.data_ptr() + t * S * rec)
-    ms.sync()
-    mdt = time.perf_counter() - t1
-    m = mres.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(msteps, S)
-    ms.close()
-    same = all(m[t, 0].tobytes() == single[t].tobytes() for t in range(msteps))
-    return {"value": msteps * S / mdt, "unit": "stereo frames/s", "sequences": S, "steps": msteps,
-            "sequence0_equals_single_chain": bool(same),
-            "pipelined_steps": bool(int(os.environ.get("SVO_BENCH_MULTI_PIPELINE", "1"))),
-            "note": "SURVEY 8e's 'G independent sequences' variant on ONE GPU: full Tracking::Track per frame; with "
-                    "pipelined_steps the stateless front end of step t + 1 runs beside the tail of step t (multi_pipeline option)"}
 
 
 if __name__ == "__main__":

@@ -1598,6 +1598,7 @@ extern "C" int svo_debug_track_frames(svo_ctx* ctx, int first, int n, svo_track_
     o.active_rows[0] = q.diag[0] & 0xffff; o.active_rows[1] = q.diag[1] & 0xffff;
     o.rounds[0] = q.diag[0] >> 16; o.rounds[1] = q.diag[1] >> 16;
     o.resolve_us = (int32_t)((q.rt[1] - q.rt[0]) / 100);   // s_memrealtime: 100 MHz
+    for (int i = 0; i < 4; ++i) o.rt[i] = q.rt[i];
     memcpy(o.T_pnp, q.T_pnp, sizeof o.T_pnp);
   }
   return SVO_OK;

@@ -15,21 +15,16 @@ import importlib
 import numpy as np
 import pytest
 
-# Per-frame relative motion GPU vs CPU port.  BASELINE.md section 1: the reference itself is ~0.1 m per frame off ground
-# truth.  Both sides run the same chain; what differs is floating-point association (tree sums, MFMA Gram, the EPnP
-# eigen-solver's pair order).  When EPnP's N = 1 candidate decides a RANSAC sample, the two PnP poses start ~1e-3 m
-# apart (see PNP_INLIER_TOL below) and g2o's LM stop rules (relative chi2 gain < 1e-3 three times) leave the
-# optimised poses within a few 1e-4 m of each other - hence 5e-4 m / 5e-5 rad.
-POSE_TOL_T = 5e-4
-POSE_TOL_R = 5e-5
+# Pose tolerances, per frame.  The tests below run the device tracker in its bit-comparable mode (svo_set_option
+# "epnp_exact": every RANSAC sample solved in OpenCV's operation order), where the discrete outcome of RANSAC and the LM's
+# iteration count equal the CPU port's and a frame's pose agrees to BASELINE.md's 1e-4 m / 1e-5 rad.  Both chains
+# dead-reckon from float32 map points, so along a free-running sequence the ABSOLUTE poses drift apart by rounding-sized
+# steps (the absolute tolerance grows with the frame index); the per-frame RELATIVE motion is held to the tight bound.
+# The default (wave-parallel EPnP) mode is validated against the same oracle in tests/test_full_length.py.
+POSE_TOL_T = 1e-4
+POSE_TOL_R = 1e-5
 COUNTERS = ("frame_id", "n_kp", "n_stereo", "n_match_pass1", "n_match_pass2", "n_lm_edges",
-            "n_new_mappoints", "n_local_map")
-# n_pnp_inliers is compared to a tolerance: the winning RANSAC sample's EPnP pose can differ by ~1e-3 m between the GPU
-# and the CPU restatement when EPnP's N = 1 candidate decides (it starts from an ARBITRARY vector of the two-dimensional
-# null space a five-point system has - whatever basis the eigen-solver's rounding leaves; OpenCV's own result depends
-# on that too), which moves a few borderline points across the 8 px threshold.  Nothing downstream reads the count
-# (src/pnpmatch.cc:229-230: only a ratio that Tracking::Track ignores), and PoseOptimization re-converges the pose.
-PNP_INLIER_TOL = 0.1
+            "n_new_mappoints", "n_local_map", "n_pnp_inliers")
 
 CAM04 = dict(W=1241, H=376, fx=707.0912, fy=707.0912, cx=601.8873, cy=183.1104, bf=379.8145)
 
@@ -50,8 +45,7 @@ def _compare_run(gpu, ref, n_abs_tol=None):
     for k, ((res, cur), (rr, rcur)) in enumerate(zip(gpu, ref)):
         for f in COUNTERS:
             assert res[f] == rr[f], (k, f, int(res[f]), int(rr[f]))
-        assert abs(int(res["n_pnp_inliers"]) - int(rr["n_pnp_inliers"])) <= max(2, PNP_INLIER_TOL * int(rr["n_lm_edges"])), k
-        assert abs(int(res["lm_iterations"]) - int(rr["lm_iterations"])) <= 2, k
+        assert abs(int(res["lm_iterations"]) - int(rr["lm_iterations"])) <= 1, k
         assert np.array_equal(cur[:rr["n_kp"]], rcur[:rr["n_kp"]]), "frame %d match indices" % k
         T, Tr = res["Tcw"].reshape(4, 4), rr["Tcw"].reshape(4, 4)
         tol = 1.0 + k / 8.0
@@ -121,6 +115,7 @@ def test_config0_kitti04_tracked_sequence_equals_oracle(pkg, orc, seq04):
     ref = [trk.track(L[k], R[k]) for k in range(len(L))]
     trk.close()
     svo = pkg.Svo(1241, 376, max_batch=1)
+    svo.set_option("epnp_exact", 1)
     svo.track_reset(pkg.Camera(**pkg.KITTI_04_12))
     gpu = []
     for k in range(len(L)):
@@ -153,6 +148,7 @@ def test_config4_boxes_with_dense_elas_depth_equals_oracle(pkg, orc):
     trk = orc.Tracker(1241, 376, pkg.KITTI_00_02)
     svo = pkg.Svo(1241, 376, max_batch=1)
     svo.set_option("depth_source", 1)
+    svo.set_option("epnp_exact", 1)
     svo.track_reset(pkg.Camera(**pkg.KITTI_00_02))
     gpu, ref, vetoes = [], [], 0
     for k in range(n):
@@ -183,6 +179,7 @@ def test_config4_boxes_with_dense_elas_depth_equals_oracle(pkg, orc):
     torch.cuda.synchronize()
     b = pkg.Svo(1241, 376, max_batch=n)
     b.set_option("depth_source", 1)
+    b.set_option("epnp_exact", 1)
     b.track_reset(pkg.Camera(**pkg.KITTI_00_02))
     b.track_batch_dev(dL.data_ptr(), dR.data_ptr(), pitch, n, res.data_ptr(), boxes=pkg.boxes_dev(tb.data_ptr(), tn.data_ptr(), 2))
     b.sync()
@@ -206,6 +203,7 @@ def test_64_frames_gpu_tracker_equals_oracle(pkg, orc):
     ref = [trk.track(L[k], R[k]) for k in range(N)]
     trk.close()
     svo = pkg.Svo(1241, 376, max_batch=1)
+    svo.set_option("epnp_exact", 1)
     svo.track_reset(pkg.Camera(**pkg.KITTI_00_02))
     gpu = []
     for k in range(N):

@@ -66,7 +66,8 @@ def test_product_8point_on_the_device(orc, pkg, noise, n):
     assert abs(np.linalg.det(Fp)) < 1e-12 and Fp[2, 2] == 1.0
     h1 = np.c_[p1, np.ones(len(p1))]; h2 = np.c_[p2, np.ones(len(p2))]
     resid = np.abs(np.einsum("ni,ij,nj->n", h2, Fp, h1))
-    assert resid.max() < (1e-8 if noise == 0 else (0.1 if n > 8 else 0.5))    # eight noisy pairs: F fits them, not the geometry
+    resid_o = np.abs(np.einsum("ni,ij,nj->n", h2, Fo, h1))
+    assert resid.max() < (1e-8 if noise == 0 else 1.0001 * resid_o.max() + 1e-9)      # as good a fit as the oracle's F
     # degenerate inputs: fewer than eight pairs, no pairs, identical points -> F = 0 like OpenCV's empty matrix
     q1, q2 = two_view(4, 7)
     assert not svo.fundamental_8point(q1, q2).any()
@@ -123,24 +124,22 @@ def test_oracle_gating_effects(orc, pkg, gated_oracle_run):
 def test_gpu_gated_tracker_matches_oracle(pkg, gated_oracle_run):
     L, R, out = gated_oracle_run
     svo = pkg.Svo(L.shape[2], L.shape[1], max_batch=1)
+    svo.set_option("epnp_exact", 1)      # the bit-comparable RANSAC: consensus, LM iterations and pose are pinned too
     svo.track_reset(pkg.Camera(**pkg.KITTI_00_02))
     for k in range(5):
         res = svo.track_frame(L[k], R[k], boxes=boxes_for(k))
         cur = svo.debug_track_matches()
         ref, ref_cur, ref_F, ref_vetoes = out[k]
         for f in ("n_kp", "n_stereo", "n_match_pass1", "n_match_pass2", "n_lm_edges",
-                  "n_new_mappoints", "n_local_map"):
+                  "n_new_mappoints", "n_local_map", "n_pnp_inliers", "lm_iterations"):
             assert res[f] == ref[f], (k, f, res[f], ref[f])
-        # the RANSAC consensus is compared to a tolerance (EPnP's N = 1 candidate depends on the eigen-solver's arbitrary
-        # null-space basis, see tests/test_configs.py)
-        assert abs(int(res["n_pnp_inliers"]) - int(ref["n_pnp_inliers"])) <= max(2, 0.1 * int(ref["n_lm_edges"])), k
         assert np.array_equal(cur[:ref["n_kp"]], ref_cur[:ref["n_kp"]]), k
         if k > 0:
             F, nv = svo.debug_track_gate()
             assert np.allclose(F.reshape(9), ref_F, rtol=1e-6, atol=1e-9), k
             assert nv == ref_vetoes, (k, nv, ref_vetoes)
         T, Tr = res["Tcw"].reshape(4, 4), ref["Tcw"].reshape(4, 4)
-        assert np.abs(T - Tr).max() < 5e-4, k
+        assert np.abs(T[:3, 3] - Tr[:3, 3]).max() < 1e-4 and np.abs(T[:3, :3] - Tr[:3, :3]).max() < 1e-5, k
     svo.close()
 
 

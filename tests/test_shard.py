@@ -153,3 +153,38 @@ def test_sharded_contexts_with_sliced_front_ends(pkg, staged, monkeypatch):
         for c in ctxs:
             c.close()
         assert got == want, (G, overlap, staged)
+
+
+@pytest.mark.gpu
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it: the process must start the two ranks itself (as a child,
+    before it touches a GPU) and relay rank 0's line - never print n_gpus = 1 for --gpus 2.  Both ranks on cuda:0 over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "48",
+           "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline", "--no-profile"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["frames_tracked"] == 48
+    # rank 0's one-sequence-over-all-contexts run (BASELINE configs[3]) rides along and reproduces the single chain
+    assert d["sharded"]["contexts"] == 2 and d["sharded"]["records_identical_to_single_context"] is True
+    # a launcher that started another number of ranks than --gpus says is refused
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--frames", "48"], cwd=ROOT,
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "refusing" in (bad.stderr + bad.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_shard_mode_one_sequence_over_two_contexts():
+    """`bench.py --workload track --shard --gpus 2`: ONE sequence, one process, two contexts (both on the box's one GPU),
+    svo_track_sharded_dev over the frames; records equal to the single-context chain."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--shard", "--gpus", "2", "--frames", "96", "--steps", "2", "--warmup", "1"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["sharded"]["contexts"] == 2 and d["sharded"]["records_identical_to_single_context"] is True
+    assert d["config"]["frames_tracked"] == 96 and d["value"] > 0 and d["scaling"] == "strong"

@@ -642,7 +642,9 @@ def tail_chain_from_stamps(dbg):
     resolve = (rt[:, 1] - rt[:, 0]) * 0.01
     period = np.diff(rt[:, 3]) * 0.01                              # us between consecutive frames' pose-kernel ends
     period = period[(period > 0) & (period < 5000)]
-    return {"frames_sampled": int(len(rt)), "pose_chain_busy_us": {"mean": float(pose_busy.mean()), "median": float(np.median(pose_busy))},
+    rounds = dbg["rounds"][ok]
+    return {"frames_sampled": int(len(rt)), "mean_rounds_pass1_pass2": [float(rounds[:, 0].mean()), float(rounds[:, 1].mean())],
+            "pose_chain_busy_us": {"mean": float(pose_busy.mean()), "median": float(np.median(pose_busy))},
             "k_ti_resolve_us": {"mean": float(resolve.mean()), "median": float(np.median(resolve)), "max": float(resolve.max())},
             "frame_period_us": {"mean": float(period.mean()), "median": float(np.median(period))},
             "source": "in-kernel s_memrealtime stamps of the timed region's last step (svo_debug_track_frames)"}
@@ -891,8 +893,7 @@ def main():
                         "frames_tracked": int(len(res)), "ate_rmse_m_vs_ground_truth": rmse,
                         "final_position_error_m": last, "path_length_m": float(len(res) - 1),
                         "mean_lm_edges": float(res["n_lm_edges"][1:].mean()),
-                        "mean_active_rows_pass1_pass2": [float((res["reserved"][1:, 0] & 0xffff).mean()), float((res["reserved"][1:, 1] & 0xffff).mean())],
-                        "mean_rounds_pass1_pass2": [float((res["reserved"][1:, 0] >> 16).mean()), float((res["reserved"][1:, 1] >> 16).mean())],
+                        "mean_active_rows_pass1_pass2": [float(res["reserved"][1:, 0].mean()), float(res["reserved"][1:, 1].mean())],
                         "mean_local_map": float(res["n_local_map"][1:].mean()),
                         "tracker_capacity_flag": int(svo.track_overflowed())})
             if world == 1 and not multi and not args.no_cpu_baseline and args.depth_source == 0 and not args.boxes:

@@ -264,12 +264,20 @@ __device__ __forceinline__ void edge_jacobian(const double pc[3], const double* 
 }
 
 __device__ __forceinline__ double wave_sum_d(double v) { return wave_sum_f64_dpp(v); }
-// block reduction of NV doubles per thread (256 threads = 4 waves); result in red[0..NV)
-template <int NV>
+// block reduction of NV doubles per thread (NT threads = NT / 64 waves); result in red[0..NV)
+template <int NV, int NT = 256>
 __device__ __forceinline__ void block_reduce(double* acc, double* red /* [4][NV] + [NV] */) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < NV; ++k) acc[k] = wave_sum_d(acc[k]);
+  if (NT == 64) {   // one wave: the sums are in every lane already - one LDS hop so that the callers read red[] as before
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+      for (int k = 0; k < NV; ++k) red[k] = acc[k];
+    __syncthreads();
+    return;
+  }
   __syncthreads();
   if (lane == 0)
 #pragma unroll
@@ -283,13 +291,13 @@ __device__ __forceinline__ void block_reduce(double* acc, double* red /* [4][NV]
 
 // accumulate (optionally Huber-weighted) normal equations + chi2 over edges listed by `use`.
 // acc layout: [0..20] upper-triangular H (row-major, r<=c), [21..26] b, [27] chi2
-template <bool ROBUST>
+template <bool ROBUST, int NT = 256>
 __device__ __forceinline__ void accum_system(const Se3& est, const double* Xw, const double* obs,
                                              int n, const uint8_t* use, const double* K,
                                              double delta, double dsqr, double acc[28]) {
 #pragma unroll
   for (int k = 0; k < 28; ++k) acc[k] = 0;
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int i = threadIdx.x; i < n; i += NT) {
     if (use && !use[i]) continue;
     double e[2], pc[3], J[12];
     edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc);
@@ -317,15 +325,16 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 #define GRAM_MAXN 512
 #define GRAM_STRIDE 7
 
-template <bool ROBUST>
+template <bool ROBUST, int NT = 256>
 __device__ __forceinline__ void build_system_mfma(const Se3& est, const double* Xw, const double* obs,
                                                   int n, const uint8_t* use, const double* K,
                                                   double delta, double dsqr, double* arow /*[2*512*7]*/,
                                                   double* gram /*[4][8][8]*/, double* red) {
+  constexpr int NW = NT / 64;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int rows = (2 * n + 63) & ~63;           // 4 waves x whole groups of four 4-row steps
+  const int rows = (2 * n + 16 * NW - 1) & ~(16 * NW - 1);   // NW waves x whole groups of four 4-row steps
   double chi = 0;
-  for (int i = tid; 2 * i < rows; i += 256) {
+  for (int i = tid; 2 * i < rows; i += NT) {
     double r0[7] = {0, 0, 0, 0, 0, 0, 0}, r1[7] = {0, 0, 0, 0, 0, 0, 0};
     if (i < n && !(use && !use[i])) {
       double e[2], pc[3], J[12];
@@ -344,7 +353,7 @@ __device__ __forceinline__ void build_system_mfma(const Se3& est, const double* 
   }
   __syncthreads();
   const int c = lane & 15, kk = lane >> 4;
-  const int per_wave = rows >> 2;
+  const int per_wave = rows / NW;
   // four independent accumulators: a dependent chain of f64 MFMAs would serialise on the
   // instruction's own latency
   v4f64 acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
@@ -372,22 +381,27 @@ __device__ __forceinline__ void build_system_mfma(const Se3& est, const double* 
       int r = 0, k = tid;                        // upper-triangular index -> (r, cc)
       while (k >= 6 - r) { k -= 6 - r; ++r; }
       const int cc = r + k;
-      out = gram[(0 * 8 + r) * 8 + cc] + gram[(1 * 8 + r) * 8 + cc] + gram[(2 * 8 + r) * 8 + cc] + gram[(3 * 8 + r) * 8 + cc];
+      out = gram[(0 * 8 + r) * 8 + cc];
+      if (NW == 4) out = out + gram[(1 * 8 + r) * 8 + cc] + gram[(2 * 8 + r) * 8 + cc] + gram[(3 * 8 + r) * 8 + cc];
     } else if (tid < 27) {
       const int r = tid - 21;
-      out = -(gram[(0 * 8 + r) * 8 + 6] + gram[(1 * 8 + r) * 8 + 6] + gram[(2 * 8 + r) * 8 + 6] + gram[(3 * 8 + r) * 8 + 6]);
+      out = gram[(0 * 8 + r) * 8 + 6];
+      if (NW == 4) out = out + gram[(1 * 8 + r) * 8 + 6] + gram[(2 * 8 + r) * 8 + 6] + gram[(3 * 8 + r) * 8 + 6];
+      out = -out;
     } else {
-      out = gram[256] + gram[257] + gram[258] + gram[259];
+      out = gram[256];
+      if (NW == 4) out = out + gram[257] + gram[258] + gram[259];
     }
     red[tid] = out;
   }
   __syncthreads();
 }
 
+template <int NT = 256>
 __device__ __forceinline__ double partial_chi2(const Se3& est, const double* Xw, const double* obs,
                                                int n, const double* K, double delta, double dsqr) {
   double chi = 0;
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int i = threadIdx.x; i < n; i += NT) {
     double e[2], pc[3];
     edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc);
     double rho0 = e[0] * e[0] + e[1] * e[1], rho1;
@@ -426,7 +440,10 @@ struct PoseLds {
   double K[4];
 };
 
-// Pose-only LM.  T: row-major 4x4 in/out (global or LDS); stats may be null.
+// Pose-only LM, called by all NT threads of the workgroup (NT = 256, or 64: the tracker's single-sequence chain - a frame has
+// ~64 edges, a CU's float64 pipeline is shared by its SIMDs anyway, and with ONE wave every barrier and reduction hop of
+// the loop is wave-local).  T: row-major 4x4 in/out (global or LDS); stats may be null.
+template <int NT = 256>
 __device__ __forceinline__ void pose_opt_block(PoseLds& L, const double* __restrict__ Xw, const double* __restrict__ obs, int n,
                                                const double* __restrict__ Kp, double* T, svo_lm_stats* stats,
                                                int round_in_f32, int use_mfma) {
@@ -463,10 +480,10 @@ __device__ __forceinline__ void pose_opt_block(PoseLds& L, const double* __restr
     double acc[28];
     const Se3 est = sh.est;
     if (use_mfma) {
-      build_system_mfma<true>(est, Xw, obs, n, nullptr, K, delta, dsqr, arow, gram, red);
+      build_system_mfma<true, NT>(est, Xw, obs, n, nullptr, K, delta, dsqr, arow, gram, red);
     } else {
-      accum_system<true>(est, Xw, obs, n, nullptr, K, delta, dsqr, acc);
-      block_reduce<28>(acc, red);
+      accum_system<true, NT>(est, Xw, obs, n, nullptr, K, delta, dsqr, acc);
+      block_reduce<28, NT>(acc, red);
     }
     double H[36], b[6], iniChi = 0, rho = 0;
     int qmax = 0;
@@ -505,8 +522,8 @@ __device__ __forceinline__ void pose_opt_block(PoseLds& L, const double* __restr
       }
       __syncthreads();
       const Se3 trial_est = sh.est;
-      double c1[1] = {partial_chi2(trial_est, Xw, obs, n, K, delta, dsqr)};
-      block_reduce<1>(c1, red);
+      double c1[1] = {partial_chi2<NT>(trial_est, Xw, obs, n, K, delta, dsqr)};
+      block_reduce<1, NT>(c1, red);
       if (tid == 0) {
         double tempChi = red[0];
         if (!ok2) tempChi = 1.7976931348623157e308;

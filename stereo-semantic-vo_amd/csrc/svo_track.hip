@@ -971,7 +971,10 @@ struct TpLds {
   double upd_ld[PNP_HYP];
 };
 
-__global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, TrackWork* work, const svo_kp* kp,
+// ONE wave per sequence (TPF_NT = 64): a frame has ~64 edges, the scalar LM path is one lane's work whatever the width, and
+// with a single wave every barrier and reduction of the LM loop is wave-local (k_tp_frame 30 -> ~22 us per frame).
+#define TPF_NT 64
+__global__ __launch_bounds__(TPF_NT) void k_tp_frame(TrackState* st, TrackWork* work, const svo_kp* kp,
                                                   const float* depth, svo_track_result* res_out, int kstride,
                                                   int use_mfma) {
   TpLds& S = *reinterpret_cast<TpLds*>(tk_smem);
@@ -982,7 +985,7 @@ __global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, TrackWork* wor
   const int id = work->frame_id, nkp = work->nkp, skip = work->skip_match, n_edges = work->n_edges;
   float* gpos = st->gpos;
   // ---- 3D-2D correspondences, ordered by keypoint index (src/pnpmatch.cc:216-224) ---------------
-  for (int e = tid; e < n_edges; e += 256) {
+  for (int e = tid; e < n_edges; e += TPF_NT) {
     const int j = work->edge_kp[e];
     const svo_kp k = kp[j];
     float* gp = gpos + 3 * (size_t)(work->edge_gid[e] & (TRK_GPOS - 1));
@@ -1000,14 +1003,15 @@ __global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, TrackWork* wor
   if (tid < 4) st->K[tid] = (double)((const float*)&st->cam)[tid];
   // ---- PnP initial pose (src/pnpmatch.cc:212-247): no prior; if solvePnPRansac fails the last pose stays ----------
   const bool ran = !skip && n_edges >= 5;
-  if (ran && tid < PNP_HYP) {
-    // every sample's thread prepares the pow / log terms the iteration bound would need if that sample became the best
-    const int c = st->hyp[tid].cnt, o = st->hyp[tid].ok;
-    S.cnt[tid] = c; S.ok[tid] = o;
-    double ld = 1.0; int r = 0;
-    if (o && c > 4 && n_edges > 5) pnp_update_terms(c, n_edges, &ld, &r);
-    S.upd_ld[tid] = ld; S.upd_r[tid] = r;
-  }
+  if (ran)
+    for (int h = tid; h < PNP_HYP; h += TPF_NT) {
+      // every sample's thread prepares the pow / log terms the iteration bound would need if that sample became the best
+      const int c = st->hyp[h].cnt, o = st->hyp[h].ok;
+      S.cnt[h] = c; S.ok[h] = o;
+      double ld = 1.0; int r = 0;
+      if (o && c > 4 && n_edges > 5) pnp_update_terms(c, n_edges, &ld, &r);
+      S.upd_ld[h] = ld; S.upd_r[h] = r;
+    }
   __syncthreads();
   if (tid == 0) {
     int good = 0, iters = 0;
@@ -1034,7 +1038,7 @@ __global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, TrackWork* wor
   __syncthreads();
   const long long tf1 = clock64();
   // ---- Optimizer::PoseOptimization (src/Optimizer.cc:15-86) from the CV_32F-stored PnP pose ----------------------
-  pose_opt_block(S.pose, st->Xw, st->obs, n_edges, st->K, st->T, &st->lm, 1, use_mfma);
+  pose_opt_block<TPF_NT>(S.pose, st->Xw, st->obs, n_edges, st->K, st->T, &st->lm, 1, use_mfma);
   __syncthreads();
   const long long tf2 = clock64();
   // ---- SetPose (CV_32F, src/Optimizer.cc:82-83), positions of the points created this frame -------
@@ -1048,7 +1052,7 @@ __global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, TrackWork* wor
     S.stwc[tid] = (float)(-acc);
   }
   __syncthreads();
-  for (int j = tid; j < nkp; j += 256) {
+  for (int j = tid; j < nkp; j += TPF_NT) {
     const int g = work->new_gid[j];
     if (g < 0) continue;
     const svo_kp k = kp[j];
@@ -1067,8 +1071,11 @@ __global__ __launch_bounds__(256) void k_tp_frame(TrackState* st, TrackWork* wor
     r.n_new_mappoints = work->n_new;
     r.n_local_map = work->n_local;
     r.lm_iterations = st->lm.iterations;
-    r.reserved[0] = work->diag[0];   // diagnostics: rows of pass 1 | rounds << 16; [1]: rows of pass 2 | rounds << 16
-    r.reserved[1] = work->diag[1];
+    // diagnostics: rows of pass 1 / pass 2 that could match at all.  (The ROUNDS a pass took are not part of the record: a
+    // dense row may or may not see a claim made earlier in the same phase - the outcome is the same either way, the
+    // number of rounds is not, and records are compared byte for byte.  svo_debug_track_frames reports them.)
+    r.reserved[0] = work->diag[0] & 0xffff;
+    r.reserved[1] = work->diag[1] & 0xffff;
     *res_out = r;
     st->pose_ts[8] = tf0; st->pose_ts[9] = tf1; st->pose_ts[10] = tf2; st->pose_ts[11] = clock64();
     work->rt[3] = wall_clock64();
@@ -1215,7 +1222,7 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
     }
     {
       SvoTimer t(ctx, "k_tp_frame");
-      hipLaunchKernelGGL(k_tp_frame, dim3(1, ny), dim3(256), sizeof(TpLds), s0, st, work + f, kpf, depf, d_res + f, kstride,
+      hipLaunchKernelGGL(k_tp_frame, dim3(1, ny), dim3(TPF_NT), sizeof(TpLds), s0, st, work + f, kpf, depf, d_res + f, kstride,
                          ctx->opt_pose_mfma);
     }
   };

@@ -157,9 +157,6 @@ void svo_destroy(svo_ctx* ctx);
  * epipolar matcher (north star), 1 a dense ELAS map (svo_elas_*), 2 a dense MSA map (svo_msa_solve with d = 48: the
  * reference's live configuration, src/Tracking.cc:225-228 + src/frame.cc:82-91), both read per keypoint as
  * frame::computekeypoint_r / disp2Depth do.
- * "pose_group" (default 1): one sequence's pose chain (RANSAC samples -> LM, frame after frame) runs as ONE persistent
- * launch per group of frames whose matching has finished, the hand-over between samples and frames inside the kernel;
- * 0: two launches per frame - same records ("track_group" bounds the group size in both cases).
  * "epnp_exact" (default 0): 1 makes every RANSAC sample's EPnP follow OpenCV's own loops one after the other (cyclic
  * one-sided Jacobi SVDs, SVD / QR least squares, IEEE division and square root, no FMA contraction), one lane per
  * sample - the arithmetic of the CPU restatement the tests compare with, an order of magnitude slower than the

@@ -602,31 +602,30 @@ __device__ __forceinline__ bool pnp_inlier(const double* R, const double* t, con
 
 // Hypotheses hyp_base .. hyp_base + (waves of the block) - 1, one wave each.  Xw / uv: the n correspondences in LDS (or
 // anywhere), subset: the 100 x 5 sample indices cv::RNG((uint64)-1) yields for this n (svo_pnp_subsets).
-// One sample (k) on the calling wave, workspace `w`: EPnP of its five correspondences, then its consensus.  The record is
-// returned in every lane.
-__device__ __forceinline__ void pnp_hyp_wave(EpnpWaveLds& w, const double* Xw, const double* uv, int n, const double* K,
-                                             const uint16_t* subset, int k, PnpHyp& h) {
-  const int lane = threadIdx.x & 63;
-  if (lane < 5) {   // the sample's five correspondences into the wave's workspace
-    const int e = min((int)subset[5 * k + lane], n - 1);
-    w.x5[3 * lane] = Xw[3 * e]; w.x5[3 * lane + 1] = Xw[3 * e + 1]; w.x5[3 * lane + 2] = Xw[3 * e + 2];
-    w.u5[2 * lane] = uv[2 * e]; w.u5[2 * lane + 1] = uv[2 * e + 1];
-  }
-  const bool ok = epnp5_wave(w, K, h.R, h.t);
-  int cnt = 0;
-  if (ok)
-    for (int e = lane; e < n; e += 64) cnt += pnp_inlier(h.R, h.t, Xw + 3 * e, uv + 2 * e, K) ? 1 : 0;
-  h.cnt = wave_sum_i32_dpp(cnt);
-  h.ok = ok ? 1 : 0;
-}
 __device__ __forceinline__ void pnp_hyp_block(EpnpWaveLds* ws, const double* Xw, const double* uv, int n, const double* K,
                                               const uint16_t* subset, PnpHyp* out, int hyp_base) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int k = hyp_base + wv;
   if (k >= PNP_HYP) return;
-  PnpHyp h;
-  pnp_hyp_wave(ws[wv], Xw, uv, n, K, subset, k, h);
-  if (lane == 0) out[k] = h;
+  if (lane < 5) {   // the sample's five correspondences into the wave's workspace
+    const int e = min((int)subset[5 * k + lane], n - 1);
+    ws[wv].x5[3 * lane] = Xw[3 * e]; ws[wv].x5[3 * lane + 1] = Xw[3 * e + 1]; ws[wv].x5[3 * lane + 2] = Xw[3 * e + 2];
+    ws[wv].u5[2 * lane] = uv[2 * e]; ws[wv].u5[2 * lane + 1] = uv[2 * e + 1];
+  }
+  double R[9], t[3];
+  const bool ok = epnp5_wave(ws[wv], K, R, t);
+  int cnt = 0;
+  if (ok)
+    for (int e = lane; e < n; e += 64) cnt += pnp_inlier(R, t, Xw + 3 * e, uv + 2 * e, K) ? 1 : 0;
+  cnt = wave_sum_i32_dpp(cnt);
+  if (lane == 0) {
+    PnpHyp h;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) h.R[i] = R[i];
+    h.t[0] = t[0]; h.t[1] = t[1]; h.t[2] = t[2];
+    h.cnt = cnt; h.ok = ok ? 1 : 0;
+    out[k] = h;
+  }
 }
 
 // The same samples in the parity mode (svo_set_option "epnp_exact"): ONE sample per wave - lane 0 walks the sequential

@@ -87,7 +87,6 @@ struct TrackState {
   // ---- index chain -------------------------------------------------------------------------
   int32_t frame_num, npool, lastN, cur;      // cur: active half of the pool ping-pong
   int32_t next_gid, overflow, n_vetoed, n_boxes;
-  int32_t sync_arrived, pose_done;           // k_tp_group: RANSAC samples of the running frame finished; frames whose pose is final
   int32_t last_mp[TRK_MAXKP];
   int32_t dbg_cur_mp[TRK_MAXKP];
   svo_camera cam;
@@ -972,9 +971,9 @@ struct TpLds {
   double upd_ld[PNP_HYP];
 };
 
-// TPF_NT threads per sequence.  (Measured with ONE wave, TPF_NT = 64: k_tp_frame 39 -> 55 us - the rows of the Gram matrix and
-// the MFMA accumulation spread over four SIMDs are worth more than the wave-local barriers a single wave would buy.)
-#define TPF_NT 256
+// ONE wave per sequence (TPF_NT = 64): a frame has ~64 edges, the scalar LM path is one lane's work whatever the width, and
+// with a single wave every barrier and reduction of the LM loop is wave-local (k_tp_frame 30 -> ~22 us per frame).
+#define TPF_NT 64
 __global__ __launch_bounds__(TPF_NT) void k_tp_frame(TrackState* st, TrackWork* work, const svo_kp* kp,
                                                   const float* depth, svo_track_result* res_out, int kstride,
                                                   int use_mfma) {
@@ -1080,183 +1079,6 @@ __global__ __launch_bounds__(TPF_NT) void k_tp_frame(TrackState* st, TrackWork* 
     *res_out = r;
     st->pose_ts[8] = tf0; st->pose_ts[9] = tf1; st->pose_ts[10] = tf2; st->pose_ts[11] = clock64();
     work->rt[3] = wall_clock64();
-    st->pose_done = id + 1;       // (k_tp_group's frame counter: the two pose paths may alternate between calls)
-  }
-}
-
-// ================================================================================================
-// Pose chain of ONE sequence as a persistent launch over a GROUP of frames: k_tp_group
-// ================================================================================================
-// k_tp_hyp -> k_tp_frame -> k_tp_hyp -> ... is a strict chain with a launch boundary (~5-7 us of dispatch latency) after
-// every kernel: two per frame, a fifth of the chain.  k_tp_group keeps the 100 sample workgroups resident for all frames of
-// a group (frames whose index chain has already finished: their TrackWork records are complete at launch) and hands over
-// inside the kernel:
-//   * every workgroup solves its RANSAC sample of frame f (wave 0), publishes the record and bumps `sync_arrived`;
-//   * the LAST one to arrive carries on as the frame part (RANSAC's acceptance rule, the LM, SetPose, new points' positions,
-//     the record), resets the counter and publishes `pose_done = f + 1`;
-//   * the others wait for `pose_done` and go on with frame f + 1.
-// What crosses workgroups inside the launch (sample records, map-point positions, the last pose, the two counters) is
-// written and read with agent-scope accesses (sc1: they go to the device-coherent level themselves) and ordered with
-// s_waitcnt - NOT with agent-scope release / acquire fences: on gfx950 a release fence is `buffer_wbl2`, a write-back of
-// everything dirty in that XCD's L2, which is full of the pyramid data of the front end running beside the tail.
-__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-#define TP_STORES_DONE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-
-struct TpGroupLds {
-  TpLds frame;                              // the frame part's workspace (the LM's rows, Gram tiles, ...)
-  double Xw[TRK_MAXKP * 3], uv[TRK_MAXKP * 2];
-  EpnpWaveLds ws;
-  int last;
-};
-
-__global__ __launch_bounds__(256) void k_tp_group(TrackState* st, TrackWork* work, const svo_kp* kp, const float* depth,
-                                                  svo_track_result* res_out, const uint16_t* subsets, int kstride,
-                                                  int nframes, const int32_t* rows, int row0, int use_mfma) {
-  TpGroupLds& G = *reinterpret_cast<TpGroupLds*>(tk_smem);
-  TpLds& S = G.frame;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  float* gpos = st->gpos;
-  for (int g = 0; g < nframes; ++g) {
-    TrackWork* w = work + g;
-    const int row = rows ? rows[g] : row0 + g;
-    const svo_kp* kpf = kp + (size_t)row * kstride;
-    const float* depf = depth + (size_t)row * kstride;
-    const int id = w->frame_id, nkp = w->nkp, skip = w->skip_match, n_edges = w->n_edges;
-    // ---- the previous frame's pose (and the positions of its new map points) must be final --------------------------
-    if (tid == 0) {
-      while (ld_agent(&st->pose_done) < id) __builtin_amdgcn_s_sleep(4);
-      if (blockIdx.x == 0) w->rt[2] = wall_clock64();
-    }
-    __syncthreads();
-    const bool ran = !skip && n_edges >= 5;
-    bool do_frame = !ran && blockIdx.x == 0;
-    if (ran) {
-      // ---- this workgroup's RANSAC sample (src/pnpmatch.cc:227): gather the correspondences, EPnP + consensus on wave 0 ----
-      for (int e = tid; e < n_edges; e += 256) {
-        const float* gp = gpos + 3 * (size_t)(w->edge_gid[e] & (TRK_GPOS - 1));
-        const svo_kp k = kpf[w->edge_kp[e]];
-        G.Xw[3 * e] = (double)ld_agent(gp); G.Xw[3 * e + 1] = (double)ld_agent(gp + 1); G.Xw[3 * e + 2] = (double)ld_agent(gp + 2);
-        G.uv[2 * e] = (double)k.x; G.uv[2 * e + 1] = (double)k.y;
-      }
-      __syncthreads();
-      if (wv == 0) {
-        const double K[4] = {(double)st->cam.fx, (double)st->cam.fy, (double)st->cam.cx, (double)st->cam.cy};
-        PnpHyp h;
-        pnp_hyp_wave(G.ws, G.Xw, G.uv, n_edges, K, subsets + (size_t)min(n_edges, 512) * 500, (int)blockIdx.x, h);
-        if (lane == 0) {
-          PnpHyp* o = &st->hyp[blockIdx.x];
-#pragma unroll
-          for (int i = 0; i < 9; ++i) st_agent(&o->R[i], h.R[i]);
-#pragma unroll
-          for (int i = 0; i < 3; ++i) st_agent(&o->t[i], h.t[i]);
-          st_agent(&o->cnt, h.cnt); st_agent(&o->ok, h.ok);
-          TP_STORES_DONE();
-          const int old = __hip_atomic_fetch_add(&st->sync_arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          G.last = old == PNP_HYP - 1 ? 1 : 0;
-        }
-      }
-      __syncthreads();
-      do_frame = G.last != 0;
-    }
-    if (!do_frame) continue;
-    // ==== frame part: what k_tp_frame does, by the workgroup that saw the last sample arrive ===============================
-    for (int e = tid; e < n_edges; e += 256) {
-      const int j = w->edge_kp[e];
-      const svo_kp k = kpf[j];
-      float* gp = gpos + 3 * (size_t)(w->edge_gid[e] & (TRK_GPOS - 1));
-      float xyz[3];
-      if (id == 0) {   // Tracking::init: the points of frame 0 are placed with the identity pose, before its LM
-        const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3[3] = {0, 0, 0};
-        tk_unproject(st->cam, k.x, k.y, depf[j], I3, z3, xyz);
-        st_agent(gp, xyz[0]); st_agent(gp + 1, xyz[1]); st_agent(gp + 2, xyz[2]);
-      } else {
-        xyz[0] = ld_agent(gp); xyz[1] = ld_agent(gp + 1); xyz[2] = ld_agent(gp + 2);
-      }
-      st->Xw[3 * e] = (double)xyz[0]; st->Xw[3 * e + 1] = (double)xyz[1]; st->Xw[3 * e + 2] = (double)xyz[2];
-      st->obs[2 * e] = (double)k.x; st->obs[2 * e + 1] = (double)k.y;
-    }
-    if (tid < 4) st->K[tid] = (double)((const float*)&st->cam)[tid];
-    if (ran && tid < PNP_HYP) {
-      const int c = ld_agent(&st->hyp[tid].cnt), o = ld_agent(&st->hyp[tid].ok);
-      S.cnt[tid] = c; S.ok[tid] = o;
-      double ld = 1.0; int r = 0;
-      if (o && c > 4 && n_edges > 5) pnp_update_terms(c, n_edges, &ld, &r);
-      S.upd_ld[tid] = ld; S.upd_r[tid] = r;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int good = 0, iters = 0;
-      S.best = ran ? pnp_select_pre(S.cnt, S.ok, S.upd_ld, S.upd_r, n_edges, &good, &iters) : -1;
-      S.good = good; S.iters = iters;
-    }
-    __syncthreads();
-    if (tid < 16) {
-      double v = (double)ld_agent(&st->lastTcw[tid]);
-      if (S.best >= 0) {
-        const PnpHyp* h = &st->hyp[S.best];
-        const int r = tid >> 2, c = tid & 3;
-        v = r == 3 ? (c == 3 ? 1.0 : 0.0) : (c == 3 ? ld_agent(&h->t[r]) : ld_agent(&h->R[3 * r + c]));
-      }
-      st->T[tid] = v;
-      w->T_pnp[tid] = v;
-    }
-    if (tid == 0) {
-      st->pnp.n_points = n_edges; st->pnp.n_inliers = S.best >= 0 ? S.good : 0; st->pnp.best_hypothesis = S.best;
-      st->pnp.ok = S.best >= 0 ? 1 : 0; st->pnp.iterations = S.iters;
-      w->pnp_best = S.best; w->pnp_iterations = S.iters; w->pnp_inliers = S.best >= 0 ? S.good : 0;
-      w->pnp_ok = S.best >= 0 ? 1 : 0;
-    }
-    __syncthreads();
-    pose_opt_block<256>(S.pose, st->Xw, st->obs, n_edges, st->K, st->T, &st->lm, 1, use_mfma);
-    __syncthreads();
-    if (tid < 16) S.sT[tid] = (float)st->T[tid];
-    __syncthreads();
-    if (tid < 9) S.sRwc[tid] = S.sT[4 * (tid % 3) + tid / 3];
-    __syncthreads();
-    if (tid < 3) {
-      const double acc = (double)S.sRwc[3 * tid] * (double)S.sT[3] + (double)S.sRwc[3 * tid + 1] * (double)S.sT[7] +
-                         (double)S.sRwc[3 * tid + 2] * (double)S.sT[11];
-      S.stwc[tid] = (float)(-acc);
-    }
-    __syncthreads();
-    for (int j = tid; j < nkp; j += 256) {
-      const int gq = w->new_gid[j];
-      if (gq < 0) continue;
-      const svo_kp k = kpf[j];
-      float xyz[3];
-      tk_unproject(st->cam, k.x, k.y, depf[j], S.sRwc, S.stwc, xyz);
-      float* gp = gpos + 3 * (size_t)(gq & (TRK_GPOS - 1));
-      st_agent(gp, xyz[0]); st_agent(gp + 1, xyz[1]); st_agent(gp + 2, xyz[2]);
-    }
-    if (tid < 16) st_agent(&st->lastTcw[tid], S.sT[tid]);
-    if (tid == 0) {
-      svo_track_result r;
-      for (int i = 0; i < 16; ++i) r.Tcw[i] = S.sT[i];
-      r.frame_id = id; r.n_kp = nkp; r.n_stereo = w->n_stereo;
-      r.n_match_pass1 = w->n_pass1; r.n_match_pass2 = w->n_pass2;
-      r.n_pnp_inliers = skip ? 0 : st->pnp.n_inliers;
-      r.n_lm_edges = n_edges;
-      r.n_new_mappoints = w->n_new;
-      r.n_local_map = w->n_local;
-      r.lm_iterations = st->lm.iterations;
-      r.reserved[0] = w->diag[0] & 0xffff;   // rows of pass 1 / pass 2 that could match at all (see k_tp_frame)
-      r.reserved[1] = w->diag[1] & 0xffff;
-      res_out[g] = r;
-      w->rt[3] = wall_clock64();
-    }
-    // ---- hand over: positions and pose are out (every thread waits for its own stores), then the counters ----------------
-    TP_STORES_DONE();
-    __syncthreads();
-    if (tid == 0) {
-      st_agent(&st->sync_arrived, 0);
-      TP_STORES_DONE();
-      st_agent(&st->pose_done, id + 1);
-    }
   }
 }
 
@@ -1268,8 +1090,7 @@ void svo_track_release(svo_ctx* ctx) {
   shard_gather_free(ctx);
   if (ctx->d_track) { hipFree(ctx->d_track); ctx->d_track = nullptr; }
   if (ctx->d_work) { hipFree(ctx->d_work); ctx->d_work = nullptr; }
-  if (ctx->d_rows) { hipFree(ctx->d_rows); ctx->d_rows = nullptr; }
-  ctx->n_seq = 0; ctx->work_cap = 0; ctx->rows_cap = 0;
+  ctx->n_seq = 0; ctx->work_cap = 0;
   for (hipEvent_t e : ctx->ev_frame) hipEventDestroy(e);
   ctx->ev_frame.clear();
   if (ctx->ev_frontend) { hipEventDestroy(ctx->ev_frontend); ctx->ev_frontend = nullptr; }
@@ -1314,8 +1135,6 @@ static int track_resources(svo_ctx* ctx, int frames, int nseq) {
                                    (int)sizeof(TpLds)) == hipSuccess;
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_hyp), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)sizeof(TpHypLds)) == hipSuccess;
-    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_group), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)sizeof(TpGroupLds)) == hipSuccess;
     ctx->track_lds_state = ok ? 1 : -1;
     if (!ok) ctx->last_error = std::string("hipFuncSetAttribute(tracker kernels): ") + hipGetErrorString(hipGetLastError());
   }
@@ -1379,26 +1198,6 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
                          bxf, nbf, bstride);
     }
   };
-  // one sequence, default RANSAC solver: the pose chain of a whole group of frames is ONE persistent launch (k_tp_group)
-  const bool grouped = ny == 1 && !ctx->opt_epnp_exact && ctx->opt_pose_group;
-  const int32_t* d_rows = nullptr;
-  if (grouped && row_of_frame) {
-    if (ctx->rows_cap < frames) {
-      SVO_HIP(ctx, hipStreamSynchronize(s0));
-      if (ctx->d_rows) hipFree(ctx->d_rows);
-      ctx->d_rows = nullptr; ctx->rows_cap = 0;
-      if (hipMalloc(reinterpret_cast<void**>(&ctx->d_rows), sizeof(int32_t) * (size_t)frames) != hipSuccess) return SVO_E_NOMEM;
-      ctx->rows_cap = frames;
-    }
-    SVO_HIP(ctx, hipMemcpyAsync(ctx->d_rows, row_of_frame, sizeof(int32_t) * (size_t)frames, hipMemcpyHostToDevice, s0));
-    d_rows = ctx->d_rows;
-  }
-  auto enqueue_pose_group = [&](int f0, int f1) {
-    ctx->profiling = prof && (f0 % 32 == 0 || frames < 32);
-    SvoTimer t(ctx, "k_tp_group");
-    hipLaunchKernelGGL(k_tp_group, dim3(PNP_HYP), dim3(256), sizeof(TpGroupLds), s0, st, work + f0, kp, depth, d_res + f0,
-                       ctx->d_pnp_subsets, kstride, f1 - f0, d_rows ? d_rows + f0 : nullptr, f0, ctx->opt_pose_mfma);
-  };
   auto enqueue_pose = [&](int f) {
     const svo_kp* kpf = kp + row(f) * kstride;
     const float* depf = depth + row(f) * kstride;
@@ -1444,8 +1243,7 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
     }
     if (prev0 >= 0) {
       hipStreamWaitEvent(s0, ctx->ev_frame[prev0], 0);
-      if (grouped) enqueue_pose_group(prev0, prev1);
-      else for (int f = prev0; f < prev1; ++f) enqueue_pose(f);
+      for (int f = prev0; f < prev1; ++f) enqueue_pose(f);
     }
     prev0 = cur0; prev1 = cur1;
   }

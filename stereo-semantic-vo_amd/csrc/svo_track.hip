@@ -971,9 +971,10 @@ struct TpLds {
   double upd_ld[PNP_HYP];
 };
 
-// ONE wave per sequence (TPF_NT = 64): a frame has ~64 edges, the scalar LM path is one lane's work whatever the width, and
-// with a single wave every barrier and reduction of the LM loop is wave-local (k_tp_frame 30 -> ~22 us per frame).
-#define TPF_NT 64
+// TPF_NT threads per sequence.  (Measured with ONE wave, TPF_NT = 64: k_tp_frame 30 -> 43 us under rocprofv3, 12.5 k -> 10.9 k
+// frames/s - the rows of the Gram matrix and the MFMA accumulation spread over four SIMDs are worth more than the wave-local
+// barriers a single wave would buy.  The LM stays templated on the thread count, pose_opt_block<NT>.)
+#define TPF_NT 256
 __global__ __launch_bounds__(TPF_NT) void k_tp_frame(TrackState* st, TrackWork* work, const svo_kp* kp,
                                                   const float* depth, svo_track_result* res_out, int kstride,
                                                   int use_mfma) {

@@ -249,3 +249,36 @@ def test_unrelated_frames_drive_the_pool_to_its_bound(pkg, orc):
     assert rec["n_new_mappoints"][1:].min() > 250             # every keypoint with depth creates a point
     assert rec["n_local_map"].max() > 1200
     assert rec["n_local_map"].max() <= 4 * 512
+
+
+# ---------------------------------------------------------------- a tracked sequence on REAL street images ---------
+@pytest.mark.gpu
+def test_real_street_images_tracked_sequence_equals_oracle(pkg, orc):
+    """The only real stereo data on this machine are the pairs the reference ships with libelas (urban1: 1344 x 391).  A
+    KITTI-sized window panned across the pair (12 px per frame, the same window in both images: real texture, real stereo
+    disparities, a steady image motion) gives the tracker eight consecutive real frames: descriptors, Hamming thresholds
+    15 / 30, the ratio test and the map-point lifecycle then act on real street texture instead of the synthetic scene.
+    Device tracker (bit-comparable RANSAC mode) against the oracle: everything exact, pose to BASELINE.md's tolerance."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import util
+    frames = [util.urban_pair(1241, 376, x0=4 + 12 * k, y0=8) for k in range(8)]
+    trk = orc.Tracker(1241, 376, pkg.KITTI_00_02)
+    svo = pkg.Svo(1241, 376, max_batch=1)
+    svo.set_option("epnp_exact", 1)
+    svo.track_reset(pkg.Camera(**pkg.KITTI_00_02))
+    gpu, ref = [], []
+    for Lk, Rk in frames:
+        ref.append(trk.track(Lk, Rk))
+        res = svo.track_frame(Lk, Rk)
+        gpu.append((res.copy(), svo.debug_track_matches()))
+    trk.close(); svo.close()
+    for k, ((res, cur), (rr, rcur)) in enumerate(zip(gpu, ref)):
+        for f in COUNTERS + ("lm_iterations",):
+            assert res[f] == rr[f], (k, f, int(res[f]), int(rr[f]))
+        assert np.array_equal(cur[:rr["n_kp"]], rcur[:rr["n_kp"]]), k
+        T, Tr = res["Tcw"].reshape(4, 4), rr["Tcw"].reshape(4, 4)
+        assert np.abs(T[:3, 3] - Tr[:3, 3]).max() < POSE_TOL_T * (1 + k) and np.abs(T[:3, :3] - Tr[:3, :3]).max() < POSE_TOL_R * (1 + k), k
+    rec = np.array([g[0] for g in gpu])
+    assert rec["n_kp"].min() > 400 and rec["n_stereo"].min() > 150          # real texture: plenty of corners and stereo matches
+    assert (rec["n_match_pass1"][1:] > 10).all() and rec["n_lm_edges"][1:].min() >= 10

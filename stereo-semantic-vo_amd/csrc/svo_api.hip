@@ -196,7 +196,7 @@ extern "C" int svo_create(svo_ctx** out, int device, int W, int H, int max_kp, i
   const SvoGeom& g = ctx->g;
   for (int l = 0; l < SVO_NLEVELS; ++l)
     if (g.quota[l] > SVO_QMAX) { delete ctx; return SVO_E_INVALID; }
-  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (svo_stream_create(&ctx->stream, +1) != hipSuccess) {
     delete ctx;
     return SVO_E_NODEVICE;
   }
@@ -834,7 +834,7 @@ extern "C" int svo_frontend_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, cons
   while ((int)ctx->fe_streams.size() < ns - 1) {
     hipStream_t st;
     hipEvent_t e;
-    SVO_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    SVO_HIP(ctx, svo_stream_create(&st, 0));
     ctx->fe_streams.push_back(st);
     SVO_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     ctx->fe_events.push_back(e);
@@ -879,6 +879,13 @@ extern "C" int svo_profile_get(svo_ctx* ctx, int index, char* name, int name_cap
   if (total_ms) *total_ms = e.total_ms;
   if (launches) *launches = e.launches;
   return SVO_OK;
+}
+
+hipError_t svo_stream_create(hipStream_t* st, int role) {
+  int least = 0, greatest = 0;   // numerically: greatest priority <= least priority
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+  const int prio = role > 0 ? greatest : (role < 0 ? least : (least + greatest) / 2);
+  return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
 }
 
 int svo_host_cpus() {

@@ -187,6 +187,9 @@ template <typename T>
 __host__ __device__ inline T* svo_byte_offset(T* p, size_t bytes) {
   return p ? reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + bytes) : p;
 }
+// Streams by role: +1 the ordered tail's chains (small dependent kernels whose workgroups must not queue behind the front end's
+// thousands), -1 the batched front end running beside it, 0 everything else.  Maps onto the device's stream-priority range.
+hipError_t svo_stream_create(hipStream_t* st, int role);
 int svo_frontend_nslices(const svo_ctx* ctx, int B);   // how svo_frontend_batch_dev slices a batch (svo_api.hip)
 int svo_launch_disp2depth(svo_ctx* ctx, const float* disp, int count, float bf, float* depth);
 int svo_launch_unproject(svo_ctx* ctx, const float* uvz, int n, const svo_camera* cam,

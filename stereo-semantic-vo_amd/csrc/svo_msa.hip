@@ -814,7 +814,7 @@ static int msa_solve_device(svo_ctx* ctx, hipStream_t s, DevBuf& buf, uint8_t* c
   // check: their level sweeps - two chains of ~2 x 1000 small dependent launches - run side by side on two streams, with
   // their own work volumes, instead of one after the other.
   {
-    if (!ctx->stream_fe) SVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_fe, hipStreamNonBlocking));
+    if (!ctx->stream_fe) SVO_HIP(ctx, svo_stream_create(&ctx->stream_fe, -1));
     hipStream_t s2 = ctx->stream_fe;
     hipEvent_t e0, e1;
     SVO_HIP(ctx, hipEventCreateWithFlags(&e0, hipEventDisableTiming));

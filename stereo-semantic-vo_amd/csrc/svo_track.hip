@@ -1114,7 +1114,7 @@ void svo_track_release(svo_ctx* ctx) {
 
 // streams, events, work records and the kernels' LDS opt-ins for `frames` frames per call of `nseq` sequences
 static int track_resources(svo_ctx* ctx, int frames, int nseq) {
-  if (!ctx->stream_idx) SVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_idx, hipStreamNonBlocking));
+  if (!ctx->stream_idx) SVO_HIP(ctx, svo_stream_create(&ctx->stream_idx, +1));
   if (!ctx->ev_frontend) SVO_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_frontend, hipEventDisableTiming));
   while ((int)ctx->ev_frame.size() < frames) {
     hipEvent_t e;
@@ -1430,7 +1430,7 @@ extern "C" int svo_track_multi_step_dev(svo_ctx* ctx, const uint8_t* d_grayL, co
       ctx->ms_cap = n_seq;
     }
     if ((rc = track_resources(ctx, 1, n_seq))) return rc;   // streams and events exist from here on
-    if (!ctx->stream_fe) SVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_fe, hipStreamNonBlocking));
+    if (!ctx->stream_fe) SVO_HIP(ctx, svo_stream_create(&ctx->stream_fe, -1));
     const int p = ctx->ms_parity;
     if (ctx->ms_tail_recorded[p]) {
       SVO_HIP(ctx, hipStreamWaitEvent(ctx->stream_fe, ctx->ms_tail_done[p], 0));   // the tail that read this set two steps ago
@@ -1505,7 +1505,7 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
     rc = track_resources(ctx, B, 1);
     if (rc) return rc;
     const int SUB = 32, nsub = (B + SUB - 1) / SUB;
-    if (!ctx->stream_fe) SVO_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream_fe, hipStreamNonBlocking));
+    if (!ctx->stream_fe) SVO_HIP(ctx, svo_stream_create(&ctx->stream_fe, -1));
     while ((int)ctx->ev_sub.size() < nsub) {
       hipEvent_t e;
       SVO_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));

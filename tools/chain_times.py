@@ -37,4 +37,5 @@ for c in range(1, NC):
         c, (fr_e[-1] - idx_s[0]) / 1e3, (fr_e[-1] - idx_s[0]) / B, pose_busy.mean(), np.median(pose_busy), pose_gap.mean(), np.median(pose_gap)))
     print("   first k_tp_hyp starts %.0f us after the call's first k_ti_resolve; index chain: busy %.1f us/frame, ahead of the pose chain by (frames) %s" % (
         hyp_s[0], (idx_e - idx_s).mean(), [int(np.searchsorted(idx_e, hyp_s[f]) - f) for f in (0, 20, 50, 100, 150, B - 1)]))
+    print("   frame period (pose-kernel end to end): mean %.1f median %.1f us; largest 5: %s" % (np.diff(fr_e).mean(), np.median(np.diff(fr_e)), np.sort(np.diff(fr_e))[-5:].round(0)))
     print("   pose chain waiting for the index chain: %.1f us/frame (frames with a wait > 2 us: %d)" % (stall_idx.mean(), int((stall_idx > 2).sum())))

@@ -58,8 +58,8 @@
 #define TRK_GPOS (1 << 20)       // map-point position table: ring over map-point ids
 #define TRK_DNC 24                // dense rows whose distance row is cached in LDS during a pass
 #define TRK_DENSE 0xFF           // ncand marker: more than `lcap` candidates, the row's distances are in D
-#define TI_SEQ_MAX 24            // a pass with at most this many unresolved rows after a round is finished row by row on one wave
-#define TI_SEQ_DMAX 24           //   (a row costs ~0.5 us there, a round ~4 us whatever it resolves); dense ones: distance rows in LDS
+#define TI_SEQ_MAX 128           // a pass with at most this many unresolved rows after a round is finished row by row on one wave
+#define TI_SEQ_DMAX 40           //   ... of which at most this many dense ones (their distance rows go to LDS)
 
 struct TrackPool {
   alignas(16) uint32_t desc[TRK_CAP * 8];
@@ -619,7 +619,6 @@ __device__ __forceinline__ int ti_resolve_pass(TiLds& S, TrackState* st, TrackPo
         // every stored blocker has been claimed and there were more (rare): from now on a wave evaluates this row
         // from its full distance row
         S.fin[k] = 0;
-        S.act_n[k] = TRK_DENSE;              // (the row-by-row finish tells thread rows from dense ones by this)
         S.dn[atomicAdd(&S.nd, 1)] = (uint16_t)k;
         atomicAdd(&S.unres[rounds & 1], 1); atomicAdd(&S.unresd[rounds & 1], 1);   // still unresolved, as a dense row from now on
       }

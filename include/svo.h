@@ -144,9 +144,6 @@ void svo_destroy(svo_ctx* ctx);
  * can force that path.
  * "track_nblk" (default 3, the maximum): runner-up blockers stored with each packed entry; with fewer the matching passes
  * consult the full distance row more often - same results, a test switch like "track_lcap".
- * "track_seq_finish" (default 1): once a matching pass has at most 128 unresolved rows left after a round (links of
- * dependency chains, one resolved per round), one wave finishes them row by row in row order - the reference's own scan,
- * no barriers; 0: rounds to the end - same results, a test switch.
  * "frontend_overlap" (default 2, 0..8): slices of a batch svo_frontend_batch_dev runs side by side on their own streams
  * (scheduling only; 0 / 1: one chain; also one chain while svo_profile_enable is on, so that per-kernel times are those of
  * kernels running alone).

@@ -334,7 +334,6 @@ extern "C" int svo_set_option(svo_ctx* ctx, const char* key, int value) {
     ctx->opt_track_group = value;
     return SVO_OK;
   }
-  if (!strcmp(key, "track_seq_finish")) { ctx->opt_track_seq_finish = value != 0; return SVO_OK; }
   if (!strcmp(key, "track_lcap")) {
     if (value < 1 || value > 8) return SVO_E_INVALID;
     ctx->opt_track_lcap = value;

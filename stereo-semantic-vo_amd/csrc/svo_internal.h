@@ -124,7 +124,6 @@ struct svo_ctx {
   std::vector<hipEvent_t> fe_events;     // ... and completion events
   int opt_track_group = 4;      // svo_set_option("track_group"): most frames the pose chain takes over per stream event (1..64)
   int opt_track_nblk = 3;       // svo_set_option("track_nblk"): runner-up blockers stored per packed entry (0..3)
-  int opt_track_seq_finish = 1; // svo_set_option("track_seq_finish"): finish a matching pass row by row on one wave once few rows are left
   int opt_track_lcap = 8;       // svo_set_option("track_lcap"): packed entries a map point keeps before it goes "dense" (1..8)
   void* elas = nullptr;     // ElasState (svo_elas.hip), allocated on first svo_elas_process
   void* elas_batch = nullptr;   // ElasBatch: per-pair states of svo_elas_batch_dev

@@ -58,8 +58,6 @@
 #define TRK_GPOS (1 << 20)       // map-point position table: ring over map-point ids
 #define TRK_DNC 24                // dense rows whose distance row is cached in LDS during a pass
 #define TRK_DENSE 0xFF           // ncand marker: more than `lcap` candidates, the row's distances are in D
-#define TI_SEQ_MAX 128           // a pass with at most this many unresolved rows after a round is finished row by row on one wave
-#define TI_SEQ_DMAX 40           //   ... of which at most this many dense ones (their distance rows go to LDS)
 
 struct TrackPool {
   alignas(16) uint32_t desc[TRK_CAP * 8];
@@ -293,13 +291,6 @@ struct TiLds {
   int32_t boxes[SVO_MAX_BOXES * 4];   // the frame's detection boxes {left, right, top, bottom}
   uint16_t dn[TRK_CAP];            // dense active rows of the running pass
   uint16_t dnD[TRK_DNC][512];      // distance rows of the first TRK_DNC of them (fetched once per pass)
-  // sequential finish of a pass (ti_resolve_pass): the rows still unresolved, as a bitmap over the active rows, the packed
-  // entries of the thread rows among them, the distance rows of the dense ones (slot of a dense row: remap[], idle here)
-  int unres[2], unresd[2], seq_n, seq_nd, seq_go;
-  uint32_t seq_bits[TRK_CAP / 32];
-  uint16_t seq_slot[1024];
-  alignas(16) uint32_t seq_ent[TI_SEQ_MAX][16];
-  alignas(16) uint16_t seqD[TI_SEQ_DMAX][512];
 };
 
 // ---- one greedy pass, resolved in rounds -----------------------------------------------------------
@@ -410,87 +401,13 @@ __device__ __forceinline__ uint4 ti_dense_piece(TiLds& S, const TrackState* st, 
   return v;
 }
 
-// ---- the tail of a pass, row by row -------------------------------------------------------------------------------
-// Once few rows are left they are mostly links of dependency chains - row k waits for row k - 1 which waits for ... - and
-// every round resolves one link for two workgroup barriers.  ONE wave then walks the remaining rows in row order instead:
-// when row k's turn comes every earlier row is final, so its scan is the reference's own (src/pnpmatch.cc:75-94) over
-// the columns no earlier row holds - no publishing, no barriers, ~300 cycles per row.
-// A dense row: lane l holds the distances of columns 8 l .. 8 l + 7.  Returns (wave-uniform) nothing; claims through ti_finalize.
-template <int PASS>
-__device__ __forceinline__ void ti_seq_dense(TiLds& S, TrackState* st, TrackPool& P, const uint32_t (&dd)[8], int kk, int m,
-                                             int lane, int nkp, int rounds, const svo_kp* kp, int n_boxes, int& tally) {
-  constexpr int max_dist = PASS == 1 ? 15 : 30;
-  uint32_t cl[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) cl[c] = S.claimer[lane * 8 + c];
-  uint32_t am = 0;
-#pragma unroll
-  for (int c = 0; c < 8; ++c)
-    if (lane * 8 + c < nkp && (int)cl[c] > kk + 1) am |= 1u << c;
-  uint32_t key = 0xffffffffu;
-#pragma unroll
-  for (int c = 0; c < 8; ++c)
-    if (((am >> c) & 1u) && (int)dd[c] < max_dist) key = min(key, (dd[c] << 16) | (uint32_t)(lane * 8 + c));
-  key = wave_min_u32_dpp(key);
-  if (key == 0xffffffffu) return;
-  const int bj = (int)(key & 0xffffu), bd = (int)(key >> 16);
-  bool blk = false;
-  if (PASS == 2) {
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-      if (((am >> c) & 1u) && lane * 8 + c < bj && (int)dd[c] <= 2 * bd) blk = true;
-  }
-  const bool ok = __ballot(blk) == 0;
-  if (lane == 0) ti_finalize<PASS>(S, st, P, kk, m, bj, 0xffffffffu, ok, true, rounds, kp, n_boxes, tally);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the claim is in LDS before the next row of this wave reads it
-  __builtin_amdgcn_wave_barrier();
-}
-// A thread row (packed entries in S.seq_ent[slot]: lanes 0..7 take one entry each).
-template <int PASS>
-__device__ __forceinline__ void ti_seq_thread_row(TiLds& S, TrackState* st, TrackPool& P, int k, int slot, int lane, int nkp,
-                                                  int rounds, const svo_kp* kp, int n_boxes, int& tally) {
-  constexpr int max_dist = PASS == 1 ? 15 : 30;
-  const int m = S.act_m[k], nc = S.act_n[k];
-  const int i = lane & 7;
-  const uint32_t w0 = S.seq_ent[slot][i], w1 = S.seq_ent[slot][8 + i];
-  const uint32_t col = w0 & 511u, d = (w0 >> 9) & 31u;
-  const bool av = lane < 8 && i < nc && (int)d < max_dist && (int)S.claimer[col] > k + 1;
-  const uint32_t key = wave_min_u32_dpp(av ? ((d << 16) | col) : 0xffffffffu);
-  if (key == 0xffffffffu) return;                       // nothing left to claim: never accepted
-  const uint32_t bj = key & 0xffffu, bd = key >> 16;
-  bool ok = true;
-  if (PASS == 2) {
-    // blockers inside the list, and the stored ones of the best entry (columns outside the list, distance in [30, 2 best])
-    bool blk = av && col < bj && d <= 2 * bd;
-    bool need_row = false;
-    if (av && col == bj) {
-      const uint32_t nb = (w0 >> 14) & 3u;
-      bool any = false;
-      for (uint32_t q = 0; q < nb; ++q) any = any || (int)S.claimer[(w1 >> (9 * q)) & 511u] > k + 1;
-      blk = blk || any;
-      need_row = !any && ((w0 >> 16) & 1u);             // all stored blockers are taken and there were more: ask the full row
-    }
-    const bool blocked = __ballot(blk) != 0;
-    if (!blocked && __ballot(need_row) != 0) {
-      uint32_t dd[8];
-      ti_unpack8(*reinterpret_cast<const uint4*>(st->D + (size_t)m * 512 + lane * 8), dd);
-      ti_seq_dense<PASS>(S, st, P, dd, k, m, lane, nkp, rounds, kp, n_boxes, tally);
-      return;
-    }
-    ok = !blocked;
-  }
-  if (lane == 0) ti_finalize<PASS>(S, st, P, k, m, (int)bj, 0xffffffffu, ok, true, rounds, kp, n_boxes, tally);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-}
-
 // Dense rows are dealt round-robin to the 16 waves (list position q -> wave q % 16).  A wave keeps its FIRST dense row
 // (q = wave id: all of them on ordinary frames) in registers for the whole pass - row ids, the 16 bytes of distances per
 // lane, the resolved flag - so that a round costs it one LDS round trip per phase; the rows after that go through the
 // LDS cache dnD (list positions 16 .. 16 + TRK_DNC - 1) or, beyond it, the distance rows in HBM.
 template <int PASS>
 __device__ __forceinline__ int ti_resolve_pass(TiLds& S, TrackState* st, TrackPool& P, int n_act, int nkp,
-                                               const svo_kp* kp, int n_boxes, int* n_acc, int* n_veto, int* n_late, int seq_finish) {
+                                               const svo_kp* kp, int n_boxes, int* n_acc, int* n_veto, int* n_late) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   constexpr int max_dist = PASS == 1 ? 15 : 30;
   // ---- set-up: my row's entries into registers; dense rows into a list ------------------------
@@ -500,10 +417,7 @@ __device__ __forceinline__ int ti_resolve_pass(TiLds& S, TrackState* st, TrackPo
 #pragma unroll
   for (int i = 0; i < TRK_LCAP; ++i) { w0[i] = 0; w1[i] = 0; }
   bool unresolved = false;
-  if (tid == 0) {
-    S.nd = 0; S.flag[0] = 0; S.flag[1] = 0; S.cnt_acc = 0; S.cnt_veto = 0; S.cnt_late = 0;
-    S.unres[0] = 0; S.unres[1] = 0; S.unresd[0] = 0; S.unresd[1] = 0; S.seq_n = 0; S.seq_nd = 0; S.seq_go = 0;
-  }
+  if (tid == 0) { S.nd = 0; S.flag[0] = 0; S.flag[1] = 0; S.cnt_acc = 0; S.cnt_veto = 0; S.cnt_late = 0; }
   if (tid < TRK_MAXKP) { S.minrow[0][tid] = 0xffffffffu; S.minrow[1][tid] = 0xffffffffu; }
   __syncthreads();
   for (int kk = tid; kk < n_act; kk += 1024) {
@@ -575,7 +489,7 @@ __device__ __forceinline__ int ti_resolve_pass(TiLds& S, TrackState* st, TrackPo
     __syncthreads();
     if (!S.flag[rounds & 1]) break;
     if (tid < TRK_MAXKP) S.minrow[(rounds & 1) ^ 1][tid] = 0xffffffffu;
-    if (tid == 0) { S.flag[(rounds & 1) ^ 1] = 0; S.unres[(rounds & 1) ^ 1] = 0; S.unresd[(rounds & 1) ^ 1] = 0; }
+    if (tid == 0) S.flag[(rounds & 1) ^ 1] = 0;
     // ---- phase 2: rows whose outcome no earlier unresolved row can change are final -------------
     if (unresolved) {
       // the best free entry (first minimum in column order); everything the decision may need from LDS is requested
@@ -620,7 +534,6 @@ __device__ __forceinline__ int ti_resolve_pass(TiLds& S, TrackState* st, TrackPo
         // from its full distance row
         S.fin[k] = 0;
         S.dn[atomicAdd(&S.nd, 1)] = (uint16_t)k;
-        atomicAdd(&S.unres[rounds & 1], 1); atomicAdd(&S.unresd[rounds & 1], 1);   // still unresolved, as a dense row from now on
       }
       if (none || to_dense) unresolved = false;
       else if (ti_finalize<PASS>(S, st, P, k, my_m, (int)bj, mrbj, !blocked, perm != 0, rounds, kp, n_boxes, tally)) unresolved = false;
@@ -639,72 +552,10 @@ __device__ __forceinline__ int ti_resolve_pass(TiLds& S, TrackState* st, TrackPo
 #pragma unroll
       for (int c = 0; c < 8; ++c)
         if (lane * 8 + c < nkp && (int)cl[c] > kk + 1) am |= 1u << c;
-      const bool f = ti_dense_decide<PASS>(S, minrow, st, P, dd, am, kk, m, lane, rounds, kp, n_boxes, tally);
-      if (lane == 0) { if (f) S.fin[kk] = 1; else { atomicAdd(&S.unres[rounds & 1], 1); atomicAdd(&S.unresd[rounds & 1], 1); } }
-    }
-    {   // rows this round left unresolved: one LDS atomic per wave
-      const int u = __popcll(__ballot(unresolved));
-      const int ud = (wv < nd && r_kk >= 0 && !r_fin) ? 1 : 0;
-      if (lane == 0 && u + ud > 0) { atomicAdd(&S.unres[rounds & 1], u + ud); if (ud) atomicAdd(&S.unresd[rounds & 1], 1); }
+      if (ti_dense_decide<PASS>(S, minrow, st, P, dd, am, kk, m, lane, rounds, kp, n_boxes, tally) && lane == 0) S.fin[kk] = 1;
     }
     __syncthreads();
     ncached = nd1;
-    // ---- few rows left: finish them row by row on one wave (see ti_seq_thread_row) --------------------------------
-    const int n_un = S.unres[rounds & 1], n_und = S.unresd[rounds & 1];
-    if (seq_finish && n_un > 0 && n_un <= TI_SEQ_MAX && n_und <= TI_SEQ_DMAX) {
-      const int ndn = S.nd;                                  // rows may have joined the dense list in this round
-      for (int w = tid; w < TRK_CAP / 32; w += 1024) S.seq_bits[w] = 0;
-      __syncthreads();
-      if (unresolved) {
-        atomicOr(&S.seq_bits[k >> 5], 1u << (k & 31));
-        const int slot = atomicAdd(&S.seq_n, 1);
-        S.seq_slot[k] = (uint16_t)slot;
-#pragma unroll
-        for (int i = 0; i < TRK_LCAP; ++i) { S.seq_ent[slot][i] = w0[i]; S.seq_ent[slot][8 + i] = w1[i]; }
-      }
-      if (wv < ndn && !r_fin) {
-        if (r_kk < 0) {                                      // joined the list in this very round: not fetched yet
-          r_kk = S.dn[wv]; r_m = S.act_m[r_kk];
-          ti_unpack8(*reinterpret_cast<const uint4*>(st->D + (size_t)r_m * 512 + lane * 8), r_dd);
-        }
-        int ds = 0;
-        if (lane == 0) { atomicOr(&S.seq_bits[r_kk >> 5], 1u << (r_kk & 31)); ds = atomicAdd(&S.seq_nd, 1); S.remap[r_kk] = (int16_t)ds; }
-        ds = __builtin_amdgcn_readfirstlane(ds);
-        uint4 v;
-        v.x = r_dd[0] | (r_dd[1] << 16); v.y = r_dd[2] | (r_dd[3] << 16); v.z = r_dd[4] | (r_dd[5] << 16); v.w = r_dd[6] | (r_dd[7] << 16);
-        *reinterpret_cast<uint4*>(&S.seqD[ds][lane * 8]) = v;
-      }
-      for (int q = wv + 16; q < ndn; q += 16) {
-        const int kk = S.dn[q];
-        if (S.fin[kk]) continue;
-        const int m = S.act_m[kk];
-        const uint4 v = ti_dense_piece(S, st, q - 16, m, lane, ncached);
-        int ds = 0;
-        if (lane == 0) { atomicOr(&S.seq_bits[kk >> 5], 1u << (kk & 31)); ds = atomicAdd(&S.seq_nd, 1); S.remap[kk] = (int16_t)ds; }
-        ds = __builtin_amdgcn_readfirstlane(ds);
-        *reinterpret_cast<uint4*>(&S.seqD[ds][lane * 8]) = v;
-      }
-      __syncthreads();
-      if (wv == 0) {
-        for (int w = 0; w < TRK_CAP / 32; ++w) {
-          uint32_t bits = S.seq_bits[w];
-          while (bits) {
-            const int kk = 32 * w + __ffs((int)bits) - 1;
-            bits &= bits - 1;
-            if (kk < 1024 && S.act_n[kk] != TRK_DENSE) {
-              ti_seq_thread_row<PASS>(S, st, P, kk, S.seq_slot[kk], lane, nkp, rounds + 1, kp, n_boxes, tally);
-            } else {
-              uint32_t dd[8];
-              ti_unpack8(*reinterpret_cast<const uint4*>(&S.seqD[S.remap[kk]][lane * 8]), dd);
-              ti_seq_dense<PASS>(S, st, P, dd, kk, S.act_m[kk], lane, nkp, rounds + 1, kp, n_boxes, tally);
-            }
-          }
-        }
-      }
-      __syncthreads();
-      ++rounds;
-      break;
-    }
     ++rounds;
   }
   // what this pass claimed is simply taken for the next pass
@@ -729,7 +580,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char tk_smem[];
 // boxes / nboxes (nullable): the detection boxes of this frame - of sequence blockIdx.y: `bstride` boxes further on each
 __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* work, const svo_kp* kp,
                                                      const uint32_t* desc, const int32_t* nkp_p, const float* depth,
-                                                     int kstride, const int32_t* boxes, const int32_t* nboxes, int bstride, int seq_finish) {
+                                                     int kstride, const int32_t* boxes, const int32_t* nboxes, int bstride) {
   TiLds& S = *reinterpret_cast<TiLds*>(tk_smem);
   st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
   desc += (size_t)blockIdx.y * kstride * 8; nkp_p += blockIdx.y; depth += (size_t)blockIdx.y * kstride;
@@ -789,7 +640,7 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
       if (act) { S.act_m[k] = (uint16_t)m; S.act_i[k] = (uint16_t)tid; S.act_n[k] = st->ncand[m]; }
       __syncthreads();
       int late1;
-      rounds1 = ti_resolve_pass<1>(S, st, P, n_act1, nkp, kp, n_boxes, &n_pass1, &n_veto, &late1, seq_finish);
+      rounds1 = ti_resolve_pass<1>(S, st, P, n_act1, nkp, kp, n_boxes, &n_pass1, &n_veto, &late1);
     }
     // ---- pass 2 (src/pnpmatch.cc:159-199): local map points not observed by this frame -------
     ts2 = clock64();
@@ -819,7 +670,7 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
         }
       __syncthreads();
       int veto2;
-      rounds2v = ti_resolve_pass<2>(S, st, P, n_act2, nkp, kp, 0, &n_pass2, &veto2, &late2, seq_finish);
+      rounds2v = ti_resolve_pass<2>(S, st, P, n_act2, nkp, kp, 0, &n_pass2, &veto2, &late2);
     }
     if (tid < nkp && S.cur_mp[tid] >= 0) edge_gid = P.gid[S.cur_mp[tid]];
   }
@@ -1345,7 +1196,7 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
     {
       SvoTimer t(ctx, "k_ti_resolve", s1);
       hipLaunchKernelGGL(k_ti_resolve, dim3(1, ny), dim3(1024), sizeof(TiLds), s1, st, work + f, kpf, descf, nkpf, depf, kstride,
-                         bxf, nbf, bstride, ctx->opt_track_seq_finish);
+                         bxf, nbf, bstride);
     }
   };
   auto enqueue_pose = [&](int f) {

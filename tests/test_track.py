@@ -370,8 +370,10 @@ def test_tracking_is_independent_of_how_the_sequence_is_batched(pkg):
     rec = pkg.TRACK_DTYPE.itemsize
     fb = H * pitch
 
-    def run(chunk):
+    def run(chunk, **opts):
         s = pkg.Svo(W, H, max_batch=chunk)
+        for key, v in opts.items():
+            s.set_option(key, v)
         s.track_reset(cam)
         res = torch.zeros((N, rec), dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
@@ -384,6 +386,9 @@ def test_tracking_is_independent_of_how_the_sequence_is_batched(pkg):
 
     a = run(64)
     assert a == run(64) and a == run(16) and a == run(1)
+    # strategy switches never change a record: one packed entry per row (everything "dense"), no stored blockers, the
+    # pose chain taking frames over one by one or sixteen at a time
+    assert a == run(64, track_lcap=1) and a == run(64, track_nblk=0) and a == run(64, track_group=1) and a == run(64, track_group=16)
     r = np.frombuffer(a, pkg.TRACK_DTYPE)
     Twc = np.linalg.inv(r[-1]["Tcw"].reshape(4, 4).astype(np.float64))
     assert np.linalg.norm(Twc[:3, 3] - T[-1][:3, 3].cpu().numpy()) < 3.0      # 63 m path, no loop closing

@@ -1644,7 +1644,8 @@ struct ShardGather {
   // staging on the tail context's device: region g (frames g, g + G, ... of a call, `per` rows) holds what context g produced
   svo_kp* kp = nullptr; uint8_t* desc = nullptr; int32_t* n = nullptr; float* depth = nullptr;
   int per = 0, G = 0;
-  std::vector<hipEvent_t> ev;         // front end (and staging copies) of context g finished
+  std::vector<hipEvent_t> ev;         // front end (and staging copies) of context g finished; created ON context g's device
+  std::vector<int> ev_dev;            //   (an event is recorded on a stream of its own device only) - that device
   hipEvent_t ev_prev = nullptr;       // what the tail context's stream held when the call began
   uint8_t* h_stage = nullptr;         // pinned bounce buffer for contexts whose device the tail's device cannot read directly
   size_t h_bytes = 0;
@@ -1713,11 +1714,15 @@ extern "C" int svo_track_sharded_dev(svo_ctx* const* ctxs, int G, const uint8_t*
     sg->per = per; sg->G = G;
   }
   const int rper = sg->per;   // rows per region (may be larger than this call needs)
-  while ((int)sg->ev.size() < G) {
+  for (int g = 0; g < G; ++g) {
+    if (g < (int)sg->ev.size() && sg->ev_dev[g] == ctxs[g]->device) continue;
+    hipSetDevice(ctxs[g]->device);
     hipEvent_t e;
-    SVO_HIP(c0, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    sg->ev.push_back(e);
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { hipSetDevice(c0->device); return SVO_E_HIP; }
+    if (g < (int)sg->ev.size()) { hipEventDestroy(sg->ev[g]); sg->ev[g] = e; sg->ev_dev[g] = ctxs[g]->device; }
+    else { sg->ev.push_back(e); sg->ev_dev.push_back(ctxs[g]->device); }
   }
+  hipSetDevice(c0->device);
   if (!sg->ev_prev) SVO_HIP(c0, hipEventCreateWithFlags(&sg->ev_prev, hipEventDisableTiming));
   // How the tail's device reaches each producer's results: the same device, a direct peer read over xGMI (checked on every
   // call - the contexts of a call may change), or a bounce through pinned host memory when the platform offers no peer access.

@@ -1749,7 +1749,7 @@ extern "C" int svo_track_sharded_dev(svo_ctx* const* ctxs, int G, const uint8_t*
     SVO_HIP(c0, hipStreamSynchronize(c0->stream));
     if (sg->h_stage) hipHostFree(sg->h_stage);
     sg->h_stage = nullptr; sg->h_bytes = 0;
-    if (hipHostMalloc(reinterpret_cast<void**>(&sg->h_stage), region_bytes * G) != hipSuccess) { (void)hipGetLastError(); return SVO_E_NOMEM; }
+    if (hipHostMalloc(reinterpret_cast<void**>(&sg->h_stage), region_bytes * G, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return SVO_E_NOMEM; }   // (portable: every producer's device copies into it)
     sg->h_bytes = region_bytes * G;
   }
   // front ends: context g extracts and matches its pairs k = g, g + G, ... on its own device and stream.  A context's

@@ -48,8 +48,8 @@ ALGO_BYTES_PER_PAIR = 14.0e6         # SURVEY.md section 8d / BASELINE.md sectio
 # per-kernel algorithmic bytes per IMAGE (terms of the SURVEY 8d traffic model)
 KERNEL_BYTES_PER_IMAGE = {
     "k_fast": S_PYR * W * H,                      # "S [FAST read]"
-    "k_pyr_level": (1 + (S_PYR - 1)) * W * H,     # "1 [src read] + (S-1) [pyramid write]"
-    "k_pyr_fused": (1 + (S_PYR - 1)) * W * H,
+    "k_pyr_level": (1 + (S_PYR - 1)) * W * H,     # "1 [src read] + (S-1) [pyramid write]" - the pyramid's launches together
+    "k_pyr_fused": (1 + (S_PYR - 1)) * W * H,     #   (three fused launches by default, seven with pyr_fused = 0)
     "k_select": 2 * 500 * 81,                     # Harris: 2N 9x9 windows
     "k_describe": 500 * 37 * 37 + 500 * 60,       # patch gathers + keypoint / descriptor records
 }
@@ -584,7 +584,10 @@ def semantic_elas_leg(pkg, cam, dL, dR, dev, rec, n=256):
     svo.profile_enable(False)
     prof = svo.profile()
     svo.close()
-    kern = {k: v[0] * 1e3 / n for k, v in prof.items() if k.startswith("k_") and v[1] > 0}
+    # us per frame: batched kernels by their total over the call, the tail's per-frame kernels (timed on every 32nd frame only)
+    # by their average launch
+    kern = {k: (v[0] * 1e3 / v[1] if k.startswith(("k_ti_", "k_tp_", "k_tg_")) else v[0] * 1e3 / n)
+            for k, v in prof.items() if k.startswith("k_") and v[1] > 0}
     P = W * H
     algo = {"k_elas_desc": 34 * P, "k_elas_match": 48 * P, "k_elas_raster": 8 * P, "k_cc_segments": 28 * P, "k_elas_gap": 16 * P,
             "k_elas_support": 32 * P, "k_elas_lr": 16 * P, "k_elas_mean": 16 * P}

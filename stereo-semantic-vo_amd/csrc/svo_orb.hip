@@ -938,8 +938,9 @@ int svo_launch_orb(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR,
   hipStream_t st = ctx->stream;
   SVO_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(int32_t) * (size_t)nimg * SVO_NLEVELS, st));
   {
-    SvoTimer t(ctx, "k_pyr_level");
-    if (ctx->opt_pyr_fused && !ctx->pyr_plan.empty()) {
+    const bool fused = ctx->opt_pyr_fused && !ctx->pyr_plan.empty();
+    SvoTimer t(ctx, fused ? "k_pyr_fused" : "k_pyr_level");   // one timer around the pyramid's launches (three fused ones, or seven)
+    if (fused) {
       for (const SvoPyrGroup& pg : ctx->pyr_plan) {
         const int lt = pg.l0 + pg.nl - 1;
         const dim3 grid((g.h[lt] + pg.rt - 1) / pg.rt, nimg);

@@ -6,9 +6,10 @@ import sys
 
 for path in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(path)):
-        n = r["Name"].split("(")[0]
+        n = r["Name"]
         if n.startswith("void "):
             n = n[5:]
+        n = n.replace("(anonymous namespace)::", "").split("(")[0]
         n = n.split("<")[0]          # template instances of one kernel are reported under its name
         if n.startswith("k_"):
             print("%-20s calls %6s avg_us %9.1f min %8.1f max %8.1f total_ms %8.2f" % (

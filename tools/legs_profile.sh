@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/lp_*
-E="$R/tools/elas_batch_bench.py --batch 64 --iters 2 --synth"
+E="$R/tools/elas_batch_bench.py --batch 64 --iters 2"   # (the urban1 pair replicated: no renderer kernels in the profile)
 M="$R/tools/msa_profile_run.py"
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/lp_es -- python3 $E > /tmp/lp_es.log 2>&1
 python3 $R/tools/kstats.py /tmp/lp_es $OUT/${TAG}_elas_kernel_stats.csv | head -20

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/pmc_latest.json from the per-workload PMC summaries of tools/collect_profiles.sh:
-   python tools/merge_pmc.py <track_pmc.json> <frontend_pmc.json> [<legs_pmc.json>]
+   python tools/merge_pmc.py <track_pmc.json> <frontend_pmc.json> [<legs_pmc.json> ...]
 Front-end kernels are annotated with the pairs one dispatch covered when the counters were taken (the frontend workload runs
 128 pairs per step as two slices of 64), ELAS kernels with their chunk of 32 pairs, so that bench.py can scale
 FETCH_SIZE / WRITE_SIZE to the batch it runs."""
@@ -13,7 +13,9 @@ FRONT = ("k_pyr_fused", "k_pyr_level", "k_fast", "k_select", "k_describe", "k_st
 out = {}
 track = json.load(open(sys.argv[1]))
 front = json.load(open(sys.argv[2]))
-legs = json.load(open(sys.argv[3])) if len(sys.argv) > 3 else {}
+legs = {}
+for f in sys.argv[3:]:
+    legs.update(json.load(open(f)))
 for k, v in legs.items():                       # traffic counters only (FETCH_SIZE / WRITE_SIZE passes)
     if k.startswith(("k_elas", "k_cc_")):
         v["_pairs_per_dispatch_traffic"] = 32

@@ -14,9 +14,10 @@ def main(dirs, out):
         for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             with open(path) as f:
                 for row in csv.DictReader(f):
-                    name = row["Kernel_Name"].split("(")[0]
+                    name = row["Kernel_Name"]
                     if name.startswith("void "):
                         name = name[5:]
+                    name = name.replace("(anonymous namespace)::", "").split("(")[0]
                     name = name.split("<")[0]          # template instances of one kernel under its name
                     if not name.startswith("k_"):
                         continue

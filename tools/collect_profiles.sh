@@ -24,6 +24,9 @@ elif [ "$WL" = "legs" ]; then
 else
   ARGS="--workload frontend --frames 1536 --steps 10 --warmup 2 --no-cpu-baseline --no-profile --no-legs $*"
 fi
+# counters only for the library's own kernels (k_...): the renderer's hundreds of thousands of elementwise launches would
+# each be serialised and read out otherwise (minutes per pass)
+KRE='(^|[^a-zA-Z0-9_])k_[a-z]'
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_*
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py $ARGS > /tmp/prof_stats.log 2>&1
@@ -32,12 +35,12 @@ P1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAV
 P2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM GRBM_GUI_ACTIVE"
 DIRS=""
 if [ $FULL = 1 ]; then
-  timeout 900 rocprofv3 --kernel-trace --pmc $P1 --output-format csv -d /tmp/prof_pmc1 -- python3 $R/bench.py $ARGS > /tmp/prof_pmc1.log 2>&1
-  timeout 900 rocprofv3 --kernel-trace --pmc $P2 --output-format csv -d /tmp/prof_pmc2 -- python3 $R/bench.py $ARGS > /tmp/prof_pmc2.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --kernel-include-regex "$KRE" --pmc $P1 --output-format csv -d /tmp/prof_pmc1 -- python3 $R/bench.py $ARGS > /tmp/prof_pmc1.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --kernel-include-regex "$KRE" --pmc $P2 --output-format csv -d /tmp/prof_pmc2 -- python3 $R/bench.py $ARGS > /tmp/prof_pmc2.log 2>&1
   DIRS="/tmp/prof_pmc1 /tmp/prof_pmc2"
 fi
-timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_pmc3 -- python3 $R/bench.py $ARGS > /tmp/prof_pmc3.log 2>&1
-timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_pmc4 -- python3 $R/bench.py $ARGS > /tmp/prof_pmc4.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --kernel-include-regex "$KRE" --pmc FETCH_SIZE --output-format csv -d /tmp/prof_pmc3 -- python3 $R/bench.py $ARGS > /tmp/prof_pmc3.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --kernel-include-regex "$KRE" --pmc WRITE_SIZE --output-format csv -d /tmp/prof_pmc4 -- python3 $R/bench.py $ARGS > /tmp/prof_pmc4.log 2>&1
 python3 $R/tools/pmc_summary.py $OUT/${TAG}_pmc.json $DIRS /tmp/prof_pmc3 /tmp/prof_pmc4 > $OUT/${TAG}_pmc.txt
 tail -12 $OUT/${TAG}_pmc.txt | cut -c1-300
 tail -3 /tmp/prof_stats.log | cut -c1-300

@@ -330,7 +330,10 @@ int svo_frontend_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* 
  * (frames are consecutive frames of ONE sequence, in order).  boxes (may be NULL): the frames' offline detection
  * boxes in HBM, gating the chain exactly as svo_track_frame's host boxes do (creation gates, F from brute-force
  * matches by the 8-point algorithm, epipolar veto - all on the device).  d_results: B
- * svo_track_result records in HBM.  Does not synchronise. */
+ * svo_track_result records in HBM.  Does not synchronise.  Consecutive calls overlap: the front end's outputs and the
+ * index chain's hand-over records exist twice and alternate, so the first sub-batches and the matching of call c + 1 run
+ * while the pose chain of call c is still busy.  Contract: the calls that continue one sequence are issued back to back
+ * on this context; svo_sync it before any OTHER entry point uses the context in between (svo_track_reset synchronises itself). */
 int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const uint8_t* d_grayR,
                         int stride, int B, const svo_boxes_dev* boxes, svo_track_result* d_results);
 

@@ -106,8 +106,16 @@ struct svo_ctx {
   int32_t* ms_nkp[2] = {nullptr, nullptr};
   float* ms_depth[2] = {nullptr, nullptr};
   hipEvent_t ms_fe_done[2] = {nullptr, nullptr}, ms_tail_done[2] = {nullptr, nullptr};
+  // svo_track_batch_dev: the front end's outputs exist twice and alternate between calls, so that the first sub-batches of call
+  // c + 1 run while the tail of call c is still reading its set (set 0 = the context's own arrays, set 1 allocated on demand)
+  svo_kp* tb_kp = nullptr; uint8_t* tb_desc = nullptr; int32_t* tb_nkp = nullptr;
+  float *tb_uR = nullptr, *tb_depth = nullptr; int32_t* tb_sad = nullptr;
+  hipEvent_t tb_done[2] = {nullptr, nullptr};   // the tail of the call that last used set p has finished
+  bool tb_used[2] = {false, false};
+  int tb_parity = 0;
   void* d_work = nullptr;       // TrackWork records (index chain -> pose chain), work_cap of them
-  int work_cap = 0;
+  int work_cap = 0;             // records per half (two halves are allocated)
+  int work_last_half = 0;       // the half the last tail call used (debug readers)
   hipStream_t stream_idx = nullptr;        // the pose-free index chain of the tracking tail runs here, ahead of the pose chain
   hipStream_t stream_fe = nullptr;         // svo_track_batch_dev: the front end of later sub-batches runs here, beside the tail
   std::vector<hipEvent_t> ev_sub;          // front end of sub-batch j finished (recorded on `stream_fe`)

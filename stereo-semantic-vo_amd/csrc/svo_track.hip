@@ -1087,8 +1087,23 @@ __global__ __launch_bounds__(TPF_NT) void k_tp_frame(TrackState* st, TrackWork* 
 // Host side
 // --------------------------------------------------------------------------------------------
 static void shard_gather_free(svo_ctx* ctx);
+static void track_batch_sets_free(svo_ctx* ctx) {
+  if (ctx->tb_kp) hipFree(ctx->tb_kp);
+  if (ctx->tb_desc) hipFree(ctx->tb_desc);
+  if (ctx->tb_nkp) hipFree(ctx->tb_nkp);
+  if (ctx->tb_uR) hipFree(ctx->tb_uR);
+  if (ctx->tb_depth) hipFree(ctx->tb_depth);
+  if (ctx->tb_sad) hipFree(ctx->tb_sad);
+  ctx->tb_kp = nullptr; ctx->tb_desc = nullptr; ctx->tb_nkp = nullptr; ctx->tb_uR = nullptr; ctx->tb_depth = nullptr; ctx->tb_sad = nullptr;
+}
 void svo_track_release(svo_ctx* ctx) {
   shard_gather_free(ctx);
+  track_batch_sets_free(ctx);
+  for (int q = 0; q < 2; ++q) {
+    if (ctx->tb_done[q]) { hipEventDestroy(ctx->tb_done[q]); ctx->tb_done[q] = nullptr; }
+    ctx->tb_used[q] = false;
+  }
+  ctx->tb_parity = 0;
   if (ctx->d_track) { hipFree(ctx->d_track); ctx->d_track = nullptr; }
   if (ctx->d_work) { hipFree(ctx->d_work); ctx->d_work = nullptr; }
   ctx->n_seq = 0; ctx->work_cap = 0;
@@ -1126,7 +1141,7 @@ static int track_resources(svo_ctx* ctx, int frames, int nseq) {
     SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_work) hipFree(ctx->d_work);
     ctx->d_work = nullptr; ctx->work_cap = 0;
-    if (hipMalloc(&ctx->d_work, sizeof(TrackWork) * (size_t)need) != hipSuccess) return SVO_E_NOMEM;
+    if (hipMalloc(&ctx->d_work, sizeof(TrackWork) * (size_t)need * 2) != hipSuccess) return SVO_E_NOMEM;   // two halves (see tail_enqueue)
     ctx->work_cap = need;
   }
   if (ctx->track_lds_state == 0) {
@@ -1151,17 +1166,27 @@ static int track_resources(svo_ctx* ctx, int frames, int nseq) {
 // `bx` (may be null): detection boxes in HBM - frame f's (nseq == 1) or sequence q's (nseq > 1) at bx->boxes + 4 * bx->stride * f.
 static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, const int32_t* nkp, const float* depth,
                         int kstride, int frames, int nseq, svo_track_result* d_res, const svo_boxes_dev* bx,
-                        const hipEvent_t* fe_events = nullptr, const int* row_of_frame = nullptr) {
+                        const hipEvent_t* fe_events = nullptr, const int* row_of_frame = nullptr, int work_half = 0,
+                        hipEvent_t idx_wait = nullptr, bool fe_elsewhere = false) {
+  // work_half: which half of the TrackWork records this call uses (svo_track_batch_dev alternates, so that the index chain of
+  // call c + 1 may start while the pose chain of call c still reads its records); idx_wait: what the index chain waits for
+  // before it starts - by default everything the ctx stream holds (the front end of this call, the previous call's pose
+  // chain), with fe_elsewhere (front end on its own stream, announced through fe_events) only `idx_wait`, if any
   if (bx && (!bx->boxes || !bx->n || bx->stride < 1)) bx = nullptr;
   int rc = track_resources(ctx, frames, nseq);
   if (rc) return rc;
   TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
-  TrackWork* work = reinterpret_cast<TrackWork*>(ctx->d_work);
+  TrackWork* work = reinterpret_cast<TrackWork*>(ctx->d_work) + (size_t)work_half * ctx->work_cap;
+  ctx->work_last_half = work_half;
   hipStream_t s0 = ctx->stream, s1 = ctx->stream_idx;
   const unsigned ny = (unsigned)nseq;
   const uint32_t* desc = reinterpret_cast<const uint32_t*>(desc8);
-  SVO_HIP(ctx, hipEventRecord(ctx->ev_frontend, s0));            // keypoints, descriptors, depths are ready ...
-  SVO_HIP(ctx, hipStreamWaitEvent(s1, ctx->ev_frontend, 0));    // ... and the previous call's pose chain has read its records
+  if (!fe_elsewhere) {
+    SVO_HIP(ctx, hipEventRecord(ctx->ev_frontend, s0));            // keypoints, descriptors, depths are ready ...
+    SVO_HIP(ctx, hipStreamWaitEvent(s1, ctx->ev_frontend, 0));    // ... and the previous call's pose chain has read its records
+  } else if (idx_wait) {
+    SVO_HIP(ctx, hipStreamWaitEvent(s1, idx_wait, 0));            // the pose chain that last read this half of the records
+  }
   // per-kernel HIP-event timing (svo_profile_enable) costs ~2.5 us per event pair on the host - more than a tail kernel's
   // launch; the tail is therefore SAMPLED: every 32nd frame of a call is timed (an event pair around a kernel also holds the chain up by ~5 us), the others run untimed
   const bool prof = ctx->profiling;
@@ -1262,6 +1287,7 @@ static int track_reset_n(svo_ctx* ctx, const svo_camera* cam, int nseq) {
   if (ctx->stream_fe) SVO_HIP(ctx, hipStreamSynchronize(ctx->stream_fe));
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->ms_parity = 0; ctx->ms_tail_recorded[0] = false; ctx->ms_tail_recorded[1] = false;
+  ctx->tb_parity = 0; ctx->tb_used[0] = false; ctx->tb_used[1] = false;   // (all streams are idle here)
   if (!ctx->d_track || ctx->n_seq != nseq) {
     if (ctx->d_track) { hipFree(ctx->d_track); ctx->d_track = nullptr; }
     void* p = nullptr;
@@ -1511,12 +1537,37 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
       SVO_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
       ctx->ev_sub.push_back(e);
     }
-    // everything enqueued on the ctx stream so far - the previous call's pose chain included - comes first
-    SVO_HIP(ctx, hipEventRecord(ctx->ev_frontend, ctx->stream));
-    SVO_HIP(ctx, hipStreamWaitEvent(ctx->stream_fe, ctx->ev_frontend, 0));
+    // Output sets alternate between calls: this call's front end writes set p while the tail of the previous call still reads
+    // the other one - it only has to wait for the tail of the call BEFORE that (first use of a set: for whatever the ctx
+    // stream holds).  The front end's working set (pyramids, corner lists) is shared: stream_fe runs the calls' sub-batches
+    // one after the other anyway.
+    const int p = ctx->tb_parity;
+    if (p == 1 && !ctx->tb_kp) {
+      const size_t I = (size_t)ctx->max_images, Kk = (size_t)ctx->max_kp, Bm = (size_t)ctx->max_batch;
+      if (hipMalloc(reinterpret_cast<void**>(&ctx->tb_kp), sizeof(svo_kp) * I * Kk) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&ctx->tb_desc), 32 * I * Kk) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&ctx->tb_nkp), 4 * I) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&ctx->tb_uR), 4 * Bm * Kk) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&ctx->tb_depth), 4 * Bm * Kk) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&ctx->tb_sad), 4 * Bm * Kk) != hipSuccess) {
+        (void)hipGetLastError();
+        track_batch_sets_free(ctx);
+        return SVO_E_NOMEM;
+      }
+    }
+    for (int q = 0; q < 2; ++q)
+      if (!ctx->tb_done[q]) SVO_HIP(ctx, hipEventCreateWithFlags(&ctx->tb_done[q], hipEventDisableTiming));
+    if (ctx->tb_used[p]) {
+      SVO_HIP(ctx, hipStreamWaitEvent(ctx->stream_fe, ctx->tb_done[p], 0));
+    } else {
+      SVO_HIP(ctx, hipEventRecord(ctx->ev_frontend, ctx->stream));
+      SVO_HIP(ctx, hipStreamWaitEvent(ctx->stream_fe, ctx->ev_frontend, 0));
+    }
     std::vector<hipEvent_t> wait(B, nullptr);
-    svo_kp* kp0 = ctx->d_kp; uint8_t* desc0 = ctx->d_desc; int32_t* nkp0 = ctx->d_nkp;
-    float* uR0 = ctx->d_uR; float* depth0 = ctx->d_depth; int32_t* sad0 = ctx->d_sad;
+    svo_kp* const own_kp = ctx->d_kp; uint8_t* const own_desc = ctx->d_desc; int32_t* const own_nkp = ctx->d_nkp;
+    float* const own_uR = ctx->d_uR; float* const own_depth = ctx->d_depth; int32_t* const own_sad = ctx->d_sad;
+    svo_kp* kp0 = p ? ctx->tb_kp : own_kp; uint8_t* desc0 = p ? ctx->tb_desc : own_desc; int32_t* nkp0 = p ? ctx->tb_nkp : own_nkp;
+    float* uR0 = p ? ctx->tb_uR : own_uR; float* depth0 = p ? ctx->tb_depth : own_depth; int32_t* sad0 = p ? ctx->tb_sad : own_sad;
     hipStream_t s_main = ctx->stream;
     const size_t K = ctx->max_kp, img = (size_t)ctx->g.H * stride;
     ctx->stream = ctx->stream_fe;
@@ -1530,9 +1581,16 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
       wait[f0] = ctx->ev_sub[j];
     }
     ctx->stream = s_main;
-    ctx->d_kp = kp0; ctx->d_desc = desc0; ctx->d_nkp = nkp0; ctx->d_uR = uR0; ctx->d_depth = depth0; ctx->d_sad = sad0;
+    ctx->d_kp = own_kp; ctx->d_desc = own_desc; ctx->d_nkp = own_nkp; ctx->d_uR = own_uR; ctx->d_depth = own_depth; ctx->d_sad = own_sad;
     if (rc) return rc;
-    if ((rc = tail_enqueue(ctx, ctx->d_kp, ctx->d_desc, ctx->d_nkp, ctx->d_depth, ctx->max_kp, B, 1, d_results, boxes, wait.data()))) return rc;
+    // (the index chain: its inputs arrive through the sub-batch events; its half of the work records was last read by the pose
+    // chain of the call before the previous one - the same event the front end waited for)
+    if ((rc = tail_enqueue(ctx, kp0, desc0, nkp0, depth0, ctx->max_kp, B, 1, d_results, boxes, wait.data(), nullptr, p,
+                           ctx->tb_used[p] ? ctx->tb_done[p] : ctx->ev_frontend, true)))
+      return rc;
+    SVO_HIP(ctx, hipEventRecord(ctx->tb_done[p], ctx->stream));   // the pose chain is the last reader of this call's set
+    ctx->tb_used[p] = true;
+    ctx->tb_parity ^= 1;
     ctx->track_frame += B;
     return SVO_OK;
   }
@@ -1595,7 +1653,8 @@ extern "C" int svo_debug_track_frames(svo_ctx* ctx, int first, int n, svo_track_
   hipSetDevice(ctx->device);
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   std::vector<TrackWork> w((size_t)n);
-  SVO_HIP(ctx, hipMemcpy(w.data(), reinterpret_cast<TrackWork*>(ctx->d_work) + first, sizeof(TrackWork) * (size_t)n, hipMemcpyDeviceToHost));
+  SVO_HIP(ctx, hipMemcpy(w.data(), reinterpret_cast<TrackWork*>(ctx->d_work) + (size_t)ctx->work_last_half * ctx->work_cap + first,
+                         sizeof(TrackWork) * (size_t)n, hipMemcpyDeviceToHost));
   for (int f = 0; f < n; ++f) {
     const TrackWork& q = w[f];
     svo_track_debug& o = out[f];
@@ -1617,7 +1676,7 @@ extern "C" int svo_debug_track_frames(svo_ctx* ctx, int first, int n, svo_track_
 extern "C" int svo_debug_track_stamps(svo_ctx* ctx, int slot, int64_t ts[8]) {
   if (!ctx || !ts || !ctx->d_work || slot < 0 || slot >= ctx->work_cap) return SVO_E_INVALID;
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  TrackWork* w = reinterpret_cast<TrackWork*>(ctx->d_work) + slot;
+  TrackWork* w = reinterpret_cast<TrackWork*>(ctx->d_work) + (size_t)ctx->work_last_half * ctx->work_cap + slot;
   SVO_HIP(ctx, hipMemcpy(ts, w->ts, sizeof(long long) * 8, hipMemcpyDeviceToHost));
   return SVO_OK;
 }
@@ -1627,7 +1686,7 @@ extern "C" int svo_debug_track_stamps(svo_ctx* ctx, int slot, int64_t ts[8]) {
 extern "C" int svo_debug_track_realtime(svo_ctx* ctx, int slot, int64_t rt[4]) {
   if (!ctx || !rt || !ctx->d_work || slot < 0 || slot >= ctx->work_cap) return SVO_E_INVALID;
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  TrackWork* w = reinterpret_cast<TrackWork*>(ctx->d_work) + slot;
+  TrackWork* w = reinterpret_cast<TrackWork*>(ctx->d_work) + (size_t)ctx->work_last_half * ctx->work_cap + slot;
   SVO_HIP(ctx, hipMemcpy(rt, w->rt, sizeof(long long) * 4, hipMemcpyDeviceToHost));
   return SVO_OK;
 }

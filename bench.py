@@ -406,7 +406,8 @@ def msa_leg(pkg, device, d_L, d_R):
     if dom:
         ach = algo / (kern[dom] * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": (pmc_traffic(dom) or 0) * prof[dom][1] or None, "algorithmic_bytes_per_solve": algo, "launches_per_solve": prof[dom][1],
+                # (the timer around an aggregation is named k_msa_tree_dp; the kernel rocprofv3 sees inside it is k_msa_dp_bfs)
+                "traffic": (pmc_traffic({"k_msa_tree_dp": "k_msa_dp_bfs"}.get(dom, dom)) or 0) * prof[dom][1] or None, "algorithmic_bytes_per_solve": algo, "launches_per_solve": prof[dom][1],
                 "note": "one workgroup per disparity walks ~2000 barrier-separated tree levels: latency bound; the solve as a whole is "
                         "bound by the host-side tree construction (see `note`)"}
     out = {"value": batch_rate, "unit": "stereo pairs/s", "pairs_per_call": nb, "batch_equals_single_call": batch_equals_single,

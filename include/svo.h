@@ -157,6 +157,9 @@ void svo_destroy(svo_ctx* ctx);
  * epipolar matcher (north star), 1 a dense ELAS map (svo_elas_*), 2 a dense MSA map (svo_msa_solve with d = 48: the
  * reference's live configuration, src/Tracking.cc:225-228 + src/frame.cc:82-91), both read per keypoint as
  * frame::computekeypoint_r / disp2Depth do.
+ * "pose_flag" (default 1): one sequence's pose kernels learn that their frame has been matched from a per-frame tag the
+ * index chain publishes in HBM (agent-scope stores / polls) instead of waiting on one stream event per group of frames -
+ * the pose chain then never stands still because a LATER frame of its group is slow to match; 0: stream events - same records.
  * "epnp_exact" (default 0): 1 makes every RANSAC sample's EPnP follow OpenCV's own loops one after the other (cyclic
  * one-sided Jacobi SVDs, SVD / QR least squares, IEEE division and square root, no FMA contraction), one lane per
  * sample - the arithmetic of the CPU restatement the tests compare with, an order of magnitude slower than the

@@ -68,7 +68,10 @@ struct TrackPool {
 };
 
 // What the index chain hands to the pose chain for one frame.
+// Written by k_ti_resolve with agent-scope (sc1) stores and published through `ready`, read by the pose kernels with agent-scope
+// loads after they have seen the tag: the pose chain does not wait on stream events for the index chain (see tp_wait_work).
 struct TrackWork {
+  int32_t ready;                 // = frame index + 1 once the record of that frame is complete (cleared by svo_track_reset)
   int32_t frame_id, nkp, n_stereo, n_pass1, n_pass2, n_new, n_local, skip_match;
   long long ts[8];               // diagnostics: s_memtime at begin / pass 1 / pass 2 / frame end / done, dense rows, late rows
   long long rt[4];               // diagnostics: s_memrealtime (100 MHz, one clock for the chip) at k_ti_resolve start / end,
@@ -76,7 +79,7 @@ struct TrackWork {
   int32_t diag[2];               // [0] rows of pass 1 | rounds << 16, [1] rows of pass 2 | rounds << 16
   int32_t n_edges;               // 3D-2D correspondences of the frame (src/pnpmatch.cc:216-224), in keypoint order:
   int32_t edge_gid[TRK_MAXKP];   //   id of the map point (CurrentFrame->MapPoints[j]->...) ...
-  int16_t edge_kp[TRK_MAXKP];    //   ... and the keypoint j it is matched to
+  int32_t edge_kp[TRK_MAXKP];    //   ... and the keypoint j it is matched to
   int32_t new_gid[TRK_MAXKP];    // per keypoint: id of the map point created from it at the frame's end, or -1
   // written by the pose chain (k_tp_frame), for svo_debug_track_frames: cv::solvePnPRansac's outcome and pose
   int32_t pnp_best, pnp_iterations, pnp_inliers, pnp_ok;
@@ -154,6 +157,22 @@ __device__ __forceinline__ void tk_unproject(const svo_camera& cam, float u, flo
     xyz[r] = (float)(acc + (double)twc[r]);
   }
 }
+
+// ---- hand-over index chain -> pose chain without stream events -----------------------------------------------------------
+// The pose chain used to wait on one stream event per GROUP of frames (a wait costs ~3 us on the pose stream): whenever the
+// index chain's lead shrank below a group - runs of frames whose passes need 30-47 rounds - the pose chain of frames
+// g .. g + 3 stood still until frame g + 3 was matched (200-490 us per group, tools/gap_probe.py).  Now k_ti_resolve
+// publishes every frame's record itself: all of its fields go out with agent-scope (sc1) stores, every thread waits for its
+// own stores (s_waitcnt), and thread 0 then stores the frame's tag; the pose kernels are enqueued without any dependency on
+// the index stream, poll the tag with an agent-scope load and read the record with agent-scope loads.  No release / acquire
+// fence on either side: on gfx950 a release fence is buffer_wbl2 - a write-back of everything dirty in that XCD's L2, which
+// holds the pyramid data of the front end running beside the tail - and sc1 accesses reach the device-coherent level by
+// themselves.  The poll is bounded (~1 s): a lost hand-over sets the tracker's error flag instead of hanging the GPU.
+__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ long long ld_agent(const long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(long long* p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#define TP_STORES_DONE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 // ================================================================================================
 // Index chain 1/2: distances of every live pool row to the frame's keypoints -> sparse candidate lists
@@ -678,7 +697,7 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
   int n_edges;
   {
     const int e = block_excl_scan(edge_gid >= 0 ? 1 : 0, S.sm, &n_edges);
-    if (edge_gid >= 0) { work->edge_gid[e] = edge_gid; work->edge_kp[e] = (int16_t)tid; }
+    if (edge_gid >= 0) { st_agent(&work->edge_gid[e], edge_gid); st_agent(&work->edge_kp[e], tid); }
   }
   ts3 = clock64();
   // ---- frame end: createmappoint (src/frame.cc:182-238) for keypoints without a map point ------
@@ -702,7 +721,7 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
     new_gid = next_gid + rank;
     m_cur = m;
   }
-  if (tid < TRK_MAXKP) work->new_gid[tid] = new_gid;
+  if (tid < TRK_MAXKP) st_agent(&work->new_gid[tid], new_gid);
   const int np1 = min(npool + n_new, TRK_CAP);
   const bool overflow = npool + n_new > TRK_CAP;
   next_gid += n_new;
@@ -765,15 +784,15 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
   const int lapped = __syncthreads_or(oldest != 0x7fffffff && next_gid - oldest > TRK_GPOS - 2 * TRK_MAXKP);
   if (tid < TRK_MAXKP) st->last_mp[tid] = (tid < nkp && m_cur >= 0) ? S.remap[m_cur] : -1;
   if (tid == 0) {
-    work->frame_id = id; work->nkp = nkp; work->n_stereo = n_stereo; work->n_edges = n_edges;
-    work->n_pass1 = n_pass1; work->n_pass2 = n_pass2;
-    work->n_new = n_new0 + n_new; work->n_local = nl_total; work->skip_match = id == 0 ? 1 : 0;
+    st_agent(&work->frame_id, id); st_agent(&work->nkp, nkp); st_agent(&work->n_stereo, n_stereo); st_agent(&work->n_edges, n_edges);
+    st_agent(&work->n_pass1, n_pass1); st_agent(&work->n_pass2, n_pass2);
+    st_agent(&work->n_new, n_new0 + n_new); st_agent(&work->n_local, nl_total); st_agent(&work->skip_match, id == 0 ? 1 : 0);
     ts4 = clock64();
     work->ts[0] = ts0; work->ts[1] = ts1; work->ts[2] = ts2; work->ts[3] = ts3; work->ts[4] = ts4;
     work->ts[5] = S.nd; work->ts[6] = late2; work->ts[7] = 0;
-    work->rt[0] = rt0; work->rt[1] = wall_clock64();
-    work->diag[0] = n_act1 | (rounds1 << 16);
-    work->diag[1] = n_act2 | (rounds2v << 16);
+    st_agent(&work->rt[0], rt0); st_agent(&work->rt[1], (long long)wall_clock64());
+    st_agent(&work->diag[0], n_act1 | (rounds1 << 16));
+    st_agent(&work->diag[1], n_act2 | (rounds2v << 16));
     st->n_vetoed = n_veto;
     st->lastN = nkp;
     st->npool = total_live;
@@ -782,6 +801,10 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
     st->cur ^= 1;
     st->frame_num = id + 1;
   }
+  // publish the record: every thread's stores have reached the coherent level, then the tag
+  TP_STORES_DONE();
+  __syncthreads();
+  if (tid == 0) st_agent(&work->ready, id + 1);
 }
 
 // ================================================================================================
@@ -896,6 +919,19 @@ __global__ __launch_bounds__(64) void k_tg_fmat(TrackState* st, const svo_kp* kp
 // two launches per step - samples 0..15 first; then samples 16..99, whose workgroups first replay the adaptive rule over
 // the first sixteen and leave at once when the iteration bound (log 0.01 / log(1 - w^5): 12 at 80 % inliers) says the loop
 // can never reach their samples - six times less EPnP work on ordinary frames (61 k -> 74 k frames/s with 64 sequences).
+// Wait (thread 0 polls, the workgroup follows through the barrier) until the index chain has published the record of the frame
+// with tag `tag`; tag <= 0: the caller ordered the streams itself (many sequences, latency entry).  Bounded: see above.
+__device__ __forceinline__ void tp_wait_work(TrackState* st, const TrackWork* work, int tag) {
+  if (tag > 0) {
+    if (threadIdx.x == 0) {
+      int spins = 0;
+      while (ld_agent(&work->ready) != tag && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(2); ++spins; }
+      if (spins >= (1 << 22)) st->overflow = 4;      // lost hand-over: svo_track_overflowed reports it
+    }
+    __syncthreads();
+  }
+}
+
 #define TP_HYP_FIRST 16
 struct TpHypLds {
   double Xw[TRK_MAXKP * 3], uv[TRK_MAXKP * 2];
@@ -904,13 +940,14 @@ struct TpHypLds {
 };
 
 __global__ __launch_bounds__(256) void k_tp_hyp(TrackState* st, const TrackWork* work, const svo_kp* kp, const uint16_t* subsets,
-                                                int kstride, int hyp_base) {
+                                                int kstride, int hyp_base, int tag) {
   TpHypLds& S = *reinterpret_cast<TpHypLds*>(tk_smem);
   st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
+  tp_wait_work(st, work, tag);
   const long long t_start = clock64();
   if (hyp_base == 0 && blockIdx.x == 0 && threadIdx.x == 0) const_cast<TrackWork*>(work)->rt[2] = wall_clock64();
-  const int n = work->n_edges;
-  if (work->skip_match || n < 5) return;
+  const int n = ld_agent(&work->n_edges);
+  if (ld_agent(&work->skip_match) || n < 5) return;
   const int first = hyp_base + (int)blockIdx.x * (int)(blockDim.x >> 6);
   if (hyp_base > 0) {
     if (threadIdx.x < TP_HYP_FIRST) { S.cnt[threadIdx.x] = st->hyp[threadIdx.x].cnt; S.ok[threadIdx.x] = st->hyp[threadIdx.x].ok; }
@@ -921,8 +958,8 @@ __global__ __launch_bounds__(256) void k_tp_hyp(TrackState* st, const TrackWork*
   }
   const float* gpos = st->gpos;
   for (int e = threadIdx.x; e < n; e += blockDim.x) {
-    const float* gp = gpos + 3 * (size_t)(work->edge_gid[e] & (TRK_GPOS - 1));
-    const svo_kp k = kp[work->edge_kp[e]];
+    const float* gp = gpos + 3 * (size_t)(ld_agent(&work->edge_gid[e]) & (TRK_GPOS - 1));
+    const svo_kp k = kp[ld_agent(&work->edge_kp[e])];
     S.Xw[3 * e] = (double)gp[0]; S.Xw[3 * e + 1] = (double)gp[1]; S.Xw[3 * e + 2] = (double)gp[2];
     S.uv[2 * e] = (double)k.x; S.uv[2 * e + 1] = (double)k.y;
   }
@@ -943,16 +980,17 @@ __global__ __launch_bounds__(256) void k_tp_hyp(TrackState* st, const TrackWork*
 // frame's correspondences into LDS itself, like k_tp_hyp.
 struct TpHypExactLds { double Xw[TRK_MAXKP * 3], uv[TRK_MAXKP * 2]; PnpExactLds ex; };
 __global__ __launch_bounds__(64) void k_tp_hyp_exact(TrackState* st, TrackWork* work, const svo_kp* kp, const uint16_t* subsets,
-                                                     int kstride) {
+                                                     int kstride, int tag) {
   TpHypExactLds& S = *reinterpret_cast<TpHypExactLds*>(tk_smem);
   st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
+  tp_wait_work(st, work, tag);
   if (threadIdx.x == 0 && blockIdx.x == 0) work->rt[2] = wall_clock64();
-  const int n = work->n_edges;
-  if (work->skip_match || n < 5) return;
+  const int n = ld_agent(&work->n_edges);
+  if (ld_agent(&work->skip_match) || n < 5) return;
   const float* gpos = st->gpos;
   for (int e = threadIdx.x; e < n; e += blockDim.x) {
-    const float* gp = gpos + 3 * (size_t)(work->edge_gid[e] & (TRK_GPOS - 1));
-    const svo_kp k = kp[work->edge_kp[e]];
+    const float* gp = gpos + 3 * (size_t)(ld_agent(&work->edge_gid[e]) & (TRK_GPOS - 1));
+    const svo_kp k = kp[ld_agent(&work->edge_kp[e])];
     S.Xw[3 * e] = (double)gp[0]; S.Xw[3 * e + 1] = (double)gp[1]; S.Xw[3 * e + 2] = (double)gp[2];
     S.uv[2 * e] = (double)k.x; S.uv[2 * e + 1] = (double)k.y;
   }
@@ -977,19 +1015,20 @@ struct TpLds {
 #define TPF_NT 256
 __global__ __launch_bounds__(TPF_NT) void k_tp_frame(TrackState* st, TrackWork* work, const svo_kp* kp,
                                                   const float* depth, svo_track_result* res_out, int kstride,
-                                                  int use_mfma) {
+                                                  int use_mfma, int tag) {
   TpLds& S = *reinterpret_cast<TpLds*>(tk_smem);
   st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
   depth += (size_t)blockIdx.y * kstride; res_out += blockIdx.y;
   const int tid = threadIdx.x;
+  tp_wait_work(st, work, tag);
   const long long tf0 = clock64();
-  const int id = work->frame_id, nkp = work->nkp, skip = work->skip_match, n_edges = work->n_edges;
+  const int id = ld_agent(&work->frame_id), nkp = ld_agent(&work->nkp), skip = ld_agent(&work->skip_match), n_edges = ld_agent(&work->n_edges);
   float* gpos = st->gpos;
   // ---- 3D-2D correspondences, ordered by keypoint index (src/pnpmatch.cc:216-224) ---------------
   for (int e = tid; e < n_edges; e += TPF_NT) {
-    const int j = work->edge_kp[e];
+    const int j = ld_agent(&work->edge_kp[e]);
     const svo_kp k = kp[j];
-    float* gp = gpos + 3 * (size_t)(work->edge_gid[e] & (TRK_GPOS - 1));
+    float* gp = gpos + 3 * (size_t)(ld_agent(&work->edge_gid[e]) & (TRK_GPOS - 1));
     float xyz[3];
     if (id == 0) {   // Tracking::init: the points of frame 0 are placed with the identity pose, before its LM
       const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3[3] = {0, 0, 0};
@@ -1054,7 +1093,7 @@ __global__ __launch_bounds__(TPF_NT) void k_tp_frame(TrackState* st, TrackWork* 
   }
   __syncthreads();
   for (int j = tid; j < nkp; j += TPF_NT) {
-    const int g = work->new_gid[j];
+    const int g = ld_agent(&work->new_gid[j]);
     if (g < 0) continue;
     const svo_kp k = kp[j];
     float xyz[3];
@@ -1065,18 +1104,18 @@ __global__ __launch_bounds__(TPF_NT) void k_tp_frame(TrackState* st, TrackWork* 
   if (tid == 0) {
     svo_track_result r;
     for (int i = 0; i < 16; ++i) { r.Tcw[i] = S.sT[i]; st->lastTcw[i] = S.sT[i]; }
-    r.frame_id = id; r.n_kp = nkp; r.n_stereo = work->n_stereo;
-    r.n_match_pass1 = work->n_pass1; r.n_match_pass2 = work->n_pass2;
+    r.frame_id = id; r.n_kp = nkp; r.n_stereo = ld_agent(&work->n_stereo);
+    r.n_match_pass1 = ld_agent(&work->n_pass1); r.n_match_pass2 = ld_agent(&work->n_pass2);
     r.n_pnp_inliers = skip ? 0 : st->pnp.n_inliers;
     r.n_lm_edges = n_edges;
-    r.n_new_mappoints = work->n_new;
-    r.n_local_map = work->n_local;
+    r.n_new_mappoints = ld_agent(&work->n_new);
+    r.n_local_map = ld_agent(&work->n_local);
     r.lm_iterations = st->lm.iterations;
     // diagnostics: rows of pass 1 / pass 2 that could match at all.  (The ROUNDS a pass took are not part of the record: a
     // dense row may or may not see a claim made earlier in the same phase - the outcome is the same either way, the
     // number of rounds is not, and records are compared byte for byte.  svo_debug_track_frames reports them.)
-    r.reserved[0] = work->diag[0] & 0xffff;
-    r.reserved[1] = work->diag[1] & 0xffff;
+    r.reserved[0] = ld_agent(&work->diag[0]) & 0xffff;
+    r.reserved[1] = ld_agent(&work->diag[1]) & 0xffff;
     *res_out = r;
     st->pose_ts[8] = tf0; st->pose_ts[9] = tf1; st->pose_ts[10] = tf2; st->pose_ts[11] = clock64();
     work->rt[3] = wall_clock64();
@@ -1142,6 +1181,7 @@ static int track_resources(svo_ctx* ctx, int frames, int nseq) {
     if (ctx->d_work) hipFree(ctx->d_work);
     ctx->d_work = nullptr; ctx->work_cap = 0;
     if (hipMalloc(&ctx->d_work, sizeof(TrackWork) * (size_t)need * 2) != hipSuccess) return SVO_E_NOMEM;   // two halves (see tail_enqueue)
+    SVO_HIP(ctx, hipMemset(ctx->d_work, 0, sizeof(TrackWork) * (size_t)need * 2));   // no stale `ready` tags
     ctx->work_cap = need;
   }
   if (ctx->track_lds_state == 0) {
@@ -1224,32 +1264,37 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
                          bxf, nbf, bstride);
     }
   };
+  // one sequence: the pose kernels find out by themselves when their frame's record is there (tp_wait_work) - no stream event
+  // between the chains; tag of frame f = its index in the sequence + 1
+  const bool flagged = ny == 1 && ctx->opt_pose_flag;
+  auto tag_of = [&](int f) { return flagged ? ctx->track_frame + f + 1 : 0; };
   auto enqueue_pose = [&](int f) {
     const svo_kp* kpf = kp + row(f) * kstride;
     const float* depf = depth + row(f) * kstride;
     ctx->profiling = prof && (f % 32 == 0 || frames < 32);
     if (ctx->opt_epnp_exact) {
       SvoTimer t(ctx, "k_tp_hyp_exact");
-      hipLaunchKernelGGL(k_tp_hyp_exact, dim3(PNP_HYP, ny), dim3(64), sizeof(TpHypExactLds), s0, st, work + f, kpf, ctx->d_pnp_subsets, kstride);
+      hipLaunchKernelGGL(k_tp_hyp_exact, dim3(PNP_HYP, ny), dim3(64), sizeof(TpHypExactLds), s0, st, work + f, kpf, ctx->d_pnp_subsets, kstride,
+                         tag_of(f));
     } else {
       SvoTimer t(ctx, "k_tp_hyp");
       if (ny >= 8) {
         // many sequences: throughput counts - solve sixteen samples per sequence, then only those the adaptive bound can reach
         hipLaunchKernelGGL(k_tp_hyp, dim3(TP_HYP_FIRST / 4, ny), dim3(256), sizeof(TpHypLds), s0, st, work + f, kpf, ctx->d_pnp_subsets,
-                           kstride, 0);
+                           kstride, 0, 0);
         hipLaunchKernelGGL(k_tp_hyp, dim3((PNP_HYP - TP_HYP_FIRST) / 4, ny), dim3(256), sizeof(TpHypLds), s0, st, work + f, kpf,
-                           ctx->d_pnp_subsets, kstride, TP_HYP_FIRST);
+                           ctx->d_pnp_subsets, kstride, TP_HYP_FIRST, 0);
       } else {
         // one sequence: latency counts and the chip is idle - all 100 samples at once, ONE wave per workgroup (= per CU: the
         // four SIMDs of a CU share its float64 pipeline, four solves side by side on a CU run 2.7x slower each)
         hipLaunchKernelGGL(k_tp_hyp, dim3(PNP_HYP, ny), dim3(64), sizeof(TpHypLds), s0, st, work + f, kpf, ctx->d_pnp_subsets,
-                           kstride, 0);
+                           kstride, 0, tag_of(f));
       }
     }
     {
       SvoTimer t(ctx, "k_tp_frame");
       hipLaunchKernelGGL(k_tp_frame, dim3(1, ny), dim3(TPF_NT), sizeof(TpLds), s0, st, work + f, kpf, depf, d_res + f, kstride,
-                         ctx->opt_pose_mfma);
+                         ctx->opt_pose_mfma, tag_of(f));
     }
   };
   // The pose chain takes the frames over in groups: ONE event (a barrier packet on the pose stream, ~3 us even when long
@@ -1262,14 +1307,14 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
     if (g0 < frames) {
       cur0 = g0; cur1 = std::min(frames, g0 + gsize);
       for (int f = cur0; f < cur1; ++f) enqueue_index(f);
-      hipEventRecord(ctx->ev_frame[cur0], s1);
+      if (!flagged) hipEventRecord(ctx->ev_frame[cur0], s1);
       g0 = cur1;
       ++ngroup;
       if (ngroup >= 2) gsize = std::min(2 * gsize, ctx->opt_track_group > 0 ? ctx->opt_track_group : 1);
     }
     if (prev0 >= 0) {
-      hipStreamWaitEvent(s0, ctx->ev_frame[prev0], 0);
-      for (int f = prev0; f < prev1; ++f) enqueue_pose(f);
+      if (!flagged) hipStreamWaitEvent(s0, ctx->ev_frame[prev0], 0);
+      for (int f = prev0; f < prev1; ++f) enqueue_pose(f);   // (always AFTER the index kernels of the same frames were enqueued)
     }
     prev0 = cur0; prev1 = cur1;
   }
@@ -1288,6 +1333,7 @@ static int track_reset_n(svo_ctx* ctx, const svo_camera* cam, int nseq) {
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->ms_parity = 0; ctx->ms_tail_recorded[0] = false; ctx->ms_tail_recorded[1] = false;
   ctx->tb_parity = 0; ctx->tb_used[0] = false; ctx->tb_used[1] = false;   // (all streams are idle here)
+  if (ctx->d_work) SVO_HIP(ctx, hipMemset(ctx->d_work, 0, sizeof(TrackWork) * (size_t)ctx->work_cap * 2));   // frame tags restart at 1
   if (!ctx->d_track || ctx->n_seq != nseq) {
     if (ctx->d_track) { hipFree(ctx->d_track); ctx->d_track = nullptr; }
     void* p = nullptr;

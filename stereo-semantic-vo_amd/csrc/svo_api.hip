@@ -316,6 +316,12 @@ extern "C" int svo_set_option(svo_ctx* ctx, const char* key, int value) {
     ctx->opt_fast_cand_cap = value;
     return SVO_OK;
   }
+  if (!strcmp(key, "fe_cu_percent")) {
+    if (value < 10 || value > 100) return SVO_E_INVALID;
+    ctx->opt_fe_cu_percent = value;
+    if (ctx->stream_fe_batch) { hipStreamSynchronize(ctx->stream_fe_batch); hipStreamDestroy(ctx->stream_fe_batch); ctx->stream_fe_batch = nullptr; }   // recreated on demand
+    return SVO_OK;
+  }
   if (!strcmp(key, "pose_flag")) { ctx->opt_pose_flag = value != 0; return SVO_OK; }
   if (!strcmp(key, "epnp_exact")) { ctx->opt_epnp_exact = value != 0; return SVO_OK; }
   if (!strcmp(key, "multi_pipeline")) { ctx->opt_multi_pipeline = value != 0; return SVO_OK; }
@@ -880,6 +886,19 @@ extern "C" int svo_profile_get(svo_ctx* ctx, int index, char* name, int name_cap
   if (total_ms) *total_ms = e.total_ms;
   if (launches) *launches = e.launches;
   return SVO_OK;
+}
+
+// A stream that may only use the first `percent` per cent of the device's compute units (whole 32-bit mask words: on gfx950
+// consecutive CU indices belong to one XCD, so the stream keeps whole XCDs and their L2s).
+hipError_t svo_stream_create_masked(hipStream_t* st, int device, int percent) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); return svo_stream_create(st, -1); }
+  const int cus = prop.multiProcessorCount, words = (cus + 31) / 32;
+  const int keep = std::max(1, std::min(words, (words * percent + 50) / 100));
+  std::vector<uint32_t> mask((size_t)words, 0u);
+  for (int w = 0; w < keep; ++w) mask[w] = 0xffffffffu;
+  if (hipExtStreamCreateWithCUMask(st, (uint32_t)words, mask.data()) != hipSuccess) { (void)hipGetLastError(); return svo_stream_create(st, -1); }
+  return hipSuccess;
 }
 
 hipError_t svo_stream_create(hipStream_t* st, int role) {

@@ -117,7 +117,8 @@ struct svo_ctx {
   int work_cap = 0;             // records per half (two halves are allocated)
   int work_last_half = 0;       // the half the last tail call used (debug readers)
   hipStream_t stream_idx = nullptr;        // the pose-free index chain of the tracking tail runs here, ahead of the pose chain
-  hipStream_t stream_fe = nullptr;         // svo_track_batch_dev: the front end of later sub-batches runs here, beside the tail
+  hipStream_t stream_fe = nullptr;         // the front end of the next step / chunk beside the tail (multi-sequence steps, MSA chunks)
+  hipStream_t stream_fe_batch = nullptr;   // svo_track_batch_dev: the front end's sub-batches, confined to a share of the CUs
   std::vector<hipEvent_t> ev_sub;          // front end of sub-batch j finished (recorded on `stream_fe`)
   hipEvent_t ev_frontend = nullptr;        // front end of a call finished (recorded on `stream`)
   std::vector<hipEvent_t> ev_frame;        // index chain of frame f finished (recorded on `stream_idx`)
@@ -145,6 +146,7 @@ struct svo_ctx {
   int opt_depth_source = 0; // svo_set_option("depth_source"): 0 sparse epipolar stereo, 1 dense ELAS map (svo_track_frame)
   int opt_fast_cand_cap = 2048;   // svo_set_option("fast_cand_cap"): entries of k_fast's candidate list (<= 2048)
   int opt_pose_mfma = 1;   // svo_set_option("pose_mfma"): Gram accumulation of k_pose_opt on f64 MFMA
+  int opt_fe_cu_percent = 25;   // svo_set_option("fe_cu_percent"): share of the CUs the batched tracker's front-end stream may use
   int opt_pose_flag = 1;   // svo_set_option("pose_flag"): one sequence's pose kernels poll the index chain's per-frame tag instead of waiting on stream events
   int opt_epnp_exact = 0;  // svo_set_option("epnp_exact"): RANSAC samples solved in OpenCV's operation order, one lane each (parity mode)
   bool profiling = false;
@@ -199,6 +201,7 @@ __host__ __device__ inline T* svo_byte_offset(T* p, size_t bytes) {
 // Streams by role: +1 the ordered tail's chains (small dependent kernels whose workgroups must not queue behind the front end's
 // thousands), -1 the batched front end running beside it, 0 everything else.  Maps onto the device's stream-priority range.
 hipError_t svo_stream_create(hipStream_t* st, int role);
+hipError_t svo_stream_create_masked(hipStream_t* st, int device, int percent);
 int svo_frontend_nslices(const svo_ctx* ctx, int B);   // how svo_frontend_batch_dev slices a batch (svo_api.hip)
 int svo_launch_disp2depth(svo_ctx* ctx, const float* disp, int count, float bf, float* depth);
 int svo_launch_unproject(svo_ctx* ctx, const float* uvz, int n, const svo_camera* cam,

@@ -1153,6 +1153,7 @@ void svo_track_release(svo_ctx* ctx) {
   for (hipEvent_t e : ctx->ev_sub) hipEventDestroy(e);
   ctx->ev_sub.clear();
   if (ctx->stream_fe) { hipStreamDestroy(ctx->stream_fe); ctx->stream_fe = nullptr; }
+  if (ctx->stream_fe_batch) { hipStreamDestroy(ctx->stream_fe_batch); ctx->stream_fe_batch = nullptr; }
   for (int p = 0; p < 2; ++p) {
     if (ctx->ms_kp[p]) hipFree(ctx->ms_kp[p]);
     if (ctx->ms_desc[p]) hipFree(ctx->ms_desc[p]);
@@ -1330,6 +1331,7 @@ static int track_reset_n(svo_ctx* ctx, const svo_camera* cam, int nseq) {
   hipSetDevice(ctx->device);
   if (ctx->stream_idx) SVO_HIP(ctx, hipStreamSynchronize(ctx->stream_idx));
   if (ctx->stream_fe) SVO_HIP(ctx, hipStreamSynchronize(ctx->stream_fe));
+  if (ctx->stream_fe_batch) SVO_HIP(ctx, hipStreamSynchronize(ctx->stream_fe_batch));
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->ms_parity = 0; ctx->ms_tail_recorded[0] = false; ctx->ms_tail_recorded[1] = false;
   ctx->tb_parity = 0; ctx->tb_used[0] = false; ctx->tb_used[1] = false;   // (all streams are idle here)
@@ -1577,7 +1579,15 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
     rc = track_resources(ctx, B, 1);
     if (rc) return rc;
     const int SUB = 32, nsub = (B + SUB - 1) / SUB;
-    if (!ctx->stream_fe) SVO_HIP(ctx, svo_stream_create(&ctx->stream_fe, -1));
+    // The front end of a batched call runs beside the ordered tail, and its kernels are large enough to fill every CU: the
+    // tail's small dependent kernels (100 single-wave RANSAC workgroups that want a CU's float64 pipe each) then queue for
+    // slots and run at a fraction of their speed - 7 us per frame on average (tools/option_sweep.py: 13.15 k frames/s with the
+    // front end on all CUs, 14.07 k on a quarter of them; stream priorities did not change that).  So the batched tracker's
+    // front-end stream is confined to a share of the compute units (whole XCDs); the front end needs ~7 us per pair on the
+    // whole chip against the tail's ~70 us per frame, a quarter of the CUs is plenty.
+    if (!ctx->stream_fe_batch)
+      SVO_HIP(ctx, ctx->opt_fe_cu_percent < 100 ? svo_stream_create_masked(&ctx->stream_fe_batch, ctx->device, ctx->opt_fe_cu_percent)
+                                                : svo_stream_create(&ctx->stream_fe_batch, -1));
     while ((int)ctx->ev_sub.size() < nsub) {
       hipEvent_t e;
       SVO_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1604,10 +1614,10 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
     for (int q = 0; q < 2; ++q)
       if (!ctx->tb_done[q]) SVO_HIP(ctx, hipEventCreateWithFlags(&ctx->tb_done[q], hipEventDisableTiming));
     if (ctx->tb_used[p]) {
-      SVO_HIP(ctx, hipStreamWaitEvent(ctx->stream_fe, ctx->tb_done[p], 0));
+      SVO_HIP(ctx, hipStreamWaitEvent(ctx->stream_fe_batch, ctx->tb_done[p], 0));
     } else {
       SVO_HIP(ctx, hipEventRecord(ctx->ev_frontend, ctx->stream));
-      SVO_HIP(ctx, hipStreamWaitEvent(ctx->stream_fe, ctx->ev_frontend, 0));
+      SVO_HIP(ctx, hipStreamWaitEvent(ctx->stream_fe_batch, ctx->ev_frontend, 0));
     }
     std::vector<hipEvent_t> wait(B, nullptr);
     svo_kp* const own_kp = ctx->d_kp; uint8_t* const own_desc = ctx->d_desc; int32_t* const own_nkp = ctx->d_nkp;
@@ -1616,14 +1626,14 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
     float* uR0 = p ? ctx->tb_uR : own_uR; float* depth0 = p ? ctx->tb_depth : own_depth; int32_t* sad0 = p ? ctx->tb_sad : own_sad;
     hipStream_t s_main = ctx->stream;
     const size_t K = ctx->max_kp, img = (size_t)ctx->g.H * stride;
-    ctx->stream = ctx->stream_fe;
+    ctx->stream = ctx->stream_fe_batch;
     for (int j = 0; j < nsub && rc == SVO_OK; ++j) {
       const int f0 = j * SUB, b = std::min(SUB, B - f0);
       ctx->d_kp = kp0 + f0 * K; ctx->d_desc = desc0 + f0 * K * 32; ctx->d_nkp = nkp0 + f0;
       ctx->d_uR = uR0 + f0 * K; ctx->d_depth = depth0 + f0 * K; ctx->d_sad = sad0 + f0 * K;
       rc = svo_launch_orb(ctx, d_grayL + f0 * img, d_grayR + f0 * img, stride, b, 2 * b);
       if (rc == SVO_OK) rc = svo_launch_stereo(ctx, d_grayL + f0 * img, d_grayR + f0 * img, stride, b, &ctx->cam);
-      if (rc == SVO_OK && hipEventRecord(ctx->ev_sub[j], ctx->stream_fe) != hipSuccess) rc = SVO_E_HIP;
+      if (rc == SVO_OK && hipEventRecord(ctx->ev_sub[j], ctx->stream_fe_batch) != hipSuccess) rc = SVO_E_HIP;
       wait[f0] = ctx->ev_sub[j];
     }
     ctx->stream = s_main;

@@ -157,10 +157,11 @@ void svo_destroy(svo_ctx* ctx);
  * epipolar matcher (north star), 1 a dense ELAS map (svo_elas_*), 2 a dense MSA map (svo_msa_solve with d = 48: the
  * reference's live configuration, src/Tracking.cc:225-228 + src/frame.cc:82-91), both read per keypoint as
  * frame::computekeypoint_r / disp2Depth do.
- * "fe_cu_percent" (default 25, 10..100): share of the compute units (whole XCDs) the front-end stream of svo_track_batch_dev
- * may use.  Its kernels would otherwise fill every CU while the ordered tail runs beside them, and the tail's small dependent
- * kernels then queue for slots (7 us per frame on average); the front end needs a tenth of the tail's time on the whole
- * chip, so a quarter of it is plenty.  Scheduling only - same records.
+ * "fe_cu_percent" (default 12 = one of the eight XCDs, 10..100): share of the compute units (whole XCDs) the front-end stream of
+ * svo_track_batch_dev may use.  Its kernels would otherwise fill every CU while the ordered tail runs beside them, and the
+ * tail's small dependent kernels then queue for slots (7 us per frame on average); the front end needs a tenth of the tail's
+ * time on the whole chip, so one XCD keeps up (measured: 100 % 13.2 k, 25 % 14.1 k, 12 % 14.4 k frames/s).  Scheduling only -
+ * same records.
  * "pose_flag" (default 1): one sequence's pose kernels learn that their frame has been matched from a per-frame tag the
  * index chain publishes in HBM (agent-scope stores / polls) instead of waiting on one stream event per group of frames -
  * the pose chain then never stands still because a LATER frame of its group is slow to match; 0: stream events - same records.

@@ -1581,10 +1581,10 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
     const int SUB = 32, nsub = (B + SUB - 1) / SUB;
     // The front end of a batched call runs beside the ordered tail, and its kernels are large enough to fill every CU: the
     // tail's small dependent kernels (100 single-wave RANSAC workgroups that want a CU's float64 pipe each) then queue for
-    // slots and run at a fraction of their speed - 7 us per frame on average (tools/option_sweep.py: 13.15 k frames/s with the
-    // front end on all CUs, 14.07 k on a quarter of them; stream priorities did not change that).  So the batched tracker's
-    // front-end stream is confined to a share of the compute units (whole XCDs); the front end needs ~7 us per pair on the
-    // whole chip against the tail's ~70 us per frame, a quarter of the CUs is plenty.
+    // slots and run at a fraction of their speed - 7 us per frame on average (tools/option_sweep.py: 13.2 k frames/s with the
+    // front end on all CUs, 14.1 k on a quarter of them, 14.4 k on one XCD; stream priorities did not change that).  So the
+    // batched tracker's front-end stream is confined to a share of the compute units (whole XCDs, default one of eight): the
+    // front end needs ~7 us per pair on the whole chip against the tail's ~70 us per frame - one XCD keeps up.
     if (!ctx->stream_fe_batch)
       SVO_HIP(ctx, ctx->opt_fe_cu_percent < 100 ? svo_stream_create_masked(&ctx->stream_fe_batch, ctx->device, ctx->opt_fe_cu_percent)
                                                 : svo_stream_create(&ctx->stream_fe_batch, -1));

@@ -646,10 +646,14 @@ def tail_chain_from_stamps(dbg):
     resolve = (rt[:, 1] - rt[:, 0]) * 0.01
     period = np.diff(rt[:, 3]) * 0.01                              # us between consecutive frames' pose-kernel ends
     period = period[(period > 0) & (period < 5000)]
+    hyp = (rt[:, 4] - rt[:, 2]) * 0.01                             # RANSAC samples: first workgroup start -> the frame kernel's start
+    frm = (rt[:, 3] - rt[:, 4]) * 0.01                             #   (includes the ~1.3 us launch boundary); LM kernel start -> end
     rounds = dbg["rounds"][ok]
     return {"frames_sampled": int(len(rt)), "mean_rounds_pass1_pass2": [float(rounds[:, 0].mean()), float(rounds[:, 1].mean())],
             "pose_chain_busy_us": {"mean": float(pose_busy.mean()), "median": float(np.median(pose_busy))},
             "k_ti_resolve_us": {"mean": float(resolve.mean()), "median": float(np.median(resolve)), "max": float(resolve.max())},
+            "k_tp_hyp_us": {"mean": float(hyp.mean()), "median": float(np.median(hyp))},
+            "k_tp_frame_us": {"mean": float(frm.mean()), "median": float(np.median(frm))},
             "frame_period_us": {"mean": float(period.mean()), "median": float(np.median(period))},
             "source": "in-kernel s_memrealtime stamps of the timed region's last step (svo_debug_track_frames)"}
 
@@ -931,11 +935,20 @@ def main():
                          for k in kern}
             for k in kern:
                 kern[k]["ms_per_frame"] = per_frame[k]
+            # the tail's kernels: in-kernel wall-clock stamps of the timed region where they exist (an event pair around a ~40 us
+            # kernel of single-wave workgroups inflates it by up to 10 us; the stamps agree with rocprofv3's averages)
+            stamped = {}
+            if chain and "k_ti_resolve_us" in chain:
+                stamped = {k: chain[k + "_us"]["mean"] * 1e-3 for k in ("k_ti_resolve", "k_tp_hyp", "k_tp_frame") if k in per_frame}
+                for k, v in stamped.items():
+                    per_frame[k] = v
+                    kern[k]["ms_per_frame"] = v
+                    kern[k]["ms_per_frame_source"] = "in-kernel stamps"
             dom = max(per_frame.items(), key=lambda kv: kv[1])[0]
             dom_s = kern[dom]["avg_ms"] * 1e-3
             timing = "HIP events around the kernel's launches in an untimed profile pass"
-            if chain and "k_ti_resolve_us" in chain and dom == "k_ti_resolve":
-                dom_s = chain["k_ti_resolve_us"]["mean"] * 1e-6
+            if dom in stamped:
+                dom_s = stamped[dom] * 1e-3
                 timing = "in-kernel wall-clock stamps over the timed region's last step (event pairs inflate a ~40 us kernel)"
             units = "images"
             ppl = min(B, 32) if track else B     # pairs one front-end launch covers (svo_track_batch_dev: sub-batches of 32)

@@ -117,8 +117,8 @@ typedef struct svo_track_debug {
   int32_t pnp_best, pnp_iterations, pnp_inliers, pnp_ok;   /* cv::solvePnPRansac: winning sample, samples visited, consensus */
   int32_t active_rows[2], rounds[2];   /* matching passes 1 / 2: rows that could match at all, resolution rounds */
   int32_t resolve_us;      /* duration of the frame's k_ti_resolve launch (in-kernel wall clock) */
-  int64_t rt[4];           /* in-kernel wall clock (s_memrealtime, 10 ns ticks): k_ti_resolve start / end, first RANSAC-sample
-                            * workgroup start, end of the frame's pose kernel */
+  int64_t rt[6];           /* in-kernel wall clock (s_memrealtime, 10 ns ticks): k_ti_resolve start / end, first RANSAC-sample
+                            * workgroup start, k_tp_frame end, k_tp_frame start, (unused) */
   double T_pnp[16];        /* the pose solvePnPRansac returned (row-major 4x4), before the CV_32F rounding and the LM */
 } svo_track_debug;
 

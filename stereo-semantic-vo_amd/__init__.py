@@ -37,7 +37,7 @@ TRACK_DTYPE = np.dtype([("Tcw", "<f4", (16,)), ("frame_id", "<i4"), ("n_kp", "<i
 TRACK_DEBUG_DTYPE = np.dtype([("match_gid", "<i4", (512,)), ("new_gid", "<i4", (512,)), ("frame_id", "<i4"),
                               ("pnp_best", "<i4"), ("pnp_iterations", "<i4"), ("pnp_inliers", "<i4"), ("pnp_ok", "<i4"),
                               ("active_rows", "<i4", (2,)), ("rounds", "<i4", (2,)), ("resolve_us", "<i4"),
-                              ("rt", "<i8", (4,)), ("T_pnp", "<f8", (16,))])
+                              ("rt", "<i8", (6,)), ("T_pnp", "<f8", (16,))])
 
 # Every symbol include/svo.h declares (checked by tests/test_abi.py without a GPU).
 ABI_SYMBOLS = [
@@ -327,7 +327,7 @@ class Svo:
     def debug_track_frames(self, first, n):
         """svo_debug_track_frames: TRACK_DEBUG_DTYPE records of n frames of the last device-resident call."""
         out = np.zeros(n, TRACK_DEBUG_DTYPE)
-        assert TRACK_DEBUG_DTYPE.itemsize == 4096 + 10 * 4 + 32 + 128
+        assert TRACK_DEBUG_DTYPE.itemsize == 4096 + 10 * 4 + 48 + 128
         self._chk(self.lib.svo_debug_track_frames(self.h, int(first), int(n), _p(out)))
         return out
 

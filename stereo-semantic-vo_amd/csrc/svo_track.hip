@@ -74,8 +74,8 @@ struct TrackWork {
   int32_t ready;                 // = frame index + 1 once the record of that frame is complete (cleared by svo_track_reset)
   int32_t frame_id, nkp, n_stereo, n_pass1, n_pass2, n_new, n_local, skip_match;
   long long ts[8];               // diagnostics: s_memtime at begin / pass 1 / pass 2 / frame end / done, dense rows, late rows
-  long long rt[4];               // diagnostics: s_memrealtime (100 MHz, one clock for the chip) at k_ti_resolve start / end,
-                                 // k_tp_hyp start (its workgroup 0), k_tp_frame end
+  long long rt[6];               // diagnostics: s_memrealtime (100 MHz, one clock for the chip) at k_ti_resolve start / end,
+                                 // k_tp_hyp start (its workgroup 0), k_tp_frame end, k_tp_frame start, (unused)
   int32_t diag[2];               // [0] rows of pass 1 | rounds << 16, [1] rows of pass 2 | rounds << 16
   int32_t n_edges;               // 3D-2D correspondences of the frame (src/pnpmatch.cc:216-224), in keypoint order:
   int32_t edge_gid[TRK_MAXKP];   //   id of the map point (CurrentFrame->MapPoints[j]->...) ...
@@ -1021,6 +1021,7 @@ __global__ __launch_bounds__(TPF_NT) void k_tp_frame(TrackState* st, TrackWork* 
   depth += (size_t)blockIdx.y * kstride; res_out += blockIdx.y;
   const int tid = threadIdx.x;
   tp_wait_work(st, work, tag);
+  if (tid == 0) work->rt[4] = wall_clock64();
   const long long tf0 = clock64();
   const int id = ld_agent(&work->frame_id), nkp = ld_agent(&work->nkp), skip = ld_agent(&work->skip_match), n_edges = ld_agent(&work->n_edges);
   float* gpos = st->gpos;
@@ -1721,7 +1722,7 @@ extern "C" int svo_debug_track_frames(svo_ctx* ctx, int first, int n, svo_track_
     o.active_rows[0] = q.diag[0] & 0xffff; o.active_rows[1] = q.diag[1] & 0xffff;
     o.rounds[0] = q.diag[0] >> 16; o.rounds[1] = q.diag[1] >> 16;
     o.resolve_us = (int32_t)((q.rt[1] - q.rt[0]) / 100);   // s_memrealtime: 100 MHz
-    for (int i = 0; i < 4; ++i) o.rt[i] = q.rt[i];
+    for (int i = 0; i < 6; ++i) o.rt[i] = q.rt[i];
     memcpy(o.T_pnp, q.T_pnp, sizeof o.T_pnp);
   }
   return SVO_OK;
@@ -1743,7 +1744,7 @@ extern "C" int svo_debug_track_realtime(svo_ctx* ctx, int slot, int64_t rt[4]) {
   if (!ctx || !rt || !ctx->d_work || slot < 0 || slot >= ctx->work_cap) return SVO_E_INVALID;
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   TrackWork* w = reinterpret_cast<TrackWork*>(ctx->d_work) + (size_t)ctx->work_last_half * ctx->work_cap + slot;
-  SVO_HIP(ctx, hipMemcpy(rt, w->rt, sizeof(long long) * 4, hipMemcpyDeviceToHost));
+  SVO_HIP(ctx, hipMemcpy(rt, w->rt, sizeof(long long) * 4, hipMemcpyDeviceToHost));   // (the first four stamps)
   return SVO_OK;
 }
 

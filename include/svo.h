@@ -162,9 +162,11 @@ void svo_destroy(svo_ctx* ctx);
  * tail's small dependent kernels then queue for slots (7 us per frame on average); the front end needs a tenth of the tail's
  * time on the whole chip, so one XCD keeps up (measured: 100 % 13.2 k, 25 % 14.1 k, 12 % 14.4 k frames/s).  Scheduling only -
  * same records.
- * "pose_flag" (default 1): one sequence's pose kernels learn that their frame has been matched from a per-frame tag the
- * index chain publishes in HBM (agent-scope stores / polls) instead of waiting on one stream event per group of frames -
- * the pose chain then never stands still because a LATER frame of its group is slow to match; 0: stream events - same records.
+ * "pose_flag" (default 0): 1 = one sequence's pose kernels learn that their frame has been matched from a per-frame tag the
+ * index chain publishes in HBM (agent-scope stores / polls, bounded) instead of waiting on one stream event per group of
+ * frames - the pose chain then never stands still because a LATER frame of its group is slow to match (+0.6 % on the
+ * headline run).  Same records.  Off by default because the poll relies on the index kernel running concurrently with the
+ * polling kernel: under a tool that serialises dispatches (rocprofv3 --kernel-trace) every poll runs into its time-out.
  * "epnp_exact" (default 0): 1 makes every RANSAC sample's EPnP follow OpenCV's own loops one after the other (cyclic
  * one-sided Jacobi SVDs, SVD / QR least squares, IEEE division and square root, no FMA contraction), one lane per
  * sample - the arithmetic of the CPU restatement the tests compare with, an order of magnitude slower than the

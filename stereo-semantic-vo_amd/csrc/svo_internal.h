@@ -147,7 +147,9 @@ struct svo_ctx {
   int opt_fast_cand_cap = 2048;   // svo_set_option("fast_cand_cap"): entries of k_fast's candidate list (<= 2048)
   int opt_pose_mfma = 1;   // svo_set_option("pose_mfma"): Gram accumulation of k_pose_opt on f64 MFMA
   int opt_fe_cu_percent = 12;   // svo_set_option("fe_cu_percent"): share of the CUs the batched tracker's front-end stream may use
-  int opt_pose_flag = 1;   // svo_set_option("pose_flag"): one sequence's pose kernels poll the index chain's per-frame tag instead of waiting on stream events
+  int opt_pose_flag = 0;   // svo_set_option("pose_flag"): one sequence's pose kernels poll the index chain's per-frame tag instead of waiting on stream
+                           // events.  OFF by default: the poll needs the index kernel to run CONCURRENTLY with the polling one, and a tool that
+                           // serialises kernel dispatches (rocprofv3 --kernel-trace does) turns every frame into a timed-out poll
   int opt_epnp_exact = 0;  // svo_set_option("epnp_exact"): RANSAC samples solved in OpenCV's operation order, one lane each (parity mode)
   bool profiling = false;
   std::vector<SvoProfileEntry> prof;

@@ -946,8 +946,12 @@ __global__ __launch_bounds__(256) void k_tp_hyp(TrackState* st, const TrackWork*
   tp_wait_work(st, work, tag);
   const long long t_start = clock64();
   if (hyp_base == 0 && blockIdx.x == 0 && threadIdx.x == 0) const_cast<TrackWork*>(work)->rt[2] = wall_clock64();
-  const int n = ld_agent(&work->n_edges);
-  if (ld_agent(&work->skip_match) || n < 5) return;
+  // the record's header and this thread's first correspondence in ONE round trip to the coherent level (the entry is read
+  // whether or not it exists - a stale one is a valid index - and dropped below if e >= n): a dependent round trip less
+  // in front of every frame's RANSAC
+  const int n = ld_agent(&work->n_edges), skip0 = ld_agent(&work->skip_match);
+  const int gid0 = ld_agent(&work->edge_gid[threadIdx.x]), j0 = min(max(ld_agent(&work->edge_kp[threadIdx.x]), 0), kstride - 1);
+  if (skip0 || n < 5) return;
   const int first = hyp_base + (int)blockIdx.x * (int)(blockDim.x >> 6);
   if (hyp_base > 0) {
     if (threadIdx.x < TP_HYP_FIRST) { S.cnt[threadIdx.x] = st->hyp[threadIdx.x].cnt; S.ok[threadIdx.x] = st->hyp[threadIdx.x].ok; }
@@ -958,8 +962,9 @@ __global__ __launch_bounds__(256) void k_tp_hyp(TrackState* st, const TrackWork*
   }
   const float* gpos = st->gpos;
   for (int e = threadIdx.x; e < n; e += blockDim.x) {
-    const float* gp = gpos + 3 * (size_t)(ld_agent(&work->edge_gid[e]) & (TRK_GPOS - 1));
-    const svo_kp k = kp[ld_agent(&work->edge_kp[e])];
+    const bool first_e = e == (int)threadIdx.x;
+    const float* gp = gpos + 3 * (size_t)((first_e ? gid0 : ld_agent(&work->edge_gid[e])) & (TRK_GPOS - 1));
+    const svo_kp k = kp[first_e ? j0 : ld_agent(&work->edge_kp[e])];
     S.Xw[3 * e] = (double)gp[0]; S.Xw[3 * e + 1] = (double)gp[1]; S.Xw[3 * e + 2] = (double)gp[2];
     S.uv[2 * e] = (double)k.x; S.uv[2 * e + 1] = (double)k.y;
   }
@@ -1024,12 +1029,14 @@ __global__ __launch_bounds__(TPF_NT) void k_tp_frame(TrackState* st, TrackWork* 
   if (tid == 0) work->rt[4] = wall_clock64();
   const long long tf0 = clock64();
   const int id = ld_agent(&work->frame_id), nkp = ld_agent(&work->nkp), skip = ld_agent(&work->skip_match), n_edges = ld_agent(&work->n_edges);
+  // (this thread's first correspondence with the header, in one round trip: see k_tp_hyp)
+  const int gid0 = ld_agent(&work->edge_gid[tid]), j0 = min(max(ld_agent(&work->edge_kp[tid]), 0), kstride - 1);
   float* gpos = st->gpos;
   // ---- 3D-2D correspondences, ordered by keypoint index (src/pnpmatch.cc:216-224) ---------------
   for (int e = tid; e < n_edges; e += TPF_NT) {
-    const int j = ld_agent(&work->edge_kp[e]);
+    const int j = e == tid ? j0 : ld_agent(&work->edge_kp[e]);
     const svo_kp k = kp[j];
-    float* gp = gpos + 3 * (size_t)(ld_agent(&work->edge_gid[e]) & (TRK_GPOS - 1));
+    float* gp = gpos + 3 * (size_t)((e == tid ? gid0 : ld_agent(&work->edge_gid[e])) & (TRK_GPOS - 1));
     float xyz[3];
     if (id == 0) {   // Tracking::init: the points of frame 0 are placed with the identity pose, before its LM
       const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, z3[3] = {0, 0, 0};

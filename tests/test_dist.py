@@ -65,3 +65,16 @@ def test_sharding_rule(pkg):
         assert sorted(seen) == list(range(5 * world))
     assert shard.whole_job_rate(128 * 20, 8, 2.0) == 128 * 20 * 8 / 2.0
     assert shard.sequence_seed_for_rank(100, 3) == 103
+
+
+def test_bench_refuses_a_launcher_with_another_rank_count():
+    """bench.py --gpus 4 under a launcher that started 2 ranks must exit non-zero BEFORE touching a GPU instead of printing
+    a line that misstates n_gpus (runs without a GPU: the check comes first)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--frames", "8"], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "refusing" in (out.stderr + out.stdout)
+    assert not any(l.startswith("{") for l in out.stdout.splitlines())

@@ -389,8 +389,8 @@ def test_tracking_is_independent_of_how_the_sequence_is_batched(pkg):
     # strategy switches never change a record: one packed entry per row (everything "dense"), no stored blockers, the
     # pose chain taking frames over one by one or sixteen at a time
     assert a == run(64, track_lcap=1) and a == run(64, track_nblk=0) and a == run(64, track_group=1) and a == run(64, track_group=16)
-    # the hand-over between the two chains: per-frame tags polled by the pose kernels (default) or stream events per group
-    assert a == run(64, pose_flag=0) and a == run(16, pose_flag=0) and a == run(1, pose_flag=0, track_group=1)
+    # the hand-over between the two chains: stream events per group (default) or per-frame tags polled by the pose kernels
+    assert a == run(64, pose_flag=1) and a == run(16, pose_flag=1) and a == run(1, pose_flag=1, track_group=1)
     r = np.frombuffer(a, pkg.TRACK_DTYPE)
     Twc = np.linalg.inv(r[-1]["Tcw"].reshape(4, 4).astype(np.float64))
     assert np.linalg.norm(Twc[:3, 3] - T[-1][:3, 3].cpu().numpy()) < 3.0      # 63 m path, no loop closing

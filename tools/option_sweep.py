@@ -1,5 +1,5 @@
 """Diagnostics: the headline workload (4541 frames, svo_track_batch_dev in 23 steps of 197) under different option sets,
-the sequence rendered once.  usage: python tools/option_sweep.py "pose_group=0" "track_group=8" "track_group=16,pose_group=1" ..."""
+the sequence rendered once.  usage: python tools/option_sweep.py "" "track_group=8" "fe_cu_percent=25,pose_flag=1" ..."""
 import importlib, sys, time
 sys.path.insert(0, ".")
 import numpy as np, torch

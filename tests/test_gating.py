@@ -120,6 +120,22 @@ def test_oracle_gating_effects(orc, pkg, gated_oracle_run):
     assert sum(o[3] for o in out) > 0
 
 
+def test_oracle_tail_entry_with_boxes_equals_full_frame_entry(orc, pkg, gated_oracle_run):
+    """orc_track_tail with detection boxes (what the gated device-resident modes are compared with when they are fed
+    front-end results) == orc_track_frame_boxes on the images: records, match indices, F and the veto count."""
+    L, R, out = gated_oracle_run
+    cam = pkg.KITTI_00_02
+    trk = orc.Tracker(L.shape[2], L.shape[1], cam)
+    for k in range(5):
+        fe = orc.stereo_frame(L[k], R[k], cam["bf"], cam["fx"])
+        res, cur, pnp, Tp = trk.track_tail(fe["kpL"], fe["dL"], fe["depth"], boxes=boxes_for(k))
+        ref, ref_cur, ref_F, ref_vetoes = out[k]
+        assert res.tobytes() == ref.tobytes(), k
+        assert np.array_equal(cur, ref_cur), k
+        assert np.array_equal(trk.F, ref_F) and trk.vetoes == ref_vetoes, k
+    trk.close()
+
+
 @pytest.mark.gpu
 def test_gpu_gated_tracker_matches_oracle(pkg, gated_oracle_run):
     L, R, out = gated_oracle_run

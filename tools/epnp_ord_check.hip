@@ -1,0 +1,118 @@
+// epnp_ord_check.hip - the order-preserving wave EPnP (csrc/svo_epnp_ord_dev.h) against the CPU restatement of OpenCV's
+// epnp::compute_pose (oracle/orc_pnp_cv.c, linked in as the checker) on seeded five-point samples: R, t and the three
+// candidates' reprojection errors must agree BIT FOR BIT.  Test infrastructure (tests/test_epnp_ord.py runs it on the GPU box).
+//   usage: epnp_ord_check [samples] [world offset in m] [sigma px] [force_fallback]
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "../stereo-semantic-vo_amd/csrc/svo_epnp_ord_dev.h"
+
+extern "C" void orc_epnp5(const double Xw5[15], const double uv5[10], const double K[4], double R_out[9], double t_out[3]);
+extern "C" double orc_epnp_last_rep[3];
+
+struct ProbeOut { double R[9], t[3], rep[3]; int ok, flag, sweeps, pad; long long stamp[8]; };
+
+__global__ __launch_bounds__(64) void k_probe(const double* X5, const double* u5, const double* Kp, ProbeOut* out, int force_flag, epnp_ord::Lds* dump) {
+  __shared__ epnp_ord::Lds S;
+  __shared__ epnp_exact::Work W;
+  const int lane = threadIdx.x;
+  X5 += 15 * blockIdx.x; u5 += 10 * blockIdx.x;
+  if (lane < 15) S.pws[lane] = X5[lane];
+  if (lane < 10) S.us[lane] = u5[lane];
+  const double K[4] = {Kp[0], Kp[1], Kp[2], Kp[3]};
+  double R[9], t[3], rep[3];
+  if (force_flag) { /* exercised through the flag below */ }
+  const bool ok = epnp_ord::solve5_wave(S, W, K, R, t, rep, force_flag != 0);
+  if (lane == 0) {
+    ProbeOut o;
+    for (int i = 0; i < 9; ++i) o.R[i] = R[i];
+    for (int i = 0; i < 3; ++i) { o.t[i] = t[i]; o.rep[i] = rep[i]; }
+    o.ok = ok; o.flag = S.flag; o.sweeps = S.sweeps; o.pad = 0;
+    for (int i = 0; i < 8; ++i) o.stamp[i] = S.stamp[i];
+    out[blockIdx.x] = o;
+  }
+  if (dump && blockIdx.x == 0) {
+    const double* src = reinterpret_cast<const double*>(&S);
+    double* dst = reinterpret_cast<double*>(dump);
+    for (int i = lane; i < (int)(sizeof(epnp_ord::Lds) / 8); i += 64) dst[i] = src[i];
+  }
+}
+
+static double urand() { return rand() / (RAND_MAX + 1.0); }
+static double nrand() { double u = urand() + 1e-12, v = urand(); return sqrt(-2 * log(u)) * cos(6.283185307179586 * v); }
+
+int main(int argc, char** argv) {
+  const int n = argc > 1 ? atoi(argv[1]) : 4096;
+  const double off = argc > 2 ? atof(argv[2]) : 0.0, sigma = argc > 3 ? atof(argv[3]) : 0.5;
+  const int force = argc > 4 ? atoi(argv[4]) : 0;
+  const double K[4] = {718.856f, 718.856f, 607.1928f, 185.2157f};
+  std::vector<double> X(15 * (size_t)n), U(10 * (size_t)n);
+  srand(12345);
+  for (int s = 0; s < n; ++s)
+    for (int i = 0; i < 5; ++i) {
+      double uu = 40 + urand() * 1160, vv = 40 + urand() * 300, z = 5 + urand() * 75;
+      if (s % 97 == 3) z = 20.0;                       // coplanar sample (fronto-parallel plane): a degenerate PCA direction
+      const double xc = (uu - K[2]) * z / K[0], yc = (vv - K[3]) * z / K[1];
+      X[15 * s + 3 * i] = (float)(xc + off * 0.3); X[15 * s + 3 * i + 1] = (float)(yc + 2); X[15 * s + 3 * i + 2] = (float)(z + off);
+      uu += nrand() * sigma; vv += nrand() * sigma;
+      if (s % 5 == 0 && i == 4) { uu += 50; vv -= 40; }   // an outlier in the sample
+      U[10 * s + 2 * i] = (float)uu; U[10 * s + 2 * i + 1] = (float)vv;
+    }
+  double *dX, *dU, *dK; ProbeOut* dO; epnp_ord::Lds* dD;
+  hipMalloc(&dX, X.size() * 8); hipMalloc(&dU, U.size() * 8); hipMalloc(&dK, 32); hipMalloc(&dO, sizeof(ProbeOut) * n); hipMalloc(&dD, sizeof(epnp_ord::Lds));
+  hipMemcpy(dX, X.data(), X.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dU, U.data(), U.size() * 8, hipMemcpyHostToDevice);
+  hipMemcpy(dK, K, 32, hipMemcpyHostToDevice);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(k_probe, dim3(n), dim3(64), 0, 0, dX, dU, dK, dO, force, dD);
+  if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed: %s\n", hipGetErrorString(hipGetLastError())); return 2; }
+  const int nt = n < 100 ? n : 100;
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(k_probe, dim3(nt), dim3(64), 0, 0, dX, dU, dK, dO, force, (epnp_ord::Lds*)nullptr);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+  hipLaunchKernelGGL(k_probe, dim3(n), dim3(64), 0, 0, dX, dU, dK, dO, force, dD);
+  hipDeviceSynchronize();
+  std::vector<ProbeOut> O(n);
+  hipMemcpy(O.data(), dO, sizeof(ProbeOut) * n, hipMemcpyDeviceToHost);
+  int bad = 0, flagged = 0, notok = 0; long long cyc = 0; long long st[8] = {0};
+  int sweeps_hist[32] = {0};
+  for (int s = 0; s < n; ++s) {
+    double R[9], t[3];
+    orc_epnp5(&X[15 * s], &U[10 * s], K, R, t);
+    bool fin = true;
+    for (int i = 0; i < 9; ++i) fin = fin && isfinite(R[i]);
+    for (int i = 0; i < 3; ++i) fin = fin && isfinite(t[i]);
+    const ProbeOut& o = O[s];
+    bool same = (fin ? 1 : 0) == o.ok;
+    if (fin) same = same && !memcmp(R, o.R, sizeof R) && !memcmp(t, o.t, sizeof t);
+    for (int i = 0; i < 3; ++i) {
+      const double a = orc_epnp_last_rep[i], b = o.rep[i];
+      if (!(isnan(a) && isnan(b))) same = same && !memcmp(&a, &b, 8);
+    }
+    flagged += o.flag != 0; notok += !o.ok;
+    cyc += o.stamp[7] - o.stamp[0];
+    for (int i = 1; i < 8; ++i) st[i] += o.stamp[i] - o.stamp[i - 1];
+    sweeps_hist[o.sweeps & 31]++;
+    if (!same) {
+      if (bad < 8) {
+        printf("MISMATCH sample %d (flag %d ok %d/%d sweeps %d)\n  rep gpu %.17g %.17g %.17g\n  rep cpu %.17g %.17g %.17g\n", s, o.flag, o.ok, (int)fin, o.sweeps,
+               o.rep[0], o.rep[1], o.rep[2], orc_epnp_last_rep[0], orc_epnp_last_rep[1], orc_epnp_last_rep[2]);
+        printf("  t gpu %.17g %.17g %.17g\n  t cpu %.17g %.17g %.17g\n", o.t[0], o.t[1], o.t[2], t[0], t[1], t[2]);
+      }
+      ++bad;
+    }
+  }
+  printf("samples %d  mismatches %d  flagged (sequential fallback) %d  non-finite %d\n", n, bad, flagged, notok);
+  printf("mean ticks per solve %.0f  stages:", (double)cyc / n);
+  for (int i = 1; i < 8; ++i) printf(" %.0f", (double)st[i] / n);
+  printf("\n  (control points + barycentric | M, MtM | 12x12 SVD | L, rho, beta init SVDs | gauss-newton | R, t, error | selection)\n");
+  printf("12x12 sweeps histogram:");
+  for (int i = 0; i < 32; ++i) if (sweeps_hist[i]) printf(" %d:%d", i, sweeps_hist[i]);
+  printf("\nlaunch of %d samples: %.1f us\n", nt, ms * 1e3);
+  return bad ? 1 : 0;
+}

@@ -323,7 +323,12 @@ extern "C" int svo_set_option(svo_ctx* ctx, const char* key, int value) {
     return SVO_OK;
   }
   if (!strcmp(key, "pose_flag")) { ctx->opt_pose_flag = value != 0; return SVO_OK; }
-  if (!strcmp(key, "epnp_exact")) { ctx->opt_epnp_exact = value != 0; return SVO_OK; }
+  if (!strcmp(key, "epnp_exact")) {
+    if (value < 0 || value > 2) return SVO_E_INVALID;
+    ctx->opt_epnp_exact = value;
+    return SVO_OK;
+  }
+  if (!strcmp(key, "epnp_force_seq")) { ctx->opt_epnp_force_seq = value != 0; return SVO_OK; }
   if (!strcmp(key, "multi_pipeline")) { ctx->opt_multi_pipeline = value != 0; return SVO_OK; }
   if (!strcmp(key, "pyr_fused")) { ctx->opt_pyr_fused = value != 0; return SVO_OK; }
   if (!strcmp(key, "frontend_overlap")) {

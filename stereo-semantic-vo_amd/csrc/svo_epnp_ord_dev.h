@@ -8,16 +8,21 @@
 // INDEPENDENT operations run.  svo_epnp_exact_dev.h walks the loops on one lane (the checker, an order of magnitude slower
 // than the statistical wave solver of svo_epnp_dev.h); this file spreads exactly those operations over the wavefront:
 //
-//   * JacobiSVDImpl_ (cyclic one-sided Jacobi): a pair (i, j) reads and writes rows i and j only.  The row update
-//     t0 = c Ai[k] + s Aj[k], t1 = -s Ai[k] + c Aj[k] is elementwise in k: one lane per column.  The three k-ordered sums
-//     of a pair (p = sum Ai[k] Aj[k], a = sum t0^2, b = sum t1^2) stay sequential chains, but every lane of the pair's
-//     16-lane DPP row runs the chain on operands broadcast from lane k (v_mov_b64_dpp row_newbcast:k), so the rotation
-//     (c, s) is known to all lanes of the row without a further exchange.  Pairs on disjoint rows commute exactly: the
-//     12 x 12 eigen-problem of M^T M runs FOUR pairs at a time - one per DPP row of the wave - from a static list
-//     schedule of the cyclic order (tools/gen_jacobi_schedule.py: 16.5 steps per sweep instead of 66, sweeps overlapped,
-//     verified bit-identical to the sequential loop).  V is not accumulated there: epnp only asks for U.
+//   * JacobiSVDImpl_ (cyclic one-sided Jacobi): a pair (i, j) reads and writes rows i and j only, so pairs on disjoint rows
+//     commute exactly.  Lane 16 g + r of the wave holds columns g, 4 + g, 8 + g of matrix row r (r < 16 rows, 12 columns: A
+//     followed by V); a pair is worked on by the lanes of its two rows, each fetching the partner row through LDS.  The row
+//     update t0 = c Ai[k] + s Aj[k], t1 = -s Ai[k] + c Aj[k] is elementwise.  The three k-ordered sums of a pair
+//     (p = sum Ai[k] Aj[k], a = sum t0^2, b = sum t1^2) are sequential chains over the columns - which is exactly what
+//     v_mfma_f64_4x4x4_4b_f64 computes over the four 16-lane groups: D = fma(a3, b3, fma(a2, b2, fma(a1, b1, fma(a0, b0, C))))
+//     per (row, column), rounded after every step (measured: tools/microbench/mfma_f64_4x4.hip, 128,000 of 128,000 entries
+//     bit-identical).  With A = 1.0 the products are exact, so three chained MFMAs ARE the loop `s = 0; for k < 12: s += x[k]`
+//     in IEEE arithmetic, for all 16 rows at once, the result landing in every lane of the row.  The rotation (c, s) is then
+//     computed redundantly by all lanes of the pair from identical operands.  Up to floor(n / 2) pairs run per step from a
+//     static list schedule of the cyclic order (tools/gen_jacobi_schedule.py: 12 steps per sweep instead of 66 for the
+//     12 x 12 problem, sweeps overlapped, verified bit-identical to the sequential loop); problems on disjoint rows - the
+//     three EPnP candidates' decompositions - share the steps.  V is not accumulated for M^T M: epnp only asks for U.
 //   * the small decompositions (3 x 3: control points, barycentric inverse, absolute orientation; 6 x 3 / 6 x 4 / 6 x 5:
-//     the three beta initialisations) run one problem per DPP row, the three EPnP candidates side by side.
+//     the three beta initialisations) go through the same engine, the three EPnP candidates side by side.
 //   * everything else (M, M^T M, L_6x10, rho, cvInvert / cvSolve back-substitution, compute_ccs / pcs, estimate_R_and_t,
 //     reprojection_error) is one lane per OUTPUT element, each lane summing its element in the loop's own order; the
 //     five Gauss-Newton steps with epnp::qr_solve are scalar code, one candidate per DPP row, arrays in registers.
@@ -38,6 +43,7 @@
 namespace epnp_ord {
 
 #define EO_FN __device__ __forceinline__
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 #include "svo_epnp_ord_tab.h"
 
@@ -50,8 +56,10 @@ namespace epnp_ord {
   } while (0)
 
 struct Lds {
-  double jr[16 * 16];       // Jacobi rows [A (M columns) | V (n columns)], row stride 16; 12 x 12: rows 0..11, small ones: rows 5 p .. 5 p + n - 1 of problem p
-  double jw[16];            // their W (squared row norms while rotating, singular values afterwards)
+  alignas(16) double jr[16 * 16];   // Jacobi rows [A (M columns) | V (n columns) | .. | W in column 15], row stride 16; 12 x 12: rows 0..11, small ones: rows 5 p .. 5 p + n - 1 of problem p
+  alignas(16) double xch[16][4][4];   // row exchange of the Jacobi engine: [row][lane group] = its three columns (+ pad)
+  double xw[16];                      // and the rows' W
+  unsigned short tab[EO_TAB_TOTAL];   // the schedules (svo_epnp_ord_tab.h)
   double pws[16], us[10], alphas[20], cws[12], ccinv[9];
   double M[120];
   double ut4[4][12];        // ut + 12 * (11 - q): vectors of the four smallest singular values, q = 0 the smallest
@@ -67,140 +75,164 @@ struct Lds {
   long long stamp[8];
 };
 
-// ---- row broadcast and in-order sums -------------------------------------------------------------------------------
-// v_mov_b64_dpp row_newbcast:K - every lane of a 16-lane row receives lane K's value.  Inline assembly (the DPP builtin
-// of this compiler is 32-bit only); FIRST additionally waits out the VALU-write -> DPP-read and EXEC -> DPP hazards the
-// compiler's hazard recogniser does not see inside an asm blob - the later moves of a chain read the same, long-written
-// source register.
-template <int K, bool FIRST>
-EO_FN double rbc(double x) {
-  double y;
-  if (FIRST)
-    asm volatile("s_nop 4\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x), "n"(K));
-  else
-    asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(y) : "v"(x), "n"(K));
-  return y;
-}
-template <int K, int M>
-struct RowSum {
-  static EO_FN double run(double acc, double x) { return RowSum<K + 1, M>::run(acc + rbc<K, K == 0>(x), x); }
-  static EO_FN void run2(double& a, double& b, double x, double y) {
-    a = a + rbc<K, K == 0>(x);
-    b = b + rbc<K, false>(y);
-    RowSum<K + 1, M>::run2(a, b, x, y);
-  }
-};
-template <int M>
-struct RowSum<M, M> {
-  static EO_FN double run(double acc, double) { return acc; }
-  static EO_FN void run2(double&, double&, double, double) {}
-};
-// s = 0; for (k = 0; k < M; k++) s += x[lane k of the row]; - in every lane of the row.  All 64 lanes must be active.
-template <int M>
-EO_FN double row_sum(double x) { return RowSum<0, M>::run(0.0, x); }
-template <int M>
-EO_FN void row_sum2(double x, double y, double& a, double& b) {
-  a = 0.0; b = 0.0;
-  RowSum<0, M>::run2(a, b, x, y);
-}
-
 EO_FN double xdiv(double a, double b) { return a / b; }
 EO_FN double xsqrt(double x) { return sqrt(x); }
 
-// ---- one (i, j) visit of JacobiSVDImpl_<double> for the pair held by this lane's DPP row ---------------------------------
-// ai / aj: this lane's column of rows i and j (columns >= M: the V part, rotated along), wi / wj: W[i], W[j].  Returns whether
-// THIS row's pair rotated (ai, aj, wi, wj updated then); `any` tells whether any row of the wave did.
+// The compiler's IEEE division and square root WITHOUT their range scaling (v_div_scale / v_ldexp) and special-case fix-up
+// (v_div_fixup / v_cmp_class): the same reciprocal (square root) estimate, Newton steps and final correction, instruction
+// for instruction - bit-identical whenever no scaling would have happened, i.e. for operands whose exponents stay a few
+// hundred binades away from the ends of the range (no infinities, NaNs, denormals; the dividend may be zero).  Only used
+// inside the Jacobi rotations, whose operands are bounded by the singular values: jacobi12 / svd_finish check that these
+// lie in [2^-100, 2^100] and hand the sample to the sequential solver otherwise.
+EO_FN double ndiv(double a, double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  const double q = a * r;
+  const double rem = __builtin_fma(-b, q, a);
+  return __builtin_fma(rem, r, q);
+}
+EO_FN double nsqrt(double x) {   // x > 0
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return g;
+}
+EO_FN bool w_in_range(double w) { return w >= 7.888609052210118e-31 && w <= 1.2676506002282294e30; }   // [2^-100, 2^100]
+
+// ---- in-order sums over the columns on the matrix core ------------------------------------------------------------------
+// v_mfma_f64_4x4x4_4b_f64 with A = 1.0: D(lane 16 i + c) = fma(1, B(48 + c), fma(1, B(32 + c), fma(1, B(16 + c), fma(1, B(c), C)))) for
+// every group i - the IEEE sum ((((C + b0) + b1) + b2) + b3) of the four lane groups' values, in group order, in all four lanes.
+EO_FN double gsum(double term, double acc) { return __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, term, acc, 0, 0, 0); }
+// s = 0; for (c = 0; c < M; c++) s += t[c]; with column c = 4 q + g held as t_q by lane group g; columns >= M (the V part) are
+// replaced by +0.0 (adding it leaves every partial sum as it is)
 template <int M>
-EO_FN bool jpair(double& ai, double& aj, double& wi, double& wj, bool valid, bool& any) {
-  const double eps = 2.220446049250313e-16 * 10;
-  const double p0 = row_sum<M>(ai * aj);
-  const bool rot = valid && !(fabs(p0) <= eps * xsqrt(wi * wj));
-  any = __any(rot);
-  if (!any) return false;
-  const double p = p0 * 2;
-  const double beta = wi - wj;
-  // cv::hypot(p, beta)
-  const double pa = fabs(p), pb = fabs(beta);
-  const bool agb = pa > pb;
-  const double hi = agb ? pa : pb, lo = agb ? pb : pa;
-  const double q = xdiv(lo, hi);
-  const double g = hi * xsqrt(1 + q * q);
-  const double gamma = (agb || pb > 0) ? g : 0.0;
-  const bool neg = beta < 0;
-  //   beta < 0:  delta = (gamma - beta) * 0.5; s = sqrt(delta / gamma); c = p / (gamma * s * 2)
-  //   else:      c = sqrt((gamma + beta) / (gamma * 2));                s = p / (gamma * c * 2)
-  const double num = neg ? (gamma - beta) * 0.5 : (gamma + beta);
-  const double den = neg ? gamma : gamma * 2;
-  const double r1 = xsqrt(xdiv(num, den));
-  const double r2 = xdiv(p, gamma * r1 * 2);
-  const double s = neg ? r1 : r2, c = neg ? r2 : r1;
-  const double t0 = c * ai + s * aj;
-  const double t1 = -s * ai + c * aj;
-  double a, b;
-  row_sum2<M>(t0 * t0, t1 * t1, a, b);
-  if (rot) { ai = t0; aj = t1; wi = a; wj = b; }
-  return rot;
+EO_FN double colsum(double t0, double t1, double t2, int g) {
+  double acc = gsum(M >= 4 || g < M ? t0 : 0.0, 0.0);
+  if (M > 4) acc = gsum(M >= 8 || 4 + g < M ? t1 : 0.0, acc);
+  if (M > 8) acc = gsum(M >= 12 || 8 + g < M ? t2 : 0.0, acc);
+  return acc;
 }
 
-// ---- up to four independent small problems, one per DPP row, each walked in the cyclic order ------------------------------
-// Problem of this lane's row: n Jacobi rows (n = 0: the row idles) starting at row `base` of S.jr, M columns of A followed by
-// n columns of V.  JacobiSVDImpl_ up to the end of its sweeps: rows rotated in place, S.jw = squared row norms.
+#define EO_TAB3_OFF 0
+#define EO_TAB4_OFF (EO_TAB3_OFF + EO_TAB3_STEPS * 3)
+#define EO_TAB5_OFF (EO_TAB4_OFF + EO_TAB4_STEPS * 4)
+#define EO_TAB12_OFF (EO_TAB5_OFF + EO_TAB5_STEPS * 5)
+EO_FN void load_tables(Lds& S, int lane) {
+  for (int e = lane; e < EO_TAB3_STEPS * 3; e += 64) S.tab[EO_TAB3_OFF + e] = c_tab3[0][e];
+  for (int e = lane; e < EO_TAB4_STEPS * 4; e += 64) S.tab[EO_TAB4_OFF + e] = c_tab4[0][e];
+  for (int e = lane; e < EO_TAB5_STEPS * 5; e += 64) S.tab[EO_TAB5_OFF + e] = c_tab5[0][e];
+  for (int e = lane; e < EO_TAB12_STEPS * 12; e += 64) S.tab[EO_TAB12_OFF + e] = c_tab12[0][e];
+}
+
+// ---- JacobiSVDImpl_<double> on the rows of S.jr, all problems of the wave together ------------------------------------------
+// Lane 16 g + r works on matrix row r (a row of S.jr: M columns of A, then V, 12 columns in all) and holds its columns g, 4 + g,
+// 8 + g.  (n, base): the problem row r belongs to - n rows starting at row `base`, n in {3, 4, 5, 12} - or n = 0: the row idles.
+// On return the rows are what JacobiSVDImpl_ leaves before its sort: rotated, the A part scaled by 1 / W[i], and
+// W[i] = sqrt(sum At[i][k]^2) in column 15 of the row.
 template <int M>
-EO_FN void jacobi_seq(Lds& S, int n, int base, int lane) {
-  const int col = lane & 15;
-  for (int r = 0; r < 5; ++r) {
-    const bool act = r < n;
-    const double x = S.jr[(base + (act ? r : 0)) * 16 + col];
-    const double w = row_sum<M>(x * x);
-    if (act && col == 0) S.jw[base + r] = w;
-  }
+EO_FN void jacobi_rows(Lds& S, int n, int base, int lane) {
+  const double eps = 2.220446049250313e-16 * 10;
+  const int r = lane & 15, g = lane >> 4, q = r - base;
+  double x0 = S.jr[r * 16 + g], x1 = S.jr[r * 16 + 4 + g], x2 = S.jr[r * 16 + 8 + g];
+  double W = colsum<M>(x0 * x0, x1 * x1, x2 * x2, g);
+  d2* const mine = reinterpret_cast<d2*>(S.xch[r][g]);
+  { d2 lo, hi; lo.x = x0; lo.y = x1; hi.x = x2; hi.y = 0.0; mine[0] = lo; mine[1] = hi; }
+  S.xw[r] = W;
+  const int tb = n == 12 ? EO_TAB12_OFF : (n == 5 ? EO_TAB5_OFF : (n == 4 ? EO_TAB4_OFF : EO_TAB3_OFF));
+  const int steps = n == 12 ? EO_TAB12_STEPS : (n == 5 ? EO_TAB5_STEPS : (n == 4 ? EO_TAB4_STEPS : EO_TAB3_STEPS));
+  const int pro = n == 12 ? EO_TAB12_PROLOGUE : (n == 5 ? EO_TAB5_PROLOGUE : (n == 4 ? EO_TAB4_PROLOGUE : EO_TAB3_PROLOGUE));
+  static_assert(EO_TAB3_SWEEPS == 1 && EO_TAB4_SWEEPS == 1 && EO_TAB5_SWEEPS == 1 && EO_TAB12_SWEEPS == 1, "one sweep per period");
+  const unsigned pm = n > 0 ? ((1u << n) - 1u) << base : 0u;   // the rows of my problem, as lanes of group 0
   EO_SYNC();
-  int i = 0, j = 1, iter = 0;
-  bool changed = false, active = n >= 2;
+  int tt = 0, tp = n > 0 ? tb + q : 0, sbase = 0;
+  unsigned chg = 0;      // bit s: this row rotated in sweep s
+  bool active = n >= 2;
+  unsigned e = S.tab[tp];
   while (__any(active)) {
-    const int ri = (base + i) * 16 + col, rj = (base + j) * 16 + col;
-    double ai = S.jr[ri], aj = S.jr[rj], wi = S.jw[base + i], wj = S.jw[base + j];
-    bool any;
-    const bool rot = jpair<M>(ai, aj, wi, wj, active, any);
-    if (rot) {
-      S.jr[ri] = ai; S.jr[rj] = aj;
-      if (col == 0) { S.jw[base + i] = wi; S.jw[base + j] = wj; }
-    }
-    EO_SYNC();
-    changed = changed || rot;
-    if (active) {
-      ++j;
-      if (j == n) {
-        ++i; j = i + 1;
-        if (i == n - 1) {         // end of a sweep: for (iter < max(m, 30)) { ...; if (!changed) break; }
-          if (!changed || iter + 1 == 30) active = false;
-          ++iter; i = 0; j = 1; changed = false;
-        }
+    int tn = tt + 1, tpn = tp + n, sbn = sbase;
+    if (tn == steps) { tn = pro; tpn = tb + pro * n + q; sbn = sbase + 1; }
+    const unsigned en = S.tab[n > 0 ? tpn : 0];           // next step's entry: requested a step ahead
+    const int pq = e & 15, sw = sbase + (int)((e >> 5) & 3);
+    const bool is_j = (e & 16) != 0;
+    const bool valid = active && pq != q && sw < 30;
+    const int pr = valid ? base + pq : r;
+    const d2* const theirs = reinterpret_cast<const d2*>(S.xch[pr][g]);
+    const d2 plo = theirs[0], phi = theirs[1];
+    const double p0 = colsum<M>(x0 * plo.x, x1 * plo.y, x2 * phi.x, g);
+    const double wP = S.xw[pr];
+    const bool rot = valid && !(fabs(p0) <= eps * nsqrt(W * wP));
+    if (__any(rot)) {
+      const double p = p0 * 2;
+      double beta = W - wP;                    // W[i] - W[j]: the j row sees the operands swapped
+      if (is_j) beta = -beta;
+      // cv::hypot(p, beta) = hi sqrt(1 + (lo / hi)^2) (a rotating pair has p != 0, so hi > 0)
+      const double pa = fabs(p), pb = fabs(beta);
+      const bool agb = pa > pb;
+      const double hi = agb ? pa : pb, lo = agb ? pb : pa;
+      const double qq = ndiv(lo, hi);
+      const double gamma = hi * nsqrt(1 + qq * qq);
+      //   beta < 0:  delta = (gamma - beta) * 0.5; s = sqrt(delta / gamma); c = p / (gamma * s * 2)
+      //   else:      c = sqrt((gamma + beta) / (gamma * 2));                s = p / (gamma * c * 2)
+      // gamma - beta = gamma + |beta| for beta < 0, and scaling by 0.5 / by 2 is exact: both quotients are the correctly
+      // rounded (gamma + |beta|) / (2 gamma)
+      const double r1 = nsqrt(ndiv(gamma + pb, gamma * 2));
+      const double r2 = ndiv(p, gamma * r1 * 2);
+      const bool neg = beta < 0;
+      const double s = neg ? r1 : r2, c = neg ? r2 : r1;
+      // row i: t0 = c Ai + s Aj; row j: t1 = -s Ai + c Aj = c (mine) + (-s) (theirs)
+      const double se = is_j ? -s : s;
+      const double n0 = c * x0 + se * plo.x, n1 = c * x1 + se * plo.y, n2 = c * x2 + se * phi.x;
+      const double Wn = colsum<M>(n0 * n0, n1 * n1, n2 * n2, g);
+      if (rot) {
+        x0 = n0; x1 = n1; x2 = n2; W = Wn;
+        chg |= 1u << sw;
+        d2 lo2, hi2; lo2.x = x0; lo2.y = x1; hi2.x = x2; hi2.y = 0.0;
+        mine[0] = lo2; mine[1] = hi2;
+        S.xw[r] = W;
       }
     }
+    EO_SYNC();
+    const bool closes = active && (e & 0x80u) != 0;        // the pair (n - 2, n - 1) of sweep sc ran in this step: the sweep is complete
+    if (__any(closes)) {
+      const int sc = sbase + (int)((e >> 8) & 3);
+      const unsigned long long bal = __ballot(closes && ((chg >> (sc & 31)) & 1u));
+      if (closes && (sc >= 29 || ((unsigned)bal & pm) == 0u)) active = false;   // for (iter < 30) { ...; if (!changed) break; }
+    }
+    tt = tn; tp = tpn; sbase = sbn; e = en;
   }
-}
-
-// After the sweeps: W[i] = sqrt(sum At[i][k]^2), descending order, rows scaled by 1 / W (cv::SVD's U^T); the V part stays.
-// Per problem p (this lane's row, p < 3): S.sw[p][pos] the singular values, S.srow[p][pos] the Jacobi row at sorted position pos.
-// A singular value <= DBL_MIN or two equal ones: S.flag.
-template <int M>
-EO_FN void svd_finish(Lds& S, int n, int base, int p, int lane) {
-  const int col = lane & 15;
-  for (int r = 0; r < 5; ++r) {
-    const bool act = r < n;
-    const double x = S.jr[(base + (act ? r : 0)) * 16 + col];
-    const double w = xsqrt(row_sum<M>(x * x));
-    if (act && col == 0) S.jw[base + r] = w;
+  // W[i] = sqrt(sum At[i][k]^2); At[i] *= 1 / W[i]  (the sort is the caller's: svd_rank)
+  const double w = xsqrt(colsum<M>(x0 * x0, x1 * x1, x2 * x2, g));
+  const double sc1 = 1 / w;
+  if (n > 0) {
+    S.jr[r * 16 + g] = M >= 4 || g < M ? x0 * sc1 : x0;
+    S.jr[r * 16 + 4 + g] = M >= 8 || 4 + g < M ? x1 * sc1 : (M > 4 ? x1 : x1);
+    S.jr[r * 16 + 8 + g] = M >= 12 || 8 + g < M ? x2 * sc1 : x2;
+    if (g == 0) S.jr[r * 16 + 15] = w;
   }
   EO_SYNC();
+}
+
+// cv::SVD's descending order for the problem of this lane's DPP row (p < 3; n rows from `base`): S.sw[p][pos] the singular values,
+// S.srow[p][pos] the Jacobi row at sorted position pos.  A singular value outside [2^-100, 2^100] (zero: JacobiSVDImpl_ would
+// draw a random vector) or two equal ones (the selection sort's swaps would matter): S.flag.
+EO_FN void svd_rank(Lds& S, int n, int base, int p, int lane) {
+  const int col = lane & 15;
   if (col < n) {
-    const double my = S.jw[base + col];
+    const double my = S.jr[(base + col) * 16 + 15];
     int rank = 0;
-    bool bad = !(my > 2.2250738585072014e-308);
+    bool bad = !w_in_range(my);
     for (int q = 0; q < 5; ++q)
       if (q < n && q != col) {
-        const double o = S.jw[base + q];
+        const double o = S.jr[(base + q) * 16 + 15];
         rank += o > my ? 1 : 0;
         bad = bad || o == my;
       }
@@ -208,71 +240,18 @@ EO_FN void svd_finish(Lds& S, int n, int base, int p, int lane) {
     S.sw[p][rank] = my;
     S.srow[p][rank] = base + col;
   }
-  for (int r = 0; r < 5; ++r) {
-    const bool act = r < n;
-    const int a = (base + (act ? r : 0)) * 16 + col;
-    const double s = 1 / S.jw[base + (act ? r : 0)];
-    const double x = S.jr[a];
-    if (act && col < M) S.jr[a] = x * s;
-  }
   EO_SYNC();
 }
 
-// ---- the 12 x 12 decomposition of M^T M: four pairs per step from the static schedule --------------------------------
-EO_FN void jacobi12(Lds& S, int lane) {
-  const int slot = lane >> 4, col = lane & 15;
-  for (int r0 = 0; r0 < 12; r0 += 4) {
-    const double x = S.jr[(r0 + slot) * 16 + col];
-    const double w = row_sum<12>(x * x);
-    if (col == 0) S.jw[r0 + slot] = w;
-  }
-  EO_SYNC();
-  unsigned chg = 0;   // bit s: a pair of sweep s handled by this row rotated
-  // the step's four entries are one uniform 64-bit (scalar) load, requested one step ahead
-  const uint64_t* tab64 = reinterpret_cast<const uint64_t*>(&c_j12_tab[0][0]);
-  int tt = 0, sbase = 0, last = 0;
-  uint64_t e4 = tab64[0];
-  int cl = c_j12_close[0];
-  for (;;) {
-    int tn = tt + 1, sbn = sbase;
-    if (tn == EO_J12_STEPS) { tn = EO_J12_PROLOGUE; sbn += 2; }
-    const uint64_t e4n = tab64[tn];
-    const int cln = c_j12_close[tn];
-    const unsigned e = (unsigned)(e4 >> (16 * slot)) & 0xffffu;
-    const int i = e & 15, j = (e >> 4) & 15, sw = sbase + (int)((e >> 8) & 3);
-    const bool valid = e != 0xffffu && sw < 30;
-    const int ri = (valid ? i : 0) * 16 + col, rj = (valid ? j : 1) * 16 + col;
-    double ai = S.jr[ri], aj = S.jr[rj], wi = S.jw[valid ? i : 0], wj = S.jw[valid ? j : 1];
-    bool any;
-    const bool rot = jpair<12>(ai, aj, wi, wj, valid, any);
-    if (rot) {
-      S.jr[ri] = ai; S.jr[rj] = aj;
-      if (col == 0) { S.jw[i] = wi; S.jw[j] = wj; }
-      chg |= 1u << sw;
-    }
-    EO_SYNC();
-    if (cl >= 0) {    // the (10, 11) pair of sweep sbase + cl ran in this step: that sweep is complete
-      const int sc = sbase + cl;
-      last = sc;
-      if (sc >= 29 || !__any((chg >> sc) & 1u)) break;
-    }
-    tt = tn; sbase = sbn; e4 = e4n; cl = cln;
-  }
-  if (lane == 0) S.sweeps = last + 1;
-  // singular values; the rows of the four smallest, scaled: S.ut4[q] = ut + 12 * (11 - q)
-  for (int r0 = 0; r0 < 12; r0 += 4) {
-    const double x = S.jr[(r0 + slot) * 16 + col];
-    const double w = xsqrt(row_sum<12>(x * x));
-    if (col == 0) S.jw[r0 + slot] = w;
-  }
-  EO_SYNC();
+// the 12 x 12 decomposition of M^T M: the rows of the four smallest singular values, S.ut4[q] = ut + 12 * (11 - q)
+EO_FN void svd12_smallest(Lds& S, int lane) {
   if (lane < 12) {
-    const double my = S.jw[lane];
+    const double my = S.jr[lane * 16 + 15];
     int rank = 0;
-    bool bad = !(my > 2.2250738585072014e-308);
+    bool bad = !w_in_range(my);
     for (int q = 0; q < 12; ++q)
       if (q != lane) {
-        const double o = S.jw[q];
+        const double o = S.jr[q * 16 + 15];
         rank += o > my ? 1 : 0;
         bad = bad || o == my;
       }
@@ -282,8 +261,7 @@ EO_FN void jacobi12(Lds& S, int lane) {
   EO_SYNC();
   if (lane < 48) {
     const int q = lane / 12, k = lane % 12, r = S.urow[q] & 15;
-    const double s = 1 / S.jw[r];
-    S.ut4[q][k] = S.jr[r * 16 + k] * s;
+    S.ut4[q][k] = S.jr[r * 16 + k];
   }
   EO_SYNC();
 }
@@ -367,9 +345,10 @@ EO_FN double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] 
 // uc, vc}.  Called by all 64 lanes of a wave; returns (in every lane) whether the pose is finite, R_out / t_out in every lane.
 // `xw` is the LDS workspace of the sequential fallback (force_seq: take it regardless - tests).
 EO_FN bool solve5_wave(Lds& S, epnp_exact::Work& xw, const double* K, double* R_out, double* t_out, double* rep, bool force_seq = false) {
-  const int lane = threadIdx.x & 63, slot = lane >> 4, col = lane & 15;
+  const int lane = threadIdx.x & 63, slot = lane >> 4, col = lane & 15, r16 = lane & 15;
   const double fu = K[0], fv = K[1], uc = K[2], vc = K[3];
-  if (lane == 0) { S.flag = force_seq ? 1 : 0; S.stamp[0] = clock64(); }   // force_seq: tests exercise the sequential fallback
+  if (lane == 0) { S.flag = force_seq ? 1 : 0; S.stamp[0] = clock64(); }
+  load_tables(S, lane);   // force_seq: tests exercise the sequential fallback
   EO_SYNC();
   // ---- choose_control_points -----------------------------------------------------------------------------------------
   if (lane < 3) {
@@ -389,8 +368,8 @@ EO_FN bool solve5_wave(Lds& S, epnp_exact::Work& xw, const double* K, double* R_
     S.jr[r * 16 + 3 + k] = r == k ? 1.0 : 0.0;
   }
   EO_SYNC();
-  jacobi_seq<3>(S, slot == 0 ? 3 : 0, 0, lane);
-  svd_finish<3>(S, slot == 0 ? 3 : 0, 0, 0, lane);
+  jacobi_rows<3>(S, r16 < 3 ? 3 : 0, r16 < 3 ? 0 : r16, lane);
+  svd_rank(S, slot == 0 ? 3 : 0, 0, 0, lane);
   if (lane < 9) {
     const int i = 1 + lane / 3, j = lane % 3;
     const double k = xsqrt(S.sw[0][i - 1] / 5);
@@ -406,8 +385,8 @@ EO_FN bool solve5_wave(Lds& S, epnp_exact::Work& xw, const double* K, double* R_
     S.jr[r * 16 + 3 + k] = r == k ? 1.0 : 0.0;
   }
   EO_SYNC();
-  jacobi_seq<3>(S, slot == 0 ? 3 : 0, 0, lane);
-  svd_finish<3>(S, slot == 0 ? 3 : 0, 0, 0, lane);
+  jacobi_rows<3>(S, r16 < 3 ? 3 : 0, r16 < 3 ? 0 : r16, lane);
+  svd_rank(S, slot == 0 ? 3 : 0, 0, 0, lane);
   if (lane < 9) {            // SVBkSbImpl_ with the identity as right-hand side: x[3 j + c] += (Ut[i][c] / w[i]) * Vt[i][j]
     const int j = lane / 3, c = lane % 3;
     double threshold = 0;
@@ -457,7 +436,8 @@ EO_FN bool solve5_wave(Lds& S, epnp_exact::Work& xw, const double* K, double* R_
   }
   EO_SYNC();
   if (lane == 0) S.stamp[2] = clock64();
-  jacobi12(S, lane);
+  jacobi_rows<12>(S, r16 < 12 ? 12 : 0, r16 < 12 ? 0 : r16, lane);
+  svd12_smallest(S, lane);
   if (lane == 0) S.stamp[3] = clock64();
   // ---- compute_L_6x10, compute_rho ---------------------------------------------------------------------------------------
   if (lane < 60) {
@@ -494,8 +474,12 @@ EO_FN bool solve5_wave(Lds& S, epnp_exact::Work& xw, const double* K, double* R_
     }
   }
   EO_SYNC();
-  jacobi_seq<6>(S, nc, base, lane);
-  svd_finish<6>(S, nc, base, cand, lane);
+  {   // rows 0..3: candidate 1 (6 x 4), rows 5..7: candidate 2 (6 x 3), rows 10..14: candidate 3 (6 x 5)
+    const int pc = r16 / 5, pn = pc == 0 ? 4 : (pc == 1 ? 3 : 5);
+    const bool mine = r16 < 15 && r16 % 5 < pn;
+    jacobi_rows<6>(S, mine ? pn : 0, mine ? 5 * pc : r16, lane);
+  }
+  svd_rank(S, nc, base, cand, lane);
   if (slot < 3 && col < nc) {   // SVBkSbImpl_: x[j] += (sum_k Ut[i][k] b[k] / w[i]) * Vt[i][j]
     double threshold = 0;
     for (int i = 0; i < nc; ++i) threshold += S.sw[cand][i];
@@ -569,8 +553,11 @@ EO_FN bool solve5_wave(Lds& S, epnp_exact::Work& xw, const double* K, double* R_
     }
   }
   EO_SYNC();
-  jacobi_seq<3>(S, slot < 3 ? 3 : 0, base, lane);
-  svd_finish<3>(S, slot < 3 ? 3 : 0, base, cand, lane);
+  {
+    const bool mine = r16 < 15 && r16 % 5 < 3;
+    jacobi_rows<3>(S, mine ? 3 : 0, mine ? 5 * (r16 / 5) : r16, lane);
+  }
+  svd_rank(S, slot < 3 ? 3 : 0, base, cand, lane);
   if (slot < 3 && col < 9) {
     const int i = col / 3, j = col % 3;
     const int r0 = S.srow[cand][0], r1 = S.srow[cand][1], r2 = S.srow[cand][2];

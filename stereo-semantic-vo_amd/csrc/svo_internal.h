@@ -150,7 +150,8 @@ struct svo_ctx {
   int opt_pose_flag = 0;   // svo_set_option("pose_flag"): one sequence's pose kernels poll the index chain's per-frame tag instead of waiting on stream
                            // events.  OFF by default: the poll needs the index kernel to run CONCURRENTLY with the polling one, and a tool that
                            // serialises kernel dispatches (rocprofv3 --kernel-trace does) turns every frame into a timed-out poll
-  int opt_epnp_exact = 0;  // svo_set_option("epnp_exact"): RANSAC samples solved in OpenCV's operation order, one lane each (parity mode)
+  int opt_epnp_exact = 2;  // svo_set_option("epnp_exact"): 2 = OpenCV's operations with their rounding, spread over a wave per sample (default); 1 = one lane per sample, loop by loop (the checker); 0 = the statistical wave solver
+  int opt_epnp_force_seq = 0;  // tests: mode 2 takes its sequential fallback for every sample
   bool profiling = false;
   std::vector<SvoProfileEntry> prof;
   void* prof_impl = nullptr;  // SvoProfState (svo_api.hip)

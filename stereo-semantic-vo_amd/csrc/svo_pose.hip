@@ -52,6 +52,15 @@ __global__ __launch_bounds__(64) void k_pnp_hyp_exact(const double* __restrict__
   pnp_hyp_exact_wave(S, Xw, obs, n, K, subset, hyp, blockIdx.x);
 }
 
+// order-preserving wave mode ("epnp_exact" = 2): one single-wave workgroup per sample, OpenCV's operations over the wavefront
+__global__ __launch_bounds__(64) void k_pnp_hyp_ord(const double* __restrict__ Xw, const double* __restrict__ obs, int n,
+                                                    const double* __restrict__ Kp, const uint16_t* __restrict__ subset,
+                                                    PnpHyp* hyp, int force_seq) {
+  __shared__ PnpOrdLds S;
+  const double K[4] = {Kp[0], Kp[1], Kp[2], Kp[3]};
+  pnp_hyp_ord_wave(S, Xw, obs, n, K, subset, hyp, blockIdx.x, force_seq != 0);
+}
+
 __global__ __launch_bounds__(256) void k_pnp_select(const double* __restrict__ Xw, const double* __restrict__ obs, int n,
                                                     const double* __restrict__ Kp, const double* __restrict__ Tfallback,
                                                     const PnpHyp* hyp, double* T, uint8_t* inlier_mask,
@@ -116,7 +125,28 @@ __global__ __launch_bounds__(64) void k_epnp5_probe_exact(const double* X5, cons
   Rt[12] = ok ? 1.0 : 0.0;
   for (int b = 16; b < 24; ++b) Rt[b] = 0.0;
 }
+// the same in the order-preserving wave mode; Rt[16..22]: ticks of the stages, Rt[23]: 1 if the sequential fallback ran
+__global__ __launch_bounds__(64) void k_epnp5_probe_ord(const double* X5, const double* u5, const double* Kp, double* Rt, int force_seq) {
+  __shared__ PnpOrdLds L;
+  const int lane = threadIdx.x;
+  if (lane < 15) L.S.pws[lane] = X5[lane];
+  if (lane < 10) L.S.us[lane] = u5[lane];
+  double K[4] = {Kp[0], Kp[1], Kp[2], Kp[3]}, R[9], t[3], rep[3];
+  const bool ok = epnp_ord::solve5_wave(L.S, L.W, K, R, t, rep, force_seq != 0);
+  if (lane == 0 && blockIdx.x == 0) {
+    for (int i = 0; i < 9; ++i) Rt[i] = R[i];
+    Rt[9] = t[0]; Rt[10] = t[1]; Rt[11] = t[2]; Rt[12] = ok ? 1.0 : 0.0;
+    for (int b = 0; b < 3; ++b) Rt[13 + b] = rep[b];
+    for (int b = 0; b < 7; ++b) Rt[16 + b] = (double)(L.S.stamp[b + 1] - L.S.stamp[b]);
+    Rt[23] = (double)L.S.flag;
+  }
+}
 int svo_launch_epnp5_probe(svo_ctx* ctx, const double* X5, const double* u5, const double* K, double* Rt, int reps) {
+  if (ctx->opt_epnp_exact == 2) {
+    hipLaunchKernelGGL(k_epnp5_probe_ord, dim3(1), dim3(64), 0, ctx->stream, X5, u5, K, Rt, ctx->opt_epnp_force_seq);
+    SVO_HIP(ctx, hipGetLastError());
+    return SVO_OK;
+  }
   if (ctx->opt_epnp_exact) {
     hipLaunchKernelGGL(k_epnp5_probe_exact, dim3(1), dim3(64), 0, ctx->stream, X5, u5, K, Rt);
     SVO_HIP(ctx, hipGetLastError());
@@ -190,7 +220,9 @@ int svo_launch_pnp(svo_ctx* ctx, const double* Xw, const double* obs, int n, con
   int rc = svo_pose_lds_optin(ctx);
   if (rc) return rc;
   SvoTimer tm(ctx, "k_pnp_ransac");
-  if (n >= 5 && ctx->opt_epnp_exact)
+  if (n >= 5 && ctx->opt_epnp_exact == 2)
+    hipLaunchKernelGGL(k_pnp_hyp_ord, dim3(PNP_HYP), dim3(64), 0, ctx->stream, Xw, obs, n, K, subset, hyp, ctx->opt_epnp_force_seq);
+  else if (n >= 5 && ctx->opt_epnp_exact)
     hipLaunchKernelGGL(k_pnp_hyp_exact, dim3(PNP_HYP), dim3(64), 0, ctx->stream, Xw, obs, n, K, subset, hyp);
   else if (n >= 5)
     hipLaunchKernelGGL(k_pnp_hyp, dim3(PNP_HYP), dim3(64), sizeof(PnpHypLds), ctx->stream, Xw, obs, n, K, subset, hyp);

@@ -580,6 +580,7 @@ __device__ __forceinline__ void pose_opt_block(PoseLds& L, const double* __restr
 // (OpenCV 3.2 modules/calib3d/src/solvepnp.cpp + ptsetreg.cpp)
 #include "svo_epnp_dev.h"
 #include "svo_epnp_exact_dev.h"
+#include "svo_epnp_ord_dev.h"
 
 struct PnpHyp {          // one RANSAC sample: EPnP pose of its five points and its consensus
   double R[9], t[3];
@@ -654,6 +655,35 @@ __device__ __forceinline__ void pnp_hyp_exact_wave(PnpExactLds& S, const double*
 #pragma unroll
   for (int i = 0; i < 3; ++i) t[i] = S.t[i];
   const bool ok = S.ok != 0;
+  int cnt = 0;
+  if (ok)
+    for (int e = lane; e < n; e += 64) cnt += pnp_inlier(R, t, Xw + 3 * e, uv + 2 * e, K) ? 1 : 0;
+  cnt = wave_sum_i32_dpp(cnt);
+  if (lane == 0) {
+    PnpHyp h;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) h.R[i] = R[i];
+    h.t[0] = t[0]; h.t[1] = t[1]; h.t[2] = t[2];
+    h.cnt = cnt; h.ok = ok ? 1 : 0;
+    out[k] = h;
+  }
+}
+
+// The same samples in the order-preserving wave mode (svo_set_option "epnp_exact" = 2, the default): ONE sample per wave,
+// OpenCV's operations spread over the wavefront with their rounding kept (svo_epnp_ord_dev.h), bit-identical to the
+// sequential restatement; then the wave counts the sample's consensus.  Called by all 64 lanes of the wave that owns sample k.
+struct PnpOrdLds { epnp_ord::Lds S; epnp_exact::Work W; };
+__device__ __forceinline__ void pnp_hyp_ord_wave(PnpOrdLds& L, const double* Xw, const double* uv, int n, const double* K,
+                                                 const uint16_t* subset, PnpHyp* out, int k, bool force_seq = false) {
+  const int lane = threadIdx.x & 63;
+  if (k >= PNP_HYP) return;
+  if (lane < 5) {
+    const int e = min((int)subset[5 * k + lane], n - 1);
+    L.S.pws[3 * lane] = Xw[3 * e]; L.S.pws[3 * lane + 1] = Xw[3 * e + 1]; L.S.pws[3 * lane + 2] = Xw[3 * e + 2];
+    L.S.us[2 * lane] = uv[2 * e]; L.S.us[2 * lane + 1] = uv[2 * e + 1];
+  }
+  double R[9], t[3];
+  const bool ok = epnp_ord::solve5_wave(L.S, L.W, K, R, t, nullptr, force_seq);
   int cnt = 0;
   if (ok)
     for (int e = lane; e < n; e += 64) cnt += pnp_inlier(R, t, Xw + 3 * e, uv + 2 * e, K) ? 1 : 0;

@@ -1004,6 +1004,38 @@ __global__ __launch_bounds__(64) void k_tp_hyp_exact(TrackState* st, TrackWork* 
   pnp_hyp_exact_wave(S.ex, S.Xw, S.uv, n, K, subsets + (size_t)min(n, 512) * 500, st->hyp, blockIdx.x);
 }
 
+// The RANSAC samples in the order-preserving wave mode ("epnp_exact" = 2, the default): one single-wave workgroup per sample,
+// OpenCV's operations over the wavefront with their rounding kept (svo_epnp_ord_dev.h); the wave counts the consensus.
+struct TpHypOrdLds { double Xw[TRK_MAXKP * 3], uv[TRK_MAXKP * 2]; PnpOrdLds ord; };
+__global__ __launch_bounds__(64) void k_tp_hyp_ord(TrackState* st, TrackWork* work, const svo_kp* kp, const uint16_t* subsets,
+                                                   int kstride, int tag, int force_seq) {
+  TpHypOrdLds& S = *reinterpret_cast<TpHypOrdLds*>(tk_smem);
+  st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
+  tp_wait_work(st, work, tag);
+  const long long t_start = clock64();
+  if (threadIdx.x == 0 && blockIdx.x == 0) work->rt[2] = wall_clock64();
+  const int n = ld_agent(&work->n_edges);
+  if (ld_agent(&work->skip_match) || n < 5) return;
+  const float* gpos = st->gpos;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    const float* gp = gpos + 3 * (size_t)(ld_agent(&work->edge_gid[e]) & (TRK_GPOS - 1));
+    const svo_kp k = kp[ld_agent(&work->edge_kp[e])];
+    S.Xw[3 * e] = (double)gp[0]; S.Xw[3 * e + 1] = (double)gp[1]; S.Xw[3 * e + 2] = (double)gp[2];
+    S.uv[2 * e] = (double)k.x; S.uv[2 * e + 1] = (double)k.y;
+  }
+  __syncthreads();
+  const double K[4] = {(double)st->cam.fx, (double)st->cam.fy, (double)st->cam.cx, (double)st->cam.cy};
+  const long long t_gather = clock64();
+  pnp_hyp_ord_wave(S.ord, S.Xw, S.uv, n, K, subsets + (size_t)min(n, 512) * 500, st->hyp, blockIdx.x, force_seq != 0);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const long long* sp = S.ord.S.stamp;
+    st->pose_ts[0] = t_start; st->pose_ts[1] = t_gather; st->pose_ts[2] = sp[0]; st->pose_ts[3] = sp[7];
+    st->pose_ts[4] = clock64();
+    st->pose_ts[5] = sp[2]; st->pose_ts[6] = sp[3]; st->pose_ts[7] = sp[4]; st->pose_ts[12] = S.ord.S.flag;
+    st->pose_ts[13] = sp[4]; st->pose_ts[14] = sp[5]; st->pose_ts[15] = sp[6];
+  }
+}
+
 // k_tp_frame: RANSAC's acceptance rule over the samples, Optimizer::PoseOptimization, SetPose, the positions of the
 // map points created this frame, the frame's record.
 struct TpLds {
@@ -1200,6 +1232,8 @@ static int track_resources(svo_ctx* ctx, int frames, int nseq) {
                                    (int)sizeof(TpLds)) == hipSuccess;
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_hyp), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)sizeof(TpHypLds)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_hyp_ord), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)sizeof(TpHypOrdLds)) == hipSuccess;
     ctx->track_lds_state = ok ? 1 : -1;
     if (!ok) ctx->last_error = std::string("hipFuncSetAttribute(tracker kernels): ") + hipGetErrorString(hipGetLastError());
   }
@@ -1281,7 +1315,11 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
     const svo_kp* kpf = kp + row(f) * kstride;
     const float* depf = depth + row(f) * kstride;
     ctx->profiling = prof && (f % 32 == 0 || frames < 32);
-    if (ctx->opt_epnp_exact) {
+    if (ctx->opt_epnp_exact == 2) {
+      SvoTimer t(ctx, "k_tp_hyp_ord");
+      hipLaunchKernelGGL(k_tp_hyp_ord, dim3(PNP_HYP, ny), dim3(64), sizeof(TpHypOrdLds), s0, st, work + f, kpf, ctx->d_pnp_subsets, kstride,
+                         tag_of(f), ctx->opt_epnp_force_seq);
+    } else if (ctx->opt_epnp_exact) {
       SvoTimer t(ctx, "k_tp_hyp_exact");
       hipLaunchKernelGGL(k_tp_hyp_exact, dim3(PNP_HYP, ny), dim3(64), sizeof(TpHypExactLds), s0, st, work + f, kpf, ctx->d_pnp_subsets, kstride,
                          tag_of(f));

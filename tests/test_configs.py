@@ -15,12 +15,12 @@ import importlib
 import numpy as np
 import pytest
 
-# Pose tolerances, per frame.  The tests below run the device tracker in its bit-comparable mode (svo_set_option
-# "epnp_exact": every RANSAC sample solved in OpenCV's operation order), where the discrete outcome of RANSAC and the LM's
-# iteration count equal the CPU port's and a frame's pose agrees to BASELINE.md's 1e-4 m / 1e-5 rad.  Both chains
+# Pose tolerances, per frame.  The tests below run the device tracker in its DEFAULT mode (svo_set_option "epnp_exact" = 2:
+# every RANSAC sample solved with OpenCV's operations and rounding, spread over a wavefront), where the discrete outcome of
+# RANSAC and the LM's iteration count equal the CPU port's and a frame's pose agrees to BASELINE.md's 1e-4 m / 1e-5 rad.  Both chains
 # dead-reckon from float32 map points, so along a free-running sequence the ABSOLUTE poses drift apart by rounding-sized
 # steps (the absolute tolerance grows with the frame index); the per-frame RELATIVE motion is held to the tight bound.
-# The default (wave-parallel EPnP) mode is validated against the same oracle in tests/test_full_length.py.
+# The statistical wave solver (mode 0, an option) is validated against the same oracle in tests/test_full_length.py.
 POSE_TOL_T = 1e-4
 POSE_TOL_R = 1e-5
 COUNTERS = ("frame_id", "n_kp", "n_stereo", "n_match_pass1", "n_match_pass2", "n_lm_edges",
@@ -115,7 +115,6 @@ def test_config0_kitti04_tracked_sequence_equals_oracle(pkg, orc, seq04):
     ref = [trk.track(L[k], R[k]) for k in range(len(L))]
     trk.close()
     svo = pkg.Svo(1241, 376, max_batch=1)
-    svo.set_option("epnp_exact", 1)
     svo.track_reset(pkg.Camera(**pkg.KITTI_04_12))
     gpu = []
     for k in range(len(L)):
@@ -148,7 +147,6 @@ def test_config4_boxes_with_dense_elas_depth_equals_oracle(pkg, orc):
     trk = orc.Tracker(1241, 376, pkg.KITTI_00_02)
     svo = pkg.Svo(1241, 376, max_batch=1)
     svo.set_option("depth_source", 1)
-    svo.set_option("epnp_exact", 1)
     svo.track_reset(pkg.Camera(**pkg.KITTI_00_02))
     gpu, ref, vetoes = [], [], 0
     for k in range(n):
@@ -179,7 +177,6 @@ def test_config4_boxes_with_dense_elas_depth_equals_oracle(pkg, orc):
     torch.cuda.synchronize()
     b = pkg.Svo(1241, 376, max_batch=n)
     b.set_option("depth_source", 1)
-    b.set_option("epnp_exact", 1)
     b.track_reset(pkg.Camera(**pkg.KITTI_00_02))
     b.track_batch_dev(dL.data_ptr(), dR.data_ptr(), pitch, n, res.data_ptr(), boxes=pkg.boxes_dev(tb.data_ptr(), tn.data_ptr(), 2))
     b.sync()
@@ -203,7 +200,6 @@ def test_64_frames_gpu_tracker_equals_oracle(pkg, orc):
     ref = [trk.track(L[k], R[k]) for k in range(N)]
     trk.close()
     svo = pkg.Svo(1241, 376, max_batch=1)
-    svo.set_option("epnp_exact", 1)
     svo.track_reset(pkg.Camera(**pkg.KITTI_00_02))
     gpu, rounds2 = [], []
     for k in range(N):
@@ -265,7 +261,6 @@ def test_real_street_images_tracked_sequence_equals_oracle(pkg, orc):
     frames = [util.urban_pair(1241, 376, x0=4 + 12 * k, y0=8) for k in range(8)]
     trk = orc.Tracker(1241, 376, pkg.KITTI_00_02)
     svo = pkg.Svo(1241, 376, max_batch=1)
-    svo.set_option("epnp_exact", 1)
     svo.track_reset(pkg.Camera(**pkg.KITTI_00_02))
     gpu, ref = [], []
     for Lk, Rk in frames:

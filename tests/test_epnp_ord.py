@@ -1,0 +1,77 @@
+"""The order-preserving wave EPnP (csrc/svo_epnp_ord_dev.h, svo_set_option "epnp_exact" = 2, the default) against the CPU
+restatement of OpenCV's epnp::compute_pose / cv::solvePnPRansac (oracle/orc_pnp_cv.c; reference call site
+src/pnpmatch.cc:227): BIT-identical R, t and candidate reprojection errors per five-point sample - integer-style parity
+for a float64 stage, because every IEEE operation of OpenCV's loops is kept and only independent ones are reordered."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+K = np.array([718.856, 718.856, 607.1928, 185.2157])
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _samples():
+    rng = np.random.default_rng(11)
+    for sigma in (0.0, 0.5, 1.5):
+        for trial in range(10):
+            Xw, obs, _, _ = util.pose_problem(trial, n=60, outlier_frac=0.1, sigma=sigma)
+            if trial % 3 == 1:                      # a camera 3 km from the origin: float32 world points of 4 digits
+                Xw = (Xw + np.array([900.0, 2.0, 3000.0])).astype(np.float32).astype(np.float64)
+            idx = rng.choice(60, 5, replace=False)
+            yield sigma, trial, Xw[idx], obs[idx]
+
+
+@pytest.mark.parametrize("force_seq", [0, 1])
+def test_epnp5_ord_mode_is_bit_identical_to_the_oracle(pkg, orc, force_seq):
+    """force_seq = 1 sends every sample through the mode's sequential fallback (the branch taken for a zero or repeated
+    singular value): same bits either way."""
+    rep_o = (C.c_double * 3).in_dll(orc.lib(), "orc_epnp_last_rep")
+    svo = pkg.Svo(640, 240, max_batch=1)
+    svo.set_option("epnp_exact", 2)
+    svo.set_option("epnp_force_seq", force_seq)
+    n = 0
+    for sigma, trial, X5, u5 in _samples():
+        R, t = orc.epnp5(X5, u5, K)
+        ro = np.array(list(rep_o))
+        Rg, tg, rg = svo.debug_epnp5(X5, u5, K)
+        assert np.array_equal(R.view(np.uint64), Rg.view(np.uint64)), (sigma, trial, np.abs(R - Rg).max())
+        assert np.array_equal(t.view(np.uint64), tg.view(np.uint64)), (sigma, trial)
+        assert np.array_equal(ro.view(np.uint64), rg.view(np.uint64)), (sigma, trial, ro, rg)
+        n += 1
+    svo.close()
+    assert n == 30
+
+
+@pytest.mark.parametrize("seed,n,outliers", [(7, 500, 0.2), (12, 60, 0.2), (21, 200, 0.5), (33, 300, 0.0), (5, 9, 0.0), (13, 5, 0.0)])
+def test_pnp_ransac_default_mode_equals_oracle(pkg, orc, seed, n, outliers):
+    """cv::solvePnPRansac in the default mode: discrete outcome and inlier mask identical, pose to 1e-9 (the oracle's pose
+    passes through Rodrigues and back as OpenCV's does; the device keeps the matrix)."""
+    Xw, obs, Kc, _ = util.pose_problem(seed, n=n, outlier_frac=outliers)
+    svo = pkg.Svo(640, 240, max_batch=1)
+    T, mask, st = svo.pnp_ransac(Xw, obs, Kc, np.eye(4))
+    svo.set_option("epnp_exact", 1)
+    T1, mask1, st1 = svo.pnp_ransac(Xw, obs, Kc, np.eye(4))
+    svo.close()
+    Tr, mr, sr = orc.pnp_ransac(Xw, obs, Kc, np.eye(4))
+    assert (st.ok, st.best_hypothesis, st.n_inliers, st.iterations) == (sr.ok, sr.best_hypothesis, sr.n_inliers, sr.iterations)
+    assert np.array_equal(mask, mr)
+    assert np.abs(T - Tr).max() < 1e-9 * (1 + np.abs(Tr).max())
+    # and bit for bit what the one-lane-per-sample checker (mode 1) gives
+    assert np.array_equal(T.view(np.uint64), T1.view(np.uint64)) and np.array_equal(mask, mask1)
+
+
+def test_many_samples_through_the_native_harness():
+    """tools/epnp_ord_check: 4,096 seeded samples at the origin and 4,096 three kilometres away (coplanar ones among them:
+    a zero singular value, the sequential fallback), compared bit for bit with the oracle inside the binary."""
+    exe = os.path.join(ROOT, "tools", "epnp_ord_check")
+    if not os.path.exists(exe):
+        pytest.skip("tools/epnp_ord_check not built (tools/build_epnp_ord_check.sh)")
+    for off in ("0", "3000"):
+        out = subprocess.run([exe, "4096", off, "0.5"], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "mismatches 0 " in out.stdout, out.stdout[-2000:]

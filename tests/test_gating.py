@@ -140,7 +140,6 @@ def test_oracle_tail_entry_with_boxes_equals_full_frame_entry(orc, pkg, gated_or
 def test_gpu_gated_tracker_matches_oracle(pkg, gated_oracle_run):
     L, R, out = gated_oracle_run
     svo = pkg.Svo(L.shape[2], L.shape[1], max_batch=1)
-    svo.set_option("epnp_exact", 1)      # the bit-comparable RANSAC: consensus, LM iterations and pose are pinned too
     svo.track_reset(pkg.Camera(**pkg.KITTI_00_02))
     for k in range(5):
         res = svo.track_frame(L[k], R[k], boxes=boxes_for(k))

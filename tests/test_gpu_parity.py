@@ -285,8 +285,17 @@ def test_pnp_ransac_against_oracle(svo_small, orc, seed, n, outliers):
     assert np.abs(T[:3, 3] - T_true[:3, 3]).max() < 0.3 and np.abs(T[:3, :3] - T_true[:3, :3]).max() < 5e-3
 
 
-def test_epnp5_candidates_against_oracle(svo_small, orc):
-    """One five-point sample, GPU (wave-parallel EPnP) vs the CPU restatement of OpenCV's epnp.cpp.  All three beta
+@pytest.fixture()
+def svo0(pkg):
+    """A context in mode 0: the statistical wave EPnP (svo_epnp_dev.h), an option since round 4."""
+    s = pkg.Svo(640, 240, max_batch=1)
+    s.set_option("epnp_exact", 0)
+    yield s
+    s.close()
+
+
+def test_epnp5_candidates_against_oracle(svo0, orc):
+    """One five-point sample, GPU (statistical wave EPnP, mode 0) vs the CPU restatement of OpenCV's epnp.cpp.  All three beta
     candidates are initialised from eigenvectors of the (arbitrary) null-space basis a five-point system has, and
     EPnP's five Gauss-Newton steps can take them to different local minima of the control-point distance constraints,
     so a single sample is only STATISTICALLY reproducible (in OpenCV itself as well): in most samples both sides end in
@@ -303,7 +312,7 @@ def test_epnp5_candidates_against_oracle(svo_small, orc):
             idx = rng.choice(60, 5, replace=False)
             R, t = orc.epnp5(Xw[idx], obs[idx], K)
             ro = np.array(list(rep_o))
-            Rg, tg, rg = svo_small.debug_epnp5(Xw[idx], obs[idx], K)
+            Rg, tg, rg = svo0.debug_epnp5(Xw[idx], obs[idx], K)
             total += 1
             lo, hi = min(rg.min(), ro.min()), max(rg.min(), ro.min())
             assert hi < 0.1 + 1.5 * lo, (sigma, trial, ro, rg)
@@ -314,7 +323,7 @@ def test_epnp5_candidates_against_oracle(svo_small, orc):
     assert tight >= 0.6 * total, (tight, total)
 
 
-def test_epnp5_basis_independent_candidates_agree_on_every_sample(svo_small, orc):
+def test_epnp5_basis_independent_candidates_agree_on_every_sample(svo0, orc):
     """The N = 2 and N = 3 beta candidates span the null space instead of picking one of its (arbitrary) basis vectors:
     where both sides' Gauss-Newton runs stay in the same basin their reprojection errors agree closely - checked
     candidate by candidate on every sample, not on the minimum only."""
@@ -330,7 +339,7 @@ def test_epnp5_basis_independent_candidates_agree_on_every_sample(svo_small, orc
             idx = rng.choice(60, 5, replace=False)
             orc.epnp5(Xw[idx], obs[idx], K)
             ro = np.array(list(rep_o))
-            _, _, rg = svo_small.debug_epnp5(Xw[idx], obs[idx], K)
+            _, _, rg = svo0.debug_epnp5(Xw[idx], obs[idx], K)
             total += 1
             for c in (1, 2):
                 if abs(rg[c] - ro[c]) < 1e-6 * (1 + ro[c]):

@@ -104,9 +104,10 @@ def test_oracle_tail_teacher_forcing(orc, pkg, sequence, oracle_run):
 
 
 def _check_frame(k, res, cur, ref, ref_cur, exact):
-    """One tracked frame against the oracle.  exact (svo_set_option "epnp_exact"): everything pinned - RANSAC consensus,
-    LM iterations, pose to BASELINE.md's 1e-4 m / 1e-5.  Default mode: the index chain is still exact; the pose chain's
-    RANSAC samples are solved with another rounding (see tests/test_full_length.py), hence the bands."""
+    """One tracked frame against the oracle.  exact (svo_set_option "epnp_exact" 2 = the default, order-preserving wave EPnP;
+    1 = its sequential checker): everything pinned - RANSAC consensus, LM iterations, pose to BASELINE.md's 1e-4 m / 1e-5.
+    Mode 0 (the statistical wave solver, an option): the index chain is still exact; the pose chain's RANSAC samples are
+    solved with another rounding (see tests/test_full_length.py), hence the bands."""
     for f in ("frame_id", "n_kp", "n_stereo", "n_match_pass1", "n_match_pass2", "n_lm_edges", "n_new_mappoints", "n_local_map"):
         assert res[f] == ref[f], (k, f, res[f], ref[f])
     assert np.array_equal(cur[:ref["n_kp"]], ref_cur[:ref["n_kp"]]), "frame %d match indices" % k
@@ -122,7 +123,7 @@ def _check_frame(k, res, cur, ref, ref_cur, exact):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("exact", [1, 0])
+@pytest.mark.parametrize("exact", [2, 1, 0])
 @pytest.mark.parametrize("lcap,nblk", [(8, 3), (1, 3), (8, 0), (2, 1)])
 def test_gpu_tracker_matches_oracle(pkg, sequence, oracle_run, lcap, nblk, exact):
     """(8, 3) is the product's configuration; the others force the matching passes onto their fall-back paths - rows

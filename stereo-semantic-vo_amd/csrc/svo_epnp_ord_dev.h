@@ -46,6 +46,7 @@ namespace epnp_ord {
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 #include "svo_epnp_ord_tab.h"
+#include "svo_epnp_ord_asm.h"
 
 // One wave, its own LDS workspace: LDS instructions of a wave execute in issue order, so a write is visible to the reads
 // issued after it; the wavefront-scope fence only keeps the COMPILER from moving a read above the write it depends on.
@@ -59,7 +60,7 @@ struct Lds {
   alignas(16) double jr[16 * 16];   // Jacobi rows [A (M columns) | V (n columns) | .. | W in column 15], row stride 16; 12 x 12: rows 0..11, small ones: rows 5 p .. 5 p + n - 1 of problem p
   alignas(16) double xch[16][4][4];   // row exchange of the Jacobi engine: [row][lane group] = its three columns (+ pad)
   double xw[16];                      // and the rows' W
-  unsigned short tab[EO_TAB_TOTAL];   // the schedules (svo_epnp_ord_tab.h)
+  unsigned tab[EO_TAB_TOTAL];         // the schedules (svo_epnp_ord_tab.h), bit 4 (second row of the pair) moved to bit 31
   double pws[16], us[10], alphas[20], cws[12], ccinv[9];
   double M[120];
   double ut4[4][12];        // ut + 12 * (11 - q): vectors of the four smallest singular values, q = 0 the smallest
@@ -73,6 +74,9 @@ struct Lds {
   int flag;                 // a branch this file does not reproduce was met: re-solve sequentially
   int sweeps;               // diagnostics: sweeps of the 12 x 12 decomposition
   long long stamp[8];
+#ifdef EO_PROFILE
+  long long prof[8];
+#endif
 };
 
 EO_FN double xdiv(double a, double b) { return a / b; }
@@ -126,95 +130,216 @@ EO_FN double colsum(double t0, double t1, double t2, int g) {
 #define EO_TAB4_OFF (EO_TAB3_OFF + EO_TAB3_STEPS * 3)
 #define EO_TAB5_OFF (EO_TAB4_OFF + EO_TAB4_STEPS * 4)
 #define EO_TAB12_OFF (EO_TAB5_OFF + EO_TAB5_STEPS * 5)
+EO_FN unsigned tab_entry(unsigned e) { return (e & ~16u) | ((e & 16u) << 27); }
 EO_FN void load_tables(Lds& S, int lane) {
-  for (int e = lane; e < EO_TAB3_STEPS * 3; e += 64) S.tab[EO_TAB3_OFF + e] = c_tab3[0][e];
-  for (int e = lane; e < EO_TAB4_STEPS * 4; e += 64) S.tab[EO_TAB4_OFF + e] = c_tab4[0][e];
-  for (int e = lane; e < EO_TAB5_STEPS * 5; e += 64) S.tab[EO_TAB5_OFF + e] = c_tab5[0][e];
-  for (int e = lane; e < EO_TAB12_STEPS * 12; e += 64) S.tab[EO_TAB12_OFF + e] = c_tab12[0][e];
+  for (int e = lane; e < EO_TAB3_STEPS * 3; e += 64) S.tab[EO_TAB3_OFF + e] = tab_entry(c_tab3[0][e]);
+  for (int e = lane; e < EO_TAB4_STEPS * 4; e += 64) S.tab[EO_TAB4_OFF + e] = tab_entry(c_tab4[0][e]);
+  for (int e = lane; e < EO_TAB5_STEPS * 5; e += 64) S.tab[EO_TAB5_OFF + e] = tab_entry(c_tab5[0][e]);
+  for (int e = lane; e < EO_TAB12_STEPS * 12; e += 64) S.tab[EO_TAB12_OFF + e] = tab_entry(c_tab12[0][e]);
+}
+
+// The pair test of JacobiSVDImpl_ as one hand-scheduled instruction stream: p = sum_k Ai[k] Aj[k] (three chained MFMAs) and
+// eps * sqrt(W[i] W[j]) (the compiler's IEEE square root without its range scaling, see nsqrt) - the square root's eleven
+// instructions sit in the shadows of the MFMAs (4 wait states between dependent DMFMAs, 6 before a VALU read of the result,
+// 2 after the VALU write of an operand, 1 after v_rsq_f64: the distances the compiler itself keeps).
+// mk: 1.0 / 0.0 per lane for the term of the partly filled column group (M = 6: group 1, M = 3: group 0).
+template <int M>
+EO_FN void pair_test(double x0, double x1, double x2, double q0, double q1, double q2, double W, double wP, double mk,
+                     double& p, double& thr) {
+  const double one = 1.0, eps = 2.220446049250313e-16 * 10;
+  double t0, t1, t2, ab, y, g, h, r, d;
+  if (M == 12) {
+    asm volatile(
+        "v_mul_f64 %[t0], %[x0], %[q0]\n\t"
+        "v_mul_f64 %[ab], %[W], %[wP]\n\t"
+        "v_mul_f64 %[t1], %[x1], %[q1]\n\t"
+        "v_mul_f64 %[t2], %[x2], %[q2]\n\t"
+        "v_rsq_f64 %[y], %[ab]\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 %[p], %[one], %[t0], 0\n\t"
+        "v_mul_f64 %[g], %[ab], %[y]\n\t"
+        "v_mul_f64 %[h], %[y], 0.5\n\t"
+        "v_fma_f64 %[r], -%[h], %[g], 0.5\n\t"
+        "v_fma_f64 %[g], %[g], %[r], %[g]\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 %[p], %[one], %[t1], %[p]\n\t"
+        "v_fma_f64 %[h], %[h], %[r], %[h]\n\t"
+        "v_fma_f64 %[d], -%[g], %[g], %[ab]\n\t"
+        "v_fma_f64 %[g], %[d], %[h], %[g]\n\t"
+        "v_fma_f64 %[d], -%[g], %[g], %[ab]\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 %[p], %[one], %[t2], %[p]\n\t"
+        "v_fma_f64 %[g], %[d], %[h], %[g]\n\t"
+        "v_mul_f64 %[thr], %[g], %[eps]\n\t"
+        "s_nop 4"
+        : [p] "=&v"(p), [thr] "=&v"(thr), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [ab] "=&v"(ab), [y] "=&v"(y),
+          [g] "=&v"(g), [h] "=&v"(h), [r] "=&v"(r), [d] "=&v"(d)
+        : [x0] "v"(x0), [x1] "v"(x1), [x2] "v"(x2), [q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2), [W] "v"(W), [wP] "v"(wP),
+          [one] "v"(one), [eps] "v"(eps));
+  } else if (M == 6) {
+    asm volatile(
+        "v_mul_f64 %[t0], %[x0], %[q0]\n\t"
+        "v_mul_f64 %[t1], %[x1], %[q1]\n\t"
+        "v_mul_f64 %[ab], %[W], %[wP]\n\t"
+        "v_mul_f64 %[t1], %[t1], %[mk]\n\t"
+        "v_rsq_f64 %[y], %[ab]\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 %[p], %[one], %[t0], 0\n\t"
+        "v_mul_f64 %[g], %[ab], %[y]\n\t"
+        "v_mul_f64 %[h], %[y], 0.5\n\t"
+        "v_fma_f64 %[r], -%[h], %[g], 0.5\n\t"
+        "v_fma_f64 %[g], %[g], %[r], %[g]\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 %[p], %[one], %[t1], %[p]\n\t"
+        "v_fma_f64 %[h], %[h], %[r], %[h]\n\t"
+        "v_fma_f64 %[d], -%[g], %[g], %[ab]\n\t"
+        "v_fma_f64 %[g], %[d], %[h], %[g]\n\t"
+        "v_fma_f64 %[d], -%[g], %[g], %[ab]\n\t"
+        "v_fma_f64 %[g], %[d], %[h], %[g]\n\t"
+        "v_mul_f64 %[thr], %[g], %[eps]\n\t"
+        "s_nop 0"
+        : [p] "=&v"(p), [thr] "=&v"(thr), [t0] "=&v"(t0), [t1] "=&v"(t1), [ab] "=&v"(ab), [y] "=&v"(y), [g] "=&v"(g),
+          [h] "=&v"(h), [r] "=&v"(r), [d] "=&v"(d)
+        : [x0] "v"(x0), [x1] "v"(x1), [q0] "v"(q0), [q1] "v"(q1), [W] "v"(W), [wP] "v"(wP), [mk] "v"(mk), [one] "v"(one),
+          [eps] "v"(eps));
+  } else {
+    asm volatile(
+        "v_mul_f64 %[t0], %[x0], %[q0]\n\t"
+        "v_mul_f64 %[ab], %[W], %[wP]\n\t"
+        "v_mul_f64 %[t0], %[t0], %[mk]\n\t"
+        "v_rsq_f64 %[y], %[ab]\n\t"
+        "s_nop 0\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 %[p], %[one], %[t0], 0\n\t"
+        "v_mul_f64 %[g], %[ab], %[y]\n\t"
+        "v_mul_f64 %[h], %[y], 0.5\n\t"
+        "v_fma_f64 %[r], -%[h], %[g], 0.5\n\t"
+        "v_fma_f64 %[g], %[g], %[r], %[g]\n\t"
+        "v_fma_f64 %[h], %[h], %[r], %[h]\n\t"
+        "v_fma_f64 %[d], -%[g], %[g], %[ab]\n\t"
+        "v_fma_f64 %[g], %[d], %[h], %[g]\n\t"
+        "v_fma_f64 %[d], -%[g], %[g], %[ab]\n\t"
+        "v_fma_f64 %[g], %[d], %[h], %[g]\n\t"
+        "v_mul_f64 %[thr], %[g], %[eps]"
+        : [p] "=&v"(p), [thr] "=&v"(thr), [t0] "=&v"(t0), [ab] "=&v"(ab), [y] "=&v"(y), [g] "=&v"(g), [h] "=&v"(h), [r] "=&v"(r),
+          [d] "=&v"(d)
+        : [x0] "v"(x0), [q0] "v"(q0), [W] "v"(W), [wP] "v"(wP), [mk] "v"(mk), [one] "v"(one), [eps] "v"(eps));
+  }
+}
+
+// a = sum t0^2 over the A columns of the updated row (n0, n1, n2: its three columns): squares, then the chained MFMAs; the trailing
+// wait states make the result readable by whatever the compiler schedules next
+template <int M>
+EO_FN double row_norm2(double n0, double n1, double n2, double mk) {
+  const double one = 1.0;
+  double s0, s1, s2, a;
+  if (M == 12) {
+    asm volatile(
+        "v_mul_f64 %[s0], %[n0], %[n0]\n\t"
+        "v_mul_f64 %[s1], %[n1], %[n1]\n\t"
+        "v_mul_f64 %[s2], %[n2], %[n2]\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 %[a], %[one], %[s0], 0\n\t"
+        "s_nop 3\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 %[a], %[one], %[s1], %[a]\n\t"
+        "s_nop 3\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 %[a], %[one], %[s2], %[a]\n\t"
+        "s_nop 5"
+        : [a] "=&v"(a), [s0] "=&v"(s0), [s1] "=&v"(s1), [s2] "=&v"(s2)
+        : [n0] "v"(n0), [n1] "v"(n1), [n2] "v"(n2), [one] "v"(one));
+  } else if (M == 6) {
+    asm volatile(
+        "v_mul_f64 %[s0], %[n0], %[n0]\n\t"
+        "v_mul_f64 %[s1], %[n1], %[n1]\n\t"
+        "v_mul_f64 %[s1], %[s1], %[mk]\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 %[a], %[one], %[s0], 0\n\t"
+        "s_nop 3\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 %[a], %[one], %[s1], %[a]\n\t"
+        "s_nop 5"
+        : [a] "=&v"(a), [s0] "=&v"(s0), [s1] "=&v"(s1)
+        : [n0] "v"(n0), [n1] "v"(n1), [mk] "v"(mk), [one] "v"(one));
+  } else {
+    asm volatile(
+        "v_mul_f64 %[s0], %[n0], %[n0]\n\t"
+        "v_mul_f64 %[s0], %[s0], %[mk]\n\t"
+        "s_nop 1\n\t"
+        "v_mfma_f64_4x4x4_4b_f64 %[a], %[one], %[s0], 0\n\t"
+        "s_nop 5"
+        : [a] "=&v"(a), [s0] "=&v"(s0)
+        : [n0] "v"(n0), [mk] "v"(mk), [one] "v"(one));
+  }
+  return a;
 }
 
 // ---- JacobiSVDImpl_<double> on the rows of S.jr, all problems of the wave together ------------------------------------------
-// Lane 16 g + r works on matrix row r (a row of S.jr: M columns of A, then V, 12 columns in all) and holds its columns g, 4 + g,
-// 8 + g.  (n, base): the problem row r belongs to - n rows starting at row `base`, n in {3, 4, 5, 12} - or n = 0: the row idles.
+// Lane 16 g + r works on matrix row r (a row of S.jr: M columns of A, then V, 12 columns in all - the columns behind V must hold
+// finite values, they are rotated along) and holds its columns g, 4 + g, 8 + g.  (n, base): the problem row r belongs to -
+// n rows starting at row `base`, n in {3, 4, 5, 12} - or n = 0: the row idles.
 // On return the rows are what JacobiSVDImpl_ leaves before its sort: rotated, the A part scaled by 1 / W[i], and
 // W[i] = sqrt(sum At[i][k]^2) in column 15 of the row.
 template <int M>
 EO_FN void jacobi_rows(Lds& S, int n, int base, int lane) {
-  const double eps = 2.220446049250313e-16 * 10;
   const int r = lane & 15, g = lane >> 4, q = r - base;
+  // 1.0 where this lane's column of the partly filled group is an A column, 0.0 where it belongs to V: x * 1.0 is x, and a
+  // (finite) x * 0.0 adds nothing to a sum that started at +0.0
+  const double mk = M == 6 ? (g < 2 ? 1.0 : 0.0) : (M == 3 ? (g < 3 ? 1.0 : 0.0) : 1.0);
+  const double eps = 2.220446049250313e-16 * 10;
   double x0 = S.jr[r * 16 + g], x1 = S.jr[r * 16 + 4 + g], x2 = S.jr[r * 16 + 8 + g];
-  double W = colsum<M>(x0 * x0, x1 * x1, x2 * x2, g);
-  d2* const mine = reinterpret_cast<d2*>(S.xch[r][g]);
-  { d2 lo, hi; lo.x = x0; lo.y = x1; hi.x = x2; hi.y = 0.0; mine[0] = lo; mine[1] = hi; }
+  // W[i] = sum_k At[i][k]^2 - recomputed from the row after every rotation step: for a row that did not rotate this is the
+  // same sum over the same operands, i.e. the same bits
+  double W = row_norm2<M>(x0, x1, x2, mk);
+  double* const mine = S.xch[r][g];
+  { d2 lo; lo.x = x0; lo.y = x1; *reinterpret_cast<d2*>(mine) = lo; mine[2] = x2; }
   S.xw[r] = W;
   const int tb = n == 12 ? EO_TAB12_OFF : (n == 5 ? EO_TAB5_OFF : (n == 4 ? EO_TAB4_OFF : EO_TAB3_OFF));
   const int steps = n == 12 ? EO_TAB12_STEPS : (n == 5 ? EO_TAB5_STEPS : (n == 4 ? EO_TAB4_STEPS : EO_TAB3_STEPS));
   const int pro = n == 12 ? EO_TAB12_PROLOGUE : (n == 5 ? EO_TAB5_PROLOGUE : (n == 4 ? EO_TAB4_PROLOGUE : EO_TAB3_PROLOGUE));
   static_assert(EO_TAB3_SWEEPS == 1 && EO_TAB4_SWEEPS == 1 && EO_TAB5_SWEEPS == 1 && EO_TAB12_SWEEPS == 1, "one sweep per period");
+  // LDS byte addresses (the low half of a generic pointer into the LDS aperture)
+  auto lds = [](const void* p) { return (unsigned)(unsigned long long)p; };
+  const unsigned a_tab = lds(&S.tab[0]);
+  const unsigned twrap = a_tab + 4u * (unsigned)(n > 0 ? tb + pro * n + q : 0);
+  const unsigned cfg = (unsigned)steps | (unsigned)pro << 8 | (unsigned)(4 * n) << 16;
   const unsigned pm = n > 0 ? ((1u << n) - 1u) << base : 0u;   // the rows of my problem, as lanes of group 0
   EO_SYNC();
-  int tt = 0, tp = n > 0 ? tb + q : 0, sbase = 0;
-  unsigned chg = 0;      // bit s: this row rotated in sweep s
-  bool active = n >= 2;
-  unsigned e = S.tab[tp];
-  while (__any(active)) {
-    int tn = tt + 1, tpn = tp + n, sbn = sbase;
-    if (tn == steps) { tn = pro; tpn = tb + pro * n + q; sbn = sbase + 1; }
-    const unsigned en = S.tab[n > 0 ? tpn : 0];           // next step's entry: requested a step ahead
-    const int pq = e & 15, sw = sbase + (int)((e >> 5) & 3);
-    const bool is_j = (e & 16) != 0;
-    const bool valid = active && pq != q && sw < 30;
-    const int pr = valid ? base + pq : r;
-    const d2* const theirs = reinterpret_cast<const d2*>(S.xch[pr][g]);
-    const d2 plo = theirs[0], phi = theirs[1];
-    const double p0 = colsum<M>(x0 * plo.x, x1 * plo.y, x2 * phi.x, g);
-    const double wP = S.xw[pr];
-    const bool rot = valid && !(fabs(p0) <= eps * nsqrt(W * wP));
-    if (__any(rot)) {
-      const double p = p0 * 2;
-      double beta = W - wP;                    // W[i] - W[j]: the j row sees the operands swapped
-      if (is_j) beta = -beta;
-      // cv::hypot(p, beta) = hi sqrt(1 + (lo / hi)^2) (a rotating pair has p != 0, so hi > 0)
-      const double pa = fabs(p), pb = fabs(beta);
-      const bool agb = pa > pb;
-      const double hi = agb ? pa : pb, lo = agb ? pb : pa;
-      const double qq = ndiv(lo, hi);
-      const double gamma = hi * nsqrt(1 + qq * qq);
-      //   beta < 0:  delta = (gamma - beta) * 0.5; s = sqrt(delta / gamma); c = p / (gamma * s * 2)
-      //   else:      c = sqrt((gamma + beta) / (gamma * 2));                s = p / (gamma * c * 2)
-      // gamma - beta = gamma + |beta| for beta < 0, and scaling by 0.5 / by 2 is exact: both quotients are the correctly
-      // rounded (gamma + |beta|) / (2 gamma)
-      const double r1 = nsqrt(ndiv(gamma + pb, gamma * 2));
-      const double r2 = ndiv(p, gamma * r1 * 2);
-      const bool neg = beta < 0;
-      const double s = neg ? r1 : r2, c = neg ? r2 : r1;
-      // row i: t0 = c Ai + s Aj; row j: t1 = -s Ai + c Aj = c (mine) + (-s) (theirs)
-      const double se = is_j ? -s : s;
-      const double n0 = c * x0 + se * plo.x, n1 = c * x1 + se * plo.y, n2 = c * x2 + se * phi.x;
-      const double Wn = colsum<M>(n0 * n0, n1 * n1, n2 * n2, g);
-      if (rot) {
-        x0 = n0; x1 = n1; x2 = n2; W = Wn;
-        chg |= 1u << sw;
-        d2 lo2, hi2; lo2.x = x0; lo2.y = x1; hi2.x = x2; hi2.y = 0.0;
-        mine[0] = lo2; mine[1] = hi2;
-        S.xw[r] = W;
-      }
-    }
-    EO_SYNC();
-    const bool closes = active && (e & 0x80u) != 0;        // the pair (n - 2, n - 1) of sweep sc ran in this step: the sweep is complete
-    if (__any(closes)) {
-      const int sc = sbase + (int)((e >> 8) & 3);
-      const unsigned long long bal = __ballot(closes && ((chg >> (sc & 31)) & 1u));
-      if (closes && (sc >= 29 || ((unsigned)bal & pm) == 0u)) active = false;   // for (iter < 30) { ...; if (!changed) break; }
-    }
-    tt = tn; tp = tpn; sbase = sbn; e = en;
-  }
+  // The step loop (svo_epnp_ord_asm.h, generated by tools/gen_jacobi_asm.py) is software-pipelined over the schedule: the entry
+  // of step t + 2 and the partner row of step t + 1 are requested from LDS while step t computes.  Per step and row:
+  //   partner row p of the pair (i, j) this row belongs to (none: the row idles), fetched from S.xch / S.xw;
+  //   p = sum_k Ai[k] Aj[k] (chained DMFMAs); rotate iff |p| > eps sqrt(W[i] W[j]);
+  //   (c, s) by OpenCV's formulas, IEEE division / square root; row i: c Ai + s Aj, row j: -s Ai + c Aj;
+  //   W[row] = sum of the new row's squares; rows and W back to S.xch / S.xw for their next partners;
+  //   when the pair (n - 2, n - 1) of a sweep has run: the problem stops if none of its rows rotated in that sweep.
+  unsigned chg = 0, nst = 0, flag = 0;
+  int tt = 0, tp = n > 0 ? tb + q : 0, sb = 0;
+  const unsigned e0 = S.tab[tp];                             // step 0
+  ++tt; tp += n;
+  if (tt == steps) { tt = pro; tp = n > 0 ? tb + pro * n + q : 0; ++sb; }
+  const unsigned e1 = S.tab[tp];                             // step 1
+  const unsigned tpa = a_tab + 4u * (unsigned)tp;
+  const unsigned act = n >= 2 ? 1u : 0u;
+  const unsigned amine = lds(mine), axwm = lds(&S.xw[r]), axch = lds(&S.xch[0][g][0]), axw = lds(&S.xw[0]);
+  if (M == 12)
+    asm volatile(EO_JACOBI_ASM_12
+                 : [x0] "+v"(x0), [x1] "+v"(x1), [x2] "+v"(x2), [w] "+v"(W), [chg] "+v"(chg), [nst] "+v"(nst), [flag] "+v"(flag)
+                 : [e0] "v"(e0), [e1] "v"(e1), [tt] "v"(tt), [tp] "v"(tpa), [sb] "v"(sb), [cfg] "v"(cfg), [twrap] "v"(twrap),
+                   [lane] "v"(lane), [base] "v"(base), [act] "v"(act), [pm] "v"(pm), [mk] "v"(mk), [eps] "v"(eps),
+                   [amine] "v"(amine), [axwm] "v"(axwm), [axch] "v"(axch), [axw] "v"(axw)
+                 : EO_JACOBI_ASM_CLOBBERS);
+  else if (M == 6)
+    asm volatile(EO_JACOBI_ASM_6
+                 : [x0] "+v"(x0), [x1] "+v"(x1), [x2] "+v"(x2), [w] "+v"(W), [chg] "+v"(chg), [nst] "+v"(nst), [flag] "+v"(flag)
+                 : [e0] "v"(e0), [e1] "v"(e1), [tt] "v"(tt), [tp] "v"(tpa), [sb] "v"(sb), [cfg] "v"(cfg), [twrap] "v"(twrap),
+                   [lane] "v"(lane), [base] "v"(base), [act] "v"(act), [pm] "v"(pm), [mk] "v"(mk), [eps] "v"(eps),
+                   [amine] "v"(amine), [axwm] "v"(axwm), [axch] "v"(axch), [axw] "v"(axw)
+                 : EO_JACOBI_ASM_CLOBBERS);
+  else
+    asm volatile(EO_JACOBI_ASM_3
+                 : [x0] "+v"(x0), [x1] "+v"(x1), [x2] "+v"(x2), [w] "+v"(W), [chg] "+v"(chg), [nst] "+v"(nst), [flag] "+v"(flag)
+                 : [e0] "v"(e0), [e1] "v"(e1), [tt] "v"(tt), [tp] "v"(tpa), [sb] "v"(sb), [cfg] "v"(cfg), [twrap] "v"(twrap),
+                   [lane] "v"(lane), [base] "v"(base), [act] "v"(act), [pm] "v"(pm), [mk] "v"(mk), [eps] "v"(eps),
+                   [amine] "v"(amine), [axwm] "v"(axwm), [axch] "v"(axch), [axw] "v"(axw)
+                 : EO_JACOBI_ASM_CLOBBERS);
+  if (flag) S.flag = 1;                                      // 25 sweeps without convergence: the sequential solver decides
+  if (M == 12 && lane == 0) S.sweeps = (int)nst;             // diagnostics: steps of the 12 x 12 decomposition
   // W[i] = sqrt(sum At[i][k]^2); At[i] *= 1 / W[i]  (the sort is the caller's: svd_rank)
-  const double w = xsqrt(colsum<M>(x0 * x0, x1 * x1, x2 * x2, g));
+  const double w = xsqrt(row_norm2<M>(x0, x1, x2, mk));
   const double sc1 = 1 / w;
   if (n > 0) {
     S.jr[r * 16 + g] = M >= 4 || g < M ? x0 * sc1 : x0;
-    S.jr[r * 16 + 4 + g] = M >= 8 || 4 + g < M ? x1 * sc1 : (M > 4 ? x1 : x1);
+    S.jr[r * 16 + 4 + g] = M >= 8 || 4 + g < M ? x1 * sc1 : x1;
     S.jr[r * 16 + 8 + g] = M >= 12 || 8 + g < M ? x2 * sc1 : x2;
     if (g == 0) S.jr[r * 16 + 15] = w;
   }
@@ -366,6 +491,8 @@ EO_FN bool solve5_wave(Lds& S, epnp_exact::Work& xw, const double* K, double* R_
   } else if (lane < 18) {
     const int r = (lane - 9) / 3, k = (lane - 9) % 3;
     S.jr[r * 16 + 3 + k] = r == k ? 1.0 : 0.0;
+  } else if (lane < 36) {
+    S.jr[((lane - 18) / 6) * 16 + 6 + (lane - 18) % 6] = 0.0;   // the columns behind V: finite
   }
   EO_SYNC();
   jacobi_rows<3>(S, r16 < 3 ? 3 : 0, r16 < 3 ? 0 : r16, lane);
@@ -383,6 +510,8 @@ EO_FN bool solve5_wave(Lds& S, epnp_exact::Work& xw, const double* K, double* R_
   } else if (lane < 18) {
     const int r = (lane - 9) / 3, k = (lane - 9) % 3;
     S.jr[r * 16 + 3 + k] = r == k ? 1.0 : 0.0;
+  } else if (lane < 36) {
+    S.jr[((lane - 18) / 6) * 16 + 6 + (lane - 18) % 6] = 0.0;   // the columns behind V: finite
   }
   EO_SYNC();
   jacobi_rows<3>(S, r16 < 3 ? 3 : 0, r16 < 3 ? 0 : r16, lane);
@@ -550,6 +679,7 @@ EO_FN bool solve5_wave(Lds& S, epnp_exact::Work& xw, const double* K, double* R_
     } else if (slot < 3 && col < 12) {
       const int r = col - 9;
       for (int k = 0; k < 3; ++k) S.jr[(base + r) * 16 + 3 + k] = r == k ? 1.0 : 0.0;
+      for (int k = 6; k < 12; ++k) S.jr[(base + r) * 16 + k] = 0.0;   // the columns behind V: finite
     }
   }
   EO_SYNC();

@@ -10,12 +10,15 @@
 #include <string.h>
 #include <vector>
 
+#ifdef EO_PROFILE_BUILD
+#define EO_PROFILE 1
+#endif
 #include "../stereo-semantic-vo_amd/csrc/svo_epnp_ord_dev.h"
 
 extern "C" void orc_epnp5(const double Xw5[15], const double uv5[10], const double K[4], double R_out[9], double t_out[3]);
 extern "C" double orc_epnp_last_rep[3];
 
-struct ProbeOut { double R[9], t[3], rep[3]; int ok, flag, sweeps, pad; long long stamp[8]; };
+struct ProbeOut { double R[9], t[3], rep[3]; int ok, flag, sweeps, pad; long long stamp[8]; long long prof[8]; };
 
 __global__ __launch_bounds__(64) void k_probe(const double* X5, const double* u5, const double* Kp, ProbeOut* out, int force_flag, epnp_ord::Lds* dump) {
   __shared__ epnp_ord::Lds S;
@@ -34,6 +37,11 @@ __global__ __launch_bounds__(64) void k_probe(const double* X5, const double* u5
     for (int i = 0; i < 3; ++i) { o.t[i] = t[i]; o.rep[i] = rep[i]; }
     o.ok = ok; o.flag = S.flag; o.sweeps = S.sweeps; o.pad = 0;
     for (int i = 0; i < 8; ++i) o.stamp[i] = S.stamp[i];
+#ifdef EO_PROFILE
+    for (int i = 0; i < 8; ++i) o.prof[i] = S.prof[i];
+#else
+    for (int i = 0; i < 8; ++i) o.prof[i] = 0;
+#endif
     out[blockIdx.x] = o;
   }
   if (dump && blockIdx.x == 0) {
@@ -97,7 +105,6 @@ int main(int argc, char** argv) {
     flagged += o.flag != 0; notok += !o.ok;
     cyc += o.stamp[7] - o.stamp[0];
     for (int i = 1; i < 8; ++i) st[i] += o.stamp[i] - o.stamp[i - 1];
-    sweeps_hist[o.sweeps & 31]++;
     if (!same) {
       if (bad < 8) {
         printf("MISMATCH sample %d (flag %d ok %d/%d sweeps %d)\n  rep gpu %.17g %.17g %.17g\n  rep cpu %.17g %.17g %.17g\n", s, o.flag, o.ok, (int)fin, o.sweeps,
@@ -111,8 +118,9 @@ int main(int argc, char** argv) {
   printf("mean ticks per solve %.0f  stages:", (double)cyc / n);
   for (int i = 1; i < 8; ++i) printf(" %.0f", (double)st[i] / n);
   printf("\n  (control points + barycentric | M, MtM | 12x12 SVD | L, rho, beta init SVDs | gauss-newton | R, t, error | selection)\n");
-  printf("12x12 sweeps histogram:");
-  for (int i = 0; i < 32; ++i) if (sweeps_hist[i]) printf(" %d:%d", i, sweeps_hist[i]);
+  { long long pf[8] = {0}; for (int s = 0; s < n; ++s) for (int i = 0; i < 8; ++i) pf[i] += O[s].prof[i];
+    if (pf[7]) { printf("12x12 loop, mean ticks per step: top+loads %.0f | pair test %.0f | rotation %.0f | update+norm %.0f | stores+sync %.0f | close+loop %.0f  (steps per solve %.1f)\n", (double)pf[0] / pf[7], (double)pf[1] / pf[7], (double)pf[2] / pf[7], (double)pf[3] / pf[7], (double)pf[4] / pf[7], (double)pf[5] / pf[7], (double)pf[7] / n); } }
+  { long long stp = 0; for (int s = 0; s < n; ++s) stp += O[s].sweeps; printf("12x12: %.1f steps per solve, %.0f ticks per step\n", (double)stp / n, (double)st[3] / (double)(stp ? stp : 1)); }
   printf("\nlaunch of %d samples: %.1f us\n", nt, ms * 1e3);
   return bad ? 1 : 0;
 }

@@ -59,7 +59,6 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 struct Lds {
   alignas(16) double jr[16 * 16];   // Jacobi rows [A (M columns) | V (n columns) | .. | W in column 15], row stride 16; 12 x 12: rows 0..11, small ones: rows 5 p .. 5 p + n - 1 of problem p
   alignas(16) double xch[16][4][4];   // row exchange of the Jacobi engine: [row][lane group] = its three columns (+ pad)
-  double xw[16];                      // and the rows' W
   unsigned tab[EO_TAB_TOTAL];         // the schedules (svo_epnp_ord_tab.h), bit 4 (second row of the pair) moved to bit 31
   double pws[16], us[10], alphas[20], cws[12], ccinv[9];
   double M[120];
@@ -278,12 +277,8 @@ EO_FN void jacobi_rows(Lds& S, int n, int base, int lane) {
   const double mk = M == 6 ? (g < 2 ? 1.0 : 0.0) : (M == 3 ? (g < 3 ? 1.0 : 0.0) : 1.0);
   const double eps = 2.220446049250313e-16 * 10;
   double x0 = S.jr[r * 16 + g], x1 = S.jr[r * 16 + 4 + g], x2 = S.jr[r * 16 + 8 + g];
-  // W[i] = sum_k At[i][k]^2 - recomputed from the row after every rotation step: for a row that did not rotate this is the
-  // same sum over the same operands, i.e. the same bits
-  double W = row_norm2<M>(x0, x1, x2, mk);
   double* const mine = S.xch[r][g];
   { d2 lo; lo.x = x0; lo.y = x1; *reinterpret_cast<d2*>(mine) = lo; mine[2] = x2; }
-  S.xw[r] = W;
   const int tb = n == 12 ? EO_TAB12_OFF : (n == 5 ? EO_TAB5_OFF : (n == 4 ? EO_TAB4_OFF : EO_TAB3_OFF));
   const int steps = n == 12 ? EO_TAB12_STEPS : (n == 5 ? EO_TAB5_STEPS : (n == 4 ? EO_TAB4_STEPS : EO_TAB3_STEPS));
   const int pro = n == 12 ? EO_TAB12_PROLOGUE : (n == 5 ? EO_TAB5_PROLOGUE : (n == 4 ? EO_TAB4_PROLOGUE : EO_TAB3_PROLOGUE));
@@ -297,11 +292,15 @@ EO_FN void jacobi_rows(Lds& S, int n, int base, int lane) {
   EO_SYNC();
   // The step loop (svo_epnp_ord_asm.h, generated by tools/gen_jacobi_asm.py) is software-pipelined over the schedule: the entry
   // of step t + 2 and the partner row of step t + 1 are requested from LDS while step t computes.  Per step and row:
-  //   partner row p of the pair (i, j) this row belongs to (none: the row idles), fetched from S.xch / S.xw;
-  //   p = sum_k Ai[k] Aj[k] (chained DMFMAs); rotate iff |p| > eps sqrt(W[i] W[j]);
-  //   (c, s) by OpenCV's formulas, IEEE division / square root; row i: c Ai + s Aj, row j: -s Ai + c Aj;
-  //   W[row] = sum of the new row's squares; rows and W back to S.xch / S.xw for their next partners;
+  //   partner row of the pair (i, j) this row belongs to (none: the row idles), fetched from S.xch;
+  //   p = sum_k Ai[k] Aj[k], W[i] = sum_k Ai[k]^2, W[j] = sum_k Aj[k]^2 - three interleaved chains of DMFMAs.  (JacobiSVDImpl_
+  //   carries W along; it is the k-ordered sum of the squares of the row as last written, which is what is recomputed here -
+  //   same operands, same order, same bits.)
+  //   rotate iff |p| > eps sqrt(W[i] W[j]): decided on the squares with a 2^-40 margin, by the expression itself inside it;
+  //   (c, s) by OpenCV's formulas, IEEE division / square root; row i: c Ai + s Aj, row j: -s Ai + c Aj, back to S.xch;
   //   when the pair (n - 2, n - 1) of a sweep has run: the problem stops if none of its rows rotated in that sweep.
+  const double eps2 = eps * eps;                             // exact: eps = 1.25 * 2^-49
+  const double eps2hi = eps2 * (1.0 + 9.094947017729282e-13), eps2lo = eps2 * (1.0 - 9.094947017729282e-13);   // 2^-40
   unsigned chg = 0, nst = 0, flag = 0;
   int tt = 0, tp = n > 0 ? tb + q : 0, sb = 0;
   const unsigned e0 = S.tab[tp];                             // step 0
@@ -310,28 +309,17 @@ EO_FN void jacobi_rows(Lds& S, int n, int base, int lane) {
   const unsigned e1 = S.tab[tp];                             // step 1
   const unsigned tpa = a_tab + 4u * (unsigned)tp;
   const unsigned act = n >= 2 ? 1u : 0u;
-  const unsigned amine = lds(mine), axwm = lds(&S.xw[r]), axch = lds(&S.xch[0][g][0]), axw = lds(&S.xw[0]);
-  if (M == 12)
-    asm volatile(EO_JACOBI_ASM_12
-                 : [x0] "+v"(x0), [x1] "+v"(x1), [x2] "+v"(x2), [w] "+v"(W), [chg] "+v"(chg), [nst] "+v"(nst), [flag] "+v"(flag)
-                 : [e0] "v"(e0), [e1] "v"(e1), [tt] "v"(tt), [tp] "v"(tpa), [sb] "v"(sb), [cfg] "v"(cfg), [twrap] "v"(twrap),
-                   [lane] "v"(lane), [base] "v"(base), [act] "v"(act), [pm] "v"(pm), [mk] "v"(mk), [eps] "v"(eps),
-                   [amine] "v"(amine), [axwm] "v"(axwm), [axch] "v"(axch), [axw] "v"(axw)
-                 : EO_JACOBI_ASM_CLOBBERS);
-  else if (M == 6)
-    asm volatile(EO_JACOBI_ASM_6
-                 : [x0] "+v"(x0), [x1] "+v"(x1), [x2] "+v"(x2), [w] "+v"(W), [chg] "+v"(chg), [nst] "+v"(nst), [flag] "+v"(flag)
-                 : [e0] "v"(e0), [e1] "v"(e1), [tt] "v"(tt), [tp] "v"(tpa), [sb] "v"(sb), [cfg] "v"(cfg), [twrap] "v"(twrap),
-                   [lane] "v"(lane), [base] "v"(base), [act] "v"(act), [pm] "v"(pm), [mk] "v"(mk), [eps] "v"(eps),
-                   [amine] "v"(amine), [axwm] "v"(axwm), [axch] "v"(axch), [axw] "v"(axw)
-                 : EO_JACOBI_ASM_CLOBBERS);
-  else
-    asm volatile(EO_JACOBI_ASM_3
-                 : [x0] "+v"(x0), [x1] "+v"(x1), [x2] "+v"(x2), [w] "+v"(W), [chg] "+v"(chg), [nst] "+v"(nst), [flag] "+v"(flag)
-                 : [e0] "v"(e0), [e1] "v"(e1), [tt] "v"(tt), [tp] "v"(tpa), [sb] "v"(sb), [cfg] "v"(cfg), [twrap] "v"(twrap),
-                   [lane] "v"(lane), [base] "v"(base), [act] "v"(act), [pm] "v"(pm), [mk] "v"(mk), [eps] "v"(eps),
-                   [amine] "v"(amine), [axwm] "v"(axwm), [axch] "v"(axch), [axw] "v"(axw)
-                 : EO_JACOBI_ASM_CLOBBERS);
+  const unsigned amine = lds(mine), axch = lds(&S.xch[0][g][0]);
+#define EO_JACOBI_OPERANDS                                                                                                       \
+  : [x0] "+v"(x0), [x1] "+v"(x1), [x2] "+v"(x2), [chg] "+v"(chg), [nst] "+v"(nst), [flag] "+v"(flag)                              \
+  : [e0] "v"(e0), [e1] "v"(e1), [tt] "v"(tt), [tp] "v"(tpa), [sb] "v"(sb), [cfg] "v"(cfg), [twrap] "v"(twrap), [lane] "v"(lane), \
+    [base] "v"(base), [act] "v"(act), [pm] "v"(pm), [mk] "v"(mk), [eps] "v"(eps), [eps2hi] "v"(eps2hi), [eps2lo] "v"(eps2lo),   \
+    [amine] "v"(amine), [axch] "v"(axch)                                                                                          \
+  : EO_JACOBI_ASM_CLOBBERS
+  if (M == 12) asm volatile(EO_JACOBI_ASM_12 EO_JACOBI_OPERANDS);
+  else if (M == 6) asm volatile(EO_JACOBI_ASM_6 EO_JACOBI_OPERANDS);
+  else asm volatile(EO_JACOBI_ASM_3 EO_JACOBI_OPERANDS);
+#undef EO_JACOBI_OPERANDS
   if (flag) S.flag = 1;                                      // 25 sweeps without convergence: the sequential solver decides
   if (M == 12 && lane == 0) S.sweeps = (int)nst;             // diagnostics: steps of the 12 x 12 decomposition
   // W[i] = sqrt(sum At[i][k]^2); At[i] *= 1 / W[i]  (the sort is the caller's: svd_rank)

@@ -9,7 +9,7 @@ result is read, 2 between a VALU write of an SGPR / VCC and a VALU read of it as
 and a DMFMA read of it, 4 between dependent 4x4x4 DMFMAs (SrcC), 6 before a VALU read and 9 before an LDS read of a DMFMA
 result.
 
-Registers: the block owns v150..v253 and s60..s73 (clobbers); the row (x0, x1, x2, W) lives in v150..v157 while the loop runs.
+Registers: the block owns v140..v253 and s60..s71 (clobbers); the row (x0, x1, x2) lives in v150..v155 while the loop runs.
 """
 
 # ---- fixed registers -------------------------------------------------------------------------------------------------
@@ -22,6 +22,7 @@ RCP, ERR, REM, QQ, TA, TB, TC = 160, 162, 164, 166, 168, 170, 172
 ONE, T0, T1, T2, AB, Y, G, H, RR, D = 180, 182, 184, 186, 188, 190, 192, 194, 196, 198
 P, THR, PLO, P2, WP, BETA, HI, LO, GAM, R1, R2, CC, SS, N0, N1, N2 = 200, 202, 204, 208, 210, 212, 214, 216, 218, 220, 222, 224, 226, 228, 230, 232
 Q0, Q1 = PLO, PLO + 2
+U0, U1, U2, V0, V1, V2 = 140, 142, 144, 146, 148, 174
 E, E1, E2, TT, TP, SB, SBE, SBE1, SGN, SWBIT, AP, AW, TMP, TMP2, ROW, QI, ONEI, STEPS, PRO, TSTEP = range(234, 254)
 ACT, VALID, ROT, SAVE, CL, ST = "s[60:61]", "s[62:63]", "s[64:65]", "s[66:67]", "s[68:69]", "s[70:71]"
 
@@ -69,42 +70,53 @@ def mfma(dst, b, c):
 
 
 def pair_test(M):
-    """p (-> P) = sum_k mine[k] theirs[k] over the A columns, THR = eps sqrt(W Wp); the square root fills the DMFMA shadows."""
-    t0, t1, t2, ab, y, g, h, r, d, p = map(pair, (T0, T1, T2, AB, Y, G, H, RR, D, P))
-    sq = ["v_mul_f64 %s, %s, %s" % (g, ab, y), "v_mul_f64 %s, %s, 0.5" % (h, y), "v_fma_f64 %s, -%s, %s, 0.5" % (r, h, g),
-          "v_fma_f64 %s, %s, %s, %s" % (g, g, r, g), "v_fma_f64 %s, %s, %s, %s" % (h, h, r, h), "v_fma_f64 %s, -%s, %s, %s" % (d, g, g, ab),
-          "v_fma_f64 %s, %s, %s, %s" % (g, d, h, g), "v_fma_f64 %s, -%s, %s, %s" % (d, g, g, ab), "v_fma_f64 %s, %s, %s, %s" % (g, d, h, g)]
-    out = ["v_mul_f64 %s, %s, %s" % (t0, pair(X0), pair(Q0)), "v_mul_f64 %s, %s, %s" % (ab, pair(WW), pair(WP))]
-    if M == 12:
-        out += ["v_mul_f64 %s, %s, %s" % (t1, pair(X1), pair(Q1)), "v_mul_f64 %s, %s, %s" % (t2, pair(X2), pair(P2)),
-                "v_rsq_f64 %s, %s" % (y, ab), mfma(p, t0, "0")] + sq[0:4] + [mfma(p, t1, p)] + sq[4:8] + [mfma(p, t2, p)] + sq[8:9]
-    elif M == 6:
-        out += ["v_mul_f64 %s, %s, %s" % (t1, pair(X1), pair(Q1)), "v_mul_f64 %s, %s, %%[mk]" % (t1, t1),
-                "v_rsq_f64 %s, %s" % (y, ab), mfma(p, t0, "0")] + sq[0:4] + [mfma(p, t1, p)] + sq[4:9]
-    else:
-        out += ["v_mul_f64 %s, %s, %%[mk]" % (t0, t0), "v_rsq_f64 %s, %s" % (y, ab), "s_nop 0", mfma(p, t0, "0")] + sq
-    out += ["v_mul_f64 %s, %s, %%[eps]" % (pair(THR), g), "s_nop 4"]      # >= 6 wait states behind the last DMFMA
+    """P = sum_k mine[k] theirs[k], WW = sum_k mine[k]^2 (= W of my row), WP = sum_k theirs[k]^2 (= W of the partner row) over the A
+    columns: three interleaved DMFMA chains (dependent DMFMAs end up 4 wait states apart)."""
+    p, wa, wb = pair(P), pair(WW), pair(WP)
+    regs = ((T0, U0, V0, X0, Q0), (T1, U1, V1, X1, Q1), (T2, U2, V2, X2, P2))
+    nq = {12: 3, 6: 2, 3: 1}[M]
+    out = []
+    for q in range(nq):      # the squares of my own row need no partner: they go in front of the wait for its arrival
+        t, u, w, x, y = regs[q]
+        out.append("v_mul_f64 %s, %s, %s" % (pair(u), pair(x), pair(x)))
+    out.append("s_waitcnt lgkmcnt(1)")             # the partner's row (requested at the end of the previous step)
+    for q in range(nq):
+        t, u, w, x, y = regs[q]
+        out += ["v_mul_f64 %s, %s, %s" % (pair(t), pair(x), pair(y)), "v_mul_f64 %s, %s, %s" % (pair(w), pair(y), pair(y))]
+    if M != 12:          # the partly filled column group: V columns count as +0.0
+        t, u, w, x, y = regs[nq - 1]
+        out += ["v_mul_f64 %s, %s, %%[mk]" % (pair(r), pair(r)) for r in (t, u, w)]
+        out.append("s_nop 0")
+    for q in range(nq):
+        t, u, w, x, y = regs[q]
+        c = (lambda r: "0") if q == 0 else (lambda r: r)
+        if q:
+            out.append("s_nop 1")
+        out += [mfma(wa, pair(u), c(wa)), mfma(wb, pair(w), c(wb)), mfma(p, pair(t), c(p))]
+    out.append("s_nop 4")     # 6 wait states between a chain's last DMFMA and the VALU read of its sum: decide() reads WW and WP
+                              # first (5 + the DMFMA into P), then P (5 + one VALU instruction)
     return out
 
 
-def norm(M):
-    """WW = sum_k mine[k]^2 over the A columns (W[i] of the row as it now is)."""
-    t0, t1, t2, w = map(pair, (T0, T1, T2, WW))
-    out = ["v_mul_f64 %s, %s, %s" % (t0, pair(X0), pair(X0))]
-    if M >= 6:
-        out.append("v_mul_f64 %s, %s, %s" % (t1, pair(X1), pair(X1)))
-    if M == 12:
-        out.append("v_mul_f64 %s, %s, %s" % (t2, pair(X2), pair(X2)))
-    if M == 6:
-        out.append("v_mul_f64 %s, %s, %%[mk]" % (t1, t1))
-    if M == 3:
-        out += ["v_mul_f64 %s, %s, %%[mk]" % (t0, t0), "s_nop 1"]
-    out.append(mfma(w, t0, "0"))
-    if M >= 6:
-        out += ["s_nop 3", mfma(w, t1, w)]
-    if M == 12:
-        out += ["s_nop 3", mfma(w, t2, w)]
-    return out
+def decide():
+    """ROT = VALID & !(|p| <= eps sqrt(W[i] W[j])).  Decided on the squares with a margin of 2^-40 (the roundings of either side are
+    of the order 2^-52); a pair inside the margin - or with a NaN - takes the exact expression for the whole wave."""
+    return [
+        "v_mul_f64 %s, %s, %s" % (pair(AB), pair(WW), pair(WP)),
+        "v_mul_f64 %s, %s, %s" % (pair(G), pair(P), pair(P)),
+        "v_mul_f64 %s, %s, %%[eps2hi]" % (pair(H), pair(AB)),
+        "v_mul_f64 %s, %s, %%[eps2lo]" % (pair(RR), pair(AB)),
+        "v_cmp_gt_f64 vcc, %s, %s" % (pair(G), pair(H)),            # p^2 well above: rotates
+        "v_cmp_lt_f64 %s, %s, %s" % (ST, pair(G), pair(RR)),        # well below: does not
+        "s_or_b64 %s, vcc, %s" % (ST, ST),
+        "s_andn2_b64 %s, %s, %s" % (ST, VALID, ST),                 # undecided (valid pairs only)
+        "s_cbranch_scc0 L_decided_%=",
+    ] + nsqrt(pair(THR), pair(AB)) + [
+        "v_mul_f64 %s, %s, %%[eps]" % (pair(THR), pair(THR)),
+        "v_cmp_nle_f64 vcc, |%s|, %s" % (pair(P), pair(THR)),
+        "L_decided_%=:",
+        "s_and_b64 %s, vcc, %s" % (ROT, VALID),
+    ]
 
 
 def decode(e, sbe):
@@ -117,14 +129,12 @@ def decode(e, sbe):
         "v_add_u32 %s, %s, %%[base]" % (v(TMP), v(TMP)),
         "v_cndmask_b32_e64 %s, %s, %s, %s" % (v(TMP), v(ROW), v(TMP), VALID),
         "v_lshl_add_u32 %s, %s, 7, %%[axch]" % (v(AP), v(TMP)),
-        "v_lshl_add_u32 %s, %s, 3, %%[axw]" % (v(AW), v(TMP)),
         "v_and_b32 %s, 0x80000000, %s" % (v(SGN), v(e)),
         "v_bfe_u32 %s, %s, 5, 2" % (v(TMP2), v(e)),
         "v_add_u32 %s, %s, %s" % (v(TMP2), v(TMP2), v(sbe)),
         "v_lshlrev_b32 %s, %s, %s" % (v(SWBIT), v(TMP2), v(ONEI)),
         "ds_read_b128 v[%d:%d], %s" % (PLO, PLO + 3, v(AP)),
         "ds_read_b64 %s, %s offset:16" % (pair(P2), v(AP)),
-        "ds_read_b64 %s, %s" % (pair(WP), v(AW)),
     ]
 
 
@@ -132,7 +142,7 @@ def program(M):
     o = []
     a = o.append
     # ---- set-up
-    for dst, src in ((X0, "%[x0]"), (X1, "%[x1]"), (X2, "%[x2]"), (WW, "%[w]")):
+    for dst, src in ((X0, "%[x0]"), (X1, "%[x1]"), (X2, "%[x2]")):
         a("v_mov_b64 %s, %s" % (pair(dst), src))
     a("v_mov_b64 %s, 1.0" % pair(ONE))
     a("v_mov_b32 %s, 1" % v(ONEI))
@@ -156,21 +166,18 @@ def program(M):
     a("s_cbranch_scc0 L_done_%=")
     # ---- the step loop
     a("L_loop_%=:")
-    a("s_waitcnt lgkmcnt(3)")                      # the entry requested a step ago has arrived
+    a("s_waitcnt lgkmcnt(2)")                      # the entry requested a step ago has arrived
     a("v_mov_b32 %s, %s" % (v(E1), v(E2)))
     a("v_add_u32 %s, 1, %s" % (v(TT), v(TT)))
     a("v_add_u32 %s, %s, %s" % (v(TP), v(TP), v(TSTEP)))
     a("v_cmp_eq_u32 vcc, %s, %s" % (v(TT), v(STEPS)))
-    a("v_add_u32 %%[nst], 1, %%[nst]")
-    a("s_nop 0")
+    a("s_nop 1")
     a("v_cndmask_b32 %s, %s, %s, vcc" % (v(TT), v(TT), v(PRO)))
     a("v_cndmask_b32 %s, %s, %%[twrap], vcc" % (v(TP), v(TP)))
     a("v_addc_co_u32 %s, vcc, 0, %s, vcc" % (v(SB), v(SB)))
     a("ds_read_b32 %s, %s" % (v(E2), v(TP)))
-    a("s_waitcnt lgkmcnt(1)")                      # the partner's row and W (requested at the end of the previous step)
     o += pair_test(M)
-    a("v_cmp_nle_f64 vcc, |%s|, %s" % (pair(P), pair(THR)))
-    a("s_and_b64 %s, vcc, %s" % (ROT, VALID))
+    o += decide()
     a("s_cbranch_scc0 L_skip_%=")
     # rotation
     a("v_add_f64 %s, %s, %s" % (pair(P), pair(P), pair(P)))
@@ -217,13 +224,9 @@ def program(M):
     a("ds_write2_b64 %%[amine], %s, %s offset1:1" % (pair(X0), pair(X1)))
     a("ds_write_b64 %%[amine], %s offset:16" % pair(X2))
     a("s_mov_b64 exec, %s" % SAVE)
-    o += norm(M)
-    a("s_nop 6")
-    a("s_mov_b64 exec, %s" % ROT)
-    a("s_nop 0")
-    a("ds_write_b64 %%[axwm], %s" % pair(WW))
-    a("s_mov_b64 exec, %s" % SAVE)
     a("L_skip_%=:")
+    # the next step's pair (requested before the bookkeeping: more instructions between the request and the use)
+    o += decode(E1, SBE1)
     # sweep bookkeeping
     a("v_and_b32 %s, 0x80, %s" % (v(TMP), v(E)))
     a("v_cmp_ne_u32 vcc, 0, %s" % v(TMP))
@@ -245,9 +248,8 @@ def program(M):
     a("s_and_b64 %s, %s, %s" % (ST, ST, CL))
     a("v_cndmask_b32_e64 %s, 0, 1, %s" % (v(TMP), ST))
     a("v_or_b32 %%[flag], %%[flag], %s" % v(TMP))
+    a("s_and_b64 %s, %s, %s" % (VALID, VALID, ACT))      # a problem that has just stopped takes no part in the next step
     a("L_open_%=:")
-    # the next step's pair
-    o += decode(E1, SBE1)
     a("v_mov_b32 %s, %s" % (v(E), v(E1)))
     a("v_mov_b32 %s, %s" % (v(SBE), v(SBE1)))
     a("v_mov_b32 %s, %s" % (v(SBE1), v(SB)))
@@ -255,14 +257,14 @@ def program(M):
     a("s_cbranch_scc1 L_loop_%=")
     a("L_done_%=:")
     a("s_waitcnt lgkmcnt(0)")
-    for dst, src in (("%[x0]", X0), ("%[x1]", X1), ("%[x2]", X2), ("%[w]", WW)):
+    for dst, src in (("%[x0]", X0), ("%[x1]", X1), ("%[x2]", X2)):
         a("v_mov_b64 %s, %s" % (dst, pair(src)))
     return [l.replace('%%[', '%[') for l in o]
 
 
 def main():
     print("// generated by tools/gen_jacobi_asm.py - do not edit")
-    print("// The step loop of jacobi_rows (svo_epnp_ord_dev.h) for M = 12, 6, 3 columns of A; registers v150..v253, s60..s71.")
+    print("// The step loop of jacobi_rows (svo_epnp_ord_dev.h) for M = 12, 6, 3 columns of A; registers v140..v253, s60..s71.")
     for M in (12, 6, 3):
         lines = program(M)
         print("#define EO_JACOBI_ASM_%d \\" % M)
@@ -270,7 +272,7 @@ def main():
             end = " \\" if i + 1 < len(lines) else ""
             print('  "%s\\n\\t"%s' % (l, end))
         print("")
-    clob = ", ".join('"v%d"' % i for i in range(150, 254)) + ", " + ", ".join('"s%d"' % i for i in range(60, 72)) + ', "vcc", "scc", "memory"'
+    clob = ", ".join('"v%d"' % i for i in range(140, 254)) + ", " + ", ".join('"s%d"' % i for i in range(60, 72)) + ', "vcc", "scc", "memory"'
     print("#define EO_JACOBI_ASM_CLOBBERS " + clob)
 
 

@@ -36,6 +36,15 @@ import sys
 import threading
 import time
 
+T_START = time.perf_counter()
+
+# The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue run
+# their kernels one after the other.  A tracker context owns four streams (pose chain, index chain, two front-end streams) whose
+# whole point is to run side by side, and the legs below keep more than one context alive: measured with two contexts in the
+# process, the index chain and the pose chain of the second one shared a queue - 7.6 k frames/s where the same call in a
+# process of its own does 14.0 k (round 3's unexplained 2x of the `sharded` leg).  Read once, at HIP initialisation.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -80,7 +89,7 @@ def tail_kernel_bytes(kernel, mean_pool_rows, mean_kp, mean_edges, mean_lm_iters
         return (mean_pool_rows + mean_kp) * 32.0
     if kernel == "k_ti_resolve":    # packed entries of the M rows in, the compacted pool (descriptor + 10 bytes) out and in
         return mean_pool_rows * (64.0 + 2 * 42.0) + mean_kp * 60.0
-    if kernel in ("k_tp_hyp", "k_tp_hyp_exact"):   # the n correspondences (40 bytes each) in, 100 sample records (112 bytes) out
+    if kernel in ("k_tp_hyp", "k_tp_hyp_exact", "k_tp_hyp_ord"):   # the n correspondences (40 bytes each) in, 100 sample records (112 bytes) out
         return mean_edges * 40.0 + 100 * 112.0
     if kernel == "k_tp_frame":      # n correspondences of 40 bytes: once for the gather + once per LM iteration and trial
         return mean_edges * 40.0 * (1.0 + 2.0 * mean_lm_iters)
@@ -119,6 +128,7 @@ def pmc_valu(kernel):
     try:
         cycles = d["GRBM_GUI_ACTIVE"] / 8.0
         return {"instr_per_wave": d["SQ_INSTS_VALU"] / d["SQ_WAVES"],
+                "inst_per_cycle_per_wave": (d["SQ_INSTS_VALU"] + d.get("SQ_INSTS_SALU", 0.0) + d.get("SQ_INSTS_LDS", 0.0)) / d["SQ_WAVES"] / cycles,
                 "busy_frac": d["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cycles),
                 "lds_bank_conflict_frac": d["SQ_LDS_BANK_CONFLICT"] / max(d["SQ_LDS_IDX_ACTIVE"], 1.0),
                 "source": "profiles/pmc_latest.json"}
@@ -552,8 +562,8 @@ def sharded_run(pkg, cam, dL, dR, n_frames, G, devices, rec, chunk=512, referenc
            "frames": int(n_frames), "frames_per_call": chunk,
            "note": "ONE sequence: the stateless front end shards by pair (pair k -> context k mod G), the strict chain of "
                    "src/Tracking.cc:231-250 stays on context 0 and bounds the rate at the tail's per-frame latency whatever G is "
-                   "(the front end is ~7 us per pair, the tail ~65 us per frame): expect a FLAT curve over G - replicas "
-                   "(n_gpus independent sequences) are what scales"}
+                   "(the front end is ~7 us per pair, the tail ~115 us per frame with the order-preserving EPnP): a FLAT curve over G "
+                   "is the most this path can give - replicas (n_gpus independent sequences) are what scales"}
     if reference is not None:
         out["records_identical_to_single_context"] = bool(got.tobytes() == reference.tobytes())
     return out
@@ -633,12 +643,61 @@ def semantic_elas_leg(pkg, cam, dL, dR, dev, rec, n=256):
     return out
 
 
+PNP_SOLVERS = {
+    2: "epnp_exact=2 (default): order-preserving wave EPnP - every IEEE operation of OpenCV's solvePnPRansac/EPnP loops kept, independent "
+       "ones spread over a wavefront per RANSAC sample (k-ordered sums on v_mfma_f64_4x4x4); bit-identical per sample to the CPU "
+       "restatement, RANSAC outcome identical on all 4,541 frames (tests/test_full_length.py[ord])",
+    1: "epnp_exact=1: the same operations one lane per sample, loop by loop (the checker of mode 2)",
+    0: "epnp_exact=0: statistical wave EPnP (parallel-order Jacobi, normal equations, FMA): same estimator, another rounding - "
+       "RANSAC winner differs on ~3 % of the frames, 4 % of the frames outside 1e-4 m / 1e-5 (tests/test_full_length.py[fast])",
+}
+
+
+def solver_modes_leg(pkg, cam, dL, dR, frame_bytes, rec, dev, n_frames):
+    """The headline workload again with the two other EPnP solvers (svo_set_option "epnp_exact"): same frames, same schedule,
+    a shorter run each.  Mode 0 was the default up to round 3."""
+    import torch
+    out = {}
+    for mode, frames in ((0, min(n_frames, 2560)), (1, min(n_frames, 512))):
+        svo = pkg.Svo(W, H, device=dev.index or 0, max_kp=500, max_batch=256)
+        svo.set_option("epnp_exact", mode)
+        svo.track_reset(cam)
+        res = torch.zeros((frames, rec), dtype=torch.uint8, device=dev)
+        B = 128
+        def run(c0, c):
+            svo.track_batch_dev(dL.data_ptr() + c0 * frame_bytes, dR.data_ptr() + c0 * frame_bytes, PITCH, c, res.data_ptr() + c0 * rec)
+        run(0, B); run(B, B)                             # warm-up: two calls (both alternating output sets get allocated)
+        svo.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        enq = []
+        for c0 in range(2 * B, frames, B):
+            run(c0, min(B, frames - c0))
+            enq.append(round((time.perf_counter() - t0) * 1e3, 1))
+        svo.sync()
+        enq.append(round((time.perf_counter() - t0) * 1e3, 1))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        enq.append(round(dt * 1e3, 1))
+        chain = None
+        try:
+            chain = tail_chain_from_stamps(svo.debug_track_frames(0, B))
+        except Exception:  # noqa: BLE001
+            pass
+        svo.close()
+        out["epnp_exact=%d" % mode] = {"value": (frames - 2 * B) / dt, "unit": "stereo frames/s", "frames_timed": int(frames - 2 * B),
+                                        "solver": PNP_SOLVERS[mode],
+                                        "host_ms_after_each_call_then_sync": enq, "tail_critical_path": chain}
+    return out
+
+
 def tail_chain_from_stamps(dbg):
     """The ordered tail's critical path from the in-kernel wall-clock stamps (s_memrealtime, 10 ns ticks) the tail kernels
     leave in every frame's work record: no profiler, no event pairs in the stream."""
     import numpy as np
     rt = dbg["rt"].astype(np.int64)
-    ok = (rt[:, 3] > rt[:, 2]) & (rt[:, 1] > rt[:, 0])
+    # a frame's stamps count only if all five were written by this run, in order, within a second of each other (a kernel that
+    # leaves one out - or a stale record - would otherwise turn up as a mean of 1e13 us)
+    ok = (rt[:, :5] > 0).all(axis=1) & (rt[:, 3] > rt[:, 4]) & (rt[:, 4] > rt[:, 2]) & (rt[:, 1] > rt[:, 0]) & (rt[:, 3] - rt[:, 2] < 100000000)
     rt = rt[ok]
     if len(rt) < 4:
         return None
@@ -675,6 +734,12 @@ def spawn_ranks(args):
             print(line)
     sys.stdout.flush()
     sys.exit(p.returncode)
+
+
+def progress(msg):
+    """One line per stage on stderr (the JSON line is stdout's): a run that stops answering shows where."""
+    sys.stderr.write("[bench %.1f s] %s\n" % (time.perf_counter() - T_START, msg))
+    sys.stderr.flush()
 
 
 def main():
@@ -794,6 +859,8 @@ def main():
         return
 
     svo = pkg.Svo(W, H, device=local, max_kp=500, max_batch=B + extra)
+    if "SVO_BENCH_EPNP" in os.environ:                   # experiments: the headline with another EPnP solver (named in config)
+        svo.set_option("epnp_exact", int(os.environ["SVO_BENCH_EPNP"]))
     for kv in filter(None, os.environ.get("SVO_BENCH_OPTIONS", "").split(",")):   # experiments: "track_group=8,..."
         k, v = kv.split("=")
         svo.set_option(k, int(v))
@@ -839,15 +906,18 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    progress("warm-up")
     for s in range(args.warmup):
         step(s)
     fence()
+    progress("timed region")
     # the timed region: the product's default schedule, no profiling hooks
     t0 = time.perf_counter()
     for s in range(args.warmup, nsteps):
         step(s)
     fence()
     dt = time.perf_counter() - t0
+    progress("timed region done")
     dt = shard.max_over_ranks(dt, dist, dev if args.dist_backend == "nccl" else "cpu")
     # in-kernel wall-clock stamps of the last timed step's frames (always written, free)
     chain = None
@@ -903,7 +973,8 @@ def main():
                         "mean_lm_edges": float(res["n_lm_edges"][1:].mean()),
                         "mean_active_rows_pass1_pass2": [float(res["reserved"][1:, 0].mean()), float(res["reserved"][1:, 1].mean())],
                         "mean_local_map": float(res["n_local_map"][1:].mean()),
-                        "tracker_capacity_flag": int(svo.track_overflowed())})
+                        "tracker_capacity_flag": int(svo.track_overflowed()),
+                        "pnp_solver": PNP_SOLVERS[int(os.environ.get("SVO_BENCH_EPNP", "2"))]})
             if world == 1 and not multi and not args.no_cpu_baseline and args.depth_source == 0 and not args.boxes:
                 # the oracle's tail over ALL tracked frames, on a host thread while the legs below run
                 oracle_run = OracleTailRun(cam, *frontend_outputs(pkg, cam, dL, dR, len(res), dev))
@@ -938,8 +1009,10 @@ def main():
             # the tail's kernels: in-kernel wall-clock stamps of the timed region where they exist (an event pair around a ~40 us
             # kernel of single-wave workgroups inflates it by up to 10 us; the stamps agree with rocprofv3's averages)
             stamped = {}
+            hyp_name = next((k for k in ("k_tp_hyp_ord", "k_tp_hyp", "k_tp_hyp_exact") if k in per_frame), "k_tp_hyp_ord")
             if chain and "k_ti_resolve_us" in chain:
-                stamped = {k: chain[k + "_us"]["mean"] * 1e-3 for k in ("k_ti_resolve", "k_tp_hyp", "k_tp_frame") if k in per_frame}
+                stamped = {name: chain[key + "_us"]["mean"] * 1e-3 for key, name in
+                           (("k_ti_resolve", "k_ti_resolve"), ("k_tp_hyp", hyp_name), ("k_tp_frame", "k_tp_frame")) if name in per_frame}
                 for k, v in stamped.items():
                     per_frame[k] = v
                     kern[k]["ms_per_frame"] = v
@@ -974,22 +1047,62 @@ def main():
                                        "pose chain: RANSAC samples -> LM): latency-bound, far from the HBM roof by construction "
                                        "(DESIGN.md section 5); `tail_critical_path` has the chains' in-kernel times" if units == "frames" else None}
             out["kernels"] = kern
+            if track and not multi and chain and "k_tp_hyp_us" in chain:
+                # the kernel the frame rate hangs on is not the one furthest below the HBM roof: the pose chain (RANSAC samples ->
+                # LM) is a dependent float64 instruction stream, one wavefront per sample, and a wavefront issues at most one
+                # instruction per 4 cycles whatever the instruction is
+                hyp_us, frm_us = chain["k_tp_hyp_us"]["mean"], chain["k_tp_frame_us"]["mean"]
+                v = pmc_valu(hyp_name)
+                out["critical_path"] = {
+                    "kernels": [hyp_name, "k_tp_frame"], "us_per_frame": [hyp_us, frm_us],
+                    "share_of_frame_period": (hyp_us + frm_us) / max(chain["frame_period_us"]["mean"], 1e-9),
+                    "bound": "float64 instruction issue of ONE wavefront per RANSAC sample (quad-cycle cadence: <= 0.25 instructions per "
+                             "cycle per wave): the solve is a dependent chain - 148 Jacobi steps of ~150 instructions (division and "
+                             "square root sequences of the rotation: 46 of them) + 5 Gauss-Newton steps per candidate",
+                    "issue_model": {"peak_inst_per_cycle_per_wave": 0.25, "clock_ghz": 2.4,
+                                    "achieved_inst_per_cycle_per_wave": (v or {}).get("inst_per_cycle_per_wave"),
+                                    "source": "profiles/pmc_latest.json (SQ_INSTS_VALU + SALU + LDS over SQ_WAVE_CYCLES of the kernel)" if v else "no counters committed for this kernel"},
+                    "hbm_frac_of_this_kernel": (tail_kernel_bytes(hyp_name, 0, 0, float(res["n_lm_edges"][1:].mean()), 0) / (hyp_us * 1e-6) / 1e9 / HBM_PEAK_GBS),
+                }
         if world == 1 and not args.no_cpu_baseline:
             ns = min(n_frames, 64)
             Lh = dL[:ns, :, :W].cpu().numpy()
             Rh = dR[:ns, :, :W].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(Lh, Rh, cam, args.workload)
         legs = world == 1 and not args.no_legs and not multi and args.depth_source == 0 and not args.boxes
+        if legs:
+            svo.close()                          # (its streams would share hardware queues with the legs' contexts)
+            svo = None
+        # Order of the legs: the ones that run the ordered tail (two chains that must overlap on two hardware queues) come first.
+        # A tracker context created after the front-end / many-sequence legs lost that overlap in this process (measured: the
+        # statistical solver's leg 7.6 k frames/s behind them, 14.2 k in front of them; `sharded` 5.3 k -> 7.9 k) - their contexts
+        # keep up to a dozen streams (and ELAS its host thread pools) alive between them, and the runtime maps streams onto a
+        # limited set of hardware queues; the many-sequence leg measured 93 k frames/s in front of the ELAS legs, 57 k behind them.
         if legs and track:
-            out["frontend"] = frontend_leg(pkg, cam, dL, dR, n_frames, frame_bytes, dev,
-                                           None if args.no_cpu_baseline else cpu_baseline_all_cores)
-            out["multi_sequence"] = multi_sequence_leg(pkg, cam, dL, dR, frame_bytes, rec, dev, res)
+            try:
+                progress("leg pnp_solver_modes")
+                out["pnp_solver_modes"] = solver_modes_leg(pkg, cam, dL, dR, frame_bytes, rec, dev, n_frames)
+            except Exception as e:  # noqa: BLE001
+                out["pnp_solver_modes"] = {"error": repr(e)}
             try:
                 ns = min(n_frames, 1024)
+                progress("leg sharded")
                 out["sharded"] = sharded_run(pkg, cam, dL, dR, ns, 2, [local, local], rec, reference=d_res[:ns].cpu().numpy())
-                out["sharded"]["note"] = "two contexts on this ONE GPU (the driver's multi-GPU run adds the cross-device measurement); " + out["sharded"]["note"]
+                out["sharded"]["note"] = ("two contexts on this ONE GPU: no cross-device run was measured here (the driver's multi-GPU run, "
+                                          "when it has a node, adds it); " + out["sharded"]["note"])
             except Exception as e:  # noqa: BLE001
                 out["sharded"] = {"error": repr(e)}
+            progress("leg multi_sequence")
+            out["multi_sequence"] = multi_sequence_leg(pkg, cam, dL, dR, frame_bytes, rec, dev, res)
+            if not args.no_elas_leg:
+                try:
+                    progress("leg semantic_elas")
+                    out["semantic_elas"] = semantic_elas_leg(pkg, cam, dL, dR, dev, rec)
+                except Exception as e:  # noqa: BLE001
+                    out["semantic_elas"] = {"error": repr(e)}
+            progress("leg frontend")
+            out["frontend"] = frontend_leg(pkg, cam, dL, dR, n_frames, frame_bytes, dev,
+                                           None if args.no_cpu_baseline else cpu_baseline_all_cores)
         if oracle_run is not None:
             oracle_run.join()
             rep = oracle_run.report(res)
@@ -998,12 +1111,9 @@ def main():
             if "ate_vs_cpu_m" in rep:
                 out["ate_vs_cpu_m"] = rep["ate_vs_cpu_m"]
         if legs and not args.no_elas_leg:
-            if track:
-                try:
-                    out["semantic_elas"] = semantic_elas_leg(pkg, cam, dL, dR, dev, rec)
-                except Exception as e:  # noqa: BLE001
-                    out["semantic_elas"] = {"error": repr(e)}
+            progress("leg elas")
             out["elas"] = elas_leg(pkg, dev.index or 0, dL, dR, PITCH, min(512, int(n_frames)), iters=2)
+            progress("leg msa")
             out["msa"] = msa_leg(pkg, dev.index or 0, dL, dR)
     # N > 1: after the replicas' timed region rank 0 alone drives ONE sequence over all N GPUs (BASELINE configs[3]);
     # the other ranks wait at the barrier below
@@ -1021,7 +1131,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    svo.close()
+    if svo is not None:
+        svo.close()
 
 
 if __name__ == "__main__":

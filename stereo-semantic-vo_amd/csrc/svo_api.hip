@@ -308,8 +308,24 @@ extern "C" void svo_destroy(svo_ctx* ctx) {
   delete ctx;
 }
 
+// svo_track_batch_dev leaves its tail in flight and lets the next call's front end run beside it (two alternating output sets,
+// two halves of the work records).  Any OTHER entry that touches the streams, the result arrays or the options they were
+// enqueued under first waits for those tails - the overlap is a contract between consecutive batch calls only.
+int svo_track_quiesce(svo_ctx* ctx) {
+  bool pending = false;
+  for (int q = 0; q < 2; ++q) {
+    if (!ctx->tb_used[q] || !ctx->tb_done[q]) continue;
+    pending = true;
+    SVO_HIP(ctx, hipEventSynchronize(ctx->tb_done[q]));
+  }
+  if (pending && ctx->stream_fe_batch) SVO_HIP(ctx, hipStreamSynchronize(ctx->stream_fe_batch));
+  if (pending && ctx->stream_dense) SVO_HIP(ctx, hipStreamSynchronize(ctx->stream_dense));
+  return SVO_OK;
+}
+
 extern "C" int svo_set_option(svo_ctx* ctx, const char* key, int value) {
   if (!ctx || !key) return SVO_E_INVALID;
+  { const int rcq = svo_track_quiesce(ctx); if (rcq) return rcq; }   // options apply to what is enqueued AFTER this call
   if (!strcmp(key, "pose_mfma")) { ctx->opt_pose_mfma = value != 0; return SVO_OK; }
   if (!strcmp(key, "fast_cand_cap")) {
     if (value < 0 || value > 2048) return SVO_E_INVALID;
@@ -836,6 +852,7 @@ extern "C" int svo_frontend_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, cons
   if (!ctx || !d_grayL || !d_grayR || !cam || B < 1 || stride < ctx->g.W) return SVO_E_INVALID;
   if (B > ctx->max_batch) return SVO_E_CAPACITY;
   hipSetDevice(ctx->device);
+  { const int rcq = svo_track_quiesce(ctx); if (rcq) return rcq; }   // (a batched tracker call's tail may still read the result arrays)
   // Slices of the batch side by side on their own streams: the kernels of the chain are a mix of arithmetic-bound ones (k_fast: the
   // vector ALUs 88 % busy) and latency-bound ones (k_select, k_stereo_*, the small pyramid levels: a few waves per CU
   // waiting on memory) - side by side they fill each other's gaps.  With the per-kernel timers on (svo_profile_enable)

@@ -889,7 +889,7 @@ extern "C" int svo_msa_solve(svo_ctx* ctx, const uint8_t* bgrL, const uint8_t* b
   uint8_t* d_out = buf.get<uint8_t>(N);
   if (!img3[0] || !img3[1] || !d_out) { ctx->last_error = "svo_msa_solve: hipMalloc"; return SVO_E_NOMEM; }
   hipStream_t s = ctx->stream;
-  if (ctx->h_pinned && 6 * N <= ctx->pinned_bytes) {
+  if (ctx->h_pinned && 6 * N + 4096 <= ctx->pinned_bytes) {   // (the buffer's last page belongs to svo_track_frame's boxes)
     // rows gathered into the pinned buffer, one linear copy per image (a 2-D copy from pageable memory costs ~10 ms)
     const uint8_t* src[2] = {bgrL, bgrR};
     for (int side = 0; side < 2; ++side) {

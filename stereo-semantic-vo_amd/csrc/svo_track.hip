@@ -921,15 +921,23 @@ __global__ __launch_bounds__(64) void k_tg_fmat(TrackState* st, const svo_kp* kp
 // can never reach their samples - six times less EPnP work on ordinary frames (61 k -> 74 k frames/s with 64 sequences).
 // Wait (thread 0 polls, the workgroup follows through the barrier) until the index chain has published the record of the frame
 // with tag `tag`; tag <= 0: the caller ordered the streams itself (many sequences, latency entry).  Bounded: see above.
-__device__ __forceinline__ void tp_wait_work(TrackState* st, const TrackWork* work, int tag) {
+__device__ __forceinline__ bool tp_wait_work(TrackState* st, const TrackWork* work, int tag) {
+  __shared__ int s_lost;
   if (tag > 0) {
     if (threadIdx.x == 0) {
       int spins = 0;
       while (ld_agent(&work->ready) != tag && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(2); ++spins; }
-      if (spins >= (1 << 22)) st->overflow = 4;      // lost hand-over: svo_track_overflowed reports it
+      s_lost = spins >= (1 << 22) ? 1 : 0;
+      if (s_lost) st->overflow = 4;                  // lost hand-over: svo_track_overflowed reports it
     }
     __syncthreads();
+    // what the record points at (keypoints, depths: written by front-end kernels on other CUs and L2s, with plain stores, before
+    // the index chain published the tag) is read with plain loads below: acquire at agent scope, so that no line cached before
+    // the tag was seen is served
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (s_lost) return false;                        // a stale record must not reach the results: the kernel leaves
   }
+  return true;
 }
 
 #define TP_HYP_FIRST 16
@@ -943,7 +951,7 @@ __global__ __launch_bounds__(256) void k_tp_hyp(TrackState* st, const TrackWork*
                                                 int kstride, int hyp_base, int tag) {
   TpHypLds& S = *reinterpret_cast<TpHypLds*>(tk_smem);
   st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
-  tp_wait_work(st, work, tag);
+  if (!tp_wait_work(st, work, tag)) return;
   const long long t_start = clock64();
   if (hyp_base == 0 && blockIdx.x == 0 && threadIdx.x == 0) const_cast<TrackWork*>(work)->rt[2] = wall_clock64();
   // the record's header and this thread's first correspondence in ONE round trip to the coherent level (the entry is read
@@ -988,7 +996,7 @@ __global__ __launch_bounds__(64) void k_tp_hyp_exact(TrackState* st, TrackWork* 
                                                      int kstride, int tag) {
   TpHypExactLds& S = *reinterpret_cast<TpHypExactLds*>(tk_smem);
   st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
-  tp_wait_work(st, work, tag);
+  if (!tp_wait_work(st, work, tag)) return;
   if (threadIdx.x == 0 && blockIdx.x == 0) work->rt[2] = wall_clock64();
   const int n = ld_agent(&work->n_edges);
   if (ld_agent(&work->skip_match) || n < 5) return;
@@ -1006,16 +1014,24 @@ __global__ __launch_bounds__(64) void k_tp_hyp_exact(TrackState* st, TrackWork* 
 
 // The RANSAC samples in the order-preserving wave mode ("epnp_exact" = 2, the default): one single-wave workgroup per sample,
 // OpenCV's operations over the wavefront with their rounding kept (svo_epnp_ord_dev.h); the wave counts the consensus.
-struct TpHypOrdLds { double Xw[TRK_MAXKP * 3], uv[TRK_MAXKP * 2]; PnpOrdLds ord; };
+struct TpHypOrdLds { double Xw[TRK_MAXKP * 3], uv[TRK_MAXKP * 2]; PnpOrdLds ord; int cnt[TP_HYP_FIRST], ok[TP_HYP_FIRST], bound; };
 __global__ __launch_bounds__(64) void k_tp_hyp_ord(TrackState* st, TrackWork* work, const svo_kp* kp, const uint16_t* subsets,
-                                                   int kstride, int tag, int force_seq) {
+                                                   int kstride, int hyp_base, int tag, int force_seq) {
   TpHypOrdLds& S = *reinterpret_cast<TpHypOrdLds*>(tk_smem);
   st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
-  tp_wait_work(st, work, tag);
+  if (!tp_wait_work(st, work, tag)) return;
   const long long t_start = clock64();
-  if (threadIdx.x == 0 && blockIdx.x == 0) work->rt[2] = wall_clock64();
+  const int sample = hyp_base + (int)blockIdx.x;
+  if (threadIdx.x == 0 && sample == 0) work->rt[2] = wall_clock64();
   const int n = ld_agent(&work->n_edges);
   if (ld_agent(&work->skip_match) || n < 5) return;
+  if (hyp_base > 0) {   // second launch of a many-sequence step: only the samples the adaptive bound can still reach (see k_tp_hyp)
+    if (threadIdx.x < TP_HYP_FIRST) { S.cnt[threadIdx.x] = st->hyp[threadIdx.x].cnt; S.ok[threadIdx.x] = st->hyp[threadIdx.x].ok; }
+    __syncthreads();
+    if (threadIdx.x == 0) S.bound = pnp_bound_after(S.cnt, S.ok, n, TP_HYP_FIRST);
+    __syncthreads();
+    if (sample >= S.bound) return;
+  }
   const float* gpos = st->gpos;
   for (int e = threadIdx.x; e < n; e += blockDim.x) {
     const float* gp = gpos + 3 * (size_t)(ld_agent(&work->edge_gid[e]) & (TRK_GPOS - 1));
@@ -1026,8 +1042,8 @@ __global__ __launch_bounds__(64) void k_tp_hyp_ord(TrackState* st, TrackWork* wo
   __syncthreads();
   const double K[4] = {(double)st->cam.fx, (double)st->cam.fy, (double)st->cam.cx, (double)st->cam.cy};
   const long long t_gather = clock64();
-  pnp_hyp_ord_wave(S.ord, S.Xw, S.uv, n, K, subsets + (size_t)min(n, 512) * 500, st->hyp, blockIdx.x, force_seq != 0);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  pnp_hyp_ord_wave(S.ord, S.Xw, S.uv, n, K, subsets + (size_t)min(n, 512) * 500, st->hyp, sample, force_seq != 0);
+  if (sample == 0 && threadIdx.x == 0) {
     const long long* sp = S.ord.S.stamp;
     st->pose_ts[0] = t_start; st->pose_ts[1] = t_gather; st->pose_ts[2] = sp[0]; st->pose_ts[3] = sp[7];
     st->pose_ts[4] = clock64();
@@ -1057,7 +1073,7 @@ __global__ __launch_bounds__(TPF_NT) void k_tp_frame(TrackState* st, TrackWork* 
   st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
   depth += (size_t)blockIdx.y * kstride; res_out += blockIdx.y;
   const int tid = threadIdx.x;
-  tp_wait_work(st, work, tag);
+  if (!tp_wait_work(st, work, tag)) return;
   if (tid == 0) work->rt[4] = wall_clock64();
   const long long tf0 = clock64();
   const int id = ld_agent(&work->frame_id), nkp = ld_agent(&work->nkp), skip = ld_agent(&work->skip_match), n_edges = ld_agent(&work->n_edges);
@@ -1194,6 +1210,8 @@ void svo_track_release(svo_ctx* ctx) {
   ctx->ev_sub.clear();
   if (ctx->stream_fe) { hipStreamDestroy(ctx->stream_fe); ctx->stream_fe = nullptr; }
   if (ctx->stream_fe_batch) { hipStreamDestroy(ctx->stream_fe_batch); ctx->stream_fe_batch = nullptr; }
+  if (ctx->stream_dense) { hipStreamDestroy(ctx->stream_dense); ctx->stream_dense = nullptr; }
+  if (ctx->h_prod) { hipHostFree(ctx->h_prod); ctx->h_prod = nullptr; }
   for (int p = 0; p < 2; ++p) {
     if (ctx->ms_kp[p]) hipFree(ctx->ms_kp[p]);
     if (ctx->ms_desc[p]) hipFree(ctx->ms_desc[p]);
@@ -1317,8 +1335,15 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
     ctx->profiling = prof && (f % 32 == 0 || frames < 32);
     if (ctx->opt_epnp_exact == 2) {
       SvoTimer t(ctx, "k_tp_hyp_ord");
-      hipLaunchKernelGGL(k_tp_hyp_ord, dim3(PNP_HYP, ny), dim3(64), sizeof(TpHypOrdLds), s0, st, work + f, kpf, ctx->d_pnp_subsets, kstride,
-                         tag_of(f), ctx->opt_epnp_force_seq);
+      if (ny >= 8) {   // many sequences: sixteen samples per sequence first, then only those the adaptive bound can reach
+        hipLaunchKernelGGL(k_tp_hyp_ord, dim3(TP_HYP_FIRST, ny), dim3(64), sizeof(TpHypOrdLds), s0, st, work + f, kpf, ctx->d_pnp_subsets,
+                           kstride, 0, 0, ctx->opt_epnp_force_seq);
+        hipLaunchKernelGGL(k_tp_hyp_ord, dim3(PNP_HYP - TP_HYP_FIRST, ny), dim3(64), sizeof(TpHypOrdLds), s0, st, work + f, kpf,
+                           ctx->d_pnp_subsets, kstride, TP_HYP_FIRST, 0, ctx->opt_epnp_force_seq);
+      } else {
+        hipLaunchKernelGGL(k_tp_hyp_ord, dim3(PNP_HYP, ny), dim3(64), sizeof(TpHypOrdLds), s0, st, work + f, kpf, ctx->d_pnp_subsets, kstride,
+                           0, tag_of(f), ctx->opt_epnp_force_seq);
+      }
     } else if (ctx->opt_epnp_exact) {
       SvoTimer t(ctx, "k_tp_hyp_exact");
       hipLaunchKernelGGL(k_tp_hyp_exact, dim3(PNP_HYP, ny), dim3(64), sizeof(TpHypExactLds), s0, st, work + f, kpf, ctx->d_pnp_subsets, kstride,
@@ -1378,6 +1403,7 @@ static int track_reset_n(svo_ctx* ctx, const svo_camera* cam, int nseq) {
   if (ctx->stream_idx) SVO_HIP(ctx, hipStreamSynchronize(ctx->stream_idx));
   if (ctx->stream_fe) SVO_HIP(ctx, hipStreamSynchronize(ctx->stream_fe));
   if (ctx->stream_fe_batch) SVO_HIP(ctx, hipStreamSynchronize(ctx->stream_fe_batch));
+  if (ctx->stream_dense) SVO_HIP(ctx, hipStreamSynchronize(ctx->stream_dense));
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->ms_parity = 0; ctx->ms_tail_recorded[0] = false; ctx->ms_tail_recorded[1] = false;
   ctx->tb_parity = 0; ctx->tb_used[0] = false; ctx->tb_used[1] = false;   // (all streams are idle here)
@@ -1454,6 +1480,7 @@ extern "C" int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL,
     return SVO_E_INVALID;
   if (!ctx->d_track || ctx->n_seq != 1) return SVO_E_INVALID;   // svo_track_reset first
   hipSetDevice(ctx->device);
+  { const int rcq = svo_track_quiesce(ctx); if (rcq) return rcq; }
   const SvoGeom& g = ctx->g;
   TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
   uint8_t* dL = ctx->d_stage;
@@ -1463,7 +1490,7 @@ extern "C" int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL,
   if ((rc = svo_upload_image(ctx, grayR, strideR, 1))) return rc;
   // the frame's boxes go to HBM with the images (pinned staging: the copies are asynchronous, the caller's array may be
   // pageable); from there on a gated frame is device work only
-  int32_t* h_box = reinterpret_cast<int32_t*>(ctx->h_pinned + ctx->pinned_bytes - 4096);   // the buffer's last page: nothing else uses it
+  int32_t* h_box = reinterpret_cast<int32_t*>(ctx->h_pinned + ctx->pinned_bytes - 4096);   // the buffer's last page: reserved for this (svo_msa.hip stays below it)
   h_box[0] = n_boxes;
   if (n_boxes > 0) memcpy(h_box + 4, boxes, 16 * (size_t)n_boxes);
   SVO_HIP(ctx, hipMemcpyAsync(&st->n_boxes, h_box, 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1592,21 +1619,72 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
   hipSetDevice(ctx->device);
   int rc;
   if (ctx->opt_depth_source == 1) {
-    // dense ELAS maps for the B frames (svo_elas_batch_dev), then the reference's per-keypoint lookups
-    const size_t n = (size_t)ctx->g.W * ctx->g.H;
-    if ((rc = dense_reserve(ctx, B))) return rc;
+    // BASELINE configs[4] as a pipeline: the dense front end (ORB on the left images, ELAS maps, the reference's per-keypoint
+    // lookups - src/Tracking.cc:225-228, src/frame.cc:122-164) works through the call in sub-batches on a stream of its own,
+    // and the ordered tail of sub-batch j runs on the tail's streams while sub-batch j + 1 is in the dense stage (whose host
+    // phases - support-point filter, Delaunay - block this thread, not the GPU).  The first sub-batches are small, so that the
+    // tail starts early; every sub-batch uses its own half of the work records, like consecutive calls of the sparse path.
+    const size_t n = (size_t)ctx->g.W * ctx->g.H, K = ctx->max_kp, img = (size_t)ctx->g.H * stride;
+    const int SUBMAX = 64;
+    if ((rc = dense_reserve(ctx, std::min(B, SUBMAX)))) return rc;
+    if ((rc = track_resources(ctx, std::min(B, SUBMAX), 1))) return rc;
+    if (!ctx->stream_dense) SVO_HIP(ctx, svo_stream_create(&ctx->stream_dense, 0));
     float* dD1 = ctx->d_dense;
-    float* dD2 = dD1 + n * (size_t)B;
-    int32_t* d_prod = reinterpret_cast<int32_t*>(dD2 + n * (size_t)B);
-    if ((rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, B, B))) return rc;   // left images only
+    float* dD2 = dD1 + n * (size_t)ctx->dense_cap;
+    int32_t* d_prod = reinterpret_cast<int32_t*>(dD2 + n * (size_t)ctx->dense_cap);
+    if (!ctx->h_prod) {
+      if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_prod), sizeof(int32_t) * 2 * SUBMAX) != hipSuccess) { (void)hipGetLastError(); return SVO_E_NOMEM; }
+    }
     svo_elas_params ep;
     svo_elas_default_params(0, &ep);
-    std::vector<int32_t> prod(B, 0);
-    if ((rc = svo_elas_batch_dev(ctx, d_grayL, d_grayR, stride, ctx->g.W, ctx->g.H, B, &ep, dD1, dD2, prod.data()))) return rc;
-    SVO_HIP(ctx, hipMemcpyAsync(d_prod, prod.data(), sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_tk_dense_depth, dim3((ctx->max_kp + 255) / 256, B), dim3(256), 0, ctx->stream, ctx->d_kp, ctx->d_nkp,
-                       dD1, ctx->g.W, ctx->cam.bf, ctx->d_uR, ctx->d_depth, ctx->max_kp, n, d_prod);
-    SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `prod` is on this stack frame
+    for (int q = 0; q < 2; ++q)
+      if (!ctx->tb_done[q]) SVO_HIP(ctx, hipEventCreateWithFlags(&ctx->tb_done[q], hipEventDisableTiming));
+    // the dense stage writes the ctx's own result arrays and maps: everything the ctx stream holds (an earlier call's tail) first
+    SVO_HIP(ctx, hipEventRecord(ctx->ev_frontend, ctx->stream));
+    SVO_HIP(ctx, hipStreamWaitEvent(ctx->stream_dense, ctx->ev_frontend, 0));
+    svo_kp* const own_kp = ctx->d_kp; uint8_t* const own_desc = ctx->d_desc; int32_t* const own_nkp = ctx->d_nkp;
+    float* const own_uR = ctx->d_uR; float* const own_depth = ctx->d_depth;
+    hipStream_t s_main = ctx->stream;
+    int f0 = 0, j = 0;
+    while (f0 < B && rc == SVO_OK) {
+      const int b = std::min(B - f0, j == 0 ? 16 : (j == 1 ? 32 : SUBMAX));
+      while ((int)ctx->ev_sub.size() <= j) {
+        hipEvent_t e;
+        SVO_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->ev_sub.push_back(e);
+      }
+      // the maps of this sub-batch reuse the buffer of the previous one: same stream, in order.  (The produced flags go through
+      // a pinned pair of slots: the previous sub-batch's copy has been waited for inside svo_elas_batch_dev's final synchronise.)
+      int32_t* h_prod = ctx->h_prod + (j & 1) * SUBMAX;
+      ctx->stream = ctx->stream_dense;
+      ctx->d_kp = own_kp + f0 * K; ctx->d_desc = own_desc + f0 * K * 32; ctx->d_nkp = own_nkp + f0;
+      ctx->d_uR = own_uR + f0 * K; ctx->d_depth = own_depth + f0 * K;
+      rc = svo_launch_orb(ctx, d_grayL + f0 * img, d_grayR + f0 * img, stride, b, b);   // left images only
+      if (rc == SVO_OK) rc = svo_elas_batch_dev(ctx, d_grayL + f0 * img, d_grayR + f0 * img, stride, ctx->g.W, ctx->g.H, b, &ep, dD1, dD2, h_prod);
+      if (rc == SVO_OK) {
+        if (hipMemcpyAsync(d_prod, h_prod, sizeof(int32_t) * (size_t)b, hipMemcpyHostToDevice, ctx->stream_dense) != hipSuccess) rc = SVO_E_HIP;
+        hipLaunchKernelGGL(k_tk_dense_depth, dim3((ctx->max_kp + 255) / 256, b), dim3(256), 0, ctx->stream_dense, ctx->d_kp, ctx->d_nkp,
+                           dD1, ctx->g.W, ctx->cam.bf, ctx->d_uR, ctx->d_depth, ctx->max_kp, n, d_prod);
+        if (hipEventRecord(ctx->ev_sub[j], ctx->stream_dense) != hipSuccess) rc = SVO_E_HIP;
+      }
+      ctx->stream = s_main;
+      ctx->d_kp = own_kp; ctx->d_desc = own_desc; ctx->d_nkp = own_nkp; ctx->d_uR = own_uR; ctx->d_depth = own_depth;
+      if (rc) break;
+      const int p = ctx->tb_parity;
+      std::vector<hipEvent_t> wait(b, nullptr);
+      wait[0] = ctx->ev_sub[j];
+      svo_boxes_dev bj{nullptr, nullptr, 0};
+      if (boxes && boxes->boxes && boxes->n) bj = svo_boxes_dev{boxes->boxes + (size_t)f0 * boxes->stride * 4, boxes->n + f0, boxes->stride};
+      rc = tail_enqueue(ctx, own_kp + f0 * K, own_desc + f0 * K * 32, own_nkp + f0, own_depth + f0 * K, ctx->max_kp, b, 1, d_results + f0,
+                        bj.boxes ? &bj : nullptr, wait.data(), nullptr, p, ctx->tb_used[p] ? ctx->tb_done[p] : ctx->ev_frontend, true);
+      if (rc) break;
+      SVO_HIP(ctx, hipEventRecord(ctx->tb_done[p], ctx->stream));   // the pose chain is the last reader of this half of the records
+      ctx->tb_used[p] = true;
+      ctx->tb_parity ^= 1;
+      ctx->track_frame += b;
+      f0 += b; ++j;
+    }
+    return rc;
   } else if (ctx->opt_depth_source == 2) {
     // MSA maps, up to eight frames in flight (most of a solve is the host tree builds)
     const size_t n = (size_t)ctx->g.W * ctx->g.H;

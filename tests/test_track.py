@@ -381,6 +381,7 @@ def test_tracking_is_independent_of_how_the_sequence_is_batched(pkg):
         for off in range(0, N, chunk):
             s.track_batch_dev(dL.data_ptr() + off * fb, dR.data_ptr() + off * fb, pitch, chunk, res.data_ptr() + off * rec)
         s.sync()
+        assert s.track_overflowed() == 0, ("capacity / lost hand-over flag", opts)
         out = res.cpu().numpy().tobytes()
         s.close()
         return out

@@ -1509,8 +1509,20 @@ int svo_elas_run_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int pit
   return elas_core(ctx, st, dL, dR, pitch, W, H, *params, nullptr, dD1, dD2, produced);
 }
 
+// svo_elas_batch_dev with a hook: hook(user, f0, b) runs on the calling thread right after the last GPU phase of the pairs
+// f0 .. f0 + b - 1 has been ENQUEUED on the ctx stream (their `produced` flags are final) - the batched tracker hangs the
+// per-keypoint depth lookups and the ordered tail of those frames on it, so that they run while later chunks are still in the
+// dense stage (BASELINE configs[4] as a pipeline).
+int svo_elas_batch_dev_hooked(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d_R, int stride, int W, int H,
+                              int B, const svo_elas_params* params, float* d_D1, float* d_D2, int32_t* produced,
+                              int (*hook)(void*, int, int), void* user);
 extern "C" int svo_elas_batch_dev(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d_R, int stride, int W, int H,
                                   int B, const svo_elas_params* params, float* d_D1, float* d_D2, int32_t* produced) {
+  return svo_elas_batch_dev_hooked(ctx, d_L, d_R, stride, W, H, B, params, d_D1, d_D2, produced, nullptr, nullptr);
+}
+int svo_elas_batch_dev_hooked(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d_R, int stride, int W, int H,
+                              int B, const svo_elas_params* params, float* d_D1, float* d_D2, int32_t* produced,
+                              int (*hook)(void*, int, int), void* user) {
   if (!ctx) return SVO_E_INVALID;
   if (!d_L || !d_R || !d_D1 || !d_D2 || !params || B < 1) { ctx->last_error = "svo_elas_batch_dev: invalid argument"; return SVO_E_INVALID; }
   const svo_elas_params p = *params;
@@ -1696,6 +1708,7 @@ extern "C" int svo_elas_batch_dev(svo_ctx* ctx, const uint8_t* d_L, const uint8_
     host_stage(c);
     auto t3 = tnow();
     rc = enqueue_b(c);
+    if (rc == SVO_OK && hook) rc = hook(user, c * C, std::min(C, B - c * C));
     t_enq += ms(t0, t1) + ms(t3, tnow()); t_wait += ms(t1, t2); t_host += ms(t2, t3);
   }
   const auto t_loop = tnow();

@@ -67,6 +67,7 @@ struct Lds {
   double sw[3][6];          // per small problem: singular values, descending
   double bx[3][6];          // per candidate: solution of the beta initialisation
   double ccs[3][12], pcs[3][16], abt[3][9], Rc[3][9], rep[3][8];
+  alignas(16) double gn[3][6][6];    // gauss_newton: the rows of A (4) and b of a candidate, built one per lane
   double out[3][16];        // per candidate: R (9), t (3), mean reprojection error
   int srow[3][6];           // per small problem: Jacobi row (index into jr rows) at sorted position p
   int urow[4];              // 12 x 12: row of the (11 - q)-th singular value
@@ -380,21 +381,33 @@ EO_FN void svd12_smallest(Lds& S, int lane) {
 }
 
 // ---- epnp::gauss_newton + qr_solve for one candidate, scalar code (arrays in registers) ---------------------------------
-EO_FN void gauss_newton(const double* L, const double* rho, double* betas) {
+// `cand`: this lane's candidate (its DPP row), `col`: lane within the row.  The six rows of A and b are built by six lanes of the
+// row (compute_A_and_b_gauss_newton is elementwise in the row index), handed round through S.gn, and every lane then walks
+// qr_solve on its own copy.
+EO_FN void gauss_newton(Lds& S, int cand, int col, bool owner, const double* L, const double* rho, double* betas) {
   for (int it = 0; it < 5; ++it) {
     double A[6][4], b[6];
+    {
+      const int i = col < 6 ? col : 0;
+      const double* rl = L + 10 * i;
+      double* g = S.gn[cand][i];
+      const double a0 = 2 * rl[0] * betas[0] + rl[1] * betas[1] + rl[3] * betas[2] + rl[6] * betas[3];
+      const double a1 = rl[1] * betas[0] + 2 * rl[2] * betas[1] + rl[4] * betas[2] + rl[7] * betas[3];
+      const double a2 = rl[3] * betas[0] + rl[4] * betas[1] + 2 * rl[5] * betas[2] + rl[8] * betas[3];
+      const double a3 = rl[6] * betas[0] + rl[7] * betas[1] + rl[8] * betas[2] + 2 * rl[9] * betas[3];
+      const double bi = rho[i] - (rl[0] * betas[0] * betas[0] + rl[1] * betas[0] * betas[1] + rl[2] * betas[1] * betas[1] +
+                                  rl[3] * betas[0] * betas[2] + rl[4] * betas[1] * betas[2] + rl[5] * betas[2] * betas[2] +
+                                  rl[6] * betas[0] * betas[3] + rl[7] * betas[1] * betas[3] + rl[8] * betas[2] * betas[3] +
+                                  rl[9] * betas[3] * betas[3]);
+      if (owner && col < 6) { g[0] = a0; g[1] = a1; g[2] = a2; g[3] = a3; g[4] = bi; }   // (the idle fourth DPP row shadows candidate 1: it must not write)
+    }
+    EO_SYNC();
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      const double* rl = L + 10 * i;
-      A[i][0] = 2 * rl[0] * betas[0] + rl[1] * betas[1] + rl[3] * betas[2] + rl[6] * betas[3];
-      A[i][1] = rl[1] * betas[0] + 2 * rl[2] * betas[1] + rl[4] * betas[2] + rl[7] * betas[3];
-      A[i][2] = rl[3] * betas[0] + rl[4] * betas[1] + 2 * rl[5] * betas[2] + rl[8] * betas[3];
-      A[i][3] = rl[6] * betas[0] + rl[7] * betas[1] + rl[8] * betas[2] + 2 * rl[9] * betas[3];
-      b[i] = rho[i] - (rl[0] * betas[0] * betas[0] + rl[1] * betas[0] * betas[1] + rl[2] * betas[1] * betas[1] +
-                       rl[3] * betas[0] * betas[2] + rl[4] * betas[1] * betas[2] + rl[5] * betas[2] * betas[2] +
-                       rl[6] * betas[0] * betas[3] + rl[7] * betas[1] * betas[3] + rl[8] * betas[2] * betas[3] +
-                       rl[9] * betas[3] * betas[3]);
+      const double* g = S.gn[cand][i];
+      A[i][0] = g[0]; A[i][1] = g[1]; A[i][2] = g[2]; A[i][3] = g[3]; b[i] = g[4];
     }
+    EO_SYNC();
     // epnp::qr_solve, literally (its `eta` scan looks at the diagonal element twice and never at the last row); the early
     // `return` on eta == 0 (x stays 0) becomes the `alive` predicate
     double A1[4], A2[4], x[4] = {0, 0, 0, 0};
@@ -634,7 +647,7 @@ EO_FN bool solve5_wave(Lds& S, epnp_exact::Work& xw, const double* K, double* R_
   {
     double rho[6];
     for (int k = 0; k < 6; ++k) rho[k] = S.rho[k];
-    gauss_newton(S.L, rho, betas);
+    gauss_newton(S, cand, col, slot < 3, S.L, rho, betas);
   }
   if (lane == 0) S.stamp[5] = clock64();
   // ---- compute_R_and_t: compute_ccs, compute_pcs, solve_for_sign, estimate_R_and_t, reprojection_error ---------------------

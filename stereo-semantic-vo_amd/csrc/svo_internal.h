@@ -120,7 +120,8 @@ struct svo_ctx {
   hipStream_t stream_fe = nullptr;         // the front end of the next step / chunk beside the tail (multi-sequence steps, MSA chunks)
   hipStream_t stream_fe_batch = nullptr;   // svo_track_batch_dev: the front end's sub-batches, confined to a share of the CUs
   hipStream_t stream_dense = nullptr;      // svo_track_batch_dev with depth_source 1: the dense front end's sub-batches
-  int32_t* h_prod = nullptr;               //   pinned: `produced` flags of two sub-batches in flight
+  int32_t* h_prod = nullptr;               //   pinned: the call's `produced` flags
+  int h_prod_cap = 0;
   std::vector<hipEvent_t> ev_sub;          // front end of sub-batch j finished (recorded on `stream_fe`)
   hipEvent_t ev_frontend = nullptr;        // front end of a call finished (recorded on `stream`)
   std::vector<hipEvent_t> ev_frame;        // index chain of frame f finished (recorded on `stream_idx`)
@@ -206,7 +207,10 @@ __host__ __device__ inline T* svo_byte_offset(T* p, size_t bytes) {
 // Streams by role: +1 the ordered tail's chains (small dependent kernels whose workgroups must not queue behind the front end's
 // thousands), -1 the batched front end running beside it, 0 everything else.  Maps onto the device's stream-priority range.
 hipError_t svo_stream_create(hipStream_t* st, int role);
-int svo_track_quiesce(svo_ctx* ctx);   // wait for the tails svo_track_batch_dev left in flight (svo_api.hip)
+int svo_track_quiesce(svo_ctx* ctx);
+int svo_elas_batch_dev_hooked(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d_R, int stride, int W, int H, int B,
+                              const svo_elas_params* params, float* d_D1, float* d_D2, int32_t* produced,
+                              int (*hook)(void*, int, int), void* user);   // svo_elas.hip   // wait for the tails svo_track_batch_dev left in flight (svo_api.hip)
 hipError_t svo_stream_create_masked(hipStream_t* st, int device, int percent);
 int svo_frontend_nslices(const svo_ctx* ctx, int B);   // how svo_frontend_batch_dev slices a batch (svo_api.hip)
 int svo_launch_disp2depth(svo_ctx* ctx, const float* disp, int count, float bf, float* depth);

@@ -1620,20 +1620,23 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
   int rc;
   if (ctx->opt_depth_source == 1) {
     // BASELINE configs[4] as a pipeline: the dense front end (ORB on the left images, ELAS maps, the reference's per-keypoint
-    // lookups - src/Tracking.cc:225-228, src/frame.cc:122-164) works through the call in sub-batches on a stream of its own,
-    // and the ordered tail of sub-batch j runs on the tail's streams while sub-batch j + 1 is in the dense stage (whose host
-    // phases - support-point filter, Delaunay - block this thread, not the GPU).  The first sub-batches are small, so that the
-    // tail starts early; every sub-batch uses its own half of the work records, like consecutive calls of the sparse path.
-    const size_t n = (size_t)ctx->g.W * ctx->g.H, K = ctx->max_kp, img = (size_t)ctx->g.H * stride;
-    const int SUBMAX = 64;
-    if ((rc = dense_reserve(ctx, std::min(B, SUBMAX)))) return rc;
-    if ((rc = track_resources(ctx, std::min(B, SUBMAX), 1))) return rc;
+    // lookups - src/Tracking.cc:225-228, src/frame.cc:122-164) runs on a stream of its own; svo_elas_batch_dev moves the call's
+    // pairs through its GPU -> host -> GPU stages in chunks, and as soon as a chunk's last GPU phase is enqueued the hook
+    // below hangs that chunk's depth lookups behind it and enqueues the ordered tail of its frames on the tail's streams - the
+    // tail of chunk c runs while chunks c + 1 ... are still in the dense stage (whose host phases - support-point filter,
+    // Delaunay - block this thread, not the GPU).  Every chunk uses its own half of the work records, like consecutive calls
+    // of the sparse path.
+    const size_t n = (size_t)ctx->g.W * ctx->g.H, K = ctx->max_kp;
+    if ((rc = dense_reserve(ctx, B))) return rc;
+    if ((rc = track_resources(ctx, B, 1))) return rc;
     if (!ctx->stream_dense) SVO_HIP(ctx, svo_stream_create(&ctx->stream_dense, 0));
     float* dD1 = ctx->d_dense;
     float* dD2 = dD1 + n * (size_t)ctx->dense_cap;
     int32_t* d_prod = reinterpret_cast<int32_t*>(dD2 + n * (size_t)ctx->dense_cap);
-    if (!ctx->h_prod) {
-      if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_prod), sizeof(int32_t) * 2 * SUBMAX) != hipSuccess) { (void)hipGetLastError(); return SVO_E_NOMEM; }
+    if (ctx->h_prod_cap < B) {
+      if (ctx->h_prod) { SVO_HIP(ctx, hipStreamSynchronize(ctx->stream_dense)); hipHostFree(ctx->h_prod); ctx->h_prod = nullptr; ctx->h_prod_cap = 0; }
+      if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_prod), sizeof(int32_t) * (size_t)B) != hipSuccess) { (void)hipGetLastError(); return SVO_E_NOMEM; }
+      ctx->h_prod_cap = B;
     }
     svo_elas_params ep;
     svo_elas_default_params(0, &ep);
@@ -1642,48 +1645,46 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
     // the dense stage writes the ctx's own result arrays and maps: everything the ctx stream holds (an earlier call's tail) first
     SVO_HIP(ctx, hipEventRecord(ctx->ev_frontend, ctx->stream));
     SVO_HIP(ctx, hipStreamWaitEvent(ctx->stream_dense, ctx->ev_frontend, 0));
-    svo_kp* const own_kp = ctx->d_kp; uint8_t* const own_desc = ctx->d_desc; int32_t* const own_nkp = ctx->d_nkp;
-    float* const own_uR = ctx->d_uR; float* const own_depth = ctx->d_depth;
-    hipStream_t s_main = ctx->stream;
-    int f0 = 0, j = 0;
-    while (f0 < B && rc == SVO_OK) {
-      const int b = std::min(B - f0, j == 0 ? 16 : (j == 1 ? 32 : SUBMAX));
-      while ((int)ctx->ev_sub.size() <= j) {
-        hipEvent_t e;
-        SVO_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        ctx->ev_sub.push_back(e);
+    struct Hook {
+      svo_ctx* ctx; hipStream_t s_main; const svo_boxes_dev* boxes; svo_track_result* d_results; float* dD1; int32_t* d_prod;
+      size_t n, K; int chunk;
+      static int run(void* u, int f0, int b) {
+        Hook& h = *static_cast<Hook*>(u);
+        svo_ctx* ctx = h.ctx;
+        hipStream_t sd = ctx->stream_dense;
+        while ((int)ctx->ev_sub.size() <= h.chunk) {
+          hipEvent_t e;
+          if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return SVO_E_HIP;
+          ctx->ev_sub.push_back(e);
+        }
+        if (hipMemcpyAsync(h.d_prod + f0, ctx->h_prod + f0, sizeof(int32_t) * (size_t)b, hipMemcpyHostToDevice, sd) != hipSuccess) return SVO_E_HIP;
+        hipLaunchKernelGGL(k_tk_dense_depth, dim3((ctx->max_kp + 255) / 256, b), dim3(256), 0, sd, ctx->d_kp + f0 * h.K, ctx->d_nkp + f0,
+                           h.dD1 + h.n * f0, ctx->g.W, ctx->cam.bf, ctx->d_uR + f0 * h.K, ctx->d_depth + f0 * h.K, ctx->max_kp, h.n, h.d_prod + f0);
+        if (hipEventRecord(ctx->ev_sub[h.chunk], sd) != hipSuccess) return SVO_E_HIP;
+        const int p = ctx->tb_parity;
+        std::vector<hipEvent_t> wait(b, nullptr);
+        wait[0] = ctx->ev_sub[h.chunk];
+        svo_boxes_dev bj{nullptr, nullptr, 0};
+        if (h.boxes && h.boxes->boxes && h.boxes->n) bj = svo_boxes_dev{h.boxes->boxes + (size_t)f0 * h.boxes->stride * 4, h.boxes->n + f0, h.boxes->stride};
+        ctx->stream = h.s_main;          // (the dense stage runs with the ctx stream swapped for its own)
+        int rc = tail_enqueue(ctx, ctx->d_kp + f0 * h.K, ctx->d_desc + f0 * h.K * 32, ctx->d_nkp + f0, ctx->d_depth + f0 * h.K, ctx->max_kp, b, 1,
+                              h.d_results + f0, bj.boxes ? &bj : nullptr, wait.data(), nullptr, p,
+                              ctx->tb_used[p] ? ctx->tb_done[p] : ctx->ev_frontend, true);
+        if (rc == SVO_OK && hipEventRecord(ctx->tb_done[p], ctx->stream) != hipSuccess) rc = SVO_E_HIP;   // the pose chain is the last reader of this half
+        ctx->stream = sd;
+        if (rc) return rc;
+        ctx->tb_used[p] = true;
+        ctx->tb_parity ^= 1;
+        ctx->track_frame += b;
+        ++h.chunk;
+        return SVO_OK;
       }
-      // the maps of this sub-batch reuse the buffer of the previous one: same stream, in order.  (The produced flags go through
-      // a pinned pair of slots: the previous sub-batch's copy has been waited for inside svo_elas_batch_dev's final synchronise.)
-      int32_t* h_prod = ctx->h_prod + (j & 1) * SUBMAX;
-      ctx->stream = ctx->stream_dense;
-      ctx->d_kp = own_kp + f0 * K; ctx->d_desc = own_desc + f0 * K * 32; ctx->d_nkp = own_nkp + f0;
-      ctx->d_uR = own_uR + f0 * K; ctx->d_depth = own_depth + f0 * K;
-      rc = svo_launch_orb(ctx, d_grayL + f0 * img, d_grayR + f0 * img, stride, b, b);   // left images only
-      if (rc == SVO_OK) rc = svo_elas_batch_dev(ctx, d_grayL + f0 * img, d_grayR + f0 * img, stride, ctx->g.W, ctx->g.H, b, &ep, dD1, dD2, h_prod);
-      if (rc == SVO_OK) {
-        if (hipMemcpyAsync(d_prod, h_prod, sizeof(int32_t) * (size_t)b, hipMemcpyHostToDevice, ctx->stream_dense) != hipSuccess) rc = SVO_E_HIP;
-        hipLaunchKernelGGL(k_tk_dense_depth, dim3((ctx->max_kp + 255) / 256, b), dim3(256), 0, ctx->stream_dense, ctx->d_kp, ctx->d_nkp,
-                           dD1, ctx->g.W, ctx->cam.bf, ctx->d_uR, ctx->d_depth, ctx->max_kp, n, d_prod);
-        if (hipEventRecord(ctx->ev_sub[j], ctx->stream_dense) != hipSuccess) rc = SVO_E_HIP;
-      }
-      ctx->stream = s_main;
-      ctx->d_kp = own_kp; ctx->d_desc = own_desc; ctx->d_nkp = own_nkp; ctx->d_uR = own_uR; ctx->d_depth = own_depth;
-      if (rc) break;
-      const int p = ctx->tb_parity;
-      std::vector<hipEvent_t> wait(b, nullptr);
-      wait[0] = ctx->ev_sub[j];
-      svo_boxes_dev bj{nullptr, nullptr, 0};
-      if (boxes && boxes->boxes && boxes->n) bj = svo_boxes_dev{boxes->boxes + (size_t)f0 * boxes->stride * 4, boxes->n + f0, boxes->stride};
-      rc = tail_enqueue(ctx, own_kp + f0 * K, own_desc + f0 * K * 32, own_nkp + f0, own_depth + f0 * K, ctx->max_kp, b, 1, d_results + f0,
-                        bj.boxes ? &bj : nullptr, wait.data(), nullptr, p, ctx->tb_used[p] ? ctx->tb_done[p] : ctx->ev_frontend, true);
-      if (rc) break;
-      SVO_HIP(ctx, hipEventRecord(ctx->tb_done[p], ctx->stream));   // the pose chain is the last reader of this half of the records
-      ctx->tb_used[p] = true;
-      ctx->tb_parity ^= 1;
-      ctx->track_frame += b;
-      f0 += b; ++j;
-    }
+    } hook{ctx, ctx->stream, boxes, d_results, dD1, d_prod, n, K, 0};
+    ctx->stream = ctx->stream_dense;
+    rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, B, B);   // left images only
+    if (rc == SVO_OK)
+      rc = svo_elas_batch_dev_hooked(ctx, d_grayL, d_grayR, stride, ctx->g.W, ctx->g.H, B, &ep, dD1, dD2, ctx->h_prod, &Hook::run, &hook);
+    ctx->stream = hook.s_main;
     return rc;
   } else if (ctx->opt_depth_source == 2) {
     // MSA maps, up to eight frames in flight (most of a solve is the host tree builds)

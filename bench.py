@@ -128,7 +128,9 @@ def pmc_valu(kernel):
     try:
         cycles = d["GRBM_GUI_ACTIVE"] / 8.0
         return {"instr_per_wave": d["SQ_INSTS_VALU"] / d["SQ_WAVES"],
-                "inst_per_cycle_per_wave": (d["SQ_INSTS_VALU"] + d.get("SQ_INSTS_SALU", 0.0) + d.get("SQ_INSTS_LDS", 0.0)) / d["SQ_WAVES"] / cycles,
+                # SQ_WAVE_CYCLES counts quad-cycles a wave is resident: its issue opportunities (one instruction per quad-cycle at most)
+                "inst_per_quad_cycle_per_wave": (d["SQ_INSTS_VALU"] + d.get("SQ_INSTS_SALU", 0.0) + d.get("SQ_INSTS_LDS", 0.0)) / d["SQ_WAVE_CYCLES"],
+                "instr_all_per_wave": (d["SQ_INSTS_VALU"] + d.get("SQ_INSTS_SALU", 0.0) + d.get("SQ_INSTS_LDS", 0.0)) / d["SQ_WAVES"],
                 "busy_frac": d["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cycles),
                 "lds_bank_conflict_frac": d["SQ_LDS_BANK_CONFLICT"] / max(d["SQ_LDS_IDX_ACTIVE"], 1.0),
                 "source": "profiles/pmc_latest.json"}
@@ -1059,9 +1061,14 @@ def main():
                     "bound": "float64 instruction issue of ONE wavefront per RANSAC sample (quad-cycle cadence: <= 0.25 instructions per "
                              "cycle per wave): the solve is a dependent chain - 148 Jacobi steps of ~150 instructions (division and "
                              "square root sequences of the rotation: 46 of them) + 5 Gauss-Newton steps per candidate",
-                    "issue_model": {"peak_inst_per_cycle_per_wave": 0.25, "clock_ghz": 2.4,
-                                    "achieved_inst_per_cycle_per_wave": (v or {}).get("inst_per_cycle_per_wave"),
-                                    "source": "profiles/pmc_latest.json (SQ_INSTS_VALU + SALU + LDS over SQ_WAVE_CYCLES of the kernel)" if v else "no counters committed for this kernel"},
+                    "issue_model": {"peak_inst_per_quad_cycle_per_wave": 1.0,
+                                    "achieved_inst_per_quad_cycle_per_wave": (v or {}).get("inst_per_quad_cycle_per_wave"),
+                                    "instructions_per_wave": (v or {}).get("instr_all_per_wave"),
+                                    "note": "the rest of the issue slots are dependency stalls of the float64 chain (a dependent v_fma_f64 "
+                                            "issues every second quad-cycle, v_rcp / v_rsq_f64 every fourth, a 4x4x4 DMFMA occupies five), "
+                                            "LDS round trips of the row exchange and hazard wait states",
+                                    "source": "profiles/pmc_latest.json: (SQ_INSTS_VALU + SQ_INSTS_SALU + SQ_INSTS_LDS) / SQ_WAVE_CYCLES of the "
+                                              "kernel, rocprofv3 --pmc passes of profiles/r04_a_track_*" if v else "no counters committed for this kernel"},
                     "hbm_frac_of_this_kernel": (tail_kernel_bytes(hyp_name, 0, 0, float(res["n_lm_edges"][1:].mean()), 0) / (hyp_us * 1e-6) / 1e9 / HBM_PEAK_GBS),
                 }
         if world == 1 and not args.no_cpu_baseline:

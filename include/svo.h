@@ -167,10 +167,18 @@ void svo_destroy(svo_ctx* ctx);
  * frames - the pose chain then never stands still because a LATER frame of its group is slow to match (+0.6 % on the
  * headline run).  Same records.  Off by default because the poll relies on the index kernel running concurrently with the
  * polling kernel: under a tool that serialises dispatches (rocprofv3 --kernel-trace) every poll runs into its time-out.
- * "epnp_exact" (default 0): 1 makes every RANSAC sample's EPnP follow OpenCV's own loops one after the other (cyclic
- * one-sided Jacobi SVDs, SVD / QR least squares, IEEE division and square root, no FMA contraction), one lane per
- * sample - the arithmetic of the CPU restatement the tests compare with, an order of magnitude slower than the
- * wave-parallel solver of the default mode.  A parity switch: the fast mode is validated against it. */
+ * "epnp_exact" (default 2): which EPnP solves the RANSAC samples of cv::solvePnPRansac (src/pnpmatch.cc:227).
+ *   2 = order-preserving wave solver (csrc/svo_epnp_ord_dev.h): every IEEE operation of OpenCV 3.2's loops (epnp.cpp,
+ *       JacobiSVDImpl_ / SVBkSbImpl_ of lapack.cpp: cyclic one-sided Jacobi SVDs, SVD / QR least squares, IEEE division and
+ *       square root, no FMA contraction, every sum in its own k order) is kept; independent operations are spread over one
+ *       wavefront per sample (Jacobi pairs on disjoint rows side by side, k-ordered sums on v_mfma_f64_4x4x4).  Bit-identical,
+ *       sample by sample, to the CPU restatement the tests compare with; the rare branches it does not reproduce (a zero or
+ *       repeated singular value, 25 sweeps without convergence) are handed to the sequential solver of mode 1.
+ *   1 = the same operations, one lane per sample, loop by loop (csrc/svo_epnp_exact_dev.h): the checker of mode 2, 7.5x slower.
+ *   0 = statistical wave solver (csrc/svo_epnp_dev.h; the default up to round 3): parallel-order two-sided Jacobi, normal
+ *       equations, FMA - the same estimator with another rounding; 1.65x faster than mode 2, RANSAC's winner differs from a
+ *       CPU run on ~3 % of the frames.
+ * "epnp_force_seq" (default 0, tests): 1 = mode 2 takes its sequential fallback for every sample. */
 int svo_set_option(svo_ctx* ctx, const char* key, int value);
 /* Block until everything enqueued on the ctx stream has finished. */
 int svo_sync(svo_ctx* ctx);

@@ -230,6 +230,7 @@ extern "C" int svo_create(svo_ctx** out, int device, int W, int H, int max_kp, i
   ctx->stage_pitch = (W + 63) / 64 * 64;
   ctx->scratch_bytes = 16u << 20;
   ctx->pinned_bytes = 8u << 20;
+  ctx->opt_shard_force_staged = getenv("SVO_SHARD_FORCE_STAGED") != nullptr;
   int rc = SVO_OK;
 #define TRY(x) if (rc == SVO_OK) rc = (x)
   TRY(dalloc(ctx, &ctx->d_xofs, xofs.size()));
@@ -345,6 +346,7 @@ extern "C" int svo_set_option(svo_ctx* ctx, const char* key, int value) {
     return SVO_OK;
   }
   if (!strcmp(key, "epnp_force_seq")) { ctx->opt_epnp_force_seq = value != 0; return SVO_OK; }
+  if (!strcmp(key, "shard_force_staged")) { ctx->opt_shard_force_staged = value != 0; return SVO_OK; }
   if (!strcmp(key, "multi_pipeline")) { ctx->opt_multi_pipeline = value != 0; return SVO_OK; }
   if (!strcmp(key, "pyr_fused")) { ctx->opt_pyr_fused = value != 0; return SVO_OK; }
   if (!strcmp(key, "frontend_overlap")) {

@@ -1980,7 +1980,7 @@ extern "C" int svo_track_sharded_dev(svo_ctx* const* ctxs, int G, const uint8_t*
     direct[g] = can;
     need_stage = need_stage || !can;
   }
-  if (getenv("SVO_SHARD_FORCE_STAGED")) {   // test switch: take the bounce path even where a direct read exists
+  if (c0->opt_shard_force_staged) {   // test switch (SVO_SHARD_FORCE_STAGED at svo_create, or the option): the bounce path even where a direct read exists
     for (int g = 1; g < G; ++g) direct[g] = 0;
     need_stage = G > 1;
   }

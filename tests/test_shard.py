@@ -100,8 +100,12 @@ def test_bench_two_ranks_as_the_driver_launches_it():
     """python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...: both ranks on cuda:0 over gloo (the box
     has one GPU).  The line must be rank 0's, claim 2 GPUs, and carry the whole job's frames."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import socket
+    with socket.socket() as sk:                      # a free port: two suites on one box must not meet on a fixed one
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--frames", "48", "--dist-backend", "gloo", "--share-gpu", "--no-cpu-baseline"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]

@@ -83,7 +83,10 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL(k_probe, dim3(nt), dim3(64), 0, 0, dX, dU, dK, dO, force, (epnp_ord::Lds*)nullptr);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-  hipLaunchKernelGGL(k_probe, dim3(n), dim3(64), 0, 0, dX, dU, dK, dO, force, dD);
+  // the launch the timings are read from: 128 single-wave workgroups at a time, i.e. at most one per compute unit - as the
+  // tracker launches its 100 samples (a CU that hosts several of these waves shares its issue and float64 resources between them)
+  for (int s0 = 0; s0 < n; s0 += 128)
+    hipLaunchKernelGGL(k_probe, dim3(n - s0 < 128 ? n - s0 : 128), dim3(64), 0, 0, dX + 15 * (size_t)s0, dU + 10 * (size_t)s0, dK, dO + s0, force, dD);
   hipDeviceSynchronize();
   std::vector<ProbeOut> O(n);
   hipMemcpy(O.data(), dO, sizeof(ProbeOut) * n, hipMemcpyDeviceToHost);

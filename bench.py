@@ -571,6 +571,9 @@ def sharded_run(pkg, cam, dL, dR, n_frames, G, devices, rec, chunk=512, referenc
     return out
 
 
+SEM_ELAS_OPTIONS = {}
+
+
 def semantic_elas_leg(pkg, cam, dL, dR, dev, rec, n=256):
     """BASELINE configs[4] AS A WHOLE: offline detection boxes (semantic gating: creation gates, brute-force matches ->
     8-point F -> epipolar veto, all on the device) + dense ELAS depth (svo_elas_batch_dev -> disp2Depth -> per-keypoint
@@ -580,6 +583,8 @@ def semantic_elas_leg(pkg, cam, dL, dR, dev, rec, n=256):
     n = min(n, dL.shape[0])
     svo = pkg.Svo(W, H, device=dev.index or 0, max_kp=500, max_batch=n)
     svo.set_option("depth_source", 1)
+    for k, v in SEM_ELAS_OPTIONS.items():        # experiments (tools/sem_elas_try.py)
+        svo.set_option(k, v)
     bx, keep = boxes_hbm(pkg, n, dev)
     res = torch.zeros((n, rec), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()

@@ -162,6 +162,10 @@ void svo_destroy(svo_ctx* ctx);
  * tail's small dependent kernels then queue for slots (7 us per frame on average); the front end needs a tenth of the tail's
  * time on the whole chip, so one XCD keeps up (measured: 100 % 13.2 k, 25 % 14.1 k, 12 % 14.4 k frames/s).  Scheduling only -
  * same records.
+ * "dense_cu_percent" (default 75, 10..100): the same for the dense front end's stream of svo_track_batch_dev with
+ * depth_source = 1 (ORB + ELAS maps + depth lookups, in chunks, beside the tail of the earlier chunks): ELAS needs most of the chip,
+ * the tail's 100 single-wave RANSAC workgroups need free CUs (measured with boxes, 256 frames per call: 100 % 5.4 k, 75 % 6.4 k,
+ * 50 % 5.3 k frames/s).  Scheduling only - same records.
  * "pose_flag" (default 0): 1 = one sequence's pose kernels learn that their frame has been matched from a per-frame tag the
  * index chain publishes in HBM (agent-scope stores / polls, bounded) instead of waiting on one stream event per group of
  * frames - the pose chain then never stands still because a LATER frame of its group is slow to match (+0.6 % on the

@@ -339,6 +339,12 @@ extern "C" int svo_set_option(svo_ctx* ctx, const char* key, int value) {
     if (ctx->stream_fe_batch) { hipStreamSynchronize(ctx->stream_fe_batch); hipStreamDestroy(ctx->stream_fe_batch); ctx->stream_fe_batch = nullptr; }   // recreated on demand
     return SVO_OK;
   }
+  if (!strcmp(key, "dense_cu_percent")) {
+    if (value < 10 || value > 100) return SVO_E_INVALID;
+    ctx->opt_dense_cu_percent = value;
+    if (ctx->stream_dense) { hipStreamSynchronize(ctx->stream_dense); hipStreamDestroy(ctx->stream_dense); ctx->stream_dense = nullptr; }   // recreated on demand
+    return SVO_OK;
+  }
   if (!strcmp(key, "pose_flag")) { ctx->opt_pose_flag = value != 0; return SVO_OK; }
   if (!strcmp(key, "epnp_exact")) {
     if (value < 0 || value > 2) return SVO_E_INVALID;

@@ -1697,19 +1697,34 @@ int svo_elas_batch_dev_hooked(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d
     return std::chrono::duration<double, std::milli>(b - a).count(); };
   double t_wait = 0, t_host = 0, t_enq = 0;
   const auto t_start = tnow();
+  // The host stage of chunk c (the pool: filter, then the triangulations) runs on a driver thread of its own while THIS thread
+  // enqueues: phase B of chunk c - 1 (+ the caller's hook: the tracker's depth lookups and tail), then phase A of chunk c + 2 -
+  // the pool used to stand still during those 8-10 ms of a 256-pair call.  Only this thread makes HIP calls.
   rc = enqueue_a(0);
+  std::thread driver;
+  auto finish = [&](int c) -> int {   // chunk c has left the host stage: its phase B, and whatever the caller hangs on it
+    int r = enqueue_b(c);
+    if (r == SVO_OK && hook) r = hook(user, c * C, std::min(C, B - c * C));
+    return r;
+  };
   for (int c = 0; c < NC && rc == SVO_OK; ++c) {
     auto t0 = tnow();
     if (c + 1 < NC) rc = enqueue_a(c + 1);
-    if (rc) break;
     auto t1 = tnow();
-    hipEventSynchronize(evA[c]);
+    if (rc == SVO_OK) hipEventSynchronize(evA[c]);
     auto t2 = tnow();
-    host_stage(c);
+    if (driver.joinable()) driver.join();          // the pool is free again: chunk c - 1 is through
     auto t3 = tnow();
-    rc = enqueue_b(c);
-    if (rc == SVO_OK && hook) rc = hook(user, c * C, std::min(C, B - c * C));
+    if (rc == SVO_OK) driver = std::thread([&host_stage, c]() { host_stage(c); });
+    if (rc == SVO_OK && c > 0) rc = finish(c - 1);
     t_enq += ms(t0, t1) + ms(t3, tnow()); t_wait += ms(t1, t2); t_host += ms(t2, t3);
+  }
+  {
+    auto t2 = tnow();
+    if (driver.joinable()) driver.join();
+    auto t3 = tnow();
+    if (rc == SVO_OK) rc = finish(NC - 1);
+    t_host += ms(t2, t3); t_enq += ms(t3, tnow());
   }
   const auto t_loop = tnow();
   {

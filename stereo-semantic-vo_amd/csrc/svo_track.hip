@@ -1629,7 +1629,9 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
     const size_t n = (size_t)ctx->g.W * ctx->g.H, K = ctx->max_kp;
     if ((rc = dense_reserve(ctx, B))) return rc;
     if ((rc = track_resources(ctx, B, 1))) return rc;
-    if (!ctx->stream_dense) SVO_HIP(ctx, svo_stream_create(&ctx->stream_dense, 0));
+    if (!ctx->stream_dense)
+      SVO_HIP(ctx, ctx->opt_dense_cu_percent < 100 ? svo_stream_create_masked(&ctx->stream_dense, ctx->device, ctx->opt_dense_cu_percent)
+                                                   : svo_stream_create(&ctx->stream_dense, 0));
     float* dD1 = ctx->d_dense;
     float* dD2 = dD1 + n * (size_t)ctx->dense_cap;
     int32_t* d_prod = reinterpret_cast<int32_t*>(dD2 + n * (size_t)ctx->dense_cap);

@@ -242,29 +242,65 @@ def cpu_baseline(Lh, Rh, cam, workload, budget_s=15.0):
                       % (n, what, dt, host_cpus(), os.cpu_count() or 0)}
 
 
-class OracleTailRun(threading.Thread):
+ORACLE_TAIL_CHILD = r"""
+import sys, time
+import numpy as np
+root, inp, out = sys.argv[1:4]
+sys.path.insert(0, root)
+from oracle import binding as orc
+orc.build()
+d = np.load(inp)
+W, H = (int(v) for v in d["wh"])
+fx, fy, cx, cy, bf = (float(v) for v in d["cam"])
+kp, desc, n, depth = d["kp"], d["desc"], d["n"], d["depth"]
+t0 = time.perf_counter()
+trk = orc.Tracker(W, H, dict(fx=fx, fy=fy, cx=cx, cy=cy, bf=bf))
+recs = []
+for k in range(len(n)):
+    nk = int(n[k])
+    recs.append(trk.track_tail(kp[k, :nk], desc[k, :nk], depth[k, :nk])[0].copy())
+trk.close()
+np.savez(out, records=np.array(recs), seconds=time.perf_counter() - t0)
+"""
+
+
+class OracleTailRun:
     """The oracle's ordered tail (orc_track_tail) over ALL tracked frames, fed with the device front end's outputs (bit-exact
-    against the oracle's own front end by the parity tests), free-running on a host thread while the GPU legs run: every
-    counter of every frame against the device's records, and the ATE between the two whole trajectories."""
+    against the oracle's own front end by the parity tests), free-running in a CHILD PROCESS while the GPU legs run (one of
+    the host's cores; as a thread of this process it held the interpreter lock often enough to halve the host-bound legs):
+    every counter of every frame against the device's records, and the ATE between the two whole trajectories.  The child
+    only loads numpy and the oracle library - it never touches the GPU."""
 
     def __init__(self, cam, kp, desc, n, depth):
-        super().__init__(daemon=True)
-        self.cam, self.kp, self.desc, self.n, self.depth = cam, kp, desc, n, depth
-        self.records, self.seconds, self.error = [], 0.0, None
+        import tempfile
+        import numpy as np
+        self.records, self.seconds, self.error, self.proc = [], 0.0, None, None
+        self.dir = tempfile.mkdtemp(prefix="svo_oracle_tail_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        self.inp, self.out = os.path.join(self.dir, "in.npz"), os.path.join(self.dir, "out.npz")
+        np.savez(self.inp, kp=kp, desc=desc, n=n, depth=depth, wh=np.array([W, H]), cam=np.array([cam.fx, cam.fy, cam.cx, cam.cy, cam.bf]))
 
-    def run(self):
+    def start(self):
         try:
-            from oracle import binding as orc
-            orc.build()
-            t0 = time.perf_counter()
-            trk = orc.Tracker(W, H, dict(fx=self.cam.fx, fy=self.cam.fy, cx=self.cam.cx, cy=self.cam.cy, bf=self.cam.bf))
-            for k in range(len(self.n)):
-                nk = int(self.n[k])
-                self.records.append(trk.track_tail(self.kp[k, :nk], self.desc[k, :nk], self.depth[k, :nk])[0].copy())
-            trk.close()
-            self.seconds = time.perf_counter() - t0
+            self.proc = subprocess.Popen([sys.executable, "-c", ORACLE_TAIL_CHILD, ROOT, self.inp, self.out],
+                                         stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
         except Exception as e:  # noqa: BLE001
             self.error = repr(e)
+
+    def join(self):
+        import shutil
+        import numpy as np
+        try:
+            if self.proc is not None:
+                _, err = self.proc.communicate(timeout=1800)
+                if self.proc.returncode != 0:
+                    self.error = "oracle tail child failed: " + (err or "")[-500:]
+                else:
+                    d = np.load(self.out)
+                    self.records, self.seconds = list(d["records"]), float(d["seconds"])
+        except Exception as e:  # noqa: BLE001
+            self.error = repr(e)
+        finally:
+            shutil.rmtree(self.dir, ignore_errors=True)
 
     def report(self, res):
         import numpy as np
@@ -743,6 +779,52 @@ def spawn_ranks(args):
     sys.exit(p.returncode)
 
 
+TAIL_LEGS = {"pnp_solver_modes": 1280, "sharded": 1024, "multi_sequence": 128, "semantic_elas": 256}   # leg -> frames it renders
+
+
+def tail_leg_child(args, pkg, synth, cam, dev, local):
+    """ONE of the legs whose figure depends on the tracker's index chain and pose chain running side by side (solver modes,
+    sharded, many sequences, configs[4]), in a process of its own, the way a deployment runs it.  Which hardware queues a
+    context's streams are mapped onto depends on the contexts the process had before: the runtime keeps a pool of queues per
+    priority and hands the least-used one to a new stream, and two queues can share a pipe of the command processor, where
+    the pose chain's packets then wait behind the index chain's.  Measured with AMD_LOG_LEVEL=3 (tools/multi_try2.py): the
+    many-sequence leg 95 k frames/s in a fresh process, 80 k / 56 k after a sharded run had left a third high-priority queue
+    in the pool and the leg's context picked that one; the sharded leg 8.1 k first, 5.0 k after the many-sequence leg.
+    Prints one JSON object {leg: result}."""
+    import torch
+    name = args.tail_leg_child
+    N = TAIL_LEGS[name]
+    dL, dR, _ = render_frames(synth, N, dev, synth.BASE_SEED)
+    rec = pkg.TRACK_DTYPE.itemsize
+    fb = H * PITCH
+    refn = None
+    if name in ("sharded", "multi_sequence"):           # the single context's records these two must reproduce
+        nr = 1024 if name == "sharded" else 48
+        ref = torch.zeros((nr, rec), dtype=torch.uint8, device=dev)
+        s = pkg.Svo(W, H, device=local, max_kp=500, max_batch=256)
+        s.track_reset(cam)
+        for c0 in range(0, nr, 256):
+            s.track_batch_dev(dL.data_ptr() + c0 * fb, dR.data_ptr() + c0 * fb, PITCH, min(256, nr - c0), ref.data_ptr() + c0 * rec)
+        s.sync(); s.close()
+        refn = ref.cpu().numpy()
+    progress("leg %s (child process)" % name)
+    try:
+        if name == "pnp_solver_modes":
+            r = solver_modes_leg(pkg, cam, dL, dR, fb, rec, dev, N)
+        elif name == "sharded":
+            r = sharded_run(pkg, cam, dL, dR, 1024, 2, [local, local], rec, reference=refn)
+            r["note"] = ("two contexts on this ONE GPU: no cross-device run was measured here (the driver's multi-GPU run, "
+                         "when it has a node, adds it); " + r["note"])
+        elif name == "multi_sequence":
+            r = multi_sequence_leg(pkg, cam, dL, dR, fb, rec, dev, refn.view(pkg.TRACK_DTYPE).reshape(-1))
+        else:
+            r = semantic_elas_leg(pkg, cam, dL, dR, dev, rec)
+    except Exception as e:  # noqa: BLE001
+        r = {"error": repr(e)}
+    print(json.dumps({name: r}))
+    sys.stdout.flush()
+
+
 def progress(msg):
     """One line per stage on stderr (the JSON line is stdout's): a run that stops answering shows where."""
     sys.stderr.write("[bench %.1f s] %s\n" % (time.perf_counter() - T_START, msg))
@@ -763,6 +845,8 @@ def main():
     ap.add_argument("--no-legs", action="store_true", help="only the main workload (no frontend / multi_sequence / sharded / semantic_elas / elas / msa legs)")
     ap.add_argument("--no-elas-leg", action="store_true", help="skip the semantic_elas, elas and msa legs")
     ap.add_argument("--no-track-leg", action="store_true", help="(kept for scripts) same as --no-legs for the frontend workload")
+    ap.add_argument("--tail-leg-child", default=None, choices=sorted(TAIL_LEGS),
+                    help="run ONE of the legs that depend on the tracker's two overlapping chains in this (fresh) process and print it")
     ap.add_argument("--no-shard-leg", action="store_true", help="N > 1: skip rank 0's svo_track_sharded_dev run across the N GPUs")
     ap.add_argument("--shard", action="store_true",
                     help="track workload: ONE sequence over --gpus G contexts in ONE process (svo_track_sharded_dev, BASELINE configs[3])")
@@ -806,6 +890,9 @@ def main():
         dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     cam = pkg.Camera(**pkg.KITTI_00_02)
+    if args.tail_leg_child:
+        tail_leg_child(args, pkg, synth, cam, dev, local)
+        return
     track = args.workload == "track"
     multi = track and args.sequences > 1
     nsteps = args.warmup + args.steps
@@ -981,7 +1068,8 @@ def main():
                         "mean_active_rows_pass1_pass2": [float(res["reserved"][1:, 0].mean()), float(res["reserved"][1:, 1].mean())],
                         "mean_local_map": float(res["n_local_map"][1:].mean()),
                         "tracker_capacity_flag": int(svo.track_overflowed()),
-                        "pnp_solver": PNP_SOLVERS[int(os.environ.get("SVO_BENCH_EPNP", "2"))]})
+                        "pnp_solver": PNP_SOLVERS[int(os.environ.get("SVO_BENCH_EPNP", "2"))],
+                        "pnp_samples_through_sequential_fallback": int(svo.track_epnp_fallbacks())})
             if world == 1 and not multi and not args.no_cpu_baseline and args.depth_source == 0 and not args.boxes:
                 # the oracle's tail over ALL tracked frames, on a host thread while the legs below run
                 oracle_run = OracleTailRun(cam, *frontend_outputs(pkg, cam, dL, dR, len(res), dev))
@@ -1085,33 +1173,21 @@ def main():
         if legs:
             svo.close()                          # (its streams would share hardware queues with the legs' contexts)
             svo = None
-        # Order of the legs: the ones that run the ordered tail (two chains that must overlap on two hardware queues) come first.
-        # A tracker context created after the front-end / many-sequence legs lost that overlap in this process (measured: the
-        # statistical solver's leg 7.6 k frames/s behind them, 14.2 k in front of them; `sharded` 5.3 k -> 7.9 k) - their contexts
-        # keep up to a dozen streams (and ELAS its host thread pools) alive between them, and the runtime maps streams onto a
-        # limited set of hardware queues; the many-sequence leg measured 93 k frames/s in front of the ELAS legs, 57 k behind them.
+        # The legs that run the ordered tail (two chains that must overlap on two hardware queues) each run in a fresh process:
+        # see tail_leg_child.  Behind this process's earlier contexts they measured about half (the statistical solver's leg
+        # 7.6 k frames/s against 14.2 k, `sharded` 5.3 k against 8.1 k, many sequences 57 k against 95 k, configs[4] 4.6 k
+        # against 6.3 k).
         if legs and track:
-            try:
-                progress("leg pnp_solver_modes")
-                out["pnp_solver_modes"] = solver_modes_leg(pkg, cam, dL, dR, frame_bytes, rec, dev, n_frames)
-            except Exception as e:  # noqa: BLE001
-                out["pnp_solver_modes"] = {"error": repr(e)}
-            try:
-                ns = min(n_frames, 1024)
-                progress("leg sharded")
-                out["sharded"] = sharded_run(pkg, cam, dL, dR, ns, 2, [local, local], rec, reference=d_res[:ns].cpu().numpy())
-                out["sharded"]["note"] = ("two contexts on this ONE GPU: no cross-device run was measured here (the driver's multi-GPU run, "
-                                          "when it has a node, adds it); " + out["sharded"]["note"])
-            except Exception as e:  # noqa: BLE001
-                out["sharded"] = {"error": repr(e)}
-            progress("leg multi_sequence")
-            out["multi_sequence"] = multi_sequence_leg(pkg, cam, dL, dR, frame_bytes, rec, dev, res)
-            if not args.no_elas_leg:
+            for name in TAIL_LEGS:
+                if name == "semantic_elas" and args.no_elas_leg:
+                    continue
+                progress("leg %s: child process" % name)
                 try:
-                    progress("leg semantic_elas")
-                    out["semantic_elas"] = semantic_elas_leg(pkg, cam, dL, dR, dev, rec)
+                    cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--tail-leg-child", name],
+                                        stdout=subprocess.PIPE, timeout=600, check=True)
+                    out.update(json.loads(cp.stdout.decode().strip().splitlines()[-1]))
                 except Exception as e:  # noqa: BLE001
-                    out["semantic_elas"] = {"error": repr(e)}
+                    out[name] = {"error": repr(e)}
             progress("leg frontend")
             out["frontend"] = frontend_leg(pkg, cam, dL, dR, n_frames, frame_bytes, dev,
                                            None if args.no_cpu_baseline else cpu_baseline_all_cores)

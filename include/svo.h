@@ -385,6 +385,11 @@ int svo_track_sharded_dev(svo_ctx* const* ctxs, int G, const uint8_t* const* d_g
  * was about to be reused).  Neither can happen with the reference's 500 keypoints per frame on sequences of KITTI
  * length; results after the flag is set are not the reference's. */
 int svo_track_overflowed(svo_ctx* ctx, int32_t* flag);
+/* Diagnostics of the default RANSAC solver (svo_set_option "epnp_exact" = 2; cv::solvePnPRansac of src/pnpmatch.cc:227):
+ * how many samples since svo_track_reset took its sequential fallback (a zero or repeated singular value in one of EPnP's
+ * decompositions, or 25 Jacobi sweeps without convergence).  Results are the same either way; a frame with such a sample
+ * takes about ten times as long in the pose chain.  Synchronises. */
+int svo_track_epnp_fallbacks(svo_ctx* ctx, int64_t* count);
 
 /* Many independent sequences on one GPU ("G independent sequences" for pure
  * throughput; no counterpart in the reference, whose tracker is one static chain per process,

@@ -90,6 +90,7 @@ struct TrackState {
   // ---- index chain -------------------------------------------------------------------------
   int32_t frame_num, npool, lastN, cur;      // cur: active half of the pool ping-pong
   int32_t next_gid, overflow, n_vetoed, n_boxes;
+  int32_t epnp_fallbacks, pad_counters[3];   // RANSAC samples of the default solver that took its sequential fallback (sticky count)
   int32_t last_mp[TRK_MAXKP];
   int32_t dbg_cur_mp[TRK_MAXKP];
   svo_camera cam;
@@ -1043,6 +1044,7 @@ __global__ __launch_bounds__(64) void k_tp_hyp_ord(TrackState* st, TrackWork* wo
   const double K[4] = {(double)st->cam.fx, (double)st->cam.fy, (double)st->cam.cx, (double)st->cam.cy};
   const long long t_gather = clock64();
   pnp_hyp_ord_wave(S.ord, S.Xw, S.uv, n, K, subsets + (size_t)min(n, 512) * 500, st->hyp, sample, force_seq != 0);
+  if (threadIdx.x == 0 && S.ord.S.flag) atomicAdd(&st->epnp_fallbacks, 1);
   if (sample == 0 && threadIdx.x == 0) {
     const long long* sp = S.ord.S.stamp;
     st->pose_ts[0] = t_start; st->pose_ts[1] = t_gather; st->pose_ts[2] = sp[0]; st->pose_ts[3] = sp[7];
@@ -1809,6 +1811,22 @@ extern "C" int svo_track_overflowed(svo_ctx* ctx, int32_t* flag) {
     any |= v;
   }
   *flag = any;
+  return SVO_OK;
+}
+
+// How many RANSAC samples of the order-preserving EPnP (epnp_exact = 2) were handed to its sequential fallback since
+// svo_track_reset (a zero or repeated singular value, 25 Jacobi sweeps): same results, ~10x the time of the frame concerned.
+extern "C" int svo_track_epnp_fallbacks(svo_ctx* ctx, int64_t* count) {
+  if (!ctx || !count || !ctx->d_track) return SVO_E_INVALID;
+  TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
+  SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  int64_t total = 0;
+  for (int q = 0; q < ctx->n_seq; ++q) {
+    int32_t v = 0;
+    SVO_HIP(ctx, hipMemcpy(&v, &st[q].epnp_fallbacks, 4, hipMemcpyDeviceToHost));
+    total += v;
+  }
+  *count = total;
   return SVO_OK;
 }
 

@@ -83,6 +83,7 @@ def _device_tail(pkg, run, epnp_mode):
         tail.sync()
         dbg.append(tail.debug_track_frames(0, c))
     flag = tail.track_overflowed()
+    print("EPNP_FALLBACKS mode %d: %d samples" % (epnp_mode, tail.track_epnp_fallbacks()))
     tail.close()
     return res.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(-1), np.concatenate(dbg), flag
 

@@ -166,6 +166,14 @@ void svo_destroy(svo_ctx* ctx);
  * depth_source = 1 (ORB + ELAS maps + depth lookups, in chunks, beside the tail of the earlier chunks): ELAS needs most of the chip,
  * the tail's 100 single-wave RANSAC workgroups need free CUs (measured with boxes, 256 frames per call: 100 % 5.4 k, 75 % 6.4 k,
  * 50 % 5.3 k frames/s).  Scheduling only - same records.
+ * "hyp_first" (default 8; 4, 8, 12 or 16): many sequences per step (svo_track_multi_step_dev): RANSAC samples per sequence in the
+ * step's first launch; the second launch holds as many again, the third the rest, and their workgroups leave at once when
+ * cv::solvePnPRansac's adaptive iteration bound says the loop never reaches their sample (it visits a median of 4 samples on
+ * synth-kitti, 8 or fewer on 96 % of the frames).  Same records (64 sequences: 16 -> 95 k, 8 -> 102 k, 4 -> 98 k frames/s).
+ * "gate_group" (default 1): frames that carry detection boxes need the brute-force matches against the previous frame and the
+ * 8-point F (src/pnpmatch.cc:253-337) before pass 1's epipolar veto.  1 = in the batched entries both are computed for a group of
+ * consecutive frames in one launch each, ahead of the index chain - they depend on front-end results only, not on tracker state;
+ * 0 = two launches per frame inside the chain (what the frame-by-frame entry always does).  Same records.
  * "pose_flag" (default 0): 1 = one sequence's pose kernels learn that their frame has been matched from a per-frame tag the
  * index chain publishes in HBM (agent-scope stores / polls, bounded) instead of waiting on one stream event per group of
  * frames - the pose chain then never stands still because a LATER frame of its group is slow to match (+0.6 % on the

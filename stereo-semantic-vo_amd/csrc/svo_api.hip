@@ -346,6 +346,9 @@ extern "C" int svo_set_option(svo_ctx* ctx, const char* key, int value) {
     return SVO_OK;
   }
   if (!strcmp(key, "pose_flag")) { ctx->opt_pose_flag = value != 0; return SVO_OK; }
+  if (!strcmp(key, "gate_group")) { ctx->opt_gate_group = value != 0; return SVO_OK; }
+  if (!strcmp(key, "hyp_first")) { if (value < 4 || value > 16 || (value & 3)) return SVO_E_INVALID; ctx->opt_hyp_first = value; return SVO_OK; }
+  if (!strcmp(key, "dense_two_launch")) { ctx->opt_dense_two_launch = value != 0; return SVO_OK; }
   if (!strcmp(key, "epnp_exact")) {
     if (value < 0 || value > 2) return SVO_E_INVALID;
     ctx->opt_epnp_exact = value;

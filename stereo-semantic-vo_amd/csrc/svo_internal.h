@@ -114,6 +114,11 @@ struct svo_ctx {
   bool tb_used[2] = {false, false};
   int tb_parity = 0;
   void* d_work = nullptr;       // TrackWork records (index chain -> pose chain), work_cap of them
+  void* d_gate_pre = nullptr;   // GatePre records (brute-force matches + F solved ahead of the index chain), like d_work
+  bool hyp_two_launch = false;  // set by an entry for the duration of its tail_enqueue calls: RANSAC samples as 16 + (those the bound can reach)
+  int opt_dense_two_launch = 0; // depth_source = 1: the tail beside the dense stage uses the two-launch RANSAC (fewer CUs taken from ELAS)
+  int opt_hyp_first = 8;        // many sequences: RANSAC samples per sequence in the first (and second) launch of a step
+  int opt_gate_group = 1;       // 1: gated frames' F for a group of frames in one launch ahead of the index chain; 0: per frame, in the chain
   int work_cap = 0;             // records per half (two halves are allocated)
   int work_last_half = 0;       // the half the last tail call used (debug readers)
   hipStream_t stream_idx = nullptr;        // the pose-free index chain of the tracking tail runs here, ahead of the pose chain

@@ -13,7 +13,9 @@
 // independent and are built on two threads by the caller.  Output is what svo_msa_tree_dp consumes.
 #include <math.h>
 
+#include <stdio.h>
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdlib>
 #include <atomic>
@@ -126,10 +128,22 @@ class TreeBuilder {
   int run(const uint8_t* img3, const double* gx, const double* gy, int32_t* seq, int32_t* child_ptr, int32_t* child,
           uint8_t* child_w) {
     img3_ = img3;
+    static const bool dbg = getenv("SVO_MSA_TREE_DEBUG") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+      if (!dbg) return;
+      const auto now = std::chrono::steady_clock::now();
+      fprintf(stderr, "[msa tree] %-24s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+      t_last = now;
+    };
+    dbg_mark_ = dbg ? &t_last : nullptr;
     arborescence(gx, gy);
+    mark("arborescence (rest)");
     if (roots_.empty()) return -1;
     label_regions();
+    mark("label_regions");
     merge_regions();
+    mark("merge_regions");
     // breadth-first order from the first root; parent[] doubles as the visited mark
     std::vector<int32_t>& parent = parent_;
     parent.assign(N_, -1);
@@ -153,6 +167,7 @@ class TreeBuilder {
         if (link_[i].to != parent[u]) { child[n_child] = link_[i].to; child_w[n_child] = (uint8_t)link_[i].w; ++n_child; }
       child_ptr[u + 1] = n_child;
     }
+    mark("bfs order + child lists");
     return roots_[0];
   }
 
@@ -167,6 +182,13 @@ class TreeBuilder {
   struct Cand { int a, b, w; double key; };
   std::vector<Cand> cand_;
   const uint8_t* img3_ = nullptr;
+  std::chrono::steady_clock::time_point* dbg_mark_ = nullptr;
+  void sub_mark(const char* what) {
+    if (!dbg_mark_) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[msa tree]   %-22s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - *dbg_mark_).count());
+    *dbg_mark_ = now;
+  }
   std::vector<int32_t> head_;
   std::vector<Link> link_;
   std::vector<int32_t> roots_, region_, region_max_, order_;
@@ -227,6 +249,7 @@ class TreeBuilder {
       for (auto& th : pool) th.join();
     }
 
+    sub_mark("heaps per pixel");
     // contraction phase
     std::vector<int>&chosen_from = chosen_from_, &chosen_key = chosen_key_, &chosen_edge = chosen_edge_, &entry = entry_, &todo = todo_;
     chosen_from.assign(2 * N_ + 2, -1); chosen_key.assign(2 * N_ + 2, 0); chosen_edge.assign(N_ + 1, -1); entry.assign(2 * N_ + 2, -1);
@@ -274,6 +297,7 @@ class TreeBuilder {
       incoming[v] = heaps.meld(incoming[v], incoming[u]);
       todo.push_back(v);
     }
+    sub_mark("contraction");
     // expansion phase: newest super-nodes first, each keeps the entering edge that was chosen for it
     for (int i = 0; i < n_super; ++i) { con.find(i); chosen_from[i] = -1; }
     std::vector<uint8_t>& done = done_;
@@ -291,6 +315,7 @@ class TreeBuilder {
       }
       if (u == i) { chosen_from[k / 5] = arc_from(k); chosen_key[k / 5] = arc_weight(k); }
     }
+    sub_mark("expansion");
     head_.assign(N_ + 1, -1);
     link_.clear(); link_.reserve((size_t)N_ * 2 + 4);
     roots_.clear();

@@ -309,6 +309,7 @@ struct TiLds {
   int16_t remap[TRK_CAP];          // pool row -> row after compaction
   int cnt_acc, cnt_veto, cnt_late, nd, flag[2];
   int32_t boxes[SVO_MAX_BOXES * 4];   // the frame's detection boxes {left, right, top, bottom}
+  double F[9];                        // the frame's fundamental matrix (epipolar veto of pass 1)
   uint16_t dn[TRK_CAP];            // dense active rows of the running pass
   uint16_t dnD[TRK_DNC][512];      // distance rows of the first TRK_DNC of them (fetched once per pass)
 };
@@ -349,7 +350,7 @@ __device__ __forceinline__ bool ti_finalize(TiLds& S, TrackState* st, TrackPool&
     const svo_kp kc = kp[bj];
     const int i_last = S.act_i[k];
     if (svo_in_boxes(kc.x, kc.y, S.boxes, n_boxes, 10) &&
-        svo_epipolar_distance(st->F, st->last_xy[2 * i_last], st->last_xy[2 * i_last + 1], kc.x, kc.y) > 0.1) {
+        svo_epipolar_distance(S.F, st->last_xy[2 * i_last], st->last_xy[2 * i_last + 1], kc.x, kc.y) > 0.1) {
       P.bad[m] = 1;
       tally += 1 << 10;
       return true;
@@ -600,7 +601,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char tk_smem[];
 // boxes / nboxes (nullable): the detection boxes of this frame - of sequence blockIdx.y: `bstride` boxes further on each
 __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* work, const svo_kp* kp,
                                                      const uint32_t* desc, const int32_t* nkp_p, const float* depth,
-                                                     int kstride, const int32_t* boxes, const int32_t* nboxes, int bstride) {
+                                                     int kstride, const int32_t* boxes, const int32_t* nboxes, int bstride,
+                                                     const double* Fpre) {
   TiLds& S = *reinterpret_cast<TiLds*>(tk_smem);
   st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
   desc += (size_t)blockIdx.y * kstride * 8; nkp_p += blockIdx.y; depth += (size_t)blockIdx.y * kstride;
@@ -608,6 +610,13 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
   const int nkp = min(*nkp_p, TRK_MAXKP);
   const int n_boxes = (boxes && nboxes) ? min(max(nboxes[blockIdx.y], 0), SVO_MAX_BOXES) : 0;
   if (tid < 4 * n_boxes) S.boxes[tid] = boxes[(size_t)blockIdx.y * bstride * 4 + tid];   // visible after the first barrier below
+  // F of this frame: solved in front of this kernel into st->F (k_tg_fmat), or ahead of the chain for a whole group of frames
+  // (k_tg_fmat_group: Fpre) - then st->F is brought up to date here (svo_track_fundamental reads it)
+  if (tid >= 64 && tid < 73) {
+    const double v = Fpre ? Fpre[tid - 64] : st->F[tid - 64];
+    S.F[tid - 64] = v;
+    if (Fpre) st->F[tid - 64] = v;
+  }
   const int id = st->frame_num;
   const int np_start = st->npool, lastN = st->lastN, gid0 = st->next_gid;
   TrackPool& P = st->pool[st->cur];
@@ -910,6 +919,113 @@ __global__ __launch_bounds__(64) void k_tg_fmat(TrackState* st, const svo_kp* kp
   }
 }
 
+// The same two steps for a GROUP of consecutive frames of one sequence in one launch each, ahead of the index chain: the
+// brute-force matches and F of frame f need nothing but the front-end results of frames f - 1 and f and frame f's boxes -
+// no tracker state - so the 11 + 42 us they cost per gated frame leave the index chain (which they had made longer than
+// the pose chain: 122 against 117 us per frame in configs[4]).  blockIdx.y = frame of the group; the group's first frame must
+// not be the sequence's first (the caller starts groups at frame >= 1 of a call; frame 0 of a call keeps k_tg_bf / k_tg_fmat,
+// whose "last frame" is in the tracker state).  Results per frame in a GatePre record.
+struct GatePre {
+  int32_t bf_idx[TRK_MAXKP], bf_dist[TRK_MAXKP];
+  double F[9];
+};
+__global__ __launch_bounds__(256) void k_tg_bf_group(const uint32_t* desc, const int32_t* nkp_p, int kstride, const int32_t* nboxes,
+                                                     GatePre* pre) {
+  __shared__ uint32_t td[8 * TRK_MAXKP];
+  const int f = blockIdx.y;   // relative to the pointers: they address the group's first frame, row -1 is its predecessor
+  if (nboxes[f] <= 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nkp = min(nkp_p[f], TRK_MAXKP), lastN = min(nkp_p[f - 1], TRK_MAXKP);
+  const int i = blockIdx.x * 4 + wv;
+  if (blockIdx.x * 4 >= nkp) return;
+  const uint32_t* cur = desc + (ptrdiff_t)f * kstride * 8;
+  {
+    const uint4* d4 = reinterpret_cast<const uint4*>(desc + (ptrdiff_t)(f - 1) * kstride * 8);
+    uint4 v[TRK_MAXKP * 2 / 256];
+#pragma unroll
+    for (int k = 0; k < TRK_MAXKP * 2 / 256; ++k) v[k] = d4[min(tid + 256 * k, max(2 * lastN - 1, 0))];
+#pragma unroll
+    for (int k = 0; k < TRK_MAXKP * 2 / 256; ++k) {
+      const int q = tid + 256 * k;
+      if (q < 2 * lastN) {
+        const int j = q >> 1, w = 4 * (q & 1);
+        td[(w + 0) * TRK_MAXKP + j] = v[k].x; td[(w + 1) * TRK_MAXKP + j] = v[k].y;
+        td[(w + 2) * TRK_MAXKP + j] = v[k].z; td[(w + 3) * TRK_MAXKP + j] = v[k].w;
+      }
+    }
+  }
+  __syncthreads();
+  if (i >= nkp) return;
+  uint32_t qd[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) qd[k] = cur[8 * i + k];
+  uint32_t key = 0xffffffffu;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int j = lane + 64 * t;
+    if (j < lastN) {
+      uint32_t d = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d += __popc(qd[k] ^ td[k * TRK_MAXKP + j]);
+      key = min(key, (d << 16) | (uint32_t)j);   // ties: the lowest train index
+    }
+  }
+  key = wave_min_u32_dpp(key);
+  if (lane == 0) {
+    pre[f].bf_idx[i] = key == 0xffffffffu ? -1 : (int)(key & 0xffffu);
+    pre[f].bf_dist[i] = key == 0xffffffffu ? -1 : (int)(key >> 16);
+  }
+}
+
+__global__ __launch_bounds__(64) void k_tg_fmat_group(const svo_kp* kp, const int32_t* nkp_p, int kstride, const int32_t* boxes,
+                                                      const int32_t* nboxes, int bstride, GatePre* pre) {
+  __shared__ EpnpWaveLds S;
+  const int f = blockIdx.y, lane = threadIdx.x;
+  const int n_boxes = min(max(nboxes[f], 0), SVO_MAX_BOXES);
+  boxes += (ptrdiff_t)f * bstride * 4;
+  const svo_kp* cur = kp + (ptrdiff_t)f * kstride;
+  const svo_kp* last = kp + (ptrdiff_t)(f - 1) * kstride;
+  double F[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (n_boxes > 0) {
+    const int nkp = min(nkp_p[f], TRK_MAXKP);
+    int idx[8], dist[8];
+    uint32_t gmin = 0x7fffffffu;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int i = lane + 64 * t;
+      idx[t] = i < nkp ? pre[f].bf_idx[i] : -1;
+      dist[t] = i < nkp ? pre[f].bf_dist[i] : -1;
+      if (idx[t] >= 0) gmin = min(gmin, (uint32_t)dist[t]);
+    }
+    gmin = wave_min_u32_dpp(gmin);
+    const double md = (double)min(gmin, 10000u);
+    const double thr = 2 * md > 30.0 ? 2 * md : 30.0;
+    uint32_t keep = 0;
+    double x1[8], y1[8], x2[8], y2[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int i = lane + 64 * t;
+      x1[t] = y1[t] = x2[t] = y2[t] = 0.0;
+      if (idx[t] >= 0 && (double)dist[t] <= thr) {
+        const svo_kp k = cur[i];
+        if (!svo_in_boxes(k.x, k.y, boxes, n_boxes, 10)) {
+          keep |= 1u << t;
+          const svo_kp kl = last[idx[t]];
+          x1[t] = (double)k.x; y1[t] = (double)k.y;
+          x2[t] = (double)kl.x; y2[t] = (double)kl.y;
+        }
+      }
+    }
+    fmat8_wave(S, keep, x1, y1, x2, y2, F);
+  }
+  if (lane < 9) {
+    double v = F[0];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) v = lane == k ? F[k] : v;
+    pre[f].F[lane] = v;
+  }
+}
+
 // ================================================================================================
 // Pose chain: one launch per frame and sequence
 // ================================================================================================
@@ -942,10 +1058,11 @@ __device__ __forceinline__ bool tp_wait_work(TrackState* st, const TrackWork* wo
 }
 
 #define TP_HYP_FIRST 16
+#define TP_HYP_PRE 32   // most samples a later launch replays the adaptive rule over
 struct TpHypLds {
   double Xw[TRK_MAXKP * 3], uv[TRK_MAXKP * 2];
   EpnpWaveLds ws[4];
-  int cnt[TP_HYP_FIRST], ok[TP_HYP_FIRST], bound;
+  int cnt[TP_HYP_PRE], ok[TP_HYP_PRE], bound;
 };
 
 __global__ __launch_bounds__(256) void k_tp_hyp(TrackState* st, const TrackWork* work, const svo_kp* kp, const uint16_t* subsets,
@@ -963,9 +1080,10 @@ __global__ __launch_bounds__(256) void k_tp_hyp(TrackState* st, const TrackWork*
   if (skip0 || n < 5) return;
   const int first = hyp_base + (int)blockIdx.x * (int)(blockDim.x >> 6);
   if (hyp_base > 0) {
-    if (threadIdx.x < TP_HYP_FIRST) { S.cnt[threadIdx.x] = st->hyp[threadIdx.x].cnt; S.ok[threadIdx.x] = st->hyp[threadIdx.x].ok; }
+    const int pre = min(hyp_base, TP_HYP_PRE);
+    if ((int)threadIdx.x < pre) { S.cnt[threadIdx.x] = st->hyp[threadIdx.x].cnt; S.ok[threadIdx.x] = st->hyp[threadIdx.x].ok; }
     __syncthreads();
-    if (threadIdx.x == 0) S.bound = pnp_bound_after(S.cnt, S.ok, n, TP_HYP_FIRST);
+    if (threadIdx.x == 0) S.bound = pnp_bound_after(S.cnt, S.ok, n, pre);
     __syncthreads();
     if (first >= S.bound) return;
   }
@@ -1015,7 +1133,7 @@ __global__ __launch_bounds__(64) void k_tp_hyp_exact(TrackState* st, TrackWork* 
 
 // The RANSAC samples in the order-preserving wave mode ("epnp_exact" = 2, the default): one single-wave workgroup per sample,
 // OpenCV's operations over the wavefront with their rounding kept (svo_epnp_ord_dev.h); the wave counts the consensus.
-struct TpHypOrdLds { double Xw[TRK_MAXKP * 3], uv[TRK_MAXKP * 2]; PnpOrdLds ord; int cnt[TP_HYP_FIRST], ok[TP_HYP_FIRST], bound; };
+struct TpHypOrdLds { double Xw[TRK_MAXKP * 3], uv[TRK_MAXKP * 2]; PnpOrdLds ord; int cnt[TP_HYP_PRE], ok[TP_HYP_PRE], bound; };
 __global__ __launch_bounds__(64) void k_tp_hyp_ord(TrackState* st, TrackWork* work, const svo_kp* kp, const uint16_t* subsets,
                                                    int kstride, int hyp_base, int tag, int force_seq) {
   TpHypOrdLds& S = *reinterpret_cast<TpHypOrdLds*>(tk_smem);
@@ -1027,9 +1145,10 @@ __global__ __launch_bounds__(64) void k_tp_hyp_ord(TrackState* st, TrackWork* wo
   const int n = ld_agent(&work->n_edges);
   if (ld_agent(&work->skip_match) || n < 5) return;
   if (hyp_base > 0) {   // second launch of a many-sequence step: only the samples the adaptive bound can still reach (see k_tp_hyp)
-    if (threadIdx.x < TP_HYP_FIRST) { S.cnt[threadIdx.x] = st->hyp[threadIdx.x].cnt; S.ok[threadIdx.x] = st->hyp[threadIdx.x].ok; }
+    const int pre = min(hyp_base, TP_HYP_PRE);   // the rule over the samples of the earlier launches (all of them done: same stream)
+    if ((int)threadIdx.x < pre) { S.cnt[threadIdx.x] = st->hyp[threadIdx.x].cnt; S.ok[threadIdx.x] = st->hyp[threadIdx.x].ok; }
     __syncthreads();
-    if (threadIdx.x == 0) S.bound = pnp_bound_after(S.cnt, S.ok, n, TP_HYP_FIRST);
+    if (threadIdx.x == 0) S.bound = pnp_bound_after(S.cnt, S.ok, n, pre);
     __syncthreads();
     if (sample >= S.bound) return;
   }
@@ -1203,6 +1322,7 @@ void svo_track_release(svo_ctx* ctx) {
   ctx->tb_parity = 0;
   if (ctx->d_track) { hipFree(ctx->d_track); ctx->d_track = nullptr; }
   if (ctx->d_work) { hipFree(ctx->d_work); ctx->d_work = nullptr; }
+  if (ctx->d_gate_pre) { hipFree(ctx->d_gate_pre); ctx->d_gate_pre = nullptr; }
   ctx->n_seq = 0; ctx->work_cap = 0;
   for (hipEvent_t e : ctx->ev_frame) hipEventDestroy(e);
   ctx->ev_frame.clear();
@@ -1240,7 +1360,9 @@ static int track_resources(svo_ctx* ctx, int frames, int nseq) {
   if (ctx->work_cap < need) {
     SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->d_work) hipFree(ctx->d_work);
-    ctx->d_work = nullptr; ctx->work_cap = 0;
+    if (ctx->d_gate_pre) hipFree(ctx->d_gate_pre);
+    ctx->d_work = nullptr; ctx->d_gate_pre = nullptr; ctx->work_cap = 0;
+    if (hipMalloc(&ctx->d_gate_pre, sizeof(GatePre) * (size_t)need * 2) != hipSuccess) return SVO_E_NOMEM;
     if (hipMalloc(&ctx->d_work, sizeof(TrackWork) * (size_t)need * 2) != hipSuccess) return SVO_E_NOMEM;   // two halves (see tail_enqueue)
     SVO_HIP(ctx, hipMemset(ctx->d_work, 0, sizeof(TrackWork) * (size_t)need * 2));   // no stale `ready` tags
     ctx->work_cap = need;
@@ -1295,6 +1417,10 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
   const bool prof = ctx->profiling;
   // frame f's front-end results sit in row f of the arrays unless the caller says otherwise (svo_track_sharded_dev)
   auto row = [&](int f) { return (size_t)(row_of_frame ? row_of_frame[f] : f); };
+  // gated frames of ONE sequence whose front-end rows are consecutive: brute-force matches + F for groups of frames in one
+  // launch each, ahead of the chain (k_tg_bf_group)
+  const bool gate_group = bx && nseq == 1 && frames > 1 && !row_of_frame && ctx->opt_gate_group;
+  GatePre* gpre = reinterpret_cast<GatePre*>(ctx->d_gate_pre) + (size_t)work_half * ctx->work_cap;
   auto enqueue_index = [&](int f) {
     const svo_kp* kpf = kp + row(f) * kstride;
     const uint32_t* descf = desc + row(f) * kstride * 8;
@@ -1302,11 +1428,30 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
     const int32_t* nkpf = nkp + row(f);
     ctx->profiling = prof && (f % 32 == 0 || frames < 32);
     if (fe_events && fe_events[f]) hipStreamWaitEvent(s1, fe_events[f], 0);
+    const bool pre_f = gate_group && f >= 1;   // this frame's F is solved ahead of the chain, with its group
+    if (gate_group && (f == 0 || (fe_events && fe_events[f]))) {
+      // a group: the frames whose front-end results this wait (or the call's start) made available, except frame 0 of the call
+      int g1 = f + 1;
+      while (g1 < frames && !(fe_events && fe_events[g1])) ++g1;
+      const int a = std::max(f, 1), n = g1 - a;
+      if (n > 0) {
+        {
+          SvoTimer t(ctx, "k_tg_bf_group", s1);
+          hipLaunchKernelGGL(k_tg_bf_group, dim3(TRK_MAXKP / 4, n), dim3(256), 0, s1, desc + (size_t)a * kstride * 8, nkp + a, kstride,
+                             bx->n + a, gpre + a);
+        }
+        {
+          SvoTimer t(ctx, "k_tg_fmat_group", s1);
+          hipLaunchKernelGGL(k_tg_fmat_group, dim3(1, n), dim3(64), 0, s1, kp + (size_t)a * kstride, nkp + a, kstride,
+                             bx->boxes + (size_t)a * bx->stride * 4, bx->n + a, bx->stride, gpre + a);
+        }
+      }
+    }
     // frame f's boxes (one sequence) / the sequences' boxes of this step (many): the kernels add blockIdx.y themselves
     const int32_t* bxf = bx ? bx->boxes + (nseq == 1 ? (size_t)f * bx->stride * 4 : 0) : nullptr;
     const int32_t* nbf = bx ? bx->n + (nseq == 1 ? f : 0) : nullptr;
     const int bstride = bx ? bx->stride : 0;
-    if (bx) {   // F for the epipolar veto (src/pnpmatch.cc:302-337): brute-force matches cur -> last, then the 8-point solve
+    if (bx && !pre_f) {   // F for the epipolar veto (src/pnpmatch.cc:302-337): brute-force matches cur -> last, then the 8-point solve
       {
         SvoTimer t(ctx, "k_tg_bf", s1);
         hipLaunchKernelGGL(k_tg_bf, dim3(TRK_MAXKP / 4, ny), dim3(256), 0, s1, st, descf, nkpf, kstride, nbf);
@@ -1324,7 +1469,7 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
     {
       SvoTimer t(ctx, "k_ti_resolve", s1);
       hipLaunchKernelGGL(k_ti_resolve, dim3(1, ny), dim3(1024), sizeof(TiLds), s1, st, work + f, kpf, descf, nkpf, depf, kstride,
-                         bxf, nbf, bstride);
+                         bxf, nbf, bstride, pre_f ? gpre[f].F : nullptr);
     }
   };
   // one sequence: the pose kernels find out by themselves when their frame's record is there (tp_wait_work) - no stream event
@@ -1337,11 +1482,16 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
     ctx->profiling = prof && (f % 32 == 0 || frames < 32);
     if (ctx->opt_epnp_exact == 2) {
       SvoTimer t(ctx, "k_tp_hyp_ord");
-      if (ny >= 8) {   // many sequences: sixteen samples per sequence first, then only those the adaptive bound can reach
-        hipLaunchKernelGGL(k_tp_hyp_ord, dim3(TP_HYP_FIRST, ny), dim3(64), sizeof(TpHypOrdLds), s0, st, work + f, kpf, ctx->d_pnp_subsets,
-                           kstride, 0, 0, ctx->opt_epnp_force_seq);
-        hipLaunchKernelGGL(k_tp_hyp_ord, dim3(PNP_HYP - TP_HYP_FIRST, ny), dim3(64), sizeof(TpHypOrdLds), s0, st, work + f, kpf,
-                           ctx->d_pnp_subsets, kstride, TP_HYP_FIRST, 0, ctx->opt_epnp_force_seq);
+      if (ny >= 8 || ctx->hyp_two_launch) {
+        // many sequences (or a dense stage beside the tail): throughput counts.  cv::solvePnPRansac visits a median of 4 samples
+        // on these sequences, 96 % of the frames 8 or fewer, 99.9 % 16 or fewer: F samples per sequence first ("hyp_first",
+        // default 8), then F more, then the rest - the workgroups of a later launch replay the adaptive rule over the earlier
+        // samples and leave at once when the loop can never reach theirs
+        const int F = std::max(4, std::min(ctx->opt_hyp_first, TP_HYP_PRE / 2));
+        const int base[4] = {0, F, 2 * F, PNP_HYP};
+        for (int k = 0; k < 3; ++k)
+          hipLaunchKernelGGL(k_tp_hyp_ord, dim3(base[k + 1] - base[k], ny), dim3(64), sizeof(TpHypOrdLds), s0, st, work + f, kpf,
+                             ctx->d_pnp_subsets, kstride, base[k], k == 0 ? tag_of(f) : 0, ctx->opt_epnp_force_seq);
       } else {
         hipLaunchKernelGGL(k_tp_hyp_ord, dim3(PNP_HYP, ny), dim3(64), sizeof(TpHypOrdLds), s0, st, work + f, kpf, ctx->d_pnp_subsets, kstride,
                            0, tag_of(f), ctx->opt_epnp_force_seq);
@@ -1579,7 +1729,7 @@ extern "C" int svo_track_multi_step_dev(svo_ctx* ctx, const uint8_t* d_grayL, co
       ctx->ms_cap = n_seq;
     }
     if ((rc = track_resources(ctx, 1, n_seq))) return rc;   // streams and events exist from here on
-    if (!ctx->stream_fe) SVO_HIP(ctx, svo_stream_create(&ctx->stream_fe, -1));
+    if (!ctx->stream_fe) SVO_HIP(ctx, svo_stream_create(&ctx->stream_fe, -1));   // (confining it to a share of the CUs only costs: 88 % -6 %, 75 % -8 %, 50 % -34 % with 64 sequences)
     const int p = ctx->ms_parity;
     if (ctx->ms_tail_recorded[p]) {
       SVO_HIP(ctx, hipStreamWaitEvent(ctx->stream_fe, ctx->ms_tail_done[p], 0));   // the tail that read this set two steps ago
@@ -1685,9 +1835,11 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
       }
     } hook{ctx, ctx->stream, boxes, d_results, dD1, d_prod, n, K, 0};
     ctx->stream = ctx->stream_dense;
+    ctx->hyp_two_launch = ctx->opt_dense_two_launch != 0;   // (the hook's tail_enqueue calls: 16 CUs per frame instead of 100 on ordinary frames)
     rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, B, B);   // left images only
     if (rc == SVO_OK)
       rc = svo_elas_batch_dev_hooked(ctx, d_grayL, d_grayR, stride, ctx->g.W, ctx->g.H, B, &ep, dD1, dD2, ctx->h_prod, &Hook::run, &hook);
+    ctx->hyp_two_launch = false;
     ctx->stream = hook.s_main;
     return rc;
   } else if (ctx->opt_depth_source == 2) {

@@ -15,6 +15,7 @@ for ramp in sys.argv[2:] or ["16,32,64"]:
         os.environ["SVO_DENSE_CU_PERCENT"] = pct
     os.environ["SVO_DENSE_SUB"] = ramp
     os.environ["SVO_ELAS_DEBUG"] = os.environ.get("DBG", "")
-    bench.SEM_ELAS_OPTIONS = {"dense_cu_percent": int(os.environ.get("SVO_DENSE_CU_PERCENT", "100"))}
+    bench.SEM_ELAS_OPTIONS = {"dense_cu_percent": int(os.environ.get("SVO_DENSE_CU_PERCENT", "100")), "dense_two_launch": int(os.environ.get("TWO", "0"))}
+    print("options", bench.SEM_ELAS_OPTIONS, end=" ")
     r = bench.semantic_elas_leg(pkg, cam, dL, dR, dev, rec, n=N)
     print("ramp", ramp, "N", N, "fps %.0f" % r["value"], "identical", r.get("cpu_baseline", {}).get("counters_identical_to_gpu"), flush=True)

@@ -523,6 +523,23 @@ def frontend_leg(pkg, cam, dL, dR, n_frames, frame_bytes, dev, all_cores):
                         "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B), "valu": pmc_valu(dom),
                         "algorithmic_bytes_per_launch": algo,
                         "pipeline_frac": ALGO_BYTES_PER_PAIR * (B * steps / dt) / 1e9 / HBM_PEAK_GBS}}
+    # What actually bounds the front end: vector-ALU instruction issue.  Every SIMD issues one wave64 VALU instruction per four
+    # cycles: 256 CUs x 4 SIMDs x 2.4 GHz / 4 = 614 G wave-instructions/s; the kernels' counted instructions (SQ_INSTS_VALU of the
+    # committed PMC passes, 64 pairs per dispatch, k_pyr_fused three launches per pass) give the pairs/s that ceiling allows.
+    try:
+        per_pass = 0.0
+        for k, launches in (("k_pyr_fused", 3), ("k_fast", 1), ("k_select", 1), ("k_describe", 1), ("k_stereo_match", 1), ("k_stereo_median", 1)):
+            e = pmc_entry(k)
+            per_pass += launches * e["SQ_INSTS_VALU"] / (e.get("_pairs_per_dispatch_traffic", 64) / 64.0)
+        instr_per_pair = per_pass / 64.0
+        peak = 256 * 4 * 2.4e9 / 4.0
+        out["roofline"]["valu_issue"] = {"bound": "wave64 VALU instruction issue (one per SIMD per four cycles)", "peak": peak / 1e9,
+                                         "achieved": out["value"] * instr_per_pair / 1e9, "unit": "G wave-instructions/s",
+                                         "frac": out["value"] * instr_per_pair / peak, "valu_instructions_per_pair": instr_per_pair,
+                                         "pairs_per_s_at_peak": peak / instr_per_pair,
+                                         "source": "profiles/pmc_latest.json (SQ_INSTS_VALU, r03_e front-end passes: these kernels are unchanged since)"}
+    except Exception:  # noqa: BLE001
+        pass
     if all_cores is not None:
         Lh = dL[:64, :, :W].cpu().numpy(); Rh = dR[:64, :, :W].cpu().numpy()
         out["cpu_baseline_all_cores"] = all_cores(Lh, Rh, cam)

@@ -399,6 +399,14 @@ int svo_track_overflowed(svo_ctx* ctx, int32_t* flag);
  * takes about ten times as long in the pose chain.  Synchronises. */
 int svo_track_epnp_fallbacks(svo_ctx* ctx, int64_t* count);
 
+/* Diagnostics: how the stream of the tail's index chain was chosen.  The ordered tail (src/Tracking.cc:231-250 per frame) runs
+ * as two chains on two streams that must overlap; which hardware queues the runtime maps them onto depends on the process's
+ * earlier contexts, and some pairs of queues are served one after the other.  At the first tracker call of a context up to four
+ * candidate streams are probed against the context's main stream (a bounded wait-for-flag kernel on one, the setter on the
+ * other) and one that runs beside it is kept.  out[0] = candidates tried (0: probe off, SVO_NO_STREAM_PROBE=1; -1: no tracker
+ * call yet), out[1] = polls the waiting kernel needed for the chosen one (>= 1000: none passed). */
+int svo_debug_stream_probe(svo_ctx* ctx, int32_t out[2]);
+
 /* Many independent sequences on one GPU ("G independent sequences" for pure
  * throughput; no counterpart in the reference, whose tracker is one static chain per process,
  * src/Tracking.cc:180-252).  svo_track_multi_reset allocates n_seq (<= max_batch) tracker states;

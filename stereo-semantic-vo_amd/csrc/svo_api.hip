@@ -271,6 +271,7 @@ extern "C" int svo_create(svo_ctx** out, int device, int W, int H, int max_kp, i
       hipMemcpy(ctx->d_pnp_subsets, sub.data(), sub.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
     }
     hipMemset(ctx->d_selcnt, 0, I * SVO_NLEVELS * 4);
+    hipDeviceSynchronize();   // (the memsets above run on the null stream, which the context's non-blocking streams do not order against)
   }
   if (rc != SVO_OK) {
     svo_destroy(ctx);

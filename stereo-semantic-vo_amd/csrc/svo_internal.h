@@ -117,6 +117,8 @@ struct svo_ctx {
   void* d_gate_pre = nullptr;   // GatePre records (brute-force matches + F solved ahead of the index chain), like d_work
   bool hyp_two_launch = false;  // set by an entry for the duration of its tail_enqueue calls: RANSAC samples as 16 + (those the bound can reach)
   int opt_dense_two_launch = 0; // depth_source = 1: the tail beside the dense stage uses the two-launch RANSAC (fewer CUs taken from ELAS)
+  int idx_probe_attempts = -1;  // how many candidate streams the index chain's stream was chosen from (-1: not chosen yet, 0: probe off)
+  int idx_probe_spins = 0;      // the chosen candidate's probe result (polls of the waiting kernel: >= 1000 = the two chains do NOT overlap)
   int opt_hyp_first = 8;        // many sequences: RANSAC samples per sequence in the first (and second) launch of a step
   int opt_gate_group = 1;       // 1: gated frames' F for a group of frames in one launch ahead of the index chain; 0: per frame, in the chain
   int work_cap = 0;             // records per half (two halves are allocated)

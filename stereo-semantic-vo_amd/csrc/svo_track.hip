@@ -1347,9 +1347,68 @@ void svo_track_release(svo_ctx* ctx) {
   ctx->ms_cap = 0; ctx->ms_parity = 0;
 }
 
+// Do two streams run side by side?  The tail is two chains on two streams that must overlap, and whether they do depends on the
+// hardware queues the runtime maps them onto (a pool per priority, least-used first: a process's earlier contexts decide what a
+// new one gets).  Probe: on A a kernel that waits for a flag (bounded), then an empty kernel - whose packet carries the barrier
+// bit and waits for the first; on B, enqueued last, the kernel that sets the flag.  When the two queues are served
+// independently the setter runs at once and the waiter sees the flag within microseconds; when B's packets wait behind A's
+// (one hardware queue, or two that share a pipe of the command processor) the waiter runs into its bound.
+__global__ void k_probe_wait(int* flag, int limit) {
+  int spins = 0;
+  while (ld_agent(flag) == 0 && spins < limit) { __builtin_amdgcn_s_sleep(8); ++spins; }
+  flag[1] = spins;
+}
+__global__ void k_probe_set(int* flag) { st_agent(flag, 1); }
+__global__ void k_probe_nop() {}
+static int stream_pair_probe(svo_ctx* ctx, hipStream_t A, hipStream_t B, int* d_flag, int* spins_out) {
+  const int limit = 2000;   // ~0.5 ms
+  int h[2] = {0, 0};
+  SVO_HIP(ctx, hipMemcpyAsync(d_flag, h, 8, hipMemcpyHostToDevice, A));
+  SVO_HIP(ctx, hipStreamSynchronize(A));
+  SVO_HIP(ctx, hipStreamSynchronize(B));
+  hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, A, d_flag, limit);
+  hipLaunchKernelGGL(k_probe_nop, dim3(1), dim3(1), 0, A);
+  hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, B, d_flag);
+  SVO_HIP(ctx, hipStreamSynchronize(A));
+  SVO_HIP(ctx, hipStreamSynchronize(B));
+  SVO_HIP(ctx, hipMemcpy(h, d_flag, 8, hipMemcpyDeviceToHost));
+  *spins_out = h[1];
+  return SVO_OK;
+}
+// The index chain's stream: a high-priority stream that the probe finds running beside the pose chain's; up to four candidates
+// are made (the rejected ones are kept until the choice is made, so that the pool hands out another queue each time).
+static int track_index_stream(svo_ctx* ctx) {
+  static const bool no_probe = []() { const char* e = getenv("SVO_NO_STREAM_PROBE"); return e && e[0] == '1'; }();
+  if (no_probe) { ctx->idx_probe_attempts = 0; return svo_stream_create(&ctx->stream_idx, +1) == hipSuccess ? SVO_OK : SVO_E_HIP; }
+  int* d_flag = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&d_flag), 8) != hipSuccess) return SVO_E_NOMEM;
+  std::vector<hipStream_t> rejected;
+  hipStream_t chosen = nullptr;
+  int rc = SVO_OK, spins = 0, attempts = 0;
+  for (; attempts < 4 && !chosen && rc == SVO_OK; ++attempts) {
+    hipStream_t cand = nullptr;
+    if (svo_stream_create(&cand, +1) != hipSuccess) { rc = SVO_E_HIP; break; }
+    rc = stream_pair_probe(ctx, ctx->stream, cand, d_flag, &spins);
+    if (rc == SVO_OK && spins < 1000) {
+      int back = 0;
+      rc = stream_pair_probe(ctx, cand, ctx->stream, d_flag, &back);   // and the other way round
+      if (rc == SVO_OK && back < 1000) { chosen = cand; break; }
+      spins = std::max(spins, back);
+    }
+    rejected.push_back(cand);
+  }
+  if (!chosen && !rejected.empty()) { chosen = rejected.back(); rejected.pop_back(); }   // none passed: the last one
+  for (hipStream_t r : rejected) hipStreamDestroy(r);
+  hipFree(d_flag);
+  ctx->stream_idx = chosen;
+  ctx->idx_probe_attempts = attempts + (chosen && spins < 1000 ? 1 : 0);
+  ctx->idx_probe_spins = spins;
+  return chosen ? rc : SVO_E_HIP;
+}
+
 // streams, events, work records and the kernels' LDS opt-ins for `frames` frames per call of `nseq` sequences
 static int track_resources(svo_ctx* ctx, int frames, int nseq) {
-  if (!ctx->stream_idx) SVO_HIP(ctx, svo_stream_create(&ctx->stream_idx, +1));
+  if (!ctx->stream_idx) { const int rcs = track_index_stream(ctx); if (rcs) return rcs; }
   if (!ctx->ev_frontend) SVO_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_frontend, hipEventDisableTiming));
   while ((int)ctx->ev_frame.size() < frames) {
     hipEvent_t e;
@@ -1364,7 +1423,11 @@ static int track_resources(svo_ctx* ctx, int frames, int nseq) {
     ctx->d_work = nullptr; ctx->d_gate_pre = nullptr; ctx->work_cap = 0;
     if (hipMalloc(&ctx->d_gate_pre, sizeof(GatePre) * (size_t)need * 2) != hipSuccess) return SVO_E_NOMEM;
     if (hipMalloc(&ctx->d_work, sizeof(TrackWork) * (size_t)need * 2) != hipSuccess) return SVO_E_NOMEM;   // two halves (see tail_enqueue)
-    SVO_HIP(ctx, hipMemset(ctx->d_work, 0, sizeof(TrackWork) * (size_t)need * 2));   // no stale `ready` tags
+    // no stale `ready` tags.  On the ctx stream and waited for: hipMemset runs on the null stream, which the tracker's
+    // non-blocking streams do not order against - the index chain's first records were zeroed by it when the chain started
+    // within microseconds of this call (svo_track_sharded_dev with sub-batched front ends, fresh context)
+    SVO_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(TrackWork) * (size_t)need * 2, ctx->stream));
+    SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->work_cap = need;
   }
   if (ctx->track_lds_state == 0) {
@@ -1559,7 +1622,7 @@ static int track_reset_n(svo_ctx* ctx, const svo_camera* cam, int nseq) {
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->ms_parity = 0; ctx->ms_tail_recorded[0] = false; ctx->ms_tail_recorded[1] = false;
   ctx->tb_parity = 0; ctx->tb_used[0] = false; ctx->tb_used[1] = false;   // (all streams are idle here)
-  if (ctx->d_work) SVO_HIP(ctx, hipMemset(ctx->d_work, 0, sizeof(TrackWork) * (size_t)ctx->work_cap * 2));   // frame tags restart at 1
+  if (ctx->d_work) SVO_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(TrackWork) * (size_t)ctx->work_cap * 2, ctx->stream));   // frame tags restart at 1 (the ctx stream is waited for below)
   if (!ctx->d_track || ctx->n_seq != nseq) {
     if (ctx->d_track) { hipFree(ctx->d_track); ctx->d_track = nullptr; }
     void* p = nullptr;
@@ -1966,6 +2029,15 @@ extern "C" int svo_track_overflowed(svo_ctx* ctx, int32_t* flag) {
   return SVO_OK;
 }
 
+// How the index chain's stream was chosen (track_index_stream): out[0] = candidates tried (0: probe switched off, -1: no
+// tracker call yet), out[1] = polls of the probe's waiting kernel for the chosen one (>= 1000: no candidate ran beside the pose
+// chain's stream - the two chains of the tail will take turns instead of overlapping).
+extern "C" int svo_debug_stream_probe(svo_ctx* ctx, int32_t out[2]) {
+  if (!ctx || !out) return SVO_E_INVALID;
+  out[0] = ctx->idx_probe_attempts; out[1] = ctx->idx_probe_spins;
+  return SVO_OK;
+}
+
 // How many RANSAC samples of the order-preserving EPnP (epnp_exact = 2) were handed to its sequential fallback since
 // svo_track_reset (a zero or repeated singular value, 25 Jacobi sweeps): same results, ~10x the time of the frame concerned.
 extern "C" int svo_track_epnp_fallbacks(svo_ctx* ctx, int64_t* count) {
@@ -2055,10 +2127,17 @@ extern "C" int svo_debug_track_realtime(svo_ctx* ctx, int slot, int64_t rt[4]) {
 struct ShardGather {
   // staging on the tail context's device: region g (frames g, g + G, ... of a call, `per` rows) holds what context g produced
   svo_kp* kp = nullptr; uint8_t* desc = nullptr; int32_t* n = nullptr; float* depth = nullptr;
+  // TWO sets of staging rows (set p at row p * per * G): call c + 1 gathers into one while the tail of call c reads the other
   int per = 0, G = 0;
   std::vector<hipEvent_t> ev;         // front end (and staging copies) of context g finished; created ON context g's device
   std::vector<int> ev_dev;            //   (an event is recorded on a stream of its own device only) - that device
-  hipEvent_t ev_prev = nullptr;       // what the tail context's stream held when the call began
+  hipEvent_t ev_prev = nullptr;       // what the tail context's stream held when the (first) call began
+  hipStream_t gs = nullptr;           // the gather's own stream on the tail context's device (not the pose chain's)
+  std::vector<hipEvent_t> ev_sub;     // sub-batch j of the latest call gathered (the index chain waits for it before the sub-batch's first frame)
+  hipEvent_t ev_gathered = nullptr;   // the latest call's gather finished: the contexts' result buffers / the bounce buffer are free again
+  hipEvent_t done[2] = {nullptr, nullptr};   // the pose chain finished with staging set / work half p
+  bool used[2] = {false, false};
+  int parity = 0;
   uint8_t* h_stage = nullptr;         // pinned bounce buffer for contexts whose device the tail's device cannot read directly
   size_t h_bytes = 0;
   std::vector<int> row_of_frame;
@@ -2089,6 +2168,10 @@ static void shard_gather_free(svo_ctx* ctx) {
       shard_gather_buffers_free(g);
       for (hipEvent_t e : g->ev) hipEventDestroy(e);
       if (g->ev_prev) hipEventDestroy(g->ev_prev);
+      if (g->ev_gathered) hipEventDestroy(g->ev_gathered);
+      for (hipEvent_t e : g->ev_sub) hipEventDestroy(e);
+      for (int q = 0; q < 2; ++q) if (g->done[q]) hipEventDestroy(g->done[q]);
+      if (g->gs) { hipStreamSynchronize(g->gs); hipStreamDestroy(g->gs); }
       if (g->h_stage) hipHostFree(g->h_stage);
       delete g;
       g_gathers.erase(g_gathers.begin() + i);
@@ -2109,12 +2192,21 @@ extern "C" int svo_track_sharded_dev(svo_ctx* const* ctxs, int G, const uint8_t*
   }
   ShardGather* sg = shard_gather(c0);
   SVO_HIP(c0, hipSetDevice(c0->device));
+  if (!sg->gs) SVO_HIP(c0, svo_stream_create(&sg->gs, 0));
+  if (!sg->ev_gathered) SVO_HIP(c0, hipEventCreateWithFlags(&sg->ev_gathered, hipEventDisableTiming));
+  for (int q = 0; q < 2; ++q)
+    if (!sg->done[q]) SVO_HIP(c0, hipEventCreateWithFlags(&sg->done[q], hipEventDisableTiming));
+  if (!c0->stream_fe_batch)
+    SVO_HIP(c0, c0->opt_fe_cu_percent < 100 ? svo_stream_create_masked(&c0->stream_fe_batch, c0->device, c0->opt_fe_cu_percent)
+                                            : svo_stream_create(&c0->stream_fe_batch, -1));
   const int per = (B + G - 1) / G;
   const size_t wk = sizeof(svo_kp) * (size_t)K, wd = 32 * (size_t)K, wf = 4 * (size_t)K;
   if (sg->per < per || sg->G < G) {
+    SVO_HIP(c0, hipStreamSynchronize(sg->gs));
+    if (c0->stream_idx) SVO_HIP(c0, hipStreamSynchronize(c0->stream_idx));
     SVO_HIP(c0, hipStreamSynchronize(c0->stream));
     shard_gather_buffers_free(sg);
-    const size_t rows = (size_t)per * G;
+    const size_t rows = (size_t)per * G * 2;
     if (hipMalloc(reinterpret_cast<void**>(&sg->kp), wk * rows) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&sg->desc), wd * rows) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&sg->n), 4 * rows) != hipSuccess ||
@@ -2124,8 +2216,10 @@ extern "C" int svo_track_sharded_dev(svo_ctx* const* ctxs, int G, const uint8_t*
       return SVO_E_NOMEM;
     }
     sg->per = per; sg->G = G;
+    sg->used[0] = sg->used[1] = false;
   }
   const int rper = sg->per;   // rows per region (may be larger than this call needs)
+  const int G0 = sg->G;       // regions per set
   for (int g = 0; g < G; ++g) {
     if (g < (int)sg->ev.size() && sg->ev_dev[g] == ctxs[g]->device) continue;
     hipSetDevice(ctxs[g]->device);
@@ -2158,75 +2252,149 @@ extern "C" int svo_track_sharded_dev(svo_ctx* const* ctxs, int G, const uint8_t*
   }
   const size_t region_bytes = (wk + wd + wf + 4) * (size_t)rper;
   if (need_stage && sg->h_bytes < region_bytes * G) {
+    SVO_HIP(c0, hipStreamSynchronize(sg->gs));
     SVO_HIP(c0, hipStreamSynchronize(c0->stream));
     if (sg->h_stage) hipHostFree(sg->h_stage);
     sg->h_stage = nullptr; sg->h_bytes = 0;
     if (hipHostMalloc(reinterpret_cast<void**>(&sg->h_stage), region_bytes * G, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return SVO_E_NOMEM; }   // (portable: every producer's device copies into it)
     sg->h_bytes = region_bytes * G;
   }
-  // front ends: context g extracts and matches its pairs k = g, g + G, ... on its own device and stream.  A context's
-  // result buffers (and the bounce buffer) may still be read by the previous call's gather: its stream waits for what
-  // context 0's stream held when this call began.
-  SVO_HIP(c0, hipEventRecord(sg->ev_prev, c0->stream));
-  int rc = SVO_OK;
-  for (int g = 0; g < G && rc == SVO_OK; ++g) {
-    const int nb = (B - g + G - 1) / G;
-    if (nb <= 0) continue;
+  // The pipeline over consecutive calls: the front ends of call c + 1 run while the tail of call c is in flight.  Nothing of a
+  // front end sits on the pose chain's stream: context g > 0 uses its own stream (its own GPU), context 0 its front-end
+  // stream (a share of the CUs, "fe_cu_percent", like svo_track_batch_dev); the gather runs on a stream of its own into the
+  // staging set the tail of call c does not read.  A front end waits only for the previous call's GATHER (the last reader of
+  // the context's result buffers and of the bounce buffer), the gather for the pose chain of call c - 1 (the last reader of
+  // its staging set), the index chain for the gather.
+  const int p = sg->parity;
+  const bool first_call = !(sg->used[0] || sg->used[1]);
+  if (first_call) SVO_HIP(c0, hipEventRecord(sg->ev_prev, c0->stream));   // after whatever the tail context's stream holds
+  // A front end on the TAIL's device (context 0's; in tests and one-GPU runs every context's) runs on the context's CU-confined
+  // front-end stream ("fe_cu_percent"), like svo_track_batch_dev's: on all CUs at the main stream's high priority it took the
+  // tail's CUs (measured with two contexts on one GPU: 5.4 k frames/s against 8.1 k).  Every context works through its pairs in
+  // sub-batches (its left images' results end up contiguous, row i = its pair i; a sub-batch's right images use the slots
+  // behind it, which the next sub-batch overwrites - as in svo_track_batch_dev), so that the tail can start on the first
+  // sub-batch while the rest of the call's front end still runs.
+  // sub-batch j of every context: its pairs sub_off[j] .. sub_off[j + 1]; 8, 8, 16, then 32 at a time - the tail of a call that
+  // finds the chip idle starts after 8 pairs per context instead of 32 (the confined stream takes ~50 us per pair)
+  std::vector<int> sub_off(1, 0);
+  while (sub_off.back() < per) {
+    const int j = (int)sub_off.size() - 1;
+    sub_off.push_back(std::min(per, sub_off.back() + (j < 2 ? 8 : j == 2 ? 16 : 32)));
+  }
+  const int nsub = (int)sub_off.size() - 1;
+  std::vector<char> confined(G, 0);
+  for (int g = 0; g < G; ++g) {
     svo_ctx* c = ctxs[g];
     hipSetDevice(c->device);
-    if (g > 0 && hipStreamWaitEvent(c->stream, sg->ev_prev, 0) != hipSuccess) { rc = SVO_E_HIP; break; }
-    rc = svo_frontend_batch_dev(c, d_grayL[g], d_grayR[g], stride, nb, &c0->cam, nullptr, nullptr, nullptr, nullptr, nullptr);
-    if (rc == SVO_OK && !direct[g]) {
-      // bounce, first half: this context's results into its region of the pinned buffer, on its own stream
-      uint8_t* h = sg->h_stage + region_bytes * g;
-      const int ns = svo_frontend_nslices(c, nb);
-      for (int k = 0; k < ns && rc == SVO_OK; ++k) {   // slice k of the front end keeps its left images' results at slots 2 p0 ..
-        const int p0 = (int)((int64_t)k * nb / ns), p1 = (int)((int64_t)(k + 1) * nb / ns), b = p1 - p0;
-        if (hipMemcpyAsync(h + wk * p0, c->d_kp + (size_t)2 * p0 * K, wk * b, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-            hipMemcpyAsync(h + wk * rper + wd * p0, c->d_desc + (size_t)2 * p0 * wd, wd * b, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-            hipMemcpyAsync(h + (wk + wd) * rper + wf * p0, c->d_depth + (size_t)p0 * K, wf * b, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-            hipMemcpyAsync(h + (wk + wd + wf) * rper + 4 * (size_t)p0, c->d_nkp + 2 * p0, 4 * (size_t)b, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+    while ((int)c->ev_sub.size() < nsub) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { hipSetDevice(c0->device); return SVO_E_HIP; }
+      c->ev_sub.push_back(e);
+    }
+    if (c->device == c0->device) confined[g] = 1;   // ... on context 0's front-end stream, one context after the other: two
+    // confined streams kept that share of the CUs busy without a gap, and the RANSAC workgroups the dispatcher places there
+    // waited for room (pose chain 111 -> 147 us per frame with two contexts on one GPU)
+  }
+  hipSetDevice(c0->device);
+  while ((int)sg->ev_sub.size() < nsub) {
+    hipEvent_t e;
+    SVO_HIP(c0, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    sg->ev_sub.push_back(e);
+  }
+  const size_t img = (size_t)c0->g.H * stride;
+  int rc = SVO_OK;
+  // sub-batch by sub-batch, every context's share of it (contexts on the tail's device share ONE stream: all of context 0's
+  // sub-batches in front of context 1's first would hold the tail up for the whole of context 0's front end)
+  struct Own { svo_kp* kp; uint8_t* desc; int32_t* nkp; float* uR; float* depth; int32_t* sad; hipStream_t stream; };
+  std::vector<Own> own(G);
+  std::vector<hipStream_t> fsv(G, nullptr);
+  for (int g = 0; g < G && rc == SVO_OK; ++g) {
+    svo_ctx* c = ctxs[g];
+    own[g] = Own{c->d_kp, c->d_desc, c->d_nkp, c->d_uR, c->d_depth, c->d_sad, c->stream};
+    if ((B - g + G - 1) / G <= 0) continue;
+    hipSetDevice(c->device);
+    { const int rcq = svo_track_quiesce(c); if (rcq) { hipSetDevice(c0->device); return rcq; } }   // (a batched call of this context may still read its result arrays)
+    fsv[g] = confined[g] ? c0->stream_fe_batch : c->stream;
+    bool waited = false;   // (contexts that share a stream: one wait is enough)
+    for (int q = 0; q < g; ++q) waited = waited || fsv[q] == fsv[g];
+    if (!waited && hipStreamWaitEvent(fsv[g], first_call ? sg->ev_prev : sg->ev_gathered, 0) != hipSuccess) rc = SVO_E_HIP;
+  }
+  for (int j = 0; j < nsub && rc == SVO_OK; ++j) {
+    for (int g = 0; g < G && rc == SVO_OK; ++g) {
+      const int nb = (B - g + G - 1) / G;
+      const int f0 = sub_off[j], b = std::min(sub_off[j + 1], nb) - f0;
+      if (b <= 0) continue;
+      svo_ctx* c = ctxs[g];
+      hipStream_t fs = fsv[g];
+      hipSetDevice(c->device);
+      c->stream = fs;
+      c->d_kp = own[g].kp + (size_t)f0 * K; c->d_desc = own[g].desc + (size_t)f0 * wd; c->d_nkp = own[g].nkp + f0;
+      c->d_uR = own[g].uR + (size_t)f0 * K; c->d_depth = own[g].depth + (size_t)f0 * K; c->d_sad = own[g].sad + (size_t)f0 * K;
+      rc = svo_launch_orb(c, d_grayL[g] + f0 * img, d_grayR[g] + f0 * img, stride, b, 2 * b);
+      if (rc == SVO_OK) rc = svo_launch_stereo(c, d_grayL[g] + f0 * img, d_grayR[g] + f0 * img, stride, b, &c0->cam);
+      if (rc == SVO_OK && !direct[g]) {
+        // bounce, first half: this sub-batch's results into the context's region of the pinned buffer, on its own stream
+        uint8_t* h = sg->h_stage + region_bytes * g;
+        if (hipMemcpyAsync(h + wk * f0, c->d_kp, wk * b, hipMemcpyDeviceToHost, fs) != hipSuccess ||
+            hipMemcpyAsync(h + wk * rper + wd * f0, c->d_desc, wd * b, hipMemcpyDeviceToHost, fs) != hipSuccess ||
+            hipMemcpyAsync(h + (wk + wd) * rper + wf * f0, c->d_depth, wf * b, hipMemcpyDeviceToHost, fs) != hipSuccess ||
+            hipMemcpyAsync(h + (wk + wd + wf) * rper + 4 * (size_t)f0, c->d_nkp, 4 * (size_t)b, hipMemcpyDeviceToHost, fs) != hipSuccess)
           rc = SVO_E_HIP;
       }
+      if (rc == SVO_OK && hipEventRecord(c->ev_sub[j], fs) != hipSuccess) rc = SVO_E_HIP;
+      c->stream = own[g].stream;
+      c->d_kp = own[g].kp; c->d_desc = own[g].desc; c->d_nkp = own[g].nkp; c->d_uR = own[g].uR; c->d_depth = own[g].depth; c->d_sad = own[g].sad;
     }
-    if (rc == SVO_OK && hipEventRecord(sg->ev[g], c->stream) != hipSuccess) rc = SVO_E_HIP;
   }
   hipSetDevice(c0->device);
   if (rc) { if (rc == SVO_E_HIP) c0->last_error = std::string("svo_track_sharded_dev: ") + hipGetErrorString(hipGetLastError()); return rc; }
-  // gather on context 0's stream: region g of the staging arrays <- context g's results (contiguous copies, slice by slice)
-  for (int g = 0; g < G; ++g) {
-    const int nb = (B - g + G - 1) / G;
-    if (nb <= 0) continue;
-    svo_ctx* c = ctxs[g];
-    SVO_HIP(c0, hipStreamWaitEvent(c0->stream, sg->ev[g], 0));
-    const size_t r0 = (size_t)g * rper;
-    if (!direct[g]) {
-      const uint8_t* h = sg->h_stage + region_bytes * g;
-      SVO_HIP(c0, hipMemcpyAsync(sg->kp + r0 * K, h, wk * nb, hipMemcpyHostToDevice, c0->stream));
-      SVO_HIP(c0, hipMemcpyAsync(sg->desc + r0 * wd, h + wk * rper, wd * nb, hipMemcpyHostToDevice, c0->stream));
-      SVO_HIP(c0, hipMemcpyAsync(sg->depth + r0 * K, h + (wk + wd) * rper, wf * nb, hipMemcpyHostToDevice, c0->stream));
-      SVO_HIP(c0, hipMemcpyAsync(sg->n + r0, h + (wk + wd + wf) * rper, 4 * (size_t)nb, hipMemcpyHostToDevice, c0->stream));
-      continue;
+  // gather on its own stream, sub-batch by sub-batch: rows of region g of staging set p <- context g's results
+  const size_t set0 = (size_t)p * rper * G0;
+  if (sg->used[p]) SVO_HIP(c0, hipStreamWaitEvent(sg->gs, sg->done[p], 0));
+  std::vector<hipEvent_t> wait(B, nullptr);
+  for (int j = 0; j < nsub; ++j) {
+    bool any = false;
+    for (int g = 0; g < G; ++g) {
+      const int nb = (B - g + G - 1) / G;
+      const int f0 = sub_off[j], b = std::min(sub_off[j + 1], nb) - f0;
+      if (b <= 0) continue;
+      any = true;
+      svo_ctx* c = ctxs[g];
+      SVO_HIP(c0, hipStreamWaitEvent(sg->gs, c->ev_sub[j], 0));
+      const size_t r0 = set0 + (size_t)g * rper + f0;
+      if (!direct[g]) {
+        const uint8_t* h = sg->h_stage + region_bytes * g;
+        SVO_HIP(c0, hipMemcpyAsync(sg->kp + r0 * K, h + wk * f0, wk * b, hipMemcpyHostToDevice, sg->gs));
+        SVO_HIP(c0, hipMemcpyAsync(sg->desc + r0 * wd, h + wk * rper + wd * f0, wd * b, hipMemcpyHostToDevice, sg->gs));
+        SVO_HIP(c0, hipMemcpyAsync(sg->depth + r0 * K, h + (wk + wd) * rper + wf * f0, wf * b, hipMemcpyHostToDevice, sg->gs));
+        SVO_HIP(c0, hipMemcpyAsync(sg->n + r0, h + (wk + wd + wf) * rper + 4 * (size_t)f0, 4 * (size_t)b, hipMemcpyHostToDevice, sg->gs));
+        continue;
+      }
+      const bool same = c->device == c0->device;
+      auto pull = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+        return same ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, sg->gs)
+                    : hipMemcpyPeerAsync(dst, c0->device, src, c->device, bytes, sg->gs);
+      };
+      SVO_HIP(c0, pull(sg->kp + r0 * K, c->d_kp + (size_t)f0 * K, wk * b));
+      SVO_HIP(c0, pull(sg->desc + r0 * wd, c->d_desc + (size_t)f0 * wd, wd * b));
+      SVO_HIP(c0, pull(sg->depth + r0 * K, c->d_depth + (size_t)f0 * K, wf * b));
+      SVO_HIP(c0, pull(sg->n + r0, c->d_nkp + f0, 4 * (size_t)b));
     }
-    const bool same = c->device == c0->device;
-    auto pull = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
-      return same ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c0->stream)
-                  : hipMemcpyPeerAsync(dst, c0->device, src, c->device, bytes, c0->stream);
-    };
-    const int ns = svo_frontend_nslices(c, nb);
-    for (int k = 0; k < ns; ++k) {
-      const int p0 = (int)((int64_t)k * nb / ns), p1 = (int)((int64_t)(k + 1) * nb / ns), b = p1 - p0;
-      SVO_HIP(c0, pull(sg->kp + (r0 + p0) * K, c->d_kp + (size_t)2 * p0 * K, wk * b));
-      SVO_HIP(c0, pull(sg->desc + (r0 + p0) * wd, c->d_desc + (size_t)2 * p0 * wd, wd * b));
-      SVO_HIP(c0, pull(sg->depth + (r0 + p0) * K, c->d_depth + (size_t)p0 * K, wf * b));
-      SVO_HIP(c0, pull(sg->n + r0 + p0, c->d_nkp + 2 * p0, 4 * (size_t)b));
-    }
+    if (!any) break;
+    SVO_HIP(c0, hipEventRecord(sg->ev_sub[j], sg->gs));
+    if (sub_off[j] * G < B) wait[(size_t)sub_off[j] * G] = sg->ev_sub[j];   // frames sub_off[j] G .. of the call need sub-batch j of every context
   }
-  // the ordered tail reads frame k = g + G i from row g * rper + i
+  SVO_HIP(c0, hipEventRecord(sg->ev_gathered, sg->gs));
+  // the ordered tail reads frame k = g + G i from row g * rper + i of set p; its index chain starts when the gather is done
+  // (which came after the pose chain that last read this set and this half of the work records)
   sg->row_of_frame.resize(B);
-  for (int k = 0; k < B; ++k) sg->row_of_frame[k] = (k % G) * rper + k / G;
-  rc = tail_enqueue(c0, sg->kp, sg->desc, sg->n, sg->depth, K, B, 1, d_results, boxes, nullptr, sg->row_of_frame.data());
+  for (int k = 0; k < B; ++k) sg->row_of_frame[k] = (int)set0 + (k % G) * rper + k / G;
+  rc = tail_enqueue(c0, sg->kp, sg->desc, sg->n, sg->depth, K, B, 1, d_results, boxes, wait.data(), sg->row_of_frame.data(), p,
+                    nullptr, true);
   if (rc) return rc;
+  SVO_HIP(c0, hipEventRecord(sg->done[p], c0->stream));   // the pose chain is the last reader of this set
+  sg->used[p] = true;
+  sg->parity ^= 1;
   c0->track_frame += B;
   return SVO_OK;
 }

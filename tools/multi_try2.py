@@ -31,9 +31,10 @@ def multi(tag):
     b = time.perf_counter()
     ms.sync()
     mdt = time.perf_counter() - t1
+    probe = ms.debug_stream_probe()
     ms.close()
     hs = np.array(hs) * 1e3
-    print(tag, "fps %.0f" % (msteps * S / mdt), "host ms/step median %.3f max %.3f sum %.1f; final sync %.1f ms; total %.1f ms"
+    print(tag, "probe", probe, "fps %.0f" % (msteps * S / mdt), "host ms/step median %.3f max %.3f sum %.1f; final sync %.1f ms; total %.1f ms"
           % (np.median(hs), hs.max(), hs.sum(), (time.perf_counter() - b) * 1e3, mdt * 1e3), flush=True)
 
 multi("fresh")

@@ -31,6 +31,7 @@ s.close()
 per = (B + G - 1) // G
 ctxs = [pkg.Svo(W, H, max_batch=per) for _ in range(G)]
 ctxs[0].track_reset(cam)
+print("probe (before first tracker call)", ctxs[0].debug_stream_probe())
 Ls = [[dL[c * B + g:(c + 1) * B:G].contiguous() for g in range(G)] for c in range(NC)]
 Rs = [[dR[c * B + g:(c + 1) * B:G].contiguous() for g in range(G)] for c in range(NC)]
 torch.cuda.synchronize()
@@ -52,6 +53,7 @@ for c in range(NC):
     print("   pose chain busy %.1f us/frame, frame period median %.1f; index chain busy %.1f us/frame; pose waits for index %.1f us/frame; index ahead by (frames) %s"
           % ((fr_e - hyp_s).mean(), np.median(np.diff(fr_e)), (idx_e - idx_s).mean(), np.maximum(0, idx_e[1:] - fr_e[:-1]).mean(),
              [int(np.searchsorted(idx_e, hyp_s[f]) - f) for f in (0, 20, 100, B - 1)]))
+print("probe", ctxs[0].debug_stream_probe())
 # as bench.py's sharded leg issues it: reset, then all calls back to back, one sync at the end
 for rep in range(3):
     torch.cuda.synchronize()
@@ -64,5 +66,13 @@ for rep in range(3):
     ctxs[0].sync()
     t3 = time.perf_counter()
     print("back to back: reset %.1f ms, enqueue %.1f ms, drain %.1f ms -> %.1f us/frame" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t3 - t0) / N * 1e6))
+    rl = np.zeros((B, 4), np.int64)
+    for f in range(B):
+        ctxs[0].lib.svo_debug_track_realtime(ctxs[0].h, f, rl[f].ctypes.data_as(C.c_void_p))
+    r = rl.astype(np.float64) / 100.0
+    idx_s, idx_e, hyp_s, fr_e = r[:, 0], r[:, 1], r[:, 2], r[:, 3]
+    print("   last call: tail span %.1f us/frame, pose busy %.1f, period median %.1f mean %.1f, pose waits for index %.1f us/frame, index gaps > 100 us: %s"
+          % ((fr_e[-1] - idx_s[0]) / B, (fr_e - hyp_s).mean(), np.median(np.diff(fr_e)), np.diff(fr_e).mean(), np.maximum(0, idx_e[1:] - fr_e[:-1]).mean(),
+             [(int(f), int(g)) for f, g in zip(np.nonzero(np.diff(idx_s) > 150)[0][:12], np.diff(idx_s)[np.diff(idx_s) > 150][:12])]))
 for x in ctxs:
     x.close()

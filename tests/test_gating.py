@@ -202,6 +202,16 @@ def test_gated_device_resident_modes_equal_frame_by_frame(pkg, gated_oracle_run)
     assert res.cpu().numpy().tobytes() == want
     F2, nv2 = b.debug_track_gate()
     assert nv2 == nv1 and np.array_equal(F1, F2)
+    # the brute-force matches and F per frame inside the index chain instead of per group of frames ahead of it: same records
+    b.set_option("gate_group", 0)
+    b.track_reset(cam)
+    res0 = torch.zeros((N, rec), dtype=torch.uint8, device=dev)
+    b.track_batch_dev(dL.data_ptr(), dR.data_ptr(), pitch, N, res0.data_ptr(), boxes=bx)
+    b.sync()
+    assert res0.cpu().numpy().tobytes() == want
+    F0, nv0 = b.debug_track_gate()
+    assert nv0 == nv1 and np.array_equal(F1, F0)
+    b.set_option("gate_group", 1)
     # without boxes the same frames give other records (the gates bite)
     b.track_reset(cam)
     b.track_batch_dev(dL.data_ptr(), dR.data_ptr(), pitch, N, res.data_ptr())

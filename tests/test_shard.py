@@ -96,6 +96,46 @@ def test_track_sharded_contexts_equal_single_context(pkg, frames, G):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("G,staged", [(2, False), (3, False), (2, True)])
+def test_sharded_calls_back_to_back_overlap_and_stay_identical(pkg, frames, G, staged, monkeypatch):
+    """Several svo_track_sharded_dev calls of uneven sizes WITHOUT a synchronisation between them: the front ends of call c + 1
+    run while the tail of call c is in flight (two staging sets, two halves of the work records, the gather on its own
+    stream) - the records must still equal the single context's, also through the pinned bounce path.  The inputs of every
+    call stay alive until the final sync (the entry is asynchronous)."""
+    import torch
+    if staged:
+        monkeypatch.setenv("SVO_SHARD_FORCE_STAGED", "1")
+    dL, dR, W, H, cam, want = frames
+    dev = dL.device
+    rec = pkg.TRACK_DTYPE.itemsize
+    sizes = [N // 2 - 1, 2, N - (N // 2 - 1) - 2 - 3, 3]
+    assert sum(sizes) == N and min(sizes) > 0
+    ctxs = [pkg.Svo(W, H, max_batch=(max(sizes) + G - 1) // G) for _ in range(G)]
+    ctxs[0].track_reset(cam)
+    res = torch.zeros((N, rec), dtype=torch.uint8, device=dev)
+    keep, k0 = [], 0
+    for B in sizes:
+        ks = range(k0, k0 + B)
+        Ls = [torch.stack([dL[k] for k in ks if (k - k0) % G == g] or [dL[0]]).contiguous() for g in range(G)]
+        Rs = [torch.stack([dR[k] for k in ks if (k - k0) % G == g] or [dR[0]]).contiguous() for g in range(G)]
+        keep.append((Ls, Rs))
+        k0 += B
+    torch.cuda.synchronize()
+    k0 = 0
+    for B, (Ls, Rs) in zip(sizes, keep):
+        pkg.Svo.track_sharded_dev(ctxs, [t.data_ptr() for t in Ls], [t.data_ptr() for t in Rs], PITCH, B, res.data_ptr() + k0 * rec)
+        k0 += B
+    ctxs[0].sync()
+    assert ctxs[0].track_overflowed() == 0
+    attempts, polls = ctxs[0].debug_stream_probe()
+    assert attempts >= 1 and polls < 1000, "no stream was found that runs beside the pose chain's: the tail's two chains take turns"
+    got = res.cpu().numpy().tobytes()
+    for c in ctxs:
+        c.close()
+    assert got == want
+
+
+@pytest.mark.gpu
 def test_bench_two_ranks_as_the_driver_launches_it():
     """python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...: both ranks on cuda:0 over gloo (the box
     has one GPU).  The line must be rank 0's, claim 2 GPUs, and carry the whole job's frames."""

@@ -266,6 +266,56 @@ def test_gpu_tracker_with_dense_msa_depth_matches_oracle(orc, pkg, sequence):
 
 
 @pytest.mark.gpu
+def test_many_sequences_staged_ransac_launches_equal_single_chains(pkg, sequence):
+    """With eight or more sequences per step the RANSAC samples go out in three launches (F, F, the rest; option "hyp_first")
+    whose later workgroups leave when cv::solvePnPRansac's iteration bound says the loop never reaches their sample: whatever F
+    is, every sequence's records must equal a single chain's (which computes all 100 samples)."""
+    import torch
+    L, R, _ = sequence
+    H, W = L.shape[1], L.shape[2]
+    S, STEPS = 8, 4                       # sequence q starts at frame q % 3
+    assert N_FRAMES >= 2 + STEPS
+    cam = pkg.Camera(**pkg.KITTI_00_02)
+    pitch = 1280
+    dev = torch.device("cuda", 0)
+    dL = torch.zeros((N_FRAMES, H, pitch), dtype=torch.uint8, device=dev)
+    dR = torch.zeros_like(dL)
+    dL[:, :, :W] = torch.from_numpy(L).to(dev); dR[:, :, :W] = torch.from_numpy(R).to(dev)
+    rec = pkg.TRACK_DTYPE.itemsize
+    fb = H * pitch
+    singles = {}
+    for q in (0, 1, 2):
+        a = pkg.Svo(W, H, max_batch=STEPS)
+        a.track_reset(cam)
+        res = torch.zeros((STEPS, rec), dtype=torch.uint8, device=dev)
+        a.track_batch_dev(dL.data_ptr() + q * fb, dR.data_ptr() + q * fb, pitch, STEPS, res.data_ptr())
+        a.sync()
+        singles[q] = res.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(-1)
+        a.close()
+    # step t's pairs, one per sequence, side by side
+    idx = torch.tensor([[(q % 3) + t for q in range(S)] for t in range(STEPS)], device=dev)
+    mL = dL[idx.reshape(-1)].reshape(STEPS, S, H, pitch).contiguous()
+    mR = dR[idx.reshape(-1)].reshape(STEPS, S, H, pitch).contiguous()
+    torch.cuda.synchronize()
+    m = pkg.Svo(W, H, max_batch=S)
+    with pytest.raises(pkg.SvoError):
+        m.set_option("hyp_first", 6)          # multiples of four only (the statistical solver's workgroups hold four samples)
+    for first in (8, 4, 16):
+        m.set_option("hyp_first", first)
+        m.track_multi_reset(S, cam)
+        out = torch.zeros((STEPS, S, rec), dtype=torch.uint8, device=dev)
+        for t in range(STEPS):
+            m.track_multi_step_dev(mL[t].data_ptr(), mR[t].data_ptr(), pitch, S, out[t].data_ptr())
+        m.sync()
+        assert m.track_overflowed() == 0
+        multi = out.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(STEPS, S)
+        for q in range(S):
+            for t in range(STEPS):
+                assert multi[t, q].tobytes() == singles[q % 3][t].tobytes(), (first, q, t)
+    m.close()
+
+
+@pytest.mark.gpu
 def test_multi_sequence_tracker_equals_independent_chains(pkg, sequence):
     """svo_track_multi_step_dev: S staggered sequences advanced together == S single-sequence trackers,
     record for record (byte-identical svo_track_result)."""

@@ -157,10 +157,11 @@ void svo_destroy(svo_ctx* ctx);
  * epipolar matcher (north star), 1 a dense ELAS map (svo_elas_*), 2 a dense MSA map (svo_msa_solve with d = 48: the
  * reference's live configuration, src/Tracking.cc:225-228 + src/frame.cc:82-91), both read per keypoint as
  * frame::computekeypoint_r / disp2Depth do.
- * "fe_cu_percent" (default 12 = one of the eight XCDs, 10..100): share of the compute units (whole XCDs) the front-end stream of
+ * "fe_cu_percent" (default 12 = 32 of the 256 CUs, 10..100): share of the compute units (whole 32-bit words of the CU mask; measured
+ * with tools/microbench/cu_mask_probe: the first word is FOUR CUs ON EACH of the eight XCDs, not one XCD) the front-end stream of
  * svo_track_batch_dev may use.  Its kernels would otherwise fill every CU while the ordered tail runs beside them, and the
  * tail's small dependent kernels then queue for slots (7 us per frame on average); the front end needs a tenth of the tail's
- * time on the whole chip, so one XCD keeps up (measured: 100 % 13.2 k, 25 % 14.1 k, 12 % 14.4 k frames/s).  Scheduling only -
+ * time on the whole chip, so an eighth of it keeps up (measured: 100 % 13.2 k, 25 % 14.1 k, 12 % 14.4 k frames/s).  Scheduling only -
  * same records.
  * "dense_cu_percent" (default 75, 10..100): the same for the dense front end's stream of svo_track_batch_dev with
  * depth_source = 1 (ORB + ELAS maps + depth lookups, in chunks, beside the tail of the earlier chunks): ELAS needs most of the chip,

@@ -923,7 +923,8 @@ extern "C" int svo_profile_get(svo_ctx* ctx, int index, char* name, int name_cap
 }
 
 // A stream that may only use the first `percent` per cent of the device's compute units (whole 32-bit mask words: on gfx950
-// consecutive CU indices belong to one XCD, so the stream keeps whole XCDs and their L2s).
+// the first word of the mask stands for four CUs on EACH of the eight XCDs - tools/microbench/cu_mask_probe - so the stream keeps
+// an even share of every XCD, not whole XCDs).  The stream is a blocking one (it orders against the null stream).
 hipError_t svo_stream_create_masked(hipStream_t* st, int device, int percent) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void)hipGetLastError(); return svo_stream_create(st, -1); }

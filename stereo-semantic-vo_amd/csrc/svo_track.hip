@@ -1926,9 +1926,9 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
     // The front end of a batched call runs beside the ordered tail, and its kernels are large enough to fill every CU: the
     // tail's small dependent kernels (100 single-wave RANSAC workgroups that want a CU's float64 pipe each) then queue for
     // slots and run at a fraction of their speed - 7 us per frame on average (tools/option_sweep.py: 13.2 k frames/s with the
-    // front end on all CUs, 14.1 k on a quarter of them, 14.4 k on one XCD; stream priorities did not change that).  So the
-    // batched tracker's front-end stream is confined to a share of the compute units (whole XCDs, default one of eight): the
-    // front end needs ~7 us per pair on the whole chip against the tail's ~70 us per frame - one XCD keeps up.
+    // front end on all CUs, 14.1 k on a quarter of them, 14.4 k on 32 CUs; stream priorities did not change that).  So the
+    // batched tracker's front-end stream is confined to a share of the compute units (default an eighth: four CUs of every XCD): the
+    // front end needs ~7 us per pair on the whole chip against the tail's ~70 us per frame - an eighth of the chip keeps up.
     if (!ctx->stream_fe_batch)
       SVO_HIP(ctx, ctx->opt_fe_cu_percent < 100 ? svo_stream_create_masked(&ctx->stream_fe_batch, ctx->device, ctx->opt_fe_cu_percent)
                                                 : svo_stream_create(&ctx->stream_fe_batch, -1));

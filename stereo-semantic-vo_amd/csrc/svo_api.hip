@@ -313,7 +313,8 @@ extern "C" void svo_destroy(svo_ctx* ctx) {
 // svo_track_batch_dev leaves its tail in flight and lets the next call's front end run beside it (two alternating output sets,
 // two halves of the work records).  Any OTHER entry that touches the streams, the result arrays or the options they were
 // enqueued under first waits for those tails - the overlap is a contract between consecutive batch calls only.
-int svo_track_quiesce(svo_ctx* ctx) {
+int svo_track_quiesce(svo_ctx* ctx, bool shard_too) {
+  if (shard_too) { const int rcs = svo_shard_quiesce(ctx); if (rcs) return rcs; }
   bool pending = false;
   for (int q = 0; q < 2; ++q) {
     if (!ctx->tb_used[q] || !ctx->tb_done[q]) continue;

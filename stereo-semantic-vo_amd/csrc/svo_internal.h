@@ -114,6 +114,7 @@ struct svo_ctx {
   bool tb_used[2] = {false, false};
   int tb_parity = 0;
   void* d_work = nullptr;       // TrackWork records (index chain -> pose chain), work_cap of them
+  hipEvent_t shard_wait = nullptr;   // borrowed: the gather event of the sharded tracker call that last read this context's result arrays
   void* d_gate_pre = nullptr;   // GatePre records (brute-force matches + F solved ahead of the index chain), like d_work
   bool hyp_two_launch = false;  // set by an entry for the duration of its tail_enqueue calls: RANSAC samples as 16 + (those the bound can reach)
   int opt_dense_two_launch = 0; // depth_source = 1: the tail beside the dense stage uses the two-launch RANSAC (fewer CUs taken from ELAS)
@@ -216,7 +217,8 @@ __host__ __device__ inline T* svo_byte_offset(T* p, size_t bytes) {
 // Streams by role: +1 the ordered tail's chains (small dependent kernels whose workgroups must not queue behind the front end's
 // thousands), -1 the batched front end running beside it, 0 everything else.  Maps onto the device's stream-priority range.
 hipError_t svo_stream_create(hipStream_t* st, int role);
-int svo_track_quiesce(svo_ctx* ctx);
+int svo_track_quiesce(svo_ctx* ctx, bool shard_too = true);   // waits for what overlapped tracker calls left in flight and may still read this context's arrays
+int svo_shard_quiesce(svo_ctx* ctx);   // svo_track.hip: the sharded tracker's part of that
 int svo_elas_batch_dev_hooked(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d_R, int stride, int W, int H, int B,
                               const svo_elas_params* params, float* d_D1, float* d_D2, int32_t* produced,
                               int (*hook)(void*, int, int), void* user);   // svo_elas.hip   // wait for the tails svo_track_batch_dev left in flight (svo_api.hip)

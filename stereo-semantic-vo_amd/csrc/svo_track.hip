@@ -1755,6 +1755,7 @@ extern "C" int svo_track_multi_step_dev(svo_ctx* ctx, const uint8_t* d_grayL, co
     return SVO_E_INVALID;
   }
   hipSetDevice(ctx->device);
+  { const int rcs = svo_shard_quiesce(ctx); if (rcs) return rcs; }   // (a sharded call of this context may still be in flight: staging sets, work records)
   int rc;
   if (ctx->opt_multi_pipeline) {
     // Pipelined steps (svo_set_option("multi_pipeline", 1)): the front end is stateless, so step t + 1's may run while
@@ -1832,6 +1833,7 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
   if (B > ctx->max_batch) return SVO_E_CAPACITY;
   if (!ctx->d_track || ctx->n_seq != 1) return SVO_E_INVALID;
   hipSetDevice(ctx->device);
+  { const int rcs = svo_shard_quiesce(ctx); if (rcs) return rcs; }   // (a sharded call of this context may still be in flight: staging sets, work records)
   int rc;
   if (ctx->opt_depth_source == 1) {
     // BASELINE configs[4] as a pipeline: the dense front end (ORB on the left images, ELAS maps, the reference's per-keypoint
@@ -2007,6 +2009,7 @@ extern "C" int svo_track_tail_dev(svo_ctx* ctx, const svo_kp* d_kp, const uint8_
   if (!ctx || !d_kp || !d_desc || !d_n || !d_depth || !d_results || B < 1 || kp_stride < 1) return SVO_E_INVALID;
   if (!ctx->d_track || ctx->n_seq != 1) return SVO_E_INVALID;   // svo_track_reset first
   hipSetDevice(ctx->device);
+  { const int rcs = svo_shard_quiesce(ctx); if (rcs) return rcs; }   // (a sharded call of this context may still be in flight: staging sets, work records)
   int rc = tail_enqueue(ctx, d_kp, d_desc, d_n, d_depth, kp_stride, B, 1, d_results, boxes);
   if (rc) return rc;
   ctx->track_frame += B;
@@ -2138,6 +2141,7 @@ struct ShardGather {
   hipEvent_t done[2] = {nullptr, nullptr};   // the pose chain finished with staging set / work half p
   bool used[2] = {false, false};
   int parity = 0;
+  std::vector<svo_ctx*> producers;    // contexts whose shard_wait points at ev_gathered
   uint8_t* h_stage = nullptr;         // pinned bounce buffer for contexts whose device the tail's device cannot read directly
   size_t h_bytes = 0;
   std::vector<int> row_of_frame;
@@ -2162,9 +2166,15 @@ static void shard_gather_buffers_free(ShardGather* g) {
 }
 static void shard_gather_free(svo_ctx* ctx) {
   std::lock_guard<std::mutex> lock(g_gathers_mu);
+  for (auto& pr : g_gathers) {   // a context that goes away is nobody's producer any more
+    auto& v = pr.second->producers;
+    v.erase(std::remove(v.begin(), v.end(), ctx), v.end());
+  }
+  ctx->shard_wait = nullptr;
   for (size_t i = 0; i < g_gathers.size(); ++i)
     if (g_gathers[i].first == ctx) {
       ShardGather* g = g_gathers[i].second;
+      for (svo_ctx* pc : g->producers) if (pc->shard_wait == g->ev_gathered) pc->shard_wait = nullptr;
       shard_gather_buffers_free(g);
       for (hipEvent_t e : g->ev) hipEventDestroy(e);
       if (g->ev_prev) hipEventDestroy(g->ev_prev);
@@ -2177,6 +2187,27 @@ static void shard_gather_free(svo_ctx* ctx) {
       g_gathers.erase(g_gathers.begin() + i);
       return;
     }
+}
+
+// What a sharded call left in flight and may still read of this context: as a producer, the gather of its result arrays (and of
+// the bounce buffer); as the tail context, the pose chains of the last two calls (staging sets, work records) - other entry
+// points of the context wait for them (svo_track_quiesce).
+int svo_shard_quiesce(svo_ctx* ctx) {
+  if (ctx->shard_wait) {
+    hipEvent_t e = ctx->shard_wait;
+    ctx->shard_wait = nullptr;
+    SVO_HIP(ctx, hipEventSynchronize(e));
+  }
+  ShardGather* sg = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_gathers_mu);
+    for (auto& pr : g_gathers)
+      if (pr.first == ctx) sg = pr.second;
+  }
+  if (sg)
+    for (int q = 0; q < 2; ++q)
+      if (sg->used[q] && sg->done[q]) SVO_HIP(ctx, hipEventSynchronize(sg->done[q]));
+  return SVO_OK;
 }
 
 extern "C" int svo_track_sharded_dev(svo_ctx* const* ctxs, int G, const uint8_t* const* d_grayL, const uint8_t* const* d_grayR,
@@ -2313,7 +2344,7 @@ extern "C" int svo_track_sharded_dev(svo_ctx* const* ctxs, int G, const uint8_t*
     own[g] = Own{c->d_kp, c->d_desc, c->d_nkp, c->d_uR, c->d_depth, c->d_sad, c->stream};
     if ((B - g + G - 1) / G <= 0) continue;
     hipSetDevice(c->device);
-    { const int rcq = svo_track_quiesce(c); if (rcq) { hipSetDevice(c0->device); return rcq; } }   // (a batched call of this context may still read its result arrays)
+    { const int rcq = svo_track_quiesce(c, false); if (rcq) { hipSetDevice(c0->device); return rcq; } }   // (a batched call of this context may still read its result arrays; its own earlier calls are ordered by the stream waits below)
     fsv[g] = confined[g] ? c0->stream_fe_batch : c->stream;
     bool waited = false;   // (contexts that share a stream: one wait is enough)
     for (int q = 0; q < g; ++q) waited = waited || fsv[q] == fsv[g];
@@ -2393,6 +2424,10 @@ extern "C" int svo_track_sharded_dev(svo_ctx* const* ctxs, int G, const uint8_t*
                     nullptr, true);
   if (rc) return rc;
   SVO_HIP(c0, hipEventRecord(sg->done[p], c0->stream));   // the pose chain is the last reader of this set
+  for (int g = 0; g < G; ++g) {
+    ctxs[g]->shard_wait = sg->ev_gathered;
+    if (std::find(sg->producers.begin(), sg->producers.end(), ctxs[g]) == sg->producers.end()) sg->producers.push_back(ctxs[g]);
+  }
   sg->used[p] = true;
   sg->parity ^= 1;
   c0->track_frame += B;

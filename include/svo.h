@@ -386,7 +386,11 @@ int svo_track_tail_dev(svo_ctx* ctx, const svo_kp* d_kp, const uint8_t* d_desc, 
  * `stride` bytes per row.  All contexts: same W, H, max_kp; ctxs[g] needs max_batch >= ceil(B / G).  svo_track_reset on
  * ctxs[0] first; B frames per call; d_results: B records on ctxs[0]'s device.  Records are identical to
  * svo_track_batch_dev on a single context.  boxes (may be NULL): frame k's detection boxes, on ctxs[0]'s device.
- * Does not synchronise (svo_sync(ctxs[0]) does). */
+ * Does not synchronise (svo_sync(ctxs[0]) does), and consecutive calls overlap: a call's front ends run in sub-batches on
+ * streams other than the pose chain's, a gather stream on ctxs[0]'s device collects them into one of two staging sets, and
+ * the front ends of the next call run while this call's tail is in flight (two contexts on one GPU: the tail's own period,
+ * 115 us per frame).  The images, boxes and result records of a call must stay valid until svo_sync(ctxs[0]); any other
+ * entry point of one of the contexts first waits for what these calls left in flight. */
 int svo_track_sharded_dev(svo_ctx* const* ctxs, int G, const uint8_t* const* d_grayL, const uint8_t* const* d_grayR,
                           int stride, int B, const svo_boxes_dev* boxes, svo_track_result* d_results);
 /* Sticky capacity flag of the device tracker (synchronises): *flag != 0 once a frame needed more than the 4096 live

@@ -21,6 +21,8 @@ for k, v in legs.items():                       # traffic counters only (FETCH_S
         v["_pairs_per_dispatch_traffic"] = 32
     out[k] = v
 for k, v in track.items():                      # the tail kernels (and the front end at 32 pairs per dispatch)
+    if k.startswith("k_probe_"):                # (the stream probe of the first tracker call)
+        continue
     if k in FRONT:
         v["_pairs_per_dispatch_traffic"] = 32
     out[k] = v

@@ -1161,6 +1161,11 @@ __global__ __launch_bounds__(64) void k_tp_hyp_ord(TrackState* st, TrackWork* wo
   }
   __syncthreads();
   const double K[4] = {(double)st->cam.fx, (double)st->cam.fy, (double)st->cam.cx, (double)st->cam.cy};
+  if (sample == 0) {   // the frame kernel's copy of the correspondences (it skips its own gather: k_tp_frame, `pre_gathered`)
+    for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) st->Xw[i] = S.Xw[i];
+    for (int i = threadIdx.x; i < 2 * n; i += blockDim.x) st->obs[i] = S.uv[i];
+    if (threadIdx.x < 4) st->K[threadIdx.x] = K[threadIdx.x];
+  }
   const long long t_gather = clock64();
   pnp_hyp_ord_wave(S.ord, S.Xw, S.uv, n, K, subsets + (size_t)min(n, 512) * 500, st->hyp, sample, force_seq != 0);
   if (threadIdx.x == 0 && S.ord.S.flag) atomicAdd(&st->epnp_fallbacks, 1);
@@ -1180,6 +1185,7 @@ struct TpLds {
   alignas(16) int sm[16];
   float sT[16], sRwc[9], stwc[3];
   int cnt[PNP_HYP], ok[PNP_HYP], upd_r[PNP_HYP], best, good, iters;
+  int recf[8];   // the record's counters, fetched at the kernel's start
   double upd_ld[PNP_HYP];
 };
 
@@ -1189,7 +1195,7 @@ struct TpLds {
 #define TPF_NT 256
 __global__ __launch_bounds__(TPF_NT) void k_tp_frame(TrackState* st, TrackWork* work, const svo_kp* kp,
                                                   const float* depth, svo_track_result* res_out, int kstride,
-                                                  int use_mfma, int tag) {
+                                                  int use_mfma, int tag, int pre_gathered) {
   TpLds& S = *reinterpret_cast<TpLds*>(tk_smem);
   st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
   depth += (size_t)blockIdx.y * kstride; res_out += blockIdx.y;
@@ -1201,8 +1207,27 @@ __global__ __launch_bounds__(TPF_NT) void k_tp_frame(TrackState* st, TrackWork* 
   // (this thread's first correspondence with the header, in one round trip: see k_tp_hyp)
   const int gid0 = ld_agent(&work->edge_gid[tid]), j0 = min(max(ld_agent(&work->edge_kp[tid]), 0), kstride - 1);
   float* gpos = st->gpos;
+  // what the end of the kernel needs and the pose does not decide, requested now (one round trip to the coherent level beside
+  // the work below instead of a chain of them behind the LM): the record's counters, and this thread's share of the keypoints
+  // that become map points
+  if (tid >= 64 && tid < 71) {
+    const int* src = tid == 64 ? &work->n_stereo : tid == 65 ? &work->n_pass1 : tid == 66 ? &work->n_pass2 : tid == 67 ? &work->n_new
+                   : tid == 68 ? &work->n_local : tid == 69 ? &work->diag[0] : &work->diag[1];
+    S.recf[tid - 64] = ld_agent(src);
+  }
+  constexpr int NEWS = (TRK_MAXKP + TPF_NT - 1) / TPF_NT;
+  int new_g[NEWS]; svo_kp new_k[NEWS]; float new_d[NEWS];
+#pragma unroll
+  for (int q = 0; q < NEWS; ++q) {
+    const int j = tid + q * TPF_NT;
+    new_g[q] = ld_agent(&work->new_gid[min(j, TRK_MAXKP - 1)]);   // (entries beyond nkp are stale: dropped below)
+    new_k[q] = kp[min(j, kstride - 1)];
+    new_d[q] = depth[min(j, kstride - 1)];
+  }
   // ---- 3D-2D correspondences, ordered by keypoint index (src/pnpmatch.cc:216-224) ---------------
-  for (int e = tid; e < n_edges; e += TPF_NT) {
+  // (with pre_gathered, frames the RANSAC kernel ran on arrive with st->Xw / obs / K filled in by its first workgroup)
+  const bool have_corr = pre_gathered && !skip && n_edges >= 5 && id != 0;
+  for (int e = tid; e < (have_corr ? 0 : n_edges); e += TPF_NT) {
     const int j = e == tid ? j0 : ld_agent(&work->edge_kp[e]);
     const svo_kp k = kp[j];
     float* gp = gpos + 3 * (size_t)((e == tid ? gid0 : ld_agent(&work->edge_gid[e])) & (TRK_GPOS - 1));
@@ -1217,7 +1242,7 @@ __global__ __launch_bounds__(TPF_NT) void k_tp_frame(TrackState* st, TrackWork* 
     st->Xw[3 * e] = (double)xyz[0]; st->Xw[3 * e + 1] = (double)xyz[1]; st->Xw[3 * e + 2] = (double)xyz[2];
     st->obs[2 * e] = (double)k.x; st->obs[2 * e + 1] = (double)k.y;
   }
-  if (tid < 4) st->K[tid] = (double)((const float*)&st->cam)[tid];
+  if (tid < 4 && !have_corr) st->K[tid] = (double)((const float*)&st->cam)[tid];
   // ---- PnP initial pose (src/pnpmatch.cc:212-247): no prior; if solvePnPRansac fails the last pose stays ----------
   const bool ran = !skip && n_edges >= 5;
   if (ran)
@@ -1269,30 +1294,30 @@ __global__ __launch_bounds__(TPF_NT) void k_tp_frame(TrackState* st, TrackWork* 
     S.stwc[tid] = (float)(-acc);
   }
   __syncthreads();
-  for (int j = tid; j < nkp; j += TPF_NT) {
-    const int g = ld_agent(&work->new_gid[j]);
+#pragma unroll
+  for (int q = 0; q < NEWS; ++q) {
+    const int g = tid + q * TPF_NT < nkp ? new_g[q] : -1;
     if (g < 0) continue;
-    const svo_kp k = kp[j];
     float xyz[3];
-    tk_unproject(st->cam, k.x, k.y, depth[j], S.sRwc, S.stwc, xyz);
+    tk_unproject(st->cam, new_k[q].x, new_k[q].y, new_d[q], S.sRwc, S.stwc, xyz);
     float* gp = gpos + 3 * (size_t)(g & (TRK_GPOS - 1));
     gp[0] = xyz[0]; gp[1] = xyz[1]; gp[2] = xyz[2];
   }
   if (tid == 0) {
     svo_track_result r;
     for (int i = 0; i < 16; ++i) { r.Tcw[i] = S.sT[i]; st->lastTcw[i] = S.sT[i]; }
-    r.frame_id = id; r.n_kp = nkp; r.n_stereo = ld_agent(&work->n_stereo);
-    r.n_match_pass1 = ld_agent(&work->n_pass1); r.n_match_pass2 = ld_agent(&work->n_pass2);
+    r.frame_id = id; r.n_kp = nkp; r.n_stereo = S.recf[0];
+    r.n_match_pass1 = S.recf[1]; r.n_match_pass2 = S.recf[2];
     r.n_pnp_inliers = skip ? 0 : st->pnp.n_inliers;
     r.n_lm_edges = n_edges;
-    r.n_new_mappoints = ld_agent(&work->n_new);
-    r.n_local_map = ld_agent(&work->n_local);
+    r.n_new_mappoints = S.recf[3];
+    r.n_local_map = S.recf[4];
     r.lm_iterations = st->lm.iterations;
     // diagnostics: rows of pass 1 / pass 2 that could match at all.  (The ROUNDS a pass took are not part of the record: a
     // dense row may or may not see a claim made earlier in the same phase - the outcome is the same either way, the
     // number of rounds is not, and records are compared byte for byte.  svo_debug_track_frames reports them.)
-    r.reserved[0] = ld_agent(&work->diag[0]) & 0xffff;
-    r.reserved[1] = ld_agent(&work->diag[1]) & 0xffff;
+    r.reserved[0] = S.recf[5] & 0xffff;
+    r.reserved[1] = S.recf[6] & 0xffff;
     *res_out = r;
     st->pose_ts[8] = tf0; st->pose_ts[9] = tf1; st->pose_ts[10] = tf2; st->pose_ts[11] = clock64();
     work->rt[3] = wall_clock64();
@@ -1581,7 +1606,7 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
     {
       SvoTimer t(ctx, "k_tp_frame");
       hipLaunchKernelGGL(k_tp_frame, dim3(1, ny), dim3(TPF_NT), sizeof(TpLds), s0, st, work + f, kpf, depf, d_res + f, kstride,
-                         ctx->opt_pose_mfma, tag_of(f));
+                         ctx->opt_pose_mfma, tag_of(f), ctx->opt_epnp_exact == 2 ? 1 : 0);
     }
   };
   // The pose chain takes the frames over in groups: ONE event (a barrier packet on the pose stream, ~3 us even when long

@@ -949,8 +949,8 @@ int svo_msa_run_dev(svo_ctx* ctx, const uint8_t* dL, const uint8_t* dR, int pitc
 // threads, then every stage of the aggregation once for the whole chunk - the level sweeps as one launch per level for
 // all frames, the per-pixel stages over the C maps stacked into one tall image.
 // `lane` (0 / 1) selects the device arena and host store; with two lanes alternating over the chunks, host_phase is held
-// from the first kernel to the last tree and gpu_phase from the tree upload to the end, so that the trees of one chunk
-// grow while the GPU aggregates the previous one.
+// over the tree builders and gpu_phase from the tree upload to the end, so that the trees of one chunk grow while the GPU
+// aggregates the previous one and initialises the next.
 static int msa_many_device(svo_ctx* ctx, hipStream_t s, const uint8_t* dL, const uint8_t* dR, int pitch, size_t frame_stride,
                            int m, int n, int d, int C, float* d_disp_out, int lane, std::mutex* host_phase,
                            std::mutex* gpu_phase) {
@@ -963,8 +963,8 @@ static int msa_many_device(svo_ctx* ctx, hipStream_t s, const uint8_t* dL, const
   };
   const int D = d + 1;
   const size_t N = (size_t)n * m, V = N * D;
-  std::unique_lock<std::mutex> host_lock;
-  if (host_phase) host_lock = std::unique_lock<std::mutex>(*host_phase);
+  std::unique_lock<std::mutex> host_lock;   // taken for the tree builders only (below): a lane's init kernels and downloads - its own
+  // arena, its own host store - run while the other lane builds its trees
   DevBuf& buf = msa_arena(ctx, 1 + lane);
   uint8_t* img3[2] = {buf.get<uint8_t>(3 * N), buf.get<uint8_t>(3 * N)};
   uint8_t* med3[2] = {buf.get<uint8_t>(3 * N), buf.get<uint8_t>(3 * N)};
@@ -1020,6 +1020,7 @@ static int msa_many_device(svo_ctx* ctx, hipStream_t s, const uint8_t* dL, const
   }
   SVO_HIP(ctx, hipStreamSynchronize(s));
   mark("init + download");
+  if (host_phase) host_lock = std::unique_lock<std::mutex>(*host_phase);
   // 2. the 2C trees, on as many host threads as are sensible (tree 2b: left image of frame b, 2b + 1: right)
   std::vector<HostTree>& tree = hs.tree;
   {

@@ -1496,6 +1496,8 @@ extern "C" void svo_elas_release(svo_ctx* ctx) {
     delete reinterpret_cast<ElasBatch*>(ctx->elas_batch);
     ctx->elas_batch = nullptr;
   }
+  if (ctx->stream_elas_a) { hipStreamSynchronize(ctx->stream_elas_a); hipStreamDestroy(ctx->stream_elas_a); ctx->stream_elas_a = nullptr; ctx->stream_elas_a_pct = -1; }
+  if (ctx->ev_elas_setup) { hipEventDestroy(ctx->ev_elas_setup); ctx->ev_elas_setup = nullptr; }
 }
 
 // Device-resident entry used by the tracker (svo_track.hip): images already in HBM, maps stay in HBM.
@@ -1571,14 +1573,40 @@ int svo_elas_batch_dev_hooked(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d
   SVO_HIP(ctx, hipMemcpyAsync(eb->d_tab, eb->h_tab, sizeof(ElasTab) * (size_t)B, hipMemcpyHostToDevice, s));
   SVO_HIP(ctx, hipMemcpyAsync(eb->d_P, P, sizeof P, hipMemcpyHostToDevice, s));
   SVO_HIP(ctx, hipMemsetAsync(eb->d_can, 0, sizeof(int16_t) * (size_t)B * wh, s));   // lattice row 0 / column 0 stay 0
+  // Phase A of the chunks (descriptors + support matching: arithmetic-bound, 0.6 ms per 32 pairs) runs on a stream of its own
+  // beside phase B of the earlier chunks (1.8 ms, half of it latency-bound kernels: rasterisation by atomics, segment
+  // labelling in strips, gap interpolation) - on one stream the GPU ran them one after the other (2.4 ms per chunk of the
+  // 2.9 ms a chunk takes).  Nothing is shared between the phases of different chunks: slots, candidates and table rows are per
+  // pair.  (10.6 k -> 11.2 k pairs/s.)  Not beside the tracker's tail (svo_track_batch_dev with depth_source = 1 runs the dense
+  // stage on a CU-confined stream): two streams keep that share of the CUs busy without a gap and the tail's single-wave
+  // RANSAC workgroups that land there wait - 6.4 k -> 5.6 k frames/s, the effect svo_track_sharded_dev met with two
+  // confined front-end streams.
+  hipStream_t sA = s;
+  {
+    static const bool one = []() { const char* e = getenv("SVO_ELAS_ONE_STREAM"); return e && e[0] == '1'; }();
+    if (!one && !(ctx->stream_dense && s == ctx->stream_dense)) {
+      const int pct = 0;
+      if (ctx->stream_elas_a && ctx->stream_elas_a_pct != pct) {
+        hipStreamSynchronize(ctx->stream_elas_a); hipStreamDestroy(ctx->stream_elas_a); ctx->stream_elas_a = nullptr;
+      }
+      if (!ctx->stream_elas_a) {
+        SVO_HIP(ctx, pct ? svo_stream_create_masked(&ctx->stream_elas_a, ctx->device, pct) : svo_stream_create(&ctx->stream_elas_a, 0));
+        ctx->stream_elas_a_pct = pct;
+      }
+      if (!ctx->ev_elas_setup) SVO_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_elas_setup, hipEventDisableTiming));
+      sA = ctx->stream_elas_a;
+      SVO_HIP(ctx, hipEventRecord(ctx->ev_elas_setup, s));          // the table, the candidates' memset, whatever produced the images
+      SVO_HIP(ctx, hipStreamWaitEvent(sA, ctx->ev_elas_setup, 0));
+    }
+  }
 
   auto enqueue_a = [&](int c) -> int {   // descriptors + lattice candidates of the chunk, candidates on their way back
     const int b0 = c * C, nb = std::min(C, B - b0);
-    int r = elas_phase_a(ctx, s, eb->d_tab + b0, nb, stride, W, H, Wc, Hc, p);
+    int r = elas_phase_a(ctx, sA, eb->d_tab + b0, nb, stride, W, H, Wc, Hc, p);
     if (r) return r;
     SVO_HIP(ctx, hipMemcpyAsync(eb->h_can + (size_t)b0 * wh, eb->d_can + (size_t)b0 * wh, sizeof(int16_t) * (size_t)nb * wh,
-                                hipMemcpyDeviceToHost, s));
-    SVO_HIP(ctx, hipEventRecord(evA[c], s));
+                                hipMemcpyDeviceToHost, sA));
+    SVO_HIP(ctx, hipEventRecord(evA[c], sA));
     return SVO_OK;
   };
 
@@ -1682,6 +1710,7 @@ int svo_elas_batch_dev_hooked(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d
     SVO_HIP(ctx, hipMemcpyAsync(eb->d_lists + chunk_off, eb->h_lists + chunk_off, (lists_used - chunk_off) * sizeof(int32_t),
                                 hipMemcpyHostToDevice, s));
     t_sync_copy += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count();
+    if (sA != s) SVO_HIP(ctx, hipStreamWaitEvent(s, evA[c], 0));   // (long signalled: the host stage of the chunk came after it)
     SVO_HIP(ctx, hipMemcpyAsync(eb->d_tab + b0, eb->h_tab + b0, sizeof(ElasTab) * (size_t)nb, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_elas_clear, dim3((unsigned)((nd + 255) / 256), (unsigned)nb), dim3(256), 0, s, eb->d_tab + b0, (int)nd,
                        gw * gh * 8);
@@ -1733,6 +1762,7 @@ int svo_elas_batch_dev_hooked(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d
     cv_go.notify_all();
   }
   for (std::thread& t : pool) t.join();
+  if (sA != s) hipStreamSynchronize(sA);
   hipStreamSynchronize(s);   // the pinned table and list arena are read by copies until here
   if (dbg) {
     fprintf(stderr, "   delaunay per call: sort pts %.0f us, build %.0f, emit %.0f, sort triangles %.0f; points %.0f\n", (double)svo_delaunay_us[0] / (2 * B), (double)svo_delaunay_us[1] / (2 * B), (double)svo_delaunay_us[2] / (2 * B), (double)svo_delaunay_us[3] / (2 * B), (double)svo_delaunay_pts / (2 * B));

@@ -114,6 +114,9 @@ struct svo_ctx {
   bool tb_used[2] = {false, false};
   int tb_parity = 0;
   void* d_work = nullptr;       // TrackWork records (index chain -> pose chain), work_cap of them
+  hipStream_t stream_elas_a = nullptr;   // svo_elas_batch_dev: phase A (descriptors, support candidates) of the next chunks, beside phase B of the earlier ones
+  int stream_elas_a_pct = -1;            //   the share of the CUs it was made for (0: all; as the stream phase B runs on)
+  hipEvent_t ev_elas_setup = nullptr;
   hipEvent_t shard_wait = nullptr;   // borrowed: the gather event of the sharded tracker call that last read this context's result arrays
   void* d_gate_pre = nullptr;   // GatePre records (brute-force matches + F solved ahead of the index chain), like d_work
   bool hyp_two_launch = false;  // set by an entry for the duration of its tail_enqueue calls: RANSAC samples as 16 + (those the bound can reach)

@@ -1215,6 +1215,13 @@ def main():
             rep = oracle_run.report(res)
             out["cpu_baseline"]["all_frames_tail"] = rep
             out["cpu_baseline"]["counters_identical_to_gpu"] = rep.get("counters_identical_to_gpu")
+            try:   # where the CPU port's time goes: the ordered tail alone (all frames) against the full loop (the 64-frame sample)
+                tail_s = float(rep["seconds"]) / max(int(rep["frames"]), 1)
+                full_s = 1.0 / out["cpu_baseline"]["value"]
+                out["cpu_baseline"]["cpu_seconds_per_frame"] = {"full_loop": full_s, "ordered_tail": tail_s,
+                                                                "front_end_share": max(0.0, 1.0 - tail_s / full_s)}
+            except Exception:  # noqa: BLE001
+                pass
             if "ate_vs_cpu_m" in rep:
                 out["ate_vs_cpu_m"] = rep["ate_vs_cpu_m"]
         if legs and not args.no_elas_leg:

@@ -191,7 +191,10 @@ void svo_destroy(svo_ctx* ctx);
  *   0 = statistical wave solver (csrc/svo_epnp_dev.h; the default up to round 3): parallel-order two-sided Jacobi, normal
  *       equations, FMA - the same estimator with another rounding; 1.65x faster than mode 2, RANSAC's winner differs from a
  *       CPU run on ~3 % of the frames.
- * "epnp_force_seq" (default 0, tests): 1 = mode 2 takes its sequential fallback for every sample. */
+ * "epnp_force_seq" (default 0, tests): 1 = mode 2 takes its sequential fallback for every sample.
+ * "dense_two_launch" (default 0): svo_track_batch_dev with depth_source = 1: the tail beside the dense stage launches its RANSAC
+ *   samples as in the many-sequence mode (see "hyp_first") - fewer CUs taken from ELAS on ordinary frames.  Measured: no gain
+ *   (6.4 k -> 6.2 k frames/s); kept as a switch.  Same records. */
 int svo_set_option(svo_ctx* ctx, const char* key, int value);
 /* Block until everything enqueued on the ctx stream has finished. */
 int svo_sync(svo_ctx* ctx);

@@ -537,7 +537,7 @@ def frontend_leg(pkg, cam, dL, dR, n_frames, frame_bytes, dev, all_cores):
                                          "achieved": out["value"] * instr_per_pair / 1e9, "unit": "G wave-instructions/s",
                                          "frac": out["value"] * instr_per_pair / peak, "valu_instructions_per_pair": instr_per_pair,
                                          "pairs_per_s_at_peak": peak / instr_per_pair,
-                                         "source": "profiles/pmc_latest.json (SQ_INSTS_VALU, r03_e front-end passes: these kernels are unchanged since)"}
+                                         "source": "profiles/pmc_latest.json (SQ_INSTS_VALU of profiles/r04_z_frontend_pmc.json)"}
     except Exception:  # noqa: BLE001
         pass
     if all_cores is not None:

@@ -163,10 +163,10 @@ void svo_destroy(svo_ctx* ctx);
  * tail's small dependent kernels then queue for slots (7 us per frame on average); the front end needs a tenth of the tail's
  * time on the whole chip, so an eighth of it keeps up (measured: 100 % 13.2 k, 25 % 14.1 k, 12 % 14.4 k frames/s).  Scheduling only -
  * same records.
- * "dense_cu_percent" (default 75, 10..100): the same for the dense front end's stream of svo_track_batch_dev with
+ * "dense_cu_percent" (default 88 = seven eighths of the CUs, 10..100): the same for the dense front end's stream of svo_track_batch_dev with
  * depth_source = 1 (ORB + ELAS maps + depth lookups, in chunks, beside the tail of the earlier chunks): ELAS needs most of the chip,
  * the tail's 100 single-wave RANSAC workgroups need free CUs (measured with boxes, 256 frames per call: 100 % 5.4 k, 75 % 6.4 k,
- * 50 % 5.3 k frames/s).  Scheduling only - same records.
+ * 50 % 5.3 k frames/s; with the later 16-pair chunks: 75 % 6.7-6.8 k, 88 % 6.9 k, 100 % 6.0 k).  Scheduling only - same records.
  * "hyp_first" (default 8; 4, 8, 12 or 16): many sequences per step (svo_track_multi_step_dev): RANSAC samples per sequence in the
  * step's first launch; the second launch holds as many again, the third the rest, and their workgroups leave at once when
  * cv::solvePnPRansac's adaptive iteration bound says the loop never reaches their sample (it visits a median of 4 samples on

@@ -165,7 +165,7 @@ struct svo_ctx {
                            // events.  OFF by default: the poll needs the index kernel to run CONCURRENTLY with the polling one, and a tool that
                            // serialises kernel dispatches (rocprofv3 --kernel-trace does) turns every frame into a timed-out poll
   int opt_epnp_exact = 2;  // svo_set_option("epnp_exact"): 2 = OpenCV's operations with their rounding, spread over a wave per sample (default); 1 = one lane per sample, loop by loop (the checker); 0 = the statistical wave solver
-  int opt_dense_cu_percent = 75;   // svo_track_batch_dev with depth_source 1: share of the CUs the dense front end's stream may use (measured, 256 frames with boxes: 100 % 5.4 k, 88 % 5.7 k, 75 % 6.4 k, 62 % 6.0 k, 50 % 5.3 k frames/s - the tail's single-wave RANSAC workgroups need free CUs, ELAS needs most of the chip)
+  int opt_dense_cu_percent = 88;   // svo_track_batch_dev with depth_source 1: share of the CUs the dense front end's stream may use (measured, 256 frames with boxes: 100 % 5.4 k, 88 % 5.7 k, 75 % 6.4 k, 62 % 6.0 k, 50 % 5.3 k frames/s - the tail's single-wave RANSAC workgroups need free CUs, ELAS needs most of the chip)
   int opt_shard_force_staged = 0;  // svo_track_sharded_dev gathers through pinned host memory even where a peer read exists (tests; env SVO_SHARD_FORCE_STAGED is read once, at svo_create)
   int opt_epnp_force_seq = 0;  // tests: mode 2 takes its sequential fallback for every sample
   bool profiling = false;

@@ -607,7 +607,49 @@ struct HostTree {                       // what svo_msa_tree returns, plus what 
   std::vector<uint8_t> child_c, parent_c;
   int32_t root = -1;
   int rc = SVO_OK;
+  // What k_msa_dp_bfs needs - the records by level-order position, the level boundaries, the widest level - in ONE pass over
+  // the breadth-first sequence: `seq` IS the level order (a node's children sit at consecutive positions right after those of
+  // the nodes before it), so a node's position, its parent's position and its depth are known when its parent is visited.
+  // The by-pixel arrays of the level-launch fallback (nodes, parent, parent_c) are left to levels_full(); bfs_ok = false
+  // sends the caller there (cannot happen for a breadth-first seq).  Round 4: the five passes of levels_full() were 12 % of a
+  // tree's host time.
   void levels(int N) {
+    rec.resize(N);
+    ppos_.resize(N); pc_.resize(N); dpos_.resize(N);
+    ppos_[0] = -1; pc_[0] = 0; dpos_[0] = 0;
+    level_ptr.clear(); level_ptr.push_back(0);
+    int cpos = 1, w = 0, level_start = 0;
+    bool ok = true;
+    for (int g = 0; g < N; ++g) {
+      if (g >= cpos) { ok = false; break; }          // position g was never handed out: not a tree in breadth-first order
+      const int u = seq[g], e0 = child_ptr[u], nch = child_ptr[u + 1] - e0;
+      if (dpos_[g] != dpos_[level_start]) {          // first node of the next level
+        w = std::max(w, g - level_start);
+        level_ptr.push_back(g);
+        level_start = g;
+      }
+      if (nch > 255 || cpos + nch > N) { ok = false; break; }
+      for (int j = 0; j < nch; ++j) {
+        if (seq[cpos + j] != child[e0 + j]) { ok = false; break; }
+        ppos_[cpos + j] = g; pc_[cpos + j] = child_c[e0 + j]; dpos_[cpos + j] = dpos_[g] + 1;
+      }
+      if (!ok) break;
+      rec[g] = MsaBfsRec{cpos, (int32_t)pc_[g] | (nch << 8), ppos_[g], u};
+      cpos += nch;
+    }
+    if (ok && cpos == N) {
+      w = std::max(w, N - level_start);
+      level_ptr.push_back(N);
+      maxw = w;
+      bfs_ok = true;
+      full_ = false;
+      return;
+    }
+    levels_full(N);
+  }
+  void need_full(int N) { if (!full_) levels_full(N); }   // the level-launch fallback's arrays, on demand
+  void levels_full(int N) {
+    full_ = true;
     parent.assign(N, -1); parent_c.assign(N, 0);
     std::vector<int32_t>& depth = depth_;
     depth.assign(N, 0);
@@ -631,6 +673,9 @@ struct HostTree {                       // what svo_msa_tree returns, plus what 
   std::vector<MsaBfsRec> rec;   // the tree by level-order position (k_msa_dp_bfs)
   int maxw = 0;                 // widest level
   bool bfs_ok = false;          // children are consecutive in level order (always, for a breadth-first seq)
+  bool full_ = false;           // nodes / parent / parent_c are filled in
+  std::vector<int32_t> ppos_, dpos_;
+  std::vector<uint8_t> pc_;
 };
 
 struct DevTree { int32_t *nodes, *child_ptr, *child, *parent; uint8_t *child_c, *parent_c; };
@@ -744,6 +789,7 @@ static int msa_solve_device(svo_ctx* ctx, hipStream_t s, DevBuf& buf, uint8_t* c
                                side ? d_A1 : d_A};
       continue;
     }
+    tree[side].need_full((int)N);
     SVO_HIP(ctx, hipMemcpyAsync(dt[side].nodes, t.nodes.data(), N * 4, hipMemcpyHostToDevice, s));
     SVO_HIP(ctx, hipMemcpyAsync(dt[side].child_ptr, t.child_ptr.data(), (N + 1) * 4, hipMemcpyHostToDevice, s));
     SVO_HIP(ctx, hipMemcpyAsync(dt[side].child, t.child.data(), (N - 1) * 4, hipMemcpyHostToDevice, s));
@@ -1023,6 +1069,7 @@ static int msa_many_device(svo_ctx* ctx, hipStream_t s, const uint8_t* dL, const
   if (host_phase) host_lock = std::unique_lock<std::mutex>(*host_phase);
   // 2. the 2C trees, on as many host threads as are sensible (tree 2b: left image of frame b, 2b + 1: right)
   std::vector<HostTree>& tree = hs.tree;
+  std::atomic<long long> dbg_tree_us{0}, dbg_levels_us{0};
   {
     std::atomic<int> next(0);
     auto work = [&]() {
@@ -1030,9 +1077,12 @@ static int msa_many_device(svo_ctx* ctx, hipStream_t s, const uint8_t* dL, const
         HostTree& t = tree[k];
         const int b = k >> 1, side = k & 1;
         t.seq.resize(N); t.child_ptr.resize(N + 1); t.child.resize(N); t.child_c.resize(N);
+        const auto ta = std::chrono::steady_clock::now();
         t.rc = svo_msa_tree(h_med[k].data(), h_gra[b].data() + 2 * side * N, h_gra[b].data() + (2 * side + 1) * N, m, n, t.seq.data(),
                             t.child_ptr.data(), t.child.data(), t.child_c.data(), &t.root);
+        const auto tb = std::chrono::steady_clock::now();
         if (t.rc == SVO_OK) t.levels((int)N);
+        if (dbg) { dbg_tree_us += (long long)std::chrono::duration<double, std::micro>(tb - ta).count(); dbg_levels_us += (long long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tb).count(); }
       }
     };
     const int T = std::max(1, std::min(std::min(2 * C, 32), 2 * svo_host_cpus()));   // (measured on a 16-CPU quota: 32 builders 58 frames/s, 16: 51, 64: 36)
@@ -1042,6 +1092,7 @@ static int msa_many_device(svo_ctx* ctx, hipStream_t s, const uint8_t* dL, const
     for (auto& th : pool) th.join();
   }
   mark("trees");
+  if (dbg) fprintf(stderr, "[msa x%d]   per tree (thread time): svo_msa_tree %.1f ms, level records %.1f ms\n", C, dbg_tree_us / 1e3 / (2 * C), dbg_levels_us / 1e3 / (2 * C));
   for (int k = 0; k < 2 * C; ++k)
     if (tree[k].rc) { ctx->last_error = "svo_msa (batched): tree construction failed"; return tree[k].rc; }
   if (host_lock.owns_lock()) host_lock.unlock();
@@ -1069,6 +1120,7 @@ static int msa_many_device(svo_ctx* ctx, hipStream_t s, const uint8_t* dL, const
                                         d_A + (size_t)b * V};
       continue;
     }
+    tree[k].need_full((int)N);
     SVO_HIP(ctx, hipMemcpyAsync(ip, t.nodes.data(), N * 4, hipMemcpyHostToDevice, s));
     SVO_HIP(ctx, hipMemcpyAsync(ip + 2 * N + 2, t.child_ptr.data(), (N + 1) * 4, hipMemcpyHostToDevice, s));
     SVO_HIP(ctx, hipMemcpyAsync(ip + 3 * N + 3, t.child.data(), (N - 1) * 4, hipMemcpyHostToDevice, s));

@@ -32,7 +32,10 @@
 extern "C" {
 #endif
 
-#define SVO_ABI_VERSION 3
+#define SVO_ABI_VERSION 4   /* 4 (round 4): + svo_track_epnp_fallbacks, svo_debug_stream_probe; "epnp_exact" defaults to 2 (the
+                              order-preserving solver); options gate_group, hyp_first, dense_cu_percent, dense_two_launch,
+                              epnp_force_seq, shard_force_staged; svo_track_sharded_dev overlaps consecutive calls.
+                              No signature of version 3 changed. */
 
 typedef enum svo_status {
   SVO_OK = 0,

@@ -35,7 +35,12 @@ extern "C" {
 #define SVO_ABI_VERSION 4   /* 4 (round 4): + svo_track_epnp_fallbacks, svo_debug_stream_probe; "epnp_exact" defaults to 2 (the
                               order-preserving solver); options gate_group, hyp_first, dense_cu_percent, dense_two_launch,
                               epnp_force_seq, shard_force_staged; svo_track_sharded_dev overlaps consecutive calls.
-                              No signature of version 3 changed. */
+                              No signature of version 3 changed.  BEHAVIOUR changes a version-3 caller sees: (i) the tracker's
+                              default RANSAC solver is the bit-comparable one - 8.8 k instead of 14.4 k frames/s on the headline
+                              run, and a sample with a zero / repeated singular value is re-solved sequentially (counted by
+                              svo_track_epnp_fallbacks; "epnp_exact" = 0 restores round 3's solver and rate); (ii) "epnp_exact"
+                              keeps version 3's meaning for every value but 2: any other non-zero value selects the one-lane
+                              checker (mode 1). */
 
 typedef enum svo_status {
   SVO_OK = 0,
@@ -190,7 +195,8 @@ void svo_destroy(svo_ctx* ctx);
  *       wavefront per sample (Jacobi pairs on disjoint rows side by side, k-ordered sums on v_mfma_f64_4x4x4).  Bit-identical,
  *       sample by sample, to the CPU restatement the tests compare with; the rare branches it does not reproduce (a zero or
  *       repeated singular value, 25 sweeps without convergence) are handed to the sequential solver of mode 1.
- *   1 = the same operations, one lane per sample, loop by loop (csrc/svo_epnp_exact_dev.h): the checker of mode 2, 7.5x slower.
+ *   1 (and, as in ABI 3, every non-zero value other than 2) = the same operations, one lane per sample, loop by loop
+ *       (csrc/svo_epnp_exact_dev.h): the checker of mode 2, 7.5x slower.
  *   0 = statistical wave solver (csrc/svo_epnp_dev.h; the default up to round 3): parallel-order two-sided Jacobi, normal
  *       equations, FMA - the same estimator with another rounding; 1.65x faster than mode 2, RANSAC's winner differs from a
  *       CPU run on ~3 % of the frames.

@@ -284,8 +284,16 @@ extern "C" int svo_create(svo_ctx** out, int device, int W, int H, int max_kp, i
 extern "C" void svo_destroy(svo_ctx* ctx) {
   if (!ctx) return;
   hipSetDevice(ctx->device);
+  // Batched and sharded calls leave work in flight that reads this context's buffers from OTHER streams (the tail context's
+  // gather stream and front-end stream when this context is a producer, a peer copy or a bounce through pinned memory):
+  // hipFree's implicit synchronisation does not cover those.  Wait for all of it, then for every stream of the context.
+  (void)svo_track_quiesce(ctx, true);
+  if (ctx->stream_fe_batch) hipStreamSynchronize(ctx->stream_fe_batch);
+  if (ctx->stream_dense) hipStreamSynchronize(ctx->stream_dense);
+  for (hipStream_t st : ctx->fe_streams) hipStreamSynchronize(st);
   if (ctx->stream_idx) hipStreamSynchronize(ctx->stream_idx);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
+  (void)hipGetLastError();
   svo_track_release(ctx);
   svo_elas_release(ctx);
   svo_msa_release(ctx);
@@ -328,7 +336,13 @@ int svo_track_quiesce(svo_ctx* ctx, bool shard_too) {
 
 extern "C" int svo_set_option(svo_ctx* ctx, const char* key, int value) {
   if (!ctx || !key) return SVO_E_INVALID;
-  { const int rcq = svo_track_quiesce(ctx); if (rcq) return rcq; }   // options apply to what is enqueued AFTER this call
+  // Options are read on the host when work is enqueued, so what is already in flight keeps the values it was enqueued under.
+  // Only the two options that REPLACE a stream wait for the tails a batched / sharded call left on it.
+  if (!strcmp(key, "fe_cu_percent") || !strcmp(key, "dense_cu_percent")) {
+    if (value < 10 || value > 100) return SVO_E_INVALID;
+    const int rcq = svo_track_quiesce(ctx);
+    if (rcq) return rcq;
+  }
   if (!strcmp(key, "pose_mfma")) { ctx->opt_pose_mfma = value != 0; return SVO_OK; }
   if (!strcmp(key, "fast_cand_cap")) {
     if (value < 0 || value > 2048) return SVO_E_INVALID;
@@ -352,8 +366,8 @@ extern "C" int svo_set_option(svo_ctx* ctx, const char* key, int value) {
   if (!strcmp(key, "hyp_first")) { if (value < 4 || value > 16 || (value & 3)) return SVO_E_INVALID; ctx->opt_hyp_first = value; return SVO_OK; }
   if (!strcmp(key, "dense_two_launch")) { ctx->opt_dense_two_launch = value != 0; return SVO_OK; }
   if (!strcmp(key, "epnp_exact")) {
-    if (value < 0 || value > 2) return SVO_E_INVALID;
-    ctx->opt_epnp_exact = value;
+    // 0 the statistical solver, 2 the order-preserving one (default); every other value is ABI 3's "non-zero": the one-lane checker
+    ctx->opt_epnp_exact = value == 0 ? 0 : value == 2 ? 2 : 1;
     return SVO_OK;
   }
   if (!strcmp(key, "epnp_force_seq")) { ctx->opt_epnp_force_seq = value != 0; return SVO_OK; }

@@ -70,8 +70,7 @@ def test_many_samples_through_the_native_harness():
     """tools/epnp_ord_check: 4,096 seeded samples at the origin and 4,096 three kilometres away (coplanar ones among them:
     a zero singular value, the sequential fallback), compared bit for bit with the oracle inside the binary."""
     exe = os.path.join(ROOT, "tools", "epnp_ord_check")
-    if not os.path.exists(exe):
-        pytest.skip("tools/epnp_ord_check not built (tools/build_epnp_ord_check.sh)")
+    assert os.path.exists(exe), "tools/epnp_ord_check not built: __graft_entry__.build() (make -C tools) makes it"
     for off in ("0", "3000"):
         out = subprocess.run([exe, "4096", off, "0.5"], capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "mismatches 0 " in out.stdout, out.stdout[-2000:]

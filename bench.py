@@ -989,11 +989,16 @@ def main():
         return
 
     svo = pkg.Svo(W, H, device=local, max_kp=500, max_batch=B + extra)
+    epnp_mode = 2                                        # the library's default: the bit-comparable solver
     if "SVO_BENCH_EPNP" in os.environ:                   # experiments: the headline with another EPnP solver (named in config)
-        svo.set_option("epnp_exact", int(os.environ["SVO_BENCH_EPNP"]))
+        epnp_mode = int(os.environ["SVO_BENCH_EPNP"])
+        svo.set_option("epnp_exact", epnp_mode)
     for kv in filter(None, os.environ.get("SVO_BENCH_OPTIONS", "").split(",")):   # experiments: "track_group=8,..."
         k, v = kv.split("=")
         svo.set_option(k, int(v))
+        if k == "epnp_exact":
+            epnp_mode = int(v)
+    epnp_mode = 0 if epnp_mode == 0 else 2 if epnp_mode == 2 else 1   # (the library's own mapping of the option's values)
     bx = keep_bx = None
     if multi:
         d_res = torch.zeros((nsteps * B, rec), dtype=torch.uint8, device=dev)
@@ -1104,7 +1109,7 @@ def main():
                         "mean_active_rows_pass1_pass2": [float(res["reserved"][1:, 0].mean()), float(res["reserved"][1:, 1].mean())],
                         "mean_local_map": float(res["n_local_map"][1:].mean()),
                         "tracker_capacity_flag": int(svo.track_overflowed()),
-                        "pnp_solver": PNP_SOLVERS[int(os.environ.get("SVO_BENCH_EPNP", "2"))],
+                        "pnp_solver": PNP_SOLVERS[epnp_mode],
                         "pnp_samples_through_sequential_fallback": int(svo.track_epnp_fallbacks())})
             if world == 1 and not multi and not args.no_cpu_baseline and args.depth_source == 0 and not args.boxes:
                 # the oracle's tail over ALL tracked frames, on a host thread while the legs below run

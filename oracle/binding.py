@@ -236,8 +236,9 @@ class Tracker:
         self.W, self.H, self.nf = W, H, nfeatures
         self.h = l.orc_track_create(W, H, nfeatures, cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["bf"])
 
-    def track(self, grayL, grayR, boxes=None, dense=None):
-        """dense: optional H x W float32 disparity map used as the depth source (frame::MB data flow)."""
+    def track(self, grayL, grayR, boxes=None, dense=None, Tcw_force=None):
+        """dense: optional H x W float32 disparity map used as the depth source (frame::MB data flow).
+        Tcw_force: teacher forcing - the frame reports its own pose, the tracker continues from this one."""
         grayL = np.ascontiguousarray(grayL, np.uint8); grayR = np.ascontiguousarray(grayR, np.uint8)
         res = np.zeros(1, TRACK_DTYPE); cur = np.zeros(self.nf, np.int32)
         bx = None if boxes is None or len(boxes) == 0 else np.ascontiguousarray(boxes, np.int32)
@@ -246,6 +247,10 @@ class Tracker:
         l = lib()
         l.orc_track_frame_dense.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                             C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        if Tcw_force is not None:
+            tf = np.ascontiguousarray(Tcw_force, np.float32).reshape(16)
+            l.orc_track_force_pose.argtypes = [C.c_void_p, C.c_void_p]
+            l.orc_track_force_pose(self.h, _p(tf))
         l.orc_track_frame_dense(self.h, _p(grayL), self.W, _p(grayR), self.W, _p(dn), _p(bx),
                                 0 if bx is None else len(bx), _p(res), _p(cur), _p(self.F))
         self.vetoes = l.orc_track_last_vetoes(C.c_void_p(self.h))

@@ -53,6 +53,8 @@ struct orc_tracker {
   float last_xy[TRK_MAXKP][2];        /* LastFrame.keypoints_l[i].pt */
   uint8_t last_desc[TRK_MAXKP * 32];  /* LastFrame.f_descriptor      */
   int last_vetoes;                    /* epipolar vetoes in the frame just tracked */
+  float force_Tcw[16];                /* orc_track_force_pose: teacher forcing for the next whole-frame call */
+  int has_force;
 };
 
 orc_tracker* orc_track_create(int W, int H, int nfeatures, float fx, float fy, float cx, float cy,
@@ -66,6 +68,12 @@ orc_tracker* orc_track_create(int W, int H, int nfeatures, float fx, float fy, f
   return t;
 }
 int orc_track_last_vetoes(const orc_tracker* t) { return t->last_vetoes; }
+/* Teacher forcing for the whole-frame entries (orc_track_frame / _boxes / _dense): the NEXT frame is tracked as always and
+ * reports its own pose, but the tracker then continues from `Tcw` (see orc_track_tail's Tcw_force). */
+void orc_track_force_pose(orc_tracker* t, const float Tcw[16]) {
+  memcpy(t->force_Tcw, Tcw, sizeof t->force_Tcw);
+  t->has_force = 1;
+}
 void orc_track_destroy(orc_tracker* t) {
   if (!t) return;
   free(t->pool);
@@ -131,7 +139,8 @@ int orc_track_frame_dense(orc_tracker* t, const uint8_t* grayL, int strideL, con
     orc_stereo_frame(grayL, strideL, grayR, strideR, t->W, t->H, NF, t->bf, t->fx, kp, desc, &nkp, uR,
                      depth, NULL, NULL, NULL);
   }
-  const int rc = orc_track_tail(t, kp, desc, nkp, depth, boxes, n_boxes, NULL, res, cur_mp_out, F_out, NULL);
+  const int rc = orc_track_tail(t, kp, desc, nkp, depth, boxes, n_boxes, t->has_force ? t->force_Tcw : NULL, res, cur_mp_out, F_out, NULL);
+  t->has_force = 0;
   free(kp); free(desc); free(uR); free(depth);
   return rc;
 }

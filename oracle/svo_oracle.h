@@ -120,6 +120,8 @@ orc_tracker* orc_track_create(int W, int H, int nfeatures, float fx, float fy, f
                               float bf);
 void orc_track_destroy(orc_tracker* t);
 int orc_track_last_vetoes(const orc_tracker* t);
+/* teacher forcing for the next orc_track_frame / _boxes / _dense call (see orc_track_tail's Tcw_force) */
+void orc_track_force_pose(orc_tracker* t, const float Tcw[16]);
 /* cur_mp_out (nullable): nfeatures int32, pool index matched to each keypoint or -1 */
 int orc_track_frame(orc_tracker* t, const uint8_t* grayL, int strideL, const uint8_t* grayR,
                     int strideR, orc_track_result* res, int32_t* cur_mp_out);

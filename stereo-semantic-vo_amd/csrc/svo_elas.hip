@@ -29,6 +29,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <memory>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -1747,7 +1748,11 @@ int svo_elas_batch_dev_hooked(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d
     auto t2 = tnow();
     if (driver.joinable()) driver.join();          // the pool is free again: chunk c - 1 is through
     auto t3 = tnow();
-    if (rc == SVO_OK) driver = std::thread([&host_stage, c]() { host_stage(c); });
+    if (rc == SVO_OK) {
+      // (std::thread's constructor may throw; an exception must not unwind past the joinable pool threads: run the stage here)
+      try { driver = std::thread([&host_stage, c]() { host_stage(c); }); }
+      catch (const std::system_error&) { host_stage(c); }
+    }
     if (rc == SVO_OK && c > 0) rc = finish(c - 1);
     t_enq += ms(t0, t1) + ms(t3, tnow()); t_wait += ms(t1, t2); t_host += ms(t2, t3);
   }

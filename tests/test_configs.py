@@ -15,12 +15,12 @@ import importlib
 import numpy as np
 import pytest
 
-# Pose tolerances, per frame.  The tests below run the device tracker in its DEFAULT mode (svo_set_option "epnp_exact" = 2:
-# every RANSAC sample solved with OpenCV's operations and rounding, spread over a wavefront), where the discrete outcome of
-# RANSAC and the LM's iteration count equal the CPU port's and a frame's pose agrees to BASELINE.md's 1e-4 m / 1e-5 rad.  Both chains
-# dead-reckon from float32 map points, so along a free-running sequence the ABSOLUTE poses drift apart by rounding-sized
-# steps (the absolute tolerance grows with the frame index); the per-frame RELATIVE motion is held to the tight bound.
-# The statistical wave solver (mode 0, an option) is validated against the same oracle in tests/test_full_length.py.
+# Pose tolerances, per frame: BASELINE.md's 1e-4 m / 1e-5 (rotation-matrix entries), FLAT along the sequence.  The tests below
+# run the device tracker in its DEFAULT mode (svo_set_option "epnp_exact" = 2: every RANSAC sample solved with OpenCV's
+# operations and rounding, spread over a wavefront) and the oracle under TEACHER FORCING (orc_track_force_pose, as
+# tests/test_full_length.py does with orc_track_tail): the oracle computes and reports its own PnP + LM pose for frame k and
+# then continues from the device's, so every frame is an independent comparison on identical map-point positions - the
+# discrete outcome (all counters, match indices, LM iterations) must be EQUAL and the pose inside the flat tolerance.
 POSE_TOL_T = 1e-4
 POSE_TOL_R = 1e-5
 COUNTERS = ("frame_id", "n_kp", "n_stereo", "n_match_pass1", "n_match_pass2", "n_lm_edges",
@@ -33,27 +33,30 @@ def _synth():
     return importlib.import_module("stereo_semantic_vo_amd.synth")
 
 
-def _rel(Ta, Tb):
-    """relative motion Tb * Ta^-1 of two row-major 4x4 float poses (float64)."""
-    return Tb.reshape(4, 4).astype(np.float64) @ np.linalg.inv(Ta.reshape(4, 4).astype(np.float64))
-
-
-def _compare_run(gpu, ref, n_abs_tol=None):
-    """gpu / ref: lists of (record, cur_mp).  Counters and match indices identical; the per-frame relative motion within
-    POSE_TOL (the absolute pose is compared too, with a tolerance that grows with the frame index: both chains
-    dead-reckon from float32 map points, so rounding differences add up along the path)."""
+def _compare_run(gpu, ref):
+    """gpu / ref: lists of (record, cur_mp), the oracle's produced under teacher forcing.  Counters, LM iterations and match
+    indices identical; every frame's pose within the flat BASELINE tolerance."""
     for k, ((res, cur), (rr, rcur)) in enumerate(zip(gpu, ref)):
-        for f in COUNTERS:
+        for f in COUNTERS + ("lm_iterations",):
             assert res[f] == rr[f], (k, f, int(res[f]), int(rr[f]))
-        assert abs(int(res["lm_iterations"]) - int(rr["lm_iterations"])) <= 1, k
         assert np.array_equal(cur[:rr["n_kp"]], rcur[:rr["n_kp"]]), "frame %d match indices" % k
         T, Tr = res["Tcw"].reshape(4, 4), rr["Tcw"].reshape(4, 4)
-        tol = 1.0 + k / 8.0
-        assert np.abs(T[:3, 3] - Tr[:3, 3]).max() < POSE_TOL_T * tol, (k, np.abs(T[:3, 3] - Tr[:3, 3]).max())
-        assert np.abs(T[:3, :3] - Tr[:3, :3]).max() < POSE_TOL_R * tol, k
-        if k > 0:
-            d = _rel(gpu[k - 1][0]["Tcw"], res["Tcw"]) - _rel(ref[k - 1][0]["Tcw"], rr["Tcw"])
-            assert np.abs(d[:3, 3]).max() < POSE_TOL_T and np.abs(d[:3, :3]).max() < POSE_TOL_R, k
+        assert np.abs(T[:3, 3] - Tr[:3, 3]).max() < POSE_TOL_T, (k, np.abs(T[:3, 3] - Tr[:3, 3]).max())
+        assert np.abs(T[:3, :3] - Tr[:3, :3]).max() < POSE_TOL_R, (k, np.abs(T[:3, :3] - Tr[:3, :3]).max())
+
+
+def _track_both(svo, trk, frames, boxes=None, dense=None, per_frame=None):
+    """Device frame k, then the oracle's frame k forced onto the device's pose.  frames: iterable of (L, R); boxes / dense:
+    optional k -> boxes array / dense disparity map for the ORACLE (the device derives its own); per_frame(k): extra checks."""
+    gpu, ref = [], []
+    for k, (Lk, Rk) in enumerate(frames):
+        bx = None if boxes is None else boxes(k)
+        res = svo.track_frame(Lk, Rk, boxes=bx) if bx is not None else svo.track_frame(Lk, Rk)
+        gpu.append((res.copy(), svo.debug_track_matches()))
+        ref.append(trk.track(Lk, Rk, boxes=bx, dense=None if dense is None else dense(k), Tcw_force=res["Tcw"]))
+        if per_frame is not None:
+            per_frame(k)
+    return gpu, ref
 
 
 # ---------------------------------------------------------------- configs[0], CPU leg (no GPU needed) -------------
@@ -112,15 +115,10 @@ def test_config0_kitti04_stereo_frame_equals_oracle(pkg, orc, seq04):
 def test_config0_kitti04_tracked_sequence_equals_oracle(pkg, orc, seq04):
     L, R, T = seq04
     trk = orc.Tracker(1241, 376, pkg.KITTI_04_12)
-    ref = [trk.track(L[k], R[k]) for k in range(len(L))]
-    trk.close()
     svo = pkg.Svo(1241, 376, max_batch=1)
     svo.track_reset(pkg.Camera(**pkg.KITTI_04_12))
-    gpu = []
-    for k in range(len(L)):
-        res = svo.track_frame(L[k], R[k])
-        gpu.append((res.copy(), svo.debug_track_matches()))
-    svo.close()
+    gpu, ref = _track_both(svo, trk, [(L[k], R[k]) for k in range(len(L))])
+    trk.close(); svo.close()
     _compare_run(gpu, ref)
     Twc = np.linalg.inv(gpu[-1][0]["Tcw"].reshape(4, 4).astype(np.float64))
     assert np.linalg.norm(Twc[:3, 3] - T[-1][:3, 3]) < 0.6
@@ -148,17 +146,14 @@ def test_config4_boxes_with_dense_elas_depth_equals_oracle(pkg, orc):
     svo = pkg.Svo(1241, 376, max_batch=1)
     svo.set_option("depth_source", 1)
     svo.track_reset(pkg.Camera(**pkg.KITTI_00_02))
-    gpu, ref, vetoes = [], [], 0
-    for k in range(n):
-        dmap = ob.ref_elas(L[k], R[k])[0]                     # the reference's own libelas, compiled from its sources
-        rr = trk.track(L[k], R[k], boxes=_boxes(k), dense=dmap)
-        res = svo.track_frame(L[k], R[k], boxes=_boxes(k))
-        gpu.append((res.copy(), svo.debug_track_matches())); ref.append(rr)
+    def gate(k):
         if k > 0:
             F, nv = svo.debug_track_gate()
             assert np.allclose(F.reshape(9), trk.F, rtol=1e-6, atol=1e-9), k
             assert nv == trk.vetoes, (k, nv, trk.vetoes)
-            vetoes += nv
+    gpu, ref = _track_both(svo, trk, [(L[k], R[k]) for k in range(n)], boxes=_boxes,
+                           dense=lambda k: ob.ref_elas(L[k], R[k])[0],   # the reference's own libelas, compiled from its sources
+                           per_frame=gate)
     trk.close(); svo.close()
     _compare_run(gpu, ref)
     assert gpu[-1][0]["n_stereo"] > 250
@@ -197,16 +192,12 @@ def test_64_frames_gpu_tracker_equals_oracle(pkg, orc):
     L, R, T = _synth().render_sequence(N, device=torch.device("cuda", 0))
     L, R = L.cpu().numpy(), R.cpu().numpy()
     trk = orc.Tracker(1241, 376, pkg.KITTI_00_02)
-    ref = [trk.track(L[k], R[k]) for k in range(N)]
-    trk.close()
     svo = pkg.Svo(1241, 376, max_batch=1)
     svo.track_reset(pkg.Camera(**pkg.KITTI_00_02))
-    gpu, rounds2 = [], []
-    for k in range(N):
-        res = svo.track_frame(L[k], R[k])
-        gpu.append((res.copy(), svo.debug_track_matches()))
-        rounds2.append(int(svo.debug_track_frames(0, 1)[0]["rounds"][1]))
-    svo.close()
+    rounds2 = []
+    gpu, ref = _track_both(svo, trk, [(L[k], R[k]) for k in range(N)],
+                           per_frame=lambda k: rounds2.append(int(svo.debug_track_frames(0, 1)[0]["rounds"][1])))
+    trk.close(); svo.close()
     _compare_run(gpu, ref)
     rec = np.array([g[0] for g in gpu])
     assert rec["n_local_map"][8:].max() > 800                 # four frames of new points
@@ -262,18 +253,9 @@ def test_real_street_images_tracked_sequence_equals_oracle(pkg, orc):
     trk = orc.Tracker(1241, 376, pkg.KITTI_00_02)
     svo = pkg.Svo(1241, 376, max_batch=1)
     svo.track_reset(pkg.Camera(**pkg.KITTI_00_02))
-    gpu, ref = [], []
-    for Lk, Rk in frames:
-        ref.append(trk.track(Lk, Rk))
-        res = svo.track_frame(Lk, Rk)
-        gpu.append((res.copy(), svo.debug_track_matches()))
+    gpu, ref = _track_both(svo, trk, frames)
     trk.close(); svo.close()
-    for k, ((res, cur), (rr, rcur)) in enumerate(zip(gpu, ref)):
-        for f in COUNTERS + ("lm_iterations",):
-            assert res[f] == rr[f], (k, f, int(res[f]), int(rr[f]))
-        assert np.array_equal(cur[:rr["n_kp"]], rcur[:rr["n_kp"]]), k
-        T, Tr = res["Tcw"].reshape(4, 4), rr["Tcw"].reshape(4, 4)
-        assert np.abs(T[:3, 3] - Tr[:3, 3]).max() < POSE_TOL_T * (1 + k) and np.abs(T[:3, :3] - Tr[:3, :3]).max() < POSE_TOL_R * (1 + k), k
+    _compare_run(gpu, ref)
     rec = np.array([g[0] for g in gpu])
     assert rec["n_kp"].min() > 400 and rec["n_stereo"].min() > 150          # real texture: plenty of corners and stereo matches
     assert (rec["n_match_pass1"][1:] > 10).all() and rec["n_lm_edges"][1:].min() >= 10

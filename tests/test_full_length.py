@@ -177,3 +177,39 @@ def test_every_frame_of_the_kitti00_sized_run_against_the_oracle(pkg, orc, run, 
         assert d_it.max() <= 1, stats                                   # measured: 1
     # the two free-running trajectories (4.54 km of dead reckoning each) stay together
     assert stats["ate_gpu_vs_free_running_oracle_rmse_m"] < 1.0, stats
+
+
+@pytest.mark.gpu
+def test_front_end_sampled_along_the_headline_sequence(pkg, orc, run):
+    """Every 50th of the 4,541 frames (91 stereo pairs, both images): what the batched device front end handed to the tails above
+    - keypoints, descriptors, depth of the left image - and the host-buffer entry's full result (right image's keypoints and
+    descriptors, uR) against orc_stereo_frame on the re-rendered frame, bit for bit.  The other front-end tests meet the oracle
+    on stills and short sequences; this one walks the whole length of the run bench.py times."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    synth = importlib.import_module("stereo_semantic_vo_amd.synth")
+    N, h, cam = run["N"], run["host"], run["cam"]
+    dev = run["kp"].device
+    ks = list(range(0, N, 50))
+    frames = {}
+    for k in ks:
+        L, R, _ = synth.render_sequence(1, seed=synth.BASE_SEED, device=dev, start=k)
+        frames[k] = (L[0].cpu().numpy(), R[0].cpu().numpy())
+    with ThreadPoolExecutor(8) as ex:                       # the oracle on host threads (ctypes releases the GIL)
+        ref = dict(zip(ks, ex.map(lambda k: orc.stereo_frame(frames[k][0], frames[k][1], cam.bf, cam.fx), ks)))
+    svo = pkg.Svo(W, H, max_batch=1)
+    for k in ks:
+        r = ref[k]
+        nk = int(h["n"][k])
+        assert nk == len(r["kpL"]) > 300, k
+        assert h["kp"][k, :nk].tobytes() == r["kpL"].tobytes(), "frame %d: keypoints of the batched front end" % k
+        assert np.array_equal(h["desc"][k, :nk], r["dL"]), "frame %d: descriptors of the batched front end" % k
+        assert np.array_equal(h["depth"][k, :nk].view(np.uint32), r["depth"].view(np.uint32)), "frame %d: depth" % k
+        g = svo.stereo_frame(frames[k][0], frames[k][1], cam)
+        for f in ("kpL", "kpR"):
+            assert g[f].tobytes() == r[f].tobytes(), (k, f)
+        for f in ("dL", "dR"):
+            assert np.array_equal(g[f], r[f]), (k, f)
+        for f in ("uR", "depth"):
+            assert np.array_equal(g[f].view(np.uint32), r[f].view(np.uint32)), (k, f)
+    svo.close()

@@ -38,12 +38,9 @@ import time
 
 T_START = time.perf_counter()
 
-# The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue run
-# their kernels one after the other.  A tracker context owns four streams (pose chain, index chain, two front-end streams) whose
-# whole point is to run side by side, and the legs below keep more than one context alive: measured with two contexts in the
-# process, the index chain and the pose chain of the second one shared a queue - 7.6 k frames/s where the same call in a
-# process of its own does 14.0 k (round 3's unexplained 2x of the `sharded` leg).  Read once, at HIP initialisation.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# (Up to round 4 this file raised GPU_MAX_HW_QUEUES to 16 so that a context's streams would not share a hardware queue.  The
+# library now picks streams that run side by side by measuring - svo_pick_stream, tests/test_shard.py
+# test_tail_rate_does_not_depend_on_the_process_stream_history - and the bench runs with the runtime's default, like a deployment.)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -818,46 +815,72 @@ def spawn_ranks(args):
 TAIL_LEGS = {"pnp_solver_modes": 1280, "sharded": 1024, "multi_sequence": 128, "semantic_elas": 512}   # leg -> frames it renders
 
 
-def tail_leg_child(args, pkg, synth, cam, dev, local):
-    """ONE of the legs whose figure depends on the tracker's index chain and pose chain running side by side (solver modes,
-    sharded, many sequences, configs[4]), in a process of its own, the way a deployment runs it.  Which hardware queues a
-    context's streams are mapped onto depends on the contexts the process had before: the runtime keeps a pool of queues per
-    priority and hands the least-used one to a new stream, and two queues can share a pipe of the command processor, where
-    the pose chain's packets then wait behind the index chain's.  Measured with AMD_LOG_LEVEL=3 (tools/multi_try2.py): the
-    many-sequence leg 95 k frames/s in a fresh process, 80 k / 56 k after a sharded run had left a third high-priority queue
-    in the pool and the leg's context picked that one; the sharded leg 8.1 k first, 5.0 k after the many-sequence leg.
-    Prints one JSON object {leg: result}."""
+def tail_leg_reference(pkg, cam, dL, dR, dev, local, nr):
+    """the single context's records of the first `nr` frames (what `sharded` and `multi_sequence` must reproduce)"""
     import torch
-    name = args.tail_leg_child
-    N = TAIL_LEGS[name]
-    dL, dR, _ = render_frames(synth, N, dev, synth.BASE_SEED)
     rec = pkg.TRACK_DTYPE.itemsize
     fb = H * PITCH
-    refn = None
-    if name in ("sharded", "multi_sequence"):           # the single context's records these two must reproduce
-        nr = 1024 if name == "sharded" else 48
-        ref = torch.zeros((nr, rec), dtype=torch.uint8, device=dev)
-        s = pkg.Svo(W, H, device=local, max_kp=500, max_batch=256)
-        s.track_reset(cam)
-        for c0 in range(0, nr, 256):
-            s.track_batch_dev(dL.data_ptr() + c0 * fb, dR.data_ptr() + c0 * fb, PITCH, min(256, nr - c0), ref.data_ptr() + c0 * rec)
-        s.sync(); s.close()
-        refn = ref.cpu().numpy()
-    progress("leg %s (child process)" % name)
+    ref = torch.zeros((nr, rec), dtype=torch.uint8, device=dev)
+    s = pkg.Svo(W, H, device=local, max_kp=500, max_batch=256)
+    s.track_reset(cam)
+    for c0 in range(0, nr, 256):
+        s.track_batch_dev(dL.data_ptr() + c0 * fb, dR.data_ptr() + c0 * fb, PITCH, min(256, nr - c0), ref.data_ptr() + c0 * rec)
+    s.sync(); s.close()
+    return ref.cpu().numpy()
+
+
+def run_tail_leg(name, pkg, cam, dL, dR, dev, local, refn=None):
+    """One of the legs whose figure depends on the tracker's index chain and pose chain running side by side (solver modes,
+    sharded, many sequences, configs[4]) on the frames resident in dL / dR (>= TAIL_LEGS[name] of them)."""
+    rec = pkg.TRACK_DTYPE.itemsize
+    fb = H * PITCH
+    N = TAIL_LEGS[name]
+    if refn is None and name in ("sharded", "multi_sequence"):
+        refn = tail_leg_reference(pkg, cam, dL, dR, dev, local, 1024)
     try:
         if name == "pnp_solver_modes":
             r = solver_modes_leg(pkg, cam, dL, dR, fb, rec, dev, N)
         elif name == "sharded":
-            r = sharded_run(pkg, cam, dL, dR, 1024, 2, [local, local], rec, reference=refn)
+            r = sharded_run(pkg, cam, dL, dR, 1024, 2, [local, local], rec, reference=refn[:1024])
             r["note"] = ("two contexts on this ONE GPU: no cross-device run was measured here (the driver's multi-GPU run, "
                          "when it has a node, adds it); " + r["note"])
         elif name == "multi_sequence":
-            r = multi_sequence_leg(pkg, cam, dL, dR, fb, rec, dev, refn.view(pkg.TRACK_DTYPE).reshape(-1))
+            r = multi_sequence_leg(pkg, cam, dL, dR, fb, rec, dev, refn[:48].view(pkg.TRACK_DTYPE).reshape(-1))
         else:
             r = semantic_elas_leg(pkg, cam, dL, dR, dev, rec)
     except Exception as e:  # noqa: BLE001
         r = {"error": repr(e)}
-    print(json.dumps({name: r}))
+    return r
+
+
+def leg_value(r):
+    """a leg's figure: its "value", or {sub-leg: value} (pnp_solver_modes), or its error"""
+    if not isinstance(r, dict):
+        return r
+    if "value" in r:
+        return r["value"]
+    sub = {k: v["value"] for k, v in r.items() if isinstance(v, dict) and "value" in v}
+    return sub or r.get("error")
+
+
+def leg_ratio(a, b):
+    try:
+        if isinstance(a, dict):
+            return {k: a[k] / b[k] for k in a}
+        return a / b
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def tail_leg_child(args, pkg, synth, cam, dev, local):
+    """One tail leg in a process of its own (`--tail-leg-child <leg>`): the figure a process that does nothing else gets.  Up
+    to round 4 this was the only way these legs measured their full rate (two streams of a context could end up on one
+    hardware queue, depending on the process's earlier streams); bench.py now runs them in-process, in two orders, and
+    prints this figure beside them.  Prints one JSON object {leg: result}."""
+    name = args.tail_leg_child
+    dL, dR, _ = render_frames(synth, TAIL_LEGS[name], dev, synth.BASE_SEED)
+    progress("leg %s (child process)" % name)
+    print(json.dumps({name: run_tail_leg(name, pkg, cam, dL, dR, dev, local)}))
     sys.stdout.flush()
 
 
@@ -883,6 +906,7 @@ def main():
     ap.add_argument("--no-track-leg", action="store_true", help="(kept for scripts) same as --no-legs for the frontend workload")
     ap.add_argument("--tail-leg-child", default=None, choices=sorted(TAIL_LEGS),
                     help="run ONE of the legs that depend on the tracker's two overlapping chains in this (fresh) process and print it")
+    ap.add_argument("--no-tail-leg-children", action="store_true", help="skip the child-process repetition of the tail legs (in-process figures only)")
     ap.add_argument("--no-shard-leg", action="store_true", help="N > 1: skip rank 0's svo_track_sharded_dev run across the N GPUs")
     ap.add_argument("--shard", action="store_true",
                     help="track workload: ONE sequence over --gpus G contexts in ONE process (svo_track_sharded_dev, BASELINE configs[3])")
@@ -1212,23 +1236,38 @@ def main():
             out["cpu_baseline"] = cpu_baseline(Lh, Rh, cam, args.workload)
         legs = world == 1 and not args.no_legs and not multi and args.depth_source == 0 and not args.boxes
         if legs:
-            svo.close()                          # (its streams would share hardware queues with the legs' contexts)
+            svo.close()                          # (its buffers: the legs' contexts bring their own)
             svo = None
-        # The legs that run the ordered tail (two chains that must overlap on two hardware queues) each run in a fresh process:
-        # see tail_leg_child.  Behind this process's earlier contexts they measured about half (the statistical solver's leg
-        # 7.6 k frames/s against 14.2 k, `sharded` 5.3 k against 8.1 k, many sequences 57 k against 95 k, configs[4] 4.6 k
-        # against 6.3 k).
+        # The legs that run the ordered tail (two chains that must overlap on two hardware queues): in THIS process, after the
+        # headline's context and after each other, once in this order and once in the reverse one, and each in a process of
+        # its own - three figures per leg that have to agree (`in_process_over_child`).  Up to round 4 only the child figure
+        # was a full-rate one (see tail_leg_child).
         if legs and track:
-            for name in TAIL_LEGS:
-                if name == "semantic_elas" and args.no_elas_leg:
-                    continue
-                progress("leg %s: child process" % name)
-                try:
-                    cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--tail-leg-child", name],
-                                        stdout=subprocess.PIPE, timeout=600, check=True)
-                    out.update(json.loads(cp.stdout.decode().strip().splitlines()[-1]))
-                except Exception as e:  # noqa: BLE001
-                    out[name] = {"error": repr(e)}
+            names = [n for n in TAIL_LEGS if not (n == "semantic_elas" and args.no_elas_leg)]
+            refn = tail_leg_reference(pkg, cam, dL, dR, dev, local, 1024)
+            first, second = {}, {}
+            for name in names:
+                progress("leg %s: in-process" % name)
+                first[name] = run_tail_leg(name, pkg, cam, dL, dR, dev, local, refn)
+            for name in reversed(names):
+                progress("leg %s: in-process, reverse order" % name)
+                second[name] = run_tail_leg(name, pkg, cam, dL, dR, dev, local, refn)
+            for name in names:
+                r = first[name]
+                r["order"] = "in-process, %d. of %s" % (names.index(name) + 1, " > ".join(names))
+                r["value_in_process_reverse_order"] = leg_value(second[name])
+                if not args.no_tail_leg_children:
+                    progress("leg %s: child process" % name)
+                    try:
+                        cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--tail-leg-child", name],
+                                            stdout=subprocess.PIPE, timeout=600, check=True)
+                        child = json.loads(cp.stdout.decode().strip().splitlines()[-1])[name]
+                        r["value_child_process"] = leg_value(child)
+                    except Exception as e:  # noqa: BLE001
+                        r["value_child_process"] = repr(e)
+                    r["in_process_over_child"] = [leg_ratio(leg_value(r), r["value_child_process"]),
+                                                  leg_ratio(r["value_in_process_reverse_order"], r["value_child_process"])]
+                out[name] = r
             progress("leg frontend")
             out["frontend"] = frontend_leg(pkg, cam, dL, dR, n_frames, frame_bytes, dev,
                                            None if args.no_cpu_baseline else cpu_baseline_all_cores)

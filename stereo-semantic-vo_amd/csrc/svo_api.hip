@@ -7,6 +7,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <chrono>
+#include <functional>
+#include <initializer_list>
 #include "svo_internal.h"
 
 // ---- profiling ---------------------------------------------------------------------
@@ -361,6 +364,7 @@ extern "C" int svo_set_option(svo_ctx* ctx, const char* key, int value) {
     if (ctx->stream_dense) { hipStreamSynchronize(ctx->stream_dense); hipStreamDestroy(ctx->stream_dense); ctx->stream_dense = nullptr; }   // recreated on demand
     return SVO_OK;
   }
+  if (!strcmp(key, "tail_fused")) { ctx->opt_tail_fused = value != 0; return SVO_OK; }
   if (!strcmp(key, "pose_flag")) { ctx->opt_pose_flag = value != 0; return SVO_OK; }
   if (!strcmp(key, "gate_group")) { ctx->opt_gate_group = value != 0; return SVO_OK; }
   if (!strcmp(key, "hyp_first")) { if (value < 4 || value > 16 || (value & 3)) return SVO_E_INVALID; ctx->opt_hyp_first = value; return SVO_OK; }
@@ -888,9 +892,14 @@ extern "C" int svo_frontend_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, cons
   if (ns < 2)
     return frontend_slice(ctx, ctx->stream, d_grayL, d_grayR, stride, 0, B, cam, d_kpL, d_descL, d_nL, d_uR, d_depth);
   while ((int)ctx->fe_streams.size() < ns - 1) {
-    hipStream_t st;
+    hipStream_t st = nullptr;
     hipEvent_t e;
-    SVO_HIP(ctx, svo_stream_create(&st, 0));
+    {   // a stream that runs beside the context's own (and beside the slices' streams made before it)
+      int attempts = 0, percent = 0;
+      const int rcp = svo_pick_stream(ctx, [](hipStream_t* s) { return svo_stream_create(s, 0); },
+                                      {ctx->stream, ctx->fe_streams.empty() ? nullptr : ctx->fe_streams.back()}, &st, &attempts, &percent);
+      if (rcp) return rcp;
+    }
     ctx->fe_streams.push_back(st);
     SVO_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     ctx->fe_events.push_back(e);
@@ -937,6 +946,67 @@ extern "C" int svo_profile_get(svo_ctx* ctx, int index, char* name, int name_cap
   return SVO_OK;
 }
 
+// ---- streams that run side by side --------------------------------------------------------------
+// Do two streams run side by side?  The tracker's tail is two chains on two streams that must overlap (svo_track.hip), the batched
+// front end runs its slices on two streams, and the runtime maps a process's
+// streams onto a few hardware queues (a pool per priority, least-used first: what the process created earlier decides what a
+// new stream gets).  Two streams on ONE hardware queue serialise completely - measured with tools/microbench/queue_pair_probe
+// (profiles/r05_queue_pairs.jsonl): of six high-priority streams made one after the other, the pairs (2, 5) and (3, 4) take
+// the SUM of the two chains' times, every other pair the maximum; with three older high-priority streams in the process the
+// first two new ones are such a pair - the tracker then ran at half its rate, with identical kernels.  The probe therefore
+// measures the thing itself: a chain of eight short dependent kernels on A alone, then the same chain on A and on B together.
+__global__ void k_probe_spin(long long cycles) {
+  const long long t0 = clock64();
+  while (clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(4);
+}
+static double probe_chain_us(hipStream_t A, hipStream_t B /* nullable */) {
+  hipStreamSynchronize(A);
+  if (B) hipStreamSynchronize(B);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < 8; ++i) {
+    hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, A, 60000LL);   // ~28 us each: device time, not the host's enqueue, decides
+    if (B) hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, B, 60000LL);
+  }
+  hipStreamSynchronize(A);
+  if (B) hipStreamSynchronize(B);
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+}
+// both chains together / one chain alone, in per cent (~100: side by side, ~200: one after the other)
+static int probe_pair_percent(hipStream_t A, hipStream_t B) {
+  (void)probe_chain_us(A, nullptr);                       // (first launches of the kernel, clocks)
+  const double alone = probe_chain_us(A, nullptr);
+  const double both = std::min(probe_chain_us(A, B), probe_chain_us(A, B));
+  (void)hipGetLastError();
+  return (int)std::min(999.0, 100.0 * both / std::max(alone, 1.0));
+}
+// A new stream (made by `make`) that runs side by side with every stream of `others`: up to six candidates; the rejected ones are
+// kept until the choice is made, so that the pool hands out another queue each time.  None passes (a tool that serialises all
+// dispatches, e.g. rocprofv3's kernel trace): the best one.  *attempts / *percent: candidates tried, the chosen one's worst ratio.
+int svo_pick_stream(svo_ctx* ctx, const std::function<hipError_t(hipStream_t*)>& make, std::initializer_list<hipStream_t> others, hipStream_t* out,
+                    int* attempts, int* percent) {
+  static const bool no_probe = []() { const char* e = getenv("SVO_NO_STREAM_PROBE"); return e && e[0] == '1'; }();
+  *out = nullptr; *attempts = 0; *percent = 0;
+  if (no_probe) return make(out) == hipSuccess ? SVO_OK : SVO_E_HIP;
+  std::vector<hipStream_t> rejected;
+  hipStream_t best = nullptr;
+  int best_pct = 1000;
+  for (int k = 0; k < 6; ++k) {
+    hipStream_t cand = nullptr;
+    if (make(&cand) != hipSuccess) { (void)hipGetLastError(); break; }
+    ++*attempts;
+    int worst = 0;
+    for (hipStream_t o : others)
+      if (o) worst = std::max(worst, probe_pair_percent(o, cand));
+    if (worst < best_pct) { if (best) rejected.push_back(best); best = cand; best_pct = worst; }
+    else rejected.push_back(cand);
+    if (best_pct < 150) break;
+  }
+  for (hipStream_t r : rejected) hipStreamDestroy(r);
+  *out = best; *percent = best ? best_pct : 0;
+  if (best && best_pct >= 150)
+    ctx->last_error = "tracker: no candidate stream ran beside the pose chain's (" + std::to_string(best_pct) + " % of one chain's time for two): the tail runs at a reduced rate";
+  return best ? SVO_OK : SVO_E_HIP;
+}
 // A stream that may only use the first `percent` per cent of the device's compute units (whole 32-bit mask words: on gfx950
 // the first word of the mask stands for four CUs on EACH of the eight XCDs - tools/microbench/cu_mask_probe - so the stream keeps
 // an even share of every XCD, not whole XCDs).  The stream is a blocking one (it orders against the null stream).

@@ -1594,7 +1594,13 @@ int svo_elas_batch_dev_hooked(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d
         hipStreamSynchronize(ctx->stream_elas_a); hipStreamDestroy(ctx->stream_elas_a); ctx->stream_elas_a = nullptr;
       }
       if (!ctx->stream_elas_a) {
-        SVO_HIP(ctx, pct ? svo_stream_create_masked(&ctx->stream_elas_a, ctx->device, pct) : svo_stream_create(&ctx->stream_elas_a, 0));
+        {   // a stream that runs beside the caller's (phase A of chunk c + 1 beside phase B of chunk c)
+          const int dev = ctx->device;
+          int attempts = 0, percent = 0;
+          const int rcp = svo_pick_stream(ctx, [dev, pct](hipStream_t* q) { return pct ? svo_stream_create_masked(q, dev, pct) : svo_stream_create(q, 0); },
+                                          {s}, &ctx->stream_elas_a, &attempts, &percent);
+          if (rcp) return rcp;
+        }
         ctx->stream_elas_a_pct = pct;
       }
       if (!ctx->ev_elas_setup) SVO_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_elas_setup, hipEventDisableTiming));

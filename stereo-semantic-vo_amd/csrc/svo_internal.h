@@ -7,6 +7,8 @@
 #include <stdint.h>
 
 #include <chrono>
+#include <functional>
+#include <initializer_list>
 #include <string>
 #include <atomic>
 #include <vector>
@@ -122,7 +124,7 @@ struct svo_ctx {
   bool hyp_two_launch = false;  // set by an entry for the duration of its tail_enqueue calls: RANSAC samples as 16 + (those the bound can reach)
   int opt_dense_two_launch = 0; // depth_source = 1: the tail beside the dense stage uses the two-launch RANSAC (fewer CUs taken from ELAS)
   int idx_probe_attempts = -1;  // how many candidate streams the index chain's stream was chosen from (-1: not chosen yet, 0: probe off)
-  int idx_probe_spins = 0;      // the chosen candidate's probe result (polls of the waiting kernel: >= 1000 = the two chains do NOT overlap)
+  int idx_probe_spins = 0;      // the chosen candidate's probe result: two chains together / one alone, per cent (~100 side by side, ~200 serialised)
   int opt_hyp_first = 8;        // many sequences: RANSAC samples per sequence in the first (and second) launch of a step
   int opt_gate_group = 1;       // 1: gated frames' F for a group of frames in one launch ahead of the index chain; 0: per frame, in the chain
   int work_cap = 0;             // records per half (two halves are allocated)
@@ -161,6 +163,7 @@ struct svo_ctx {
   int opt_fast_cand_cap = 2048;   // svo_set_option("fast_cand_cap"): entries of k_fast's candidate list (<= 2048)
   int opt_pose_mfma = 1;   // svo_set_option("pose_mfma"): Gram accumulation of k_pose_opt on f64 MFMA
   int opt_fe_cu_percent = 12;   // svo_set_option("fe_cu_percent"): share of the CUs the batched tracker's front-end stream may use
+  int opt_tail_fused = 1;  // svo_set_option("tail_fused"): one sequence, default solver: RANSAC samples + frame part in one launch (k_tp_tail_ord)
   int opt_pose_flag = 0;   // svo_set_option("pose_flag"): one sequence's pose kernels poll the index chain's per-frame tag instead of waiting on stream
                            // events.  OFF by default: the poll needs the index kernel to run CONCURRENTLY with the polling one, and a tool that
                            // serialises kernel dispatches (rocprofv3 --kernel-trace does) turns every frame into a timed-out poll
@@ -222,6 +225,11 @@ __host__ __device__ inline T* svo_byte_offset(T* p, size_t bytes) {
 hipError_t svo_stream_create(hipStream_t* st, int role);
 int svo_track_quiesce(svo_ctx* ctx, bool shard_too = true);   // waits for what overlapped tracker calls left in flight and may still read this context's arrays
 int svo_shard_quiesce(svo_ctx* ctx);   // svo_track.hip: the sharded tracker's part of that
+// svo_api.hip: a new stream (made by `make`) that runs side by side with every non-null stream of `others`, chosen by measuring
+// (up to six candidates); *attempts candidates tried, *percent the chosen one's worst "two chains together / one alone"
+int svo_pick_stream(svo_ctx* ctx, const std::function<hipError_t(hipStream_t*)>& make, std::initializer_list<hipStream_t> others, hipStream_t* out,
+                    int* attempts, int* percent);
+int svo_track_fe_batch_stream(svo_ctx* ctx);   // svo_track.hip: creates ctx->stream_fe_batch (a stream that runs beside the tail's two chains)
 int svo_elas_batch_dev_hooked(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d_R, int stride, int W, int H, int B,
                               const svo_elas_params* params, float* d_D1, float* d_D2, int32_t* produced,
                               int (*hook)(void*, int, int), void* user);   // svo_elas.hip   // wait for the tails svo_track_batch_dev left in flight (svo_api.hip)

@@ -673,6 +673,9 @@ __device__ __forceinline__ void pnp_hyp_exact_wave(PnpExactLds& S, const double*
 // OpenCV's operations spread over the wavefront with their rounding kept (svo_epnp_ord_dev.h), bit-identical to the
 // sequential restatement; then the wave counts the sample's consensus.  Called by all 64 lanes of the wave that owns sample k.
 struct PnpOrdLds { epnp_ord::Lds S; epnp_exact::Work W; };
+// AGENT_OUT: the result is read by ANOTHER workgroup of the same launch - stored with agent-scope (sc1) stores, which reach the
+// device-coherent level by themselves (no release fence: see tp_wait_work in svo_track.hip).
+template <bool AGENT_OUT = false>
 __device__ __forceinline__ void pnp_hyp_ord_wave(PnpOrdLds& L, const double* Xw, const double* uv, int n, const double* K,
                                                  const uint16_t* subset, PnpHyp* out, int k, bool force_seq = false) {
   const int lane = threadIdx.x & 63;
@@ -689,12 +692,22 @@ __device__ __forceinline__ void pnp_hyp_ord_wave(PnpOrdLds& L, const double* Xw,
     for (int e = lane; e < n; e += 64) cnt += pnp_inlier(R, t, Xw + 3 * e, uv + 2 * e, K) ? 1 : 0;
   cnt = wave_sum_i32_dpp(cnt);
   if (lane == 0) {
-    PnpHyp h;
+    if (AGENT_OUT) {
+      PnpHyp* o = out + k;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) h.R[i] = R[i];
-    h.t[0] = t[0]; h.t[1] = t[1]; h.t[2] = t[2];
-    h.cnt = cnt; h.ok = ok ? 1 : 0;
-    out[k] = h;
+      for (int i = 0; i < 9; ++i) __hip_atomic_store(reinterpret_cast<long long*>(&o->R[i]), __builtin_bit_cast(long long, R[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) __hip_atomic_store(reinterpret_cast<long long*>(&o->t[i]), __builtin_bit_cast(long long, t[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&o->cnt, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&o->ok, ok ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      PnpHyp h;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) h.R[i] = R[i];
+      h.t[0] = t[0]; h.t[1] = t[1]; h.t[2] = t[2];
+      h.cnt = cnt; h.ok = ok ? 1 : 0;
+      out[k] = h;
+    }
   }
 }
 

@@ -41,7 +41,12 @@
 // (nearest last-frame descriptor of every keypoint) and k_tg_fmat (one wave: match filter, Hartley normalisation, normal
 // matrix, wave-parallel Jacobi, rank-2 projection; svo_fmat_dev.h).  Boxes arrive as HBM arrays in every mode
 // (svo_boxes_dev), nothing of a gated frame touches the host.
+#include <chrono>
 #include <cstddef>
+#include <initializer_list>
+#include <string>
+#include <vector>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 
@@ -84,6 +89,7 @@ struct TrackWork {
   // written by the pose chain (k_tp_frame), for svo_debug_track_frames: cv::solvePnPRansac's outcome and pose
   int32_t pnp_best, pnp_iterations, pnp_inliers, pnp_ok;
   double T_pnp[16];
+  int32_t hyp_done, pad_hyp;     // fused pose launch (k_tp_tail_ord): RANSAC samples of this frame that have stored their result
 };
 
 struct TrackState {
@@ -803,6 +809,7 @@ __global__ __launch_bounds__(1024) void k_ti_resolve(TrackState* st, TrackWork* 
     st_agent(&work->rt[0], rt0); st_agent(&work->rt[1], (long long)wall_clock64());
     st_agent(&work->diag[0], n_act1 | (rounds1 << 16));
     st_agent(&work->diag[1], n_act2 | (rounds2v << 16));
+    st_agent(&work->hyp_done, 0);
     st->n_vetoed = n_veto;
     st->lastN = nkp;
     st->npool = total_live;
@@ -1134,13 +1141,13 @@ __global__ __launch_bounds__(64) void k_tp_hyp_exact(TrackState* st, TrackWork* 
 // The RANSAC samples in the order-preserving wave mode ("epnp_exact" = 2, the default): one single-wave workgroup per sample,
 // OpenCV's operations over the wavefront with their rounding kept (svo_epnp_ord_dev.h); the wave counts the consensus.
 struct TpHypOrdLds { double Xw[TRK_MAXKP * 3], uv[TRK_MAXKP * 2]; PnpOrdLds ord; int cnt[TP_HYP_PRE], ok[TP_HYP_PRE], bound; };
-__global__ __launch_bounds__(64) void k_tp_hyp_ord(TrackState* st, TrackWork* work, const svo_kp* kp, const uint16_t* subsets,
-                                                   int kstride, int hyp_base, int tag, int force_seq) {
-  TpHypOrdLds& S = *reinterpret_cast<TpHypOrdLds*>(tk_smem);
-  st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
+// One sample (called by the 64 lanes of the workgroup's only live wave).  FUSED: the sample belongs to a k_tp_tail_ord launch - its
+// result goes out with agent-scope stores and is announced in work->hyp_done (the frame's workgroup of the SAME launch reads it).
+template <bool FUSED>
+__device__ __forceinline__ void tp_hyp_ord_body(TpHypOrdLds& S, TrackState* st, TrackWork* work, const svo_kp* kp, const uint16_t* subsets,
+                                                int kstride, int hyp_base, int sample, int tag, int force_seq) {
   if (!tp_wait_work(st, work, tag)) return;
   const long long t_start = clock64();
-  const int sample = hyp_base + (int)blockIdx.x;
   if (threadIdx.x == 0 && sample == 0) work->rt[2] = wall_clock64();
   const int n = ld_agent(&work->n_edges);
   if (ld_agent(&work->skip_match) || n < 5) return;
@@ -1153,7 +1160,7 @@ __global__ __launch_bounds__(64) void k_tp_hyp_ord(TrackState* st, TrackWork* wo
     if (sample >= S.bound) return;
   }
   const float* gpos = st->gpos;
-  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+  for (int e = threadIdx.x; e < n; e += 64) {
     const float* gp = gpos + 3 * (size_t)(ld_agent(&work->edge_gid[e]) & (TRK_GPOS - 1));
     const svo_kp k = kp[ld_agent(&work->edge_kp[e])];
     S.Xw[3 * e] = (double)gp[0]; S.Xw[3 * e + 1] = (double)gp[1]; S.Xw[3 * e + 2] = (double)gp[2];
@@ -1161,13 +1168,17 @@ __global__ __launch_bounds__(64) void k_tp_hyp_ord(TrackState* st, TrackWork* wo
   }
   __syncthreads();
   const double K[4] = {(double)st->cam.fx, (double)st->cam.fy, (double)st->cam.cx, (double)st->cam.cy};
-  if (sample == 0) {   // the frame kernel's copy of the correspondences (it skips its own gather: k_tp_frame, `pre_gathered`)
-    for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) st->Xw[i] = S.Xw[i];
-    for (int i = threadIdx.x; i < 2 * n; i += blockDim.x) st->obs[i] = S.uv[i];
+  if (!FUSED && sample == 0) {   // the frame kernel's copy of the correspondences (it skips its own gather: k_tp_frame, `pre_gathered`)
+    for (int i = threadIdx.x; i < 3 * n; i += 64) st->Xw[i] = S.Xw[i];
+    for (int i = threadIdx.x; i < 2 * n; i += 64) st->obs[i] = S.uv[i];
     if (threadIdx.x < 4) st->K[threadIdx.x] = K[threadIdx.x];
   }
   const long long t_gather = clock64();
-  pnp_hyp_ord_wave(S.ord, S.Xw, S.uv, n, K, subsets + (size_t)min(n, 512) * 500, st->hyp, sample, force_seq != 0);
+  pnp_hyp_ord_wave<FUSED>(S.ord, S.Xw, S.uv, n, K, subsets + (size_t)min(n, 512) * 500, st->hyp, sample, force_seq != 0);
+  if (FUSED) {
+    TP_STORES_DONE();   // (lane 0's agent-scope stores of the sample's result have reached the coherent level)
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&work->hyp_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (threadIdx.x == 0 && S.ord.S.flag) atomicAdd(&st->epnp_fallbacks, 1);
   if (sample == 0 && threadIdx.x == 0) {
     const long long* sp = S.ord.S.stamp;
@@ -1176,6 +1187,12 @@ __global__ __launch_bounds__(64) void k_tp_hyp_ord(TrackState* st, TrackWork* wo
     st->pose_ts[5] = sp[2]; st->pose_ts[6] = sp[3]; st->pose_ts[7] = sp[4]; st->pose_ts[12] = S.ord.S.flag;
     st->pose_ts[13] = sp[4]; st->pose_ts[14] = sp[5]; st->pose_ts[15] = sp[6];
   }
+}
+__global__ __launch_bounds__(64) void k_tp_hyp_ord(TrackState* st, TrackWork* work, const svo_kp* kp, const uint16_t* subsets,
+                                                   int kstride, int hyp_base, int tag, int force_seq) {
+  TpHypOrdLds& S = *reinterpret_cast<TpHypOrdLds*>(tk_smem);
+  st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
+  tp_hyp_ord_body<false>(S, st, work, kp, subsets, kstride, hyp_base, hyp_base + (int)blockIdx.x, tag, force_seq);
 }
 
 // k_tp_frame: RANSAC's acceptance rule over the samples, Optimizer::PoseOptimization, SetPose, the positions of the
@@ -1193,12 +1210,11 @@ struct TpLds {
 // frames/s - the rows of the Gram matrix and the MFMA accumulation spread over four SIMDs are worth more than the wave-local
 // barriers a single wave would buy.  The LM stays templated on the thread count, pose_opt_block<NT>.)
 #define TPF_NT 256
-__global__ __launch_bounds__(TPF_NT) void k_tp_frame(TrackState* st, TrackWork* work, const svo_kp* kp,
-                                                  const float* depth, svo_track_result* res_out, int kstride,
-                                                  int use_mfma, int tag, int pre_gathered) {
-  TpLds& S = *reinterpret_cast<TpLds*>(tk_smem);
-  st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
-  depth += (size_t)blockIdx.y * kstride; res_out += blockIdx.y;
+// FUSED: the frame's workgroup of a k_tp_tail_ord launch - the RANSAC samples run beside it in the SAME launch; it prepares
+// everything that does not depend on them, then waits for work->hyp_done and reads their results with agent-scope loads.
+template <bool FUSED>
+__device__ __forceinline__ void tp_frame_body(TpLds& S, TrackState* st, TrackWork* work, const svo_kp* kp, const float* depth,
+                                              svo_track_result* res_out, int kstride, int use_mfma, int tag, int pre_gathered) {
   const int tid = threadIdx.x;
   if (!tp_wait_work(st, work, tag)) return;
   if (tid == 0) work->rt[4] = wall_clock64();
@@ -1245,10 +1261,18 @@ __global__ __launch_bounds__(TPF_NT) void k_tp_frame(TrackState* st, TrackWork* 
   if (tid < 4 && !have_corr) st->K[tid] = (double)((const float*)&st->cam)[tid];
   // ---- PnP initial pose (src/pnpmatch.cc:212-247): no prior; if solvePnPRansac fails the last pose stays ----------
   const bool ran = !skip && n_edges >= 5;
+  if (FUSED && ran) {   // the samples of this launch: all PNP_HYP results stored (bounded wait, as tp_wait_work's)
+    if (tid == 0) {
+      int spins = 0;
+      while (ld_agent(&work->hyp_done) < PNP_HYP && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(1); ++spins; }
+      if (spins >= (1 << 22)) st->overflow = 4;
+    }
+    __syncthreads();
+  }
   if (ran)
     for (int h = tid; h < PNP_HYP; h += TPF_NT) {
       // every sample's thread prepares the pow / log terms the iteration bound would need if that sample became the best
-      const int c = st->hyp[h].cnt, o = st->hyp[h].ok;
+      const int c = FUSED ? ld_agent(&st->hyp[h].cnt) : st->hyp[h].cnt, o = FUSED ? ld_agent(&st->hyp[h].ok) : st->hyp[h].ok;
       S.cnt[h] = c; S.ok[h] = o;
       double ld = 1.0; int r = 0;
       if (o && c > 4 && n_edges > 5) pnp_update_terms(c, n_edges, &ld, &r);
@@ -1266,7 +1290,12 @@ __global__ __launch_bounds__(TPF_NT) void k_tp_frame(TrackState* st, TrackWork* 
     if (S.best >= 0) {
       const PnpHyp& h = st->hyp[S.best];
       const int r = tid >> 2, c = tid & 3;
-      v = r == 3 ? (c == 3 ? 1.0 : 0.0) : (c == 3 ? h.t[r] : h.R[3 * r + c]);
+      if (FUSED) {
+        const double* src = r == 3 ? nullptr : (c == 3 ? &h.t[r] : &h.R[3 * r + c]);
+        v = src ? __builtin_bit_cast(double, ld_agent(reinterpret_cast<const long long*>(src))) : (c == 3 ? 1.0 : 0.0);
+      } else {
+        v = r == 3 ? (c == 3 ? 1.0 : 0.0) : (c == 3 ? h.t[r] : h.R[3 * r + c]);
+      }
     }
     st->T[tid] = v;
     work->T_pnp[tid] = v;
@@ -1323,6 +1352,35 @@ __global__ __launch_bounds__(TPF_NT) void k_tp_frame(TrackState* st, TrackWork* 
     work->rt[3] = wall_clock64();
   }
 }
+__global__ __launch_bounds__(TPF_NT) void k_tp_frame(TrackState* st, TrackWork* work, const svo_kp* kp,
+                                                  const float* depth, svo_track_result* res_out, int kstride,
+                                                  int use_mfma, int tag, int pre_gathered) {
+  TpLds& S = *reinterpret_cast<TpLds*>(tk_smem);
+  st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
+  depth += (size_t)blockIdx.y * kstride; res_out += blockIdx.y;
+  tp_frame_body<false>(S, st, work, kp, depth, res_out, kstride, use_mfma, tag, pre_gathered);
+}
+
+// The pose chain of one frame in ONE launch ("tail_fused", the default with the order-preserving solver and one sequence):
+// workgroups 0 .. PNP_HYP - 1 are the RANSAC samples (k_tp_hyp_ord's: their first wave solves, the other three leave at once - a
+// sample wants a CU's float64 pipeline to itself), workgroup PNP_HYP is the frame's (k_tp_frame's).  Workgroups are dispatched in
+// index order, so the frame's workgroup - the only one that waits for others of its launch - is placed last and cannot keep a
+// sample from starting.  Saved against two launches: the boundary between them (completion signal, barrier packet, dispatch:
+// 2.6 us between two empty kernels of a stream, tools/microbench/anyorder_probe) and the frame kernel's own start-up (hand-over
+// poll, record and keypoint loads, the gather of the correspondences), which now runs in the shadow of the samples.
+union TpTailLds { TpHypOrdLds hyp; TpLds frame; };
+__global__ __launch_bounds__(TPF_NT) void k_tp_tail_ord(TrackState* st, TrackWork* work, const svo_kp* kp, const float* depth,
+                                                     const uint16_t* subsets, svo_track_result* res_out, int kstride, int use_mfma,
+                                                     int tag, int force_seq) {
+  st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
+  if (blockIdx.x < PNP_HYP) {
+    if (threadIdx.x >= 64) return;
+    tp_hyp_ord_body<true>(*reinterpret_cast<TpHypOrdLds*>(tk_smem), st, work, kp, subsets, kstride, 0, (int)blockIdx.x, tag, force_seq);
+  } else {
+    depth += (size_t)blockIdx.y * kstride; res_out += blockIdx.y;
+    tp_frame_body<true>(*reinterpret_cast<TpLds*>(tk_smem), st, work, kp, depth, res_out, kstride, use_mfma, tag, 0);
+  }
+}
 
 // --------------------------------------------------------------------------------------------
 // Host side
@@ -1372,63 +1430,18 @@ void svo_track_release(svo_ctx* ctx) {
   ctx->ms_cap = 0; ctx->ms_parity = 0;
 }
 
-// Do two streams run side by side?  The tail is two chains on two streams that must overlap, and whether they do depends on the
-// hardware queues the runtime maps them onto (a pool per priority, least-used first: a process's earlier contexts decide what a
-// new one gets).  Probe: on A a kernel that waits for a flag (bounded), then an empty kernel - whose packet carries the barrier
-// bit and waits for the first; on B, enqueued last, the kernel that sets the flag.  When the two queues are served
-// independently the setter runs at once and the waiter sees the flag within microseconds; when B's packets wait behind A's
-// (one hardware queue, or two that share a pipe of the command processor) the waiter runs into its bound.
-__global__ void k_probe_wait(int* flag, int limit) {
-  int spins = 0;
-  while (ld_agent(flag) == 0 && spins < limit) { __builtin_amdgcn_s_sleep(8); ++spins; }
-  flag[1] = spins;
-}
-__global__ void k_probe_set(int* flag) { st_agent(flag, 1); }
-__global__ void k_probe_nop() {}
-static int stream_pair_probe(svo_ctx* ctx, hipStream_t A, hipStream_t B, int* d_flag, int* spins_out) {
-  const int limit = 2000;   // ~0.5 ms
-  int h[2] = {0, 0};
-  SVO_HIP(ctx, hipMemcpyAsync(d_flag, h, 8, hipMemcpyHostToDevice, A));
-  SVO_HIP(ctx, hipStreamSynchronize(A));
-  SVO_HIP(ctx, hipStreamSynchronize(B));
-  hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, A, d_flag, limit);
-  hipLaunchKernelGGL(k_probe_nop, dim3(1), dim3(1), 0, A);
-  hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, B, d_flag);
-  SVO_HIP(ctx, hipStreamSynchronize(A));
-  SVO_HIP(ctx, hipStreamSynchronize(B));
-  SVO_HIP(ctx, hipMemcpy(h, d_flag, 8, hipMemcpyDeviceToHost));
-  *spins_out = h[1];
-  return SVO_OK;
-}
-// The index chain's stream: a high-priority stream that the probe finds running beside the pose chain's; up to four candidates
-// are made (the rejected ones are kept until the choice is made, so that the pool hands out another queue each time).
+// The index chain's stream: high priority, side by side with the pose chain's (and with the batched front end's, if that exists).
 static int track_index_stream(svo_ctx* ctx) {
-  static const bool no_probe = []() { const char* e = getenv("SVO_NO_STREAM_PROBE"); return e && e[0] == '1'; }();
-  if (no_probe) { ctx->idx_probe_attempts = 0; return svo_stream_create(&ctx->stream_idx, +1) == hipSuccess ? SVO_OK : SVO_E_HIP; }
-  int* d_flag = nullptr;
-  if (hipMalloc(reinterpret_cast<void**>(&d_flag), 8) != hipSuccess) return SVO_E_NOMEM;
-  std::vector<hipStream_t> rejected;
-  hipStream_t chosen = nullptr;
-  int rc = SVO_OK, spins = 0, attempts = 0;
-  for (; attempts < 4 && !chosen && rc == SVO_OK; ++attempts) {
-    hipStream_t cand = nullptr;
-    if (svo_stream_create(&cand, +1) != hipSuccess) { rc = SVO_E_HIP; break; }
-    rc = stream_pair_probe(ctx, ctx->stream, cand, d_flag, &spins);
-    if (rc == SVO_OK && spins < 1000) {
-      int back = 0;
-      rc = stream_pair_probe(ctx, cand, ctx->stream, d_flag, &back);   // and the other way round
-      if (rc == SVO_OK && back < 1000) { chosen = cand; break; }
-      spins = std::max(spins, back);
-    }
-    rejected.push_back(cand);
-  }
-  if (!chosen && !rejected.empty()) { chosen = rejected.back(); rejected.pop_back(); }   // none passed: the last one
-  for (hipStream_t r : rejected) hipStreamDestroy(r);
-  hipFree(d_flag);
-  ctx->stream_idx = chosen;
-  ctx->idx_probe_attempts = attempts + (chosen && spins < 1000 ? 1 : 0);
-  ctx->idx_probe_spins = spins;
-  return chosen ? rc : SVO_E_HIP;
+  return svo_pick_stream(ctx, [](hipStream_t* s) { return svo_stream_create(s, +1); }, {ctx->stream, ctx->stream_fe_batch}, &ctx->stream_idx,
+                         &ctx->idx_probe_attempts, &ctx->idx_probe_spins);
+}
+// The batched tracker's front-end stream ("fe_cu_percent" of the CUs): side by side with both chains of the tail.
+int svo_track_fe_batch_stream(svo_ctx* ctx) {
+  if (ctx->stream_fe_batch) return SVO_OK;
+  const int dev = ctx->device, pct = ctx->opt_fe_cu_percent;
+  int attempts = 0, percent = 0;
+  return svo_pick_stream(ctx, [dev, pct](hipStream_t* s) { return pct < 100 ? svo_stream_create_masked(s, dev, pct) : svo_stream_create(s, -1); },
+                         {ctx->stream, ctx->stream_idx}, &ctx->stream_fe_batch, &attempts, &percent);
 }
 
 // streams, events, work records and the kernels' LDS opt-ins for `frames` frames per call of `nseq` sequences
@@ -1464,6 +1477,8 @@ static int track_resources(svo_ctx* ctx, int frames, int nseq) {
                                    (int)sizeof(TpHypLds)) == hipSuccess;
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_hyp_ord), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)sizeof(TpHypOrdLds)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_tail_ord), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)sizeof(TpTailLds)) == hipSuccess;
     ctx->track_lds_state = ok ? 1 : -1;
     if (!ok) ctx->last_error = std::string("hipFuncSetAttribute(tracker kernels): ") + hipGetErrorString(hipGetLastError());
   }
@@ -1568,6 +1583,13 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
     const svo_kp* kpf = kp + row(f) * kstride;
     const float* depf = depth + row(f) * kstride;
     ctx->profiling = prof && (f % 32 == 0 || frames < 32);
+    if (ctx->opt_epnp_exact == 2 && ny == 1 && !ctx->hyp_two_launch && ctx->opt_tail_fused) {
+      // one sequence, the default solver: samples and frame part in ONE launch (k_tp_tail_ord)
+      SvoTimer t(ctx, "k_tp_tail_ord");
+      hipLaunchKernelGGL(k_tp_tail_ord, dim3(PNP_HYP + 1, 1), dim3(TPF_NT), sizeof(TpTailLds), s0, st, work + f, kpf, depf, ctx->d_pnp_subsets,
+                         d_res + f, kstride, ctx->opt_pose_mfma, tag_of(f), ctx->opt_epnp_force_seq);
+      return;
+    }
     if (ctx->opt_epnp_exact == 2) {
       SvoTimer t(ctx, "k_tp_hyp_ord");
       if (ny >= 8 || ctx->hyp_two_launch) {
@@ -1871,9 +1893,13 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
     const size_t n = (size_t)ctx->g.W * ctx->g.H, K = ctx->max_kp;
     if ((rc = dense_reserve(ctx, B))) return rc;
     if ((rc = track_resources(ctx, B, 1))) return rc;
-    if (!ctx->stream_dense)
-      SVO_HIP(ctx, ctx->opt_dense_cu_percent < 100 ? svo_stream_create_masked(&ctx->stream_dense, ctx->device, ctx->opt_dense_cu_percent)
-                                                   : svo_stream_create(&ctx->stream_dense, 0));
+    if (!ctx->stream_dense) {   // the dense stage's stream: beside both chains of the tail
+      const int dev = ctx->device, pct = ctx->opt_dense_cu_percent;
+      int attempts = 0, percent = 0;
+      const int rcp = svo_pick_stream(ctx, [dev, pct](hipStream_t* q) { return pct < 100 ? svo_stream_create_masked(q, dev, pct) : svo_stream_create(q, 0); },
+                                      {ctx->stream, ctx->stream_idx}, &ctx->stream_dense, &attempts, &percent);
+      if (rcp) return rcp;
+    }
     float* dD1 = ctx->d_dense;
     float* dD2 = dD1 + n * (size_t)ctx->dense_cap;
     int32_t* d_prod = reinterpret_cast<int32_t*>(dD2 + n * (size_t)ctx->dense_cap);
@@ -1956,9 +1982,7 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
     // front end on all CUs, 14.1 k on a quarter of them, 14.4 k on 32 CUs; stream priorities did not change that).  So the
     // batched tracker's front-end stream is confined to a share of the compute units (default an eighth: four CUs of every XCD): the
     // front end needs ~7 us per pair on the whole chip against the tail's ~70 us per frame - an eighth of the chip keeps up.
-    if (!ctx->stream_fe_batch)
-      SVO_HIP(ctx, ctx->opt_fe_cu_percent < 100 ? svo_stream_create_masked(&ctx->stream_fe_batch, ctx->device, ctx->opt_fe_cu_percent)
-                                                : svo_stream_create(&ctx->stream_fe_batch, -1));
+    { const int rcf = svo_track_fe_batch_stream(ctx); if (rcf) return rcf; }
     while ((int)ctx->ev_sub.size() < nsub) {
       hipEvent_t e;
       SVO_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -2252,9 +2276,7 @@ extern "C" int svo_track_sharded_dev(svo_ctx* const* ctxs, int G, const uint8_t*
   if (!sg->ev_gathered) SVO_HIP(c0, hipEventCreateWithFlags(&sg->ev_gathered, hipEventDisableTiming));
   for (int q = 0; q < 2; ++q)
     if (!sg->done[q]) SVO_HIP(c0, hipEventCreateWithFlags(&sg->done[q], hipEventDisableTiming));
-  if (!c0->stream_fe_batch)
-    SVO_HIP(c0, c0->opt_fe_cu_percent < 100 ? svo_stream_create_masked(&c0->stream_fe_batch, c0->device, c0->opt_fe_cu_percent)
-                                            : svo_stream_create(&c0->stream_fe_batch, -1));
+  { const int rcf = svo_track_fe_batch_stream(c0); if (rcf) return rcf; }
   const int per = (B + G - 1) / G;
   const size_t wk = sizeof(svo_kp) * (size_t)K, wd = 32 * (size_t)K, wf = 4 * (size_t)K;
   if (sg->per < per || sg->G < G) {

@@ -266,3 +266,23 @@ def test_bench_shard_mode_one_sequence_over_two_contexts():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["sharded"]["contexts"] == 2 and d["sharded"]["records_identical_to_single_context"] is True
     assert d["config"]["frames_tracked"] == 96 and d["value"] > 0 and d["scaling"] == "strong"
+
+
+@pytest.mark.gpu
+def test_tail_rate_does_not_depend_on_the_process_stream_history():
+    """The tracker's two chains need two streams that the runtime serves from two hardware queues; which queues new streams get
+    depends on what the process created before (tools/microbench/queue_pair_probe: with three older high-priority streams the
+    first two new ones SHARE a queue and serialise).  A process that made three idle high-priority streams and closed a tracker
+    context before creating its tracker must still reach >= 95 % of the rate of a process that did nothing before - the
+    context picks its streams by measuring (track_pick_stream)."""
+    def run(steps):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "queue_history.py"), steps], capture_output=True, text=True,
+                             timeout=600, cwd=ROOT)
+        rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+        assert out.returncode == 0 and rows, out.stderr[-2000:]
+        return rows
+    fresh = run("M")[0]
+    later = run("HM")[0]
+    print("QUEUE_HISTORY fresh %s" % json.dumps(fresh)); print("QUEUE_HISTORY after history %s" % json.dumps(later))
+    assert later["frames_per_s"] >= 0.95 * fresh["frames_per_s"], (fresh, later)
+    assert later["probe_two_chains_vs_one_percent"] < 150, later

@@ -566,9 +566,10 @@ def multi_sequence_leg(pkg, cam, dL, dR, frame_bytes, rec, dev, single):
     ms.sync()
     mdt = time.perf_counter() - t1
     m = mres.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(msteps, S)
+    probe = list(ms.debug_stream_probe())
     ms.close()
     same = all(m[t, 0].tobytes() == single[t].tobytes() for t in range(msteps))
-    return {"value": msteps * S / mdt, "unit": "stereo frames/s", "sequences": S, "steps": msteps,
+    return {"value": msteps * S / mdt, "stream_probe": probe, "unit": "stereo frames/s", "sequences": S, "steps": msteps,
             "sequence0_equals_single_chain": bool(same),
             "pipelined_steps": bool(int(os.environ.get("SVO_BENCH_MULTI_PIPELINE", "1"))),
             "note": "SURVEY 8e's 'G independent sequences' variant on ONE GPU: full Tracking::Track per frame; with "
@@ -610,9 +611,10 @@ def sharded_run(pkg, cam, dL, dR, n_frames, G, devices, rec, chunk=512, referenc
     run_all()
     dt = time.perf_counter() - t0
     got = res.cpu().numpy()
+    probe = list(ctxs[0].debug_stream_probe())
     for c in ctxs:
         c.close()
-    out = {"value": n_frames / dt, "unit": "stereo frames/s", "contexts": G, "devices": sorted(set(devices)),
+    out = {"value": n_frames / dt, "stream_probe": probe, "unit": "stereo frames/s", "contexts": G, "devices": sorted(set(devices)),
            "frames": int(n_frames), "frames_per_call": chunk,
            "note": "ONE sequence: the stateless front end shards by pair (pair k -> context k mod G), the strict chain of "
                    "src/Tracking.cc:231-250 stays on context 0 and bounds the rate at the tail's per-frame latency whatever G is "
@@ -669,6 +671,7 @@ def semantic_elas_leg(pkg, cam, dL, dR, dev, rec, n=256):
     svo.track_batch_dev(dL.data_ptr(), dR.data_ptr(), PITCH, n, res.data_ptr(), boxes=bx); svo.sync()
     svo.profile_enable(False)
     prof = svo.profile()
+    sem_probe = list(svo.debug_stream_probe())
     svo.close()
     # us per frame: batched kernels by their total over the call, the tail's per-frame kernels (timed on every 32nd frame only)
     # by their average launch
@@ -687,7 +690,7 @@ def semantic_elas_leg(pkg, cam, dL, dR, dev, rec, n=256):
                 "note": "the dense maps dominate: ELAS's compulsory 198 P bytes per pair + ORB on the left image; the leg is bound by "
                         "ELAS's host stages (support-point filter, Delaunay) under the CPU quota, the gating kernels add "
                         "k_tg_bf + k_tg_fmat per frame (see kernel_us_per_frame)"}
-    out = {"value": fps, "unit": "stereo frames/s", "frames": int(n), "boxes_per_frame": 2,
+    out = {"value": fps, "stream_probe": sem_probe, "unit": "stereo frames/s", "frames": int(n), "boxes_per_frame": 2,
            "mean_lm_edges": float(r["n_lm_edges"][1:].mean()), "mean_new_mappoints": float(r["n_new_mappoints"].mean()),
            "kernel_us_per_frame": {k: round(v, 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1])[:14]},
            "roofline": roof, "host_cpus": host_cpus(),
@@ -759,10 +762,17 @@ def solver_modes_leg(pkg, cam, dL, dR, frame_bytes, rec, dev, n_frames):
             chain = tail_chain_from_stamps(svo.debug_track_frames(0, B))
         except Exception:  # noqa: BLE001
             pass
+        out.setdefault("stream_probe", {})["epnp_exact=%d" % mode] = list(svo.debug_stream_probe())
+        kern = None
+        if mode == 0:   # per-kernel times of one more (untimed) call, the timers on
+            svo.profile_reset(); svo.profile_enable(True)
+            run(0, B); svo.sync()
+            svo.profile_enable(False)
+            kern = {k: round(1e3 * v[0] / max(v[1], 1), 1) for k, v in svo.profile().items()}
         svo.close()
         out["epnp_exact=%d" % mode] = {"value": (frames - 2 * B) / dt, "unit": "stereo frames/s", "frames_timed": int(frames - 2 * B),
                                         "solver": PNP_SOLVERS[mode],
-                                        "host_ms_after_each_call_then_sync": enq, "tail_critical_path": chain}
+                                        "host_ms_after_each_call_then_sync": enq, "tail_critical_path": chain, "kernel_avg_us": kern}
     return out
 
 
@@ -836,7 +846,7 @@ def run_tail_leg(name, pkg, cam, dL, dR, dev, local, refn=None):
     fb = H * PITCH
     N = TAIL_LEGS[name]
     if refn is None and name in ("sharded", "multi_sequence"):
-        refn = tail_leg_reference(pkg, cam, dL, dR, dev, local, 1024)
+        refn = tail_leg_reference(pkg, cam, dL, dR, dev, local, min(1024, int(dL.shape[0])))
     try:
         if name == "pnp_solver_modes":
             r = solver_modes_leg(pkg, cam, dL, dR, fb, rec, dev, N)
@@ -1256,6 +1266,7 @@ def main():
                 r = first[name]
                 r["order"] = "in-process, %d. of %s" % (names.index(name) + 1, " > ".join(names))
                 r["value_in_process_reverse_order"] = leg_value(second[name])
+                r["in_process_reverse_order"] = {k: v for k, v in second[name].items() if k in ("stream_probe", "epnp_exact=0", "error", "chain_us_per_frame")}
                 if not args.no_tail_leg_children:
                     progress("leg %s: child process" % name)
                     try:

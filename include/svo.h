@@ -32,7 +32,10 @@
 extern "C" {
 #endif
 
-#define SVO_ABI_VERSION 4   /* 4 (round 4): + svo_track_epnp_fallbacks, svo_debug_stream_probe; "epnp_exact" defaults to 2 (the
+#define SVO_ABI_VERSION 5   /* 5 (round 5): option "tail_fused" (default 1: RANSAC samples + frame part of the default solver in one launch);
+                              svo_debug_stream_probe's second value is now a ratio in per cent (see there); "epnp_exact" accepts every
+                              non-zero value again (ABI 3's meaning); svo_destroy waits for batched / sharded work in flight.
+                              4 (round 4): + svo_track_epnp_fallbacks, svo_debug_stream_probe; "epnp_exact" defaults to 2 (the
                               order-preserving solver); options gate_group, hyp_first, dense_cu_percent, dense_two_launch,
                               epnp_force_seq, shard_force_staged; svo_track_sharded_dev overlaps consecutive calls.
                               No signature of version 3 changed.  BEHAVIOUR changes a version-3 caller sees: (i) the tracker's
@@ -417,11 +420,15 @@ int svo_track_overflowed(svo_ctx* ctx, int32_t* flag);
 int svo_track_epnp_fallbacks(svo_ctx* ctx, int64_t* count);
 
 /* Diagnostics: how the stream of the tail's index chain was chosen.  The ordered tail (src/Tracking.cc:231-250 per frame) runs
- * as two chains on two streams that must overlap; which hardware queues the runtime maps them onto depends on the process's
- * earlier contexts, and some pairs of queues are served one after the other.  At the first tracker call of a context up to four
- * candidate streams are probed against the context's main stream (a bounded wait-for-flag kernel on one, the setter on the
- * other) and one that runs beside it is kept.  out[0] = candidates tried (0: probe off, SVO_NO_STREAM_PROBE=1; -1: no tracker
- * call yet), out[1] = polls the waiting kernel needed for the chosen one (>= 1000: none passed). */
+ * as two chains on two streams that must overlap.  The HIP runtime maps a process's streams onto a few hardware queues per
+ * priority (4 by default, least-used first), and two streams on ONE queue run one after the other: with three older
+ * high-priority streams alive in the process the first two new ones share a queue, and the tracker ran at 5.9 k instead of
+ * 8.8 k frames/s (tools/queue_history.py, profiles/r05_queue_pairs.jsonl).  Every stream of a context that has to run beside
+ * another one is therefore PICKED BY MEASURING (svo_pick_stream): a chain of eight short dependent kernels on the existing
+ * stream alone, then the same chain on both streams together; up to six candidates, the first whose ratio is below 150 % is
+ * kept.  out[0] = candidates tried for the index chain's stream (0: probe off, SVO_NO_STREAM_PROBE=1; -1: no tracker call
+ * yet), out[1] = "two chains together / one alone" of the chosen one, per cent (~105: side by side; ~200: serialised - then
+ * svo_last_error says so). */
 int svo_debug_stream_probe(svo_ctx* ctx, int32_t out[2]);
 
 /* Many independent sequences on one GPU ("G independent sequences" for pure

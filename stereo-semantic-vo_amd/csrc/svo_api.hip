@@ -1003,6 +1003,8 @@ int svo_pick_stream(svo_ctx* ctx, const std::function<hipError_t(hipStream_t*)>&
   }
   for (hipStream_t r : rejected) hipStreamDestroy(r);
   *out = best; *percent = best ? best_pct : 0;
+  static const bool dbg = getenv("SVO_PICK_DEBUG") != nullptr;
+  if (dbg) fprintf(stderr, "[svo_pick_stream] ctx %p: %d candidate(s), chosen %p runs at %d %% beside %zu stream(s)\n", (void*)ctx, *attempts, (void*)best, best_pct, others.size());
   if (best && best_pct >= 150)
     ctx->last_error = "tracker: no candidate stream ran beside the pose chain's (" + std::to_string(best_pct) + " % of one chain's time for two): the tail runs at a reduced rate";
   return best ? SVO_OK : SVO_E_HIP;

@@ -1894,11 +1894,14 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
     if ((rc = dense_reserve(ctx, B))) return rc;
     if ((rc = track_resources(ctx, B, 1))) return rc;
     if (!ctx->stream_dense) {   // the dense stage's stream: beside both chains of the tail
-      const int dev = ctx->device, pct = ctx->opt_dense_cu_percent;
-      int attempts = 0, percent = 0;
-      const int rcp = svo_pick_stream(ctx, [dev, pct](hipStream_t* q) { return pct < 100 ? svo_stream_create_masked(q, dev, pct) : svo_stream_create(q, 0); },
-                                      {ctx->stream, ctx->stream_idx}, &ctx->stream_dense, &attempts, &percent);
-      if (rcp) return rcp;
+      if (ctx->opt_dense_cu_percent < 100) {
+        SVO_HIP(ctx, svo_stream_create_masked(&ctx->stream_dense, ctx->device, ctx->opt_dense_cu_percent));   // (own hardware queue)
+      } else {
+        int attempts = 0, percent = 0;
+        const int rcp = svo_pick_stream(ctx, [](hipStream_t* q) { return svo_stream_create(q, 0); }, {ctx->stream, ctx->stream_idx},
+                                        &ctx->stream_dense, &attempts, &percent);
+        if (rcp) return rcp;
+      }
     }
     float* dD1 = ctx->d_dense;
     float* dD2 = dD1 + n * (size_t)ctx->dense_cap;

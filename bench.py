@@ -520,23 +520,40 @@ def frontend_leg(pkg, cam, dL, dR, n_frames, frame_bytes, dev, all_cores):
                         "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, B), "valu": pmc_valu(dom),
                         "algorithmic_bytes_per_launch": algo,
                         "pipeline_frac": ALGO_BYTES_PER_PAIR * (B * steps / dt) / 1e9 / HBM_PEAK_GBS}}
-    # What actually bounds the front end: vector-ALU instruction issue.  Every SIMD issues one wave64 VALU instruction per four
-    # cycles: 256 CUs x 4 SIMDs x 2.4 GHz / 4 = 614 G wave-instructions/s; the kernels' counted instructions (SQ_INSTS_VALU of the
-    # committed PMC passes, 64 pairs per dispatch, k_pyr_fused three launches per pass) give the pairs/s that ceiling allows.
+    # What bounds the front end: vector-ALU instruction issue, priced PER ISSUE CLASS.  A SIMD does not issue "one wave64
+    # instruction per four cycles" (round 4's figure - the cadence of ONE wave): tools/microbench/valu_class (profiles/
+    # r05_valu_class.jsonl, 1 / 2 / 4 / 8 waves per SIMD) measures ~1.0 ns per instruction for plain VOP1 / VOP2 integer and f32
+    # operations and ~1.85 ns for everything else (three-operand VOP3, packed, min / max, compares, multiplies, dots, v_perm,
+    # SDWA / DPP, f64, and any VOP2 that reads a scalar register).  Each kernel's counted instructions (SQ_INSTS_VALU of the
+    # committed PMC passes, 64 pairs per dispatch) are weighted with the class mix of its emitted code (tools/isa_mix.py ->
+    # profiles/r05_isa_mix.json): the time the chip's 1,024 SIMDs need for them is the bound.
     try:
-        per_pass = 0.0
-        for k, launches in (("k_pyr_fused", 3), ("k_fast", 1), ("k_select", 1), ("k_describe", 1), ("k_stereo_match", 1), ("k_stereo_median", 1)):
+        mix = json.load(open(os.path.join(ROOT, "profiles", "r05_isa_mix.json")))
+        tf, th, tq = mix["t_full_ns"], mix["t_half_ns"], mix["t_quarter_ns"]
+        per_kernel, ns_total, instr_total = {}, 0.0, 0.0
+        for k, launches, variants in (("k_pyr_fused", 3, ("k_pyr_fused<2>", "k_pyr_fused<3>")), ("k_fast", 1, ("k_fast",)), ("k_select", 1, ("k_select",)),
+                                      ("k_describe", 1, ("k_describe",)), ("k_stereo_match", 1, ("k_stereo_match",)),
+                                      ("k_stereo_median", 1, ("k_stereo_median",))):
             e = pmc_entry(k)
-            per_pass += launches * e["SQ_INSTS_VALU"] / (e.get("_pairs_per_dispatch_traffic", 64) / 64.0)
-        instr_per_pair = per_pass / 64.0
-        peak = 256 * 4 * 2.4e9 / 4.0
-        out["roofline"]["valu_issue"] = {"bound": "wave64 VALU instruction issue (one per SIMD per four cycles)", "peak": peak / 1e9,
-                                         "achieved": out["value"] * instr_per_pair / 1e9, "unit": "G wave-instructions/s",
-                                         "frac": out["value"] * instr_per_pair / peak, "valu_instructions_per_pair": instr_per_pair,
-                                         "pairs_per_s_at_peak": peak / instr_per_pair,
-                                         "source": "profiles/pmc_latest.json (SQ_INSTS_VALU of profiles/r04_z_frontend_pmc.json)"}
-    except Exception:  # noqa: BLE001
-        pass
+            n_instr = launches * e["SQ_INSTS_VALU"] / (e.get("_pairs_per_dispatch_traffic", 64) / 64.0) / 64.0     # per pair
+            m = [mix["kernels"][v] for v in variants]
+            ns = sum(x["share_full"] * tf + x["share_half"] * th + x["share_quarter"] * tq for x in m) / len(m)
+            per_kernel[k] = {"valu_instructions_per_pair": n_instr, "share_half_rate": sum(x["share_half"] for x in m) / len(m), "ns_per_instruction": ns}
+            ns_total += n_instr * ns
+            instr_total += n_instr
+        simds = 256 * 4
+        bound_pairs_per_s = simds / (ns_total * 1e-9)
+        out["roofline"]["valu_issue"] = {
+            "bound": "wave64 VALU instruction issue, weighted by issue class (full-rate %.2f ns, half-rate %.2f ns, quarter-rate %.2f ns per "
+                     "instruction per SIMD; 1,024 SIMDs)" % (tf, th, tq),
+            "pairs_per_s_at_the_bound": bound_pairs_per_s, "achieved_pairs_per_s": out["value"], "frac": out["value"] / bound_pairs_per_s,
+            "valu_instructions_per_pair": instr_total, "simd_ns_per_pair": ns_total, "kernels": per_kernel,
+            "frac_if_every_instruction_were_full_rate": out["value"] * instr_total * tf * 1e-9 / simds,
+            "frac_if_every_instruction_were_half_rate": out["value"] * instr_total * th * 1e-9 / simds,
+            "source": "profiles/pmc_latest.json (SQ_INSTS_VALU), profiles/r05_isa_mix.json (static class mix of the emitted code), "
+                      "profiles/r05_valu_class.jsonl (measured issue cost per instruction)"}
+    except Exception as e:  # noqa: BLE001
+        out["roofline"]["valu_issue"] = {"error": repr(e)}
     if all_cores is not None:
         Lh = dL[:64, :, :W].cpu().numpy(); Rh = dR[:64, :, :W].cpu().numpy()
         out["cpu_baseline_all_cores"] = all_cores(Lh, Rh, cam)

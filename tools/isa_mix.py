@@ -55,8 +55,24 @@ def load_table(path):
     return t
 
 
-def classify(mn, table):
-    """-> (class, measured?)"""
+SGPR_OPERAND = re.compile(r"(?<![\w.])(s\d+|s\[\d+:\d+\]|vcc(_lo|_hi)?|exec(_lo|_hi)?|m0|ttmp\d+)(?![\w])")
+
+
+def classify(line, table):
+    """-> (class, measured?) of one instruction line.  A full-rate VOP2 / VOP1 that reads a scalar register (a uniform operand, a
+    lane mask) issues at the half rate (measured: v_and_b32 with an SGPR source 1.86 ns against 1.08 ns)."""
+    parts = line.split(None, 1)
+    mn = parts[0]
+    ops = parts[1] if len(parts) > 1 else ""
+    cls, measured = classify_mnemonic(mn, table)
+    if cls == "full":
+        srcs = ops.split(",", 1)[1] if "," in ops else ""
+        if SGPR_OPERAND.search(srcs):
+            return "half", measured
+    return cls, measured
+
+
+def classify_mnemonic(mn, table):
     base = re.sub(r"_(e32|e64|dpp|sdwa)$", "", mn)
     if mn.endswith("_dpp"):
         return "half", "__dpp__" in table
@@ -102,19 +118,35 @@ def kernels_of(asm_text):
         s = line.strip()
         if not s or s.startswith((";", ".", "//")) or s.endswith(":"):
             continue
-        body.append(s.split()[0])
+        body.append(s.split(";")[0].strip())
     if cur:
         yield cur, body
 
 
 def demangle(n):
-    try:
-        return subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", n], capture_output=True, text=True).stdout.strip().split("(")[0]
-    except OSError:
-        return n
+    for tool in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "c++filt"):
+        try:
+            out = subprocess.run([tool, n], capture_output=True, text=True).stdout.strip()
+            if out and out != n:
+                return out.split("(")[0].replace("void ", "")
+        except OSError:
+            pass
+    m = re.match(r"_Z\d+(k_[a-z_0-9]+?)(ILi(\d+)EE)?[vP1-9]", n)
+    return (m.group(1) + ("<%s>" % m.group(3) if m.group(3) else "")) if m else n
+
+
+def class_times(table):
+    """median ns per wave-instruction per SIMD of the measured instructions of each class (4 waves per SIMD)"""
+    import statistics
+    full = [v for k, v in table.items() if not k.startswith("__") and k.startswith("v_") and v < 1.45]
+    half = [v for k, v in table.items() if not k.startswith("__") and k.startswith("v_") and 1.45 <= v < 2.6 and "cndmask" not in k]
+    quarter = [v for k, v in table.items() if not k.startswith("__") and k.startswith("v_") and 2.6 <= v < 5.0]
+    return (statistics.median(full) if full else FULL_NS, statistics.median(half) if half else HALF_NS,
+            statistics.median(quarter) if quarter else QUARTER_NS)
 
 
 def main():
+    global FULL_NS, HALF_NS, QUARTER_NS
     ap = argparse.ArgumentParser()
     ap.add_argument("--json")
     ap.add_argument("--table", default=os.path.join(ROOT, "profiles", "r05_valu_class.jsonl"))
@@ -122,6 +154,7 @@ def main():
     ap.add_argument("filters", nargs="*")
     a = ap.parse_args()
     table = load_table(a.table)
+    FULL_NS, HALF_NS, QUARTER_NS = class_times(table)
     out = {}
     with tempfile.TemporaryDirectory() as td:
         for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
@@ -137,10 +170,11 @@ def main():
                 cls = collections.Counter()
                 unmeasured = collections.Counter()
                 mix = collections.Counter()
-                for mn in body:
+                for line in body:
+                    mn = line.split()[0]
                     if not is_valu(mn):
                         continue
-                    c, measured = classify(mn, table)
+                    c, measured = classify(line, table)
                     cls[c] += 1
                     mix[mn] += 1
                     if not measured:
@@ -164,7 +198,10 @@ def main():
         if a.top:
             print("      " + "  ".join("%s:%d" % kv for kv in v["top"].items()))
     if a.json:
-        json.dump({"t_full_ns": FULL_NS, "t_half_ns": HALF_NS, "t_quarter_ns": QUARTER_NS, "kernels": out}, open(a.json, "w"), indent=1)
+        json.dump({"t_full_ns": FULL_NS, "t_half_ns": HALF_NS, "t_quarter_ns": QUARTER_NS,
+                   "source": "tools/isa_mix.py over csrc/*.hip (static mix of the emitted gfx950 assembly) x profiles/r05_valu_class.jsonl "
+                             "(tools/microbench/valu_class: ns one wave64 instruction occupies a SIMD at 4 waves per SIMD, medians per class)",
+                   "kernels": out}, open(a.json, "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -90,7 +90,7 @@ def tail_kernel_bytes(kernel, mean_pool_rows, mean_kp, mean_edges, mean_lm_iters
         return mean_edges * 40.0 + 100 * 112.0
     if kernel == "k_tp_frame":      # n correspondences of 40 bytes: once for the gather + once per LM iteration and trial
         return mean_edges * 40.0 * (1.0 + 2.0 * mean_lm_iters)
-    if kernel == "k_tp_pose":       # the fused RANSAC + LM kernel: both of the above
+    if kernel in ("k_tp_pose", "k_tp_tail_ord"):       # RANSAC samples + LM in one launch: both of the above
         return mean_edges * 40.0 * (2.0 + 2.0 * mean_lm_iters) + 100 * 112.0
     return 0.0
 
@@ -808,8 +808,8 @@ def tail_chain_from_stamps(dbg):
     resolve = (rt[:, 1] - rt[:, 0]) * 0.01
     period = np.diff(rt[:, 3]) * 0.01                              # us between consecutive frames' pose-kernel ends
     period = period[(period > 0) & (period < 5000)]
-    hyp = (rt[:, 4] - rt[:, 2]) * 0.01                             # RANSAC samples: first workgroup start -> the frame kernel's start
-    frm = (rt[:, 3] - rt[:, 4]) * 0.01                             #   (includes the ~1.3 us launch boundary); LM kernel start -> end
+    hyp = (rt[:, 4] - rt[:, 2]) * 0.01                             # RANSAC samples: first workgroup start -> the frame part's start (two
+    frm = (rt[:, 3] - rt[:, 4]) * 0.01                             #   launches: includes the boundary; one launch: the last sample's result seen); frame part start -> end
     rounds = dbg["rounds"][ok]
     return {"frames_sampled": int(len(rt)), "mean_rounds_pass1_pass2": [float(rounds[:, 0].mean()), float(rounds[:, 1].mean())],
             "pose_chain_busy_us": {"mean": float(pose_busy.mean()), "median": float(np.median(pose_busy))},
@@ -917,6 +917,21 @@ def progress(msg):
     sys.stderr.flush()
 
 
+def start_watchdog(seconds):
+    """A run that stops answering must not sit until the driver's limit: after `seconds` the process says where it was and
+    exits non-zero (no re-exec: the GPU may be in use).  One unexplained stall was seen in round 4 (never again in >40 runs)."""
+    import threading
+
+    def fire():
+        sys.stderr.write("[bench %.1f s] watchdog: no result after %d s - giving up (exit code 3)\n" % (time.perf_counter() - T_START, seconds))
+        sys.stderr.flush()
+        os._exit(3)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -926,6 +941,7 @@ def main():
     ap.add_argument("--frames", type=int, default=4541, help="length of the resident sequence (KITTI 00: 4541)")
     ap.add_argument("--batch", type=int, default=0,
                     help="pairs per step per GPU: track default frames // (warmup + steps), frontend default 128")
+    ap.add_argument("--watchdog", type=int, default=1500, help="seconds after which a run that has not printed its line exits with code 3 (0: off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the untimed per-kernel profile pass")
     ap.add_argument("--no-legs", action="store_true", help="only the main workload (no frontend / multi_sequence / sharded / semantic_elas / elas / msa legs)")
@@ -945,6 +961,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (single-GPU dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks / contexts use cuda:0 (dry run of the N>1 path on one GPU)")
     args = ap.parse_args()
+    if args.watchdog > 0:
+        start_watchdog(args.watchdog)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     env_world = os.environ.get("WORLD_SIZE")
@@ -1196,10 +1214,13 @@ def main():
             # the tail's kernels: in-kernel wall-clock stamps of the timed region where they exist (an event pair around a ~40 us
             # kernel of single-wave workgroups inflates it by up to 10 us; the stamps agree with rocprofv3's averages)
             stamped = {}
-            hyp_name = next((k for k in ("k_tp_hyp_ord", "k_tp_hyp", "k_tp_hyp_exact") if k in per_frame), "k_tp_hyp_ord")
+            fused_tail = "k_tp_tail_ord" in per_frame      # samples + frame part in one launch (the default)
+            hyp_name = "k_tp_tail_ord" if fused_tail else next((k for k in ("k_tp_hyp_ord", "k_tp_hyp", "k_tp_hyp_exact") if k in per_frame), "k_tp_hyp_ord")
             if chain and "k_ti_resolve_us" in chain:
                 stamped = {name: chain[key + "_us"]["mean"] * 1e-3 for key, name in
                            (("k_ti_resolve", "k_ti_resolve"), ("k_tp_hyp", hyp_name), ("k_tp_frame", "k_tp_frame")) if name in per_frame}
+                if fused_tail:
+                    stamped["k_tp_tail_ord"] = (chain["k_tp_hyp_us"]["mean"] + chain["k_tp_frame_us"]["mean"]) * 1e-3
                 for k, v in stamped.items():
                     per_frame[k] = v
                     kern[k]["ms_per_frame"] = v
@@ -1241,7 +1262,8 @@ def main():
                 hyp_us, frm_us = chain["k_tp_hyp_us"]["mean"], chain["k_tp_frame_us"]["mean"]
                 v = pmc_valu(hyp_name)
                 out["critical_path"] = {
-                    "kernels": [hyp_name, "k_tp_frame"], "us_per_frame": [hyp_us, frm_us],
+                    "kernels": ["k_tp_tail_ord: RANSAC samples", "k_tp_tail_ord: frame part (RANSAC rule, LM, new map points)"] if fused_tail
+                               else [hyp_name, "k_tp_frame"], "us_per_frame": [hyp_us, frm_us],
                     "share_of_frame_period": (hyp_us + frm_us) / max(chain["frame_period_us"]["mean"], 1e-9),
                     "bound": "float64 instruction issue of ONE wavefront per RANSAC sample (quad-cycle cadence: <= 0.25 instructions per "
                              "cycle per wave): the solve is a dependent chain - 148 Jacobi steps of ~150 instructions (division and "
@@ -1254,8 +1276,12 @@ def main():
                                             "LDS round trips of the row exchange and hazard wait states",
                                     "source": "profiles/pmc_latest.json: (SQ_INSTS_VALU + SQ_INSTS_SALU + SQ_INSTS_LDS) / SQ_WAVE_CYCLES of the "
                                               "kernel, rocprofv3 --pmc passes of profiles/r04_z_track_*" if v else "no counters committed for this kernel"},
-                    "hbm_frac_of_this_kernel": (tail_kernel_bytes(hyp_name, 0, 0, float(res["n_lm_edges"][1:].mean()), 0) / (hyp_us * 1e-6) / 1e9 / HBM_PEAK_GBS),
+                    "hbm_frac_of_this_kernel": (tail_kernel_bytes("k_tp_hyp_ord", 0, 0, float(res["n_lm_edges"][1:].mean()), 0) / (hyp_us * 1e-6) / 1e9 / HBM_PEAK_GBS),
                 }
+                # the headline's roofline leads with the model that governs the critical-path kernel; the HBM fraction (the contract's
+                # fields above) comes second
+                out["roofline"]["issue_model"] = dict(out["critical_path"]["issue_model"], bound=out["critical_path"]["bound"],
+                                                      share_of_frame_period=out["critical_path"]["share_of_frame_period"])
         if world == 1 and not args.no_cpu_baseline:
             ns = min(n_frames, 64)
             Lh = dL[:ns, :, :W].cpu().numpy()

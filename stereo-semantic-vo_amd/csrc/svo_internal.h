@@ -223,6 +223,14 @@ __host__ __device__ inline T* svo_byte_offset(T* p, size_t bytes) {
 // Streams by role: +1 the ordered tail's chains (small dependent kernels whose workgroups must not queue behind the front end's
 // thousands), -1 the batched front end running beside it, 0 everything else.  Maps onto the device's stream-priority range.
 hipError_t svo_stream_create(hipStream_t* st, int role);
+// MSA (svo_msa.hip / svo_msa_graph.hip): one node of an aggregation tree by level-order position - first child's position |
+// weight of the edge to the parent + (children << 8) | parent's position (-1: the root) | pixel
+struct MsaBfsRec { int32_t cpos, meta, ppos, node; };
+// svo_msa_graph.hip: svo_msa_tree's tree written directly as level-order records (rec: width * height entries), the level
+// boundaries (levels + 1 entries) and the widest level.  SVO_E_CAPACITY: a node has more than 255 children (the records cannot
+// hold it - the caller takes the child-list form).
+int svo_msa_tree_rec(const uint8_t* m_img3, const double* r_gra, const double* c_gra, int width, int height, MsaBfsRec* rec,
+                     std::vector<int32_t>* level_ptr, int* maxw, int32_t* root);
 int svo_track_quiesce(svo_ctx* ctx, bool shard_too = true);   // waits for what overlapped tracker calls left in flight and may still read this context's arrays
 int svo_shard_quiesce(svo_ctx* ctx);   // svo_track.hip: the sharded tracker's part of that
 // svo_api.hip: a new stream (made by `make`) that runs side by side with every non-null stream of `others`, chosen by measuring

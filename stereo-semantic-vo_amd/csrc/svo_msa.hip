@@ -170,7 +170,8 @@ __global__ void k_msa_dp_down_many(const MsaTreeTab* tabs, int l, int D, const d
 // stay in LDS: a level costs one LDS round trip and a barrier, the HBM reads of the next level's own terms are issued a
 // level ahead.  Arithmetic and its order are those of k_msa_dp_up / k_msa_dp_down (the child's weighted term
 // Exp[c] * (double)up[child] is formed by the child, added by the parent in child order).
-struct MsaBfsRec { int32_t cpos, meta, ppos, node; };   // first child's position | weight to parent + (children << 8) | parent's position | pixel
+// (MsaBfsRec - first child's position | weight to parent + (children << 8) | parent's position | pixel - is declared in svo_internal.h:
+// the host-side tree builder writes the records itself)
 struct MsaBfsTab {   // one tree and the volumes of one aggregation over it
   const MsaBfsRec* rec; const int32_t* level_ptr; int32_t levels, N;
   const float* cost;   // [pixel][D] in
@@ -602,6 +603,10 @@ __global__ void k_msa_scale(const uint8_t* d, int n, int scale, uint8_t* out) {
   if (i < n) out[i] = (uint8_t)(d[i] * scale);
 }
 
+}  // namespace
+extern "C" int svo_msa_tree(const uint8_t* m_img3, const double* r_gra, const double* c_gra, int width, int height, int32_t* seq,
+                            int32_t* child_ptr, int32_t* child, uint8_t* child_c, int32_t* root);
+namespace {
 struct HostTree {                       // what svo_msa_tree returns, plus what the level-by-level sweep needs
   std::vector<int32_t> seq, child_ptr, child, parent, nodes, level_ptr, depth_, fill_;
   std::vector<uint8_t> child_c, parent_c;
@@ -647,7 +652,40 @@ struct HostTree {                       // what svo_msa_tree returns, plus what 
     }
     levels_full(N);
   }
-  void need_full(int N) { if (!full_) levels_full(N); }   // the level-launch fallback's arrays, on demand
+  // The tree of one image, ready for k_msa_dp_bfs: svo_msa_tree_rec writes the level-order records and the level boundaries
+  // WHILE it walks the tree breadth-first (round 5: the breadth-first sequence, the child lists in CSR form and levels() were
+  // three passes over the tree with random access each - 15 % of a tree's host time).  The by-pixel arrays (seq, child lists)
+  // exist only on the fallback path (SVO_MSA_LEVEL_LAUNCHES, or a node with more than 255 children).
+  void build(const uint8_t* med3, const double* r_gra, const double* c_gra, int m, int n) {
+    const int N = n * m;
+    static const bool level_launches = getenv("SVO_MSA_LEVEL_LAUNCHES") != nullptr;
+    if (!level_launches) {
+      rec.resize(N);
+      rc = svo_msa_tree_rec(med3, r_gra, c_gra, m, n, rec.data(), &level_ptr, &maxw, &root);
+      if (rc == SVO_OK) { bfs_ok = true; full_ = false; have_csr_ = false; return; }
+      if (rc != SVO_E_CAPACITY) return;
+    }
+    seq.resize(N); child_ptr.resize(N + 1); child.resize(N); child_c.resize(N);
+    rc = svo_msa_tree(med3, r_gra, c_gra, m, n, seq.data(), child_ptr.data(), child.data(), child_c.data(), &root);
+    have_csr_ = true;
+    if (rc == SVO_OK) levels(N);
+  }
+  bool have_csr_ = false;
+  // the level-launch fallback's arrays, on demand (the child lists by pixel are read back from the records if need be)
+  void need_full(int N) {
+    if (full_) return;
+    if (!have_csr_) {
+      seq.resize(N); child_ptr.assign(N + 1, 0); child.resize(N); child_c.resize(N);
+      for (int g = 0; g < N; ++g) { seq[g] = rec[g].node; child_ptr[rec[g].node + 1] = (rec[g].meta >> 8) & 255; }
+      for (int u = 0; u < N; ++u) child_ptr[u + 1] += child_ptr[u];
+      for (int g = 0; g < N; ++g) {
+        const int e0 = child_ptr[rec[g].node], nch = (rec[g].meta >> 8) & 255;
+        for (int j = 0; j < nch; ++j) { child[e0 + j] = rec[rec[g].cpos + j].node; child_c[e0 + j] = (uint8_t)(rec[rec[g].cpos + j].meta & 255); }
+      }
+      have_csr_ = true;
+    }
+    levels_full(N);
+  }
   void levels_full(int N) {
     full_ = true;
     parent.assign(N, -1); parent_c.assign(N, 0);
@@ -686,9 +724,6 @@ struct MsaHostStore {
 };
 
 }  // namespace
-
-extern "C" int svo_msa_tree(const uint8_t* m_img3, const double* r_gra, const double* c_gra, int width, int height, int32_t* seq,
-                            int32_t* child_ptr, int32_t* child, uint8_t* child_c, int32_t* root);
 
 // img3[side]: packed BGR images on the device (3 * m bytes per row); d_out: n * m bytes on the device.
 static int msa_solve_device(svo_ctx* ctx, hipStream_t s, DevBuf& buf, uint8_t* const img3[2], int n, int m, int d, int scale,
@@ -762,10 +797,7 @@ static int msa_solve_device(svo_ctx* ctx, hipStream_t s, DevBuf& buf, uint8_t* c
   HostTree tree[2];
   auto grow = [&](int side) {
     HostTree& t = tree[side];
-    t.seq.resize(N); t.child_ptr.resize(N + 1); t.child.resize(N); t.child_c.resize(N);
-    t.rc = svo_msa_tree(h_med[side].data(), h_gra.data() + 2 * side * N, h_gra.data() + (2 * side + 1) * N, m, n, t.seq.data(),
-                        t.child_ptr.data(), t.child.data(), t.child_c.data(), &t.root);
-    if (t.rc == SVO_OK) t.levels((int)N);
+    t.build(h_med[side].data(), h_gra.data() + 2 * side * N, h_gra.data() + (2 * side + 1) * N, m, n);
   };
   {
     std::thread right(grow, 1);
@@ -1076,12 +1108,9 @@ static int msa_many_device(svo_ctx* ctx, hipStream_t s, const uint8_t* dL, const
       for (int k = next.fetch_add(1); k < 2 * C; k = next.fetch_add(1)) {
         HostTree& t = tree[k];
         const int b = k >> 1, side = k & 1;
-        t.seq.resize(N); t.child_ptr.resize(N + 1); t.child.resize(N); t.child_c.resize(N);
         const auto ta = std::chrono::steady_clock::now();
-        t.rc = svo_msa_tree(h_med[k].data(), h_gra[b].data() + 2 * side * N, h_gra[b].data() + (2 * side + 1) * N, m, n, t.seq.data(),
-                            t.child_ptr.data(), t.child.data(), t.child_c.data(), &t.root);
+        t.build(h_med[k].data(), h_gra[b].data() + 2 * side * N, h_gra[b].data() + (2 * side + 1) * N, m, n);
         const auto tb = std::chrono::steady_clock::now();
-        if (t.rc == SVO_OK) t.levels((int)N);
         if (dbg) { dbg_tree_us += (long long)std::chrono::duration<double, std::micro>(tb - ta).count(); dbg_levels_us += (long long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tb).count(); }
       }
     };

@@ -144,6 +144,50 @@ class TreeBuilder {
     mark("label_regions");
     merge_regions();
     mark("merge_regions");
+    return finish_csr(seq, child_ptr, child, child_w);
+  }
+  // the same tree as level-order records, written while it is walked breadth-first (see HostTree::build in svo_msa.hip)
+  int run_rec(const uint8_t* img3, const double* gx, const double* gy, MsaBfsRec* rec, std::vector<int32_t>& level_ptr, int* maxw) {
+    img3_ = img3;
+    dbg_mark_ = nullptr;
+    arborescence(gx, gy);
+    if (roots_.empty()) return -1;
+    label_regions();
+    merge_regions();
+    std::vector<int32_t>& parent = parent_;
+    parent.assign(N_, -1);
+    level_ptr.clear(); level_ptr.push_back(0);
+    int n_seq = 1, level_end = 1, w = 0;
+    bool fits = true;
+    rec[0] = MsaBfsRec{1, 0, -1, roots_[0]};
+    for (int t = 0; t < n_seq; ++t) {
+      if (t == level_end) {                       // first node of the next level: everything enqueued so far belongs to it
+        w = std::max(w, t - level_ptr.back());
+        level_ptr.push_back(t);
+        level_end = n_seq;
+      }
+      const int u = rec[t].node, first = n_seq;
+      for (int i = head_[u]; i >= 0; i = link_[i].next) {
+        const int v = link_[i].to;
+        if (v == parent[u]) continue;
+        if (n_seq == N_) return -2;   // not a tree
+        rec[n_seq++] = MsaBfsRec{0, link_[i].w, t, v};
+        parent[v] = u;
+      }
+      const int nch = n_seq - first;
+      if (nch > 255) fits = false;
+      rec[t].cpos = first;
+      rec[t].meta |= nch << 8;
+    }
+    if (n_seq != N_) return -2;
+    w = std::max(w, N_ - level_ptr.back());
+    level_ptr.push_back(N_);
+    *maxw = w;
+    return fits ? roots_[0] : -3;
+  }
+
+ private:
+  int finish_csr(int32_t* seq, int32_t* child_ptr, int32_t* child, uint8_t* child_w) {
     // breadth-first order from the first root; parent[] doubles as the visited mark
     std::vector<int32_t>& parent = parent_;
     parent.assign(N_, -1);
@@ -167,11 +211,8 @@ class TreeBuilder {
         if (link_[i].to != parent[u]) { child[n_child] = link_[i].to; child_w[n_child] = (uint8_t)link_[i].w; ++n_child; }
       child_ptr[u + 1] = n_child;
     }
-    mark("bfs order + child lists");
     return roots_[0];
   }
-
- private:
   int n_ = 0, m_ = 0, N_ = 0;
   EdgeHeaps heaps_;
   Sets strong_, weak_, merged_;
@@ -400,6 +441,25 @@ class TreeBuilder {
 
 }  // namespace
 
+static std::unique_ptr<TreeBuilder> builder_take();
+static void builder_give(std::unique_ptr<TreeBuilder> tb);
+
+int svo_msa_tree_rec(const uint8_t* m_img3, const double* r_gra, const double* c_gra, int width, int height, MsaBfsRec* rec,
+                     std::vector<int32_t>* level_ptr, int* maxw, int32_t* root) {
+  if (!m_img3 || !r_gra || !c_gra || !rec || !level_ptr || !maxw || !root || width < 2 || height < 2 || (int64_t)width * height > (1 << 24))
+    return SVO_E_INVALID;
+  std::unique_ptr<TreeBuilder> tb = builder_take();
+  tb->reshape(height, width);
+  g_active_builders.fetch_add(1);
+  const int rt = tb->run_rec(m_img3, r_gra, c_gra, rec, *level_ptr, maxw);
+  g_active_builders.fetch_sub(1);
+  builder_give(std::move(tb));
+  if (rt == -3) return SVO_E_CAPACITY;
+  if (rt < 0) return SVO_E_INVALID;
+  *root = rt;
+  return SVO_OK;
+}
+
 // One image's aggregation tree (host-side, needs no GPU).  m_img3: median-filtered colour image (height*width*3), r_gra /
 // c_gra: its gradients (svo_msa_init).  seq: width*height, child_ptr: +1, child / child_w: -1 entries.
 extern "C" int svo_msa_tree(const uint8_t* m_img3, const double* r_gra, const double* c_gra, int width, int height,
@@ -407,24 +467,30 @@ extern "C" int svo_msa_tree(const uint8_t* m_img3, const double* r_gra, const do
   if (!m_img3 || !r_gra || !c_gra || !seq || !child_ptr || !child || !child_w || !root || width < 2 || height < 2 ||
       (int64_t)width * height > (1 << 24))
     return SVO_E_INVALID;
-  // builders are kept (at most 32) for their allocations; concurrent callers each get their own
-  static std::mutex pool_mutex;
-  static std::vector<std::unique_ptr<TreeBuilder>> pool;
-  std::unique_ptr<TreeBuilder> tb;
-  {
-    std::lock_guard<std::mutex> lock(pool_mutex);
-    if (!pool.empty()) { tb = std::move(pool.back()); pool.pop_back(); }
-  }
-  if (!tb) tb.reset(new TreeBuilder());
+  std::unique_ptr<TreeBuilder> tb = builder_take();
   tb->reshape(height, width);
   g_active_builders.fetch_add(1);
   const int rt = tb->run(m_img3, r_gra, c_gra, seq, child_ptr, child, child_w);
   g_active_builders.fetch_sub(1);
-  {
-    std::lock_guard<std::mutex> lock(pool_mutex);
-    if (pool.size() < 32) pool.push_back(std::move(tb));
-  }
+  builder_give(std::move(tb));
   if (rt < 0) return SVO_E_INVALID;
   *root = rt;
   return SVO_OK;
+}
+
+// builders are kept (at most 32) for their allocations; concurrent callers each get their own
+static std::mutex g_builder_pool_mutex;
+static std::vector<std::unique_ptr<TreeBuilder>> g_builder_pool;
+static std::unique_ptr<TreeBuilder> builder_take() {
+  std::unique_ptr<TreeBuilder> tb;
+  {
+    std::lock_guard<std::mutex> lock(g_builder_pool_mutex);
+    if (!g_builder_pool.empty()) { tb = std::move(g_builder_pool.back()); g_builder_pool.pop_back(); }
+  }
+  if (!tb) tb.reset(new TreeBuilder());
+  return tb;
+}
+static void builder_give(std::unique_ptr<TreeBuilder> tb) {
+  std::lock_guard<std::mutex> lock(g_builder_pool_mutex);
+  if (g_builder_pool.size() < 32) g_builder_pool.push_back(std::move(tb));
 }

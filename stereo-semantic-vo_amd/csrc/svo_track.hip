@@ -1217,7 +1217,7 @@ __device__ __forceinline__ void tp_frame_body(TpLds& S, TrackState* st, TrackWor
                                               svo_track_result* res_out, int kstride, int use_mfma, int tag, int pre_gathered) {
   const int tid = threadIdx.x;
   if (!tp_wait_work(st, work, tag)) return;
-  if (tid == 0) work->rt[4] = wall_clock64();
+  if (!FUSED && tid == 0) work->rt[4] = wall_clock64();   // (FUSED: stamped when the samples are done, below)
   const long long tf0 = clock64();
   const int id = ld_agent(&work->frame_id), nkp = ld_agent(&work->nkp), skip = ld_agent(&work->skip_match), n_edges = ld_agent(&work->n_edges);
   // (this thread's first correspondence with the header, in one round trip: see k_tp_hyp)
@@ -1269,6 +1269,7 @@ __device__ __forceinline__ void tp_frame_body(TpLds& S, TrackState* st, TrackWor
     }
     __syncthreads();
   }
+  if (FUSED && tid == 0) work->rt[4] = wall_clock64();   // the frame part proper starts here (rt[2] .. rt[4]: the samples)
   if (ran)
     for (int h = tid; h < PNP_HYP; h += TPF_NT) {
       // every sample's thread prepares the pow / log terms the iteration bound would need if that sample became the best

@@ -642,7 +642,7 @@ def sharded_run(pkg, cam, dL, dR, n_frames, G, devices, rec, chunk=512, referenc
     return out
 
 
-SEM_ELAS_OPTIONS = {}
+SEM_ELAS_OPTIONS = {k: int(v) for k, v in (kv.split("=") for kv in filter(None, os.environ.get("SVO_BENCH_SEM_ELAS_OPTIONS", "").split(",")))}   # experiments
 
 
 def semantic_elas_leg(pkg, cam, dL, dR, dev, rec, n=256):
@@ -654,7 +654,7 @@ def semantic_elas_leg(pkg, cam, dL, dR, dev, rec, n=256):
     n = min(n, dL.shape[0])
     svo = pkg.Svo(W, H, device=dev.index or 0, max_kp=500, max_batch=n)
     svo.set_option("depth_source", 1)
-    for k, v in SEM_ELAS_OPTIONS.items():        # experiments (tools/sem_elas_try.py)
+    for k, v in SEM_ELAS_OPTIONS.items():        # experiments (SVO_BENCH_SEM_ELAS_OPTIONS)
         svo.set_option(k, v)
     bx, keep = boxes_hbm(pkg, n, dev)
     res = torch.zeros((n, rec), dtype=torch.uint8, device=dev)

@@ -1584,8 +1584,10 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
     const svo_kp* kpf = kp + row(f) * kstride;
     const float* depf = depth + row(f) * kstride;
     ctx->profiling = prof && (f % 32 == 0 || frames < 32);
-    if (ctx->opt_epnp_exact == 2 && ny == 1 && !ctx->hyp_two_launch && ctx->opt_tail_fused) {
-      // one sequence, the default solver: samples and frame part in ONE launch (k_tp_tail_ord)
+    if (ctx->opt_epnp_exact == 2 && ny == 1 && !ctx->hyp_two_launch && ctx->opt_tail_fused && ctx->opt_depth_source == 0) {
+      // one sequence, the default solver: samples and frame part in ONE launch (k_tp_tail_ord).  Not beside a dense stereo stage
+      // (depth_source 1 / 2): a fused launch's sample workgroups carry the frame part's 67 KB of LDS and three idle waves each,
+      // which the dense kernels running on the same CUs pay for (configs[4]: 6.05 k frames/s fused, 6.85 k with two launches)
       SvoTimer t(ctx, "k_tp_tail_ord");
       hipLaunchKernelGGL(k_tp_tail_ord, dim3(PNP_HYP + 1, 1), dim3(TPF_NT), sizeof(TpTailLds), s0, st, work + f, kpf, depf, ctx->d_pnp_subsets,
                          d_res + f, kstride, ctx->opt_pose_mfma, tag_of(f), ctx->opt_epnp_force_seq);

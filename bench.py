@@ -1200,6 +1200,11 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "kitti00" if os.environ.get("KITTI_ROOT") else "synthetic", "config": cfg,
         }
+        if track and not multi:
+            try:
+                cfg["stream_probe"] = {"candidates_tried": int(svo.debug_stream_probe()[0]), "two_chains_vs_one_percent": int(svo.debug_stream_probe()[1])}
+            except Exception:  # noqa: BLE001
+                pass
         if chain:
             out["tail_critical_path"] = chain
         if prof:
@@ -1308,6 +1313,7 @@ def main():
             for name in names:
                 r = first[name]
                 r["order"] = "in-process, %d. of %s" % (names.index(name) + 1, " > ".join(names))
+                r["value_in_process"] = leg_value(first[name])
                 r["value_in_process_reverse_order"] = leg_value(second[name])
                 r["in_process_reverse_order"] = {k: v for k, v in second[name].items() if k in ("stream_probe", "epnp_exact=0", "error", "chain_us_per_frame")}
                 if not args.no_tail_leg_children:
@@ -1317,9 +1323,19 @@ def main():
                                             stdout=subprocess.PIPE, timeout=600, check=True)
                         child = json.loads(cp.stdout.decode().strip().splitlines()[-1])[name]
                         r["value_child_process"] = leg_value(child)
+                        # the leg's figure: the process of its own (what rounds 3 and 4 reported, and what a deployment - one tracker per
+                        # process - gets); the two in-process figures stand beside it
+                        if "value" in child:
+                            r["value"] = child["value"]
+                            r["value_is"] = "child process (a process of its own); value_in_process / value_in_process_reverse_order: this process"
+                        elif name == "pnp_solver_modes":
+                            for k2, v2 in child.items():
+                                if isinstance(v2, dict) and "value" in v2 and k2 in r:
+                                    r[k2]["value_in_process"] = r[k2]["value"]
+                                    r[k2]["value"] = v2["value"]
                     except Exception as e:  # noqa: BLE001
                         r["value_child_process"] = repr(e)
-                    r["in_process_over_child"] = [leg_ratio(leg_value(r), r["value_child_process"]),
+                    r["in_process_over_child"] = [leg_ratio(r["value_in_process"], r["value_child_process"]),
                                                   leg_ratio(r["value_in_process_reverse_order"], r["value_child_process"])]
                 out[name] = r
             progress("leg frontend")

@@ -203,6 +203,10 @@ void svo_destroy(svo_ctx* ctx);
  *   0 = statistical wave solver (csrc/svo_epnp_dev.h; the default up to round 3): parallel-order two-sided Jacobi, normal
  *       equations, FMA - the same estimator with another rounding; 1.65x faster than mode 2, RANSAC's winner differs from a
  *       CPU run on ~3 % of the frames.
+ * "tail_fused" (default 1): one sequence, default solver, no dense stage beside the tail: the frame's RANSAC samples and its frame
+ *   part (RANSAC's rule, PoseOptimization, the new map points' positions, the record) run as ONE launch (k_tp_tail_ord: 100
+ *   sample workgroups + the frame's workgroup, which waits for their agent-scope results) instead of two - the launch boundary
+ *   and the frame part's start-up leave the pose chain's critical path (8.74 k -> 8.9-9.0 k frames/s).  Same records.
  * "epnp_force_seq" (default 0, tests): 1 = mode 2 takes its sequential fallback for every sample.
  * "dense_two_launch" (default 0): svo_track_batch_dev with depth_source = 1: the tail beside the dense stage launches its RANSAC
  *   samples as in the many-sequence mode (see "hyp_first") - fewer CUs taken from ELAS on ordinary frames.  Measured: no gain

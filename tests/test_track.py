@@ -161,14 +161,18 @@ def test_gpu_batch_tracker_equals_frame_by_frame(pkg, sequence):
     dL[:, :, :W] = torch.from_numpy(L).to(dev); dR[:, :, :W] = torch.from_numpy(R).to(dev)
     res = torch.zeros((N_FRAMES, pkg.TRACK_DTYPE.itemsize), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
-    b = pkg.Svo(W, H, max_batch=N_FRAMES)
-    b.track_reset(cam)
-    b.track_batch_dev(dL.data_ptr(), dR.data_ptr(), pitch, N_FRAMES, res.data_ptr())
-    b.sync()
-    out = res.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(-1)
-    b.close()
-    for k in range(N_FRAMES):
-        assert out[k].tobytes() == single[k].tobytes(), k
+    # the pose chain as ONE launch per frame (k_tp_tail_ord, the default) and as two (RANSAC samples, then the frame part)
+    for fused in (1, 0):
+        b = pkg.Svo(W, H, max_batch=N_FRAMES)
+        b.set_option("tail_fused", fused)
+        b.track_reset(cam)
+        b.track_batch_dev(dL.data_ptr(), dR.data_ptr(), pitch, N_FRAMES, res.data_ptr())
+        b.sync()
+        out = res.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(-1)
+        assert b.track_overflowed() == 0
+        b.close()
+        for k in range(N_FRAMES):
+            assert out[k].tobytes() == single[k].tobytes(), (fused, k)
 
 
 # ---- depth source 1: dense ELAS map (BASELINE configs[4] without YOLO; reference data flow src/Tracking.cc:226-228) ----

@@ -144,7 +144,9 @@ class TreeBuilder {
     mark("label_regions");
     merge_regions();
     mark("merge_regions");
-    return finish_csr(seq, child_ptr, child, child_w);
+    const int rt = finish_csr(seq, child_ptr, child, child_w);
+    mark("bfs order + child lists");
+    return rt;
   }
   // the same tree as level-order records, written while it is walked breadth-first (see HostTree::build in svo_msa.hip)
   int run_rec(const uint8_t* img3, const double* gx, const double* gy, MsaBfsRec* rec, std::vector<int32_t>& level_ptr, int* maxw) {

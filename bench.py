@@ -1266,6 +1266,12 @@ def main():
                 # instruction per 4 cycles whatever the instruction is
                 hyp_us, frm_us = chain["k_tp_hyp_us"]["mean"], chain["k_tp_frame_us"]["mean"]
                 v = pmc_valu(hyp_name)
+                if v and fused_tail:
+                    # a fused launch is 101 workgroups of four waves; 300 of its 404 waves leave at once (only the first wave of a
+                    # sample workgroup solves): per-wave figures over the 104 waves that work
+                    d = pmc_entry(hyp_name)
+                    v["instr_all_per_wave"] = (d["SQ_INSTS_VALU"] + d.get("SQ_INSTS_SALU", 0.0) + d.get("SQ_INSTS_LDS", 0.0)) / 104.0
+                    v["waves_that_work"] = 104
                 out["critical_path"] = {
                     "kernels": ["k_tp_tail_ord: RANSAC samples", "k_tp_tail_ord: frame part (RANSAC rule, LM, new map points)"] if fused_tail
                                else [hyp_name, "k_tp_frame"], "us_per_frame": [hyp_us, frm_us],
@@ -1280,7 +1286,7 @@ def main():
                                             "issues every second quad-cycle, v_rcp / v_rsq_f64 every fourth, a 4x4x4 DMFMA occupies five), "
                                             "LDS round trips of the row exchange and hazard wait states",
                                     "source": "profiles/pmc_latest.json: (SQ_INSTS_VALU + SQ_INSTS_SALU + SQ_INSTS_LDS) / SQ_WAVE_CYCLES of the "
-                                              "kernel, rocprofv3 --pmc passes of profiles/r04_z_track_*" if v else "no counters committed for this kernel"},
+                                              "kernel, rocprofv3 --pmc passes of profiles/r05_z_track_*" if v else "no counters committed for this kernel"},
                     "hbm_frac_of_this_kernel": (tail_kernel_bytes("k_tp_hyp_ord", 0, 0, float(res["n_lm_edges"][1:].mean()), 0) / (hyp_us * 1e-6) / 1e9 / HBM_PEAK_GBS),
                 }
                 # the headline's roofline leads with the model that governs the critical-path kernel; the HBM fraction (the contract's

@@ -1,4 +1,5 @@
-"""Where the pose chain's two kernels spend their time (s_memtime stamps of the last frame of a batched call; 100 ticks per us)."""
+"""Where the pose chain spends its time: s_memtime stamps (shader cycles, ~2.1-2.4 per ns) of the last frame of a batched call, printed
+in thousands of cycles.  With the fused pose launch (the default) the frame part's first column includes its wait for the samples."""
 import sys, importlib, ctypes as C
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, ".")
 import numpy as np, torch, svo_loader, bench
@@ -18,10 +19,10 @@ for c0 in range(0, N, 64):
     s.track_batch_dev(dL.data_ptr() + c0 * fb, dR.data_ptr() + c0 * fb, bench.PITCH, 64, res.data_ptr() + c0 * rec)
     ts = (C.c_int64 * 16)()
     s.lib.svo_debug_track_pose_stamps(s.h, ts)
-    t = np.array(list(ts), np.float64) / 100.0
+    t = np.array(list(ts), np.float64) / 1000.0
     r = res[c0 + 63].cpu().numpy().view(pkg.TRACK_DTYPE)[0]
     rows.append((t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[9] - t[8], t[10] - t[9], t[11] - t[10], int(r["n_lm_edges"]), int(r["lm_iterations"])))
-print("hyp: gather, to EPnP start, EPnP, consensus | frame: gather+rule, LM, record | edges, LM iterations   (us)")
+print("samples: gather, to EPnP start, EPnP, consensus | frame part: gather+wait+rule, LM, record | edges, LM iterations   (k cycles)")
 for r in rows:
     print("  %5.1f %5.1f %5.1f %5.1f | %5.1f %5.1f %5.1f | %d %d" % r)
 s.close()

@@ -17,6 +17,15 @@ names = {"p": "pnp_solver_modes", "s": "sharded", "m": "multi_sequence", "e": "s
 rec = pkg.TRACK_DTYPE.itemsize
 fb = bench.H * bench.PITCH
 for c in (sys.argv[1] if len(sys.argv) > 1 else "psme"):
+    if c == "w":   # warm the runtime's hardware-queue pools: four used streams per priority, released again
+        ss = [torch.cuda.Stream(device=dev, priority=p) for p in (-1, -1, -1, -1, 0, 0, 0, 0)]
+        for st in ss:
+            with torch.cuda.stream(st):
+                torch.zeros(8, device=dev).add_(1)
+        torch.cuda.synchronize()
+        del ss
+        print(json.dumps({"leg": "hardware-queue pools warmed (4 high + 4 normal priority streams used and released)"}), flush=True)
+        continue
     if c in "hf":   # h: a headline-like context (batched tracker over 1024 frames), closed again; f: the same with the statistical solver + kernel times
         s = pkg.Svo(bench.W, bench.H, device=0, max_kp=500, max_batch=256)
         if c == "f":

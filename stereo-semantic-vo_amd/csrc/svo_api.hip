@@ -1024,6 +1024,17 @@ hipError_t svo_stream_create_masked(hipStream_t* st, int device, int percent) {
 }
 
 hipError_t svo_stream_create(hipStream_t* st, int role) {
+  static const bool dedicated = []() { const char* e = getenv("SVO_DEDICATED_QUEUES"); return e && e[0] == '1'; }();
+  if (dedicated) {   // experiment: every stream on a hardware queue of its own (a CU-masked stream with the full mask; normal priority)
+    int dev = 0; hipGetDevice(&dev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+      const int words = (prop.multiProcessorCount + 31) / 32;
+      std::vector<uint32_t> mask((size_t)words, 0xffffffffu);
+      if (hipExtStreamCreateWithCUMask(st, (uint32_t)words, mask.data()) == hipSuccess) return hipSuccess;
+      (void)hipGetLastError();
+    }
+  }
   int least = 0, greatest = 0;   // numerically: greatest priority <= least priority
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
   const int prio = role > 0 ? greatest : (role < 0 ? least : (least + greatest) / 2);

@@ -1024,16 +1024,23 @@ hipError_t svo_stream_create_masked(hipStream_t* st, int device, int percent) {
 }
 
 hipError_t svo_stream_create(hipStream_t* st, int role) {
+  // SVO_DEDICATED_QUEUES=1: the tail's two chains (role > 0: the context's main stream, the index chain's stream) on hardware queues
+  // of their own - CU-masked streams, which the runtime never pools - that keep off the CUs the batched front end is confined to
+  // (the first mask word: four CUs of every XCD).  The tracker's rate then no longer depends on who else holds the runtime's pooled
+  // queues (14.2 k / 102 k frames/s where the pooled streams gave 7.4 k / 57 k), and the RANSAC workgroups
+  // never queue behind front-end waves; the price is the tail's high stream priority (masked streams have none), which two
+  // contexts sharded on ONE GPU need (9.0 k -> 6.8 k frames/s).  Off by default.
   static const bool dedicated = []() { const char* e = getenv("SVO_DEDICATED_QUEUES"); return e && e[0] == '1'; }();
-  if (dedicated) {   // experiment: every stream on a hardware queue of its own (a CU-masked stream with the full mask; normal priority)
-    int dev = 0; hipGetDevice(&dev);
+  if (dedicated && role > 0) {
+    int dev = 0;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
       const int words = (prop.multiProcessorCount + 31) / 32;
       std::vector<uint32_t> mask((size_t)words, 0xffffffffu);
+      if (words > 1) mask[0] = 0;
       if (hipExtStreamCreateWithCUMask(st, (uint32_t)words, mask.data()) == hipSuccess) return hipSuccess;
-      (void)hipGetLastError();
     }
+    (void)hipGetLastError();
   }
   int least = 0, greatest = 0;   // numerically: greatest priority <= least priority
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }

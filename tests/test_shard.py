@@ -282,7 +282,12 @@ def test_tail_rate_does_not_depend_on_the_process_stream_history():
         assert out.returncode == 0 and rows, out.stderr[-2000:]
         return rows
     fresh = run("M")[0]
-    later = run("HM")[0]
-    print("QUEUE_HISTORY fresh %s" % json.dumps(fresh)); print("QUEUE_HISTORY after history %s" % json.dumps(later))
-    assert later["frames_per_s"] >= 0.95 * fresh["frames_per_s"], (fresh, later)
-    assert later["probe_two_chains_vs_one_percent"] < 150, later
+    print("QUEUE_HISTORY fresh %s" % json.dumps(fresh))
+    # S: three contexts created first and left open, idle - the history that, without the picker, puts the new context's two
+    # chains on ONE hardware queue (5.9 k instead of 8.8 k frames/s with SVO_NO_STREAM_PROBE=1); H: three used high-priority streams
+    # of another library (torch) and a closed tracker context
+    for steps in ("SM", "HM"):
+        later = run(steps)[0]
+        print("QUEUE_HISTORY %s %s" % (steps, json.dumps(later)))
+        assert later["frames_per_s"] >= 0.95 * fresh["frames_per_s"], (steps, fresh, later)
+        assert later["probe_two_chains_vs_one_percent"] < 150, (steps, later)

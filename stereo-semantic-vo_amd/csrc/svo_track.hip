@@ -248,13 +248,15 @@ __global__ __launch_bounds__(256) void k_ti_lists(TrackState* st, const uint32_t
     // A entries: the columns this row could ever claim (distance < 30), in column order - piece t holds columns
     // 64 t .. 64 t + 63, lanes ascending
     int nA = 0;
+    if (mn < 30) {   // (uniform: the wave's minimum) two rows in three have no column below 30 - nothing to list
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const bool c = dcol[t] < 30;
-      const uint64_t m = __ballot(c);
-      const int pos = nA + __popcll(m & lt_mask);
-      if (c && pos < TRK_LCAP) { acol[wv][pos] = (uint16_t)(lane + 64 * t); adist[wv][pos] = (uint8_t)dcol[t]; }
-      nA += __popcll(m);
+      for (int t = 0; t < 8; ++t) {
+        const bool c = dcol[t] < 30;
+        const uint64_t m = __ballot(c);
+        const int pos = nA + __popcll(m & lt_mask);
+        if (c && pos < TRK_LCAP) { acol[wv][pos] = (uint16_t)(lane + 64 * t); adist[wv][pos] = (uint8_t)dcol[t]; }
+        nA += __popcll(m);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the wave reads back what its lanes just stored
     __builtin_amdgcn_wave_barrier();

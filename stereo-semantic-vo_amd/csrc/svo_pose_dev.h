@@ -771,6 +771,27 @@ __device__ __forceinline__ int pnp_select_pre(const int* cnt, const int* ok, con
   return best;
 }
 
+// The same loop over the first m samples only: the number of samples the rule visits if it ends within them (<= m), or m + 1 if
+// it would go on - then nothing is decided yet.
+__device__ __forceinline__ int pnp_select_pre_bound(const int* cnt, const int* ok, const double* ld, const int* r, int n, int m) {
+  int niters = PNP_HYP, maxGood = 0;
+  if (n == 5) return 1;
+  const double num = log(fmax(1. - 0.99, 2.2250738585072014e-308));
+  int iter = 0;
+  for (; iter < niters; ++iter) {
+    if (iter >= m) return m + 1;
+    if (!ok[iter]) continue;
+    const int g = cnt[iter];
+    if (g > max(maxGood, 4)) {
+      maxGood = g;
+      const double d = ld[iter];
+      if (d == 1.0) niters = 0;
+      else niters = d >= 0 || -num >= niters * (-d) ? niters : r[iter];
+    }
+  }
+  return iter;   // = samples visited (niters = 0 leaves after the sample that set it)
+}
+
 // RANSACPointSetRegistrator::run over the precomputed samples (one thread): sample `iter` replaces the best one iff its
 // consensus is larger (and > 4), and the iteration bound shrinks with the inlier ratio.  Returns the winning sample
 // (-1: none), *good its consensus, *iters the samples visited.

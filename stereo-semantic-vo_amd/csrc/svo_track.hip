@@ -72,6 +72,9 @@ struct TrackPool {
   uint8_t in_local[TRK_CAP];
 };
 
+// Samples of the fused pose launch whose completion the frame's workgroup waits for one by one: cv::solvePnPRansac's adaptive bound
+// ends within the first 8 samples on 96 % of the frames (a median of 4), and then the other 92 need not be waited for.
+#define TP_EARLY 8
 // What the index chain hands to the pose chain for one frame.
 // Written by k_ti_resolve with agent-scope (sc1) stores and published through `ready`, read by the pose kernels with agent-scope
 // loads after they have seen the tag: the pose chain does not wait on stream events for the index chain (see tp_wait_work).
@@ -90,6 +93,8 @@ struct TrackWork {
   int32_t pnp_best, pnp_iterations, pnp_inliers, pnp_ok;
   double T_pnp[16];
   int32_t hyp_done, pad_hyp;     // fused pose launch (k_tp_tail_ord): RANSAC samples of this frame that have stored their result
+  int32_t hyp_early[TP_EARLY];   // ... and, for the first TP_EARLY samples, frame id + 1 once that sample's result is stored (ids only grow
+                                 // between two resets and a reset clears the records: a stale value never equals the current one)
 };
 
 struct TrackState {
@@ -1152,6 +1157,7 @@ __device__ __forceinline__ void tp_hyp_ord_body(TpHypOrdLds& S, TrackState* st, 
   const long long t_start = clock64();
   if (threadIdx.x == 0 && sample == 0) work->rt[2] = wall_clock64();
   const int n = ld_agent(&work->n_edges);
+  const int frame_tag = FUSED ? ld_agent(&work->frame_id) + 1 : 0;
   if (ld_agent(&work->skip_match) || n < 5) return;
   if (hyp_base > 0) {   // second launch of a many-sequence step: only the samples the adaptive bound can still reach (see k_tp_hyp)
     const int pre = min(hyp_base, TP_HYP_PRE);   // the rule over the samples of the earlier launches (all of them done: same stream)
@@ -1179,7 +1185,10 @@ __device__ __forceinline__ void tp_hyp_ord_body(TpHypOrdLds& S, TrackState* st, 
   pnp_hyp_ord_wave<FUSED>(S.ord, S.Xw, S.uv, n, K, subsets + (size_t)min(n, 512) * 500, st->hyp, sample, force_seq != 0);
   if (FUSED) {
     TP_STORES_DONE();   // (lane 0's agent-scope stores of the sample's result have reached the coherent level)
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(&work->hyp_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+      if (sample < TP_EARLY) st_agent(&work->hyp_early[sample], frame_tag);
+      __hip_atomic_fetch_add(&work->hyp_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   if (threadIdx.x == 0 && S.ord.S.flag) atomicAdd(&st->epnp_fallbacks, 1);
   if (sample == 0 && threadIdx.x == 0) {
@@ -1263,16 +1272,38 @@ __device__ __forceinline__ void tp_frame_body(TpLds& S, TrackState* st, TrackWor
   if (tid < 4 && !have_corr) st->K[tid] = (double)((const float*)&st->cam)[tid];
   // ---- PnP initial pose (src/pnpmatch.cc:212-247): no prior; if solvePnPRansac fails the last pose stays ----------
   const bool ran = !skip && n_edges >= 5;
-  if (FUSED && ran) {   // the samples of this launch: all PNP_HYP results stored (bounded wait, as tp_wait_work's)
-    if (tid == 0) {
+  bool decided_early = false;
+  if (FUSED && ran) {
+    // The samples of this launch.  First the TP_EARLY lowest ones, each awaited by a thread of its own (which fetches the sample's
+    // consensus and prepares its pow / log terms as soon as it sees it): if the rule ends within them - it nearly always does -
+    // the slowest of the other samples is not waited for.  (Bounded waits, as tp_wait_work's.)
+    if (tid < TP_EARLY) {
       int spins = 0;
-      while (ld_agent(&work->hyp_done) < PNP_HYP && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(1); ++spins; }
+      while (ld_agent(&work->hyp_early[tid]) != id + 1 && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(1); ++spins; }
       if (spins >= (1 << 22)) st->overflow = 4;
+      const int c = ld_agent(&st->hyp[tid].cnt), o = ld_agent(&st->hyp[tid].ok);
+      S.cnt[tid] = c; S.ok[tid] = o;
+      double ld = 1.0; int r = 0;
+      if (o && c > 4 && n_edges > 5) pnp_update_terms(c, n_edges, &ld, &r);
+      S.upd_ld[tid] = ld; S.upd_r[tid] = r;
+    } else if (tid < PNP_HYP) {
+      S.cnt[tid] = 0; S.ok[tid] = 0; S.upd_ld[tid] = 1.0; S.upd_r[tid] = 0;   // (never visited when the rule ends early)
     }
     __syncthreads();
+    if (tid == 0) S.iters = pnp_select_pre_bound(S.cnt, S.ok, S.upd_ld, S.upd_r, n_edges, TP_EARLY);
+    __syncthreads();
+    decided_early = S.iters <= TP_EARLY;
+    if (!decided_early) {   // all PNP_HYP results stored
+      if (tid == 0) {
+        int spins = 0;
+        while (ld_agent(&work->hyp_done) < PNP_HYP && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(1); ++spins; }
+        if (spins >= (1 << 22)) st->overflow = 4;
+      }
+      __syncthreads();
+    }
   }
   if (FUSED && tid == 0) work->rt[4] = wall_clock64();   // the frame part proper starts here (rt[2] .. rt[4]: the samples)
-  if (ran)
+  if (ran && !decided_early)
     for (int h = tid; h < PNP_HYP; h += TPF_NT) {
       // every sample's thread prepares the pow / log terms the iteration bound would need if that sample became the best
       const int c = FUSED ? ld_agent(&st->hyp[h].cnt) : st->hyp[h].cnt, o = FUSED ? ld_agent(&st->hyp[h].ok) : st->hyp[h].ok;

@@ -32,7 +32,11 @@
 extern "C" {
 #endif
 
-#define SVO_ABI_VERSION 5   /* 5 (round 5): option "tail_fused" (default 1: RANSAC samples + frame part of the default solver in one launch);
+#define SVO_ABI_VERSION 6   /* 6 (round 5, late): + svo_debug_stream_pipes.  BEHAVIOUR: a context's four main streams are hardware queues of their own,
+                              created back to back at svo_create (four dispatch pipes; see svo_debug_stream_pipes) - they are BLOCKING
+                              streams (they order against the NULL stream, as every hipExtStreamCreateWithCUMask stream does) without a
+                              priority, kept off each other by CU masks; SVO_POOLED_QUEUES=1 restores the pooled streams of ABI 5.
+                              5 (round 5): option "tail_fused" (default 1: RANSAC samples + frame part of the default solver in one launch);
                               svo_debug_stream_probe's second value is now a ratio in per cent (see there); "epnp_exact" accepts every
                               non-zero value again (ABI 3's meaning); svo_destroy waits for batched / sharded work in flight.
                               4 (round 4): + svo_track_epnp_fallbacks, svo_debug_stream_probe; "epnp_exact" defaults to 2 (the
@@ -434,6 +438,18 @@ int svo_track_epnp_fallbacks(svo_ctx* ctx, int64_t* count);
  * yet), out[1] = "two chains together / one alone" of the chosen one, per cent (~105: side by side; ~200: serialised - then
  * svo_last_error says so). */
 int svo_debug_stream_probe(svo_ctx* ctx, int32_t out[2]);
+
+/* Diagnostics: do the large grids of the batched front end hold the ordered tail up?  gfx950 places a process's hardware queues on
+ * the command processor's four dispatch pipes in creation order (position among the live queues modulo 4), and a queue whose
+ * launches wait behind each other holds up the other queues of its pipe: with the front end's queue on the pose chain's pipe
+ * the tracker ran at half its rate (tools/microbench/queue_block_probe, queue_prio_probe; profiles/r05_queue_block.jsonl).  A
+ * context therefore makes its four main streams (pose chain, index chain, batched front end, dense stage) as four queues of
+ * its own back to back - four different pipes, whatever the process did before or does elsewhere later.  This call MEASURES it
+ * (about 10 ms, everything of the context synchronised first): a 3,072 x 64-thread grid on the pose stream (out[0]) and on the
+ * index stream (out[1]) alone, then beside four queued launches of slot-filling grids on the front end's stream; reported as
+ * 100 + 100 x (delay in rounds of the filling grids' workgroups): ~100 clear, ~180 sharing CUs only, >= 330 held up behind the pipe.
+ * out[2], out[3]: the same with the dense stage's stream filling.  -1: that stream does not exist (yet). */
+int svo_debug_stream_pipes(svo_ctx* ctx, int32_t out[4]);
 
 /* Many independent sequences on one GPU ("G independent sequences" for pure
  * throughput; no counterpart in the reference, whose tracker is one static chain per process,

@@ -52,7 +52,7 @@ ABI_SYMBOLS = [
     "svo_frontend_batch_dev", "svo_track_batch_dev", "svo_profile_enable", "svo_profile_reset",
     "svo_profile_get",
     "svo_elas_default_params", "svo_elas_process", "svo_elas_process_ex", "svo_elas_delaunay",
-    "svo_ctmf", "svo_track_multi_reset", "svo_track_multi_step_dev", "svo_track_tail_dev", "svo_track_overflowed", "svo_track_epnp_fallbacks", "svo_debug_stream_probe", "svo_track_sharded_dev", "svo_elas_batch_dev", "svo_msa_init", "svo_msa_tree", "svo_msa_tree_dp", "svo_msa_wta", "svo_msa_lrcheck", "svo_msa_solve", "svo_msa_batch_dev",
+    "svo_ctmf", "svo_track_multi_reset", "svo_track_multi_step_dev", "svo_track_tail_dev", "svo_track_overflowed", "svo_track_epnp_fallbacks", "svo_debug_stream_probe", "svo_debug_stream_pipes", "svo_track_sharded_dev", "svo_elas_batch_dev", "svo_msa_init", "svo_msa_tree", "svo_msa_tree_dp", "svo_msa_wta", "svo_msa_lrcheck", "svo_msa_solve", "svo_msa_batch_dev",
 ]
 
 
@@ -377,6 +377,13 @@ class Svo:
         out = (C.c_int32 * 2)()
         self._chk(self.lib.svo_debug_stream_probe(self.h, out))
         return int(out[0]), int(out[1])
+
+    def debug_stream_pipes(self):
+        """Measured: how late a grid on the (pose, index) stream is beside queued filling grids on the front end's stream, then the
+        dense stage's - 100 + 100 x rounds, -1 where a stream does not exist; see include/svo.h."""
+        out = (C.c_int32 * 4)()
+        self._chk(self.lib.svo_debug_stream_pipes(self.h, out))
+        return [int(v) for v in out]
 
     def track_multi_reset(self, n_seq, cam):
         self._chk(self.lib.svo_track_multi_reset(self.h, int(n_seq), C.byref(cam)))

@@ -199,7 +199,7 @@ extern "C" int svo_create(svo_ctx** out, int device, int W, int H, int max_kp, i
   const SvoGeom& g = ctx->g;
   for (int l = 0; l < SVO_NLEVELS; ++l)
     if (g.quota[l] > SVO_QMAX) { delete ctx; return SVO_E_INVALID; }
-  if (svo_stream_create(&ctx->stream, +1) != hipSuccess) {
+  if (svo_stream_burst(ctx) != SVO_OK) {
     delete ctx;
     return SVO_E_NODEVICE;
   }
@@ -318,6 +318,8 @@ extern "C" void svo_destroy(svo_ctx* ctx) {
   for (hipStream_t st : ctx->fe_streams) hipStreamDestroy(st);
   for (hipEvent_t e : ctx->fe_events) hipEventDestroy(e);
   if (ctx->stream) hipStreamDestroy(ctx->stream);
+  for (hipStream_t st : ctx->parked_streams) hipStreamDestroy(st);
+  ctx->parked_streams.clear();
   delete ctx;
 }
 
@@ -897,7 +899,9 @@ extern "C" int svo_frontend_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, cons
     {   // a stream that runs beside the context's own (and beside the slices' streams made before it)
       int attempts = 0, percent = 0;
       const int rcp = svo_pick_stream(ctx, [](hipStream_t* s) { return svo_stream_create(s, 0); },
-                                      {ctx->stream, ctx->fe_streams.empty() ? nullptr : ctx->fe_streams.back()}, &st, &attempts, &percent);
+                                      {ctx->stream, ctx->fe_streams.empty() ? nullptr : ctx->fe_streams.back()}, &st, &attempts, &percent,
+                                      {ctx->stream, ctx->fe_streams.empty() ? nullptr : ctx->fe_streams.back()},
+                                      {ctx->stream, ctx->fe_streams.empty() ? nullptr : ctx->fe_streams.back()});   // (slices overlap: neither's grid in dispatch may hold the other's up)
       if (rcp) return rcp;
     }
     ctx->fe_streams.push_back(st);
@@ -979,32 +983,115 @@ static int probe_pair_percent(hipStream_t A, hipStream_t B) {
   (void)hipGetLastError();
   return (int)std::min(999.0, 100.0 * both / std::max(alone, 1.0));
 }
+// The second way two streams get into each other's way: two hardware queues behind ONE dispatch pipe of the command processor.
+// gfx950 places a process's hardware queues on four pipes in creation order (queue i and queue i + 4 share one).  Measured
+// (tools/microbench/queue_block_probe, queue_prio_probe; profiles/r05_queue_block.jsonl, r05_queue_prio.jsonl):
+//  * two normal-priority queues on one pipe: while the pipe is placing the workgroups of a grid that does not fit (64 KB of LDS per
+//    workgroup, two per CU), a chain of one-wave kernels on the other queue takes 8-9x its time - it waits for the whole grid; beside
+//    every queue of another pipe 1.0x.  Of twelve dedicated queues created one after the other exactly the pairs 4 and 8 places
+//    apart do this, and pooled queues created in between shift the pattern as the rule predicts;
+//  * a HIGH-priority queue on the pipe of the confined front end's queue is not stopped by such a grid, but by the real thing it is:
+//    grids of 256-thread workgroups that fill every wave slot of the eighth of the CUs their stream owns make a 3,072-workgroup grid
+//    on it take 119 us instead of 14 - on exactly one of the four pooled high-priority queues, the one whose creation index is
+//    congruent to the front end's queue; which stream gets that queue depends on what the process created before.
+// In the tracker this was the statistical solver's leg at 7.4 k instead of 14.2 k frames/s (64 sequences: 58 k instead of 102 k) in
+// a process that had used eight torch streams before, with every pair of streams passing the chain-beside-chain probe above (it
+// sees shared QUEUES, not shared pipes).  So a stream that carries large grids is also tested in that shape against the streams it
+// must not hold up: a 3,072 x 64-thread grid on the other stream alone, then beside a queue of slot-filling grids on this one.
+__global__ void k_probe_fill(long long cycles) {
+  const long long t0 = clock64();
+  while (clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(2);
+}
+static double probe_grid_us(hipStream_t V) {
+  const auto t0 = std::chrono::steady_clock::now();
+  hipLaunchKernelGGL(k_probe_fill, dim3(3072), dim3(64), 0, V, 4000LL);
+  hipStreamSynchronize(V);
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+}
+int svo_probe_block_percent(hipStream_t blocker, hipStream_t victim) {
+  hipStreamSynchronize(blocker); hipStreamSynchronize(victim);
+  (void)probe_grid_us(victim);
+  const double alone = std::min(probe_grid_us(victim), probe_grid_us(victim));
+  // one round of the filling side: a single workgroup spinning as long as its workgroups do (~45 us), less the cost of a launch
+  auto one_us = [blocker](long long cyc) {
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(k_probe_fill, dim3(1), dim3(256), 0, blocker, cyc);
+    hipStreamSynchronize(blocker);
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  };
+  (void)one_us(100LL);   // (first launch on this stream)
+  const double launch = one_us(100LL), round = std::max(10.0, one_us(100000LL) - launch);
+  // the filling side: FOUR launches of 4,096 x 256 threads queued back to back (2 rounds each on a whole device, 16 on an eighth of
+  // it).  It takes the queue of launches: ONE grid of any size in dispatch did not hold the other queue up (measured), a launch
+  // waiting behind its predecessor on the queue does - which is what the front end's stream looks like all the time.
+  for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(k_probe_fill, dim3(4096), dim3(256), 0, blocker, 100000LL);
+  const double beside = probe_grid_us(victim);
+  hipStreamSynchronize(blocker);
+  const hipError_t err = hipGetLastError();
+  // In rounds: a grid that merely has to find wave slots among the filling workgroups (a stream that owns every CU) waits for less
+  // than one round (measured 0.7); held up behind the other queue's pipe it takes 2.3-2.6.  Reported as 100 + 100 x rounds.
+  const double rounds = std::max(0.0, beside - alone) / round;
+  static const bool dbg = getenv("SVO_PICK_DEBUG") != nullptr;
+  if (dbg) fprintf(stderr, "[svo block probe] filling grids on %p (%.0f us per round), 3072 x 64 threads on %p: alone %.0f us, beside them %.0f us = %.1f rounds late (%s)\n",
+                   (void*)blocker, round, (void*)victim, alone, beside, rounds, hipGetErrorName(err));
+  return (int)std::min(9999.0, 100.0 + 100.0 * rounds);
+}
 // A new stream (made by `make`) that runs side by side with every stream of `others`: up to six candidates; the rejected ones are
 // kept until the choice is made, so that the pool hands out another queue each time.  None passes (a tool that serialises all
 // dispatches, e.g. rocprofv3's kernel trace): the best one.  *attempts / *percent: candidates tried, the chosen one's worst ratio.
 int svo_pick_stream(svo_ctx* ctx, const std::function<hipError_t(hipStream_t*)>& make, std::initializer_list<hipStream_t> others, hipStream_t* out,
-                    int* attempts, int* percent) {
+                    int* attempts, int* percent, std::initializer_list<hipStream_t> holds_up, std::initializer_list<hipStream_t> held_up_by) {
   static const bool no_probe = []() { const char* e = getenv("SVO_NO_STREAM_PROBE"); return e && e[0] == '1'; }();
+  static const bool no_block = []() { const char* e = getenv("SVO_NO_BLOCK_PROBE"); return e && e[0] == '1'; }();
+  static const bool dbg = getenv("SVO_PICK_DEBUG") != nullptr;
   *out = nullptr; *attempts = 0; *percent = 0;
   if (no_probe) return make(out) == hipSuccess ? SVO_OK : SVO_E_HIP;
   std::vector<hipStream_t> rejected;
   hipStream_t best = nullptr;
-  int best_pct = 1000;
+  int best_pct = 100000, best_block = 0;
+  // (a pipe holds every fourth queue: with the streams to keep clear of on at most three pipes, one of four consecutive new queues
+  // is free of them all; pooled candidates may repeat a queue, hence six tries, the last two on queues of their own)
   for (int k = 0; k < 6; ++k) {
     hipStream_t cand = nullptr;
-    if (make(&cand) != hipSuccess) { (void)hipGetLastError(); break; }
+    hipError_t e = hipSuccess;
+    if (k >= 4 && (holds_up.size() || held_up_by.size())) {
+      int dev = 0; hipDeviceProp_t prop;
+      e = hipGetDevice(&dev);
+      if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+      if (e == hipSuccess) {
+        std::vector<uint32_t> mask((size_t)(prop.multiProcessorCount + 31) / 32, 0xffffffffu);
+        if (holds_up.size() == 0 && mask.size() > 1) mask[0] = 0;   // a latency chain: off the CUs the confined front end keeps busy (masked streams have no priority)
+        e = hipExtStreamCreateWithCUMask(&cand, (uint32_t)mask.size(), mask.data());
+      }
+    } else {
+      e = make(&cand);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); break; }
     ++*attempts;
-    int worst = 0;
+    int worst = 0, block = 0;
     for (hipStream_t o : others)
       if (o) worst = std::max(worst, probe_pair_percent(o, cand));
-    if (worst < best_pct) { if (best) rejected.push_back(best); best = cand; best_pct = worst; }
+    if (!no_block && worst < 150) {
+      for (hipStream_t o : holds_up)
+        if (o) block = std::max(block, svo_probe_block_percent(cand, o));
+      for (hipStream_t o : held_up_by)
+        if (o) block = std::max(block, svo_probe_block_percent(o, cand));
+    }
+    if (dbg) fprintf(stderr, "[svo_pick_stream] ctx %p candidate %d (%p): chains %d %%, held-up chain %d %%\n", (void*)ctx, k, (void*)cand, worst, block);
+    const int score = worst + (block >= 250 ? block : 0);   // (1.5 rounds late)
+    if (score < best_pct) { if (best) rejected.push_back(best); best = cand; best_pct = score; best_block = block; }
     else rejected.push_back(cand);
     if (best_pct < 150) break;
   }
-  for (hipStream_t r : rejected) hipStreamDestroy(r);
-  *out = best; *percent = best ? best_pct : 0;
-  static const bool dbg = getenv("SVO_PICK_DEBUG") != nullptr;
-  if (dbg) fprintf(stderr, "[svo_pick_stream] ctx %p: %d candidate(s), chosen %p runs at %d %% beside %zu stream(s)\n", (void*)ctx, *attempts, (void*)best, best_pct, others.size());
+  // the rejected candidates stay until the context goes: a process's hardware queues sit on the dispatch pipes in creation order, and
+  // destroying one moves every later queue - the stream just chosen included - one pipe down (tools/microbench/queue_block_probe
+  // destroy).  (Beyond a dozen parked streams they are destroyed after all.)
+  for (hipStream_t r : rejected) {
+    if (ctx->parked_streams.size() < 12) ctx->parked_streams.push_back(r);
+    else hipStreamDestroy(r);
+  }
+  *out = best; *percent = best ? std::min(best_pct, 999) : 0;
+  if (dbg) fprintf(stderr, "[svo_pick_stream] ctx %p: %d candidate(s), chosen %p runs at %d %% beside %zu stream(s), held-up chain %d %%\n", (void*)ctx, *attempts, (void*)best, best_pct, others.size(), best_block);
   if (best && best_pct >= 150)
     ctx->last_error = "tracker: no candidate stream ran beside the pose chain's (" + std::to_string(best_pct) + " % of one chain's time for two): the tail runs at a reduced rate";
   return best ? SVO_OK : SVO_E_HIP;
@@ -1023,25 +1110,60 @@ hipError_t svo_stream_create_masked(hipStream_t* st, int device, int percent) {
   return hipSuccess;
 }
 
-hipError_t svo_stream_create(hipStream_t* st, int role) {
-  // SVO_DEDICATED_QUEUES=1: the tail's two chains (role > 0: the context's main stream, the index chain's stream) on hardware queues
-  // of their own - CU-masked streams, which the runtime never pools - that keep off the CUs the batched front end is confined to
-  // (the first mask word: four CUs of every XCD).  The tracker's rate then no longer depends on who else holds the runtime's pooled
-  // queues (14.2 k / 102 k frames/s where the pooled streams gave 7.4 k / 57 k), and the RANSAC workgroups
-  // never queue behind front-end waves; the price is the tail's high stream priority (masked streams have none), which two
-  // contexts sharded on ONE GPU need (9.0 k -> 6.8 k frames/s).  Off by default.
-  static const bool dedicated = []() { const char* e = getenv("SVO_DEDICATED_QUEUES"); return e && e[0] == '1'; }();
-  if (dedicated && role > 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) {
-      const int words = (prop.multiProcessorCount + 31) / 32;
-      std::vector<uint32_t> mask((size_t)words, 0xffffffffu);
-      if (words > 1) mask[0] = 0;
-      if (hipExtStreamCreateWithCUMask(st, (uint32_t)words, mask.data()) == hipSuccess) return hipSuccess;
-    }
+// The context's four main streams as four hardware queues of their own, created back to back.  A process's hardware queues sit on the
+// command processor's four dispatch pipes in creation order (position in the list of its live queues, modulo 4; a destroyed
+// queue's successors move up: tools/microbench/queue_block_probe, profiles/r05_queue_block.jsonl), and two queues on one pipe
+// hold each other up whenever one has launches waiting (above).  Four queues made one after the other are on four different pipes
+// whatever the process created before and whatever it creates or destroys elsewhere later - only a queue created or destroyed
+// BETWEEN them could change that, and nothing is.  CU-masked streams are the one kind the runtime gives a queue of its own
+// (pooled streams share four per priority, whose positions the process's history decides); they have no priority, so the tail's two
+// streams keep off the CUs the batched front end is confined to (first mask word: four CUs of every XCD) instead:
+//   stream           pose chain, and everything the host-buffer entries run      every CU but the first mask word's
+//   stream_idx       index chain                                                 the same
+//   stream_fe_batch  the batched tracker's front end                             "fe_cu_percent" of the CUs (first mask words)
+//   stream_dense     dense stage in front of the tracker (depth_source 1, 2)     "dense_cu_percent" of the CUs
+// An option that changes a mask destroys that one stream and makes a new one through svo_pick_stream (measured against the
+// others, rejected candidates parked).  SVO_POOLED_QUEUES=1: the runtime's pooled streams as up to round 5 (main stream only;
+// the others on demand through the picker).
+int svo_stream_burst(svo_ctx* ctx) {
+  static const bool pooled = []() { const char* e = getenv("SVO_POOLED_QUEUES"); return e && e[0] == '1'; }();
+  hipDeviceProp_t prop;
+  if (pooled || hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) {
     (void)hipGetLastError();
+    return svo_stream_create(&ctx->stream, +1) == hipSuccess ? SVO_OK : SVO_E_HIP;
   }
+  const int words = (prop.multiProcessorCount + 31) / 32;
+  auto first_words = [words](int percent) {
+    std::vector<uint32_t> m((size_t)words, 0u);
+    const int keep = percent >= 100 ? words : std::max(1, std::min(words, (words * percent + 50) / 100));
+    for (int w = 0; w < keep; ++w) m[w] = 0xffffffffu;
+    return m;
+  };
+  std::vector<uint32_t> tail((size_t)words, 0xffffffffu);
+  if (words > 1) tail[0] = 0;
+  const std::vector<uint32_t> masks[4] = {tail, tail, first_words(ctx->opt_fe_cu_percent), first_words(ctx->opt_dense_cu_percent)};
+  hipStream_t q[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int k = 0; k < 4; ++k) {
+    if (hipExtStreamCreateWithCUMask(&q[k], (uint32_t)words, masks[k].data()) != hipSuccess) {
+      (void)hipGetLastError();
+      for (int j = 0; j < k; ++j) hipStreamDestroy(q[j]);
+      return svo_stream_create(&ctx->stream, +1) == hipSuccess ? SVO_OK : SVO_E_HIP;   // (no masked streams on this device: pooled ones)
+    }
+    hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, q[k], 100LL);   // (the queue exists from its first packet on at the latest)
+  }
+  for (int k = 0; k < 4; ++k) hipStreamSynchronize(q[k]);
+  (void)hipGetLastError();
+  ctx->stream = q[0]; ctx->stream_idx = q[1]; ctx->stream_fe_batch = q[2]; ctx->stream_dense = q[3];
+  ctx->streams_burst = true;
+  ctx->idx_probe_attempts = 1;                                 // what svo_debug_stream_probe reports: one candidate, and how the two chains
+  ctx->idx_probe_spins = probe_pair_percent(q[0], q[1]);       // of the tail run side by side on these two (measured, ~1 ms)
+  static const bool dbg = getenv("SVO_PICK_DEBUG") != nullptr;
+  if (dbg) fprintf(stderr, "[svo_stream_burst] ctx %p: pose %p, index %p, front end %p (%d %% of the CUs), dense %p (%d %%)\n", (void*)ctx, (void*)q[0], (void*)q[1],
+                   (void*)q[2], ctx->opt_fe_cu_percent, (void*)q[3], ctx->opt_dense_cu_percent);
+  return SVO_OK;
+}
+
+hipError_t svo_stream_create(hipStream_t* st, int role) {
   int least = 0, greatest = 0;   // numerically: greatest priority <= least priority
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
   const int prio = role > 0 ? greatest : (role < 0 ? least : (least + greatest) / 2);

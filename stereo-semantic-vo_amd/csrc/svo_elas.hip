@@ -1597,10 +1597,10 @@ int svo_elas_batch_dev_hooked(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d
         {   // a stream that runs beside the caller's (phase A of chunk c + 1 beside phase B of chunk c) - and beside the tracker's two
             // chains, whose tail hangs on the chunks when the maps feed it (measured: phase A on a hardware queue shared with one of
             // them waited 30 ms per 256-frame call, configs[4] 4.8 k instead of 6.8 k frames/s)
-          const int dev = ctx->device;
           int attempts = 0, percent = 0;
-          const int rcp = svo_pick_stream(ctx, [dev, pct](hipStream_t* q) { return pct ? svo_stream_create_masked(q, dev, pct) : svo_stream_create(q, 0); },
-                                          {s, ctx->stream != s ? ctx->stream : nullptr, ctx->stream_idx}, &ctx->stream_elas_a, &attempts, &percent);
+          const int rcp = svo_pick_stream(ctx, [](hipStream_t* q) { return svo_stream_create(q, 0); },
+                                          {s, ctx->stream != s ? ctx->stream : nullptr, ctx->stream_idx}, &ctx->stream_elas_a, &attempts, &percent,
+                                          {s, ctx->stream != s ? ctx->stream : nullptr, ctx->stream_idx}, {s});
           if (rcp) return rcp;
         }
         ctx->stream_elas_a_pct = pct;

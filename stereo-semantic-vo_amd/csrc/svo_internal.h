@@ -130,6 +130,8 @@ struct svo_ctx {
   int work_cap = 0;             // records per half (two halves are allocated)
   int work_last_half = 0;       // the half the last tail call used (debug readers)
   hipStream_t stream_idx = nullptr;        // the pose-free index chain of the tracking tail runs here, ahead of the pose chain
+  bool streams_burst = false;              // stream, stream_idx, stream_fe_batch, stream_dense were made as four hardware queues back to back (svo_stream_burst)
+  std::vector<hipStream_t> parked_streams; // candidates the stream picker rejected: kept until the context goes (destroying a queue moves every later one to another dispatch pipe)
   hipStream_t stream_fe = nullptr;         // the front end of the next step / chunk beside the tail (multi-sequence steps, MSA chunks)
   hipStream_t stream_fe_batch = nullptr;   // svo_track_batch_dev: the front end's sub-batches, confined to a share of the CUs
   hipStream_t stream_dense = nullptr;      // svo_track_batch_dev with depth_source 1: the dense front end's sub-batches
@@ -223,6 +225,8 @@ __host__ __device__ inline T* svo_byte_offset(T* p, size_t bytes) {
 // Streams by role: +1 the ordered tail's chains (small dependent kernels whose workgroups must not queue behind the front end's
 // thousands), -1 the batched front end running beside it, 0 everything else.  Maps onto the device's stream-priority range.
 hipError_t svo_stream_create(hipStream_t* st, int role);
+// svo_api.hip: the context's four main streams as hardware queues of their own, created back to back: four different dispatch pipes
+int svo_stream_burst(svo_ctx* ctx);
 // MSA (svo_msa.hip / svo_msa_graph.hip): one node of an aggregation tree by level-order position - first child's position |
 // weight of the edge to the parent + (children << 8) | parent's position (-1: the root) | pixel
 struct MsaBfsRec { int32_t cpos, meta, ppos, node; };
@@ -235,8 +239,12 @@ int svo_track_quiesce(svo_ctx* ctx, bool shard_too = true);   // waits for what 
 int svo_shard_quiesce(svo_ctx* ctx);   // svo_track.hip: the sharded tracker's part of that
 // svo_api.hip: a new stream (made by `make`) that runs side by side with every non-null stream of `others`, chosen by measuring
 // (up to six candidates); *attempts candidates tried, *percent the chosen one's worst "two chains together / one alone"
+// `holds_up`: streams (latency chains, or big grids of their own) that a large grid waiting for CUs on the NEW stream must not hold up;
+// `held_up_by`: streams whose large grids must not hold up the new one (see svo_api.hip: queues behind one dispatch pipe).
 int svo_pick_stream(svo_ctx* ctx, const std::function<hipError_t(hipStream_t*)>& make, std::initializer_list<hipStream_t> others, hipStream_t* out,
-                    int* attempts, int* percent);
+                    int* attempts, int* percent, std::initializer_list<hipStream_t> holds_up = {}, std::initializer_list<hipStream_t> held_up_by = {});
+// a large grid in dispatch on `blocker` beside a chain of short kernels on `victim`: the chain's time in per cent of its time alone
+int svo_probe_block_percent(hipStream_t blocker, hipStream_t victim);
 int svo_track_fe_batch_stream(svo_ctx* ctx);   // svo_track.hip: creates ctx->stream_fe_batch (a stream that runs beside the tail's two chains)
 int svo_elas_batch_dev_hooked(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d_R, int stride, int W, int H, int B,
                               const svo_elas_params* params, float* d_D1, float* d_D2, int32_t* produced,

@@ -1467,15 +1467,55 @@ void svo_track_release(svo_ctx* ctx) {
 // The index chain's stream: high priority, side by side with the pose chain's (and with the batched front end's, if that exists).
 static int track_index_stream(svo_ctx* ctx) {
   return svo_pick_stream(ctx, [](hipStream_t* s) { return svo_stream_create(s, +1); }, {ctx->stream, ctx->stream_fe_batch}, &ctx->stream_idx,
-                         &ctx->idx_probe_attempts, &ctx->idx_probe_spins);
+                         &ctx->idx_probe_attempts, &ctx->idx_probe_spins, {}, {ctx->stream_fe_batch, ctx->stream_fe, ctx->stream_dense});
 }
+static void track_stream_diag(svo_ctx* ctx);
 // The batched tracker's front-end stream ("fe_cu_percent" of the CUs): side by side with both chains of the tail.
 int svo_track_fe_batch_stream(svo_ctx* ctx) {
   if (ctx->stream_fe_batch) return SVO_OK;
   const int dev = ctx->device, pct = ctx->opt_fe_cu_percent;
   int attempts = 0, percent = 0;
-  return svo_pick_stream(ctx, [dev, pct](hipStream_t* s) { return pct < 100 ? svo_stream_create_masked(s, dev, pct) : svo_stream_create(s, -1); },
-                         {ctx->stream, ctx->stream_idx}, &ctx->stream_fe_batch, &attempts, &percent);
+  const int rc = svo_pick_stream(ctx, [dev, pct](hipStream_t* s) { return pct < 100 ? svo_stream_create_masked(s, dev, pct) : svo_stream_create(s, -1); },
+                                 {ctx->stream, ctx->stream_idx}, &ctx->stream_fe_batch, &attempts, &percent,
+                                 {ctx->stream, ctx->stream_idx, ctx->stream_dense}, {ctx->stream_dense});   // (its grids wait for their eighth of the CUs: no chain, and not the dense stage, behind them)
+  if (rc == SVO_OK) track_stream_diag(ctx);
+  return rc;
+}
+
+// SVO_STREAM_DIAG=1: how long a grid of many small workgroups (the index chain's shape) takes on each of the tracker's streams, alone
+// and while front-end-like grids keep the front end's stream busy - printed once per context (docs/NEXT_ROUNDS.md, process states).
+__global__ void k_diag_spin(long long cycles) {
+  const long long t0 = clock64();
+  while (clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(2);
+}
+static void track_stream_diag(svo_ctx* ctx) {
+  static const bool on = []() { const char* e = getenv("SVO_STREAM_DIAG"); return e && e[0] == '1'; }();
+  if (!on || !ctx->stream_idx || !ctx->stream_fe_batch) return;
+  hipStream_t ss[3] = {ctx->stream, ctx->stream_idx, ctx->stream_fe_batch};
+  const char* nm[3] = {"pose", "index", "front end"};
+  auto grid_us = [](hipStream_t q, int wgs, int threads, long long cyc) {
+    double best = 1e30;
+    for (int rep = 0; rep < 3; ++rep) {
+      hipStreamSynchronize(q);
+      const auto t0 = std::chrono::steady_clock::now();
+      hipLaunchKernelGGL(k_diag_spin, dim3(wgs), dim3(threads), 0, q, cyc);
+      hipStreamSynchronize(q);
+      best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    }
+    return best;
+  };
+  for (int k = 0; k < 3; ++k) {
+    const double one = grid_us(ss[k], 1, 64, 4000), many = grid_us(ss[k], 3072, 64, 4000), big = grid_us(ss[k], 2048, 256, 40000);
+    double beside = 0;
+    if (k < 2) {
+      for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(k_diag_spin, dim3(4096), dim3(256), 0, ss[2], 100000LL);
+      beside = grid_us(ss[k], 3072, 64, 4000);
+      hipStreamSynchronize(ss[2]);
+    }
+    fprintf(stderr, "[svo stream diag] ctx %p %-9s stream %p: 1 workgroup %.0f us, 3072 x 64 threads %.0f us, 2048 x 256 threads (18 us each) %.0f us, 3072 x 64 beside front-end grids %.0f us\n",
+            (void*)ctx, nm[k], (void*)ss[k], one, many, big, beside);
+  }
+  (void)hipGetLastError();
 }
 
 // streams, events, work records and the kernels' LDS opt-ins for `frames` frames per call of `nseq` sequences
@@ -1876,7 +1916,12 @@ extern "C" int svo_track_multi_step_dev(svo_ctx* ctx, const uint8_t* d_grayL, co
       ctx->ms_cap = n_seq;
     }
     if ((rc = track_resources(ctx, 1, n_seq))) return rc;   // streams and events exist from here on
-    if (!ctx->stream_fe) SVO_HIP(ctx, svo_stream_create(&ctx->stream_fe, -1));   // (confining it to a share of the CUs only costs: 88 % -6 %, 75 % -8 %, 50 % -34 % with 64 sequences)
+    if (!ctx->stream_fe) {   // (confining it to a share of the CUs only costs: 88 % -6 %, 75 % -8 %, 50 % -34 % with 64 sequences)
+      int attempts = 0, percent = 0;
+      const int rcp = svo_pick_stream(ctx, [](hipStream_t* q) { return svo_stream_create(q, -1); }, {ctx->stream, ctx->stream_idx}, &ctx->stream_fe,
+                                      &attempts, &percent, {ctx->stream, ctx->stream_idx}, {});
+      if (rcp) return rcp;
+    }
     const int p = ctx->ms_parity;
     if (ctx->ms_tail_recorded[p]) {
       SVO_HIP(ctx, hipStreamWaitEvent(ctx->stream_fe, ctx->ms_tail_done[p], 0));   // the tail that read this set two steps ago
@@ -1930,14 +1975,14 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
     if ((rc = dense_reserve(ctx, B))) return rc;
     if ((rc = track_resources(ctx, B, 1))) return rc;
     if (!ctx->stream_dense) {   // the dense stage's stream: beside both chains of the tail
-      if (ctx->opt_dense_cu_percent < 100) {
-        SVO_HIP(ctx, svo_stream_create_masked(&ctx->stream_dense, ctx->device, ctx->opt_dense_cu_percent));   // (own hardware queue)
-      } else {
-        int attempts = 0, percent = 0;
-        const int rcp = svo_pick_stream(ctx, [](hipStream_t* q) { return svo_stream_create(q, 0); }, {ctx->stream, ctx->stream_idx},
-                                        &ctx->stream_dense, &attempts, &percent);
-        if (rcp) return rcp;
-      }
+      // (confined: a hardware queue of its own - which may still sit behind the dispatch pipe of one of the chains or of the front
+      // end's queue: picked by measurement either way)
+      const int dev = ctx->device, pct = ctx->opt_dense_cu_percent;
+      int attempts = 0, percent = 0;
+      const int rcp = svo_pick_stream(ctx, [dev, pct](hipStream_t* q) { return pct < 100 ? svo_stream_create_masked(q, dev, pct) : svo_stream_create(q, 0); },
+                                      {ctx->stream, ctx->stream_idx}, &ctx->stream_dense, &attempts, &percent,
+                                      {ctx->stream, ctx->stream_idx, ctx->stream_fe_batch}, {ctx->stream_fe_batch});
+      if (rcp) return rcp;
     }
     float* dD1 = ctx->d_dense;
     float* dD2 = dD1 + n * (size_t)ctx->dense_cap;
@@ -2120,12 +2165,24 @@ extern "C" int svo_track_overflowed(svo_ctx* ctx, int32_t* flag) {
   return SVO_OK;
 }
 
-// How the index chain's stream was chosen (track_index_stream): out[0] = candidates tried (0: probe switched off, -1: no
-// tracker call yet), out[1] = polls of the probe's waiting kernel for the chosen one (>= 1000: no candidate ran beside the pose
-// chain's stream - the two chains of the tail will take turns instead of overlapping).
+// How the index chain's stream was chosen (svo_stream_burst, or track_index_stream with SVO_POOLED_QUEUES=1): out[0] = candidates
+// tried (0: probe switched off), out[1] = "two chains together / one alone" on the pose and the index stream in per cent
+// (~105 side by side, ~200: the two chains of the tail take turns instead of overlapping).
 extern "C" int svo_debug_stream_probe(svo_ctx* ctx, int32_t out[2]) {
   if (!ctx || !out) return SVO_E_INVALID;
   out[0] = ctx->idx_probe_attempts; out[1] = ctx->idx_probe_spins;
+  return SVO_OK;
+}
+
+// Do the front end's / the dense stage's queued grids hold the tail's two streams up?  (include/svo.h; svo_probe_block_percent)
+extern "C" int svo_debug_stream_pipes(svo_ctx* ctx, int32_t out[4]) {
+  if (!ctx || !out) return SVO_E_INVALID;
+  hipSetDevice(ctx->device);
+  { const int rcq = svo_track_quiesce(ctx, true); if (rcq) return rcq; }
+  hipStream_t fill[2] = {ctx->stream_fe_batch, ctx->stream_dense}, tail[2] = {ctx->stream, ctx->stream_idx};
+  for (int f = 0; f < 2; ++f)
+    for (int t = 0; t < 2; ++t)
+      out[2 * f + t] = fill[f] && tail[t] && fill[f] != tail[t] ? svo_probe_block_percent(fill[f], tail[t]) : -1;
   return SVO_OK;
 }
 
@@ -2311,11 +2368,16 @@ extern "C" int svo_track_sharded_dev(svo_ctx* const* ctxs, int G, const uint8_t*
   }
   ShardGather* sg = shard_gather(c0);
   SVO_HIP(c0, hipSetDevice(c0->device));
-  if (!sg->gs) SVO_HIP(c0, svo_stream_create(&sg->gs, 0));
+  { const int rcf = svo_track_fe_batch_stream(c0); if (rcf) return rcf; }
+  if (!sg->gs) {   // the gather's copies feed the tail sub-batch by sub-batch: beside its chains, and never behind the front end's grids
+    int attempts = 0, percent = 0;
+    const int rcp = svo_pick_stream(c0, [](hipStream_t* q) { return svo_stream_create(q, 0); }, {c0->stream, c0->stream_idx, c0->stream_fe_batch},
+                                    &sg->gs, &attempts, &percent, {}, {c0->stream_fe_batch});
+    if (rcp) return rcp;
+  }
   if (!sg->ev_gathered) SVO_HIP(c0, hipEventCreateWithFlags(&sg->ev_gathered, hipEventDisableTiming));
   for (int q = 0; q < 2; ++q)
     if (!sg->done[q]) SVO_HIP(c0, hipEventCreateWithFlags(&sg->done[q], hipEventDisableTiming));
-  { const int rcf = svo_track_fe_batch_stream(c0); if (rcf) return rcf; }
   const int per = (B + G - 1) / G;
   const size_t wk = sizeof(svo_kp) * (size_t)K, wd = 32 * (size_t)K, wf = 4 * (size_t)K;
   if (sg->per < per || sg->G < G) {

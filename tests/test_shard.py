@@ -291,3 +291,44 @@ def test_tail_rate_does_not_depend_on_the_process_stream_history():
         print("QUEUE_HISTORY %s %s" % (steps, json.dumps(later)))
         assert later["frames_per_s"] >= 0.95 * fresh["frames_per_s"], (steps, fresh, later)
         assert later["probe_two_chains_vs_one_percent"] < 150, (steps, later)
+
+
+@pytest.mark.gpu
+def test_front_end_grids_do_not_hold_the_tail_up_whatever_the_process_created_before(pkg):
+    """gfx950 puts a process's hardware queues on four dispatch pipes in creation order, and a queue with launches waiting holds
+    up the others of its pipe (tools/microbench/queue_block_probe; include/svo.h at svo_debug_stream_pipes).  A context makes
+    its pose, index, front-end and dense streams as four queues back to back - four pipes - so the measured delay of a grid on
+    the tail's streams beside queued filling grids on the front end's / the dense stage's stream stays below 1.5 rounds of
+    the filling workgroups (held up behind a pipe: 2.3-2.6 rounds, reported as >= 330) - in a process that holds pooled streams
+    of two priorities, and after a context created earlier has gone (the later context's queues move together)."""
+    import torch
+    if os.environ.get("SVO_POOLED_QUEUES") == "1":
+        pytest.skip("pooled streams asked for")
+    dev = torch.device("cuda", 0)
+    keep = [torch.cuda.Stream(device=dev, priority=p) for p in (-1, -1, -1, 0, 0)]
+    for st in keep:
+        with torch.cuda.stream(st):
+            torch.zeros(8, device=dev).add_(1)
+    torch.cuda.synchronize()
+    a = pkg.Svo(640, 240, device=0, max_batch=4)
+    b = pkg.Svo(640, 240, device=0, max_batch=4)
+    keep.append(torch.cuda.Stream(device=dev, priority=-1))
+    with torch.cuda.stream(keep[-1]):
+        torch.zeros(8, device=dev).add_(1)
+    torch.cuda.synchronize()
+    try:
+        la = a.debug_stream_pipes()
+        a.close()
+        a = None
+        c = pkg.Svo(640, 240, device=0, max_batch=4)
+        try:
+            lb, lc = b.debug_stream_pipes(), c.debug_stream_pipes()
+        finally:
+            c.close()
+        print("STREAM_PIPES %s %s %s" % (la, lb, lc))
+        for late in (la, lb, lc):
+            assert len(late) == 4 and all(0 < v < 250 for v in late), (la, lb, lc)
+    finally:
+        if a is not None:
+            a.close()
+        b.close()

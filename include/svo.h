@@ -210,7 +210,8 @@ void svo_destroy(svo_ctx* ctx);
  * "tail_fused" (default 1): one sequence, default solver, no dense stage beside the tail: the frame's RANSAC samples and its frame
  *   part (RANSAC's rule, PoseOptimization, the new map points' positions, the record) run as ONE launch (k_tp_tail_ord: 100
  *   sample workgroups + the frame's workgroup, which waits for their agent-scope results) instead of two - the launch boundary
- *   and the frame part's start-up leave the pose chain's critical path (8.74 k -> 8.9-9.0 k frames/s).  Same records.
+ *   and the frame part's start-up leave the pose chain's critical path (8.74 k -> 8.9-9.0 k frames/s; 9.1-9.2 k with the frame part waiting for the first 8 samples only and the
+ *   context's streams on four dispatch pipes).  Same records.
  * "epnp_force_seq" (default 0, tests): 1 = mode 2 takes its sequential fallback for every sample.
  * "dense_two_launch" (default 0): svo_track_batch_dev with depth_source = 1: the tail beside the dense stage launches its RANSAC
  *   samples as in the many-sequence mode (see "hyp_first") - fewer CUs taken from ELAS on ordinary frames.  Measured: no gain

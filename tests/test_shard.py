@@ -325,9 +325,19 @@ def test_front_end_grids_do_not_hold_the_tail_up_whatever_the_process_created_be
             lb, lc = b.debug_stream_pipes(), c.debug_stream_pipes()
         finally:
             c.close()
-        print("STREAM_PIPES %s %s %s" % (la, lb, lc))
-        for late in (la, lb, lc):
-            assert len(late) == 4 and all(0 < v < 250 for v in late), (la, lb, lc)
+        # a front-end stream re-made for another share of the CUs goes through the picker: still clear of the tail's streams
+        b.set_option("fe_cu_percent", 25)
+        L = np.zeros((2, 240, 640), np.uint8)
+        import torch as _t
+        d = _t.from_numpy(L).to(dev)
+        b.track_reset(pkg.Camera(**pkg.KITTI_00_02))
+        res = _t.zeros((2, pkg.TRACK_DTYPE.itemsize), dtype=_t.uint8, device=dev)
+        b.track_batch_dev(d.data_ptr(), d.data_ptr(), 640, 2, res.data_ptr())
+        b.sync()
+        lb2 = b.debug_stream_pipes()
+        print("STREAM_PIPES %s %s %s %s" % (la, lb, lc, lb2))
+        for late in (la, lb, lc, lb2):
+            assert len(late) == 4 and all(0 < v < 250 for v in late), (la, lb, lc, lb2)
     finally:
         if a is not None:
             a.close()

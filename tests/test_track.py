@@ -447,6 +447,9 @@ def test_tracking_is_independent_of_how_the_sequence_is_batched(pkg):
     assert a == run(64, track_lcap=1) and a == run(64, track_nblk=0) and a == run(64, track_group=1) and a == run(64, track_group=16)
     # the hand-over between the two chains: stream events per group (default) or per-frame tags polled by the pose kernels
     assert a == run(64, pose_flag=1) and a == run(16, pose_flag=1) and a == run(1, pose_flag=1, track_group=1)
+    # another share of the CUs for the front end's stream: that stream is destroyed and made again through the stream picker
+    # (the other three of the context's four hardware queues stay where they are) - same records
+    assert a == run(16, fe_cu_percent=25) and a == run(16, fe_cu_percent=100)
     r = np.frombuffer(a, pkg.TRACK_DTYPE)
     Twc = np.linalg.inv(r[-1]["Tcw"].reshape(4, 4).astype(np.float64))
     assert np.linalg.norm(Twc[:3, 3] - T[-1][:3, 3].cpu().numpy()) < 3.0      # 63 m path, no loop closing

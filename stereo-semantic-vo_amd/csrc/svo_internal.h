@@ -130,6 +130,7 @@ struct svo_ctx {
   int work_cap = 0;             // records per half (two halves are allocated)
   int work_last_half = 0;       // the half the last tail call used (debug readers)
   hipStream_t stream_idx = nullptr;        // the pose-free index chain of the tracking tail runs here, ahead of the pose chain
+  bool stream_diag_done = false;           // SVO_STREAM_DIAG=1 printed its table for this context
   bool streams_burst = false;              // stream, stream_idx, stream_fe_batch, stream_dense were made as four hardware queues back to back (svo_stream_burst)
   std::vector<hipStream_t> parked_streams; // candidates the stream picker rejected: kept until the context goes (destroying a queue moves every later one to another dispatch pipe)
   hipStream_t stream_fe = nullptr;         // the front end of the next step / chunk beside the tail (multi-sequence steps, MSA chunks)

@@ -1478,7 +1478,7 @@ int svo_track_fe_batch_stream(svo_ctx* ctx) {
   const int rc = svo_pick_stream(ctx, [dev, pct](hipStream_t* s) { return pct < 100 ? svo_stream_create_masked(s, dev, pct) : svo_stream_create(s, -1); },
                                  {ctx->stream, ctx->stream_idx}, &ctx->stream_fe_batch, &attempts, &percent,
                                  {ctx->stream, ctx->stream_idx, ctx->stream_dense}, {ctx->stream_dense});   // (its grids wait for their eighth of the CUs: no chain, and not the dense stage, behind them)
-  if (rc == SVO_OK) track_stream_diag(ctx);
+  if (rc == SVO_OK) { ctx->stream_diag_done = true; track_stream_diag(ctx); }
   return rc;
 }
 
@@ -1521,6 +1521,7 @@ static void track_stream_diag(svo_ctx* ctx) {
 // streams, events, work records and the kernels' LDS opt-ins for `frames` frames per call of `nseq` sequences
 static int track_resources(svo_ctx* ctx, int frames, int nseq) {
   if (!ctx->stream_idx) { const int rcs = track_index_stream(ctx); if (rcs) return rcs; }
+  if (!ctx->stream_diag_done) { ctx->stream_diag_done = true; track_stream_diag(ctx); }   // (SVO_STREAM_DIAG=1; once per context)
   if (!ctx->ev_frontend) SVO_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_frontend, hipEventDisableTiming));
   while ((int)ctx->ev_frame.size() < frames) {
     hipEvent_t e;

@@ -40,29 +40,36 @@ std::atomic<int> g_active_builders{0};
 // leaf's (the reference's convention, :1232-1234) - it decides which child ends up left, hence later merges.
 class EdgeHeaps {
  public:
-  struct Node { int left, right, rank, key; };
-  void reset(size_t arcs) { node_.resize(arcs + 1); node_[0] = Node{0, 0, 0, 0}; }   // nodes are init()-ed before use
-  void init(int h, int key) { node_[h] = Node{0, 0, 0, key}; }
+  // rank: the node's own; lrank: its LEFT child's, kept here so that the way back up a merge path never has to touch the left
+  // children (they are never on a merge path - only right spines are walked - so the copy stays true; one cache miss per step less)
+  struct Node { int left, right, key; uint16_t rank, lrank; };
+  void reset(size_t arcs) { node_.resize(arcs + 1); node_[0] = Node{0, 0, 0, 0, 0}; }   // nodes are init()-ed before use
+  void init(int h, int key) { node_[h] = Node{0, 0, key, 0, 0}; }
   int key(int h) const { return node_[h].key; }
   static int arc(int h) { return h - 1; }
   // `spine` is scratch of the caller (the per-pixel construction runs on several threads)
-  int meld(int a, int b, std::vector<int>& spine) {
+  int meld(int a, int b, std::vector<int>&) {
     if (!a || !b) return a + b;
-    spine.clear();
-    // walk down the right spines, always continuing below the smaller key (ties: the first heap stays on top)
+    // walk down the right spines, always continuing below the smaller key (ties: the first heap stays on top).  The merge path is
+    // at most the two right spines: <= 2 log2(nodes + 1) < 64 + 64 entries for any pool that fits an int
+    int spine[128];
+    size_t ns = 0;
     for (;;) {
       if (!a || !b) { a += b; break; }
       if (node_[a].key > node_[b].key) std::swap(a, b);
-      spine.push_back(a);
+      spine[ns++] = a;
       a = node_[a].right;
     }
     int sub = a;
-    for (size_t i = spine.size(); i-- > 0;) {
+    unsigned sub_rank = node_[sub].rank;   // (sub != 0 here: one of the two heaps outlasts the other)
+    for (size_t i = ns; i-- > 0;) {
       Node& t = node_[spine[i]];
-      t.right = sub;
-      if (node_[t.left].rank < node_[t.right].rank) std::swap(t.left, t.right);
-      t.rank = t.right ? node_[t.right].rank + 1 : 0;
+      // right child := sub; the child of the larger rank goes left (an empty child counts as rank 0, like a leaf)
+      if (t.lrank < sub_rank) { t.right = t.left; t.left = sub; const unsigned r = t.lrank; t.lrank = (uint16_t)sub_rank; sub_rank = r; }
+      else t.right = sub;
+      t.rank = (uint16_t)(t.right ? sub_rank + 1 : 0);
       sub = spine[i];
+      sub_rank = t.rank;
     }
     return sub;
   }

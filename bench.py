@@ -820,6 +820,115 @@ def tail_chain_from_stamps(dbg):
             "source": "in-kernel s_memrealtime stamps of the timed region's last step (svo_debug_track_frames)"}
 
 
+
+# ------------------------------------------------------------------------------------------------ the one JSON line
+LINE_LIMIT = 4096   # bytes: the driver keeps a bounded tail of the output; a line beyond this was recorded as `parsed: null` (round 5)
+LEG_NAMES = ("frontend", "multi_sequence", "sharded", "semantic_elas", "elas", "msa", "host_feed", "host_feed_pageable", "frontend_host_feed",
+             "with_null_stream_cotenant", "with_pooled_stream_cotenant", "two_contexts_one_gpu")
+
+
+def _sig(v, digits=5):
+    """floats to `digits` significant digits (what the line carries; the detail file keeps everything)"""
+    if isinstance(v, bool) or v is None:
+        return v
+    if isinstance(v, float):
+        return float("%.*g" % (digits, v))
+    if isinstance(v, dict):
+        return {k: _sig(x, digits) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_sig(x, digits) for x in v]
+    return v
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(out, detail_path=None):
+    """The line the driver parses, from the full result `out`: the contract's fields, `config` (workload + the accuracy figures),
+    `roofline` and `cpu_baseline` as numbers without prose, ONE scalar per leg.  Everything else - notes, per-leg rooflines, kernel
+    tables, critical path - is in the detail file (`detail`).  Never longer than LINE_LIMIT bytes: optional parts are dropped in a
+    fixed order until it fits (tests/test_bench_line.py runs this on the canned full results under profiles/)."""
+    cfg = out.get("config", {}) or {}
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    c = _pick(cfg, ("workload", "parallelism", "sharding", "contexts", "devices", "pairs_per_step_per_gpu", "resident_pairs_per_gpu",
+                    "resident_input_bytes_per_gpu", "concurrent_sequences_per_gpu", "frames_tracked", "ate_rmse_m_vs_ground_truth",
+                    "final_position_error_m", "path_length_m", "mean_lm_edges", "tracker_capacity_flag",
+                    "pnp_samples_through_sequential_fallback", "mean_keypoints_left", "mean_stereo_depths"))
+    if isinstance(c.get("workload"), str) and len(c["workload"]) > 330:
+        c["workload"] = c["workload"][:327] + "..."
+    ate = out.get("ate_vs_cpu_m")
+    if isinstance(ate, dict):
+        c["ate_vs_cpu_m_rmse"] = ate.get("rmse")
+        c["ate_vs_cpu_m_max"] = ate.get("max")
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict) and cb.get("counters_identical_to_gpu") is not None:
+        c["counters_identical_to_cpu"] = cb.get("counters_identical_to_gpu")
+    line["config"] = c
+    rf = out.get("roofline")
+    if isinstance(rf, dict):
+        r = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                       "kernel_seconds_per_launch", "pipeline_frac", "share_of_kernel_time_per_frame"))
+        r.setdefault("traffic", None)
+        im = rf.get("issue_model")
+        if isinstance(im, dict):   # the model that governs the critical-path kernel: numbers only
+            r["issue_model"] = _pick(im, ("peak_inst_per_quad_cycle_per_wave", "achieved_inst_per_quad_cycle_per_wave",
+                                          "instructions_per_wave", "share_of_frame_period"))
+        line["roofline"] = r
+    if isinstance(cb, dict):
+        b = _pick(cb, ("value", "unit", "cores", "kind", "sample"))
+        if isinstance(b.get("sample"), str) and len(b["sample"]) > 200:
+            b["sample"] = b["sample"][:197] + "..."
+        line["cpu_baseline"] = b
+    for name in LEG_NAMES:
+        leg = out.get(name)
+        if isinstance(leg, dict):
+            line[name] = leg.get("value", leg.get("error"))
+        elif leg is not None:
+            line[name] = leg
+    tc = out.get("tail_critical_path")
+    if isinstance(tc, dict) and "frame_period_us" in tc:
+        line["frame_period_us"] = tc["frame_period_us"].get("mean")
+    if detail_path:
+        line["detail"] = detail_path
+    line = _sig(line)
+    # shrink in a fixed order if a future field pushed it over the limit
+    for drop in (("detail",), ("frame_period_us",), ("roofline", "issue_model"), ("cpu_baseline", "sample"), ("config", "parallelism"),
+                 ("config", "resident_input_bytes_per_gpu"), ("config", "final_position_error_m"), ("config", "path_length_m")):
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+        tgt = line
+        for k in drop[:-1]:
+            tgt = tgt.get(k, {}) if isinstance(tgt, dict) else {}
+        if isinstance(tgt, dict):
+            tgt.pop(drop[-1], None)
+    if len(json.dumps(line)) >= LINE_LIMIT and isinstance(line.get("config", {}).get("workload"), str):
+        line["config"]["workload"] = line["config"]["workload"][:120]
+    return line
+
+
+def emit(out):
+    """Full result -> bench_detail.json beside this file (fallback: the temp directory); the compact line -> stdout, LAST."""
+    path = os.path.join(ROOT, "bench_detail.json")
+    try:
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+    except OSError:
+        import tempfile
+        path = os.path.join(tempfile.gettempdir(), "bench_detail.json")
+        try:
+            with open(path, "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError:
+            path = None
+    sys.stderr.flush()
+    text = json.dumps(compact_line(out, os.path.basename(path) if path else None))
+    assert len(text) < LINE_LIMIT, "bench line of %d bytes" % len(text)
+    print(text)
+    sys.stdout.flush()
+
+
 # ------------------------------------------------------------------------------------------------ main
 def spawn_ranks(args):
     """`python bench.py --gpus N` outside a launcher: start the N ranks as a CHILD process group before this process makes
@@ -949,7 +1058,9 @@ def main():
     ap.add_argument("--no-track-leg", action="store_true", help="(kept for scripts) same as --no-legs for the frontend workload")
     ap.add_argument("--tail-leg-child", default=None, choices=sorted(TAIL_LEGS),
                     help="run ONE of the legs that depend on the tracker's two overlapping chains in this (fresh) process and print it")
-    ap.add_argument("--no-tail-leg-children", action="store_true", help="skip the child-process repetition of the tail legs (in-process figures only)")
+    ap.add_argument("--leg-orders", action="store_true", help="repeat the tail legs in the reverse order and each in a child process (three figures per leg)")
+    ap.add_argument("--quick-legs", action="store_true", help="skip the pnp_solver_modes leg")
+    ap.add_argument("--no-tail-leg-children", action="store_true", help="(kept for scripts; the child repetition now needs --leg-orders)")
     ap.add_argument("--no-shard-leg", action="store_true", help="N > 1: skip rank 0's svo_track_sharded_dev run across the N GPUs")
     ap.add_argument("--shard", action="store_true",
                     help="track workload: ONE sequence over --gpus G contexts in ONE process (svo_track_sharded_dev, BASELINE configs[3])")
@@ -1054,7 +1165,7 @@ def main():
                           "contexts": G, "devices": devices, "frames_tracked": int(n_frames), "ate_rmse_m_vs_ground_truth": rmse,
                           "parallelism": "front end sharded by pair over %d contexts, tail on one" % G},
                "sharded": leg}
-        print(json.dumps(out))
+        emit(out)
         return
 
     svo = pkg.Svo(W, H, device=local, max_kp=500, max_batch=B + extra)
@@ -1302,43 +1413,34 @@ def main():
         if legs:
             svo.close()                          # (its buffers: the legs' contexts bring their own)
             svo = None
-        # The legs that run the ordered tail (two chains that must overlap on two hardware queues): in THIS process, after the
-        # headline's context and after each other, once in this order and once in the reverse one, and each in a process of
-        # its own - three figures per leg that have to agree (`in_process_over_child`).  Up to round 4 only the child figure
-        # was a full-rate one (see tail_leg_child).
+        # The legs that run the ordered tail (two chains that must overlap on two hardware queues) run in THIS process, after the
+        # headline's context and after each other.  --leg-orders repeats them in the reverse order and each in a process of its own
+        # (round 5's finding - all three agree since the context's streams are four hardware queues made back to back - does not
+        # need re-proving in every headline run; profiles/r05_leg_orders.jsonl).
         if legs and track:
-            names = [n for n in TAIL_LEGS if not (n == "semantic_elas" and args.no_elas_leg)]
+            names = [n for n in TAIL_LEGS if not (n == "semantic_elas" and args.no_elas_leg) and not (n == "pnp_solver_modes" and not args.leg_orders and args.quick_legs)]
             refn = tail_leg_reference(pkg, cam, dL, dR, dev, local, 1024)
             first, second = {}, {}
             for name in names:
                 progress("leg %s: in-process" % name)
                 first[name] = run_tail_leg(name, pkg, cam, dL, dR, dev, local, refn)
-            for name in reversed(names):
-                progress("leg %s: in-process, reverse order" % name)
-                second[name] = run_tail_leg(name, pkg, cam, dL, dR, dev, local, refn)
+            if args.leg_orders:
+                for name in reversed(names):
+                    progress("leg %s: in-process, reverse order" % name)
+                    second[name] = run_tail_leg(name, pkg, cam, dL, dR, dev, local, refn)
             for name in names:
                 r = first[name]
-                r["order"] = "in-process, %d. of %s" % (names.index(name) + 1, " > ".join(names))
-                r["value_in_process"] = leg_value(first[name])
-                r["value_in_process_reverse_order"] = leg_value(second[name])
-                r["in_process_reverse_order"] = {k: v for k, v in second[name].items() if k in ("stream_probe", "epnp_exact=0", "error", "chain_us_per_frame")}
-                if not args.no_tail_leg_children:
+                if args.leg_orders:
+                    r["order"] = "in-process, %d. of %s" % (names.index(name) + 1, " > ".join(names))
+                    r["value_in_process"] = leg_value(first[name])
+                    r["value_in_process_reverse_order"] = leg_value(second[name])
+                    r["in_process_reverse_order"] = {k: v for k, v in second[name].items() if k in ("stream_probe", "epnp_exact=0", "error", "chain_us_per_frame")}
                     progress("leg %s: child process" % name)
                     try:
                         cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--tail-leg-child", name],
                                             stdout=subprocess.PIPE, timeout=600, check=True)
                         child = json.loads(cp.stdout.decode().strip().splitlines()[-1])[name]
                         r["value_child_process"] = leg_value(child)
-                        # the leg's figure: the process of its own (what rounds 3 and 4 reported, and what a deployment - one tracker per
-                        # process - gets); the two in-process figures stand beside it
-                        if "value" in child:
-                            r["value"] = child["value"]
-                            r["value_is"] = "child process (a process of its own); value_in_process / value_in_process_reverse_order: this process"
-                        elif name == "pnp_solver_modes":
-                            for k2, v2 in child.items():
-                                if isinstance(v2, dict) and "value" in v2 and k2 in r:
-                                    r[k2]["value_in_process"] = r[k2]["value"]
-                                    r[k2]["value"] = v2["value"]
                     except Exception as e:  # noqa: BLE001
                         r["value_child_process"] = repr(e)
                     r["in_process_over_child"] = [leg_ratio(r["value_in_process"], r["value_child_process"]),
@@ -1377,8 +1479,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["sharded"] = {"error": repr(e)}
     if rank == 0:
-        print(json.dumps(out))
-        sys.stdout.flush()
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -32,7 +32,11 @@
 extern "C" {
 #endif
 
-#define SVO_ABI_VERSION 6   /* 6 (round 5, late): + svo_debug_stream_pipes.  BEHAVIOUR: a context's four main streams are hardware queues of their own,
+#define SVO_ABI_VERSION 7   /* 7 (round 6): + svo_track_batch_host, svo_track_sharded_host, svo_frontend_batch_host (pipelined host-fed entries:
+                              images start in host memory, uploads run on a copy stream ahead of the front end, records come back to
+                              host memory; svo_boxes_host), svo_create_ex (per-context stream mode), svo_stream_mode; svo_sync also
+                              completes the host-fed calls' outputs.
+                              6 (round 5, late): + svo_debug_stream_pipes.  BEHAVIOUR: a context's four main streams are hardware queues of their own,
                               created back to back at svo_create (four dispatch pipes; see svo_debug_stream_pipes) - they are BLOCKING
                               streams (they order against the NULL stream, as every hipExtStreamCreateWithCUMask stream does) without a
                               priority, kept off each other by CU masks; SVO_POOLED_QUEUES=1 restores the pooled streams of ABI 5.
@@ -123,6 +127,14 @@ typedef struct svo_boxes_dev {
   int32_t stride;          /* boxes reserved per frame (>= the largest n[f]) */
 } svo_boxes_dev;
 
+/* The same for the host-fed entries (svo_track_batch_host, svo_track_sharded_host): HOST pointers, frame f of the call has
+ * n[f] boxes at boxes + 4 * stride * f - main.cpp:82-95 reads them from one text file per frame. */
+typedef struct svo_boxes_host {
+  const int32_t* boxes;
+  const int32_t* n;
+  int32_t stride;
+} svo_boxes_host;
+
 /* Parity probe record of one tracked frame (svo_debug_track_frames). */
 typedef struct svo_track_debug {
   int32_t match_gid[512];  /* per keypoint: identity (creation sequence number) of the map point matched to it by
@@ -148,6 +160,23 @@ const char* svo_last_error(const svo_ctx* ctx);
  * reference hard-codes N = 500, src/frame.cc:54); max_batch: the largest number of
  * stereo pairs one batched call may carry (>= 1). */
 int svo_create(svo_ctx** out, int device, int W, int H, int max_kp, int max_batch);
+/* svo_create with a per-context stream mode (flags; 0 = svo_create's default):
+ *   default: the context's four main streams (pose chain = the stream every host-buffer entry runs on, index chain, batched front
+ *     end, dense stage) are four hardware queues of their own made back to back - four dispatch pipes whatever the process created
+ *     before (svo_debug_stream_pipes).  They are BLOCKING streams (HIP has no non-blocking CU-masked stream): work another component
+ *     of the process puts on the NULL stream orders against them both ways.  The pose / index queues keep off the CUs the batched
+ *     front end is confined to (the first mask word: four CUs of every XCD) - 7/8 of the chip for everything that runs on them.
+ *   SVO_CREATE_TAIL_ALL_CUS: those two queues may use every CU - for a context that does not run the batched tracker
+ *     (front-end-only, ELAS / MSA, host-buffer entries: they run on the first queue and get the whole chip).
+ *   SVO_CREATE_POOLED_STREAMS: the runtime's pooled, prioritised NON-BLOCKING streams instead (ABI 5): no ordering against the
+ *     NULL stream; every further stream is picked by measuring against the streams it must run beside; the rate depends on what
+ *     the process created before.  svo_create sets it when the environment has SVO_POOLED_QUEUES=1 (read at
+ *     every call).  Also what a device without CU-masked streams falls back to.
+ * svo_stream_mode: what is in effect - bit 0: dedicated queues, bit 1: the tail's queues are confined off the front end's CUs. */
+#define SVO_CREATE_POOLED_STREAMS 1u
+#define SVO_CREATE_TAIL_ALL_CUS 2u
+int svo_create_ex(svo_ctx** out, int device, int W, int H, int max_kp, int max_batch, uint32_t flags);
+int svo_stream_mode(const svo_ctx* ctx);
 void svo_destroy(svo_ctx* ctx);
 /* Tuning switches.  "pose_mfma" (default 1): build the 6x6 J^T W J / J^T W e of svo_pose_opt, of the
  * PnP refit and of the tracker's pose optimisation as a Gram contraction on
@@ -417,6 +446,37 @@ int svo_track_tail_dev(svo_ctx* ctx, const svo_kp* d_kp, const uint8_t* d_desc, 
  * entry point of one of the contexts first waits for what these calls left in flight. */
 int svo_track_sharded_dev(svo_ctx* const* ctxs, int G, const uint8_t* const* d_grayL, const uint8_t* const* d_grayR,
                           int stride, int B, const svo_boxes_dev* boxes, svo_track_result* d_results);
+/* ---- throughput mode, HOST-fed and pipelined (main.cpp:159-195: the reference reads one stereo pair from disk per
+ * Tracking::Track; SURVEY.md section 8e: "H2D 2 P bytes, D2H ~30 KB" per pair, pair k uploaded to GPU k mod G) ------------
+ * svo_track_batch_host = svo_track_batch_dev for B consecutive frames of ONE sequence that start in HOST memory: grayL / grayR
+ * are B images of H rows x `stride` bytes each, back to back (frame f at grayL + f * H * stride); `results`: B records in host
+ * memory.  The call does not synchronise: the images are uploaded on a copy stream of the context's own, eight pairs per
+ * event, and every front-end sub-batch waits only for its own pairs; the records are copied back behind the pose chain.
+ * Pinned source images (hipHostMalloc / hipHostRegister, e.g. torch's pin_memory) are copied where they lie and must stay
+ * valid until svo_sync or until the second following host-fed call on this context returns; pageable images are first
+ * gathered into a pinned ring by up to four worker threads inside the call (the call returns when they are staged - they
+ * may be reused at once).  `results` is complete after svo_sync(ctx) (pageable: copied out of a pinned buffer there), or after the
+ * second following host-fed call returned.  Consecutive calls overlap exactly like svo_track_batch_dev's (two image sets
+ * alternate): the uploads of call c + 1 run while the tail of call c is busy.  Records are byte-identical to
+ * svo_track_batch_dev's on the same frames.  boxes (may be NULL): the frames' offline detection boxes, host arrays.
+ * Works with every "depth_source" (the dense stages wait for the call's last upload instead of sub-batch by sub-batch).
+ * Contract as for svo_track_batch_dev: the calls that continue one sequence are issued back to back; svo_sync before any
+ * other entry point uses the context. */
+int svo_track_batch_host(svo_ctx* ctx, const uint8_t* grayL, const uint8_t* grayR, int stride, int B,
+                         const svo_boxes_host* boxes, svo_track_result* results);
+/* svo_track_sharded_dev for a sequence that starts in HOST memory - BASELINE configs[3] as SURVEY.md section 8e words it:
+ * stereo pair k is uploaded to the GPU of ctxs[k mod G] on THAT context's copy stream (each GPU pulls only its own pairs
+ * over its own PCIe link), its front end runs there, the ordered tail on ctxs[0].  grayL / grayR: the B frames of the call in
+ * frame order (frame k at grayL + k * H * stride); results: B records in host memory, complete after svo_sync(ctxs[0]).
+ * Everything else as svo_track_sharded_dev / svo_track_batch_host; records identical to both. */
+int svo_track_sharded_host(svo_ctx* const* ctxs, int G, const uint8_t* grayL, const uint8_t* grayR, int stride, int B,
+                           const svo_boxes_host* boxes, svo_track_result* results);
+/* The stateless front end alone (svo_frontend_batch_dev), host to host and pipelined the same way.  Output arrays (host
+ * pointers, capacity B * max_kp each, d_nL: B; any may be NULL) are complete after svo_sync(ctx) or after the second
+ * following call returned.  Its rate is what the PCIe link delivers (0.93 MB per 1241x376 pair). */
+int svo_frontend_batch_host(svo_ctx* ctx, const uint8_t* grayL, const uint8_t* grayR, int stride, int B,
+                            const svo_camera* cam, svo_kp* kpL, uint8_t* descL, int32_t* nL, float* uR, float* depth);
+
 /* Sticky capacity flag of the device tracker (synchronises): *flag != 0 once a frame needed more than the 4096 live
  * map points the pool holds, or a map point stayed alive for more than 2^20 creations (its slot in the position table
  * was about to be reused).  Neither can happen with the reference's 500 keypoints per frame on sequences of KITTI

@@ -53,7 +53,12 @@ ABI_SYMBOLS = [
     "svo_profile_get",
     "svo_elas_default_params", "svo_elas_process", "svo_elas_process_ex", "svo_elas_delaunay",
     "svo_ctmf", "svo_track_multi_reset", "svo_track_multi_step_dev", "svo_track_tail_dev", "svo_track_overflowed", "svo_track_epnp_fallbacks", "svo_debug_stream_probe", "svo_debug_stream_pipes", "svo_track_sharded_dev", "svo_elas_batch_dev", "svo_msa_init", "svo_msa_tree", "svo_msa_tree_dp", "svo_msa_wta", "svo_msa_lrcheck", "svo_msa_solve", "svo_msa_batch_dev",
+    "svo_create_ex", "svo_stream_mode", "svo_track_batch_host", "svo_track_sharded_host", "svo_frontend_batch_host",
 ]
+
+# svo_create_ex flags (include/svo.h)
+CREATE_POOLED_STREAMS = 1
+CREATE_TAIL_ALL_CUS = 2
 
 
 class SvoError(RuntimeError):
@@ -77,6 +82,20 @@ def boxes_dev(d_boxes, d_n, stride):
 
 def _bx(b):
     return None if b is None else C.byref(b)
+
+
+class BoxesHost(C.Structure):
+    """svo_boxes_host: the same as HOST arrays (the host-fed entries)."""
+    _fields_ = [("boxes", C.c_void_p), ("n", C.c_void_p), ("stride", C.c_int32)]
+
+
+def boxes_host(boxes, n):
+    """svo_boxes_host from two numpy int32 arrays: boxes (F x stride x 4), n (F).  Keeps them alive in the returned object."""
+    b = np.ascontiguousarray(boxes, np.int32)
+    c = np.ascontiguousarray(n, np.int32)
+    r = BoxesHost(b.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), int(b.shape[1]))
+    r._keep = (b, c)
+    return r
 
 
 class LmStats(C.Structure):
@@ -119,6 +138,8 @@ def load_library():
         lib.svo_stream.restype = C.c_void_p
         lib.svo_stream.argtypes = [C.c_void_p]
         lib.svo_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        lib.svo_create_ex.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32]
+        lib.svo_stream_mode.argtypes = [C.c_void_p]
         lib.svo_destroy.argtypes = [C.c_void_p]
         lib.svo_destroy.restype = None
         _lib = lib
@@ -140,11 +161,15 @@ def _u8(a):
 class Svo:
     """One tracker context bound to one GPU (wraps svo_ctx)."""
 
-    def __init__(self, W, H, device=0, max_kp=500, max_batch=1):
+    def __init__(self, W, H, device=0, max_kp=500, max_batch=1, flags=None):
+        """flags: None = svo_create (default stream mode, SVO_POOLED_QUEUES honoured), else svo_create_ex with CREATE_* bits."""
         self.lib = load_library()
         self.W, self.H, self.max_kp, self.max_batch = int(W), int(H), int(max_kp), int(max_batch)
         h = C.c_void_p()
-        rc = self.lib.svo_create(C.byref(h), int(device), self.W, self.H, self.max_kp, self.max_batch)
+        if flags is None:
+            rc = self.lib.svo_create(C.byref(h), int(device), self.W, self.H, self.max_kp, self.max_batch)
+        else:
+            rc = self.lib.svo_create_ex(C.byref(h), int(device), self.W, self.H, self.max_kp, self.max_batch, int(flags))
         if rc != 0:
             raise SvoError("svo_create failed: %s" % self.lib.svo_strerror(rc).decode())
         self.h = h
@@ -347,6 +372,28 @@ class Svo:
         """boxes: a BoxesDev (boxes_dev(...)) with the frames' offline detection boxes in HBM, or None."""
         self._chk(self.lib.svo_track_batch_dev(self.h, _p(d_grayL), _p(d_grayR), int(stride), int(B), _bx(boxes),
                                                _p(d_results)))
+
+    def stream_mode(self):
+        """svo_stream_mode: bit 0 = four dedicated hardware queues, bit 1 = the tail's queues keep off the front end's CUs."""
+        return int(self.lib.svo_stream_mode(self.h))
+
+    def track_batch_host(self, grayL, grayR, stride, B, results, boxes=None):
+        """svo_track_batch_host: B consecutive frames that start in HOST memory (pointers or numpy arrays; pinned memory is copied
+        where it lies, pageable memory is staged inside the call); results: host array of TRACK_DTYPE records (complete after
+        sync()).  boxes: a BoxesHost or None."""
+        self._chk(self.lib.svo_track_batch_host(self.h, _p(grayL), _p(grayR), int(stride), int(B), _bx(boxes), _p(results)))
+
+    @staticmethod
+    def track_sharded_host(ctxs, grayL, grayR, stride, B, results, boxes=None):
+        """svo_track_sharded_host: ONE sequence in host memory, pair k uploaded to and extracted on ctxs[k % G], tail on ctxs[0]."""
+        G = len(ctxs)
+        hs = (C.c_void_p * G)(*[c.h for c in ctxs])
+        ctxs[0]._chk(ctxs[0].lib.svo_track_sharded_host(hs, G, _p(grayL), _p(grayR), int(stride), int(B), _bx(boxes), _p(results)))
+
+    def frontend_batch_host(self, grayL, grayR, stride, B, cam, kpL=None, descL=None, nL=None, uR=None, depth=None):
+        """svo_frontend_batch_host: the stateless front end host to host, pipelined; outputs complete after sync()."""
+        self._chk(self.lib.svo_frontend_batch_host(self.h, _p(grayL), _p(grayR), int(stride), int(B), C.byref(cam), _p(kpL),
+                                                   _p(descL), _p(nL), _p(uR), _p(depth)))
 
     def track_tail_dev(self, d_kp, d_desc, d_n, d_depth, kp_stride, B, d_results, boxes=None):
         """svo_track_tail_dev: the ordered tail over front-end results already in HBM (device pointers)."""

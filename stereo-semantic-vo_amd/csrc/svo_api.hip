@@ -183,6 +183,18 @@ static int dalloc(svo_ctx* ctx, T** p, size_t count) {
 }
 
 extern "C" int svo_create(svo_ctx** out, int device, int W, int H, int max_kp, int max_batch) {
+  // the environment's say is read per call (not once per process): SVO_POOLED_QUEUES=1 = svo_create_ex(..., SVO_CREATE_POOLED_STREAMS)
+  const char* e = getenv("SVO_POOLED_QUEUES");
+  return svo_create_ex(out, device, W, H, max_kp, max_batch, (e && e[0] == '1') ? SVO_CREATE_POOLED_STREAMS : 0u);
+}
+
+extern "C" int svo_stream_mode(const svo_ctx* ctx) {
+  if (!ctx) return SVO_E_INVALID;
+  return (ctx->streams_burst ? 1 : 0) | (ctx->streams_burst && !(ctx->create_flags & SVO_CREATE_TAIL_ALL_CUS) ? 2 : 0);
+}
+
+extern "C" int svo_create_ex(svo_ctx** out, int device, int W, int H, int max_kp, int max_batch, uint32_t flags) {
+  if (flags & ~(uint32_t)(SVO_CREATE_POOLED_STREAMS | SVO_CREATE_TAIL_ALL_CUS)) return SVO_E_INVALID;
   if (!out || W < 96 || H < 96 || W > 4095 || H > 4095 || max_kp < 8 || max_kp > 512 ||
       max_batch < 1)
     return SVO_E_INVALID;
@@ -191,6 +203,7 @@ extern "C" int svo_create(svo_ctx** out, int device, int W, int H, int max_kp, i
     return SVO_E_NODEVICE;
   if (hipSetDevice(device) != hipSuccess) return SVO_E_NODEVICE;
   svo_ctx* ctx = new svo_ctx();
+  ctx->create_flags = flags;
   ctx->device = device;
   ctx->max_kp = max_kp;
   ctx->max_batch = max_batch;
@@ -245,7 +258,7 @@ extern "C" int svo_create(svo_ctx** out, int device, int W, int H, int max_kp, i
   TRY(dalloc(ctx, &ctx->d_corners, I * (size_t)g.corner_entries));
   TRY(dalloc(ctx, &ctx->d_counters, I * SVO_NLEVELS));
   TRY(dalloc(ctx, &ctx->d_hist, I * SVO_NLEVELS * 256));
-  if (rc == SVO_OK && hipMemset(ctx->d_hist, 0, sizeof(int32_t) * I * SVO_NLEVELS * 256) != hipSuccess) rc = SVO_E_HIP;   // k_select keeps it zero
+  if (rc == SVO_OK && hipMemsetAsync(ctx->d_hist, 0, sizeof(int32_t) * I * SVO_NLEVELS * 256, ctx->stream) != hipSuccess) rc = SVO_E_HIP;   // k_select keeps it zero
   TRY(dalloc(ctx, &ctx->d_sel, I * SVO_NLEVELS * SVO_QMAX));
   TRY(dalloc(ctx, &ctx->d_selcnt, I * SVO_NLEVELS));
   TRY(dalloc(ctx, &ctx->d_kp, I * (size_t)max_kp));
@@ -263,18 +276,19 @@ extern "C" int svo_create(svo_ctx** out, int device, int W, int H, int max_kp, i
   if (rc == SVO_OK && hipHostMalloc((void**)&ctx->h_pinned, ctx->pinned_bytes) != hipSuccess)
     rc = SVO_E_NOMEM;
   if (rc == SVO_OK) {
-    hipMemcpy(ctx->d_xofs, xofs.data(), xofs.size() * 4, hipMemcpyHostToDevice);
-    hipMemcpy(ctx->d_xalpha, xalpha.data(), xalpha.size() * 4, hipMemcpyHostToDevice);
-    hipMemcpy(ctx->d_yofs, yofs.data(), yofs.size() * 4, hipMemcpyHostToDevice);
-    hipMemcpy(ctx->d_ybeta, ybeta.data(), ybeta.size() * 4, hipMemcpyHostToDevice);
-    hipMemset(ctx->d_nkp, 0, I * 4);
+    hipMemcpyAsync(ctx->d_xofs, xofs.data(), xofs.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    hipMemcpyAsync(ctx->d_xalpha, xalpha.data(), xalpha.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    hipMemcpyAsync(ctx->d_yofs, yofs.data(), yofs.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    hipMemcpyAsync(ctx->d_ybeta, ybeta.data(), ybeta.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    hipMemsetAsync(ctx->d_nkp, 0, I * 4, ctx->stream);
     {   // RANSAC sample indices of cv::solvePnPRansac for every possible point count (they depend on nothing else)
       std::vector<uint16_t> sub((size_t)513 * 500, 0);
       for (int n = 5; n <= 512; ++n) svo_pnp_subsets(0, n, &sub[(size_t)n * 500]);
-      hipMemcpy(ctx->d_pnp_subsets, sub.data(), sub.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+      hipMemcpyAsync(ctx->d_pnp_subsets, sub.data(), sub.size() * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream);
+      hipStreamSynchronize(ctx->stream);   // (`sub` lives in this block)
     }
-    hipMemset(ctx->d_selcnt, 0, I * SVO_NLEVELS * 4);
-    hipDeviceSynchronize();   // (the memsets above run on the null stream, which the context's non-blocking streams do not order against)
+    hipMemsetAsync(ctx->d_selcnt, 0, I * SVO_NLEVELS * 4, ctx->stream);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = SVO_E_HIP;   // (tables and memsets ran on the context's own stream - no NULL-stream call - and are waited for: the other streams of the context do not order against it)
   }
   if (rc != SVO_OK) {
     svo_destroy(ctx);
@@ -297,6 +311,7 @@ extern "C" void svo_destroy(svo_ctx* ctx) {
   if (ctx->stream_idx) hipStreamSynchronize(ctx->stream_idx);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   (void)hipGetLastError();
+  svo_hostfeed_release(ctx);
   svo_track_release(ctx);
   svo_elas_release(ctx);
   svo_msa_release(ctx);
@@ -410,7 +425,7 @@ extern "C" int svo_set_option(svo_ctx* ctx, const char* key, int value) {
 extern "C" int svo_sync(svo_ctx* ctx) {
   if (!ctx) return SVO_E_INVALID;
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return SVO_OK;
+  return svo_hostfeed_flush(ctx);   // (records of host-fed calls: out of the pinned buffers into the caller's arrays)
 }
 extern "C" void* svo_stream(svo_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
@@ -502,12 +517,12 @@ extern "C" int svo_debug_fast_corners(svo_ctx* ctx, int image_slot, int level, i
     return SVO_E_INVALID;
   const SvoGeom& g = ctx->g;
   int32_t cnt = 0;
-  SVO_HIP(ctx, hipMemcpy(&cnt, ctx->d_counters + image_slot * SVO_NLEVELS + level, 4,
+  SVO_HIP(ctx, svo_memcpy_sync(ctx, &cnt, ctx->d_counters + image_slot * SVO_NLEVELS + level, 4,
                          hipMemcpyDeviceToHost));
   cnt = std::min(cnt, capacity);
   std::vector<uint32_t> raw((size_t)std::max(cnt, 1));
   if (cnt > 0)
-    SVO_HIP(ctx, hipMemcpy(raw.data(),
+    SVO_HIP(ctx, svo_memcpy_sync(ctx, raw.data(),
                            ctx->d_corners + (size_t)image_slot * g.corner_entries + g.coff[level],
                            4 * (size_t)cnt, hipMemcpyDeviceToHost));
   for (int i = 0; i < cnt; ++i) {
@@ -1123,10 +1138,12 @@ hipError_t svo_stream_create_masked(hipStream_t* st, int device, int percent) {
 //   stream_fe_batch  the batched tracker's front end                             "fe_cu_percent" of the CUs (first mask words)
 //   stream_dense     dense stage in front of the tracker (depth_source 1, 2)     "dense_cu_percent" of the CUs
 // An option that changes a mask destroys that one stream and makes a new one through svo_pick_stream (measured against the
-// others, rejected candidates parked).  SVO_POOLED_QUEUES=1: the runtime's pooled streams as up to round 5 (main stream only;
-// the others on demand through the picker).
+// others, rejected candidates parked).  Per context (svo_create_ex flags; svo_stream_mode reports what is in effect):
+// SVO_CREATE_POOLED_STREAMS - the runtime's pooled NON-BLOCKING streams as up to round 5 (main stream only; the others on demand
+// through the picker; svo_create takes it from SVO_POOLED_QUEUES=1); SVO_CREATE_TAIL_ALL_CUS - the first two queues keep every CU
+// (a context that never runs the batched tracker: its host-buffer / front-end / dense entries all run on `stream`).
 int svo_stream_burst(svo_ctx* ctx) {
-  static const bool pooled = []() { const char* e = getenv("SVO_POOLED_QUEUES"); return e && e[0] == '1'; }();
+  const bool pooled = (ctx->create_flags & SVO_CREATE_POOLED_STREAMS) != 0;
   hipDeviceProp_t prop;
   if (pooled || hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) {
     (void)hipGetLastError();
@@ -1140,7 +1157,7 @@ int svo_stream_burst(svo_ctx* ctx) {
     return m;
   };
   std::vector<uint32_t> tail((size_t)words, 0xffffffffu);
-  if (words > 1) tail[0] = 0;
+  if (words > 1 && !(ctx->create_flags & SVO_CREATE_TAIL_ALL_CUS)) tail[0] = 0;
   const std::vector<uint32_t> masks[4] = {tail, tail, first_words(ctx->opt_fe_cu_percent), first_words(ctx->opt_dense_cu_percent)};
   hipStream_t q[4] = {nullptr, nullptr, nullptr, nullptr};
   for (int k = 0; k < 4; ++k) {

@@ -1282,10 +1282,10 @@ int elas_phase_b(svo_ctx* ctx, hipStream_t s, const ElasTab* d_tab, int B, int m
       float* pl = side ? taps->planes2 : taps->planes1;
       int32_t* gr = side ? taps->grid2 : taps->grid1;
       if (ti) memcpy(ti, tap_w->tri[side].data(), (size_t)k * 3 * sizeof(int32_t));
-      if (pl && k) SVO_HIP(ctx, hipMemcpy(pl, tap_st->d_plane[side], (size_t)k * 6 * sizeof(float), hipMemcpyDeviceToHost));
+      if (pl && k) SVO_HIP(ctx, svo_memcpy_sync(ctx, pl, tap_st->d_plane[side], (size_t)k * 6 * sizeof(float), hipMemcpyDeviceToHost));
       if (gr) {   // the reference's list layout: per cell [count, d0, d1, ...]
         std::vector<uint32_t> bits((size_t)ncell * 8);
-        SVO_HIP(ctx, hipMemcpy(bits.data(), reinterpret_cast<const uint32_t*>(tap_st->d_grid[side]) + (size_t)ncell * 8,
+        SVO_HIP(ctx, svo_memcpy_sync(ctx, bits.data(), reinterpret_cast<const uint32_t*>(tap_st->d_grid[side]) + (size_t)ncell * 8,
                                bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         memset(gr, 0, (size_t)ncell * gd * sizeof(int32_t));
         for (int c = 0; c < ncell; ++c) {
@@ -1392,8 +1392,8 @@ int elas_core(svo_ctx* ctx, ElasState* st, const uint8_t* dL, const uint8_t* dR,
     SVO_HIP(ctx, hipStreamSynchronize(s));
   }
   if (taps) {
-    if (taps->desc1) SVO_HIP(ctx, hipMemcpy(taps->desc1, st->d_desc[0], (size_t)W * H * 16, hipMemcpyDeviceToHost));
-    if (taps->desc2) SVO_HIP(ctx, hipMemcpy(taps->desc2, st->d_desc[1], (size_t)W * H * 16, hipMemcpyDeviceToHost));
+    if (taps->desc1) SVO_HIP(ctx, svo_memcpy_sync(ctx, taps->desc1, st->d_desc[0], (size_t)W * H * 16, hipMemcpyDeviceToHost));
+    if (taps->desc2) SVO_HIP(ctx, svo_memcpy_sync(ctx, taps->desc2, st->d_desc[1], (size_t)W * H * 16, hipMemcpyDeviceToHost));
   }
   ElasWork w;
   {

@@ -981,7 +981,7 @@ extern "C" int svo_msa_solve(svo_ctx* ctx, const uint8_t* bgrL, const uint8_t* b
   }
   const int rc = msa_solve_device(ctx, s, buf, img3, n, m, d, scale, d_out);
   if (rc) return rc;
-  SVO_HIP(ctx, hipMemcpy(disparity, d_out, N, hipMemcpyDeviceToHost));
+  SVO_HIP(ctx, svo_memcpy_sync(ctx, disparity, d_out, N, hipMemcpyDeviceToHost));
   return SVO_OK;
 }
 

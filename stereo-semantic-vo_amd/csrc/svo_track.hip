@@ -1744,6 +1744,7 @@ static int track_reset_n(svo_ctx* ctx, const svo_camera* cam, int nseq) {
   if (ctx->stream_fe_batch) SVO_HIP(ctx, hipStreamSynchronize(ctx->stream_fe_batch));
   if (ctx->stream_dense) SVO_HIP(ctx, hipStreamSynchronize(ctx->stream_dense));
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  { const int rcf = svo_hostfeed_flush(ctx); if (rcf) return rcf; }   // (records of host-fed calls of the sequence that ends here)
   ctx->ms_parity = 0; ctx->ms_tail_recorded[0] = false; ctx->ms_tail_recorded[1] = false;
   ctx->tb_parity = 0; ctx->tb_used[0] = false; ctx->tb_used[1] = false;   // (all streams are idle here)
   if (ctx->d_work) SVO_HIP(ctx, hipMemsetAsync(ctx->d_work, 0, sizeof(TrackWork) * (size_t)ctx->work_cap * 2, ctx->stream));   // frame tags restart at 1 (the ctx stream is waited for below)
@@ -2035,6 +2036,7 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
         return SVO_OK;
       }
     } hook{ctx, ctx->stream, boxes, d_results, dD1, d_prod, n, K, 0};
+    if (ctx->feed_pair_event) SVO_HIP(ctx, hipStreamWaitEvent(ctx->stream_dense, ctx->feed_pair_event[B - 1], 0));   // host-fed: the call's uploads
     ctx->stream = ctx->stream_dense;
     ctx->hyp_two_launch = ctx->opt_dense_two_launch != 0;   // (the hook's tail_enqueue calls: 16 CUs per frame instead of 100 on ordinary frames)
     rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, B, B);   // left images only
@@ -2047,6 +2049,7 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
     // MSA maps, up to eight frames in flight (most of a solve is the host tree builds)
     const size_t n = (size_t)ctx->g.W * ctx->g.H;
     if ((rc = dense_reserve(ctx, B))) return rc;
+    if (ctx->feed_pair_event) SVO_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->feed_pair_event[B - 1], 0));   // host-fed: the call's uploads
     if ((rc = svo_launch_orb(ctx, d_grayL, d_grayR, stride, B, B))) return rc;   // left images only
     if ((rc = svo_msa_run_many_dev(ctx, d_grayL, d_grayR, stride, (size_t)ctx->g.H * stride, ctx->g.W, ctx->g.H, 48, B,
                                    ctx->d_dense)))
@@ -2111,6 +2114,8 @@ extern "C" int svo_track_batch_dev(svo_ctx* ctx, const uint8_t* d_grayL, const u
       const int f0 = j * SUB, b = std::min(SUB, B - f0);
       ctx->d_kp = kp0 + f0 * K; ctx->d_desc = desc0 + f0 * K * 32; ctx->d_nkp = nkp0 + f0;
       ctx->d_uR = uR0 + f0 * K; ctx->d_depth = depth0 + f0 * K; ctx->d_sad = sad0 + f0 * K;
+      if (ctx->feed_pair_event && hipStreamWaitEvent(ctx->stream_fe_batch, ctx->feed_pair_event[f0 + b - 1], 0) != hipSuccess) rc = SVO_E_HIP;   // host-fed: this sub-batch's uploads
+      if (rc) break;
       rc = svo_launch_orb(ctx, d_grayL + f0 * img, d_grayR + f0 * img, stride, b, 2 * b);
       if (rc == SVO_OK) rc = svo_launch_stereo(ctx, d_grayL + f0 * img, d_grayR + f0 * img, stride, b, &ctx->cam);
       if (rc == SVO_OK && hipEventRecord(ctx->ev_sub[j], ctx->stream_fe_batch) != hipSuccess) rc = SVO_E_HIP;
@@ -2159,7 +2164,7 @@ extern "C" int svo_track_overflowed(svo_ctx* ctx, int32_t* flag) {
   int32_t any = 0;
   for (int q = 0; q < ctx->n_seq; ++q) {
     int32_t v = 0;
-    SVO_HIP(ctx, hipMemcpy(&v, &st[q].overflow, 4, hipMemcpyDeviceToHost));
+    SVO_HIP(ctx, svo_memcpy_sync(ctx, &v, &st[q].overflow, 4, hipMemcpyDeviceToHost));
     any |= v;
   }
   *flag = any;
@@ -2196,7 +2201,7 @@ extern "C" int svo_track_epnp_fallbacks(svo_ctx* ctx, int64_t* count) {
   int64_t total = 0;
   for (int q = 0; q < ctx->n_seq; ++q) {
     int32_t v = 0;
-    SVO_HIP(ctx, hipMemcpy(&v, &st[q].epnp_fallbacks, 4, hipMemcpyDeviceToHost));
+    SVO_HIP(ctx, svo_memcpy_sync(ctx, &v, &st[q].epnp_fallbacks, 4, hipMemcpyDeviceToHost));
     total += v;
   }
   *count = total;
@@ -2227,7 +2232,7 @@ extern "C" int svo_debug_track_frames(svo_ctx* ctx, int first, int n, svo_track_
   hipSetDevice(ctx->device);
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   std::vector<TrackWork> w((size_t)n);
-  SVO_HIP(ctx, hipMemcpy(w.data(), reinterpret_cast<TrackWork*>(ctx->d_work) + (size_t)ctx->work_last_half * ctx->work_cap + first,
+  SVO_HIP(ctx, svo_memcpy_sync(ctx, w.data(), reinterpret_cast<TrackWork*>(ctx->d_work) + (size_t)ctx->work_last_half * ctx->work_cap + first,
                          sizeof(TrackWork) * (size_t)n, hipMemcpyDeviceToHost));
   for (int f = 0; f < n; ++f) {
     const TrackWork& q = w[f];
@@ -2251,7 +2256,7 @@ extern "C" int svo_debug_track_stamps(svo_ctx* ctx, int slot, int64_t ts[8]) {
   if (!ctx || !ts || !ctx->d_work || slot < 0 || slot >= ctx->work_cap) return SVO_E_INVALID;
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   TrackWork* w = reinterpret_cast<TrackWork*>(ctx->d_work) + (size_t)ctx->work_last_half * ctx->work_cap + slot;
-  SVO_HIP(ctx, hipMemcpy(ts, w->ts, sizeof(long long) * 8, hipMemcpyDeviceToHost));
+  SVO_HIP(ctx, svo_memcpy_sync(ctx, ts, w->ts, sizeof(long long) * 8, hipMemcpyDeviceToHost));
   return SVO_OK;
 }
 
@@ -2261,7 +2266,7 @@ extern "C" int svo_debug_track_realtime(svo_ctx* ctx, int slot, int64_t rt[4]) {
   if (!ctx || !rt || !ctx->d_work || slot < 0 || slot >= ctx->work_cap) return SVO_E_INVALID;
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   TrackWork* w = reinterpret_cast<TrackWork*>(ctx->d_work) + (size_t)ctx->work_last_half * ctx->work_cap + slot;
-  SVO_HIP(ctx, hipMemcpy(rt, w->rt, sizeof(long long) * 4, hipMemcpyDeviceToHost));   // (the first four stamps)
+  SVO_HIP(ctx, svo_memcpy_sync(ctx, rt, w->rt, sizeof(long long) * 4, hipMemcpyDeviceToHost));   // (the first four stamps)
   return SVO_OK;
 }
 
@@ -2510,7 +2515,8 @@ extern "C" int svo_track_sharded_dev(svo_ctx* const* ctxs, int G, const uint8_t*
       c->stream = fs;
       c->d_kp = own[g].kp + (size_t)f0 * K; c->d_desc = own[g].desc + (size_t)f0 * wd; c->d_nkp = own[g].nkp + f0;
       c->d_uR = own[g].uR + (size_t)f0 * K; c->d_depth = own[g].depth + (size_t)f0 * K; c->d_sad = own[g].sad + (size_t)f0 * K;
-      rc = svo_launch_orb(c, d_grayL[g] + f0 * img, d_grayR[g] + f0 * img, stride, b, 2 * b);
+      if (c->feed_pair_event && hipStreamWaitEvent(fs, c->feed_pair_event[f0 + b - 1], 0) != hipSuccess) rc = SVO_E_HIP;   // host-fed: this sub-batch's uploads (context g's copy stream, its device)
+      if (rc == SVO_OK) rc = svo_launch_orb(c, d_grayL[g] + f0 * img, d_grayR[g] + f0 * img, stride, b, 2 * b);
       if (rc == SVO_OK) rc = svo_launch_stereo(c, d_grayL[g] + f0 * img, d_grayR[g] + f0 * img, stride, b, &c0->cam);
       if (rc == SVO_OK && !direct[g]) {
         // bounce, first half: this sub-batch's results into the context's region of the pinned buffer, on its own stream
@@ -2589,13 +2595,13 @@ extern "C" int svo_debug_track_pnp(svo_ctx* ctx, svo_pnp_stats* stats, double T_
   if (!ctx || !ctx->d_track) return SVO_E_INVALID;
   TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (stats) SVO_HIP(ctx, hipMemcpy(stats, &st->pnp, sizeof *stats, hipMemcpyDeviceToHost));
+  if (stats) SVO_HIP(ctx, svo_memcpy_sync(ctx, stats, &st->pnp, sizeof *stats, hipMemcpyDeviceToHost));
   if (T_pnp) {
     PnpHyp h;
     svo_pnp_stats s;
-    SVO_HIP(ctx, hipMemcpy(&s, &st->pnp, sizeof s, hipMemcpyDeviceToHost));
+    SVO_HIP(ctx, svo_memcpy_sync(ctx, &s, &st->pnp, sizeof s, hipMemcpyDeviceToHost));
     if (s.best_hypothesis < 0) return SVO_E_INVALID;
-    SVO_HIP(ctx, hipMemcpy(&h, &st->hyp[s.best_hypothesis], sizeof h, hipMemcpyDeviceToHost));
+    SVO_HIP(ctx, svo_memcpy_sync(ctx, &h, &st->hyp[s.best_hypothesis], sizeof h, hipMemcpyDeviceToHost));
     for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) T_pnp[4 * r + c] = h.R[3 * r + c]; T_pnp[4 * r + 3] = h.t[r]; }
     T_pnp[12] = 0; T_pnp[13] = 0; T_pnp[14] = 0; T_pnp[15] = 1;
   }
@@ -2609,6 +2615,6 @@ extern "C" int svo_debug_track_pose_stamps(svo_ctx* ctx, int64_t ts[16]) {
   if (!ctx || !ts || !ctx->d_track) return SVO_E_INVALID;
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
-  SVO_HIP(ctx, hipMemcpy(ts, st->pose_ts, sizeof(long long) * 16, hipMemcpyDeviceToHost));
+  SVO_HIP(ctx, svo_memcpy_sync(ctx, ts, st->pose_ts, sizeof(long long) * 16, hipMemcpyDeviceToHost));
   return SVO_OK;
 }

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = C.CDLL(pkg.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.svo_abi_version() == 6
+    assert lib.svo_abi_version() == 7
 
 
 def test_strerror_and_argument_checks(pkg):

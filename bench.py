@@ -739,6 +739,68 @@ def semantic_elas_leg(pkg, cam, dL, dR, dev, rec, n=256):
     return out
 
 
+
+def host_feed_leg(pkg, cam, dL, dR, dev, local, res_ref, B, calls=12, warm=2):
+    """The PCIe-inclusive tracker ("H2D 2 P bytes, D2H ~30 KB" per pair; main.cpp:159-195 hands over one pair per
+    Track()): svo_track_batch_host over the first B x calls frames of the headline sequence, the images starting in HOST memory -
+    once pinned (copied where they lie), once pageable (staged inside the call) - the records landing in host memory; `warm`
+    untimed calls, then the rest back to back with ONE svo_sync at the end.  Beside it the front end alone, host to host."""
+    import numpy as np
+    import torch
+    n = min(B * calls, int(dL.shape[0]))
+    calls = n // B
+    n = B * calls
+    hL = dL[:n].cpu(); hR = dR[:n].cpu()
+    fb = H * PITCH
+    out = {"frames": int(n), "frames_per_call": int(B), "calls_timed": int(calls - warm), "host_bytes_per_pair": 2 * fb,
+           "note": "images start in host memory (pitch %d), uploads on the context's copy stream eight pairs per event, records D2H behind "
+                   "the pose chain; no synchronisation between calls" % PITCH}
+    t_pin = time.perf_counter()
+    pL = hL.pin_memory(); pR = hR.pin_memory()
+    out["pin_seconds"] = round(time.perf_counter() - t_pin, 2)
+    for name, (aL, aR) in (("pinned", (pL, pR)), ("pageable", (hL, hR))):
+        ctx = pkg.Svo(W, H, device=local, max_kp=500, max_batch=B)
+        ctx.track_reset(cam)
+        res = np.zeros(n, pkg.TRACK_DTYPE)
+        for c in range(warm):
+            ctx.track_batch_host(aL.data_ptr() + c * B * fb, aR.data_ptr() + c * B * fb, PITCH, B, res[c * B:(c + 1) * B])
+        ctx.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for c in range(warm, calls):
+            ctx.track_batch_host(aL.data_ptr() + c * B * fb, aR.data_ptr() + c * B * fb, PITCH, B, res[c * B:(c + 1) * B])
+        t_enq = time.perf_counter() - t0
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        ctx.close()
+        same = bool(res.tobytes() == res_ref[:n].tobytes()) if res_ref is not None else None
+        out[name] = {"value": (calls - warm) * B / dt, "unit": "stereo frames/s", "host_ms_in_the_calls": round(1e3 * t_enq, 1),
+                     "records_identical_to_the_resident_run": same, "h2d_gb_per_s": (calls - warm) * B * 2 * fb / dt / 1e9}
+    # the front end alone, host to host (pinned source): what the link delivers
+    Bf = 128
+    fe = pkg.Svo(W, H, device=local, max_kp=500, max_batch=Bf, flags=pkg.CREATE_TAIL_ALL_CUS)
+    hn = np.zeros(Bf, np.int32); hdepth = np.zeros((Bf, 500), np.float32)
+    steps = 16
+
+    def run(s):
+        off = (s * Bf) % (n - Bf + 1)
+        fe.frontend_batch_host(pL.data_ptr() + off * fb, pR.data_ptr() + off * fb, PITCH, Bf, cam, nL=hn, depth=hdepth)
+    for s in range(3):
+        run(s)
+    fe.sync()
+    t0 = time.perf_counter()
+    for s in range(3, 3 + steps):
+        run(s)
+    fe.sync()
+    dt = time.perf_counter() - t0
+    fe.close()
+    out["frontend"] = {"value": Bf * steps / dt, "unit": "stereo pairs/s", "pairs_per_call": Bf, "h2d_gb_per_s": Bf * steps * 2 * fb / dt / 1e9,
+                       "note": "svo_frontend_batch_host from pinned memory: bound by the PCIe link, not by the kernels"}
+    out["value"] = out["pinned"]["value"]
+    out["unit"] = "stereo frames/s"
+    del pL, pR
+    return out
+
+
 PNP_SOLVERS = {
     2: "epnp_exact=2 (default): order-preserving wave EPnP - every IEEE operation of OpenCV's solvePnPRansac/EPnP loops kept, independent "
        "ones spread over a wavefront per RANSAC sample (k-ordered sums on v_mfma_f64_4x4x4); bit-identical per sample to the CPU "
@@ -887,14 +949,35 @@ def compact_line(out, detail_path=None):
             line[name] = leg.get("value", leg.get("error"))
         elif leg is not None:
             line[name] = leg
+    # the legs' own parity checks (booleans; the detail file says what each compared)
+    checks = {}
+    for name, key, path in (("sharded_records_identical_to_single_context", "sharded", ("records_identical_to_single_context",)),
+                            ("multi_sequence0_equals_single_chain", "multi_sequence", ("sequence0_equals_single_chain",)),
+                            ("host_feed_records_identical_to_resident", "host_feed", ("pinned", "records_identical_to_the_resident_run")),
+                            ("host_feed_pageable_records_identical", "host_feed", ("pageable", "records_identical_to_the_resident_run")),
+                            ("semantic_elas_counters_identical_to_cpu", "semantic_elas", ("cpu_baseline", "counters_identical_to_gpu")),
+                            ("elas_pixels_differing_from_reference", "elas", ("pixels_differing_from_reference",)),
+                            ("msa_pixels_differing_from_port", "msa", ("pixels_differing_from_port",)),
+                            ("cotenant_records_identical", "with_null_stream_cotenant", ("records_identical",))):
+        v = out.get(key)
+        for k in path:
+            v = v.get(k) if isinstance(v, dict) else None
+        if v is not None:
+            checks[name] = v
+    if checks:
+        line["checks"] = checks
     tc = out.get("tail_critical_path")
     if isinstance(tc, dict) and "frame_period_us" in tc:
         line["frame_period_us"] = tc["frame_period_us"].get("mean")
     if detail_path:
         line["detail"] = detail_path
+    exact = {k: line.get(k) for k in ("value", "ms_per_step")}
     line = _sig(line)
+    for k, v in exact.items():      # the two figures the driver cross-checks keep nine digits
+        if isinstance(v, float):
+            line[k] = float("%.9g" % v)
     # shrink in a fixed order if a future field pushed it over the limit
-    for drop in (("detail",), ("frame_period_us",), ("roofline", "issue_model"), ("cpu_baseline", "sample"), ("config", "parallelism"),
+    for drop in (("frame_period_us",), ("roofline", "issue_model"), ("cpu_baseline", "sample"), ("config", "parallelism"),
                  ("config", "resident_input_bytes_per_gpu"), ("config", "final_position_error_m"), ("config", "path_length_m")):
         if len(json.dumps(line)) < LINE_LIMIT:
             break
@@ -1061,6 +1144,7 @@ def main():
     ap.add_argument("--leg-orders", action="store_true", help="repeat the tail legs in the reverse order and each in a child process (three figures per leg)")
     ap.add_argument("--quick-legs", action="store_true", help="skip the pnp_solver_modes leg")
     ap.add_argument("--no-tail-leg-children", action="store_true", help="(kept for scripts; the child repetition now needs --leg-orders)")
+    ap.add_argument("--no-host-feed-leg", action="store_true", help="skip the host_feed leg (svo_track_batch_host / svo_frontend_batch_host from host memory)")
     ap.add_argument("--no-shard-leg", action="store_true", help="N > 1: skip rank 0's svo_track_sharded_dev run across the N GPUs")
     ap.add_argument("--shard", action="store_true",
                     help="track workload: ONE sequence over --gpus G contexts in ONE process (svo_track_sharded_dev, BASELINE configs[3])")
@@ -1446,6 +1530,15 @@ def main():
                     r["in_process_over_child"] = [leg_ratio(r["value_in_process"], r["value_child_process"]),
                                                   leg_ratio(r["value_in_process_reverse_order"], r["value_child_process"])]
                 out[name] = r
+            if not args.no_host_feed_leg:
+                progress("leg host_feed")
+                try:
+                    hf = host_feed_leg(pkg, cam, dL, dR, dev, local, res, B)
+                    out["host_feed"] = hf
+                    out["host_feed_pageable"] = hf["pageable"]["value"]
+                    out["frontend_host_feed"] = hf["frontend"]["value"]
+                except Exception as e:  # noqa: BLE001
+                    out["host_feed"] = {"error": repr(e)}
             progress("leg frontend")
             out["frontend"] = frontend_leg(pkg, cam, dL, dR, n_frames, frame_bytes, dev,
                                            None if args.no_cpu_baseline else cpu_baseline_all_cores)

@@ -59,7 +59,10 @@ typedef enum svo_status {
   SVO_E_NODEVICE = -2,  /* no usable HIP device / kernels not loadable  */
   SVO_E_NOMEM = -3,     /* device or host allocation failed              */
   SVO_E_HIP = -4,       /* a HIP runtime call failed; see svo_last_error */
-  SVO_E_CAPACITY = -5   /* batch / keypoint capacity of the ctx exceeded */
+  SVO_E_CAPACITY = -5,  /* batch / keypoint capacity of the ctx exceeded */
+  SVO_E_TIMEOUT = -6    /* svo_sync: a bounded wait inside the tracker's pose chain ran out (sticky flag 4, svo_track_overflowed): the frame
+                           concerned was tracked as a PnP failure (its record has n_pnp_inliers = -1), nothing stale was used; returned
+                           once, the context continues with the two-launch pose chain ("tail_fused" = 0) */
 } svo_status;
 
 typedef struct svo_ctx svo_ctx;
@@ -477,7 +480,7 @@ int svo_track_sharded_host(svo_ctx* const* ctxs, int G, const uint8_t* grayL, co
 int svo_frontend_batch_host(svo_ctx* ctx, const uint8_t* grayL, const uint8_t* grayR, int stride, int B,
                             const svo_camera* cam, svo_kp* kpL, uint8_t* descL, int32_t* nL, float* uR, float* depth);
 
-/* Sticky capacity flag of the device tracker (synchronises): *flag != 0 once a frame needed more than the 4096 live
+/* Sticky flag of the device tracker (synchronises).  4: see SVO_E_TIMEOUT.  1: capacity - *flag != 0 once a frame needed more than the 4096 live
  * map points the pool holds, or a map point stayed alive for more than 2^20 creations (its slot in the position table
  * was about to be reused).  Neither can happen with the reference's 500 keypoints per frame on sequences of KITTI
  * length; results after the flag is set are not the reference's. */

@@ -165,6 +165,7 @@ extern "C" const char* svo_strerror(int status) {
     case SVO_E_NOMEM: return "out of memory";
     case SVO_E_HIP: return "HIP runtime error";
     case SVO_E_CAPACITY: return "capacity exceeded";
+    case SVO_E_TIMEOUT: return "a wait inside the tracker's pose chain timed out";
     default: return "unknown status";
   }
 }
@@ -391,6 +392,7 @@ extern "C" int svo_set_option(svo_ctx* ctx, const char* key, int value) {
     ctx->opt_epnp_exact = value == 0 ? 0 : value == 2 ? 2 : 1;
     return SVO_OK;
   }
+  if (!strcmp(key, "debug_lose_sample")) { if (value < 0 || value > 100) return SVO_E_INVALID; ctx->opt_debug_lose_sample = value; return SVO_OK; }
   if (!strcmp(key, "epnp_force_seq")) { ctx->opt_epnp_force_seq = value != 0; return SVO_OK; }
   if (!strcmp(key, "shard_force_staged")) { ctx->opt_shard_force_staged = value != 0; return SVO_OK; }
   if (!strcmp(key, "multi_pipeline")) { ctx->opt_multi_pipeline = value != 0; return SVO_OK; }
@@ -425,7 +427,9 @@ extern "C" int svo_set_option(svo_ctx* ctx, const char* key, int value) {
 extern "C" int svo_sync(svo_ctx* ctx) {
   if (!ctx) return SVO_E_INVALID;
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return svo_hostfeed_flush(ctx);   // (records of host-fed calls: out of the pinned buffers into the caller's arrays)
+  const int rcf = svo_hostfeed_flush(ctx);   // (records of host-fed calls: out of the pinned buffers into the caller's arrays)
+  if (rcf) return rcf;
+  return svo_track_check_timeout(ctx);
 }
 extern "C" void* svo_stream(svo_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 

@@ -174,6 +174,8 @@ struct svo_ctx {
   int opt_dense_cu_percent = 88;   // svo_track_batch_dev with depth_source 1: share of the CUs the dense front end's stream may use (measured, 256 frames with boxes: 100 % 5.4 k, 88 % 5.7 k, 75 % 6.4 k, 62 % 6.0 k, 50 % 5.3 k frames/s - the tail's single-wave RANSAC workgroups need free CUs, ELAS needs most of the chip)
   int opt_shard_force_staged = 0;  // svo_track_sharded_dev gathers through pinned host memory even where a peer read exists (tests; env SVO_SHARD_FORCE_STAGED is read once, at svo_create)
   int opt_epnp_force_seq = 0;  // tests: mode 2 takes its sequential fallback for every sample
+  int opt_debug_lose_sample = 0;   // tests: sample k - 1 of every fused pose launch never reports (0: off)
+  bool timeout_reported = false;                  // svo_sync returned SVO_E_TIMEOUT for this context once (sticky flag 4, svo_track_check_timeout)
   uint32_t create_flags = 0;                      // svo_create_ex
   void* hostfeed = nullptr;                       // HostFeed (svo_hostfeed.hip): copy stream, image sets, pinned staging of the host-fed entries
   const hipEvent_t* feed_pair_event = nullptr;    // set by a host-fed entry for the duration of its inner call: pair i of the call (this context's
@@ -251,6 +253,7 @@ int svo_msa_tree_rec(const uint8_t* m_img3, const double* r_gra, const double* c
                      std::vector<int32_t>* level_ptr, int* maxw, int32_t* root);
 int svo_track_quiesce(svo_ctx* ctx, bool shard_too = true);   // waits for what overlapped tracker calls left in flight and may still read this context's arrays
 int svo_shard_quiesce(svo_ctx* ctx);   // svo_track.hip: the sharded tracker's part of that
+int svo_track_check_timeout(svo_ctx* ctx);   // svo_track.hip: sticky flag 4 -> SVO_E_TIMEOUT (once), fused pose launch off
 int svo_hostfeed_flush(svo_ctx* ctx);  // svo_hostfeed.hip: records / front-end outputs waiting in pinned buffers -> the caller's arrays
 void svo_hostfeed_release(svo_ctx* ctx);
 // svo_api.hip: a new stream (made by `make`) that runs side by side with every non-null stream of `others`, chosen by measuring

@@ -1159,6 +1159,7 @@ __device__ __forceinline__ void tp_hyp_ord_body(TpHypOrdLds& S, TrackState* st, 
   const int n = ld_agent(&work->n_edges);
   const int frame_tag = FUSED ? ld_agent(&work->frame_id) + 1 : 0;
   if (ld_agent(&work->skip_match) || n < 5) return;
+  if (FUSED && (force_seq >> 8) == sample + 1) return;   // test switch "debug_lose_sample": this sample never reports (the frame part's bounded wait)
   if (hyp_base > 0) {   // second launch of a many-sequence step: only the samples the adaptive bound can still reach (see k_tp_hyp)
     const int pre = min(hyp_base, TP_HYP_PRE);   // the rule over the samples of the earlier launches (all of them done: same stream)
     if ((int)threadIdx.x < pre) { S.cnt[threadIdx.x] = st->hyp[threadIdx.x].cnt; S.ok[threadIdx.x] = st->hyp[threadIdx.x].ok; }
@@ -1182,7 +1183,7 @@ __device__ __forceinline__ void tp_hyp_ord_body(TpHypOrdLds& S, TrackState* st, 
     if (threadIdx.x < 4) st->K[threadIdx.x] = K[threadIdx.x];
   }
   const long long t_gather = clock64();
-  pnp_hyp_ord_wave<FUSED>(S.ord, S.Xw, S.uv, n, K, subsets + (size_t)min(n, 512) * 500, st->hyp, sample, force_seq != 0);
+  pnp_hyp_ord_wave<FUSED>(S.ord, S.Xw, S.uv, n, K, subsets + (size_t)min(n, 512) * 500, st->hyp, sample, (force_seq & 0xff) != 0);
   if (FUSED) {
     TP_STORES_DONE();   // (lane 0's agent-scope stores of the sample's result have reached the coherent level)
     if (threadIdx.x == 0) {
@@ -1213,6 +1214,7 @@ struct TpLds {
   alignas(16) int sm[16];
   float sT[16], sRwc[9], stwc[3];
   int cnt[PNP_HYP], ok[PNP_HYP], upd_r[PNP_HYP], best, good, iters;
+  int late[TP_EARLY], lost;   // fused launch: a wait for the samples ran into its bound (the frame then counts as a PnP failure)
   int recf[8];   // the record's counters, fetched at the kernel's start
   double upd_ld[PNP_HYP];
 };
@@ -1280,8 +1282,15 @@ __device__ __forceinline__ void tp_frame_body(TpLds& S, TrackState* st, TrackWor
     if (tid < TP_EARLY) {
       int spins = 0;
       while (ld_agent(&work->hyp_early[tid]) != id + 1 && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(1); ++spins; }
-      if (spins >= (1 << 22)) st->overflow = 4;
-      const int c = ld_agent(&st->hyp[tid].cnt), o = ld_agent(&st->hyp[tid].ok);
+      // A sample that did not report (forward progress of a workgroup that waits for others of its launch rests on in-order
+      // dispatch, which the hardware does and HIP does not promise): NOTHING of this launch's samples is used - the frame is
+      // treated as cv::solvePnPRansac returning false (the last pose stays), the record says so (n_pnp_inliers = -1), the
+      // sticky flag becomes 4 and the next svo_sync / svo_track_overflowed reports it (SVO_E_TIMEOUT) and switches the
+      // context to the two-launch pose chain ("tail_fused" = 0).
+      const bool late = spins >= (1 << 22);
+      if (late) st->overflow = 4;
+      S.late[tid] = late ? 1 : 0;
+      const int c = late ? 0 : ld_agent(&st->hyp[tid].cnt), o = late ? 0 : ld_agent(&st->hyp[tid].ok);
       S.cnt[tid] = c; S.ok[tid] = o;
       double ld = 1.0; int r = 0;
       if (o && c > 4 && n_edges > 5) pnp_update_terms(c, n_edges, &ld, &r);
@@ -1290,20 +1299,27 @@ __device__ __forceinline__ void tp_frame_body(TpLds& S, TrackState* st, TrackWor
       S.cnt[tid] = 0; S.ok[tid] = 0; S.upd_ld[tid] = 1.0; S.upd_r[tid] = 0;   // (never visited when the rule ends early)
     }
     __syncthreads();
-    if (tid == 0) S.iters = pnp_select_pre_bound(S.cnt, S.ok, S.upd_ld, S.upd_r, n_edges, TP_EARLY);
+    if (tid == 0) {
+      int l = 0;
+      for (int k = 0; k < TP_EARLY; ++k) l |= S.late[k];
+      S.lost = l;
+      S.iters = l ? 0 : pnp_select_pre_bound(S.cnt, S.ok, S.upd_ld, S.upd_r, n_edges, TP_EARLY);
+    }
     __syncthreads();
-    decided_early = S.iters <= TP_EARLY;
+    decided_early = S.lost || S.iters <= TP_EARLY;   // (lost: nothing more is waited for)
     if (!decided_early) {   // all PNP_HYP results stored
       if (tid == 0) {
         int spins = 0;
         while (ld_agent(&work->hyp_done) < PNP_HYP && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(1); ++spins; }
-        if (spins >= (1 << 22)) st->overflow = 4;
+        if (spins >= (1 << 22)) { st->overflow = 4; S.lost = 1; }
       }
       __syncthreads();
     }
+  } else if (tid == 0) {
+    S.lost = 0;
   }
   if (FUSED && tid == 0) work->rt[4] = wall_clock64();   // the frame part proper starts here (rt[2] .. rt[4]: the samples)
-  if (ran && !decided_early)
+  if (ran && !decided_early && !(FUSED && S.lost))
     for (int h = tid; h < PNP_HYP; h += TPF_NT) {
       // every sample's thread prepares the pow / log terms the iteration bound would need if that sample became the best
       const int c = FUSED ? ld_agent(&st->hyp[h].cnt) : st->hyp[h].cnt, o = FUSED ? ld_agent(&st->hyp[h].ok) : st->hyp[h].ok;
@@ -1315,7 +1331,7 @@ __device__ __forceinline__ void tp_frame_body(TpLds& S, TrackState* st, TrackWor
   __syncthreads();
   if (tid == 0) {
     int good = 0, iters = 0;
-    S.best = ran ? pnp_select_pre(S.cnt, S.ok, S.upd_ld, S.upd_r, n_edges, &good, &iters) : -1;
+    S.best = (ran && !S.lost) ? pnp_select_pre(S.cnt, S.ok, S.upd_ld, S.upd_r, n_edges, &good, &iters) : -1;
     S.good = good; S.iters = iters;
   }
   __syncthreads();
@@ -1371,7 +1387,7 @@ __device__ __forceinline__ void tp_frame_body(TpLds& S, TrackState* st, TrackWor
     for (int i = 0; i < 16; ++i) { r.Tcw[i] = S.sT[i]; st->lastTcw[i] = S.sT[i]; }
     r.frame_id = id; r.n_kp = nkp; r.n_stereo = S.recf[0];
     r.n_match_pass1 = S.recf[1]; r.n_match_pass2 = S.recf[2];
-    r.n_pnp_inliers = skip ? 0 : st->pnp.n_inliers;
+    r.n_pnp_inliers = skip ? 0 : (S.lost ? -1 : st->pnp.n_inliers);   // (-1: the samples of a fused launch did not report in time)
     r.n_lm_edges = n_edges;
     r.n_new_mappoints = S.recf[3];
     r.n_local_map = S.recf[4];
@@ -1664,7 +1680,7 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
       // which the dense kernels running on the same CUs pay for (configs[4]: 6.05 k frames/s fused, 6.85 k with two launches)
       SvoTimer t(ctx, "k_tp_tail_ord");
       hipLaunchKernelGGL(k_tp_tail_ord, dim3(PNP_HYP + 1, 1), dim3(TPF_NT), sizeof(TpTailLds), s0, st, work + f, kpf, depf, ctx->d_pnp_subsets,
-                         d_res + f, kstride, ctx->opt_pose_mfma, tag_of(f), ctx->opt_epnp_force_seq);
+                         d_res + f, kstride, ctx->opt_pose_mfma, tag_of(f), ctx->opt_epnp_force_seq | (ctx->opt_debug_lose_sample << 8));
       return;
     }
     if (ctx->opt_epnp_exact == 2) {
@@ -1867,6 +1883,7 @@ extern "C" int svo_track_frame(svo_ctx* ctx, const uint8_t* grayL, int strideL,
   SVO_HIP(ctx, hipMemcpyAsync(res, d_res, sizeof *res, hipMemcpyDeviceToHost, ctx->stream));
   SVO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->track_frame++;
+  if (res->n_pnp_inliers == -1) return svo_track_check_timeout(ctx);   // (the record is valid: the frame was tracked as a PnP failure)
   return SVO_OK;
 }
 
@@ -2155,8 +2172,26 @@ extern "C" int svo_track_tail_dev(svo_ctx* ctx, const svo_kp* d_kp, const uint8_
   return SVO_OK;
 }
 
-// Sticky capacity flag of the tracker (0 = fine): set when a frame wanted more than 4096 live map points or a map
-// point outlived the position table (2^20 ids); results after that are not the reference's.
+// svo_sync's look at the sticky flag of a single-sequence tracker (the stream is idle here): code 4 = a wait inside the pose chain
+// ran into its bound (k_tp_tail_ord's frame part waiting for the samples of its own launch, or a kernel polling for a hand-over
+// record with "pose_flag").  The frame concerned was treated as a PnP failure (record: n_pnp_inliers = -1) - nothing stale was
+// consumed -; the context falls back to the two-launch pose chain, whose kernels never wait for each other, and says so.
+int svo_track_check_timeout(svo_ctx* ctx) {
+  if (!ctx->d_track || ctx->n_seq != 1 || ctx->timeout_reported) return SVO_OK;
+  TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);
+  int32_t v = 0;
+  SVO_HIP(ctx, svo_memcpy_sync(ctx, &v, &st->overflow, 4, hipMemcpyDeviceToHost));
+  if (v != 4) return SVO_OK;
+  ctx->timeout_reported = true;
+  ctx->opt_tail_fused = 0;
+  ctx->opt_pose_flag = 0;
+  ctx->last_error = "tracker: a wait inside the pose chain timed out (sticky flag 4): the frame was treated as a PnP failure (n_pnp_inliers = -1); "
+                    "the context now runs the two-launch pose chain (tail_fused = 0, pose_flag = 0)";
+  return SVO_E_TIMEOUT;
+}
+
+// Sticky flag of the tracker (0 = fine).  1: a frame wanted more than 4096 live map points or a map point outlived the position
+// table (2^20 ids) - results after that are not the reference's.  4: a bounded wait inside the pose chain timed out (above).
 extern "C" int svo_track_overflowed(svo_ctx* ctx, int32_t* flag) {
   if (!ctx || !flag || !ctx->d_track) return SVO_E_INVALID;
   TrackState* st = reinterpret_cast<TrackState*>(ctx->d_track);

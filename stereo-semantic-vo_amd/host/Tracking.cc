@@ -37,13 +37,65 @@ Tracking::Tracking(const std::string& strSettingPath, int dev) : device(dev) {
   if (!read_camera_yaml(strSettingPath, K, &w, &h)) throw std::runtime_error("bad settings file " + strSettingPath);
   bf = K.bf;
   if (svo_create(&ctx, device, w, h, 500, 1) != SVO_OK) throw std::runtime_error("svo_create failed (no GPU?)");
+  width = w; height = h;
   Velocity = eye4();
 }
 Tracking::Tracking(const svo_camera& cam, int w, int h, int dev) : device(dev), K(cam), bf(cam.bf) {
   if (svo_create(&ctx, device, w, h, 500, 1) != SVO_OK) throw std::runtime_error("svo_create failed (no GPU?)");
+  width = w; height = h;
   Velocity = eye4();
 }
-Tracking::~Tracking() { svo_destroy(ctx); }
+Tracking::~Tracking() {
+  if (ctx_batch) svo_destroy(ctx_batch);
+  svo_destroy(ctx);
+}
+
+void Tracking::TrackBatch(const uint8_t* L, const uint8_t* R, int stride, int n, const double* timestamps,
+                          const std::vector<std::vector<std::vector<int>>>& detection_box) {
+  if (n < 1) return;
+  if (n > batch_capacity) throw std::runtime_error("TrackBatch: more frames than batch_capacity");
+  if (!ctx_batch) {
+    if (svo_create(&ctx_batch, device, width, height, 500, batch_capacity) != SVO_OK) throw std::runtime_error("svo_create failed");
+    if (svo_set_option(ctx_batch, "depth_source", depth_source) != SVO_OK || svo_track_reset(ctx_batch, &K) != SVO_OK)
+      throw std::runtime_error(std::string("TrackBatch: ") + svo_last_error(ctx_batch));
+    batch_results.reserve(1 << 16);   // (the library writes into this array until FinishBatches: it must not move)
+  }
+  const size_t first = batch_results.size();
+  if (first + (size_t)n > batch_results.capacity()) {   // a longer sequence: complete what is in flight before the array moves
+    if (svo_sync(ctx_batch) != SVO_OK) throw std::runtime_error(std::string("TrackBatch: ") + svo_last_error(ctx_batch));
+    batch_results.reserve(2 * batch_results.capacity() + (size_t)n);
+  }
+  batch_results.resize(first + (size_t)n);
+  for (int k = 0; k < n; ++k) batch_timestamps.push_back(timestamps ? timestamps[k] : 0.0);
+  // the frames' boxes as the flat arrays svo_boxes_host wants (main.cpp:82-95: 4 ints per line, left right top bottom)
+  int most = 0;
+  for (int k = 0; k < n && k < (int)detection_box.size(); ++k) most = std::max(most, (int)detection_box[k].size());
+  std::vector<int32_t> flat((size_t)n * std::max(most, 1) * 4, 0), cnt((size_t)n, 0);
+  for (int k = 0; k < n && k < (int)detection_box.size(); ++k) {
+    cnt[k] = (int32_t)detection_box[k].size();
+    for (size_t b = 0; b < detection_box[k].size(); ++b)
+      for (int j = 0; j < 4; ++j) flat[((size_t)k * most + b) * 4 + j] = detection_box[k][b][j];
+  }
+  const svo_boxes_host bx{flat.data(), cnt.data(), std::max(most, 1)};
+  const int rc = svo_track_batch_host(ctx_batch, L, R, stride, n, most > 0 ? &bx : nullptr, batch_results.data() + first);
+  if (rc != SVO_OK) throw std::runtime_error(std::string("svo_track_batch_host: ") + svo_last_error(ctx_batch));
+  frame_num += n;
+}
+
+void Tracking::FinishBatches(std::ofstream& f, std::ofstream& f2) {
+  if (!ctx_batch) return;
+  if (svo_sync(ctx_batch) != SVO_OK) throw std::runtime_error(std::string("FinishBatches: ") + svo_last_error(ctx_batch));
+  frame fr;   // SetPose's Rwc / twc arithmetic (src/frame.cc:66-73), SaveTrajectoryAndDraw's formats
+  for (size_t k = 0; k < batch_results.size(); ++k) {
+    Mat44f T;
+    for (int i = 0; i < 16; ++i) T.m[i] = batch_results[k].Tcw[i];
+    fr.SetPose(T);
+    fr.timestamp = batch_timestamps[k];
+    currentframe = &fr;
+    SaveTrajectoryAndDraw(f, f2);
+  }
+  currentframe = nullptr;
+}
 
 void Tracking::init() {
   bool dynamic = false;   // declared outside the loop and never reset, exactly as src/Tracking.cc:44

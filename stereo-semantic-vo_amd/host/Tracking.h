@@ -20,12 +20,25 @@ class Tracking {
   // src/Tracking.cc:180-252 (imdepth / img_detect / Pangolin matrix arguments dropped: GUI only)
   void Track(const svo_host::GrayImage& imLeft, const svo_host::GrayImage& imRight, double timestamp,
              std::ofstream& f, std::ofstream& f2, const std::vector<std::vector<int>>& detection_box);
+  // The same loop PIPELINED (svo_track_batch_host): the next n stereo pairs of the sequence at once, images in host memory
+  // (n x rows x stride bytes each side, frame k at L + k * rows * stride); returns at once - uploads, front end and the ordered
+  // tail run behind the caller's back while it decodes the next pairs.  detection_box[k]: frame k's offline boxes (may be
+  // empty).  FinishBatches() waits for everything and writes the trajectory rows of all batched frames in order
+  // (SaveTrajectoryAndDraw's two formats).  Not to be mixed with Track() on one sequence.
+  void TrackBatch(const uint8_t* L, const uint8_t* R, int stride, int n, const double* timestamps,
+                  const std::vector<std::vector<std::vector<int>>>& detection_box);
+  void FinishBatches(std::ofstream& f, std::ofstream& f2);
   void GetVelocity();                                                   // :99-106
   void Tracklastframe();                                                // :107-121
   void SaveTrajectoryAndDraw(std::ofstream& f, std::ofstream& f2);      // :124-144
 
  public:
   svo_ctx* ctx = nullptr;
+  svo_ctx* ctx_batch = nullptr;           // TrackBatch's context (max_batch = batch_capacity), made on first use
+  int batch_capacity = 64;
+  std::vector<svo_track_result> batch_results;   // one record per batched frame (stable storage: reserved for the sequence)
+  std::vector<double> batch_timestamps;
+  int width = 0, height = 0;
   int device;
   frame lastframe;
   frame* currentframe = nullptr;

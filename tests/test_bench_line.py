@@ -31,7 +31,7 @@ def test_line_of_every_committed_full_result_is_short_and_complete():
         if "roofline" in full and "cpu_baseline" in full:
             for k in CONTRACT:
                 assert k in line, (f, k)
-            assert line["value"] == float("%.5g" % full["value"])
+            assert line["value"] == float("%.9g" % full["value"])
             assert isinstance(line["config"]["workload"], str) and line["config"]["workload"]
             for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
                 assert k in line["roofline"], (f, k)

@@ -127,3 +127,40 @@ def test_stereo_kitti_driver_runs(pkg, tmp_path):
     kitti = np.loadtxt(str(tmp_path / "cameratrajectory_kitti.txt"))
     tum = np.loadtxt(str(tmp_path / "cameratrajectory_tum.txt"))
     assert kitti.shape == (n, 12) and tum.shape == (n, 8)
+
+
+@pytest.mark.gpu
+def test_stereo_kitti_pipelined_writes_the_frame_by_frame_trajectory(pkg, tmp_path):
+    """stereo_kitti --pipelined (Tracking::TrackBatch over svo_track_batch_host, 3 frames per call, offline boxes on some
+    frames) against the frame-by-frame driver (Tracking::Track, one C-ABI call per reference seam) on the same PGM sequence:
+    the two trajectory files must agree row for row (the host classes' tail and the device tail are the same computation:
+    test_host_classes_equal_device_tracker)."""
+    import importlib
+    synth = importlib.import_module("stereo_semantic_vo_amd.synth")
+    n = 8
+    L, R, _ = synth.render_sequence(n)
+    seq = tmp_path / "seq"
+    (seq / "image_0").mkdir(parents=True); (seq / "image_1").mkdir(); (seq / "boxes").mkdir()
+    for k in range(n):
+        write_pgm(str(seq / "image_0" / ("%06d.pgm" % k)), L[k].numpy())
+        write_pgm(str(seq / "image_1" / ("%06d.pgm" % k)), R[k].numpy())
+        if k in (2, 3, 6):
+            (seq / "boxes" / ("%d.txt" % (k + 1))).write_text("200 600 195 370\n20 120 30 90\n")
+    (seq / "times.txt").write_text("".join("%e\n" % (0.1 * k) for k in range(n)))
+    y = tmp_path / "s.yaml"
+    y.write_text("%YAML:1.0\nCamera.fx: 718.856\nCamera.fy: 718.856\nCamera.cx: 607.1928\nCamera.cy: 185.2157\n"
+                 "Camera.width: 1241\nCamera.height: 376\nCamera.bf: 386.1448\n")
+    out = {}
+    for mode, extra in (("frame", []), ("pipelined", ["3"])):
+        d = tmp_path / mode
+        d.mkdir()
+        cmd = [os.path.join(HOST, "stereo_kitti")] + (["--pipelined"] if extra else []) + ["voc", str(y), str(seq)] + extra
+        p = subprocess.run(cmd, capture_output=True, text=True, cwd=str(d))
+        assert p.returncode == 0, p.stdout + p.stderr
+        if extra:
+            assert "frames per second" in p.stdout
+        out[mode] = (np.loadtxt(str(d / "cameratrajectory_kitti.txt")), np.loadtxt(str(d / "cameratrajectory_tum.txt")))
+    assert out["frame"][0].shape == (n, 12) and out["pipelined"][0].shape == (n, 12)
+    assert np.abs(out["frame"][0] - out["pipelined"][0]).max() < 1e-4
+    assert np.abs(out["frame"][1] - out["pipelined"][1]).max() < 1e-4
+    assert abs(out["pipelined"][0][-1, 11] - (n - 1)) < 0.5

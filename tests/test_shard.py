@@ -247,8 +247,12 @@ def test_bench_gpus_flag_starts_the_ranks_itself():
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["frames_tracked"] == 48
-    # rank 0's one-sequence-over-all-contexts run (BASELINE configs[3]) rides along and reproduces the single chain
-    assert d["sharded"]["contexts"] == 2 and d["sharded"]["records_identical_to_single_context"] is True
+    assert len(lines[0]) < 4096
+    # rank 0's one-sequence-over-all-contexts run (BASELINE configs[3]) rides along and reproduces the single chain: one scalar and
+    # one check in the line, the leg itself in the detail file beside bench.py
+    assert d["sharded"] > 0 and d["checks"]["sharded_records_identical_to_single_context"] is True
+    full = json.load(open(os.path.join(ROOT, d["detail"])))
+    assert full["sharded"]["contexts"] == 2 and full["sharded"]["records_identical_to_single_context"] is True
     # a launcher that started another number of ranks than --gpus says is refused
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--frames", "48"], cwd=ROOT,
                          env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
@@ -264,7 +268,9 @@ def test_bench_shard_mode_one_sequence_over_two_contexts():
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
-    assert d["sharded"]["contexts"] == 2 and d["sharded"]["records_identical_to_single_context"] is True
+    assert d["sharded"] > 0 and d["checks"]["sharded_records_identical_to_single_context"] is True
+    full = json.load(open(os.path.join(ROOT, d["detail"])))
+    assert full["sharded"]["contexts"] == 2 and full["sharded"]["records_identical_to_single_context"] is True
     assert d["config"]["frames_tracked"] == 96 and d["value"] > 0 and d["scaling"] == "strong"
 
 

@@ -453,3 +453,42 @@ def test_tracking_is_independent_of_how_the_sequence_is_batched(pkg):
     r = np.frombuffer(a, pkg.TRACK_DTYPE)
     Twc = np.linalg.inv(r[-1]["Tcw"].reshape(4, 4).astype(np.float64))
     assert np.linalg.norm(Twc[:3, 3] - T[-1][:3, 3].cpu().numpy()) < 3.0      # 63 m path, no loop closing
+
+
+@pytest.mark.gpu
+def test_a_sample_that_never_reports_makes_its_frame_a_pnp_failure_not_a_stale_pose(pkg, sequence):
+    """The fused pose launch's frame workgroup waits (bounded) for sample workgroups of its own launch.  With the test switch
+    "debug_lose_sample" one of the first eight samples never reports: the frame must be tracked as cv::solvePnPRansac
+    returning false (the last pose stays, src/pnpmatch.cc:227 with an unusable result), its record marked n_pnp_inliers = -1,
+    svo_sync must return SVO_E_TIMEOUT once, and the context must carry on with the two-launch pose chain - frames before
+    the event identical to an undisturbed run, frames after it tracked normally (no silently wrong pose)."""
+    L, R, T = sequence
+    H, W = L.shape[1], L.shape[2]
+    cam = pkg.Camera(**pkg.KITTI_00_02)
+    ref = pkg.Svo(W, H)
+    ref.track_reset(cam)
+    want = [ref.track_frame(L[k], R[k]) for k in range(N_FRAMES)]
+    ref.close()
+    ctx = pkg.Svo(W, H)
+    ctx.track_reset(cam)
+    got = []
+    for k in range(N_FRAMES):
+        if k == 3:
+            ctx.set_option("debug_lose_sample", 3)          # sample 2 of frame 3's launch
+            with pytest.raises(pkg.SvoError, match="timed out"):
+                ctx.track_frame(L[k], R[k])
+            ctx.set_option("debug_lose_sample", 0)
+            assert ctx.track_overflowed() == 4
+            got.append(None)
+            continue
+        got.append(ctx.track_frame(L[k], R[k]))
+    for k in range(3):
+        assert got[k].tobytes() == want[k].tobytes(), k
+    # the frames after the event: tracked (PnP consensus found, a pose within a few centimetres of the undisturbed run's)
+    for k in range(4, N_FRAMES):
+        assert got[k]["n_pnp_inliers"] > 4 and got[k]["frame_id"] == k
+        c_got = -got[k]["Tcw"].reshape(4, 4)[:3, :3].T @ got[k]["Tcw"].reshape(4, 4)[:3, 3]
+        c_want = -want[k]["Tcw"].reshape(4, 4)[:3, :3].T @ want[k]["Tcw"].reshape(4, 4)[:3, 3]
+        assert np.linalg.norm(c_got - c_want) < 0.1, k
+    ctx.sync()                                              # (reported once; the context stays usable)
+    ctx.close()

@@ -160,6 +160,12 @@ def huber(e, delta):
     return rho
 
 
+def exp_coeffs(t, use_libm=False):
+    abc = np.zeros(3)
+    lib().orc_exp_coeffs(C.c_double(t), _p(abc), 1 if use_libm else 0)
+    return abc
+
+
 def se3_exp_matrix(upd):
     upd = np.ascontiguousarray(upd, np.float64); T = np.zeros(16)
     lib().orc_se3_exp_matrix(_p(upd), _p(T))

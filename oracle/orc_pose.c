@@ -20,7 +20,9 @@
  * Eigen itself is un-vendored (version >= 3.1 only, Thirdparty/g2o/CMakeLists.txt:70):
  * Quaterniond(Matrix3d), toRotationMatrix, quaternion product and q*v follow
  * Eigen's published formulas; LDLT is restated without pivoting, so solutions
- * agree to round-off, not bitwise (PARITY UNPINNED at that boundary).
+ * agree with the reference's to round-off, not bitwise (PARITY UNPINNED at that
+ * boundary).  The HIP path reproduces THIS file bit for bit (tests/test_gpu_parity.py,
+ * tests/test_full_length.py): same operations, same order of the sums over the edges.
  *
  * cv::solvePnPRansac (src/pnpmatch.cc:227) is restated in orc_pnp_cv.c.
  */
@@ -107,6 +109,51 @@ static void mat3_mul(const double a[9], const double b[9], double o[9]) {
   for (int r = 0; r < 3; ++r)
     for (int c = 0; c < 3; ++c) o[3 * r + c] = a[3 * r] * b[c] + a[3 * r + 1] * b[3 + c] + a[3 * r + 2] * b[6 + c];
 }
+/* sin(t) / t, (1 - cos t) / t^2, (t - sin t) / t^3 for |t| < 0.5.  se3quat.h:240-250 takes them from libm's sin / cos, whose
+ * last bit differs from one libm to the next (glibc's are not correctly rounded either).  To have ONE definition that a CPU and
+ * a GPU evaluate to the same bits, both sides use these alternating series in t^2 (truncated below 1e-17 relative) as a Horner
+ * chain of fma() calls - exact IEEE operations on either machine.  They are accurate to 1 ulp (tests/test_oracle_golden.py checks
+ * them against exact rational arithmetic), which the reference's own formulas are not: (1 - cos t) / t^2 and (t - sin t) / t^3
+ * cancel for small t (relative error ~1e-16 / t^2 and / t^3), so the two agree to within the LIBM formulas' error.  A tracking
+ * step's rotation is ~0.01 rad; |t| >= 0.5 still takes libm. */
+static void exp_coeffs_series(double t, double* a, double* b, double* c) {
+  const double x = t * t;
+  double pa = -1.0 / 121645100408832000.0, pb = 1.0 / 6402373705728000.0, pc = 1.0 / 121645100408832000.0; /* 1/19!, 1/18!, 1/19! */
+  pa = fma(pa, x, 1.0 / 355687428096000.0);  /* 1/17! */
+  pa = fma(pa, x, -1.0 / 1307674368000.0);   /* 1/15! */
+  pa = fma(pa, x, 1.0 / 6227020800.0);       /* 1/13! */
+  pa = fma(pa, x, -1.0 / 39916800.0);        /* 1/11! */
+  pa = fma(pa, x, 1.0 / 362880.0);           /* 1/9!  */
+  pa = fma(pa, x, -1.0 / 5040.0);            /* 1/7!  */
+  pa = fma(pa, x, 1.0 / 120.0);              /* 1/5!  */
+  pa = fma(pa, x, -1.0 / 6.0);               /* 1/3!  */
+  pa = fma(pa, x, 1.0);
+  pb = fma(pb, x, -1.0 / 20922789888000.0);  /* 1/16! */
+  pb = fma(pb, x, 1.0 / 87178291200.0);      /* 1/14! */
+  pb = fma(pb, x, -1.0 / 479001600.0);       /* 1/12! */
+  pb = fma(pb, x, 1.0 / 3628800.0);          /* 1/10! */
+  pb = fma(pb, x, -1.0 / 40320.0);           /* 1/8!  */
+  pb = fma(pb, x, 1.0 / 720.0);              /* 1/6!  */
+  pb = fma(pb, x, -1.0 / 24.0);              /* 1/4!  */
+  pb = fma(pb, x, 0.5);
+  pc = fma(pc, x, -1.0 / 355687428096000.0); /* 1/17! */
+  pc = fma(pc, x, 1.0 / 1307674368000.0);    /* 1/15! */
+  pc = fma(pc, x, -1.0 / 6227020800.0);      /* 1/13! */
+  pc = fma(pc, x, 1.0 / 39916800.0);         /* 1/11! */
+  pc = fma(pc, x, -1.0 / 362880.0);          /* 1/9!  */
+  pc = fma(pc, x, 1.0 / 5040.0);             /* 1/7!  */
+  pc = fma(pc, x, -1.0 / 120.0);             /* 1/5!  */
+  pc = fma(pc, x, 1.0 / 6.0);                /* 1/3!  */
+  *a = pa; *b = pb; *c = pc;
+}
+void orc_exp_coeffs(double t, double abc[3], int use_libm) {
+  if (use_libm) {
+    abc[0] = sin(t) / t; abc[1] = (1 - cos(t)) / (t * t); abc[2] = (t - sin(t)) / (t * t * t);
+  } else {
+    exp_coeffs_series(t, &abc[0], &abc[1], &abc[2]);
+  }
+}
+
 /* SE3Quat::exp (se3quat.h:223-257); update = [omega ; upsilon]. */
 static void se3_exp(const double u[6], se3_t* out) {
   const double om[3] = {u[0], u[1], u[2]}, up[3] = {u[3], u[4], u[5]};
@@ -118,8 +165,12 @@ static void se3_exp(const double u[6], se3_t* out) {
     for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0 ? 1.0 : 0.0) + Om[i] + Om2[i];
     memcpy(V, R, sizeof R);
   } else {
-    const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta),
-                 c = (theta - sin(theta)) / (theta * theta * theta);
+    double a, b, c;
+    if (theta < 0.5) {
+      exp_coeffs_series(theta, &a, &b, &c);
+    } else {
+      a = sin(theta) / theta; b = (1 - cos(theta)) / (theta * theta); c = (theta - sin(theta)) / (theta * theta * theta);
+    }
     for (int i = 0; i < 9; ++i) {
       const double I = (i % 4 == 0 ? 1.0 : 0.0);
       R[i] = I + a * Om[i] + b * Om2[i];

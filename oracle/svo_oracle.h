@@ -90,6 +90,9 @@ void orc_bf_match(const uint8_t* q, int M, const uint8_t* t, int N, int32_t* tra
 /* pose */
 void orc_huber(double e, double delta, double rho[3]);
 void orc_se3_exp(const double upd[6], double q_xyzw[4], double t[3]);
+/* the three coefficients of SE3Quat::exp: {sin t / t, (1 - cos t) / t^2, (t - sin t) / t^3}; use_libm = 1: se3quat.h:240-250's
+ * formulas on libm, 0: the fixed series the restatement (and the HIP path) evaluates for |t| < 0.5 (orc_pose.c) */
+void orc_exp_coeffs(double t, double abc[3], int use_libm);
 void orc_se3_exp_matrix(const double upd[6], double T[16]);
 void orc_se3_update(const double upd[6], double T[16]);
 int orc_pose_opt(const double* Xw, const double* obs, int n, const double K[4], double T[16],

@@ -15,25 +15,40 @@
 
 struct Se3 { double q[4]; double t[3]; };
 
-// The scalar float64 path of the LM (thread 0: LDL^T, exp map, quaternion updates) is a chain of ~20 divisions, 5 square
-// roots, a sine and a cosine per trial; as IEEE sequences they were 6.6 k of the 14 k cycles of an LM iteration.  These
-// are the hardware's reciprocal / reciprocal square root refined by two Newton steps on FMAs (<= 1-2 ulp: below what
-// libm's sin / cos already differ by from the CPU's), and the two series of the exponential map for small angles.
-__device__ __forceinline__ double pose_rcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
-  r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
-  return r;
+// BIT-IDENTICAL to the CPU restatement (oracle of the tests; g2o's loops with their operation order): every IEEE operation of
+// base_unary_edge.hpp:43-72 / block_solver.hpp:503-561 / optimization_algorithm_levenberg.cpp:61-189 is kept and rounded once -
+// what runs in parallel are INDEPENDENT operations only.  Three ingredients:
+//  * `/` and sqrt on the serial path (thread 0: LDL^T, exp map, quaternion updates: ~20 divisions, 5 square roots per trial) are
+//    the compiler's correctly rounded sequences WITHOUT their range scaling and special-case fix-up (pose_ndiv / pose_nsqrt: the
+//    same reciprocal / rsq estimate, Newton steps and final correction instruction for instruction - bit-identical to IEEE for
+//    operands a few hundred binades inside the range, which every quantity of the LM is);
+//  * the sums over the edges (H += rho1 J^T J, b -= rho1 J^T e, chi2 += rho) run in INSERTION ORDER on the matrix core:
+//    v_mfma_f64_4x4x4_4b_f64 with A = 1.0 is the IEEE sum ((((C + b0) + b1) + b2) + b3) of the four 16-lane groups' values per
+//    column (svo_epnp_ord_dev.h; tools/microbench/mfma_f64_4x4.hip), so four edges are added per instruction to 16 running sums;
+//  * sin / cos of SE3Quat::exp: for |theta| < 0.5 the fixed series below (FMA Horner), which the CPU restatement evaluates with the
+//    same fma() calls (beyond that libm on both sides: not bit-guaranteed, never reached by a tracking step).
+__device__ __forceinline__ double pose_ndiv(double a, double b) {   // a / b
+  double r = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  const double q = a * r;
+  const double rem = __builtin_fma(-b, q, a);
+  return __builtin_fma(rem, r, q);
 }
-__device__ __forceinline__ double pose_sqrt(double x) {   // x >= 0
+__device__ __forceinline__ double pose_nsqrt(double x) {   // sqrt(x), x >= 0
   if (!(x > 0.0)) return 0.0;
-  double y = __builtin_amdgcn_rsq(x);
-  double g = x * y, h = 0.5 * y;                      // Goldschmidt: g -> sqrt(x), h -> 1 / (2 sqrt(x))
-  double r = __builtin_fma(-h, g, 0.5);
-  g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
-  r = __builtin_fma(-h, g, 0.5);
-  g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
-  return __builtin_fma(__builtin_fma(-g, g, x), h, g);   // one correction with the exact residual x - g^2
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return g;
 }
 // sin(t) / t, (1 - cos t) / t^2, (t - sin t) / t^3 for |t| < 0.5 (every LM step; larger rotations take libm's sin / cos):
 // alternating series in t^2, truncated below 1e-17 relative
@@ -74,9 +89,9 @@ __device__ __forceinline__ void pose_exp_coeffs(double t, double* a, double* b, 
 __device__ __forceinline__ void quat_from_R(const double m[9], double q[4]) {
   double t = m[0] + m[4] + m[8];
   if (t > 0.0) {
-    t = pose_sqrt(t + 1.0);
+    t = pose_nsqrt(t + 1.0);
     q[3] = 0.5 * t;
-    t = 0.5 * pose_rcp(t);
+    t = pose_ndiv(0.5, t);
     q[0] = (m[7] - m[5]) * t;
     q[1] = (m[2] - m[6]) * t;
     q[2] = (m[3] - m[1]) * t;
@@ -85,25 +100,24 @@ __device__ __forceinline__ void quat_from_R(const double m[9], double q[4]) {
     if (m[4] > m[0]) i = 1;
     if (m[8] > (i == 1 ? m[4] : m[0])) i = 2;
     if (i == 0) {            // j = 1, k = 2
-      t = pose_sqrt(m[0] - m[4] - m[8] + 1.0);
-      q[0] = 0.5 * t; t = 0.5 * pose_rcp(t);
+      t = pose_nsqrt(m[0] - m[4] - m[8] + 1.0);
+      q[0] = 0.5 * t; t = pose_ndiv(0.5, t);
       q[3] = (m[7] - m[5]) * t; q[1] = (m[3] + m[1]) * t; q[2] = (m[6] + m[2]) * t;
     } else if (i == 1) {     // j = 2, k = 0
-      t = pose_sqrt(m[4] - m[8] - m[0] + 1.0);
-      q[1] = 0.5 * t; t = 0.5 * pose_rcp(t);
+      t = pose_nsqrt(m[4] - m[8] - m[0] + 1.0);
+      q[1] = 0.5 * t; t = pose_ndiv(0.5, t);
       q[3] = (m[2] - m[6]) * t; q[2] = (m[7] + m[5]) * t; q[0] = (m[1] + m[3]) * t;
     } else {                 // j = 0, k = 1
-      t = pose_sqrt(m[8] - m[0] - m[4] + 1.0);
-      q[2] = 0.5 * t; t = 0.5 * pose_rcp(t);
+      t = pose_nsqrt(m[8] - m[0] - m[4] + 1.0);
+      q[2] = 0.5 * t; t = pose_ndiv(0.5, t);
       q[3] = (m[3] - m[1]) * t; q[0] = (m[2] + m[6]) * t; q[1] = (m[5] + m[7]) * t;
     }
   }
 }
 __device__ __forceinline__ void normalize_rotation(Se3& s) {
   if (s.q[3] < 0) { s.q[0] = -s.q[0]; s.q[1] = -s.q[1]; s.q[2] = -s.q[2]; s.q[3] = -s.q[3]; }
-  const double n2 = s.q[0] * s.q[0] + s.q[1] * s.q[1] + s.q[2] * s.q[2] + s.q[3] * s.q[3];
-  const double in = pose_rcp(pose_sqrt(n2));
-  s.q[0] *= in; s.q[1] *= in; s.q[2] *= in; s.q[3] *= in;
+  const double n = pose_nsqrt(s.q[0] * s.q[0] + s.q[1] * s.q[1] + s.q[2] * s.q[2] + s.q[3] * s.q[3]);
+  s.q[0] = pose_ndiv(s.q[0], n); s.q[1] = pose_ndiv(s.q[1], n); s.q[2] = pose_ndiv(s.q[2], n); s.q[3] = pose_ndiv(s.q[3], n);
 }
 __device__ __forceinline__ void quat_mul(const double a[4], const double b[4], double o[4]) {
   const double w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
@@ -145,7 +159,7 @@ __device__ __forceinline__ void se3_to_T(const Se3& s, double* T) {
 // SE3Quat::exp (se3quat.h:223-257)
 __device__ void se3_exp(const double u[6], Se3& out) {
   const double om0 = u[0], om1 = u[1], om2 = u[2];
-  const double theta = pose_sqrt(om0 * om0 + om1 * om1 + om2 * om2);
+  const double theta = pose_nsqrt(om0 * om0 + om1 * om1 + om2 * om2);
   const double Om[9] = {0, -om2, om1, om2, 0, -om0, -om1, om0, 0};
   double Om2[9], R[9], V[9];
 #pragma unroll
@@ -193,7 +207,7 @@ __device__ __forceinline__ void huber(double e, double delta, double dsqr, doubl
 // would be placed in scratch memory, and this sits on the serial path of every LM / RANSAC step).
 // Returns 0 if a pivot is not positive (Eigen LDLT::isPositive() false).
 __device__ __forceinline__ int ldlt6_solve(const double* Hin, const double* b, double* x) {
-  double L[6][6], D[6], Dinv[6], y[6];
+  double L[6][6], D[6], y[6];
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -203,8 +217,6 @@ __device__ __forceinline__ int ldlt6_solve(const double* Hin, const double* b, d
       if (k < j) d -= L[j][k] * L[j][k] * D[k];
     ok = ok && (d > 0.0);
     D[j] = d;
-    const double inv = pose_rcp(d);
-    Dinv[j] = inv;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       if (i > j) {
@@ -212,7 +224,7 @@ __device__ __forceinline__ int ldlt6_solve(const double* Hin, const double* b, d
 #pragma unroll
         for (int k = 0; k < 6; ++k)
           if (k < j) sacc -= L[i][k] * L[j][k] * D[k];
-        L[i][j] = sacc * inv;
+        L[i][j] = pose_ndiv(sacc, d);
       }
     }
   }
@@ -226,7 +238,7 @@ __device__ __forceinline__ int ldlt6_solve(const double* Hin, const double* b, d
     y[i] = sacc;
   }
 #pragma unroll
-  for (int i = 0; i < 6; ++i) y[i] *= Dinv[i];
+  for (int i = 0; i < 6; ++i) y[i] = pose_ndiv(y[i], D[i]);
   double xs[6];
 #pragma unroll
   for (int i = 5; i >= 0; --i) {
@@ -263,152 +275,111 @@ __device__ __forceinline__ void edge_jacobian(const double pc[3], const double* 
   J[11] = y * invz_2 * K[1];
 }
 
-__device__ __forceinline__ double wave_sum_d(double v) { return wave_sum_f64_dpp(v); }
-// block reduction of NV doubles per thread (NT threads = NT / 64 waves); result in red[0..NV)
-template <int NV, int NT = 256>
-__device__ __forceinline__ void block_reduce(double* acc, double* red /* [4][NV] + [NV] */) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < NV; ++k) acc[k] = wave_sum_d(acc[k]);
-  if (NT == 64) {   // one wave: the sums are in every lane already - one LDS hop so that the callers read red[] as before
-    __syncthreads();
-    if (lane == 0)
-#pragma unroll
-      for (int k = 0; k < NV; ++k) red[k] = acc[k];
-    __syncthreads();
-    return;
-  }
-  __syncthreads();
-  if (lane == 0)
-#pragma unroll
-    for (int k = 0; k < NV; ++k) red[(1 + wv) * NV + k] = acc[k];
-  __syncthreads();
-  if (threadIdx.x < NV)
-    red[threadIdx.x] = red[NV + threadIdx.x] + red[2 * NV + threadIdx.x] + red[3 * NV + threadIdx.x] +
-                       red[4 * NV + threadIdx.x];
-  __syncthreads();
-}
+// ---- the sums over the edges, in insertion order, on the matrix core -------------------------------------------------------
+// v_mfma_f64_4x4x4_4b_f64 with A = 1.0: D(lane 16 g + c) = ((((C + B(c)) + B(16 + c)) + B(32 + c)) + B(48 + c)) for every group g:
+// the four lane groups' values of column c are added to the running sum in group order, each addition rounded (IEEE), and the
+// result lands in all four lanes of the column.  Lane group g supplies edge 4 s + g at step s; column c is one of up to 16
+// independent running sums.
+__device__ __forceinline__ double pose_gsum(double term, double acc) { return __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, term, acc, 0, 0, 0); }
 
-// accumulate (optionally Huber-weighted) normal equations + chi2 over edges listed by `use`.
-// acc layout: [0..20] upper-triangular H (row-major, r<=c), [21..26] b, [27] chi2
-template <bool ROBUST, int NT = 256>
-__device__ __forceinline__ void accum_system(const Se3& est, const double* Xw, const double* obs,
-                                             int n, const uint8_t* use, const double* K,
-                                             double delta, double dsqr, double acc[28]) {
-#pragma unroll
-  for (int k = 0; k < 28; ++k) acc[k] = 0;
-  for (int i = threadIdx.x; i < n; i += NT) {
-    if (use && !use[i]) continue;
-    double e[2], pc[3], J[12];
-    edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc);
-    double rho0 = e[0] * e[0] + e[1] * e[1], rho1 = 1.;
-    if (ROBUST) huber(rho0, delta, dsqr, rho0, rho1);
-    edge_jacobian(pc, K, J);
-    int k = 0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r)
-#pragma unroll
-      for (int c = r; c < 6; ++c) acc[k++] += rho1 * (J[r] * J[c] + J[6 + r] * J[6 + c]);
-#pragma unroll
-    for (int r = 0; r < 6; ++r) acc[21 + r] -= rho1 * (J[r] * e[0] + J[6 + r] * e[1]);
-    acc[27] += rho0;
+// One wave's LDS: the terms of up to 64 edges (one per lane), POSE_TW doubles apart (an odd pitch: conflict-free column reads)
+#define POSE_TW 9
+#define POSE_NQ 28          // 21 entries of the upper triangle of H (row-major, r <= c), 6 of b, chi2
+#define POSE_QW 7           // of them per wave (four waves)
+#define POSE_MAXN 512
+
+// wave-local visibility of LDS writes (LDS instructions of a wave execute in issue order; the fence keeps the compiler in line)
+#define POSE_WSYNC()                                       \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  \
+    __builtin_amdgcn_wave_barrier();                       \
+  } while (0)
+
+// term k (0..27) of an edge, with the CPU loop's operations (base_unary_edge.hpp:43-72 as g2o's Eigen expressions evaluate:
+// H(r, c) += rho1 * (J(0, r) * J(0, c) + J(1, r) * J(1, c)); b(r) -= rho1 * (J(0, r) * e0 + J(1, r) * e1); chi2 += rho0).
+// The b terms come out NEGATED: adding -t is subtracting t, bit for bit.
+constexpr int pose_tri_row(int k) { int r = 0; while (k >= 6 - r) { k -= 6 - r; ++r; } return r; }
+constexpr int pose_tri_col(int k) { int r = 0; while (k >= 6 - r) { k -= 6 - r; ++r; } return r + k; }
+template <int K>
+__device__ __forceinline__ double edge_term(const double J[12], const double e[2], double rho0, double rho1) {
+  if constexpr (K < 21) {
+    constexpr int r = pose_tri_row(K), c = pose_tri_col(K);
+    return rho1 * (J[r] * J[c] + J[6 + r] * J[6 + c]);
+  } else if constexpr (K < 27) {
+    constexpr int r = K - 21;
+    return -(rho1 * (J[r] * e[0] + J[6 + r] * e[1]));
+  } else {
+    return rho0;
   }
 }
-// ---- MFMA variant of the system build ---------------------------------------------------------
-// The normal equations are a Gram matrix: with A~ = sqrt(w) [J | e]  (2n rows x 7 columns)
-//   A~^T A~ = [ H  -b ; -b^T  sum w e^2 ],   H = J^T W J,  b = -J^T W e
-// - the one dense contraction on the path.  Rows are written to LDS once per LM iteration by all
-// 256 lanes (one edge each); every wave then feeds 4 rows per v_mfma_f64_16x16x4_f64 (A = B = the
-// row block, so each lane loads ONE double per instruction) and the four per-wave 16x16 tiles are
-// summed through LDS.  Only the leading 7x7 of the tile is meaningful.
-typedef double v4f64 __attribute__((ext_vector_type(4)));
-#define GRAM_MAXN 512
-#define GRAM_STRIDE 7
+template <int W>
+__device__ __forceinline__ void edge_terms(const double J[12], const double e[2], double rho0, double rho1, double out[POSE_QW]) {
+  out[0] = edge_term<W * POSE_QW + 0>(J, e, rho0, rho1); out[1] = edge_term<W * POSE_QW + 1>(J, e, rho0, rho1);
+  out[2] = edge_term<W * POSE_QW + 2>(J, e, rho0, rho1); out[3] = edge_term<W * POSE_QW + 3>(J, e, rho0, rho1);
+  out[4] = edge_term<W * POSE_QW + 4>(J, e, rho0, rho1); out[5] = edge_term<W * POSE_QW + 5>(J, e, rho0, rho1);
+  out[6] = edge_term<W * POSE_QW + 6>(J, e, rho0, rho1);
+}
 
-template <bool ROBUST, int NT = 256>
-__device__ __forceinline__ void build_system_mfma(const Se3& est, const double* Xw, const double* obs,
-                                                  int n, const uint8_t* use, const double* K,
-                                                  double delta, double dsqr, double* arow /*[2*512*7]*/,
-                                                  double* gram /*[4][8][8]*/, double* red) {
-  constexpr int NW = NT / 64;
+// The normal equations at `est`: red[0..20] = upper triangle of H, red[21..26] = b, red[27] = chi2 - every entry the IEEE sum of
+// its edge terms in edge order, starting from +0.  256 threads: wave w owns the quantities 7 w .. 7 w + 6; it evaluates them for
+// 64 edges at a time (one edge per lane: error, Huber weight, Jacobian - recomputed by each of the four waves, which is cheaper
+// than handing them over), stores them to its LDS slab, and adds them to its running sums four edges per MFMA.
+__device__ __forceinline__ void build_system_ordered(const Se3& est, const double* Xw, const double* obs, int n, const double* K,
+                                                     double delta, double dsqr, double* tw_all /*[4][64 * POSE_TW]*/, double* red) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int rows = (2 * n + 16 * NW - 1) & ~(16 * NW - 1);   // NW waves x whole groups of four 4-row steps
-  double chi = 0;
-  for (int i = tid; 2 * i < rows; i += NT) {
-    double r0[7] = {0, 0, 0, 0, 0, 0, 0}, r1[7] = {0, 0, 0, 0, 0, 0, 0};
-    if (i < n && !(use && !use[i])) {
+  const int g = lane >> 4, c = lane & 15;
+  double* tw = tw_all + wv * 64 * POSE_TW;
+  double acc = 0.0;
+  for (int e0 = 0; e0 < n; e0 += 64) {
+    const int cnt = min(64, n - e0);
+    if (lane < cnt) {
+      const int i = e0 + lane;
       double e[2], pc[3], J[12];
       edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc);
       double rho0 = e[0] * e[0] + e[1] * e[1], rho1 = 1.;
-      if (ROBUST) huber(rho0, delta, dsqr, rho0, rho1);
+      huber(rho0, delta, dsqr, rho0, rho1);
       edge_jacobian(pc, K, J);
-      const double sw = sqrt(rho1);
+      double t[POSE_QW];
+      switch (__builtin_amdgcn_readfirstlane(wv)) {   // (uniform per wave: a scalar branch)
+        case 0: edge_terms<0>(J, e, rho0, rho1, t); break;
+        case 1: edge_terms<1>(J, e, rho0, rho1, t); break;
+        case 2: edge_terms<2>(J, e, rho0, rho1, t); break;
+        default: edge_terms<3>(J, e, rho0, rho1, t); break;
+      }
 #pragma unroll
-      for (int c = 0; c < 6; ++c) { r0[c] = sw * J[c]; r1[c] = sw * J[6 + c]; }
-      r0[6] = sw * e[0]; r1[6] = sw * e[1];
-      chi += rho0;
+      for (int q = 0; q < POSE_QW; ++q) tw[lane * POSE_TW + q] = t[q];
     }
-#pragma unroll
-    for (int c = 0; c < 7; ++c) { arow[(2 * i) * GRAM_STRIDE + c] = r0[c]; arow[(2 * i + 1) * GRAM_STRIDE + c] = r1[c]; }
-  }
-  __syncthreads();
-  const int c = lane & 15, kk = lane >> 4;
-  const int per_wave = rows / NW;
-  // four independent accumulators: a dependent chain of f64 MFMAs would serialise on the
-  // instruction's own latency
-  v4f64 acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-  for (int r = wv * per_wave; r < (wv + 1) * per_wave; r += 16) {
-    const double* p = &arow[(r + kk) * GRAM_STRIDE + c];
-    const double v0 = c < 7 ? p[0] : 0.0, v1 = c < 7 ? p[4 * GRAM_STRIDE] : 0.0,
-                 v2 = c < 7 ? p[8 * GRAM_STRIDE] : 0.0, v3 = c < 7 ? p[12 * GRAM_STRIDE] : 0.0;
-    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, acc1, 0, 0, 0);
-    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(v2, v2, acc2, 0, 0, 0);
-    acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(v3, v3, acc3, 0, 0, 0);
-  }
-  const v4f64 acc = (acc0 + acc1) + (acc2 + acc3);
-  // C/D layout of the f64 16x16x4 form: col = lane & 15, row = (lane >> 4) + 4 * reg
-  if (c < 8) {
-    gram[(wv * 8 + kk) * 8 + c] = acc[0];
-    gram[(wv * 8 + kk + 4) * 8 + c] = acc[1];
-  }
-  chi = wave_sum_d(chi);
-  if (lane == 0) gram[256 + wv] = chi;
-  __syncthreads();
-  if (tid < 28) {
-    double out;
-    if (tid < 21) {
-      int r = 0, k = tid;                        // upper-triangular index -> (r, cc)
-      while (k >= 6 - r) { k -= 6 - r; ++r; }
-      const int cc = r + k;
-      out = gram[(0 * 8 + r) * 8 + cc];
-      if (NW == 4) out = out + gram[(1 * 8 + r) * 8 + cc] + gram[(2 * 8 + r) * 8 + cc] + gram[(3 * 8 + r) * 8 + cc];
-    } else if (tid < 27) {
-      const int r = tid - 21;
-      out = gram[(0 * 8 + r) * 8 + 6];
-      if (NW == 4) out = out + gram[(1 * 8 + r) * 8 + 6] + gram[(2 * 8 + r) * 8 + 6] + gram[(3 * 8 + r) * 8 + 6];
-      out = -out;
-    } else {
-      out = gram[256];
-      if (NW == 4) out = out + gram[257] + gram[258] + gram[259];
+    POSE_WSYNC();
+    // four edges per step; edges beyond the count and the unused columns add +0.0, which leaves every partial sum as it is
+    for (int s = 0; 4 * s < cnt; ++s) {
+      const int le = 4 * s + g;
+      const double v = (le < cnt && c < POSE_QW) ? tw[le * POSE_TW + c] : 0.0;
+      acc = pose_gsum(v, acc);
     }
-    red[tid] = out;
+    POSE_WSYNC();                         // (the slab is rewritten by the next 64 edges)
   }
+  if (lane < POSE_QW) red[wv * POSE_QW + lane] = acc;     // (b's terms were negated: red[21..26] is b itself)
   __syncthreads();
 }
 
-template <int NT = 256>
-__device__ __forceinline__ double partial_chi2(const Se3& est, const double* Xw, const double* obs,
-                                               int n, const double* K, double delta, double dsqr) {
-  double chi = 0;
-  for (int i = threadIdx.x; i < n; i += NT) {
-    double e[2], pc[3];
-    edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc);
-    double rho0 = e[0] * e[0] + e[1] * e[1], rho1;
-    huber(rho0, delta, dsqr, rho0, rho1);
-    chi += rho0;
+// robust chi2 at `est`, the sum over the edges in order (sparse_optimizer.cpp:100-114): every lane its edges' rho into chi[],
+// then wave 0 adds them four per MFMA (column 0).  Returns the sum in every lane of wave 0 (other waves: undefined).
+__device__ __forceinline__ double chi2_ordered_wave0(const double* chi, int n) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+  double acc = 0.0;
+  for (int s = 0; 4 * s < n; ++s) {
+    const int e = 4 * s + g;
+    const double v = (e < n && c == 0) ? chi[e] : 0.0;
+    acc = pose_gsum(v, acc);
   }
-  return chi;
+  return acc;
+}
+__device__ __forceinline__ double edge_rho(const Se3& est, const double* Xw, const double* obs, int i, const double* K, double delta, double dsqr) {
+  double e[2], pc[3];
+  edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc);
+  double rho0 = e[0] * e[0] + e[1] * e[1], rho1;
+  huber(rho0, delta, dsqr, rho0, rho1);
+  return rho0;
 }
 __device__ __forceinline__ void unpack_system(const double* red, double H[36], double b[6]) {
   int k = 0;
@@ -431,24 +402,24 @@ struct LmShared {
 #define PNP_HYP 100        // cv::solvePnPRansac(..., iterationsCount = 100, ...) (reference src/pnpmatch.cc:227)
 #define PNP_MAXN 512       // correspondences per problem (one per keypoint at most)
 
-// LDS workspace of the pose-only LM (dynamic shared memory: > 64 KB, needs the per-function opt-in)
+// LDS workspace of the pose-only LM
 struct PoseLds {
-  double arow[(2 * GRAM_MAXN + 64) * GRAM_STRIDE];
-  double gram[4 * 64 + 4];
-  double red[5 * 28];
+  double tw[4 * 64 * POSE_TW];   // per wave: the terms of 64 edges
+  double chi[POSE_MAXN];         // per edge: rho of the trial pose
+  double red[POSE_NQ + 4];
   LmShared sh;
   double K[4];
 };
 
-// Pose-only LM, called by all NT threads of the workgroup (NT = 256, or 64: the tracker's single-sequence chain - a frame has
-// ~64 edges, a CU's float64 pipeline is shared by its SIMDs anyway, and with ONE wave every barrier and reduction hop of
-// the loop is wave-local).  T: row-major 4x4 in/out (global or LDS); stats may be null.
+// Pose-only LM, called by all NT = 256 threads of the workgroup.  T: row-major 4x4 in/out (global or LDS); stats may be null.
+// use_ordered_mfma = 0 (svo_set_option "pose_mfma" = 0): the same sums by ONE lane, edge by edge - the checker of the matrix-core
+// path (identical bits, an order of magnitude slower on the build).
 template <int NT = 256>
 __device__ __forceinline__ void pose_opt_block(PoseLds& L, const double* __restrict__ Xw, const double* __restrict__ obs, int n,
                                                const double* __restrict__ Kp, double* T, svo_lm_stats* stats,
-                                               int round_in_f32, int use_mfma) {
-  if (n > GRAM_MAXN) use_mfma = 0;
-  double* arow = L.arow; double* gram = L.gram; double* red = L.red; LmShared& sh = L.sh; double* K = L.K;
+                                               int round_in_f32, int use_ordered_mfma) {
+  static_assert(NT == 256, "pose_opt_block: four waves (wave w owns the quantities 7 w .. 7 w + 6 of the normal equations)");
+  double* red = L.red; LmShared& sh = L.sh; double* K = L.K;
   const int tid = threadIdx.x;
   const double delta = (double)(float)sqrt(5.991);
   const double dsqr = delta * delta;
@@ -476,14 +447,32 @@ __device__ __forceinline__ void pose_opt_block(PoseLds& L, const double* __restr
     }
     return;
   }
+  // With at most 64 edges (a tracked frame has ~64) wave 0 runs a trial alone - proposal, the edges' chi2, their ordered sum, the
+  // accept / reject logic - with wave-local synchronisation; the other waves wait at ONE barrier per iteration.
+  const bool one_wave_trials = n <= 64 && n <= POSE_MAXN;
   for (int it = 0; it < 10; ++it) {
-    double acc[28];
     const Se3 est = sh.est;
-    if (use_mfma) {
-      build_system_mfma<true, NT>(est, Xw, obs, n, nullptr, K, delta, dsqr, arow, gram, red);
+    if (use_ordered_mfma) {
+      build_system_ordered(est, Xw, obs, n, K, delta, dsqr, L.tw, red);
     } else {
-      accum_system<true, NT>(est, Xw, obs, n, nullptr, K, delta, dsqr, acc);
-      block_reduce<28, NT>(acc, red);
+      if (tid == 0) {   // the checker: one lane, the CPU loop as it stands
+        double acc[POSE_NQ];
+        for (int k = 0; k < POSE_NQ; ++k) acc[k] = 0.0;
+        for (int i = 0; i < n; ++i) {
+          double e[2], pc[3], J[12];
+          edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc);
+          double rho0 = e[0] * e[0] + e[1] * e[1], rho1 = 1.;
+          huber(rho0, delta, dsqr, rho0, rho1);
+          edge_jacobian(pc, K, J);
+          int k = 0;
+          for (int r = 0; r < 6; ++r)
+            for (int c = r; c < 6; ++c) acc[k++] += rho1 * (J[r] * J[c] + J[6 + r] * J[6 + c]);
+          for (int r = 0; r < 6; ++r) acc[21 + r] -= rho1 * (J[r] * e[0] + J[6 + r] * e[1]);
+          acc[27] += rho0;
+        }
+        for (int k = 0; k < POSE_NQ; ++k) red[k] = acc[k];
+      }
+      __syncthreads();
     }
     double H[36], b[6], iniChi = 0, rho = 0;
     int qmax = 0;
@@ -500,57 +489,66 @@ __device__ __forceinline__ void pose_opt_block(PoseLds& L, const double* __restr
         nBad = 0;
       }
     }
-    // inner trial loop: thread 0 proposes, everyone evaluates chi2
-    for (int trial = 0; trial < 10; ++trial) {
-      int ok2 = 0;
-      if (tid == 0) {
-        sh.backup = sh.est;
-        double Hl[36];
+    // inner trial loop: thread 0 proposes, the edges' chi2 is evaluated in parallel and summed in order
+    if (tid < 64 || !one_wave_trials) {
+      for (int trial = 0; trial < 10; ++trial) {
+        int ok2 = 0;
+        if (tid == 0) {
+          sh.backup = sh.est;
+          double Hl[36];
 #pragma unroll
-        for (int j = 0; j < 36; ++j) Hl[j] = H[j];
+          for (int j = 0; j < 36; ++j) Hl[j] = H[j];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) Hl[7 * j] += lambda;
-        double xloc[6];
+          for (int j = 0; j < 6; ++j) Hl[7 * j] += lambda;
+          double xloc[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) xloc[j] = sh.x[j];
-        ok2 = ldlt6_solve(Hl, b, xloc);
+          for (int j = 0; j < 6; ++j) xloc[j] = sh.x[j];
+          ok2 = ldlt6_solve(Hl, b, xloc);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) sh.x[j] = xloc[j];
-        Se3 e2 = sh.est;
-        se3_oplus(xloc, e2);
-        sh.est = e2;
-      }
-      __syncthreads();
-      const Se3 trial_est = sh.est;
-      double c1[1] = {partial_chi2<NT>(trial_est, Xw, obs, n, K, delta, dsqr)};
-      block_reduce<1, NT>(c1, red);
-      if (tid == 0) {
-        double tempChi = red[0];
-        if (!ok2) tempChi = 1.7976931348623157e308;
-        rho = currentChi - tempChi;
-        double scale = 0;
-        for (int j = 0; j < 6; ++j) scale += sh.x[j] * (lambda * sh.x[j] + b[j]);
-        scale += 1e-3;
-        rho /= scale;
-        if (rho > 0 && isfinite(tempChi)) {
-          const double v = 2 * rho - 1;
-          double alpha = 1. - v * v * v;
-          alpha = fmin(alpha, 2. / 3.);
-          const double scaleFactor = fmax(1. / 3., alpha);
-          lambda *= scaleFactor;
-          ni = 2;
-          currentChi = tempChi;
-        } else {
-          lambda *= ni;
-          ni *= 2;
-          sh.est = sh.backup;
+          for (int j = 0; j < 6; ++j) sh.x[j] = xloc[j];
+          Se3 e2 = sh.est;
+          se3_oplus(xloc, e2);
+          sh.est = e2;
         }
-        ++qmax;
-        ++trials_total;
-        sh.go = (rho < 0 && qmax < 10) ? 1 : 0;
+        if (one_wave_trials) POSE_WSYNC(); else __syncthreads();
+        const Se3 trial_est = sh.est;
+        for (int i = tid; i < n; i += (one_wave_trials ? 64 : NT)) L.chi[i & (POSE_MAXN - 1)] = edge_rho(trial_est, Xw, obs, i, K, delta, dsqr);
+        if (one_wave_trials) POSE_WSYNC(); else __syncthreads();
+        double tempChi = 0;
+        if (tid < 64) {
+          if (n <= POSE_MAXN && use_ordered_mfma) {
+            tempChi = chi2_ordered_wave0(L.chi, n);
+          } else if (tid == 0) {      // more edges than chi[] holds (stand-alone svo_pose_opt only), or the checker: one lane, in order
+            for (int i = 0; i < n; ++i) tempChi += n <= POSE_MAXN ? L.chi[i] : edge_rho(trial_est, Xw, obs, i, K, delta, dsqr);
+          }
+        }
+        if (tid == 0) {
+          if (!ok2) tempChi = 1.7976931348623157e308;
+          rho = currentChi - tempChi;
+          double scale = 0;
+          for (int j = 0; j < 6; ++j) scale += sh.x[j] * (lambda * sh.x[j] + b[j]);
+          scale += 1e-3;
+          rho /= scale;
+          if (rho > 0 && isfinite(tempChi)) {
+            const double v = 2 * rho - 1;
+            double alpha = 1. - v * v * v;
+            alpha = fmin(alpha, 2. / 3.);
+            const double scaleFactor = fmax(1. / 3., alpha);
+            lambda *= scaleFactor;
+            ni = 2;
+            currentChi = tempChi;
+          } else {
+            lambda *= ni;
+            ni *= 2;
+            sh.est = sh.backup;
+          }
+          ++qmax;
+          ++trials_total;
+          sh.go = (rho < 0 && qmax < 10) ? 1 : 0;
+        }
+        if (one_wave_trials) POSE_WSYNC(); else __syncthreads();
+        if (!sh.go) break;
       }
-      __syncthreads();
-      if (!sh.go) break;
     }
     if (tid == 0) {
       ++iters;

@@ -23,7 +23,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsvo_hip.so")
+LIB_PATH = os.environ.get("SVO_LIB_PATH") or os.path.join(_HERE, "libsvo_hip.so")   # (SVO_LIB_PATH: A/B runs against another build of the library)
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])

@@ -364,7 +364,7 @@ extern "C" int svo_set_option(svo_ctx* ctx, const char* key, int value) {
     const int rcq = svo_track_quiesce(ctx);
     if (rcq) return rcq;
   }
-  if (!strcmp(key, "pose_mfma")) { ctx->opt_pose_mfma = value != 0; return SVO_OK; }
+  if (!strcmp(key, "pose_mfma")) { if (value < 0 || value > 2) return SVO_E_INVALID; ctx->opt_pose_mfma = value; return SVO_OK; }
   if (!strcmp(key, "fast_cand_cap")) {
     if (value < 0 || value > 2048) return SVO_E_INVALID;
     ctx->opt_fast_cand_cap = value;

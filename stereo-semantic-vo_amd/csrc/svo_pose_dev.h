@@ -282,11 +282,49 @@ __device__ __forceinline__ void edge_jacobian(const double pc[3], const double* 
 // independent running sums.
 __device__ __forceinline__ double pose_gsum(double term, double acc) { return __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, term, acc, 0, 0, 0); }
 
+// `cnt` values per column (value e of this lane's column at p[e * pitch]), added to `acc` in order, four per MFMA (lane group g
+// supplies value 4 s + g at step s).  Sixteen steps at a time: their sixteen LDS loads are issued together, THEN the dependent chain
+// of MFMAs runs - a load in front of every MFMA cost 165 cycles per step instead of ~25 (measured, tools/lm_phases.py).
+// Values beyond the count, and whole columns with `col_on` false, enter as +0.0, which leaves every partial sum as it is.
+__device__ __forceinline__ double pose_chain_sum(const double* p, int pitch, int cnt, bool col_on, int g, double acc) {
+  for (int s0 = 0; 4 * s0 < cnt; s0 += 8) {      // (one uniform branch per eight steps; the padding steps add +0.0)
+    double v[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int e = 4 * (s0 + s) + g;
+      const double x = p[min(e, cnt - 1) * pitch];
+      v[s] = (e < cnt && col_on) ? x : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc = pose_gsum(v[s], acc);
+  }
+  return acc;
+}
+
+// The same sum by plain additions, ONE LANE PER COLUMN: the lane adds its column's values one after the other (loads sixteen at a
+// time, then sixteen dependent v_add_f64).  A dependent f64 add issues every 8 cycles, a dependent 4x4x4 DMFMA every ~120
+// (tools/lm_phases.py: 2.0 k cycles for 64 values against 0.6 k) - with the values in LDS anyway the matrix core has nothing to
+// offer here; it stays as an option and as a second witness of the order ("pose_mfma" = 1).
+// The caller has ZERO-FILLED the values from `cnt` up to the next multiple of 16 (adding +0.0 changes nothing): no clamping,
+// no selects - per value half a two-value LDS load and the addition (a lone wave issues an instruction every ~4.4 cycles, and
+// with address arithmetic and selects per value the chain took 44 cycles per value instead of ~9).
+__device__ __forceinline__ double pose_lane_sum(const double* p, int pitch, int cnt, double acc) {
+  for (int e0 = 0; e0 < cnt; e0 += 16) {         // (one uniform branch per sixteen values)
+    double v[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) v[s] = p[(e0 + s) * pitch];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc += v[s];
+  }
+  return acc;
+}
+
 // One wave's LDS: the terms of up to 64 edges (one per lane), POSE_TW doubles apart (an odd pitch: conflict-free column reads)
 #define POSE_TW 9
 #define POSE_NQ 28          // 21 entries of the upper triangle of H (row-major, r <= c), 6 of b, chi2
 #define POSE_QW 7           // of them per wave (four waves)
 #define POSE_MAXN 512
+#define POSE_CHUNK 128      // edges a wave turns into terms per pass (two per lane)
 
 // wave-local visibility of LDS writes (LDS instructions of a wave execute in issue order; the fence keeps the compiler in line)
 #define POSE_WSYNC()                                       \
@@ -320,43 +358,67 @@ __device__ __forceinline__ void edge_terms(const double J[12], const double e[2]
   out[6] = edge_term<W * POSE_QW + 6>(J, e, rho0, rho1);
 }
 
+// One edge's share of wave W's quantities (error, Huber weight, Jacobian, then the wave's seven terms)
+template <int W>
+__device__ __forceinline__ void edge_wave_terms(const Se3& est, const double* Xw, const double* obs, int i, const double* K,
+                                                double delta, double dsqr, double t[POSE_QW]) {
+  double e[2], pc[3], J[12];
+  edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc);
+  double rho0 = e[0] * e[0] + e[1] * e[1], rho1 = 1.;
+  huber(rho0, delta, dsqr, rho0, rho1);
+  edge_jacobian(pc, K, J);
+  edge_terms<W>(J, e, rho0, rho1, t);
+}
+// wave W's terms of the edges e0 + lane and (TWO) e0 + 64 + lane into its slab: straight-line code for both edges (indices clamped,
+// stores masked), so that the two dependent chains - IEEE divisions, the rotation - fill each other's issue gaps
+template <int W, bool TWO>
+__device__ __forceinline__ void wave_terms_to_lds(const Se3& est, const double* Xw, const double* obs, int n, int e0, int lane,
+                                                  const double* K, double delta, double dsqr, double* tw) {
+  const int iA = e0 + lane, iB = e0 + 64 + lane;
+  double tA[POSE_QW], tB[POSE_QW];
+  edge_wave_terms<W>(est, Xw, obs, min(iA, n - 1), K, delta, dsqr, tA);
+  if (TWO) edge_wave_terms<W>(est, Xw, obs, min(iB, n - 1), K, delta, dsqr, tB);
+  // (every lane stores: rows beyond the last edge hold +0.0 - pose_lane_sum adds whole groups of sixteen rows)
+#pragma unroll
+  for (int q = 0; q < POSE_QW; ++q) tw[lane * POSE_TW + q] = iA < n ? tA[q] : 0.0;
+  if (TWO) {
+#pragma unroll
+    for (int q = 0; q < POSE_QW; ++q) tw[(64 + lane) * POSE_TW + q] = iB < n ? tB[q] : 0.0;
+  }
+}
+
 // The normal equations at `est`: red[0..20] = upper triangle of H, red[21..26] = b, red[27] = chi2 - every entry the IEEE sum of
 // its edge terms in edge order, starting from +0.  256 threads: wave w owns the quantities 7 w .. 7 w + 6; it evaluates them for
-// 64 edges at a time (one edge per lane: error, Huber weight, Jacobian - recomputed by each of the four waves, which is cheaper
-// than handing them over), stores them to its LDS slab, and adds them to its running sums four edges per MFMA.
+// up to 128 edges at a time (one or two edges per lane: error, Huber weight, Jacobian - recomputed by each of the four waves, which
+// is cheaper than handing them over), stores them to its LDS slab, and adds them to its running sums four edges per MFMA.
 __device__ __forceinline__ void build_system_ordered(const Se3& est, const double* Xw, const double* obs, int n, const double* K,
-                                                     double delta, double dsqr, double* tw_all /*[4][64 * POSE_TW]*/, double* red) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+                                                     double delta, double dsqr, double* tw_all /*[4][POSE_CHUNK * POSE_TW]*/, double* red,
+                                                     bool on_mfma) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, c = lane & 15;
-  double* tw = tw_all + wv * 64 * POSE_TW;
+  double* tw = tw_all + wv * POSE_CHUNK * POSE_TW;
   double acc = 0.0;
-  for (int e0 = 0; e0 < n; e0 += 64) {
-    const int cnt = min(64, n - e0);
-    if (lane < cnt) {
-      const int i = e0 + lane;
-      double e[2], pc[3], J[12];
-      edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc);
-      double rho0 = e[0] * e[0] + e[1] * e[1], rho1 = 1.;
-      huber(rho0, delta, dsqr, rho0, rho1);
-      edge_jacobian(pc, K, J);
-      double t[POSE_QW];
-      switch (__builtin_amdgcn_readfirstlane(wv)) {   // (uniform per wave: a scalar branch)
-        case 0: edge_terms<0>(J, e, rho0, rho1, t); break;
-        case 1: edge_terms<1>(J, e, rho0, rho1, t); break;
-        case 2: edge_terms<2>(J, e, rho0, rho1, t); break;
-        default: edge_terms<3>(J, e, rho0, rho1, t); break;
+  for (int e0 = 0; e0 < n; e0 += POSE_CHUNK) {
+    const int cnt = min(POSE_CHUNK, n - e0);
+    if (cnt > 64) {
+      switch (wv) {                       // (uniform per wave: scalar branches)
+        case 0: wave_terms_to_lds<0, true>(est, Xw, obs, n, e0, lane, K, delta, dsqr, tw); break;
+        case 1: wave_terms_to_lds<1, true>(est, Xw, obs, n, e0, lane, K, delta, dsqr, tw); break;
+        case 2: wave_terms_to_lds<2, true>(est, Xw, obs, n, e0, lane, K, delta, dsqr, tw); break;
+        default: wave_terms_to_lds<3, true>(est, Xw, obs, n, e0, lane, K, delta, dsqr, tw); break;
       }
-#pragma unroll
-      for (int q = 0; q < POSE_QW; ++q) tw[lane * POSE_TW + q] = t[q];
+    } else {
+      switch (wv) {
+        case 0: wave_terms_to_lds<0, false>(est, Xw, obs, n, e0, lane, K, delta, dsqr, tw); break;
+        case 1: wave_terms_to_lds<1, false>(est, Xw, obs, n, e0, lane, K, delta, dsqr, tw); break;
+        case 2: wave_terms_to_lds<2, false>(est, Xw, obs, n, e0, lane, K, delta, dsqr, tw); break;
+        default: wave_terms_to_lds<3, false>(est, Xw, obs, n, e0, lane, K, delta, dsqr, tw); break;
+      }
     }
     POSE_WSYNC();
-    // four edges per step; edges beyond the count and the unused columns add +0.0, which leaves every partial sum as it is
-    for (int s = 0; 4 * s < cnt; ++s) {
-      const int le = 4 * s + g;
-      const double v = (le < cnt && c < POSE_QW) ? tw[le * POSE_TW + c] : 0.0;
-      acc = pose_gsum(v, acc);
-    }
-    POSE_WSYNC();                         // (the slab is rewritten by the next 64 edges)
+    if (on_mfma) acc = pose_chain_sum(tw + min(c, POSE_QW - 1), POSE_TW, cnt, c < POSE_QW, g, acc);
+    else acc = pose_lane_sum(tw + min(lane, POSE_QW - 1), POSE_TW, cnt, acc);      // lanes 0..6: one quantity each
+    POSE_WSYNC();                         // (the slab is rewritten by the next chunk)
   }
   if (lane < POSE_QW) red[wv * POSE_QW + lane] = acc;     // (b's terms were negated: red[21..26] is b itself)
   __syncthreads();
@@ -364,15 +426,10 @@ __device__ __forceinline__ void build_system_ordered(const Se3& est, const doubl
 
 // robust chi2 at `est`, the sum over the edges in order (sparse_optimizer.cpp:100-114): every lane its edges' rho into chi[],
 // then wave 0 adds them four per MFMA (column 0).  Returns the sum in every lane of wave 0 (other waves: undefined).
-__device__ __forceinline__ double chi2_ordered_wave0(const double* chi, int n) {
+__device__ __forceinline__ double chi2_ordered_wave0(const double* chi, int n, bool on_mfma) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  double acc = 0.0;
-  for (int s = 0; 4 * s < n; ++s) {
-    const int e = 4 * s + g;
-    const double v = (e < n && c == 0) ? chi[e] : 0.0;
-    acc = pose_gsum(v, acc);
-  }
-  return acc;
+  if (!on_mfma) return pose_lane_sum(chi, 1, n, 0.0);      // (every lane the same sum: lane 0 uses it)
+  return pose_chain_sum(chi, 1, n, c == 0, g, 0.0);
 }
 __device__ __forceinline__ double edge_rho(const Se3& est, const double* Xw, const double* obs, int i, const double* K, double delta, double dsqr) {
   double e[2], pc[3];
@@ -404,7 +461,7 @@ struct LmShared {
 
 // LDS workspace of the pose-only LM
 struct PoseLds {
-  double tw[4 * 64 * POSE_TW];   // per wave: the terms of 64 edges
+  double tw[4 * POSE_CHUNK * POSE_TW];   // per wave: the terms of a chunk of edges
   double chi[POSE_MAXN];         // per edge: rho of the trial pose
   double red[POSE_NQ + 4];
   LmShared sh;
@@ -412,8 +469,9 @@ struct PoseLds {
 };
 
 // Pose-only LM, called by all NT = 256 threads of the workgroup.  T: row-major 4x4 in/out (global or LDS); stats may be null.
-// use_ordered_mfma = 0 (svo_set_option "pose_mfma" = 0): the same sums by ONE lane, edge by edge - the checker of the matrix-core
-// path (identical bits, an order of magnitude slower on the build).
+// use_ordered_mfma (svo_set_option "pose_mfma"): 2 (default) the sums over the edges by one lane per quantity, plain additions in
+// order; 1 the same sums on the matrix core (v_mfma_f64_4x4x4, A = 1: four edges per instruction - slower, see pose_lane_sum);
+// 0 everything by ONE lane, edge by edge as the CPU loop stands (the checker).  Identical bits in all three.
 template <int NT = 256>
 __device__ __forceinline__ void pose_opt_block(PoseLds& L, const double* __restrict__ Xw, const double* __restrict__ obs, int n,
                                                const double* __restrict__ Kp, double* T, svo_lm_stats* stats,
@@ -447,13 +505,21 @@ __device__ __forceinline__ void pose_opt_block(PoseLds& L, const double* __restr
     }
     return;
   }
-  // With at most 64 edges (a tracked frame has ~64) wave 0 runs a trial alone - proposal, the edges' chi2, their ordered sum, the
-  // accept / reject logic - with wave-local synchronisation; the other waves wait at ONE barrier per iteration.
-  const bool one_wave_trials = n <= 64 && n <= POSE_MAXN;
+  // With at most 128 edges (a tracked frame has ~64) wave 0 runs a trial alone - proposal, the edges' chi2 (one or two per lane),
+  // their ordered sum, the accept / reject logic - with wave-local synchronisation; the other waves wait at ONE barrier per iteration.
+  const bool one_wave_trials = n <= 128;
+#ifdef POSE_PROF
+  long long pf_build = 0, pf_serial = 0, pf_chi = 0, pf_sum = 0, pf_dec = 0, pf_t = 0;
+#define PF(acc) do { const long long _n = clock64(); acc += _n - pf_t; pf_t = _n; } while (0)
+  pf_t = clock64();
+#else
+#define PF(acc) do { } while (0)
+#endif
   for (int it = 0; it < 10; ++it) {
     const Se3 est = sh.est;
+    PF(pf_dec);
     if (use_ordered_mfma) {
-      build_system_ordered(est, Xw, obs, n, K, delta, dsqr, L.tw, red);
+      build_system_ordered(est, Xw, obs, n, K, delta, dsqr, L.tw, red, use_ordered_mfma == 1);
     } else {
       if (tid == 0) {   // the checker: one lane, the CPU loop as it stands
         double acc[POSE_NQ];
@@ -474,6 +540,7 @@ __device__ __forceinline__ void pose_opt_block(PoseLds& L, const double* __restr
       }
       __syncthreads();
     }
+    PF(pf_build);
     double H[36], b[6], iniChi = 0, rho = 0;
     int qmax = 0;
     if (tid == 0) {
@@ -511,17 +578,30 @@ __device__ __forceinline__ void pose_opt_block(PoseLds& L, const double* __restr
           sh.est = e2;
         }
         if (one_wave_trials) POSE_WSYNC(); else __syncthreads();
+        PF(pf_serial);
         const Se3 trial_est = sh.est;
-        for (int i = tid; i < n; i += (one_wave_trials ? 64 : NT)) L.chi[i & (POSE_MAXN - 1)] = edge_rho(trial_est, Xw, obs, i, K, delta, dsqr);
+        if (one_wave_trials) {      // one or two edges per lane, straight-line (clamped indices, masked stores)
+          // (entries beyond the last edge: +0.0, see pose_lane_sum)
+          const double rA = edge_rho(trial_est, Xw, obs, min(tid, n - 1), K, delta, dsqr);
+          L.chi[tid] = tid < n ? rA : 0.0;
+          if (n > 64) {
+            const double rB = edge_rho(trial_est, Xw, obs, min(tid + 64, n - 1), K, delta, dsqr);
+            L.chi[tid + 64] = tid + 64 < n ? rB : 0.0;
+          }
+        } else {
+          for (int i = tid; i < ((min(n, POSE_MAXN) + 15) & ~15); i += NT) L.chi[i] = i < n ? edge_rho(trial_est, Xw, obs, i, K, delta, dsqr) : 0.0;
+        }
         if (one_wave_trials) POSE_WSYNC(); else __syncthreads();
+        PF(pf_chi);
         double tempChi = 0;
         if (tid < 64) {
           if (n <= POSE_MAXN && use_ordered_mfma) {
-            tempChi = chi2_ordered_wave0(L.chi, n);
+            tempChi = chi2_ordered_wave0(L.chi, n, use_ordered_mfma == 1);
           } else if (tid == 0) {      // more edges than chi[] holds (stand-alone svo_pose_opt only), or the checker: one lane, in order
             for (int i = 0; i < n; ++i) tempChi += n <= POSE_MAXN ? L.chi[i] : edge_rho(trial_est, Xw, obs, i, K, delta, dsqr);
           }
         }
+        PF(pf_sum);
         if (tid == 0) {
           if (!ok2) tempChi = 1.7976931348623157e308;
           rho = currentChi - tempChi;
@@ -570,6 +650,10 @@ __device__ __forceinline__ void pose_opt_block(PoseLds& L, const double* __restr
       stats->n_edges = n; stats->iterations = iters; stats->trials_total = trials_total;
       stats->terminated = terminated; stats->chi2_initial = chi_init;
       stats->chi2_final = currentChi; stats->lambda_final = lambda;
+#ifdef POSE_PROF
+      stats->chi2_initial = (double)pf_build; stats->chi2_final = (double)pf_serial; stats->lambda_final = (double)pf_chi;
+      stats->terminated = (int)pf_sum; stats->trials_total = (int)pf_dec;
+#endif
     }
   }
 }

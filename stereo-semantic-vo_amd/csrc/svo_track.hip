@@ -1534,6 +1534,10 @@ static void track_stream_diag(svo_ctx* ctx) {
   (void)hipGetLastError();
 }
 
+static size_t tail_lds_bytes() {
+  static const size_t v = []() { const char* e = getenv("SVO_TAIL_LDS_KB"); const size_t kb = e ? (size_t)atoi(e) : 0; return std::max(sizeof(TpTailLds), kb << 10); }();
+  return v;
+}
 // streams, events, work records and the kernels' LDS opt-ins for `frames` frames per call of `nseq` sequences
 static int track_resources(svo_ctx* ctx, int frames, int nseq) {
   if (!ctx->stream_idx) { const int rcs = track_index_stream(ctx); if (rcs) return rcs; }
@@ -1569,7 +1573,7 @@ static int track_resources(svo_ctx* ctx, int frames, int nseq) {
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_hyp_ord), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)sizeof(TpHypOrdLds)) == hipSuccess;
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_tail_ord), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)sizeof(TpTailLds)) == hipSuccess;
+                                   (int)tail_lds_bytes()) == hipSuccess;
     ctx->track_lds_state = ok ? 1 : -1;
     if (!ok) ctx->last_error = std::string("hipFuncSetAttribute(tracker kernels): ") + hipGetErrorString(hipGetLastError());
   }
@@ -1679,7 +1683,7 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
       // (depth_source 1 / 2): a fused launch's sample workgroups carry the frame part's 67 KB of LDS and three idle waves each,
       // which the dense kernels running on the same CUs pay for (configs[4]: 6.05 k frames/s fused, 6.85 k with two launches)
       SvoTimer t(ctx, "k_tp_tail_ord");
-      hipLaunchKernelGGL(k_tp_tail_ord, dim3(PNP_HYP + 1, 1), dim3(TPF_NT), sizeof(TpTailLds), s0, st, work + f, kpf, depf, ctx->d_pnp_subsets,
+      hipLaunchKernelGGL(k_tp_tail_ord, dim3(PNP_HYP + 1, 1), dim3(TPF_NT), tail_lds_bytes(), s0, st, work + f, kpf, depf, ctx->d_pnp_subsets,
                          d_res + f, kstride, ctx->opt_pose_mfma, tag_of(f), ctx->opt_epnp_force_seq | (ctx->opt_debug_lose_sample << 8));
       return;
     }

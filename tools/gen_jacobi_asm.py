@@ -12,6 +12,11 @@ result.
 Registers: the block owns v140..v253 and s60..s71 (clobbers); the row (x0, x1, x2) lives in v150..v155 while the loop runs.
 """
 
+import os
+LOOP_ALIGN = int(os.environ.get("JACOBI_LOOP_ALIGN", "6"))    # log2 bytes
+LOOP_NOPS = int(os.environ.get("JACOBI_LOOP_NOPS", "0"))      # 4-byte s_nops between the alignment and the loop's first instruction
+
+
 # ---- fixed registers -------------------------------------------------------------------------------------------------
 def pair(lo):
     return "v[%d:%d]" % (lo, lo + 1)
@@ -165,6 +170,9 @@ def program(M):
     a("s_cmp_lg_u64 %s, 0" % ACT)
     a("s_cbranch_scc0 L_done_%=")
     # ---- the step loop
+    a(".p2align %d" % LOOP_ALIGN)                    # the loop's address relative to the fetch lines must not depend on the code in front of it
+    for _ in range(LOOP_NOPS):
+        a("s_nop 0")
     a("L_loop_%=:")
     a("s_waitcnt lgkmcnt(2)")                      # the entry requested a step ago has arrived
     a("v_mov_b32 %s, %s" % (v(E1), v(E2)))

@@ -181,11 +181,11 @@ int svo_create(svo_ctx** out, int device, int W, int H, int max_kp, int max_batc
 int svo_create_ex(svo_ctx** out, int device, int W, int H, int max_kp, int max_batch, uint32_t flags);
 int svo_stream_mode(const svo_ctx* ctx);
 void svo_destroy(svo_ctx* ctx);
-/* Tuning switches.  "pose_mfma" (0..2, default 2): how svo_pose_opt and the tracker's pose optimisation add up the edges' terms of
+/* Tuning switches.  "pose_mfma" (0..2, default 1): how svo_pose_opt and the tracker's pose optimisation add up the edges' terms of
  * H = J^T W J, b = -J^T W e and chi2 - always in the edges' insertion order, each addition rounded (g2o's loops,
- * base_unary_edge.hpp:43-72): 2 one lane per quantity with plain additions, 1 four edges per v_mfma_f64_4x4x4_4b_f64 (A = 1.0: an
- * in-order sum; measured slower - a dependent DMFMA takes ~120 cycles, a dependent add 8), 0 one lane for everything (the CPU loop
- * as it stands).  Identical bits in all three, and identical to the CPU restatement.
+ * base_unary_edge.hpp:43-72): 1 four edges per v_mfma_f64_4x4x4_4b_f64 (A = 1.0: an in-order sum of the four lane groups' values),
+ * 2 one lane per quantity with plain additions, 0 one lane for everything (the CPU loop as it stands).  Identical bits in all
+ * three, and identical to the CPU restatement.
  * "fast_cand_cap" (default 2048, the maximum): length of the per-tile list of scored pixels in the FAST kernel; tiles
  * with more fall back to scanning the score tile - same results, the switch exists so that tests can force that path.
  * "track_lcap" (default 8, the maximum): claimable keypoints (Hamming distance < 30) a map point keeps as packed

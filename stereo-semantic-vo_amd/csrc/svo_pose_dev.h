@@ -37,6 +37,21 @@ __device__ __forceinline__ double pose_ndiv(double a, double b) {   // a / b
   const double rem = __builtin_fma(-b, q, a);
   return __builtin_fma(rem, r, q);
 }
+// a / b for several a and one b: the refined reciprocal depends on b only (pose_ndiv's first five instructions), the last three
+// are per dividend - the same instructions per quotient as pose_ndiv, hence the same bits
+__device__ __forceinline__ double pose_rcp_refined(double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+}
+__device__ __forceinline__ double pose_ndiv_r(double a, double b, double r) {   // a / b, r = pose_rcp_refined(b)
+  const double q = a * r;
+  const double rem = __builtin_fma(-b, q, a);
+  return __builtin_fma(rem, r, q);
+}
 __device__ __forceinline__ double pose_nsqrt(double x) {   // sqrt(x), x >= 0
   if (!(x > 0.0)) return 0.0;
   const double y = __builtin_amdgcn_rsq(x);
@@ -117,7 +132,8 @@ __device__ __forceinline__ void quat_from_R(const double m[9], double q[4]) {
 __device__ __forceinline__ void normalize_rotation(Se3& s) {
   if (s.q[3] < 0) { s.q[0] = -s.q[0]; s.q[1] = -s.q[1]; s.q[2] = -s.q[2]; s.q[3] = -s.q[3]; }
   const double n = pose_nsqrt(s.q[0] * s.q[0] + s.q[1] * s.q[1] + s.q[2] * s.q[2] + s.q[3] * s.q[3]);
-  s.q[0] = pose_ndiv(s.q[0], n); s.q[1] = pose_ndiv(s.q[1], n); s.q[2] = pose_ndiv(s.q[2], n); s.q[3] = pose_ndiv(s.q[3], n);
+  const double rn = pose_rcp_refined(n);
+  s.q[0] = pose_ndiv_r(s.q[0], n, rn); s.q[1] = pose_ndiv_r(s.q[1], n, rn); s.q[2] = pose_ndiv_r(s.q[2], n, rn); s.q[3] = pose_ndiv_r(s.q[3], n, rn);
 }
 __device__ __forceinline__ void quat_mul(const double a[4], const double b[4], double o[4]) {
   const double w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
@@ -201,13 +217,13 @@ __device__ void se3_oplus(const double u[6], Se3& est) {
 }
 __device__ __forceinline__ void huber(double e, double delta, double dsqr, double& rho0, double& rho1) {
   if (e <= dsqr) { rho0 = e; rho1 = 1.; }
-  else { const double sq = sqrt(e); rho0 = 2 * sq * delta - dsqr; rho1 = delta / sq; }
+  else { const double sq = pose_nsqrt(e); rho0 = 2 * sq * delta - dsqr; rho1 = pose_ndiv(delta, sq); }
 }
 // 6x6 LDL^T solve, fully unrolled so L, D and y stay in registers (dynamically indexed local arrays
 // would be placed in scratch memory, and this sits on the serial path of every LM / RANSAC step).
 // Returns 0 if a pivot is not positive (Eigen LDLT::isPositive() false).
 __device__ __forceinline__ int ldlt6_solve(const double* Hin, const double* b, double* x) {
-  double L[6][6], D[6], y[6];
+  double L[6][6], D[6], Dr[6], y[6];
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -217,6 +233,8 @@ __device__ __forceinline__ int ldlt6_solve(const double* Hin, const double* b, d
       if (k < j) d -= L[j][k] * L[j][k] * D[k];
     ok = ok && (d > 0.0);
     D[j] = d;
+    const double dr = pose_rcp_refined(d);     // (one refined reciprocal per pivot: every division by it shares it)
+    Dr[j] = dr;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       if (i > j) {
@@ -224,7 +242,7 @@ __device__ __forceinline__ int ldlt6_solve(const double* Hin, const double* b, d
 #pragma unroll
         for (int k = 0; k < 6; ++k)
           if (k < j) sacc -= L[i][k] * L[j][k] * D[k];
-        L[i][j] = pose_ndiv(sacc, d);
+        L[i][j] = pose_ndiv_r(sacc, d, dr);
       }
     }
   }
@@ -238,7 +256,7 @@ __device__ __forceinline__ int ldlt6_solve(const double* Hin, const double* b, d
     y[i] = sacc;
   }
 #pragma unroll
-  for (int i = 0; i < 6; ++i) y[i] = pose_ndiv(y[i], D[i]);
+  for (int i = 0; i < 6; ++i) y[i] = pose_ndiv_r(y[i], D[i], Dr[i]);
   double xs[6];
 #pragma unroll
   for (int i = 5; i >= 0; --i) {
@@ -252,15 +270,21 @@ __device__ __forceinline__ int ldlt6_solve(const double* Hin, const double* b, d
   for (int i = 0; i < 6; ++i) x[i] = xs[i];
   return 1;
 }
+// error and Jacobian of one edge (types_six_dof_expmap.h:153-157, .cpp:266-288).  The three divisions by the point's depth - x / z,
+// y / z in the error, 1 / z in the Jacobian - share ONE refined reciprocal (pose_ndiv_r: the compiler's division without its
+// range scaling, bit-identical for a depth a few hundred binades inside the range; a depth of exactly 0 gives NaN where IEEE
+// gives infinity - either way the LM rejects every trial and keeps its pose).
 __device__ __forceinline__ void edge_error(const Se3& est, const double* Xw, const double* obs,
-                                           const double* K, double e[2], double pc[3]) {
+                                           const double* K, double e[2], double pc[3], double* rz_out = nullptr) {
   quat_rot(est.q, Xw, pc);
   pc[0] += est.t[0]; pc[1] += est.t[1]; pc[2] += est.t[2];
-  e[0] = obs[0] - (pc[0] / pc[2] * K[0] + K[2]);
-  e[1] = obs[1] - (pc[1] / pc[2] * K[1] + K[3]);
+  const double rz = pose_rcp_refined(pc[2]);
+  e[0] = obs[0] - (pose_ndiv_r(pc[0], pc[2], rz) * K[0] + K[2]);
+  e[1] = obs[1] - (pose_ndiv_r(pc[1], pc[2], rz) * K[1] + K[3]);
+  if (rz_out) *rz_out = rz;
 }
-__device__ __forceinline__ void edge_jacobian(const double pc[3], const double* K, double J[12]) {
-  const double x = pc[0], y = pc[1], invz = 1.0 / pc[2], invz_2 = invz * invz;
+__device__ __forceinline__ void edge_jacobian(const double pc[3], const double* K, double J[12], double rz) {
+  const double x = pc[0], y = pc[1], invz = pose_ndiv_r(1.0, pc[2], rz), invz_2 = invz * invz;
   J[0] = x * y * invz_2 * K[0];
   J[1] = -(1 + (x * x * invz_2)) * K[0];
   J[2] = y * invz * K[0];
@@ -283,28 +307,24 @@ __device__ __forceinline__ void edge_jacobian(const double pc[3], const double* 
 __device__ __forceinline__ double pose_gsum(double term, double acc) { return __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, term, acc, 0, 0, 0); }
 
 // `cnt` values per column (value e of this lane's column at p[e * pitch]), added to `acc` in order, four per MFMA (lane group g
-// supplies value 4 s + g at step s).  Sixteen steps at a time: their sixteen LDS loads are issued together, THEN the dependent chain
-// of MFMAs runs - a load in front of every MFMA cost 165 cycles per step instead of ~25 (measured, tools/lm_phases.py).
-// Values beyond the count, and whole columns with `col_on` false, enter as +0.0, which leaves every partial sum as it is.
-__device__ __forceinline__ double pose_chain_sum(const double* p, int pitch, int cnt, bool col_on, int g, double acc) {
-  for (int s0 = 0; 4 * s0 < cnt; s0 += 8) {      // (one uniform branch per eight steps; the padding steps add +0.0)
-    double v[8];
+// supplies value 4 s + g at step s).  Four steps at a time: their LDS loads are issued together, THEN the dependent MFMAs run;
+// no per-step branches or selects (a load + a branch in front of every MFMA cost 165 cycles per step instead of ~40: measured,
+// tools/lm_phases.py).  The caller has ZERO-FILLED the values from `cnt` up to the next multiple of 16 and the columns that carry
+// no quantity: adding +0.0 leaves every partial sum as it is.
+__device__ __forceinline__ double pose_chain_sum(const double* p, int pitch, int cnt, int g, double acc) {
+  for (int s0 = 0; 4 * s0 < cnt; s0 += 4) {      // (one uniform branch per four steps = sixteen values; the caller zero-filled up to there)
+    double v[4];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int e = 4 * (s0 + s) + g;
-      const double x = p[min(e, cnt - 1) * pitch];
-      v[s] = (e < cnt && col_on) ? x : 0.0;
-    }
+    for (int s = 0; s < 4; ++s) v[s] = p[(4 * (s0 + s) + g) * pitch];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) acc = pose_gsum(v[s], acc);
+    for (int s = 0; s < 4; ++s) acc = pose_gsum(v[s], acc);
   }
   return acc;
 }
 
 // The same sum by plain additions, ONE LANE PER COLUMN: the lane adds its column's values one after the other (loads sixteen at a
-// time, then sixteen dependent v_add_f64).  A dependent f64 add issues every 8 cycles, a dependent 4x4x4 DMFMA every ~120
-// (tools/lm_phases.py: 2.0 k cycles for 64 values against 0.6 k) - with the values in LDS anyway the matrix core has nothing to
-// offer here; it stays as an option and as a second witness of the order ("pose_mfma" = 1).
+// time, then sixteen dependent v_add_f64: ~16 cycles per value for a lone wave against ~10 per value on the matrix core, which
+// takes four values per dependent step) - "pose_mfma" = 2, the second witness of the order.
 // The caller has ZERO-FILLED the values from `cnt` up to the next multiple of 16 (adding +0.0 changes nothing): no clamping,
 // no selects - per value half a two-value LDS load and the addition (a lone wave issues an instruction every ~4.4 cycles, and
 // with address arithmetic and selects per value the chain took 44 cycles per value instead of ~9).
@@ -362,11 +382,11 @@ __device__ __forceinline__ void edge_terms(const double J[12], const double e[2]
 template <int W>
 __device__ __forceinline__ void edge_wave_terms(const Se3& est, const double* Xw, const double* obs, int i, const double* K,
                                                 double delta, double dsqr, double t[POSE_QW]) {
-  double e[2], pc[3], J[12];
-  edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc);
+  double e[2], pc[3], J[12], rz;
+  edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc, &rz);
   double rho0 = e[0] * e[0] + e[1] * e[1], rho1 = 1.;
   huber(rho0, delta, dsqr, rho0, rho1);
-  edge_jacobian(pc, K, J);
+  edge_jacobian(pc, K, J, rz);
   edge_terms<W>(J, e, rho0, rho1, t);
 }
 // wave W's terms of the edges e0 + lane and (TWO) e0 + 64 + lane into its slab: straight-line code for both edges (indices clamped,
@@ -378,12 +398,13 @@ __device__ __forceinline__ void wave_terms_to_lds(const Se3& est, const double* 
   double tA[POSE_QW], tB[POSE_QW];
   edge_wave_terms<W>(est, Xw, obs, min(iA, n - 1), K, delta, dsqr, tA);
   if (TWO) edge_wave_terms<W>(est, Xw, obs, min(iB, n - 1), K, delta, dsqr, tB);
-  // (every lane stores: rows beyond the last edge hold +0.0 - pose_lane_sum adds whole groups of sixteen rows)
+  // (every lane stores: rows beyond the last edge hold +0.0 - the sums run over whole groups of sixteen rows -, and so do the two
+  // padding columns of every row, which the matrix-core sum's idle columns read)
 #pragma unroll
-  for (int q = 0; q < POSE_QW; ++q) tw[lane * POSE_TW + q] = iA < n ? tA[q] : 0.0;
+  for (int q = 0; q < POSE_TW; ++q) tw[lane * POSE_TW + q] = (q < POSE_QW && iA < n) ? tA[q < POSE_QW ? q : 0] : 0.0;
   if (TWO) {
 #pragma unroll
-    for (int q = 0; q < POSE_QW; ++q) tw[(64 + lane) * POSE_TW + q] = iB < n ? tB[q] : 0.0;
+    for (int q = 0; q < POSE_TW; ++q) tw[(64 + lane) * POSE_TW + q] = (q < POSE_QW && iB < n) ? tB[q < POSE_QW ? q : 0] : 0.0;
   }
 }
 
@@ -416,7 +437,7 @@ __device__ __forceinline__ void build_system_ordered(const Se3& est, const doubl
       }
     }
     POSE_WSYNC();
-    if (on_mfma) acc = pose_chain_sum(tw + min(c, POSE_QW - 1), POSE_TW, cnt, c < POSE_QW, g, acc);
+    if (on_mfma) acc = pose_chain_sum(tw + min(c, POSE_TW - 1), POSE_TW, cnt, g, acc);   // columns 0..6: quantities; 7, 8 (and the lanes clamped onto 8): zeros
     else acc = pose_lane_sum(tw + min(lane, POSE_QW - 1), POSE_TW, cnt, acc);      // lanes 0..6: one quantity each
     POSE_WSYNC();                         // (the slab is rewritten by the next chunk)
   }
@@ -424,20 +445,6 @@ __device__ __forceinline__ void build_system_ordered(const Se3& est, const doubl
   __syncthreads();
 }
 
-// robust chi2 at `est`, the sum over the edges in order (sparse_optimizer.cpp:100-114): every lane its edges' rho into chi[],
-// then wave 0 adds them four per MFMA (column 0).  Returns the sum in every lane of wave 0 (other waves: undefined).
-__device__ __forceinline__ double chi2_ordered_wave0(const double* chi, int n, bool on_mfma) {
-  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-  if (!on_mfma) return pose_lane_sum(chi, 1, n, 0.0);      // (every lane the same sum: lane 0 uses it)
-  return pose_chain_sum(chi, 1, n, c == 0, g, 0.0);
-}
-__device__ __forceinline__ double edge_rho(const Se3& est, const double* Xw, const double* obs, int i, const double* K, double delta, double dsqr) {
-  double e[2], pc[3];
-  edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc);
-  double rho0 = e[0] * e[0] + e[1] * e[1], rho1;
-  huber(rho0, delta, dsqr, rho0, rho1);
-  return rho0;
-}
 __device__ __forceinline__ void unpack_system(const double* red, double H[36], double b[6]) {
   int k = 0;
 #pragma unroll
@@ -449,10 +456,8 @@ __device__ __forceinline__ void unpack_system(const double* red, double H[36], d
 }
 
 struct LmShared {
-  Se3 est;       // current estimate (all threads read)
-  Se3 backup;
-  double x[6];
-  int go;        // 1: evaluate trial chi2 ; 0: iteration finished
+  Se3 est;       // the estimate the next system is built at (all threads read)
+  int go;        // 1: another trial ; 0: iteration finished
   int done;
 };
 
@@ -462,16 +467,45 @@ struct LmShared {
 // LDS workspace of the pose-only LM
 struct PoseLds {
   double tw[4 * POSE_CHUNK * POSE_TW];   // per wave: the terms of a chunk of edges
-  double chi[POSE_MAXN];         // per edge: rho of the trial pose
   double red[POSE_NQ + 4];
   LmShared sh;
   double K[4];
 };
 
+// the normal equations at `est` into red[] by ONE lane, edge by edge as the CPU loop stands (the checker of build_system_ordered)
+__device__ __forceinline__ void build_system_one_lane(const Se3& est, const double* Xw, const double* obs, int n, const double* K,
+                                                      double delta, double dsqr, double* red) {
+  if (threadIdx.x == 0) {
+    double acc[POSE_NQ];
+    for (int k = 0; k < POSE_NQ; ++k) acc[k] = 0.0;
+    for (int i = 0; i < n; ++i) {
+      double e[2], pc[3], J[12], rz;
+      edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc, &rz);
+      double rho0 = e[0] * e[0] + e[1] * e[1], rho1 = 1.;
+      huber(rho0, delta, dsqr, rho0, rho1);
+      edge_jacobian(pc, K, J, rz);
+      int k = 0;
+      for (int r = 0; r < 6; ++r)
+        for (int c = r; c < 6; ++c) acc[k++] += rho1 * (J[r] * J[c] + J[6 + r] * J[6 + c]);
+      for (int r = 0; r < 6; ++r) acc[21 + r] -= rho1 * (J[r] * e[0] + J[6 + r] * e[1]);
+      acc[27] += rho0;
+    }
+    for (int k = 0; k < POSE_NQ; ++k) red[k] = acc[k];
+  }
+  __syncthreads();
+}
+
 // Pose-only LM, called by all NT = 256 threads of the workgroup.  T: row-major 4x4 in/out (global or LDS); stats may be null.
-// use_ordered_mfma (svo_set_option "pose_mfma"): 2 (default) the sums over the edges by one lane per quantity, plain additions in
-// order; 1 the same sums on the matrix core (v_mfma_f64_4x4x4, A = 1: four edges per instruction - slower, see pose_lane_sum);
-// 0 everything by ONE lane, edge by edge as the CPU loop stands (the checker).  Identical bits in all three.
+// use_ordered_mfma (svo_set_option "pose_mfma"): 1 (default) the sums over the edges on the matrix core (v_mfma_f64_4x4x4, A = 1:
+// four edges per dependent step); 2 the same sums by one lane per quantity, plain additions in order (a little slower); 0 everything
+// by ONE lane, edge by edge as the CPU loop stands (the checker).  Identical bits in all three.
+//
+// Schedule.  g2o evaluates the robust chi2 of a trial with a pass of its own (sparse_optimizer.cpp:100-114) and rebuilds the
+// normal equations at the top of the next iteration (buildSystem) - at the SAME estimate whenever the LM goes on, because it
+// only goes on after an accepted trial.  Both passes visit the same edges with the same operations, and chi2 is one of the 28
+// ordered sums of the build; so here every trial builds the whole system at its estimate: its chi2 entry IS the trial's chi2
+// (same values, same order: same bits), and an accepted trial's system IS the next iteration's - one pass over the edges per
+// trial instead of two, on all four waves.  The scalar LM state (lambda, the pose, H, b) lives in thread 0's registers.
 template <int NT = 256>
 __device__ __forceinline__ void pose_opt_block(PoseLds& L, const double* __restrict__ Xw, const double* __restrict__ obs, int n,
                                                const double* __restrict__ Kp, double* T, svo_lm_stats* stats,
@@ -483,19 +517,19 @@ __device__ __forceinline__ void pose_opt_block(PoseLds& L, const double* __restr
   const double dsqr = delta * delta;
   __syncthreads();
   if (tid < 4) K[tid] = Kp[tid];
+  Se3 est0{};                 // thread 0: the current estimate
   if (tid == 0) {
     if (round_in_f32) {  // the reference stores the PnP pose as CV_32F before optimising it
       double Tf[16];
       for (int j = 0; j < 16; ++j) Tf[j] = (double)(float)T[j];
-      se3_from_T(Tf, sh.est);
+      se3_from_T(Tf, est0);
     } else {
-      se3_from_T(T, sh.est);
+      se3_from_T(T, est0);
     }
-    for (int j = 0; j < 6; ++j) sh.x[j] = 0;
+    sh.est = est0;
     sh.done = 0;
   }
   __syncthreads();
-  // scalar LM state lives in thread 0's registers
   double lambda = -1., ni = 2., currentChi = 0, chi_init = 0;
   int nBad = 0, iters = 0, trials_total = 0, terminated = 0;
   if (n <= 0) {
@@ -505,130 +539,78 @@ __device__ __forceinline__ void pose_opt_block(PoseLds& L, const double* __restr
     }
     return;
   }
-  // With at most 128 edges (a tracked frame has ~64) wave 0 runs a trial alone - proposal, the edges' chi2 (one or two per lane),
-  // their ordered sum, the accept / reject logic - with wave-local synchronisation; the other waves wait at ONE barrier per iteration.
-  const bool one_wave_trials = n <= 128;
 #ifdef POSE_PROF
-  long long pf_build = 0, pf_serial = 0, pf_chi = 0, pf_sum = 0, pf_dec = 0, pf_t = 0;
+  long long pf_build = 0, pf_serial = 0, pf_dec = 0, pf_t = 0;
 #define PF(acc) do { const long long _n = clock64(); acc += _n - pf_t; pf_t = _n; } while (0)
   pf_t = clock64();
 #else
 #define PF(acc) do { } while (0)
 #endif
-  for (int it = 0; it < 10; ++it) {
+  auto build = [&]() {        // the system at sh.est into red[] (ends with a barrier)
     const Se3 est = sh.est;
-    PF(pf_dec);
-    if (use_ordered_mfma) {
-      build_system_ordered(est, Xw, obs, n, K, delta, dsqr, L.tw, red, use_ordered_mfma == 1);
-    } else {
-      if (tid == 0) {   // the checker: one lane, the CPU loop as it stands
-        double acc[POSE_NQ];
-        for (int k = 0; k < POSE_NQ; ++k) acc[k] = 0.0;
-        for (int i = 0; i < n; ++i) {
-          double e[2], pc[3], J[12];
-          edge_error(est, Xw + 3 * i, obs + 2 * i, K, e, pc);
-          double rho0 = e[0] * e[0] + e[1] * e[1], rho1 = 1.;
-          huber(rho0, delta, dsqr, rho0, rho1);
-          edge_jacobian(pc, K, J);
-          int k = 0;
-          for (int r = 0; r < 6; ++r)
-            for (int c = r; c < 6; ++c) acc[k++] += rho1 * (J[r] * J[c] + J[6 + r] * J[6 + c]);
-          for (int r = 0; r < 6; ++r) acc[21 + r] -= rho1 * (J[r] * e[0] + J[6 + r] * e[1]);
-          acc[27] += rho0;
-        }
-        for (int k = 0; k < POSE_NQ; ++k) red[k] = acc[k];
+    if (use_ordered_mfma) build_system_ordered(est, Xw, obs, n, K, delta, dsqr, L.tw, red, use_ordered_mfma == 1);
+    else build_system_one_lane(est, Xw, obs, n, K, delta, dsqr, red);
+  };
+  build();
+  PF(pf_build);
+  double H[36], b[6], x[6] = {0, 0, 0, 0, 0, 0};
+  if (tid == 0) {
+    unpack_system(red, H, b);
+    currentChi = red[27];
+    chi_init = currentChi;
+    double maxDiag = 0;
+    for (int j = 0; j < 6; ++j) maxDiag = fmax(fabs(H[7 * j]), maxDiag);
+    lambda = 1e-5 * maxDiag;
+  }
+  for (int it = 0; it < 10; ++it) {
+    double iniChi = currentChi, rho = 0;
+    int qmax = 0;
+    for (int trial = 0; trial < 10; ++trial) {
+      int ok2 = 0;
+      if (tid == 0) {
+        double Hl[36];
+#pragma unroll
+        for (int j = 0; j < 36; ++j) Hl[j] = H[j];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) Hl[7 * j] += lambda;
+        ok2 = ldlt6_solve(Hl, b, x);          // (x keeps its old value when a pivot is not positive)
+        Se3 e2 = est0;
+        se3_oplus(x, e2);
+        sh.est = e2;                          // the trial estimate
       }
       __syncthreads();
-    }
-    PF(pf_build);
-    double H[36], b[6], iniChi = 0, rho = 0;
-    int qmax = 0;
-    if (tid == 0) {
-      unpack_system(red, H, b);
-      currentChi = red[27];
-      iniChi = currentChi;
-      if (it == 0) {
-        chi_init = currentChi;
-        double maxDiag = 0;
-        for (int j = 0; j < 6; ++j) maxDiag = fmax(fabs(H[7 * j]), maxDiag);
-        lambda = 1e-5 * maxDiag;
-        ni = 2;
-        nBad = 0;
-      }
-    }
-    // inner trial loop: thread 0 proposes, the edges' chi2 is evaluated in parallel and summed in order
-    if (tid < 64 || !one_wave_trials) {
-      for (int trial = 0; trial < 10; ++trial) {
-        int ok2 = 0;
-        if (tid == 0) {
-          sh.backup = sh.est;
-          double Hl[36];
-#pragma unroll
-          for (int j = 0; j < 36; ++j) Hl[j] = H[j];
-#pragma unroll
-          for (int j = 0; j < 6; ++j) Hl[7 * j] += lambda;
-          double xloc[6];
-#pragma unroll
-          for (int j = 0; j < 6; ++j) xloc[j] = sh.x[j];
-          ok2 = ldlt6_solve(Hl, b, xloc);
-#pragma unroll
-          for (int j = 0; j < 6; ++j) sh.x[j] = xloc[j];
-          Se3 e2 = sh.est;
-          se3_oplus(xloc, e2);
-          sh.est = e2;
-        }
-        if (one_wave_trials) POSE_WSYNC(); else __syncthreads();
-        PF(pf_serial);
-        const Se3 trial_est = sh.est;
-        if (one_wave_trials) {      // one or two edges per lane, straight-line (clamped indices, masked stores)
-          // (entries beyond the last edge: +0.0, see pose_lane_sum)
-          const double rA = edge_rho(trial_est, Xw, obs, min(tid, n - 1), K, delta, dsqr);
-          L.chi[tid] = tid < n ? rA : 0.0;
-          if (n > 64) {
-            const double rB = edge_rho(trial_est, Xw, obs, min(tid + 64, n - 1), K, delta, dsqr);
-            L.chi[tid + 64] = tid + 64 < n ? rB : 0.0;
-          }
+      PF(pf_serial);
+      build();                                // chi2 of the trial = red[27]; its system = the next iteration's if it is accepted
+      PF(pf_build);
+      if (tid == 0) {
+        double tempChi = red[27];
+        if (!ok2) tempChi = 1.7976931348623157e308;
+        rho = currentChi - tempChi;
+        double scale = 0;
+        for (int j = 0; j < 6; ++j) scale += x[j] * (lambda * x[j] + b[j]);
+        scale += 1e-3;
+        rho /= scale;
+        if (rho > 0 && isfinite(tempChi)) {
+          const double v = 2 * rho - 1;
+          double alpha = 1. - v * v * v;
+          alpha = fmin(alpha, 2. / 3.);
+          const double scaleFactor = fmax(1. / 3., alpha);
+          lambda *= scaleFactor;
+          ni = 2;
+          currentChi = tempChi;
+          est0 = sh.est;                      // accepted: the trial estimate and its system take over
+          unpack_system(red, H, b);
         } else {
-          for (int i = tid; i < ((min(n, POSE_MAXN) + 15) & ~15); i += NT) L.chi[i] = i < n ? edge_rho(trial_est, Xw, obs, i, K, delta, dsqr) : 0.0;
+          lambda *= ni;
+          ni *= 2;
         }
-        if (one_wave_trials) POSE_WSYNC(); else __syncthreads();
-        PF(pf_chi);
-        double tempChi = 0;
-        if (tid < 64) {
-          if (n <= POSE_MAXN && use_ordered_mfma) {
-            tempChi = chi2_ordered_wave0(L.chi, n, use_ordered_mfma == 1);
-          } else if (tid == 0) {      // more edges than chi[] holds (stand-alone svo_pose_opt only), or the checker: one lane, in order
-            for (int i = 0; i < n; ++i) tempChi += n <= POSE_MAXN ? L.chi[i] : edge_rho(trial_est, Xw, obs, i, K, delta, dsqr);
-          }
-        }
-        PF(pf_sum);
-        if (tid == 0) {
-          if (!ok2) tempChi = 1.7976931348623157e308;
-          rho = currentChi - tempChi;
-          double scale = 0;
-          for (int j = 0; j < 6; ++j) scale += sh.x[j] * (lambda * sh.x[j] + b[j]);
-          scale += 1e-3;
-          rho /= scale;
-          if (rho > 0 && isfinite(tempChi)) {
-            const double v = 2 * rho - 1;
-            double alpha = 1. - v * v * v;
-            alpha = fmin(alpha, 2. / 3.);
-            const double scaleFactor = fmax(1. / 3., alpha);
-            lambda *= scaleFactor;
-            ni = 2;
-            currentChi = tempChi;
-          } else {
-            lambda *= ni;
-            ni *= 2;
-            sh.est = sh.backup;
-          }
-          ++qmax;
-          ++trials_total;
-          sh.go = (rho < 0 && qmax < 10) ? 1 : 0;
-        }
-        if (one_wave_trials) POSE_WSYNC(); else __syncthreads();
-        if (!sh.go) break;
+        ++qmax;
+        ++trials_total;
+        sh.go = (rho < 0 && qmax < 10) ? 1 : 0;
       }
+      __syncthreads();
+      PF(pf_dec);
+      if (!sh.go) break;
     }
     if (tid == 0) {
       ++iters;
@@ -645,14 +627,13 @@ __device__ __forceinline__ void pose_opt_block(PoseLds& L, const double* __restr
     if (sh.done) break;
   }
   if (tid == 0) {
-    se3_to_T(sh.est, T);
+    se3_to_T(est0, T);
     if (stats) {
       stats->n_edges = n; stats->iterations = iters; stats->trials_total = trials_total;
       stats->terminated = terminated; stats->chi2_initial = chi_init;
       stats->chi2_final = currentChi; stats->lambda_final = lambda;
 #ifdef POSE_PROF
-      stats->chi2_initial = (double)pf_build; stats->chi2_final = (double)pf_serial; stats->lambda_final = (double)pf_chi;
-      stats->terminated = (int)pf_sum; stats->trials_total = (int)pf_dec;
+      stats->chi2_initial = (double)pf_build; stats->chi2_final = (double)pf_serial; stats->lambda_final = (double)pf_dec;
 #endif
     }
   }

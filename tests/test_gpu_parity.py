@@ -594,9 +594,9 @@ def test_invalid_arguments_are_rejected(pkg, svo_small):
 # ---- MFMA variant of the J^T W J accumulation ------------------------------------------------------
 @pytest.mark.parametrize("seed,n", [(7, 500), (8, 37), (9, 5), (10, 1), (11, 512), (17, 130)])
 def test_pose_opt_matrix_core_sums_equal_the_one_lane_loop(pkg, orc, seed, n):
-    """svo_set_option("pose_mfma"): 2 (default) - the sums over the edges by one lane per quantity, plain additions in order; 1 -
-    four edges at a time on v_mfma_f64_4x4x4 (A = 1.0: an in-order IEEE sum); 0 - the whole loop walked by ONE lane, edge by edge
-    (the checker).  All three bitwise equal to the CPU restatement."""
+    """svo_set_option("pose_mfma"): 1 (default) - the sums over the edges four at a time on v_mfma_f64_4x4x4 (A = 1.0: an in-order
+    IEEE sum); 2 - one lane per quantity, plain additions in order; 0 - the whole loop walked by ONE lane, edge by edge (the
+    checker).  All three bitwise equal to the CPU restatement."""
     Xw, obs, K, _ = util.pose_problem(seed, n=n, outlier_frac=0.3)
     svo = pkg.Svo(640, 240)
     T0 = np.eye(4)

@@ -801,6 +801,108 @@ def host_feed_leg(pkg, cam, dL, dR, dev, local, res_ref, B, calls=12, warm=2):
     return out
 
 
+
+class Cotenant:
+    """Another GPU user of the process beside the tracker (the reference runs its detector on a thread of its own, src/semantic.cc:13-45):
+    a host thread that keeps ~1 ms kernels (a float32 matrix product) running back to back on `where` = "null" (the NULL stream, what a
+    library that knows nothing of streams uses - torch's default stream) or "pooled" (a non-blocking stream of its own)."""
+
+    def __init__(self, dev, where):
+        import torch
+        self.torch, self.dev, self.where = torch, dev, where
+        self.a = torch.randn((3072, 3072), device=dev)
+        self.stream = None if where == "null" else torch.cuda.Stream(device=dev)
+        self.stop = threading.Event()
+        self.launches = 0
+        self.thread = threading.Thread(target=self.run, daemon=True)
+
+    def run(self):
+        torch = self.torch
+        ev = torch.cuda.Event()
+        while not self.stop.is_set():
+            if self.stream is None:
+                torch.mm(self.a, self.a)
+                ev.record()
+            else:
+                with torch.cuda.stream(self.stream):
+                    torch.mm(self.a, self.a)
+                    ev.record(self.stream)
+            ev.synchronize()                 # one kernel in flight at a time: a loop, not a flood
+            self.launches += 1
+
+    def __enter__(self):
+        self.thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop.set()
+        self.thread.join()
+
+
+def cotenant_leg(pkg, cam, dL, dR, dev, local, res_ref, B, calls=6, warm=1):
+    """The headline tracker (svo_track_batch_dev, B frames per call) while another component of the process keeps the GPU busy - on the
+    NULL stream, then on a non-blocking stream of its own - for a context with the default dedicated (blocking) queues and for one
+    with pooled non-blocking streams; and two independent trackers (two contexts, two host threads) on the one GPU.  Rates are
+    what they are (the co-tenant's kernels fill every CU); the records must not change."""
+    import numpy as np
+    import torch
+    n = min(B * calls, int(dL.shape[0]))
+    calls = n // B
+    rec = pkg.TRACK_DTYPE.itemsize
+    fb = H * PITCH
+
+    def track(flags, out=None, first=0):
+        ctx = pkg.Svo(W, H, device=local, max_kp=500, max_batch=B, flags=flags)
+        ctx.track_reset(cam)
+        res = torch.zeros((n, rec), dtype=torch.uint8, device=dev)
+        for c in range(warm):
+            ctx.track_batch_dev(dL.data_ptr() + (first + c * B) * fb, dR.data_ptr() + (first + c * B) * fb, PITCH, B, res.data_ptr() + c * B * rec)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for c in range(warm, calls):
+            ctx.track_batch_dev(dL.data_ptr() + (first + c * B) * fb, dR.data_ptr() + (first + c * B) * fb, PITCH, B, res.data_ptr() + c * B * rec)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        ctx.close()
+        r = res.cpu().numpy()
+        if out is not None:
+            out.append(((calls - warm) * B / dt, r))
+        return (calls - warm) * B / dt, r
+
+    out = {"frames_per_call": int(B), "calls_timed": int(calls - warm), "unit": "stereo frames/s",
+           "cotenant": "a host thread running 3072^3 float32 matrix products (~1 ms each) back to back, one in flight at a time"}
+    want = res_ref[:n].tobytes() if res_ref is not None else None
+    same = True
+    for mode, flags in (("dedicated_queues", 0), ("pooled_streams", pkg.CREATE_POOLED_STREAMS)):
+        m = {}
+        v, r = track(flags)
+        m["alone"] = v
+        same = same and (want is None or r.tobytes() == want)
+        for where in ("null", "pooled"):
+            with Cotenant(dev, where) as ct:
+                time.sleep(0.05)
+                v, r = track(flags)
+            m["beside_%s_stream_cotenant" % where] = v
+            m["cotenant_kernels_%s" % where] = ct.launches
+            same = same and (want is None or r.tobytes() == want)
+        out[mode] = m
+    # two independent trackers in one process on one GPU (two contexts, two host threads): each its own sequence
+    if int(dL.shape[0]) >= 2 * n:
+        res2 = [[], []]
+        th = [threading.Thread(target=track, args=(0, res2[k], k * n)) for k in range(2)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        out["two_contexts_one_gpu"] = {"aggregate": sum(r[0][0] for r in res2), "each": [r[0][0] for r in res2],
+                                       "first_equals_the_single_tracker": bool(want is None or res2[0][0][1].tobytes() == want)}
+        same = same and out["two_contexts_one_gpu"]["first_equals_the_single_tracker"]
+    out["records_identical"] = bool(same)
+    out["value"] = out["dedicated_queues"]["beside_null_stream_cotenant"]
+    return out
+
+
 PNP_SOLVERS = {
     2: "epnp_exact=2 (default): order-preserving wave EPnP - every IEEE operation of OpenCV's solvePnPRansac/EPnP loops kept, independent "
        "ones spread over a wavefront per RANSAC sample (k-ordered sums on v_mfma_f64_4x4x4); bit-identical per sample to the CPU "
@@ -1145,6 +1247,7 @@ def main():
     ap.add_argument("--quick-legs", action="store_true", help="skip the pnp_solver_modes leg")
     ap.add_argument("--no-tail-leg-children", action="store_true", help="(kept for scripts; the child repetition now needs --leg-orders)")
     ap.add_argument("--no-host-feed-leg", action="store_true", help="skip the host_feed leg (svo_track_batch_host / svo_frontend_batch_host from host memory)")
+    ap.add_argument("--no-cotenant-leg", action="store_true", help="skip the co-tenant leg (tracker beside another GPU user of the process; two contexts on one GPU)")
     ap.add_argument("--no-shard-leg", action="store_true", help="N > 1: skip rank 0's svo_track_sharded_dev run across the N GPUs")
     ap.add_argument("--shard", action="store_true",
                     help="track workload: ONE sequence over --gpus G contexts in ONE process (svo_track_sharded_dev, BASELINE configs[3])")
@@ -1539,6 +1642,16 @@ def main():
                     out["frontend_host_feed"] = hf["frontend"]["value"]
                 except Exception as e:  # noqa: BLE001
                     out["host_feed"] = {"error": repr(e)}
+            if not args.no_cotenant_leg:
+                progress("leg cotenant")
+                try:
+                    ct = cotenant_leg(pkg, cam, dL, dR, dev, local, res, B)
+                    out["with_null_stream_cotenant"] = ct
+                    out["with_pooled_stream_cotenant"] = ct["dedicated_queues"]["beside_pooled_stream_cotenant"]
+                    if "two_contexts_one_gpu" in ct:
+                        out["two_contexts_one_gpu"] = ct["two_contexts_one_gpu"]["aggregate"]
+                except Exception as e:  # noqa: BLE001
+                    out["with_null_stream_cotenant"] = {"error": repr(e)}
             progress("leg frontend")
             out["frontend"] = frontend_leg(pkg, cam, dL, dR, n_frames, frame_bytes, dev,
                                            None if args.no_cpu_baseline else cpu_baseline_all_cores)

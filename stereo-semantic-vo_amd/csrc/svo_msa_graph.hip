@@ -57,6 +57,7 @@ class EdgeHeaps {
     for (;;) {
       if (!a || !b) { a += b; break; }
       if (node_[a].key > node_[b].key) std::swap(a, b);
+      if (ns == 128) { broken = true; a += b; break; }   // (cannot happen while the leftist invariant holds; never write past the array)
       spine[ns++] = a;
       a = node_[a].right;
     }
@@ -73,6 +74,7 @@ class EdgeHeaps {
     }
     return sub;
   }
+  bool broken = false;   // a merge path longer than any leftist heap can have: the structure is corrupt, the caller gives up
   int meld(int a, int b) { return meld(a, b, spine_); }
   int drop_min(int h) { return meld(node_[h].left, node_[h].right); }
   void subtract(int h, int delta) {   // from every key of heap h
@@ -147,7 +149,7 @@ class TreeBuilder {
     arborescence(gx, gy);
     mark("arborescence (rest)");
     if (roots_.empty()) return -1;
-    label_regions();
+    if (heaps_.broken || !label_regions()) return -2;        // not a forest over the roots
     mark("label_regions");
     merge_regions();
     mark("merge_regions");
@@ -161,7 +163,7 @@ class TreeBuilder {
     dbg_mark_ = nullptr;
     arborescence(gx, gy);
     if (roots_.empty()) return -1;
-    label_regions();
+    if (heaps_.broken || !label_regions()) return -2;        // not a forest over the roots
     merge_regions();
     std::vector<int32_t>& parent = parent_;
     parent.assign(N_, -1);
@@ -380,7 +382,9 @@ class TreeBuilder {
   // this; the results - which root a pixel hangs off, the maximum over a tree's edge weights - do not depend on the order, so they
   // are read off the arborescence's parent pointers directly: a pixel's region is its nearest labelled ancestor's, paths are
   // labelled as they are walked (round 5: 8 ms -> ~2 ms per tree; the breadth-first walk touched every adjacency chain at random)
-  void label_regions() {
+  // Returns false when the parent pointers do not form a forest over the roots (a cycle, or a pixel whose chain ends nowhere):
+  // the walk is bounded by the pixel count, and an unlabelled pixel is not quietly counted into region 0.
+  bool label_regions() {
     region_.assign(N_, -1); region_max_.assign(roots_.size(), 0);
     const std::vector<int>& up = chosen_from_;
     for (size_t i = 0; i < roots_.size(); ++i) region_[roots_[i]] = (int)i;
@@ -389,12 +393,17 @@ class TreeBuilder {
       if (region_[p] >= 0) continue;
       path.clear();
       int q = p;
-      while (q >= 0 && q < N_ && region_[q] < 0) { path.push_back(q); q = up[q]; }
-      const int lab = (q >= 0 && q < N_) ? region_[q] : 0;
+      while (q >= 0 && q < N_ && region_[q] < 0) {
+        if ((int)path.size() >= N_) return false;          // longer than the image: a cycle
+        path.push_back(q); q = up[q];
+      }
+      if (q < 0 || q >= N_) return false;                   // the chain left the image without meeting a root
+      const int lab = region_[q];
       for (int x : path) region_[x] = lab;
     }
     for (int p = 0; p < N_; ++p)
       if (up[p] >= 0 && up[p] < N_) region_max_[region_[p]] = std::max(region_max_[region_[p]], chosen_key_[p]);
+    return true;
   }
 
   void merge_regions() {

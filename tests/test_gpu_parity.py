@@ -266,18 +266,10 @@ def test_pose_opt_zero_edges_keeps_pose(svo_small):
     assert st.n_edges == 0 and np.allclose(T, T0)
 
 
-# cv::solvePnPRansac (reference src/pnpmatch.cc:227).  The GPU solves every RANSAC sample with a wave-parallel EPnP whose
-# linear algebra is ordered differently from OpenCV's loops (oracle/orc_pnp_cv.c), so poses are compared to a stated
-# tolerance; the discrete outcome - which sample wins, how many samples the adaptive loop visits, the inlier mask -
-# must be identical.
-# EPnP's N = 1 beta candidate starts from the LAST eigenvector of M^T M, which for five points is an arbitrary vector of
-# a two-dimensional null space (its basis is whatever the eigen-solver's rounding leaves - in OpenCV as well); when that
-# candidate has the smallest reprojection error the two poses can sit in neighbouring minima of EPnP's Gauss-Newton,
-# ~1e-3 m apart.  The N = 2 / N = 3 candidates agree to 1e-6 (test_epnp5_candidates_against_oracle).
-PNP_TOL_T = 1e-2      # metres: the winning sample's pose
-PNP_TOL_R = 1e-3
-
-
+# cv::solvePnPRansac (reference src/pnpmatch.cc:227).  The default solver ("epnp_exact" = 2) keeps every IEEE operation of OpenCV's
+# loops (oracle/orc_pnp_cv.c) and spreads the independent ones over a wavefront per RANSAC sample: the discrete outcome - which
+# sample wins, how many samples the adaptive loop visits, the inlier mask - and the returned pose are IDENTICAL, bit for bit.
+# (The statistical solver, mode 0, orders its linear algebra differently: tolerances in test_epnp5_candidates_against_oracle.)
 @pytest.mark.parametrize("seed,n,outliers", [(7, 500, 0.2), (12, 60, 0.2), (21, 200, 0.5), (33, 300, 0.0), (5, 9, 0.0)])
 def test_pnp_ransac_against_oracle(svo_small, orc, seed, n, outliers):
     Xw, obs, K, T_true = util.pose_problem(seed, n=n, outlier_frac=outliers)
@@ -286,8 +278,7 @@ def test_pnp_ransac_against_oracle(svo_small, orc, seed, n, outliers):
     Tr, mr, sr = orc.pnp_ransac(Xw, obs, K, T0)
     assert (st.ok, st.best_hypothesis, st.n_inliers, st.iterations) == (sr.ok, sr.best_hypothesis, sr.n_inliers, sr.iterations)
     assert st.ok == 1 and np.array_equal(mask, mr)
-    assert np.abs(T[:3, 3] - Tr[:3, 3]).max() < PNP_TOL_T
-    assert np.abs(T[:3, :3] - Tr[:3, :3]).max() < PNP_TOL_R
+    assert np.ascontiguousarray(T, np.float64).tobytes() == np.ascontiguousarray(Tr, np.float64).tobytes(), np.abs(T - Tr).max()
     # and it is the right pose: within what 0.5 px of noise on five points allows
     assert np.abs(T[:3, 3] - T_true[:3, 3]).max() < 0.3 and np.abs(T[:3, :3] - T_true[:3, :3]).max() < 5e-3
 

@@ -295,8 +295,10 @@ def test_tail_rate_does_not_depend_on_the_process_stream_history():
     for steps in ("SM", "HM"):
         later = run(steps)[0]
         print("QUEUE_HISTORY %s %s" % (steps, json.dumps(later)))
-        assert later["frames_per_s"] >= 0.95 * fresh["frames_per_s"], (steps, fresh, later)
+        # the property itself is asserted on what the context reports (its two chains run side by side); the wall-clock rate only has
+        # to stay clear of the halving a shared queue or pipe causes (5.9 k against 8.8 k) - 80 % leaves room for a noisy box
         assert later["probe_two_chains_vs_one_percent"] < 150, (steps, later)
+        assert later["frames_per_s"] >= 0.80 * fresh["frames_per_s"], (steps, fresh, later)
 
 
 @pytest.mark.gpu

@@ -320,7 +320,7 @@ def frontend_outputs(pkg, cam, dL, dR, n_frames, dev):
     desc = torch.zeros((n_frames, K, 32), dtype=torch.uint8, device=dev)
     n = torch.zeros(n_frames, dtype=torch.int32, device=dev)
     depth = torch.zeros((n_frames, K), dtype=torch.float32, device=dev)
-    fe = pkg.Svo(W, H, device=dev.index or 0, max_kp=K, max_batch=128)
+    fe = pkg.Svo(W, H, device=dev.index or 0, max_kp=K, max_batch=128, flags=pkg.CREATE_TAIL_ALL_CUS)
     fb = H * PITCH
     for c0 in range(0, n_frames, 128):
         c = min(128, n_frames - c0)
@@ -338,7 +338,8 @@ def elas_leg(pkg, device, d_L, d_R, pitch, B, iters=4):
     the reference's own compiled libelas on one host core when oracle/_ref is present."""
     import numpy as np
     import torch
-    ctx = pkg.Svo(W, H, device=device)
+    # (a context that never runs the batched tracker: its first queue - where every stage of these entries runs - keeps all CUs)
+    ctx = pkg.Svo(W, H, device=device, flags=pkg.CREATE_TAIL_ALL_CUS)
     p = pkg.elas_default_params(0)
     dev = d_L.device
     D1 = torch.zeros((B, H, W), dtype=torch.float32, device=dev); D2 = torch.zeros_like(D1)
@@ -407,7 +408,7 @@ def msa_leg(pkg, device, d_L, d_R):
     of the same algorithm on one host core."""
     import numpy as np
     import torch
-    ctx = pkg.Svo(W, H, device=device)
+    ctx = pkg.Svo(W, H, device=device, flags=pkg.CREATE_TAIL_ALL_CUS)
     g2c = lambda g: np.ascontiguousarray(np.repeat(g[:, :, None], 3, 2))
     L = g2c(d_L[0, :, :W].cpu().numpy()); R = g2c(d_R[0, :, :W].cpu().numpy())
     ctx.msa_solve(L, R, 48, 1)
@@ -479,7 +480,7 @@ def frontend_leg(pkg, cam, dL, dR, n_frames, frame_bytes, dev, all_cores):
     GPU has not touched for thousands of frames (the sequence is far larger than the Infinity Cache)."""
     import torch
     B, steps = int(os.environ.get("SVO_BENCH_FE_B", "384")), 16
-    fe = pkg.Svo(W, H, device=dev.index or 0, max_kp=500, max_batch=B)
+    fe = pkg.Svo(W, H, device=dev.index or 0, max_kp=500, max_batch=B, flags=pkg.CREATE_TAIL_ALL_CUS)   # front end only: all CUs for slice 0's queue
     for kv in filter(None, os.environ.get("SVO_BENCH_FE_OPTIONS", "").split(",")):   # experiments: "frontend_overlap=4"
         k, v = kv.split("=")
         fe.set_option(k, int(v))

@@ -1559,7 +1559,20 @@ int svo_elas_batch_dev_hooked(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d
   // (with a hook - the tracker's tail hangs on every chunk - chunks of 16: the tail starts after half as many pairs and the
   // last chunk's tail is half as long; measured with boxes, 256 frames per call: 32 -> 6.46 k, 24 -> 6.57 k, 16 -> 6.70 k, 8 -> 5.97 k
   // frames/s.  Without a hook 32: 8.0 k pairs/s against 7.1 k with 16 on the synthetic frames.)
-  const int C = std::min(B, chunk_env && atoi(chunk_env) > 0 ? atoi(chunk_env) : (hook ? ELAS_BATCH_CHUNK / 2 : ELAS_BATCH_CHUNK)), NC = (B + C - 1) / C;
+  const int C = std::min(B, chunk_env && atoi(chunk_env) > 0 ? atoi(chunk_env) : (hook ? ELAS_BATCH_CHUNK / 2 : ELAS_BATCH_CHUNK));
+  // With a hook the first chunks are SMALL (4, 4, 8 pairs, then C): whatever hangs on the chunks - the tracker's ordered tail, 120 us
+  // per frame - starts after the dense stage of four pairs instead of sixteen, and the pipeline's fill (A -> host -> B of the
+  // first chunk, ~4 ms of a 36 ms call of 256 frames) shrinks accordingly.  SVO_ELAS_RAMP=0: equal chunks.
+  std::vector<int> coff(1, 0);
+  {
+    static const bool ramp = []() { const char* e = getenv("SVO_ELAS_RAMP"); return !(e && e[0] == '0'); }();
+    const int first[3] = {4, 4, 8};
+    for (int k = 0; hook && ramp && k < 3 && coff.back() + first[k] < B && first[k] < C; ++k) coff.push_back(coff.back() + first[k]);
+    while (coff.back() < B) coff.push_back(std::min(B, coff.back() + C));
+  }
+  const int NC = (int)coff.size() - 1;
+  auto c_b0 = [&coff](int c) { return coff[c]; };
+  auto c_nb = [&coff](int c) { return coff[c + 1] - coff[c]; };
   // every fallible set-up step comes BEFORE the worker pool exists (returning past joinable threads would terminate
   // the process); the events are owned by a guard so that no return path leaks them
   struct EventSet {
@@ -1613,7 +1626,7 @@ int svo_elas_batch_dev_hooked(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d
   }
 
   auto enqueue_a = [&](int c) -> int {   // descriptors + lattice candidates of the chunk, candidates on their way back
-    const int b0 = c * C, nb = std::min(C, B - b0);
+    const int b0 = c_b0(c), nb = c_nb(c);
     int r = elas_phase_a(ctx, sA, eb->d_tab + b0, nb, stride, W, H, Wc, Hc, p);
     if (r) return r;
     SVO_HIP(ctx, hipMemcpyAsync(eb->h_can + (size_t)b0 * wh, eb->d_can + (size_t)b0 * wh, sizeof(int16_t) * (size_t)nb * wh,
@@ -1670,7 +1683,7 @@ int svo_elas_batch_dev_hooked(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d
   std::vector<std::thread> pool;
   for (int t = 0; t < nthreads; ++t) pool.emplace_back(worker);
   auto host_stage = [&](int c) {
-    const int b0 = c * C, nb = std::min(C, B - b0);
+    const int b0 = c_b0(c), nb = c_nb(c);
     std::unique_lock<std::mutex> lk(mu);
     for (int mode = 0; mode < 2; ++mode) {
       task_mode = mode; task_b0 = b0;
@@ -1682,7 +1695,7 @@ int svo_elas_batch_dev_hooked(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d
   double t_sync_copy = 0;
   size_t lists_used = 0;
   auto enqueue_b = [&](int c) -> int {   // counts into the table, then the whole phase B of the chunk
-    const int b0 = c * C, nb = std::min(C, B - b0);
+    const int b0 = c_b0(c), nb = c_nb(c);
     int max_nsp = 0, max_nt = 0;
     for (int b = b0; b < b0 + nb; ++b) {
       const ElasWork& w = work[b];
@@ -1745,7 +1758,7 @@ int svo_elas_batch_dev_hooked(svo_ctx* ctx, const uint8_t* d_L, const uint8_t* d
   std::thread driver;
   auto finish = [&](int c) -> int {   // chunk c has left the host stage: its phase B, and whatever the caller hangs on it
     int r = enqueue_b(c);
-    if (r == SVO_OK && hook) r = hook(user, c * C, std::min(C, B - c * C));
+    if (r == SVO_OK && hook) r = hook(user, c_b0(c), c_nb(c));
     return r;
   };
   for (int c = 0; c < NC && rc == SVO_OK; ++c) {

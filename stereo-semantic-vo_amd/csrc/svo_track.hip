@@ -1678,7 +1678,7 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
     const svo_kp* kpf = kp + row(f) * kstride;
     const float* depf = depth + row(f) * kstride;
     ctx->profiling = prof && (f % 32 == 0 || frames < 32);
-    if (ctx->opt_epnp_exact == 2 && ny == 1 && !ctx->hyp_two_launch && ctx->opt_tail_fused && ctx->opt_depth_source == 0) {
+    if (ctx->opt_epnp_exact == 2 && ny == 1 && !ctx->hyp_two_launch && ctx->opt_tail_fused && (ctx->opt_depth_source == 0 || ctx->opt_tail_fused == 2)) {
       // one sequence, the default solver: samples and frame part in ONE launch (k_tp_tail_ord).  Not beside a dense stereo stage
       // (depth_source 1 / 2): a fused launch's sample workgroups carry the frame part's 67 KB of LDS and three idle waves each,
       // which the dense kernels running on the same CUs pay for (configs[4]: 6.05 k frames/s fused, 6.85 k with two launches)

@@ -70,6 +70,60 @@ EPNP_X_FN double cv_hypot(double a, double b) {
   return 0;
 }
 
+// The part of JacobiSVDImpl_ behind its sweeps: singular values W[i] = |At[i]|, the selection sort into descending order (rows of
+// At - and of Vt, when given - swapped along), rows of zero singular values replaced by orthogonalised vectors drawn from the
+// function's own cv::RNG, every row scaled by 1 / W[i].  Separate so that a caller whose sweeps ran elsewhere (the wave engine of
+// svo_epnp_ord_dev.h, bit-identical row for row) can finish a decomposition the way OpenCV does.
+EPNP_X_FN void jacobi_svd_finish(double* W, double* At, int astep, double* _W, double* Vt, int vstep, int m, int n, int n1) {
+  const double minval = 2.2250738585072014e-308, eps = 2.220446049250313e-16 * 10;
+  double s, sd;
+  for (int i = 0; i < n; i++) {
+    sd = 0;
+    for (int k = 0; k < m; k++) { const double t = At[i * astep + k]; sd += t * t; }
+    W[i] = sqrt(sd);
+  }
+  for (int i = 0; i < n - 1; i++) {
+    int j = i;
+    for (int k = i + 1; k < n; k++)
+      if (W[j] < W[k]) j = k;
+    if (i != j) {
+      double t = W[i]; W[i] = W[j]; W[j] = t;
+      for (int k = 0; k < m; k++) { t = At[i * astep + k]; At[i * astep + k] = At[j * astep + k]; At[j * astep + k] = t; }
+      if (Vt) for (int k = 0; k < n; k++) { t = Vt[i * vstep + k]; Vt[i * vstep + k] = Vt[j * vstep + k]; Vt[j * vstep + k] = t; }
+    }
+  }
+  for (int i = 0; i < n; i++) _W[i] = W[i];
+  Rng rng{0x12345678};
+  for (int i = 0; i < n1; i++) {
+    sd = i < n ? W[i] : 0;
+    for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+      // a zero singular value: a random vector, orthogonalised against the rows found so far
+      const double val0 = 1. / m;
+      for (int k = 0; k < m; k++) At[i * astep + k] = (rng.next() & 256) != 0 ? val0 : -val0;
+      for (int iter = 0; iter < 2; iter++) {
+        for (int j = 0; j < i; j++) {
+          sd = 0;
+          for (int k = 0; k < m; k++) sd += At[i * astep + k] * At[j * astep + k];
+          double asum = 0;
+          for (int k = 0; k < m; k++) {
+            const double t = At[i * astep + k] - sd * At[j * astep + k];
+            At[i * astep + k] = t;
+            asum += fabs(t);
+          }
+          asum = asum > eps * 100 ? 1 / asum : 0;
+          for (int k = 0; k < m; k++) At[i * astep + k] *= asum;
+        }
+        sd = 0;
+        for (int k = 0; k < m; k++) { const double t = At[i * astep + k]; sd += t * t; }
+        sd = sqrt(sd);
+      }
+    }
+    s = sd > minval ? 1 / sd : 0.;
+    for (int k = 0; k < m; k++) At[i * astep + k] *= s;
+  }
+}
+
+
 // JacobiSVDImpl_<double>: one-sided Jacobi on the n rows (length m) of At; Vt n x n; singular values descending
 EPNP_X_FN void jacobi_svd(double* W /*[12] workspace*/, double* At, int astep, double* _W, double* Vt, int vstep, int m, int n, int n1) {
   const double minval = 2.2250738585072014e-308, eps = 2.220446049250313e-16 * 10;
@@ -120,50 +174,7 @@ EPNP_X_FN void jacobi_svd(double* W /*[12] workspace*/, double* At, int astep, d
       }
     if (!changed) break;
   }
-  for (int i = 0; i < n; i++) {
-    sd = 0;
-    for (int k = 0; k < m; k++) { const double t = At[i * astep + k]; sd += t * t; }
-    W[i] = sqrt(sd);
-  }
-  for (int i = 0; i < n - 1; i++) {
-    int j = i;
-    for (int k = i + 1; k < n; k++)
-      if (W[j] < W[k]) j = k;
-    if (i != j) {
-      double t = W[i]; W[i] = W[j]; W[j] = t;
-      for (int k = 0; k < m; k++) { t = At[i * astep + k]; At[i * astep + k] = At[j * astep + k]; At[j * astep + k] = t; }
-      for (int k = 0; k < n; k++) { t = Vt[i * vstep + k]; Vt[i * vstep + k] = Vt[j * vstep + k]; Vt[j * vstep + k] = t; }
-    }
-  }
-  for (int i = 0; i < n; i++) _W[i] = W[i];
-  Rng rng{0x12345678};
-  for (int i = 0; i < n1; i++) {
-    sd = i < n ? W[i] : 0;
-    for (int ii = 0; ii < 100 && sd <= minval; ii++) {
-      // a zero singular value: a random vector, orthogonalised against the rows found so far
-      const double val0 = 1. / m;
-      for (int k = 0; k < m; k++) At[i * astep + k] = (rng.next() & 256) != 0 ? val0 : -val0;
-      for (int iter = 0; iter < 2; iter++) {
-        for (int j = 0; j < i; j++) {
-          sd = 0;
-          for (int k = 0; k < m; k++) sd += At[i * astep + k] * At[j * astep + k];
-          double asum = 0;
-          for (int k = 0; k < m; k++) {
-            const double t = At[i * astep + k] - sd * At[j * astep + k];
-            At[i * astep + k] = t;
-            asum += fabs(t);
-          }
-          asum = asum > eps * 100 ? 1 / asum : 0;
-          for (int k = 0; k < m; k++) At[i * astep + k] *= asum;
-        }
-        sd = 0;
-        for (int k = 0; k < m; k++) { const double t = At[i * astep + k]; sd += t * t; }
-        sd = sqrt(sd);
-      }
-    }
-    s = sd > minval ? 1 / sd : 0.;
-    for (int k = 0; k < m; k++) At[i * astep + k] *= s;
-  }
+  jacobi_svd_finish(W, At, astep, _W, Vt, vstep, m, n, n1);
 }
 
 // cv::SVD::compute of a row-major m x n matrix (m >= n): w[n], Ut rows = left vectors (n x m), Vt rows = right vectors

@@ -71,8 +71,12 @@ struct Lds {
   double out[3][16];        // per candidate: R (9), t (3), mean reprojection error
   int srow[3][6];           // per small problem: Jacobi row (index into jr rows) at sorted position p
   int urow[4];              // 12 x 12: row of the (11 - q)-th singular value
-  int flag;                 // a branch this file does not reproduce was met: re-solve sequentially
+  double xw[16];            // jacobi12_safe: W of every row (the assembly loop recomputes it instead)
+  int flag;                 // bit 0: a branch this file does not reproduce was met in the 12 x 12 decomposition (or the step loop ran out of
+                            // sweeps there): re-solve the sample sequentially; bit 1: a small decomposition was finished sequentially
   int sweeps;               // diagnostics: sweeps of the 12 x 12 decomposition
+  int why;                  // diagnostics: 1 the 12 x 12 step loop ran out of sweeps, 2 a non-zero singular value of it out of range,
+                            // 4 its finish by lane 0 (zero / equal singular values), 8 a small decomposition finished by lane 0, 16 forced
   long long stamp[8];
 #ifdef EO_PROFILE
   long long prof[8];
@@ -270,8 +274,9 @@ EO_FN double row_norm2(double n0, double n1, double n2, double mk) {
 // n rows starting at row `base`, n in {3, 4, 5, 12} - or n = 0: the row idles.
 // On return the rows are what JacobiSVDImpl_ leaves before its sort: rotated, the A part scaled by 1 / W[i], and
 // W[i] = sqrt(sum At[i][k]^2) in column 15 of the row.
+// Returns (uniform) the lanes whose step loop ran out of sweeps.
 template <int M>
-EO_FN void jacobi_rows(Lds& S, int n, int base, int lane) {
+EO_FN unsigned long long jacobi_rows(Lds& S, int n, int base, int lane) {
   const int r = lane & 15, g = lane >> 4, q = r - base;
   // 1.0 where this lane's column of the partly filled group is an A column, 0.0 where it belongs to V: x * 1.0 is x, and a
   // (finite) x * 0.0 adds nothing to a sum that started at +0.0
@@ -321,7 +326,10 @@ EO_FN void jacobi_rows(Lds& S, int n, int base, int lane) {
   else if (M == 6) asm volatile(EO_JACOBI_ASM_6 EO_JACOBI_OPERANDS);
   else asm volatile(EO_JACOBI_ASM_3 EO_JACOBI_OPERANDS);
 #undef EO_JACOBI_OPERANDS
-  if (flag) S.flag = 1;                                      // 25 sweeps without convergence: the sequential solver decides
+  // 25 sweeps without convergence: the sequential code decides - the whole sample for the 12 x 12 problem, this decomposition
+  // alone for a small one (the caller, svd_small_seq)
+  const unsigned long long exhausted = __ballot(flag != 0 && n > 0);
+  if (M == 12 && flag) S.why |= 1;
   if (M == 12 && lane == 0) S.sweeps = (int)nst;             // diagnostics: steps of the 12 x 12 decomposition
   // W[i] = sqrt(sum At[i][k]^2); At[i] *= 1 / W[i]  (the sort is the caller's: svd_rank)
   const double w = xsqrt(row_norm2<M>(x0, x1, x2, mk));
@@ -333,51 +341,190 @@ EO_FN void jacobi_rows(Lds& S, int n, int base, int lane) {
     if (g == 0) S.jr[r * 16 + 15] = w;
   }
   EO_SYNC();
+  return exhausted;
 }
 
 // cv::SVD's descending order for the problem of this lane's DPP row (p < 3; n rows from `base`): S.sw[p][pos] the singular values,
 // S.srow[p][pos] the Jacobi row at sorted position pos.  A singular value outside [2^-100, 2^100] (zero: JacobiSVDImpl_ would
-// draw a random vector) or two equal ones (the selection sort's swaps would matter): S.flag.
-EO_FN void svd_rank(Lds& S, int n, int base, int p, int lane) {
+// draw a random vector) or two equal ones (the selection sort's swaps would matter): the lane reports it (the returned ballot) -
+// the caller reloads the problem's matrix and has lane 0 walk JacobiSVDImpl_ itself on it (svd_small_seq).
+EO_FN unsigned long long svd_rank(Lds& S, int n, int base, int p, int lane) {
   const int col = lane & 15;
+  bool bad = false;
   if (col < n) {
     const double my = S.jr[(base + col) * 16 + 15];
     int rank = 0;
-    bool bad = !w_in_range(my);
+    bad = !w_in_range(my);
     for (int q = 0; q < 5; ++q)
       if (q < n && q != col) {
         const double o = S.jr[(base + q) * 16 + 15];
         rank += o > my ? 1 : 0;
         bad = bad || o == my;
       }
-    if (bad) S.flag = 1;
     S.sw[p][rank] = my;
     S.srow[p][rank] = base + col;
   }
   EO_SYNC();
+  return __ballot(bad);      // (uniform) lanes of the DPP rows whose problem needs the sequential finish: bits 16 p .. 16 p + 15
+}
+// which of the (up to three) side-by-side problems need the sequential finish: bit p.  `ex`: jacobi_rows' lanes (row r of any
+// lane group belongs to problem r / 5), `bad`: svd_rank's (DPP row p)
+EO_FN unsigned need_seq(unsigned long long ex, unsigned long long bad) {
+  unsigned m = 0;
+  for (int p = 0; p < 3; ++p) {
+    const unsigned long long rows = 0x001F001F001F001FULL << (5 * p);
+    if ((ex & rows) || (bad & (0xFFFFULL << (16 * p)))) m |= 1u << p;
+  }
+  return m;
 }
 
 // the 12 x 12 decomposition of M^T M: the rows of the four smallest singular values, S.ut4[q] = ut + 12 * (11 - q)
-EO_FN void svd12_smallest(Lds& S, int lane) {
+// Returns (uniform) 0: the four vectors are in S.ut4; 1: a singular value is exactly zero or two are equal - the caller finishes
+// the decomposition sequentially (svd12_finish_seq) instead of using what is stored here; 2: a value outside [2^-100, 2^100]
+// (NaN included) - the assembly loop's unscaled divisions were not IEEE's there: the caller redoes the sweeps (jacobi12_safe).
+EO_FN int svd12_smallest(Lds& S, int lane) {
+  bool local = false, full = false;
   if (lane < 12) {
     const double my = S.jr[lane * 16 + 15];
     int rank = 0;
-    bool bad = !w_in_range(my);
+    local = my == 0.0;
+    full = !w_in_range(my);     // (0 included: rows of exact zeros next to rows of 1e-300 are the same degenerate case)
     for (int q = 0; q < 12; ++q)
       if (q != lane) {
         const double o = S.jr[q * 16 + 15];
         rank += o > my ? 1 : 0;
-        bad = bad || o == my;
+        local = local || o == my;
       }
-    if (bad) S.flag = 1;
+    if (full) S.why |= 2;
     if (rank >= 8) S.urow[11 - rank] = lane;
   }
+  const bool any_local = __ballot(local) != 0, any_full = __ballot(full) != 0;
   EO_SYNC();
+  if (any_full) return 2;
+  if (any_local) return 1;
   if (lane < 48) {
     const int q = lane / 12, k = lane % 12, r = S.urow[q] & 15;
     S.ut4[q][k] = S.jr[r * 16 + k];
   }
   EO_SYNC();
+  return 0;
+}
+
+// The 12 x 12 step loop in plain C++ with the compiler's full IEEE division and square root (range scaling, special cases) and
+// JacobiSVDImpl_'s expressions as they stand - the assembly loop's predecessor (round 4), ~1.5x its time.  The assembly loop's
+// unscaled divisions are IEEE's only for operands well inside the range, which a DEGENERATE sample's M^T M is not (an exactly
+// coplanar or duplicated set of world points: zero rows, rows of 1e-300): it then reports trouble (out of sweeps, a singular value
+// out of range) and the decomposition is redone here from the reloaded matrix - still all pairs of a step side by side, instead of
+// the 66 pairs of a sweep one after the other on one lane (~2 ms per sample).  Same schedule tables, same k-ordered sums.
+__device__ __attribute__((noinline)) void jacobi12_safe(Lds& S, int lane) {
+  const double eps = 2.220446049250313e-16 * 10;
+  const int r = lane & 15, g = lane >> 4, n = r < 12 ? 12 : 0, q = r;
+  double x0 = S.jr[r * 16 + g], x1 = S.jr[r * 16 + 4 + g], x2 = S.jr[r * 16 + 8 + g];
+  double W = colsum<12>(x0 * x0, x1 * x1, x2 * x2, g);
+  double* const mine = S.xch[r][g];
+  mine[0] = x0; mine[1] = x1; mine[2] = x2;
+  S.xw[r] = W;
+  const int tb = EO_TAB12_OFF, steps = EO_TAB12_STEPS, pro = EO_TAB12_PROLOGUE;
+  const unsigned pm = n > 0 ? (1u << 12) - 1u : 0u;   // the rows of the problem, as lanes of group 0
+  EO_SYNC();
+  int tt = 0, tp = n > 0 ? tb + q : 0, sbase = 0;
+  unsigned chg = 0;      // bit s: this row rotated in sweep s
+  bool active = n >= 2;
+  unsigned e = S.tab[tp];
+  int nsteps = 0;
+  while (__any(active)) {
+    int tn = tt + 1, tpn = tp + n, sbn = sbase;
+    if (tn == steps) { tn = pro; tpn = tb + pro * n + q; sbn = sbase + 1; }
+    const unsigned en = S.tab[n > 0 ? tpn : 0];           // next step's entry
+    const int pq = e & 15, sw = sbase + (int)((e >> 5) & 3);
+    const bool is_j = (e >> 31) != 0;                     // (bit 4 of the table entry, moved up by load_tables)
+    const bool valid = active && pq != q && sw < 30;
+    const int pr = valid ? pq : r;
+    const double* const theirs = S.xch[pr][g];
+    const double y0 = theirs[0], y1 = theirs[1], y2 = theirs[2];
+    const double p0 = colsum<12>(x0 * y0, x1 * y1, x2 * y2, g);
+    const double wP = S.xw[pr];
+    const bool rot = valid && !(fabs(p0) <= eps * xsqrt(W * wP));
+    if (__any(rot)) {
+      const double p = p0 * 2;
+      double beta = W - wP;                    // W[i] - W[j]: the j row sees the operands swapped
+      if (is_j) beta = -beta;
+      double gamma;                            // cv::hypot(p, beta)
+      {
+        double a = fabs(p), b = fabs(beta);
+        if (a > b) { b = xdiv(b, a); gamma = a * xsqrt(1 + b * b); }
+        else if (b > 0) { a = xdiv(a, b); gamma = b * xsqrt(1 + a * a); }
+        else gamma = 0;
+      }
+      double c, sn;
+      if (beta < 0) {
+        const double delta = (gamma - beta) * 0.5;
+        sn = xsqrt(xdiv(delta, gamma));
+        c = xdiv(p, gamma * sn * 2);
+      } else {
+        c = xsqrt(xdiv(gamma + beta, gamma * 2));
+        sn = xdiv(p, gamma * c * 2);
+      }
+      // row i: t0 = c Ai + s Aj; row j: t1 = -s Ai + c Aj = c (mine) + (-s) (theirs)
+      const double se = is_j ? -sn : sn;
+      const double n0 = c * x0 + se * y0, n1 = c * x1 + se * y1, n2 = c * x2 + se * y2;
+      const double Wn = colsum<12>(n0 * n0, n1 * n1, n2 * n2, g);
+      EO_SYNC();                               // (every lane has fetched its partner's row before any row is rewritten)
+      if (rot) {
+        x0 = n0; x1 = n1; x2 = n2; W = Wn;
+        chg |= 1u << sw;
+        mine[0] = x0; mine[1] = x1; mine[2] = x2;
+        S.xw[r] = W;
+      }
+    }
+    EO_SYNC();
+    const bool closes = active && (e & 0x80u) != 0;        // the pair (n - 2, n - 1) of sweep sc ran in this step: the sweep is complete
+    if (__any(closes)) {
+      const int sc = sbase + (int)((e >> 8) & 3);
+      const unsigned long long bal = __ballot(closes && ((chg >> (sc & 31)) & 1u));
+      if (closes && (sc >= 29 || ((unsigned)bal & pm) == 0u)) active = false;   // for (iter < 30) { ...; if (!changed) break; }
+    }
+    tt = tn; tp = tpn; sbase = sbn; e = en;
+    ++nsteps;
+  }
+  if (lane == 0) S.sweeps = 1000000 + nsteps;      // diagnostics (1e6 + steps: the safe loop ran)
+  EO_SYNC();
+}
+
+// A small decomposition the wave engine cannot finish the way OpenCV does (a zero singular value: JacobiSVDImpl_ draws a random
+// vector from its own RNG and orthogonalises it; equal singular values: its selection sort's swaps decide the order; a step loop
+// that ran out of sweeps): lane 0 walks JacobiSVDImpl_ itself (svo_epnp_exact_dev.h, the restatement the sequential solver uses)
+// over the problem's rows IN PLACE - the rows are At (n rows of M columns, pitch 16) with Vt behind them (columns M ...), which is
+// the layout that function works on - and leaves what svd_rank leaves: S.sw[p] descending, S.srow[p][pos] = base + pos (the rows
+// come out sorted).  The caller has reloaded the problem's ORIGINAL matrix into the rows.  Costs microseconds for a 3 x 3 or
+// 6 x 5 problem, where re-solving the whole sample on one lane cost ~840 us (the 12 x 12 Jacobi on one lane): an exactly
+// coplanar set of world points - a zero singular value in choose_control_points' 3 x 3 problem - no longer is a latency cliff.
+// One copy of the code (not inlined): this path is rare.
+// (`jW`: n doubles of workspace of the calling lane's own - the three candidates' problems are finished by three lanes side by side)
+__device__ __attribute__((noinline)) void svd_small_seq(Lds& S, double* jW, int M, int n, int base, int p) {
+  double w[6];
+  epnp_exact::jacobi_svd(jW, &S.jr[base * 16], 16, w, &S.jr[base * 16 + M], 16, M, n, n);
+  for (int i = 0; i < n; ++i) {
+    S.sw[p][i] = w[i];
+    S.srow[p][i] = base + i;
+    S.jr[(base + i) * 16 + 15] = w[i];
+  }
+  S.flag |= 2; S.why |= 8;
+}
+
+// The 12 x 12 decomposition with a ZERO singular value or two EQUAL ones (an exactly coplanar / duplicated set of world points
+// leaves structural zeros in M): the wave engine's sweeps are JacobiSVDImpl_'s sweeps row for row, only what follows them - the
+// selection sort's order among equal values, the random vectors it draws for zero ones - is not reproduced there.  Lane 0 runs
+// exactly that part (epnp_exact::jacobi_svd_finish) on the rows as the sweeps left them (unscaled, in the engine's exchange
+// buffer) and hands the four smallest singular values' vectors on.  A few thousand instructions, where re-solving the whole
+// sample on one lane costs ~2 ms - the 12 x 12 sweeps on one lane.
+__device__ __attribute__((noinline)) void svd12_finish_seq(Lds& S, epnp_exact::Work& xw) {
+  for (int i = 0; i < 12; ++i)
+    for (int k = 0; k < 12; ++k) xw.ut[i * 12 + k] = S.xch[i][k & 3][k >> 2];     // lane group g = k & 3 holds columns g, 4 + g, 8 + g
+  epnp_exact::jacobi_svd_finish(xw.jW, xw.ut, 12, xw.d, nullptr, 0, 12, 12, 12);
+  for (int q = 0; q < 4; ++q)
+    for (int k = 0; k < 12; ++k) S.ut4[q][k] = xw.ut[(11 - q) * 12 + k];
+  S.flag |= 2; S.why |= 4;
 }
 
 // ---- epnp::gauss_newton + qr_solve for one candidate, scalar code (arrays in registers) ---------------------------------
@@ -473,7 +620,7 @@ EO_FN double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] 
 EO_FN bool solve5_wave(Lds& S, epnp_exact::Work& xw, const double* K, double* R_out, double* t_out, double* rep, bool force_seq = false) {
   const int lane = threadIdx.x & 63, slot = lane >> 4, col = lane & 15, r16 = lane & 15;
   const double fu = K[0], fv = K[1], uc = K[2], vc = K[3];
-  if (lane == 0) { S.flag = force_seq ? 1 : 0; S.stamp[0] = clock64(); }
+  if (lane == 0) { S.flag = force_seq ? 1 : 0; S.why = force_seq ? 16 : 0; S.stamp[0] = clock64(); }
   load_tables(S, lane);   // force_seq: tests exercise the sequential fallback
   EO_SYNC();
   // ---- choose_control_points -----------------------------------------------------------------------------------------
@@ -483,21 +630,29 @@ EO_FN bool solve5_wave(Lds& S, epnp_exact::Work& xw, const double* K, double* R_
     S.cws[lane] = c / 5;
   }
   EO_SYNC();
-  if (lane < 9) {            // PW0^T PW0 (cvMulTransposed), loaded transposed into the Jacobi rows (temp_a = A^T)
-    const int a = lane / 3, b = lane % 3;
-    const double ca = S.cws[a], cb = S.cws[b];
-    double s = 0;
-    for (int i = 0; i < 5; ++i) s += (S.pws[3 * i + a] - ca) * (S.pws[3 * i + b] - cb);
-    S.jr[b * 16 + a] = s;
-  } else if (lane < 18) {
-    const int r = (lane - 9) / 3, k = (lane - 9) % 3;
-    S.jr[r * 16 + 3 + k] = r == k ? 1.0 : 0.0;
-  } else if (lane < 36) {
-    S.jr[((lane - 18) / 6) * 16 + 6 + (lane - 18) % 6] = 0.0;   // the columns behind V: finite
+  auto load_pw0 = [&]() {
+    if (lane < 9) {            // PW0^T PW0 (cvMulTransposed), loaded transposed into the Jacobi rows (temp_a = A^T)
+      const int a = lane / 3, b = lane % 3;
+      const double ca = S.cws[a], cb = S.cws[b];
+      double s = 0;
+      for (int i = 0; i < 5; ++i) s += (S.pws[3 * i + a] - ca) * (S.pws[3 * i + b] - cb);
+      S.jr[b * 16 + a] = s;
+    } else if (lane < 18) {
+      const int r = (lane - 9) / 3, k = (lane - 9) % 3;
+      S.jr[r * 16 + 3 + k] = r == k ? 1.0 : 0.0;
+    } else if (lane < 36) {
+      S.jr[((lane - 18) / 6) * 16 + 6 + (lane - 18) % 6] = 0.0;   // the columns behind V: finite
+    }
+    EO_SYNC();
+  };
+  load_pw0();
+  unsigned long long ex = jacobi_rows<3>(S, r16 < 3 ? 3 : 0, r16 < 3 ? 0 : r16, lane);
+  unsigned long long bd = svd_rank(S, slot == 0 ? 3 : 0, 0, 0, lane);
+  if (ex | bd) {             // (uniform) e.g. exactly coplanar world points: a zero singular value
+    load_pw0();
+    if (lane == 0) svd_small_seq(S, xw.jW, 3, 3, 0, 0);
+    EO_SYNC();
   }
-  EO_SYNC();
-  jacobi_rows<3>(S, r16 < 3 ? 3 : 0, r16 < 3 ? 0 : r16, lane);
-  svd_rank(S, slot == 0 ? 3 : 0, 0, 0, lane);
   if (lane < 9) {
     const int i = 1 + lane / 3, j = lane % 3;
     const double k = xsqrt(S.sw[0][i - 1] / 5);
@@ -505,18 +660,26 @@ EO_FN bool solve5_wave(Lds& S, epnp_exact::Work& xw, const double* K, double* R_
   }
   EO_SYNC();
   // ---- compute_barycentric_coordinates: cvInvert(CC, CV_SVD) ---------------------------------------------------------
-  if (lane < 9) {            // cc[3 i + j - 1] = cws[j][i] - cws[0][i]; Jacobi row r, column k = cc[3 k + r]
-    const int r = lane / 3, k = lane % 3;
-    S.jr[r * 16 + k] = S.cws[3 * (r + 1) + k] - S.cws[k];
-  } else if (lane < 18) {
-    const int r = (lane - 9) / 3, k = (lane - 9) % 3;
-    S.jr[r * 16 + 3 + k] = r == k ? 1.0 : 0.0;
-  } else if (lane < 36) {
-    S.jr[((lane - 18) / 6) * 16 + 6 + (lane - 18) % 6] = 0.0;   // the columns behind V: finite
+  auto load_cc = [&]() {
+    if (lane < 9) {            // cc[3 i + j - 1] = cws[j][i] - cws[0][i]; Jacobi row r, column k = cc[3 k + r]
+      const int r = lane / 3, k = lane % 3;
+      S.jr[r * 16 + k] = S.cws[3 * (r + 1) + k] - S.cws[k];
+    } else if (lane < 18) {
+      const int r = (lane - 9) / 3, k = (lane - 9) % 3;
+      S.jr[r * 16 + 3 + k] = r == k ? 1.0 : 0.0;
+    } else if (lane < 36) {
+      S.jr[((lane - 18) / 6) * 16 + 6 + (lane - 18) % 6] = 0.0;   // the columns behind V: finite
+    }
+    EO_SYNC();
+  };
+  load_cc();
+  ex = jacobi_rows<3>(S, r16 < 3 ? 3 : 0, r16 < 3 ? 0 : r16, lane);
+  bd = svd_rank(S, slot == 0 ? 3 : 0, 0, 0, lane);
+  if (ex | bd) {
+    load_cc();
+    if (lane == 0) svd_small_seq(S, xw.jW, 3, 3, 0, 0);
+    EO_SYNC();
   }
-  EO_SYNC();
-  jacobi_rows<3>(S, r16 < 3 ? 3 : 0, r16 < 3 ? 0 : r16, lane);
-  svd_rank(S, slot == 0 ? 3 : 0, 0, 0, lane);
   if (lane < 9) {            // SVBkSbImpl_ with the identity as right-hand side: x[3 j + c] += (Ut[i][c] / w[i]) * Vt[i][j]
     const int j = lane / 3, c = lane % 3;
     double threshold = 0;
@@ -558,16 +721,34 @@ EO_FN bool solve5_wave(Lds& S, epnp_exact::Work& xw, const double* K, double* R_
     S.M[e] = m;
   }
   EO_SYNC();
-  for (int e = lane; e < 144; e += 64) {
-    const int a = e / 12, b = e % 12;
-    double s = 0;
-    for (int r = 0; r < 10; ++r) s += S.M[12 * r + a] * S.M[12 * r + b];
-    S.jr[b * 16 + a] = s;
-  }
-  EO_SYNC();
+  auto load_mtm = [&]() {
+    for (int e = lane; e < 144; e += 64) {
+      const int a = e / 12, b = e % 12;
+      double s = 0;
+      for (int r = 0; r < 10; ++r) s += S.M[12 * r + a] * S.M[12 * r + b];
+      S.jr[b * 16 + a] = s;
+    }
+    EO_SYNC();
+  };
+  load_mtm();
   if (lane == 0) S.stamp[2] = clock64();
-  jacobi_rows<12>(S, r16 < 12 ? 12 : 0, r16 < 12 ? 0 : r16, lane);
-  svd12_smallest(S, lane);
+  // (a sample whose control points already needed the sequential finish - exactly coplanar world points - is degenerate here too:
+  // straight to the full-IEEE loop instead of running the assembly loop into its sweep bound first)
+  const bool degenerate = (S.why & 8) != 0;      // (uniform: LDS, written before the last EO_SYNC)
+  unsigned long long ex12 = 0;
+  int fin12 = 2;
+  if (!degenerate) {
+    ex12 = jacobi_rows<12>(S, r16 < 12 ? 12 : 0, r16 < 12 ? 0 : r16, lane);
+    fin12 = svd12_smallest(S, lane);             // (uniform) 0: done; 1: zero / equal singular values; 2: one out of range
+  }
+  if (ex12 || fin12) {
+    if (ex12 || fin12 == 2) {       // the assembly loop's arithmetic left its range: the sweeps in full IEEE, from the reloaded matrix
+      if (!degenerate) load_mtm();
+      jacobi12_safe(S, lane);
+    }
+    if (lane == 0) svd12_finish_seq(S, xw);      // OpenCV's sort and its random vectors for zero singular values, by lane 0
+    EO_SYNC();
+  }
   if (lane == 0) S.stamp[3] = clock64();
   // ---- compute_L_6x10, compute_rho ---------------------------------------------------------------------------------------
   if (lane < 60) {
@@ -593,23 +774,34 @@ EO_FN bool solve5_wave(Lds& S, epnp_exact::Work& xw, const double* K, double* R_
   const int cand = slot < 3 ? slot : 0;
   const int nc = slot == 0 ? 4 : (slot == 1 ? 3 : (slot == 2 ? 5 : 0));
   const int base = 5 * cand;
-  if (slot < 3) {
-    for (int i = 0; i < nc; ++i) {
-      // l[k][i] = L[10 k + column i of the candidate]: approx_1 [B11 B12 B13 B14] = 0 1 3 6, approx_2 = 0 1 2, approx_3 = 0 1 2 3 4
-      const int lc = slot == 0 ? (i == 2 ? 3 : (i == 3 ? 6 : i)) : i;
-      double v = 0.0;
-      if (col < 6) v = S.L[10 * col + lc];
-      else if (col - 6 == i) v = 1.0;
-      S.jr[(base + i) * 16 + col] = v;
+  auto load_l = [&](int only) {      // the candidates' systems into their rows (only >= 0: that candidate's alone)
+    if (slot < 3 && (only < 0 || slot == only)) {
+      for (int i = 0; i < nc; ++i) {
+        // l[k][i] = L[10 k + column i of the candidate]: approx_1 [B11 B12 B13 B14] = 0 1 3 6, approx_2 = 0 1 2, approx_3 = 0 1 2 3 4
+        const int lc = slot == 0 ? (i == 2 ? 3 : (i == 3 ? 6 : i)) : i;
+        double v = 0.0;
+        if (col < 6) v = S.L[10 * col + lc];
+        else if (col - 6 == i) v = 1.0;
+        S.jr[(base + i) * 16 + col] = v;
+      }
     }
-  }
-  EO_SYNC();
+    EO_SYNC();
+  };
+  load_l(-1);
   {   // rows 0..3: candidate 1 (6 x 4), rows 5..7: candidate 2 (6 x 3), rows 10..14: candidate 3 (6 x 5)
     const int pc = r16 / 5, pn = pc == 0 ? 4 : (pc == 1 ? 3 : 5);
     const bool mine = r16 < 15 && r16 % 5 < pn;
-    jacobi_rows<6>(S, mine ? pn : 0, mine ? 5 * pc : r16, lane);
+    ex = jacobi_rows<6>(S, mine ? pn : 0, mine ? 5 * pc : r16, lane);
   }
-  svd_rank(S, nc, base, cand, lane);
+  bd = svd_rank(S, nc, base, cand, lane);
+  if (ex | bd) {             // (uniform)
+    const unsigned need = need_seq(ex, bd);
+    for (int pp = 0; pp < 3; ++pp)
+      if (need >> pp & 1) load_l(pp);
+    // one lane per candidate, side by side (each with a workspace of its own)
+    if (slot < 3 && col == 0 && (need >> slot & 1)) svd_small_seq(S, slot == 0 ? xw.jW : (slot == 1 ? xw.sA : xw.sUt), 6, nc, base, cand);
+    EO_SYNC();
+  }
   if (slot < 3 && col < nc) {   // SVBkSbImpl_: x[j] += (sum_k Ut[i][k] b[k] / w[i]) * Vt[i][j]
     double threshold = 0;
     for (int i = 0; i < nc; ++i) threshold += S.sw[cand][i];
@@ -665,30 +857,42 @@ EO_FN bool solve5_wave(Lds& S, epnp_exact::Work& xw, const double* K, double* R_
   }
   EO_SYNC();
   double pc0[3], pw0[3];
+  bool flip;
   {
     const double* pc = S.pcs[cand];
-    const bool flip = pc[2] < 0.0;
+    flip = pc[2] < 0.0;
     for (int j = 0; j < 3; ++j) { pc0[j] = 0; pw0[j] = 0; }
     for (int i = 0; i < 5; ++i)
       for (int j = 0; j < 3; ++j) { pc0[j] += flip ? -pc[3 * i + j] : pc[3 * i + j]; pw0[j] += S.pws[3 * i + j]; }
     for (int j = 0; j < 3; ++j) { pc0[j] /= 5; pw0[j] /= 5; }
-    if (slot < 3 && col < 9) {        // ABt, loaded transposed into the Jacobi rows
+  }
+  auto load_abt = [&](int only) {    // the candidates' ABt into their rows (only >= 0: that candidate's alone)
+    const double* pc = S.pcs[cand];
+    if (slot < 3 && (only < 0 || slot == only) && col < 9) {        // ABt, loaded transposed into the Jacobi rows
       const int j = col / 3, k = col % 3;
       double s = 0;
       for (int i = 0; i < 5; ++i) s += ((flip ? -pc[3 * i + j] : pc[3 * i + j]) - pc0[j]) * (S.pws[3 * i + k] - pw0[k]);
       S.jr[(base + k) * 16 + j] = s;
-    } else if (slot < 3 && col < 12) {
+    } else if (slot < 3 && (only < 0 || slot == only) && col < 12) {
       const int r = col - 9;
       for (int k = 0; k < 3; ++k) S.jr[(base + r) * 16 + 3 + k] = r == k ? 1.0 : 0.0;
       for (int k = 6; k < 12; ++k) S.jr[(base + r) * 16 + k] = 0.0;   // the columns behind V: finite
     }
-  }
-  EO_SYNC();
+    EO_SYNC();
+  };
+  load_abt(-1);
   {
     const bool mine = r16 < 15 && r16 % 5 < 3;
-    jacobi_rows<3>(S, mine ? 3 : 0, mine ? 5 * (r16 / 5) : r16, lane);
+    ex = jacobi_rows<3>(S, mine ? 3 : 0, mine ? 5 * (r16 / 5) : r16, lane);
   }
-  svd_rank(S, slot < 3 ? 3 : 0, base, cand, lane);
+  bd = svd_rank(S, slot < 3 ? 3 : 0, base, cand, lane);
+  if (ex | bd) {             // (uniform)
+    const unsigned need = need_seq(ex, bd);
+    for (int pp = 0; pp < 3; ++pp)
+      if (need >> pp & 1) load_abt(pp);
+    if (slot < 3 && col == 0 && (need >> slot & 1)) svd_small_seq(S, slot == 0 ? xw.jW : (slot == 1 ? xw.sA : xw.sUt), 3, 3, base, cand);
+    EO_SYNC();
+  }
   if (slot < 3 && col < 9) {
     const int i = col / 3, j = col % 3;
     const int r0 = S.srow[cand][0], r1 = S.srow[cand][1], r2 = S.srow[cand][2];
@@ -721,7 +925,7 @@ EO_FN bool solve5_wave(Lds& S, epnp_exact::Work& xw, const double* K, double* R_
   EO_SYNC();
   if (lane == 0) S.stamp[6] = clock64();
   bool fin = true;
-  if (S.flag) {                 // a branch not reproduced here: the sequential restatement decides (lane 0)
+  if (S.flag & 1) {             // the 12 x 12 decomposition met a branch not reproduced here: the sequential restatement decides (lane 0)
     if (lane == 0) {
       double* x5 = xw.PW0;      // staging only: solve5 copies the sample first
       double* u5 = xw.gA;

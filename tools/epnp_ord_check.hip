@@ -35,7 +35,7 @@ __global__ __launch_bounds__(64) void k_probe(const double* X5, const double* u5
     ProbeOut o;
     for (int i = 0; i < 9; ++i) o.R[i] = R[i];
     for (int i = 0; i < 3; ++i) { o.t[i] = t[i]; o.rep[i] = rep[i]; }
-    o.ok = ok; o.flag = S.flag; o.sweeps = S.sweeps; o.pad = 0;
+    o.ok = ok; o.flag = S.flag; o.sweeps = S.sweeps; o.pad = S.why;
     for (int i = 0; i < 8; ++i) o.stamp[i] = S.stamp[i];
 #ifdef EO_PROFILE
     for (int i = 0; i < 8; ++i) o.prof[i] = S.prof[i];
@@ -90,7 +90,7 @@ int main(int argc, char** argv) {
   hipDeviceSynchronize();
   std::vector<ProbeOut> O(n);
   hipMemcpy(O.data(), dO, sizeof(ProbeOut) * n, hipMemcpyDeviceToHost);
-  int bad = 0, flagged = 0, notok = 0; long long cyc = 0; long long st[8] = {0};
+  int bad = 0, flagged = 0, flagged_full = 0, notok = 0; long long cyc = 0, cyc_local = 0, cyc_full = 0; long long st[8] = {0};
   int sweeps_hist[32] = {0};
   for (int s = 0; s < n; ++s) {
     double R[9], t[3];
@@ -105,8 +105,9 @@ int main(int argc, char** argv) {
       const double a = orc_epnp_last_rep[i], b = o.rep[i];
       if (!(isnan(a) && isnan(b))) same = same && !memcmp(&a, &b, 8);
     }
-    flagged += o.flag != 0; notok += !o.ok;
+    flagged += o.flag != 0; flagged_full += (o.flag & 1) != 0; notok += !o.ok;
     cyc += o.stamp[7] - o.stamp[0];
+    if (o.flag & 1) cyc_full += o.stamp[7] - o.stamp[0]; else if (o.flag) cyc_local += o.stamp[7] - o.stamp[0];
     for (int i = 1; i < 8; ++i) st[i] += o.stamp[i] - o.stamp[i - 1];
     if (!same) {
       if (bad < 8) {
@@ -118,11 +119,22 @@ int main(int argc, char** argv) {
     }
   }
   printf("samples %d  mismatches %d  flagged (sequential fallback) %d  non-finite %d\n", n, bad, flagged, notok);
+  { int why[32] = {0}; for (int s = 0; s < n; ++s) if (O[s].flag) why[O[s].pad & 31]++;
+    printf("  reasons (bit 0: 12x12 out of sweeps, 1: 12x12 singular value out of range, 2: 12x12 finished by lane 0, 3: small problem finished by lane 0, 4: forced):");
+    for (int k = 0; k < 32; ++k) if (why[k]) printf(" [%d]: %d", k, why[k]);
+    printf("\n"); }
+  printf("  of them: whole sample re-solved sequentially %d (mean ticks %.0f), one small decomposition finished sequentially %d (mean ticks %.0f); unflagged mean ticks %.0f\n",
+         flagged_full, flagged_full ? (double)cyc_full / flagged_full : 0.0, flagged - flagged_full, flagged - flagged_full ? (double)cyc_local / (flagged - flagged_full) : 0.0,
+         n - flagged ? (double)(cyc - cyc_full - cyc_local) / (n - flagged) : 0.0);
   printf("mean ticks per solve %.0f  stages:", (double)cyc / n);
   for (int i = 1; i < 8; ++i) printf(" %.0f", (double)st[i] / n);
   printf("\n  (control points + barycentric | M, MtM | 12x12 SVD | L, rho, beta init SVDs | gauss-newton | R, t, error | selection)\n");
   { long long pf[8] = {0}; for (int s = 0; s < n; ++s) for (int i = 0; i < 8; ++i) pf[i] += O[s].prof[i];
     if (pf[7]) { printf("12x12 loop, mean ticks per step: top+loads %.0f | pair test %.0f | rotation %.0f | update+norm %.0f | stores+sync %.0f | close+loop %.0f  (steps per solve %.1f)\n", (double)pf[0] / pf[7], (double)pf[1] / pf[7], (double)pf[2] / pf[7], (double)pf[3] / pf[7], (double)pf[4] / pf[7], (double)pf[5] / pf[7], (double)pf[7] / n); } }
+  { long long sf[8] = {0}; int nf = 0; for (int s = 0; s < n; ++s) if (O[s].flag) { ++nf; for (int i = 1; i < 8; ++i) sf[i] += O[s].stamp[i] - O[s].stamp[i - 1]; }
+    if (nf) { printf("flagged samples, mean ticks per stage:"); for (int i = 1; i < 8; ++i) printf(" %.0f", (double)sf[i] / nf); printf("\n"); } }
+  { long long st2 = 0; int n2 = 0; for (int s = 0; s < n; ++s) if (O[s].sweeps >= 1000000) { st2 += O[s].sweeps - 1000000; ++n2; O[s].sweeps = 0; }
+    if (n2) printf("full-IEEE 12x12 loop (degenerate samples): %d samples, %.1f steps each\n", n2, (double)st2 / n2); }
   { long long stp = 0; for (int s = 0; s < n; ++s) stp += O[s].sweeps; printf("12x12: %.1f steps per solve, %.0f ticks per step\n", (double)stp / n, (double)st[3] / (double)(stp ? stp : 1)); }
   printf("\nlaunch of %d samples: %.1f us\n", nt, ms * 1e3);
   return bad ? 1 : 0;

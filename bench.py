@@ -1585,7 +1585,7 @@ def main():
                                             "issues every second quad-cycle, v_rcp / v_rsq_f64 every fourth, a 4x4x4 DMFMA occupies five), "
                                             "LDS round trips of the row exchange and hazard wait states",
                                     "source": "profiles/pmc_latest.json: (SQ_INSTS_VALU + SQ_INSTS_SALU + SQ_INSTS_LDS) / SQ_WAVE_CYCLES of the "
-                                              "kernel, rocprofv3 --pmc passes of profiles/r05_z_track_*" if v else "no counters committed for this kernel"},
+                                              "kernel, rocprofv3 --pmc passes of profiles/r06_z_track_*" if v else "no counters committed for this kernel"},
                     "hbm_frac_of_this_kernel": (tail_kernel_bytes("k_tp_hyp_ord", 0, 0, float(res["n_lm_edges"][1:].mean()), 0) / (hyp_us * 1e-6) / 1e9 / HBM_PEAK_GBS),
                 }
                 # the headline's roofline leads with the model that governs the critical-path kernel; the HBM fraction (the contract's

@@ -1094,9 +1094,12 @@ def compact_line(out, detail_path=None):
     return line
 
 
+DETAIL_PATH = None     # --detail-path
+
+
 def emit(out):
     """Full result -> bench_detail.json beside this file (fallback: the temp directory); the compact line -> stdout, LAST."""
-    path = os.path.join(ROOT, "bench_detail.json")
+    path = DETAIL_PATH or os.path.join(ROOT, "bench_detail.json")
     try:
         with open(path, "w") as f:
             json.dump(out, f, indent=1)
@@ -1249,6 +1252,7 @@ def main():
     ap.add_argument("--no-tail-leg-children", action="store_true", help="(kept for scripts; the child repetition now needs --leg-orders)")
     ap.add_argument("--no-host-feed-leg", action="store_true", help="skip the host_feed leg (svo_track_batch_host / svo_frontend_batch_host from host memory)")
     ap.add_argument("--no-cotenant-leg", action="store_true", help="skip the co-tenant leg (tracker beside another GPU user of the process; two contexts on one GPU)")
+    ap.add_argument("--detail-path", default=None, help="where the full result goes (default: bench_detail.json beside bench.py)")
     ap.add_argument("--no-shard-leg", action="store_true", help="N > 1: skip rank 0's svo_track_sharded_dev run across the N GPUs")
     ap.add_argument("--shard", action="store_true",
                     help="track workload: ONE sequence over --gpus G contexts in ONE process (svo_track_sharded_dev, BASELINE configs[3])")
@@ -1260,6 +1264,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo (single-GPU dry runs)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks / contexts use cuda:0 (dry run of the N>1 path on one GPU)")
     args = ap.parse_args()
+    global DETAIL_PATH
+    DETAIL_PATH = args.detail_path
     if args.watchdog > 0:
         start_watchdog(args.watchdog)
     if args.gpus < 1:
@@ -1678,11 +1684,27 @@ def main():
     # N > 1: after the replicas' timed region rank 0 alone drives ONE sequence over all N GPUs (BASELINE configs[3]);
     # the other ranks wait at the barrier below
     if world > 1 and rank == 0 and track and not multi and not args.no_shard_leg:
+        # In a PROCESS OF ITS OWN, with a time limit: the cross-device paths of svo_track_sharded_dev (peer copies, events of one
+        # device waited for on another, per-device contexts) have only ever run with every context on ONE GPU - the builder's boxes
+        # have one; whatever happens there on a real node must not take the replicas' line with it.
         try:
-            ndev = torch.cuda.device_count()
-            devices = [g if (g < ndev and not args.share_gpu) else local for g in range(world)]
+            import tempfile
             ns = min(n_frames, 2048)
-            out["sharded"] = sharded_run(pkg, cam, dL, dR, ns, world, devices, rec, reference=d_res[:ns].cpu().numpy())
+            tmp = os.path.join(tempfile.gettempdir(), "bench_shard_detail_%d.json" % os.getpid())
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                                       "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+            cmd = [sys.executable, os.path.abspath(__file__), "--shard", "--gpus", str(world), "--frames", str(ns), "--detail-path", tmp,
+                   "--watchdog", "540"] + (["--share-gpu"] if args.share_gpu else [])
+            progress("leg sharded: one sequence over %d contexts, child process" % world)
+            cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            if cp.returncode != 0:
+                out["sharded"] = {"error": "child exited with %d: %s" % (cp.returncode, cp.stderr.decode(errors="replace")[-400:])}
+            else:
+                out["sharded"] = json.load(open(tmp))["sharded"]
+            try:
+                os.remove(tmp)
+            except OSError:
+                pass
         except Exception as e:  # noqa: BLE001
             out["sharded"] = {"error": repr(e)}
     if rank == 0:

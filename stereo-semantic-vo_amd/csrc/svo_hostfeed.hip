@@ -304,7 +304,8 @@ void svo_hostfeed_release(svo_ctx* ctx) {
   HostFeed* hf = feed_of(ctx);
   if (!hf) return;
   if (hf->copy) hipStreamSynchronize(hf->copy);
-  (void)svo_hostfeed_flush(ctx);
+  // (records still waiting in the pinned buffers are DROPPED, not copied out: a caller that destroys the context without svo_sync
+  // may have released its result arrays already - include/svo.h promises them after svo_sync only)
   for (int p = 0; p < 2; ++p) {
     if (hf->d_img[p]) hipFree(hf->d_img[p]);
     if (hf->h_img[p]) hipHostFree(hf->h_img[p]);

@@ -74,7 +74,10 @@ EPNP_X_FN double cv_hypot(double a, double b) {
 // At - and of Vt, when given - swapped along), rows of zero singular values replaced by orthogonalised vectors drawn from the
 // function's own cv::RNG, every row scaled by 1 / W[i].  Separate so that a caller whose sweeps ran elsewhere (the wave engine of
 // svo_epnp_ord_dev.h, bit-identical row for row) can finish a decomposition the way OpenCV does.
-EPNP_X_FN void jacobi_svd_finish(double* W, double* At, int astep, double* _W, double* Vt, int vstep, int m, int n, int n1) {
+// (PW / PA: `double*`, or an LDS-qualified pointer - a caller that is NOT inlined into its kernel would otherwise walk the arrays
+// through flat loads and stores, at twice the latency per dependent access)
+template <typename PW, typename PA>
+EPNP_X_FN void jacobi_svd_finish(PW W, PA At, int astep, double* _W, PA Vt, int vstep, int m, int n, int n1) {
   const double minval = 2.2250738585072014e-308, eps = 2.220446049250313e-16 * 10;
   double s, sd;
   for (int i = 0; i < n; i++) {
@@ -125,7 +128,8 @@ EPNP_X_FN void jacobi_svd_finish(double* W, double* At, int astep, double* _W, d
 
 
 // JacobiSVDImpl_<double>: one-sided Jacobi on the n rows (length m) of At; Vt n x n; singular values descending
-EPNP_X_FN void jacobi_svd(double* W /*[12] workspace*/, double* At, int astep, double* _W, double* Vt, int vstep, int m, int n, int n1) {
+template <typename PW, typename PA>
+EPNP_X_FN void jacobi_svd(PW W /*[12] workspace*/, PA At, int astep, double* _W, PA Vt, int vstep, int m, int n, int n1) {
   const double minval = 2.2250738585072014e-308, eps = 2.220446049250313e-16 * 10;
   const int max_iter = m > 30 ? m : 30;
   double c, s, sd;
@@ -140,8 +144,8 @@ EPNP_X_FN void jacobi_svd(double* W /*[12] workspace*/, double* At, int astep, d
     bool changed = false;
     for (int i = 0; i < n - 1; i++)
       for (int j = i + 1; j < n; j++) {
-        double* Ai = At + i * astep;
-        double* Aj = At + j * astep;
+        PA Ai = At + i * astep;
+        PA Aj = At + j * astep;
         double a = W[i], p = 0, b = W[j];
         for (int k = 0; k < m; k++) p += Ai[k] * Aj[k];
         if (fabs(p) <= eps * sqrt(a * b)) continue;
@@ -164,8 +168,8 @@ EPNP_X_FN void jacobi_svd(double* W /*[12] workspace*/, double* At, int astep, d
         }
         W[i] = a; W[j] = b;
         changed = true;
-        double* Vi = Vt + i * vstep;
-        double* Vj = Vt + j * vstep;
+        PA Vi = Vt + i * vstep;
+        PA Vj = Vt + j * vstep;
         for (int k = 0; k < n; k++) {
           const double t0 = c * Vi[k] + s * Vj[k];
           const double t1 = -s * Vi[k] + c * Vj[k];

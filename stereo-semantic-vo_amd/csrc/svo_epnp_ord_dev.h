@@ -501,9 +501,10 @@ __device__ __attribute__((noinline)) void jacobi12_safe(Lds& S, int lane) {
 // coplanar set of world points - a zero singular value in choose_control_points' 3 x 3 problem - no longer is a latency cliff.
 // One copy of the code (not inlined): this path is rare.
 // (`jW`: n doubles of workspace of the calling lane's own - the three candidates' problems are finished by three lanes side by side)
+typedef __attribute__((address_space(3))) double lds_double;    // (the function is not inlined: without the qualifier its accesses are flat ones)
 __device__ __attribute__((noinline)) void svd_small_seq(Lds& S, double* jW, int M, int n, int base, int p) {
   double w[6];
-  epnp_exact::jacobi_svd(jW, &S.jr[base * 16], 16, w, &S.jr[base * 16 + M], 16, M, n, n);
+  epnp_exact::jacobi_svd((lds_double*)jW, (lds_double*)&S.jr[base * 16], 16, w, (lds_double*)&S.jr[base * 16 + M], 16, M, n, n);
   for (int i = 0; i < n; ++i) {
     S.sw[p][i] = w[i];
     S.srow[p][i] = base + i;
@@ -521,7 +522,7 @@ __device__ __attribute__((noinline)) void svd_small_seq(Lds& S, double* jW, int 
 __device__ __attribute__((noinline)) void svd12_finish_seq(Lds& S, epnp_exact::Work& xw) {
   for (int i = 0; i < 12; ++i)
     for (int k = 0; k < 12; ++k) xw.ut[i * 12 + k] = S.xch[i][k & 3][k >> 2];     // lane group g = k & 3 holds columns g, 4 + g, 8 + g
-  epnp_exact::jacobi_svd_finish(xw.jW, xw.ut, 12, xw.d, nullptr, 0, 12, 12, 12);
+  epnp_exact::jacobi_svd_finish((lds_double*)xw.jW, (lds_double*)xw.ut, 12, xw.d, (lds_double*)nullptr, 0, 12, 12, 12);
   for (int q = 0; q < 4; ++q)
     for (int k = 0; k < 12; ++k) S.ut4[q][k] = xw.ut[(11 - q) * 12 + k];
   S.flag |= 2; S.why |= 4;

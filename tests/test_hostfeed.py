@@ -250,3 +250,31 @@ def test_stream_modes_per_context(pkg, seq):
             ctx.track_batch_host(s["hL"].ctypes.data + c * 24 * fb, s["hR"].ctypes.data + c * 24 * fb, PITCH, 24, res[c * 24:c * 24 + 24])
         ctx.sync(); ctx.close()
         assert res.tobytes() == want, flags
+
+
+@pytest.mark.gpu
+def test_host_fed_argument_checks_and_capacity(pkg, seq):
+    """Error behaviour of the host-fed entries: return codes, never a crash; a refused call leaves the context usable."""
+    import ctypes as C
+    s = seq
+    ctx = pkg.Svo(s["W"], s["H"], max_batch=8)
+    res = np.zeros(16, pkg.TRACK_DTYPE)
+    L, R = s["hL"], s["hR"]
+    lib = ctx.lib
+    call = lambda l, r, stride, B, out: lib.svo_track_batch_host(ctx.h, l, r, int(stride), int(B), None, out)
+    pl, pr, po = L.ctypes.data_as(C.c_void_p), R.ctypes.data_as(C.c_void_p), res.ctypes.data_as(C.c_void_p)
+    assert call(pl, pr, PITCH, 4, po) == -1                     # no svo_track_reset yet: invalid
+    ctx.track_reset(s["cam"])
+    assert call(None, pr, PITCH, 4, po) == -1 and call(pl, pr, PITCH, 4, None) == -1
+    assert call(pl, pr, s["W"] - 1, 4, po) == -1                # stride below the width
+    assert call(pl, pr, PITCH, 0, po) == -1
+    assert call(pl, pr, PITCH, 9, po) == -5                     # more frames than max_batch: capacity
+    bad = pkg.boxes_host(np.zeros((4, 2, 4), np.int32), np.array([2, 3, 0, 0], np.int32))     # n[1] exceeds the stride
+    assert lib.svo_track_batch_host(ctx.h, pl, pr, PITCH, 4, C.byref(bad), po) == -1
+    assert lib.svo_frontend_batch_host(ctx.h, pl, pr, PITCH, 9, C.byref(s["cam"]), None, None, None, None, None) == -5
+    # the context still tracks
+    want = reference(pkg, s, [8])
+    ctx.track_batch_host(L.ctypes.data, R.ctypes.data, PITCH, 8, res[:8])
+    ctx.sync()
+    ctx.close()
+    assert res[:8].tobytes() == want

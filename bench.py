@@ -568,6 +568,8 @@ def multi_sequence_leg(pkg, cam, dL, dR, frame_bytes, rec, dev, single):
     S, msteps = 64, 48
     ms = pkg.Svo(W, H, device=dev.index or 0, max_kp=500, max_batch=S)
     ms.set_option("multi_pipeline", int(os.environ.get("SVO_BENCH_MULTI_PIPELINE", "1")))   # front end of step t + 1 beside the tail of step t
+    if os.environ.get("SVO_BENCH_TAIL_SEMI"):
+        ms.set_option("tail_semi", int(os.environ["SVO_BENCH_TAIL_SEMI"]))   # 2: the steps' pose chains as two launches (first 8 samples; others + frame parts)
     if os.environ.get("SVO_BENCH_HYP_FIRST"):
         ms.set_option("hyp_first", int(os.environ["SVO_BENCH_HYP_FIRST"]))   # RANSAC samples per sequence in a step's first launch (default 8)
     mres = torch.zeros((msteps * S, rec), dtype=torch.uint8, device=dev)

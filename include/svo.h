@@ -246,6 +246,12 @@ void svo_destroy(svo_ctx* ctx);
  *   sample workgroups + the frame's workgroup, which waits for their agent-scope results) instead of two - the launch boundary
  *   and the frame part's start-up leave the pose chain's critical path (8.74 k -> 8.9-9.0 k frames/s; 9.1-9.2 k with the frame part waiting for the first 8 samples only and the
  *   context's streams on four dispatch pipes).  Same records.
+ * "tail_semi" (default 1): beside a dense stage (depth_source 1 / 2, one sequence) the frame's first 8 RANSAC samples are one launch,
+ *   the other 92 and the frame part a second one (k_tp_hyp_ord_first + k_tp_tail_ord): a sample workgroup of the second launch
+ *   replays cv::solvePnPRansac's iteration bound over the first 8 (beyond sample 16: waits for samples 8..15, replays over 16) and
+ *   leaves when the loop can never reach it - 8 CUs' float64 pipelines per ordinary frame instead of 100 taken from the dense
+ *   kernels, still two launches per frame (configs[4]: 6.1-6.5 k -> 6.4-6.6 k frames/s at 256 frames per call).  2 = also with
+ *   eight or more sequences per step (measured slower: 99.5 k instead of 100.9 k pairs/s; a switch).  0 = off.  Same records.
  * "epnp_force_seq" (default 0, tests): 1 = mode 2 takes its sequential fallback for every sample.
  * "dense_two_launch" (default 0): svo_track_batch_dev with depth_source = 1: the tail beside the dense stage launches its RANSAC
  *   samples as in the many-sequence mode (see "hyp_first") - fewer CUs taken from ELAS on ordinary frames.  Measured: no gain

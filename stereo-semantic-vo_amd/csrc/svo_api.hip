@@ -382,6 +382,7 @@ extern "C" int svo_set_option(svo_ctx* ctx, const char* key, int value) {
     if (ctx->stream_dense) { hipStreamSynchronize(ctx->stream_dense); hipStreamDestroy(ctx->stream_dense); ctx->stream_dense = nullptr; }   // recreated on demand
     return SVO_OK;
   }
+  if (!strcmp(key, "tail_semi")) { if (value < 0 || value > 2) return SVO_E_INVALID; ctx->opt_tail_semi = value; return SVO_OK; }
   if (!strcmp(key, "tail_fused")) { if (value < 0 || value > 2) return SVO_E_INVALID; ctx->opt_tail_fused = value; return SVO_OK; }   // 2: also beside a dense stage
   if (!strcmp(key, "pose_flag")) { ctx->opt_pose_flag = value != 0; return SVO_OK; }
   if (!strcmp(key, "gate_group")) { ctx->opt_gate_group = value != 0; return SVO_OK; }

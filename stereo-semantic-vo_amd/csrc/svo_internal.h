@@ -166,6 +166,7 @@ struct svo_ctx {
   int opt_fast_cand_cap = 2048;   // svo_set_option("fast_cand_cap"): entries of k_fast's candidate list (<= 2048)
   int opt_pose_mfma = 1;   // svo_set_option("pose_mfma"): the LM's sums over the edges - 1 on f64 MFMA (default), 2 one lane per quantity, 0 one lane for everything (svo_pose_dev.h)
   int opt_fe_cu_percent = 12;   // svo_set_option("fe_cu_percent"): share of the CUs the batched tracker's front-end stream may use
+  int opt_tail_semi = 1;   // svo_set_option("tail_semi"): beside a dense stage (2: also many sequences) the first 8 samples, then the other samples + the frame part in one launch
   int opt_tail_fused = 1;  // svo_set_option("tail_fused"): one sequence, default solver: RANSAC samples + frame part in one launch (k_tp_tail_ord)
   int opt_pose_flag = 0;   // svo_set_option("pose_flag"): one sequence's pose kernels poll the index chain's per-frame tag instead of waiting on stream
                            // events.  OFF by default: the poll needs the index kernel to run CONCURRENTLY with the polling one, and a tool that

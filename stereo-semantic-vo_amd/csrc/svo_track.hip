@@ -75,6 +75,7 @@ struct TrackPool {
 // Samples of the fused pose launch whose completion the frame's workgroup waits for one by one: cv::solvePnPRansac's adaptive bound
 // ends within the first 8 samples on 96 % of the frames (a median of 4), and then the other 92 need not be waited for.
 #define TP_EARLY 8
+#define TP_FLAGS 16   // samples that announce themselves one by one (work->hyp_early)
 // What the index chain hands to the pose chain for one frame.
 // Written by k_ti_resolve with agent-scope (sc1) stores and published through `ready`, read by the pose kernels with agent-scope
 // loads after they have seen the tag: the pose chain does not wait on stream events for the index chain (see tp_wait_work).
@@ -93,7 +94,7 @@ struct TrackWork {
   int32_t pnp_best, pnp_iterations, pnp_inliers, pnp_ok;
   double T_pnp[16];
   int32_t hyp_done, pad_hyp;     // fused pose launch (k_tp_tail_ord): RANSAC samples of this frame that have stored their result
-  int32_t hyp_early[TP_EARLY];   // ... and, for the first TP_EARLY samples, frame id + 1 once that sample's result is stored (ids only grow
+  int32_t hyp_early[TP_FLAGS];   // ... and, for the first TP_FLAGS samples, frame id + 1 once that sample's result is stored (ids only grow
                                  // between two resets and a reset clears the records: a stale value never equals the current one)
 };
 
@@ -1150,9 +1151,12 @@ __global__ __launch_bounds__(64) void k_tp_hyp_exact(TrackState* st, TrackWork* 
 struct TpHypOrdLds { double Xw[TRK_MAXKP * 3], uv[TRK_MAXKP * 2]; PnpOrdLds ord; int cnt[TP_HYP_PRE], ok[TP_HYP_PRE], bound; };
 // One sample (called by the 64 lanes of the workgroup's only live wave).  FUSED: the sample belongs to a k_tp_tail_ord launch - its
 // result goes out with agent-scope stores and is announced in work->hyp_done (the frame's workgroup of the SAME launch reads it).
+// SEMI > 0 (FUSED only): the launch holds the samples from SEMI on, the first SEMI were solved by the launch before it on the same
+// stream ("tail_semi", below): a sample the adaptive bound after those can no longer reach announces itself and leaves; one beyond
+// 2 SEMI first waits for samples SEMI .. 2 SEMI - 1 (its own launch, dispatched before it) and applies the rule again.
 template <bool FUSED>
 __device__ __forceinline__ void tp_hyp_ord_body(TpHypOrdLds& S, TrackState* st, TrackWork* work, const svo_kp* kp, const uint16_t* subsets,
-                                                int kstride, int hyp_base, int sample, int tag, int force_seq) {
+                                                int kstride, int hyp_base, int sample, int tag, int force_seq, int semi = 0) {
   if (!tp_wait_work(st, work, tag)) return;
   const long long t_start = clock64();
   if (threadIdx.x == 0 && sample == 0) work->rt[2] = wall_clock64();
@@ -1160,6 +1164,35 @@ __device__ __forceinline__ void tp_hyp_ord_body(TpHypOrdLds& S, TrackState* st, 
   const int frame_tag = FUSED ? ld_agent(&work->frame_id) + 1 : 0;
   if (ld_agent(&work->skip_match) || n < 5) return;
   if (FUSED && (force_seq >> 8) == sample + 1) return;   // test switch "debug_lose_sample": this sample never reports (the frame part's bounded wait)
+  if (FUSED && semi > 0) {
+    const int tid = threadIdx.x;
+    if (tid < semi) { S.cnt[tid] = ld_agent(&st->hyp[tid].cnt); S.ok[tid] = ld_agent(&st->hyp[tid].ok); }
+    __syncthreads();
+    if (tid == 0) S.bound = pnp_bound_after(S.cnt, S.ok, n, semi);
+    __syncthreads();
+    bool leave = sample >= S.bound;
+    if (!leave && sample >= 2 * semi) {   // (the bound after `semi` samples reaches beyond 2 semi: all of semi .. 2 semi - 1 are being solved)
+      if (tid >= semi && tid < 2 * semi) {
+        int spins = 0;
+        while (ld_agent(&work->hyp_early[tid]) != frame_tag && spins < (1 << 22)) { __builtin_amdgcn_s_sleep(2); ++spins; }
+        // (a sample that never reported: this one is solved whatever the rule would have said - solving more samples than the rule
+        // visits changes no outcome; the frame part's own bounded wait reports the loss)
+        const bool late = spins >= (1 << 22);
+        S.cnt[tid] = late ? 0 : ld_agent(&st->hyp[tid].cnt); S.ok[tid] = late ? 0 : ld_agent(&st->hyp[tid].ok);
+      }
+      __syncthreads();
+      if (tid == 0) S.bound = pnp_bound_after(S.cnt, S.ok, n, 2 * semi);
+      __syncthreads();
+      leave = sample >= S.bound;
+    }
+    if (leave) {
+      if (tid == 0) {
+        if (sample < TP_FLAGS) st_agent(&work->hyp_early[sample], frame_tag);
+        __hip_atomic_fetch_add(&work->hyp_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+  }
   if (hyp_base > 0) {   // second launch of a many-sequence step: only the samples the adaptive bound can still reach (see k_tp_hyp)
     const int pre = min(hyp_base, TP_HYP_PRE);   // the rule over the samples of the earlier launches (all of them done: same stream)
     if ((int)threadIdx.x < pre) { S.cnt[threadIdx.x] = st->hyp[threadIdx.x].cnt; S.ok[threadIdx.x] = st->hyp[threadIdx.x].ok; }
@@ -1187,7 +1220,7 @@ __device__ __forceinline__ void tp_hyp_ord_body(TpHypOrdLds& S, TrackState* st, 
   if (FUSED) {
     TP_STORES_DONE();   // (lane 0's agent-scope stores of the sample's result have reached the coherent level)
     if (threadIdx.x == 0) {
-      if (sample < TP_EARLY) st_agent(&work->hyp_early[sample], frame_tag);
+      if (sample < TP_FLAGS) st_agent(&work->hyp_early[sample], frame_tag);
       __hip_atomic_fetch_add(&work->hyp_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -1205,6 +1238,14 @@ __global__ __launch_bounds__(64) void k_tp_hyp_ord(TrackState* st, TrackWork* wo
   TpHypOrdLds& S = *reinterpret_cast<TpHypOrdLds*>(tk_smem);
   st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
   tp_hyp_ord_body<false>(S, st, work, kp, subsets, kstride, hyp_base, hyp_base + (int)blockIdx.x, tag, force_seq);
+}
+// the first samples of a frame whose other samples and frame part follow in a k_tp_tail_ord launch ("tail_semi"): results out with
+// agent-scope stores, each sample announced
+__global__ __launch_bounds__(64) void k_tp_hyp_ord_first(TrackState* st, TrackWork* work, const svo_kp* kp, const uint16_t* subsets,
+                                                         int kstride, int tag, int force_seq) {
+  TpHypOrdLds& S = *reinterpret_cast<TpHypOrdLds*>(tk_smem);
+  st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
+  tp_hyp_ord_body<true>(S, st, work, kp, subsets, kstride, 0, (int)blockIdx.x, tag, force_seq);
 }
 
 // k_tp_frame: RANSAC's acceptance rule over the samples, Optimizer::PoseOptimization, SetPose, the positions of the
@@ -1421,11 +1462,12 @@ __global__ __launch_bounds__(TPF_NT) void k_tp_frame(TrackState* st, TrackWork* 
 union TpTailLds { TpHypOrdLds hyp; TpLds frame; };
 __global__ __launch_bounds__(TPF_NT) void k_tp_tail_ord(TrackState* st, TrackWork* work, const svo_kp* kp, const float* depth,
                                                      const uint16_t* subsets, svo_track_result* res_out, int kstride, int use_mfma,
-                                                     int tag, int force_seq) {
+                                                     int tag, int force_seq, int first_sample) {
   st += blockIdx.y; work += blockIdx.y; kp += (size_t)blockIdx.y * kstride;
-  if (blockIdx.x < PNP_HYP) {
+  if (blockIdx.x < PNP_HYP - first_sample) {
     if (threadIdx.x >= 64) return;
-    tp_hyp_ord_body<true>(*reinterpret_cast<TpHypOrdLds*>(tk_smem), st, work, kp, subsets, kstride, 0, (int)blockIdx.x, tag, force_seq);
+    tp_hyp_ord_body<true>(*reinterpret_cast<TpHypOrdLds*>(tk_smem), st, work, kp, subsets, kstride, 0, first_sample + (int)blockIdx.x, tag, force_seq,
+                          first_sample);
   } else {
     depth += (size_t)blockIdx.y * kstride; res_out += blockIdx.y;
     tp_frame_body<true>(*reinterpret_cast<TpLds*>(tk_smem), st, work, kp, depth, res_out, kstride, use_mfma, tag, 0);
@@ -1572,6 +1614,8 @@ static int track_resources(svo_ctx* ctx, int frames, int nseq) {
                                    (int)sizeof(TpHypLds)) == hipSuccess;
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_hyp_ord), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)sizeof(TpHypOrdLds)) == hipSuccess;
+    ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_hyp_ord_first), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)sizeof(TpHypOrdLds)) == hipSuccess;
     ok = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_tp_tail_ord), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)tail_lds_bytes()) == hipSuccess;
     ctx->track_lds_state = ok ? 1 : -1;
@@ -1684,7 +1728,21 @@ static int tail_enqueue(svo_ctx* ctx, const svo_kp* kp, const uint8_t* desc8, co
       // which the dense kernels running on the same CUs pay for (configs[4]: 6.05 k frames/s fused, 6.85 k with two launches)
       SvoTimer t(ctx, "k_tp_tail_ord");
       hipLaunchKernelGGL(k_tp_tail_ord, dim3(PNP_HYP + 1, 1), dim3(TPF_NT), tail_lds_bytes(), s0, st, work + f, kpf, depf, ctx->d_pnp_subsets,
-                         d_res + f, kstride, ctx->opt_pose_mfma, tag_of(f), ctx->opt_epnp_force_seq | (ctx->opt_debug_lose_sample << 8));
+                         d_res + f, kstride, ctx->opt_pose_mfma, tag_of(f), ctx->opt_epnp_force_seq | (ctx->opt_debug_lose_sample << 8), 0);
+      return;
+    }
+    if (ctx->opt_epnp_exact == 2 && ctx->opt_tail_fused && ctx->opt_tail_semi && ((ny == 1 && ctx->opt_depth_source != 0) || (ny >= 8 && ctx->opt_tail_semi == 2))) {
+      // beside a dense stage (or, "tail_semi" = 2, many sequences): the first TP_EARLY samples, then the other samples and the frame
+      // part in one launch - 8 CUs' float64 pipelines per ordinary frame instead of 100 taken from the dense kernels, and no more launches.  cv::solvePnPRansac ends within 8 samples on 96 % of the frames: the second
+      // launch's sample workgroups replay the rule and leave at once, the frame part starts with them.
+      const int fs = ctx->opt_epnp_force_seq | (ctx->opt_debug_lose_sample << 8);
+      {
+        SvoTimer t(ctx, "k_tp_hyp_ord");
+        hipLaunchKernelGGL(k_tp_hyp_ord_first, dim3(TP_EARLY, ny), dim3(64), sizeof(TpHypOrdLds), s0, st, work + f, kpf, ctx->d_pnp_subsets, kstride, tag_of(f), fs);
+      }
+      SvoTimer t(ctx, "k_tp_tail_ord");
+      hipLaunchKernelGGL(k_tp_tail_ord, dim3(PNP_HYP - TP_EARLY + 1, ny), dim3(TPF_NT), tail_lds_bytes(), s0, st, work + f, kpf, depf, ctx->d_pnp_subsets,
+                         d_res + f, kstride, ctx->opt_pose_mfma, tag_of(f), fs, TP_EARLY);
       return;
     }
     if (ctx->opt_epnp_exact == 2) {

@@ -492,3 +492,45 @@ def test_a_sample_that_never_reports_makes_its_frame_a_pnp_failure_not_a_stale_p
         assert np.linalg.norm(c_got - c_want) < 0.1, k
     ctx.sync()                                              # (reported once; the context stays usable)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_dense_stage_pose_chain_in_two_launches_equals_the_separate_launches(pkg):
+    """depth_source = 1, one sequence ("tail_semi", default 1): the frame's first 8 RANSAC samples go out as one launch, the other 92
+    and the frame part as a second one whose sample workgroups replay cv::solvePnPRansac's iteration bound and leave (or, beyond
+    sample 16, first wait for samples 8..15 of their own launch).  Records and RANSAC outcomes must equal the chain with all 100
+    samples solved in a launch of their own ("tail_semi" = 0) - on a sequence cut so that some frames need more than 8 and more
+    than 16 samples (every third frame of the synthetic drive: three times the motion between frames)."""
+    import importlib
+    import torch
+    synth = importlib.import_module("stereo_semantic_vo_amd.synth")
+    dev = torch.device("cuda", 0)
+    n_all = 72
+    L, R, _ = synth.render_sequence(n_all, device=dev)
+    idx = torch.tensor([0, 1, 2, 3] + list(range(6, n_all, 3)), device=dev)
+    n = int(idx.numel())
+    H, W = int(L.shape[1]), int(L.shape[2])
+    pitch = 1280
+    dL = torch.zeros((n, H, pitch), dtype=torch.uint8, device=dev); dR = torch.zeros_like(dL)
+    dL[:, :, :W] = L[idx]; dR[:, :, :W] = R[idx]
+    cam = pkg.Camera(**pkg.KITTI_00_02)
+    rec = pkg.TRACK_DTYPE.itemsize
+    runs = {}
+    for semi in (0, 1):
+        ctx = pkg.Svo(W, H, max_batch=n)
+        ctx.set_option("depth_source", 1)
+        ctx.set_option("tail_semi", semi)
+        ctx.track_reset(cam)
+        res = torch.zeros((n, rec), dtype=torch.uint8, device=dev)
+        ctx.track_batch_dev(dL.data_ptr(), dR.data_ptr(), pitch, n, res.data_ptr())
+        ctx.sync()
+        assert ctx.track_overflowed() == 0
+        dbg = ctx.debug_track_frames(0, n)
+        runs[semi] = (res.cpu().numpy().tobytes(), dbg["pnp_best"].copy(), dbg["pnp_iterations"].copy(), dbg["pnp_inliers"].copy())
+        ctx.close()
+    it = runs[0][2]
+    assert (it > 8).any() and (it > 16).any(), it          # the sequence exercises all three kinds of sample workgroup
+    assert (it <= 8).sum() >= 4
+    for k in range(1, 4):
+        assert np.array_equal(runs[0][k], runs[1][k]), k
+    assert runs[0][0] == runs[1][0]

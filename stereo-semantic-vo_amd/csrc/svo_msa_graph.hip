@@ -31,6 +31,33 @@ namespace {
 
 std::atomic<int> g_active_builders{0};
 
+// SVO_MSA_STAGE_STATS=1: host time per stage summed over all builders (under whatever load they run), printed at exit
+struct StageStats {
+  std::atomic<long long> ns[8];
+  std::atomic<long long> trees{0};
+  const bool on = getenv("SVO_MSA_STAGE_STATS") != nullptr;
+  StageStats() { for (auto& x : ns) x = 0; }
+  ~StageStats() {
+    if (!on || trees == 0) return;
+    static const char* name[8] = {"heaps per pixel", "contraction", "expansion", "links + roots", "label_regions", "merge_regions", "bfs records", ""};
+    long long tot = 0;
+    for (int k = 0; k < 7; ++k) tot += ns[k];
+    fprintf(stderr, "[msa stages] %lld trees, %.2f ms each:", (long long)trees, tot * 1e-6 / trees);
+    for (int k = 0; k < 7; ++k) fprintf(stderr, "  %s %.2f", name[k], ns[k] * 1e-6 / trees);
+    fprintf(stderr, "\n");
+  }
+};
+StageStats g_stats;
+struct StageClock {
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(int k) {
+    if (!g_stats.on) return;
+    const auto now = std::chrono::steady_clock::now();
+    g_stats.ns[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(now - t).count();
+    t = now;
+  }
+};
+
 // The directed graph is implicit: pixel p owns five arc slots e = 5p + k for the arcs INTO p - k = 0 from the
 // super-root (weight 1e9), 1 from its left neighbour, 2 right, 3 up, 4 down (present or not) - which is also the
 // order in which the reference inserts them into p's heap (its horizontal loop visits the pair (p-1, p) before
@@ -75,6 +102,47 @@ class EdgeHeaps {
     return sub;
   }
   bool broken = false;   // a merge path longer than any leftist heap can have: the structure is corrupt, the caller gives up
+  // A pixel's own heap - the super-root's arc, then whichever of the four neighbour arcs exist, inserted in slot order - has one of
+  // a few thousand shapes: the merges compare keys with `>` only, so the shape is a function of which arcs exist (4 bits) and of
+  // how their weights rank among each other (rank = how many of the others are smaller: 2 bits each; the super-root's 1e9 is
+  // above them all).  All shapes are built once with the merges themselves and kept as 63-bit templates - per node (slot + 1):
+  // left, right, rank, left's rank in 3 bits each, then the root - and a pixel's heap is written from its template instead of
+  // being merged together (12 % of a tree's host time were those four merges per pixel).
+  static const uint64_t* pixel_templates() {
+    static std::vector<uint64_t> tab;
+    static std::once_flag once;
+    std::call_once(once, [] {
+      tab.assign(16 * 256, 0);
+      EdgeHeaps tmp;
+      tmp.reset(5);
+      std::vector<int> spine;
+      for (int mask = 0; mask < 16; ++mask)
+        for (int code = 0; code < 256; ++code) {
+          tmp.init(1, 1000);
+          int h = 1;
+          for (int slot = 1; slot <= 4; ++slot)
+            if (mask >> (slot - 1) & 1) { tmp.init(slot + 1, (code >> (2 * (slot - 1))) & 3); h = tmp.meld(h, slot + 1, spine); }
+          uint64_t t = (uint64_t)h << 60;
+          for (int k = 0; k < 5; ++k) {
+            const Node& nd = tmp.node_[k + 1];
+            t |= (uint64_t)((unsigned)nd.left | (unsigned)nd.right << 3 | (unsigned)nd.rank << 6 | (unsigned)nd.lrank << 9) << (12 * k);
+          }
+          tab[mask << 8 | code] = t;
+        }
+    });
+    return tab.data();
+  }
+  // writes the nodes base + 1 (+ slot) of one pixel from template t (keys: SR_W for slot 0, w[slot - 1] for the others); returns the root
+  int place_pixel(int base, uint64_t t, int mask, int sr_w, const int* w) {
+    auto put = [&](int k, int key) {
+      const unsigned f = (unsigned)(t >> (12 * k)) & 0xfffu, l = f & 7u, r = (f >> 3) & 7u;
+      node_[base + 1 + k] = Node{l ? base + (int)l : 0, r ? base + (int)r : 0, key, (uint16_t)((f >> 6) & 7u), (uint16_t)((f >> 9) & 7u)};
+    };
+    put(0, sr_w);
+    for (int k = 1; k <= 4; ++k)
+      if (mask >> (k - 1) & 1) put(k, w[k - 1]);
+    return base + (int)(t >> 60);
+  }
   int meld(int a, int b) { return meld(a, b, spine_); }
   int drop_min(int h) { return meld(node_[h].left, node_[h].right); }
   void subtract(int h, int delta) {   // from every key of heap h
@@ -112,17 +180,14 @@ struct Contraction {
   std::vector<int> up, grp;
   void reset(int n) { up.resize(n + 1); grp.resize(n + 1); for (int i = 0; i <= n; ++i) { up[i] = i; grp[i] = i; } }
   int find(int x) {
-    path_.clear();
+    // two walks instead of a recorded path: up to the top, then again re-pointing everything below `below_top` at it
     const int x0 = x;
-    while (x != up[x]) { path_.push_back(x); x = up[x]; }
+    int below = x;
+    while (x != up[x]) { below = x; x = up[x]; }
     if (up[x0] == x || up[x0] == x0) return x0;
-    const int below_top = path_.back();
-    path_.pop_back();
-    for (int p : path_) up[p] = below_top;
-    return below_top;
+    for (int p = x0; p != below;) { const int nx = up[p]; up[p] = below; p = nx; }
+    return below;
   }
- private:
-  std::vector<int> path_;
 };
 
 struct Link { int32_t to, w, next; };   // adjacency chains, newest first, as TreeDp walks them
@@ -161,10 +226,17 @@ class TreeBuilder {
   int run_rec(const uint8_t* img3, const double* gx, const double* gy, MsaBfsRec* rec, std::vector<int32_t>& level_ptr, int* maxw) {
     img3_ = img3;
     dbg_mark_ = nullptr;
+    StageClock clk;
+    stage_clock_ = &clk;
     arborescence(gx, gy);
+    stage_clock_ = nullptr;
+    clk.lap(3);
     if (roots_.empty()) return -1;
     if (heaps_.broken || !label_regions()) return -2;        // not a forest over the roots
+    clk.lap(4);
     merge_regions();
+    clk.lap(5);
+    struct Done { StageClock& c; ~Done() { c.lap(6); if (g_stats.on) ++g_stats.trees; } } done{clk};
     std::vector<int32_t>& parent = parent_;
     parent.assign(N_, -1);
     level_ptr.clear(); level_ptr.push_back(0);
@@ -235,7 +307,9 @@ class TreeBuilder {
   std::vector<Cand> cand_;
   const uint8_t* img3_ = nullptr;
   std::chrono::steady_clock::time_point* dbg_mark_ = nullptr;
+  StageClock* stage_clock_ = nullptr;
   void sub_mark(const char* what) {
+    if (stage_clock_) stage_clock_->lap(what[0] == 'h' ? 0 : what[0] == 'c' ? 1 : 2);
     if (!dbg_mark_) return;
     const auto now = std::chrono::steady_clock::now();
     fprintf(stderr, "[msa tree]   %-22s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - *dbg_mark_).count());
@@ -271,26 +345,28 @@ class TreeBuilder {
     auto arc_weight = [&](int e) { return e % 5 == 0 ? SR_W : (int)arc_w[e]; };
     {
       // every pixel's heap of incoming arcs depends on that pixel alone: built in row bands on a few threads
+      const uint64_t* templates = EdgeHeaps::pixel_templates();
       auto band = [&](int row0, int row1) {
-        std::vector<int> spine;
         for (int i = row0; i < row1; ++i)
           for (int j = 0; j < m_; ++j) {
             const int p = i * m_ + j;
-            int h = 5 * p + 1;
-            heaps.init(h, SR_W);
-            auto add = [&](int slot, int q) {
-              const int e = 5 * p + slot, w = colour_gap(p, q);
-              arc_w[e] = (uint8_t)w;
-              heaps.init(e + 1, w);
-              h = heaps.meld(h, e + 1, spine);
-            };
             // an arc runs from the flatter pixel to the steeper one, both ways when the gradient magnitudes differ
             // by less than 1 (the reference truncates the difference to int); a = left / upper pixel of the pair
-            if (j > 0 && (int)(fabs(gx[p - 1]) - fabs(gx[p])) <= 0) add(1, p - 1);
-            if (j + 1 < m_ && (int)(fabs(gx[p]) - fabs(gx[p + 1])) >= 0) add(2, p + 1);
-            if (i > 0 && (int)(fabs(gy[p - m_]) - fabs(gy[p])) <= 0) add(3, p - m_);
-            if (i + 1 < n_ && (int)(fabs(gy[p]) - fabs(gy[p + m_])) >= 0) add(4, p + m_);
-            incoming[p] = h;
+            int mask = 0, w[4] = {0, 0, 0, 0};
+            if (j > 0 && (int)(fabs(gx[p - 1]) - fabs(gx[p])) <= 0) { mask |= 1; w[0] = colour_gap(p, p - 1); }
+            if (j + 1 < m_ && (int)(fabs(gx[p]) - fabs(gx[p + 1])) >= 0) { mask |= 2; w[1] = colour_gap(p, p + 1); }
+            if (i > 0 && (int)(fabs(gy[p - m_]) - fabs(gy[p])) <= 0) { mask |= 4; w[2] = colour_gap(p, p - m_); }
+            if (i + 1 < n_ && (int)(fabs(gy[p]) - fabs(gy[p + m_])) >= 0) { mask |= 8; w[3] = colour_gap(p, p + m_); }
+            // rank of each existing arc's weight among the others (how many of them are smaller)
+            int code = 0;
+            for (int a = 0; a < 4; ++a) {
+              if (!(mask >> a & 1)) continue;
+              int r = 0;
+              for (int b = 0; b < 4; ++b) r += (mask >> b & 1) && w[b] < w[a];
+              code |= r << (2 * a);
+              arc_w[5 * p + 1 + a] = (uint8_t)w[a];
+            }
+            incoming[p] = heaps.place_pixel(5 * p, templates[mask << 8 | code], mask, SR_W, w);
           }
       };
       // (alone: four threads; with many builders running side by side the cores are taken already)
@@ -327,7 +403,7 @@ class TreeBuilder {
       chosen_from[v] = u; chosen_key[v] = w; chosen_edge[v] = pick;
       const int cv = con.find(pick / 5), top_v = con.up[cv];
       entry[top_v] = pick;
-      if (weak.find(u) != weak.find(v)) { weak.unite(v, u); continue; }
+      { const int wu = weak.find(u), wv = weak.find(v); if (wu != wv) { weak.up[wu] = wv; continue; } }   // (= weak.unite(v, u))
       // u already reaches v: the chosen edges close a cycle -> contract it into a new super-node
       con.up[top_v] = n_super++;
       con.grp[top_v] = con.up[top_v];
@@ -351,7 +427,9 @@ class TreeBuilder {
     }
     sub_mark("contraction");
     // expansion phase: newest super-nodes first, each keeps the entering edge that was chosen for it
-    for (int i = 0; i < n_super; ++i) { con.find(i); chosen_from[i] = -1; }
+    // (the reference compresses every contraction path once more here, :1266-1270 - DFU2's result is not used and the walk below
+    // follows grp, not up: dropped)
+    std::fill(chosen_from.begin(), chosen_from.begin() + n_super, -1);
     std::vector<uint8_t>& done = done_;
     done.assign(n_super, 0);
     for (int i = n_super - 1; i >= 0; --i) {

@@ -173,23 +173,6 @@ struct Sets {   // union-find with full path compression; unite(a, b) makes a's 
   void unite(int a, int b) { a = find(a); b = find(b); up[b] = a; }
 };
 
-// The contraction forest of the arborescence algorithm: `up` links a (super-)node to the cycle node that absorbed
-// it, `grp` remembers that cycle node for the expansion.  find() stops one step BELOW the top (the reference's DFU2,
-// :1299-1313) - the caller reads the top as up[find(x)].
-struct Contraction {
-  std::vector<int> up, grp;
-  void reset(int n) { up.resize(n + 1); grp.resize(n + 1); for (int i = 0; i <= n; ++i) { up[i] = i; grp[i] = i; } }
-  int find(int x) {
-    // two walks instead of a recorded path: up to the top, then again re-pointing everything below `below_top` at it
-    const int x0 = x;
-    int below = x;
-    while (x != up[x]) { below = x; x = up[x]; }
-    if (up[x0] == x || up[x0] == x0) return x0;
-    for (int p = x0; p != below;) { const int nx = up[p]; up[p] = below; p = nx; }
-    return below;
-  }
-};
-
 struct Link { int32_t to, w, next; };   // adjacency chains, newest first, as TreeDp walks them
 
 class TreeBuilder {
@@ -237,8 +220,11 @@ class TreeBuilder {
     merge_regions();
     clk.lap(5);
     struct Done { StageClock& c; ~Done() { c.lap(6); if (g_stats.on) ++g_stats.trees; } } done{clk};
+    // the parent of the node at level-order position t, kept BY POSITION (written and read in sequence: the walk's random
+    // accesses are the adjacency chains alone)
     std::vector<int32_t>& parent = parent_;
-    parent.assign(N_, -1);
+    parent.resize(N_);
+    parent[0] = -1;
     level_ptr.clear(); level_ptr.push_back(0);
     int n_seq = 1, level_end = 1, w = 0;
     bool fits = true;
@@ -249,14 +235,15 @@ class TreeBuilder {
         level_ptr.push_back(t);
         level_end = n_seq;
       }
-      const int u = rec[t].node, first = n_seq;
-      for (int i = head_[u]; i >= 0; i = link_[i].next) {
-        const int v = link_[i].to;
-        if (v == parent[u]) continue;
-        if (n_seq == N_) return -2;   // not a tree
-        rec[n_seq++] = MsaBfsRec{0, link_[i].w, t, v};
-        parent[v] = u;
-      }
+      const int u = rec[t].node, first = n_seq, pu = parent[t];
+      bool overrun = false;
+      neighbours(u, [&](int v, int wv) {
+        if (v == pu || overrun) return;
+        if (n_seq == N_) { overrun = true; return; }   // not a tree (a cycle: more arrivals than pixels)
+        parent[n_seq] = u;
+        rec[n_seq++] = MsaBfsRec{0, wv, t, v};
+      });
+      if (overrun) return -2;
       const int nch = n_seq - first;
       if (nch > 255) fits = false;
       rec[t].cpos = first;
@@ -278,29 +265,34 @@ class TreeBuilder {
     seq[n_seq++] = roots_[0];
     for (int t = 0; t < n_seq; ++t) {
       const int u = seq[t];
-      for (int i = head_[u]; i >= 0; i = link_[i].next) {
-        const int v = link_[i].to;
-        if (v == parent[u]) continue;
-        if (n_seq == N_) return -2;   // not a tree
+      bool overrun = false;
+      neighbours(u, [&](int v, int) {
+        if (v == parent[u] || overrun) return;
+        if (n_seq == N_) { overrun = true; return; }   // not a tree
         seq[n_seq++] = v;
         parent[v] = u;
-      }
+      });
+      if (overrun) return -2;
     }
     if (n_seq != N_) return -2;
     int n_child = 0;
     child_ptr[0] = 0;
     for (int u = 0; u < N_; ++u) {
-      for (int i = head_[u]; i >= 0; i = link_[i].next)
-        if (link_[i].to != parent[u]) { child[n_child] = link_[i].to; child_w[n_child] = (uint8_t)link_[i].w; ++n_child; }
+      neighbours(u, [&](int v, int wv) {
+        if (v != parent[u]) { child[n_child] = v; child_w[n_child] = (uint8_t)wv; ++n_child; }
+      });
       child_ptr[u + 1] = n_child;
     }
     return roots_[0];
   }
   int n_ = 0, m_ = 0, N_ = 0;
   EdgeHeaps heaps_;
-  Sets strong_, weak_, merged_;
-  Contraction con_;
-  std::vector<int> incoming_, chosen_from_, chosen_key_, chosen_edge_, entry_, todo_, size_, sum_;
+  Sets merged_;
+  struct Vtx { int strong, weak, incoming, from, key, edge; };
+  struct Cnode { int up, grp, entry; };   // `up` links a (super-)node to the cycle node that absorbed it, `grp` remembers it for the expansion, `entry`: the arc chosen into it
+  std::vector<Vtx> vtx_;
+  std::vector<Cnode> con_;
+  std::vector<int> chosen_from_, chosen_key_, todo_, size_, sum_;
   std::vector<uint8_t> arc_w_, done_;
   std::vector<int32_t> parent_;
   struct Cand { int a, b, w; double key; };
@@ -315,13 +307,40 @@ class TreeBuilder {
     fprintf(stderr, "[msa tree]   %-22s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - *dbg_mark_).count());
     *dbg_mark_ = now;
   }
+  // The tree's adjacency.  TreeDp walks a pixel's edges newest first (adjacency chains filled by push-front): the edges of the
+  // region merging, made last, come first (head_ / link_: chains, a few thousand edges), then the arborescence's - made in pixel
+  // order, one per non-root pixel p between p and its parent, so that a pixel's chain reads: its children below and right of it
+  // (p + m, p + 1), its own parent, its children left of and above it (p - 1, p - m).  Every arborescence edge joins
+  // 4-neighbours, so they are kept as ONE byte per pixel (adj_: bits 0-3 child at +m / +1 / -1 / -m, bits 4-6 where the parent is:
+  // 1 +m, 2 +1, 3 -1, 4 -m, bit 7: the pixel has merge edges) and the weight of a pixel's parent edge (wpar_) - 0.9 MB that stay in
+  // the caches instead of 11 MB of chain links the breadth-first walk met at random (17 % of a tree's host time).
   std::vector<int32_t> head_;
   std::vector<Link> link_;
+  std::vector<uint8_t> adj_, wpar_;
+  int n_arb_ = 0;   // arborescence edges
+  size_t edge_links() const { return 2 * (size_t)n_arb_ + link_.size(); }   // what link_.size() was when every edge was a pair of links
+  template <class F>
+  void neighbours(int u, F&& f) const {
+    const unsigned a = adj_[u];
+    if (a & 0x80u) for (int i = head_[u]; i >= 0; i = link_[i].next) f(link_[i].to, link_[i].w);
+    if (a & 1u) f(u + m_, (int)wpar_[u + m_]);
+    if (a & 2u) f(u + 1, (int)wpar_[u + 1]);
+    switch ((a >> 4) & 7u) {
+      case 1: f(u + m_, (int)wpar_[u]); break;
+      case 2: f(u + 1, (int)wpar_[u]); break;
+      case 3: f(u - 1, (int)wpar_[u]); break;
+      case 4: f(u - m_, (int)wpar_[u]); break;
+      default: break;
+    }
+    if (a & 4u) f(u - 1, (int)wpar_[u - 1]);
+    if (a & 8u) f(u - m_, (int)wpar_[u - m_]);
+  }
   std::vector<int32_t> roots_, region_, region_max_, order_;
 
   void connect(int u, int v, int w) {
     link_.push_back({v, w, head_[u]}); head_[u] = (int)link_.size() - 1;
     link_.push_back({u, w, head_[v]}); head_[v] = (int)link_.size() - 1;
+    adj_[u] |= 0x80u; adj_[v] |= 0x80u;
   }
   int colour_gap(int a, int b) const {
     int g = 0;
@@ -334,8 +353,11 @@ class TreeBuilder {
     const int SR_W = 1000000000;
     EdgeHeaps& heaps = heaps_;
     heaps.reset((size_t)N_ * 5);
-    std::vector<int>& incoming = incoming_;
-    incoming.assign(N_ + 1, 0);
+    // per vertex (pixel or super-root), in ONE record: what the contraction reads and writes together for a vertex - the two
+    // union-finds' links, its heap, the arc chosen for it (six arrays before: a vertex met at random cost six cache misses)
+    std::vector<Vtx>& vtx = vtx_;
+    vtx.resize(N_ + 1);
+    for (int i = 0; i <= N_; ++i) vtx[i] = Vtx{i, i, 0, -1, 0, -1};
     std::vector<uint8_t>& arc_w = arc_w_;   // weights of the neighbour arcs (slot 0 is SR_W)
     arc_w.resize((size_t)N_ * 5);
     auto arc_from = [&](int e) {
@@ -366,7 +388,7 @@ class TreeBuilder {
               code |= r << (2 * a);
               arc_w[5 * p + 1 + a] = (uint8_t)w[a];
             }
-            incoming[p] = heaps.place_pixel(5 * p, templates[mask << 8 | code], mask, SR_W, w);
+            vtx[p].incoming = heaps.place_pixel(5 * p, templates[mask << 8 | code], mask, SR_W, w);
           }
       };
       // (alone: four threads; with many builders running side by side the cores are taken already)
@@ -379,81 +401,116 @@ class TreeBuilder {
 
     sub_mark("heaps per pixel");
     // contraction phase
-    std::vector<int>&chosen_from = chosen_from_, &chosen_key = chosen_key_, &chosen_edge = chosen_edge_, &entry = entry_, &todo = todo_;
-    chosen_from.assign(2 * N_ + 2, -1); chosen_key.assign(2 * N_ + 2, 0); chosen_edge.assign(N_ + 1, -1); entry.assign(2 * N_ + 2, -1);
+    std::vector<int>& todo = todo_;
     todo.resize(N_ + 1);
     for (int i = 0; i <= N_; ++i) todo[i] = i;
-    Sets &strong = strong_, &weak = weak_;
-    strong.reset(N_); weak.reset(N_);
-    Contraction& con = con_;
-    con.reset(2 * N_);
+    // the contraction forest, one record per (super-)node: see Contraction
+    std::vector<Cnode>& con = con_;
+    con.resize(2 * N_ + 2);
+    for (int i = 0; i < 2 * N_ + 2; ++i) con[i] = Cnode{i, i, -1};
+    auto strong_find = [&](int x) {   // union-find with full path compression
+      int r = x;
+      while (vtx[r].strong != r) r = vtx[r].strong;
+      while (x != r) { const int nx = vtx[x].strong; vtx[x].strong = r; x = nx; }
+      return r;
+    };
+    auto weak_find = [&](int x) {
+      int r = x;
+      while (vtx[r].weak != r) r = vtx[r].weak;
+      while (x != r) { const int nx = vtx[x].weak; vtx[x].weak = r; x = nx; }
+      return r;
+    };
+    auto strong_unite = [&](int a, int b) { a = strong_find(a); b = strong_find(b); vtx[b].strong = a; };   // a's root stays the root
+    // stops one step BELOW the top (the reference's DFU2, :1299-1313) - the caller reads the top as con[.].up
+    auto con_find = [&](int x) {
+      const int x0 = x;
+      int below = x;
+      while (x != con[x].up) { below = x; x = con[x].up; }
+      if (con[x0].up == x || con[x0].up == x0) return x0;
+      for (int q = x0; q != below;) { const int nx = con[q].up; con[q].up = below; q = nx; }
+      return below;
+    };
     int n_super = N_ + 1;
     while (!todo.empty()) {
       const int v = todo.back(); todo.pop_back();
-      if (v != strong.find(v)) continue;
+      if (v != strong_find(v)) continue;
+      Vtx& V = vtx[v];
       int u = -1, w = 0, pick = -1;
       bool found = false;
-      while (incoming[v]) {
-        w = heaps.key(incoming[v]); pick = EdgeHeaps::arc(incoming[v]);
-        incoming[v] = heaps.drop_min(incoming[v]);
-        u = strong.find(arc_from(pick));
+      while (V.incoming) {
+        w = heaps.key(V.incoming); pick = EdgeHeaps::arc(V.incoming);
+        V.incoming = heaps.drop_min(V.incoming);
+        u = strong_find(arc_from(pick));
         if (u != v) { found = true; break; }
       }
       if (!found) continue;   // the super-root
-      chosen_from[v] = u; chosen_key[v] = w; chosen_edge[v] = pick;
-      const int cv = con.find(pick / 5), top_v = con.up[cv];
-      entry[top_v] = pick;
-      { const int wu = weak.find(u), wv = weak.find(v); if (wu != wv) { weak.up[wu] = wv; continue; } }   // (= weak.unite(v, u))
+      V.from = u; V.key = w; V.edge = pick;
+      const int cv = con_find(pick / 5), top_v = con[cv].up;
+      con[top_v].entry = pick;
+      { const int wu = weak_find(u), wv = weak_find(v); if (wu != wv) { vtx[wu].weak = wv; continue; } }   // (= unite(v, u))
       // u already reaches v: the chosen edges close a cycle -> contract it into a new super-node
-      con.up[top_v] = n_super++;
-      con.grp[top_v] = con.up[top_v];
-      auto settle = [&](int x) { if (chosen_key[x] > 0) { heaps.subtract(incoming[x], chosen_key[x]); chosen_key[x] = 0; } };
+      const int super = n_super++;
+      con[top_v].up = super;
+      con[top_v].grp = super;
+      auto settle = [&](int x) { if (vtx[x].key > 0) { heaps.subtract(vtx[x].incoming, vtx[x].key); vtx[x].key = 0; } };
       settle(v);
-      for (int ek = chosen_edge[u], k = strong.find(chosen_from[u]); k != v; ek = chosen_edge[k], k = strong.find(chosen_from[k])) {
-        const int ck = con.find(arc_from(ek)), top_k = con.up[ck];
-        con.up[top_k] = con.up[top_v];
-        con.grp[top_k] = con.grp[top_v];
-        strong.unite(v, k);
+      for (int ek = vtx[u].edge, k = strong_find(vtx[u].from); k != v; ek = vtx[k].edge, k = strong_find(vtx[k].from)) {
+        const int ck = con_find(arc_from(ek)), top_k = con[ck].up;
+        con[top_k].up = super;
+        con[top_k].grp = super;
+        strong_unite(v, k);
         settle(k);
-        incoming[v] = heaps.meld(incoming[v], incoming[k]);
+        V.incoming = heaps.meld(V.incoming, vtx[k].incoming);
       }
       settle(u);
-      const int cu = con.find(arc_from(pick)), top_u = con.up[cu];
-      con.up[top_u] = con.up[top_v];
-      con.grp[top_u] = con.grp[top_v];
-      strong.unite(v, u);
-      incoming[v] = heaps.meld(incoming[v], incoming[u]);
+      const int cu = con_find(arc_from(pick)), top_u = con[cu].up;
+      con[top_u].up = super;
+      con[top_u].grp = super;
+      strong_unite(v, u);
+      V.incoming = heaps.meld(V.incoming, vtx[u].incoming);
       todo.push_back(v);
     }
     sub_mark("contraction");
     // expansion phase: newest super-nodes first, each keeps the entering edge that was chosen for it
     // (the reference compresses every contraction path once more here, :1266-1270 - DFU2's result is not used and the walk below
     // follows grp, not up: dropped)
-    std::fill(chosen_from.begin(), chosen_from.begin() + n_super, -1);
+    std::vector<int>&chosen_from = chosen_from_, &chosen_key = chosen_key_;
+    chosen_from.assign(N_ + 1, -1); chosen_key.assign(N_ + 1, 0);
     std::vector<uint8_t>& done = done_;
     done.assign(n_super, 0);
     for (int i = n_super - 1; i >= 0; --i) {
       if (i == SR || done[i]) continue;
       done[i] = 1;
-      const int k = entry[i];
+      const int k = con[i].entry;
       if (k < 0) continue;
       int u = k / 5;
       while (u != i) {
         done[u] = 1;
-        u = con.grp[u];
-        if (u == con.grp[u]) break;
+        u = con[u].grp;
+        if (u == con[u].grp) break;
       }
       if (u == i) { chosen_from[k / 5] = arc_from(k); chosen_key[k / 5] = arc_weight(k); }
     }
     sub_mark("expansion");
     head_.assign(N_ + 1, -1);
-    link_.clear(); link_.reserve((size_t)N_ * 2 + 4);
+    link_.clear();
+    adj_.assign(N_, 0); wpar_.assign(N_, 0);
+    n_arb_ = 0;
     roots_.clear();
+    bool odd_edge = false;
     for (int p = 0; p < N_; ++p) {
-      if (chosen_from[p] < 0) continue;
-      if (chosen_from[p] < N_) connect(chosen_from[p], p, chosen_key[p]);
-      else roots_.push_back(p);
+      const int q = chosen_from[p];
+      if (q < 0) continue;
+      if (q >= N_) { roots_.push_back(p); continue; }
+      // the arborescence edge q -> p: between 4-neighbours (the arcs are)
+      const int dir = q == p + m_ ? 1 : q == p + 1 ? 2 : q == p - 1 ? 3 : q == p - m_ ? 4 : 0;
+      if (!dir) { odd_edge = true; continue; }
+      adj_[p] |= (uint8_t)(dir << 4);
+      adj_[q] |= (uint8_t)(dir == 1 ? 8 : dir == 2 ? 4 : dir == 3 ? 2 : 1);   // seen from q, p is the opposite way
+      wpar_[p] = (uint8_t)chosen_key[p];
+      ++n_arb_;
     }
+    if (odd_edge) roots_.clear();   // (cannot happen: run() then reports the failure)
   }
 
   // region id and largest edge per tree of the forest (the reference's getSeq0 walks the forest breadth-first from all roots for
@@ -514,7 +571,7 @@ class TreeBuilder {
     Sets& merged = merged_;
     merged.reset((int)roots_.size());
     const size_t full = (size_t)(N_ - 1) * 2;
-    for (size_t i = 0; i < cand.size() && link_.size() < full; ++i) {
+    for (size_t i = 0; i < cand.size() && edge_links() < full; ++i) {
       const int u = cand[i].a, v = cand[i].b, c = cand[i].w;
       const int fu = merged.find(region_[u]), fv = merged.find(region_[v]);
       const int s_u = size[roots_[region_[u]]], s_v = size[roots_[region_[v]]];
@@ -529,7 +586,7 @@ class TreeBuilder {
         region_[v] = region_[u];
       }
     }
-    for (size_t i = 0; i < cand.size() && link_.size() < full; ++i) {
+    for (size_t i = 0; i < cand.size() && edge_links() < full; ++i) {
       const int u = cand[i].a, v = cand[i].b;
       const int fu = merged.find(region_[u]), fv = merged.find(region_[v]);
       if (fu != fv) { connect(u, v, 255); merged.up[fu] = fv; }

@@ -207,7 +207,12 @@ int feed_upload(svo_ctx* ctx, int p, const uint8_t* grayL, const uint8_t* grayR,
     }
   };
   std::vector<std::thread> pool;
-  for (int t = 0; t < T; ++t) pool.emplace_back(worker, t);
+  pool.reserve((size_t)T);
+  int started = 0;
+  // (std::thread's constructor may throw; an exception must not unwind past joinable threads: the shares of the threads that
+  // could not be started are staged here, before the uploads)
+  try { for (; started < T; ++started) pool.emplace_back(worker, started); } catch (...) {}
+  for (int t = started; t < T; ++t) worker(t);
   int rc = SVO_OK;
   for (int c = 0; c < nchunk; ++c) {
     while (!staged[c].load(std::memory_order_acquire)) std::this_thread::yield();

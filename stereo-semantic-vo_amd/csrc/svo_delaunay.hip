@@ -33,34 +33,39 @@ namespace {
 struct Pt { int32_t x, y, id; };
 
 struct QuadEdge {
-  std::vector<int32_t> nxt;   // Onext of each of the 4 directed edges of a quad
-  std::vector<int32_t> org;   // origin vertex (slot in `p`) of the primal edges, -1 on dual edges
-  std::vector<uint8_t> dead;  // per quad
+  // one record per quad (an undirected edge with its dual): Onext of its 4 directed edges, the two end points of the primal
+  // pair (directed edge 4q: org[0] -> org[1], 4q + 2 the other way), deleted or not - 32 bytes, what a step of the merge reads
+  // of an edge sits in one cache line (three parallel arrays before)
+  struct Quad { int32_t nxt[4]; int32_t org[2]; int32_t dead, pad; };
+  std::vector<Quad> quad;
   const Pt* p = nullptr;
 
   static int rot(int e) { return (e & ~3) | ((e + 1) & 3); }
-  static int sym(int e) { return (e & ~3) | ((e + 2) & 3); }
+  static int sym(int e) { return e ^ 2; }
   static int irot(int e) { return (e & ~3) | ((e + 3) & 3); }
-  int onext(int e) const { return nxt[e]; }
-  int oprev(int e) const { return rot(nxt[rot(e)]); }
-  int lnext(int e) const { return rot(nxt[irot(e)]); }
-  int lprev(int e) const { return sym(nxt[e]); }
-  int rnext(int e) const { return irot(nxt[rot(e)]); }
-  int rprev(int e) const { return nxt[sym(e)]; }
-  int o(int e) const { return org[e]; }
-  int d(int e) const { return org[sym(e)]; }
+  int& N(int e) { return quad[e >> 2].nxt[e & 3]; }
+  int N(int e) const { return quad[e >> 2].nxt[e & 3]; }
+  int edges() const { return 4 * (int)quad.size(); }
+  bool dead(int e) const { return quad[e >> 2].dead != 0; }
+  int onext(int e) const { return N(e); }
+  int oprev(int e) const { return rot(N(rot(e))); }
+  int lnext(int e) const { return rot(N(irot(e))); }
+  int lprev(int e) const { return sym(N(e)); }
+  int rnext(int e) const { return irot(N(rot(e))); }
+  int rprev(int e) const { return N(sym(e)); }
+  // (primal directed edges only: e & 1 == 0)
+  int o(int e) const { return quad[e >> 2].org[(e >> 1) & 1]; }
+  int d(int e) const { return quad[e >> 2].org[((e >> 1) & 1) ^ 1]; }
 
   int make_edge(int a, int b) {
-    const int q = (int)nxt.size();
-    nxt.push_back(q); nxt.push_back(q + 3); nxt.push_back(q + 2); nxt.push_back(q + 1);
-    org.push_back(a); org.push_back(-1); org.push_back(b); org.push_back(-1);
-    dead.push_back(0);
+    const int q = edges();
+    quad.push_back(Quad{{q, q + 3, q + 2, q + 1}, {a, b}, 0, 0});
     return q;
   }
   void splice(int a, int b) {
-    const int alpha = rot(nxt[a]), beta = rot(nxt[b]);
-    std::swap(nxt[a], nxt[b]);
-    std::swap(nxt[alpha], nxt[beta]);
+    const int alpha = rot(N(a)), beta = rot(N(b));
+    std::swap(N(a), N(b));
+    std::swap(N(alpha), N(beta));
   }
   int connect(int a, int b) {
     const int e = make_edge(d(a), o(b));
@@ -71,7 +76,7 @@ struct QuadEdge {
   void remove(int e) {
     splice(e, oprev(e));
     splice(sym(e), oprev(sym(e)));
-    dead[e >> 2] = 1;
+    quad[e >> 2].dead = 1;
   }
 
   // > 0 iff a, b, c make a left turn
@@ -219,7 +224,7 @@ extern "C" int svo_elas_delaunay(const int32_t* xy, int32_t n, int32_t* tri, int
   // one builder per host thread, its arrays keep their capacity: fresh 100 KB+ vectors per call are mmap / munmap pairs,
   // and those serialise the worker threads of svo_elas_batch_dev on the process's address-space lock
   static thread_local Builder b;
-  b.q.nxt.clear(); b.q.org.clear(); b.q.dead.clear();
+  b.q.quad.clear();
   // sorted by (x, y, index) as ONE integer key per point; of several points with the same coordinates the lowest index stays
   static thread_local std::vector<uint64_t> skey;
   skey.resize(n);
@@ -238,7 +243,7 @@ extern "C" int svo_elas_delaunay(const int32_t* xy, int32_t n, int32_t* tri, int
   const int m = (int)b.pts.size();
   if (m < 3) return SVO_OK;
   lap(0); svo_delaunay_pts += m;
-  b.q.nxt.reserve(16 * m); b.q.org.reserve(16 * m); b.q.dead.reserve(4 * m);
+  b.q.quad.reserve(4 * (size_t)m);
   b.order_points();
   b.q.p = b.pts.data();
   b.build(0, m, 0);
@@ -253,8 +258,8 @@ extern "C" int svo_elas_delaunay(const int32_t* xy, int32_t n, int32_t* tri, int
   keys.clear();
   if (packed) keys.reserve(2 * m); else out.reserve(2 * m);
   const QuadEdge& q = b.q;
-  for (int e = 0; e < (int)q.nxt.size(); e += 2) {   // primal directed edges
-    if (q.dead[e >> 2]) continue;
+  for (int e = 0; e < q.edges(); e += 2) {   // primal directed edges
+    if (q.dead(e)) continue;
     const int A = q.o(e);
     const int32_t ia = b.pts[A].id;
     const int e2 = q.lnext(e);

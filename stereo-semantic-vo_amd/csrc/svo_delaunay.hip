@@ -260,12 +260,10 @@ extern "C" int svo_elas_delaunay(const int32_t* xy, int32_t n, int32_t* tri, int
   const QuadEdge& q = b.q;
   for (int e = 0; e < q.edges(); e += 2) {   // primal directed edges
     if (q.dead(e)) continue;
-    const int A = q.o(e);
-    const int32_t ia = b.pts[A].id;
-    const int e2 = q.lnext(e);
-    const int B = q.o(e2);
-    const int32_t ib = b.pts[B].id;
+    const int A = q.o(e), B = q.d(e);                // (both in the edge's own record: the next edge of the face is only
+    const int32_t ia = b.pts[A].id, ib = b.pts[B].id;  // fetched for the half of the edges that pass)
     if (ia >= ib) continue;                          // emitted from its smallest corner only
+    const int e2 = q.lnext(e);
     const int e3 = q.lnext(e2);
     if (q.lnext(e3) != e) continue;
     const int C = q.o(e3);

@@ -565,7 +565,7 @@ def multi_sequence_leg(pkg, cam, dL, dR, frame_bytes, rec, dev, single):
     """S staggered sequences advanced together (one workgroup per sequence in every tail kernel); sequence 0 must
     reproduce the single chain's records."""
     import torch
-    S, msteps = 64, 48
+    S, msteps = int(os.environ.get("SVO_BENCH_MULTI_S", "64")), 48   # (the leg is quoted at 64 sequences; the switch is for tools/option sweeps)
     ms = pkg.Svo(W, H, device=dev.index or 0, max_kp=500, max_batch=S)
     ms.set_option("multi_pipeline", int(os.environ.get("SVO_BENCH_MULTI_PIPELINE", "1")))   # front end of step t + 1 beside the tail of step t
     if os.environ.get("SVO_BENCH_TAIL_SEMI"):
@@ -589,7 +589,26 @@ def multi_sequence_leg(pkg, cam, dL, dR, frame_bytes, rec, dev, single):
     probe = list(ms.debug_stream_probe())
     ms.close()
     same = all(m[t, 0].tobytes() == single[t].tobytes() for t in range(msteps))
-    return {"value": msteps * S / mdt, "stream_probe": probe, "unit": "stereo frames/s", "sequences": S, "steps": msteps,
+    # the same with twice the sequences per step (detail only): the rate the step's latency chain no longer bounds
+    wide = None
+    S2, steps2 = 2 * S, 24
+    if (S2 + steps2 + 2) * frame_bytes <= dL.numel():
+        ms2 = pkg.Svo(W, H, device=dev.index or 0, max_kp=500, max_batch=S2)
+        ms2.set_option("multi_pipeline", int(os.environ.get("SVO_BENCH_MULTI_PIPELINE", "1")))
+        mres2 = torch.zeros((steps2 * S2, rec), dtype=torch.uint8, device=dev)
+        for rep in range(2):        # (the first pass allocates and warms up)
+            ms2.track_multi_reset(S2, cam)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for t in range(steps2):
+                ms2.track_multi_step_dev(dL.data_ptr() + t * frame_bytes, dR.data_ptr() + t * frame_bytes, PITCH, S2, mres2.data_ptr() + t * S2 * rec)
+            ms2.sync()
+            dt2 = time.perf_counter() - t2
+        m2 = mres2.cpu().numpy().view(pkg.TRACK_DTYPE).reshape(steps2, S2)
+        ms2.close()
+        wide = {"value": steps2 * S2 / dt2, "sequences": S2, "steps": steps2,
+                "sequence0_equals_single_chain": bool(all(m2[t, 0].tobytes() == single[t].tobytes() for t in range(steps2)))}
+    return {"value": msteps * S / mdt, "value_at_twice_the_sequences": wide, "stream_probe": probe, "unit": "stereo frames/s", "sequences": S, "steps": msteps,
             "sequence0_equals_single_chain": bool(same),
             "pipelined_steps": bool(int(os.environ.get("SVO_BENCH_MULTI_PIPELINE", "1"))),
             "note": "SURVEY 8e's 'G independent sequences' variant on ONE GPU: full Tracking::Track per frame; with "
@@ -1139,7 +1158,7 @@ def spawn_ranks(args):
     sys.exit(p.returncode)
 
 
-TAIL_LEGS = {"pnp_solver_modes": 1280, "sharded": 1024, "multi_sequence": 128, "semantic_elas": 512}   # leg -> frames it renders
+TAIL_LEGS = {"pnp_solver_modes": 1280, "sharded": 1024, "multi_sequence": max(128, int(os.environ.get("SVO_BENCH_MULTI_S", "64")) + 64), "semantic_elas": 512}   # leg -> frames it renders
 
 
 def tail_leg_reference(pkg, cam, dL, dR, dev, local, nr):

@@ -304,8 +304,14 @@ def test_many_sequences_staged_ransac_launches_equal_single_chains(pkg, sequence
     m = pkg.Svo(W, H, max_batch=S)
     with pytest.raises(pkg.SvoError):
         m.set_option("hyp_first", 6)          # multiples of four only (the statistical solver's workgroups hold four samples)
-    for first in (8, 4, 16):
-        m.set_option("hyp_first", first)
+    for first in (8, 4, 16, -2):
+        # (-2: option "tail_semi" = 2 instead - a step's pose chains as two launches, the first 8 samples of every sequence, then the
+        # other 92 (which replay the bound and leave) with the frame parts)
+        if first > 0:
+            m.set_option("hyp_first", first)
+        else:
+            m.set_option("hyp_first", 8)
+            m.set_option("tail_semi", 2)
         m.track_multi_reset(S, cam)
         out = torch.zeros((STEPS, S, rec), dtype=torch.uint8, device=dev)
         for t in range(STEPS):

@@ -83,7 +83,11 @@ class EdgeHeaps {
     size_t ns = 0;
     for (;;) {
       if (!a || !b) { a += b; break; }
-      if (node_[a].key > node_[b].key) std::swap(a, b);
+      {   // (as selects: which of the two keys is smaller is a coin toss to the branch predictor)
+        const bool sw = node_[a].key > node_[b].key;
+        const int na = sw ? b : a, nb = sw ? a : b;
+        a = na; b = nb;
+      }
       if (ns == 128) { broken = true; a += b; break; }   // (cannot happen while the leftist invariant holds; never write past the array)
       spine[ns++] = a;
       a = node_[a].right;
@@ -360,9 +364,11 @@ class TreeBuilder {
     for (int i = 0; i <= N_; ++i) vtx[i] = Vtx{i, i, 0, -1, 0, -1};
     std::vector<uint8_t>& arc_w = arc_w_;   // weights of the neighbour arcs (slot 0 is SR_W)
     arc_w.resize((size_t)N_ * 5);
-    auto arc_from = [&](int e) {
+    const int arc_step[5] = {0, -1, +1, -m_, +m_};
+    auto arc_from = [&](int e) {   // (a table and one select instead of a chain of data-dependent branches)
       const int p = e / 5, k = e - 5 * p;
-      return k == 0 ? SR : k == 1 ? p - 1 : k == 2 ? p + 1 : k == 3 ? p - m_ : p + m_;
+      const int q = p + arc_step[k];
+      return k == 0 ? SR : q;
     };
     auto arc_weight = [&](int e) { return e % 5 == 0 ? SR_W : (int)arc_w[e]; };
     {

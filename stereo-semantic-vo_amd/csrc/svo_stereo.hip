@@ -16,6 +16,7 @@
 #define SAD_L 5
 #define KP_PER_WG 64
 #define MAXKP_LDS 512
+#define ST_NB 512   // row buckets of the right image's keypoints (below)
 
 struct StereoSrc {
   const uint8_t* L;
@@ -52,6 +53,13 @@ __global__ __launch_bounds__(256) void k_stereo_match(SvoGeom g, StereoSrc s, co
   __shared__ int8_t roct[MAXKP_LDS];
   __shared__ float rx[MAXKP_LDS];
   __shared__ int sadbuf[4][128];
+  // The right keypoints bucketed by row (counting sort, once per workgroup): a left keypoint's candidates lie within
+  // 2 * scale[octave] + 1 rows of its own, i.e. in a few buckets - one pass of the wave over ~30 candidates instead of eight
+  // passes over all 500 with the band test failing for 97 % of them.  The argmin packs the ORIGINAL index, so the winner (ties:
+  // lowest index) is the one the full scan finds.
+  __shared__ int bcur[ST_NB + 1];      // bucket b: order[bstart[b] .. bstart[b + 1]) (bcur: the fill cursors, then unused)
+  __shared__ int bstart[ST_NB + 1];
+  __shared__ uint16_t order[MAXKP_LDS];
   __shared__ uint64_t winL[4][ST_G][11][2];   // per wave and keypoint: 11 rows x 16 bytes of the left SAD window
   __shared__ uint64_t winR[4][ST_G][11][3];   // per wave and keypoint: 11 rows x 24 bytes of the right search band
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -80,6 +88,30 @@ __global__ __launch_bounds__(256) void k_stereo_match(SvoGeom g, StereoSrc s, co
     roct[i] = (int8_t)k.octave;
     rx[i] = k.x;
   }
+  int bshift = 0;
+  while ((g.H >> bshift) >= ST_NB) ++bshift;
+  const int band = (int)ceilf(2.0f * g.scale[SVO_NLEVELS - 1]) + 1;   // |row - (int)y| of a candidate never exceeds this
+  for (int i = tid; i <= ST_NB; i += 256) bcur[i] = 0;
+  __syncthreads();
+  auto bucket_of = [&](int i) { return min(max((int)kpR[i].y, 0), g.H - 1) >> bshift; };
+  for (int i = tid; i < nR; i += 256) atomicAdd(&bcur[bucket_of(i) + 1], 1);
+  __syncthreads();
+  if (tid < 64) {   // exclusive prefix over the ST_NB + 1 counters: 8 (+1) per lane, then across the wave
+    int loc[ST_NB / 64], sum = 0;
+#pragma unroll
+    for (int k = 0; k < ST_NB / 64; ++k) { loc[k] = bcur[1 + tid * (ST_NB / 64) + k]; sum += loc[k]; }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (tid >= o) incl += v; }
+    int run = incl - sum;
+    if (tid == 0) bstart[0] = 0;
+#pragma unroll
+    for (int k = 0; k < ST_NB / 64; ++k) { run += loc[k]; bstart[1 + tid * (ST_NB / 64) + k] = run; }
+  }
+  __syncthreads();
+  for (int i = tid; i <= ST_NB; i += 256) bcur[i] = bstart[i];
+  __syncthreads();
+  for (int i = tid; i < nR; i += 256) order[atomicAdd(&bcur[bucket_of(i)], 1)] = (uint16_t)i;
   __syncthreads();
   const float maxD = fx;
   typedef uint64_t __attribute__((aligned(1))) u64u;
@@ -106,7 +138,10 @@ __global__ __launch_bounds__(256) void k_stereo_match(SvoGeom g, StereoSrc s, co
       const float minU = uL - maxD, maxU = uL;
       uint32_t b = ((uint32_t)TH_HIGH << 16) | 0xffffu;
       if (iL0 + j < nL && maxU >= 0) {
-        for (int iR = lane; iR < nR; iR += 64) {
+        const int rc = min(max(row, 0), g.H - 1);
+        const int c0 = bstart[max(rc - band, 0) >> bshift], c1 = bstart[(min(rc + band, g.H - 1) >> bshift) + 1];
+        for (int c = c0 + lane; c < c1; c += 64) {
+          const int iR = order[c];
           const int oc = roct[iR];
           const float u = rx[iR];
           const bool ok = row >= rminr[iR] && row <= rmaxr[iR] && oc >= levelL - 1 &&
